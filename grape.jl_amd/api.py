@@ -1,0 +1,243 @@
+"""ctypes binding of the C ABI in ``include/grape_hip.h`` (library: ``csrc/libgrape_hip.so``).
+
+This is the Python analogue of the Julia ``ccall`` glue shown in INTEGRATION.md: it passes plain
+host (or device) pointers and sizes, owns no arithmetic, and raises ``GrapeHipError`` whenever
+the library reports a failure.  There is no CPU fallback: if the HIP library cannot be loaded,
+constructing a ``GrapeHip`` fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIBNAME = "libgrape_hip.so"
+
+J_T_SM, J_T_SS, J_T_RE = 0, 1, 2
+GRAD_GRADGEN, GRAD_TAYLOR = 0, 1
+ABI_VERSION = 1
+
+STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAPE_ERR_CHI_NORM",
+          -4: "GRAPE_ERR_SINGULAR", -5: "GRAPE_ERR_TAYLOR", -6: "GRAPE_ERR_NO_CONTROLS"}
+
+# every symbol include/grape_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = ["grape_create", "grape_destroy", "grape_eval", "grape_forward", "grape_backward",
+           "grape_forward_device", "grape_backward_device", "grape_check", "grape_get_propagator",
+           "grape_get_tau_grads", "grape_get_storage", "grape_get_timings", "grape_get_work",
+           "grape_last_error", "grape_abi_version"]
+
+
+class GrapeHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class _Problem(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("N", C.c_int32), ("L", C.c_int32), ("K", C.c_int32),
+                ("K_total", C.c_int32), ("N_T", C.c_int32), ("functional", C.c_int32),
+                ("gradient_method", C.c_int32), ("hc_per_traj", C.c_int32), ("device", C.c_int32),
+                ("tlist", C.c_void_p), ("H0", C.c_void_p), ("Hc", C.c_void_p), ("shape", C.c_void_p),
+                ("psi0", C.c_void_p), ("target", C.c_void_p), ("weights", C.c_void_p),
+                ("chi_min_norm", C.c_double), ("taylor_max_order", C.c_int32),
+                ("taylor_tolerance", C.c_double)]
+
+
+def library_path() -> str:
+    return os.path.join(_CSRC, _LIBNAME)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = library_path()
+    srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_kernels.hip.h")]
+    hdr = os.path.join(_HERE, "..", "include", "grape_hip.h")
+    if (not force and os.path.exists(out)
+            and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs + [hdr])):
+        return out
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           srcs[0], "-o", out]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(res.stdout, res.stderr)
+    if res.returncode:
+        raise RuntimeError("hipcc failed building " + out)
+    return out
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise GrapeHipError(-2, f"{path} not built; run __graft_entry__.build() (no CPU fallback exists)")
+    lib = C.CDLL(path)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.c_int
+    lib.grape_create.argtypes = [C.POINTER(vp), C.POINTER(_Problem)]
+    lib.grape_destroy.argtypes = [vp]
+    lib.grape_destroy.restype = None
+    lib.grape_eval.argtypes = [vp, vp, dp, vp, vp, vp]
+    lib.grape_forward.argtypes = [vp, vp, vp]
+    lib.grape_backward.argtypes = [vp, vp, vp]
+    lib.grape_forward_device.argtypes = [vp, vp, vp, vp]
+    lib.grape_backward_device.argtypes = [vp, vp, vp, vp]
+    lib.grape_check.argtypes = [vp, vp]
+    lib.grape_get_propagator.argtypes = [vp, ip, ip, vp]
+    lib.grape_get_tau_grads.argtypes = [vp, vp]
+    lib.grape_get_storage.argtypes = [vp, ip, vp]
+    lib.grape_get_timings.argtypes = [vp, vp, ip]
+    lib.grape_get_work.argtypes = [vp, vp, ip]
+    lib.grape_last_error.argtypes = [vp]
+    lib.grape_last_error.restype = C.c_char_p
+    lib.grape_abi_version.restype = ip
+    _lib = lib
+    return lib
+
+
+def _c128(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+class GrapeHip:
+    """One handle = the device-resident GrapeWrk data of one (shard of a) problem.
+
+    H0: [K, N, N] complex, ``H0[k][i, j]`` (row, column);  Hc: [L, N, N] or [K, L, N, N];
+    psi0/target: [K, N];  tlist: [N_T+1];  pulsevals: control-major [L*N_T].
+    The C ABI wants Julia's column-major matrices, so matrices are transposed on the way in.
+    """
+
+    def __init__(self, H0, Hc, tlist, psi0, target, weights=None, functional=J_T_SM,
+                 gradient_method=GRAD_GRADGEN, shape=None, K_total=None, device=0,
+                 chi_min_norm=0.0, taylor_max_order=0, taylor_tolerance=0.0):
+        self._lib = load_library()
+        H0 = np.asarray(H0)
+        K, N = H0.shape[0], H0.shape[1]
+        Hc = np.asarray(Hc)
+        per_traj = Hc.ndim == 4
+        L = Hc.shape[1] if per_traj else Hc.shape[0]
+        tlist = np.ascontiguousarray(tlist, dtype=np.float64)
+        N_T = len(tlist) - 1
+        self.N, self.L, self.K, self.N_T = N, L, K, N_T
+        self.K_total = K if K_total is None else int(K_total)
+        self.functional = functional
+        # column-major for the ABI == transpose of numpy's row-major
+        self._H0 = _c128(np.swapaxes(H0, -1, -2), (K, N, N))
+        self._Hc = _c128(np.swapaxes(Hc, -1, -2))
+        self._psi0 = _c128(psi0, (K, N))
+        self._target = _c128(target, (K, N))
+        self._tlist = tlist
+        self._weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self._shape = None if shape is None else np.ascontiguousarray(shape, dtype=np.float64).reshape(L, N_T)
+        p = _Problem()
+        p.abi_version = ABI_VERSION
+        p.N, p.L, p.K, p.K_total, p.N_T = N, L, K, self.K_total, N_T
+        p.functional, p.gradient_method, p.hc_per_traj, p.device = functional, gradient_method, int(per_traj), device
+        p.tlist = self._tlist.ctypes.data
+        p.H0 = self._H0.ctypes.data
+        p.Hc = self._Hc.ctypes.data
+        p.shape = None if self._shape is None else self._shape.ctypes.data
+        p.psi0 = self._psi0.ctypes.data
+        p.target = self._target.ctypes.data
+        p.weights = None if self._weights is None else self._weights.ctypes.data
+        p.chi_min_norm, p.taylor_max_order, p.taylor_tolerance = chi_min_norm, taylor_max_order, taylor_tolerance
+        self._h = C.c_void_p()
+        rc = self._lib.grape_create(C.byref(self._h), C.byref(p))
+        if rc:
+            msg = self._lib.grape_last_error(None).decode()
+            self._h = None
+            raise GrapeHipError(rc, msg)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.grape_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise GrapeHipError(rc, self._lib.grape_last_error(self._h).decode())
+
+    # -- host-pointer API -------------------------------------------------------------------
+    def eval(self, pulsevals, gradient=True, want_psiT=False):
+        """fg!(F, G, x): returns (J, G or None, tau[, psiT])."""
+        x = np.ascontiguousarray(pulsevals, dtype=np.float64)
+        assert x.size == self.L * self.N_T
+        J = C.c_double(0.0)
+        G = np.empty(self.L * self.N_T) if gradient else None
+        tau = np.empty(self.K, dtype=np.complex128)
+        psiT = np.empty((self.K, self.N), dtype=np.complex128) if want_psiT else None
+        self._chk(self._lib.grape_eval(self._h, x.ctypes.data, C.byref(J),
+                                       None if G is None else G.ctypes.data, tau.ctypes.data,
+                                       None if psiT is None else psiT.ctypes.data))
+        return (J.value, G, tau, psiT) if want_psiT else (J.value, G, tau)
+
+    def forward(self, pulsevals):
+        x = np.ascontiguousarray(pulsevals, dtype=np.float64)
+        tau = np.empty(self.K, dtype=np.complex128)
+        self._chk(self._lib.grape_forward(self._h, x.ctypes.data, tau.ctypes.data))
+        return tau
+
+    def backward(self, f_total):
+        f = np.array([np.real(f_total), np.imag(f_total)], dtype=np.float64)
+        G = np.empty(self.L * self.N_T)
+        self._chk(self._lib.grape_backward(self._h, f.ctypes.data, G.ctypes.data))
+        return G
+
+    # -- device-pointer API (torch tensors on the handle's device) -----------------------------
+    def forward_device(self, d_pulsevals_ptr, d_out_ptr, stream=0):
+        self._chk(self._lib.grape_forward_device(self._h, d_pulsevals_ptr, d_out_ptr, stream))
+
+    def backward_device(self, d_f_ptr, d_G_ptr, stream=0):
+        self._chk(self._lib.grape_backward_device(self._h, d_f_ptr, d_G_ptr, stream))
+
+    def check(self, stream=0):
+        self._chk(self._lib.grape_check(self._h, stream))
+
+    # -- diagnostics ------------------------------------------------------------------------
+    def propagator(self, k, n):
+        out = np.empty((self.N, self.N), dtype=np.complex128)
+        self._chk(self._lib.grape_get_propagator(self._h, k, n, out.ctypes.data))
+        return out.T.copy()  # column-major -> [row, col]
+
+    def tau_grads(self):
+        out = np.empty((self.K, self.L, self.N_T), dtype=np.complex128)
+        self._chk(self._lib.grape_get_tau_grads(self._h, out.ctypes.data))
+        return out
+
+    def storage(self, which=0):
+        out = np.empty((self.K, self.N_T + 1, self.N), dtype=np.complex128)
+        self._chk(self._lib.grape_get_storage(self._h, which, out.ctypes.data))
+        return out
+
+    def timings(self):
+        ms = np.zeros(6)
+        self._lib.grape_get_timings(self._h, ms.ctypes.data, 6)
+        return dict(zip(["expm", "forward", "backward", "deriv", "reduce", "total"], ms.tolist()))
+
+    def work(self):
+        w = np.zeros(5)
+        self._lib.grape_get_work(self._h, w.ctypes.data, 5)
+        return dict(cells=w[0], squarings=w[1], flop_expm=w[2], flop_deriv=w[3], deriv_orders=w[4])

@@ -1,0 +1,480 @@
+// grape_hip.hip -- host side of the C ABI declared in include/grape_hip.h (gfx950 only).
+//
+// Owns every device buffer of the hot path (the GrapeWrk data of
+// /root/reference/src/workspace.jl:147-362) and sequences the kernels of
+// grape_kernels.hip.h on one HIP stream:
+//   expm (all cells) -> forward sweep -> tau partial sums | chi boundary + backward sweep ->
+//   per-cell derivative overlaps -> sum over trajectories.
+// No CPU fallback exists: every entry point fails loudly when HIP does.
+#include "../../include/grape_hip.h"
+#include "grape_kernels.hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Phase { hipEvent_t e0, e1; bool used; };
+
+}  // namespace
+
+struct grape_handle {
+    grape_problem p{};
+    int N = 0, NP = 0, NT = 0, L = 0, K = 0, K_total = 0, N_T = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // static problem
+    double *d_H0f = nullptr, *d_Hcf = nullptr, *d_H0t = nullptr, *d_Hct = nullptr;
+    double *d_dts = nullptr, *d_shape = nullptr, *d_weights = nullptr;
+    double2 *d_psi0 = nullptr, *d_target = nullptr;
+    // per-evaluation
+    double *d_eps = nullptr;
+    double2 *d_U = nullptr, *d_fw = nullptr, *d_bw = nullptr, *d_tg = nullptr;
+    double *d_out = nullptr;  // [2K + 4] tau + partial sums (host API)
+    double *d_f = nullptr, *d_G = nullptr, *d_rho = nullptr;
+    int *d_flags = nullptr;
+    unsigned long long *d_stats = nullptr;
+    double *h_pin = nullptr;  // pinned staging
+    size_t h_pin_doubles = 0;
+    Phase ph[6]{};
+    std::string err;
+    bool have_forward = false;
+    double chi_min_norm = 1e-100, taylor_tol = 1e-16;
+    int taylor_max_order = 100;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return GRAPE_ERR_HIP;                                                               \
+        }                                                                                       \
+    } while (0)
+
+template <typename T>
+hipError_t dmalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
+
+size_t expm_lds_bytes(int NT) {
+    const int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
+    return sizeof(double) * (size_t)(4 * NP * LD + 512 + NTH + 8 + NP);
+}
+
+template <int NT>
+hipError_t launch_expm(const ExpmArgs &a, hipStream_t s) {
+    static bool attr_set[8] = {false};
+    const size_t lds = expm_lds_bytes(NT);
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (!attr_set[dev & 7]) {
+        hipError_t e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 7] = true;
+    }
+    hipLaunchKernelGGL(expm_pade_kernel<NT>, dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NP>
+hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s) {
+    if (backward) hipLaunchKernelGGL((sweep_kernel<NP, true>), dim3(a.K), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((sweep_kernel<NP, false>), dim3(a.K), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int NP>
+hipError_t launch_deriv(const DerivArgs &a, int nblocks, hipStream_t s) {
+    if (a.L <= 2) hipLaunchKernelGGL((deriv_kernel<NP, 2>), dim3(nblocks), dim3(256), 0, s, a);
+    else if (a.L <= 4) hipLaunchKernelGGL((deriv_kernel<NP, 4>), dim3(nblocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((deriv_kernel<NP, 8>), dim3(nblocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+void phase_begin(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[i].e0, s); }
+void phase_end(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[i].e1, s); h->ph[i].used = true; }
+
+int status_from_flags(grape_handle *h, int flags) {
+    if (flags & 1) { h->err = "Pade denominator numerically singular in at least one cell"; return GRAPE_ERR_SINGULAR; }
+    if (flags & 2) {
+        h->err = "The chi state of at least one trajectory has norm < chi_min_norm (optimize.jl:1021-1025)";
+        return GRAPE_ERR_CHI_NORM;
+    }
+    if (flags & 4) {
+        h->err = "taylor_grad_step! did not converge within max_order iterations (optimize.jl:644-648)";
+        return GRAPE_ERR_TAYLOR;
+    }
+    return GRAPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grape_abi_version(void) { return GRAPE_HIP_ABI_VERSION; }
+
+const char *grape_last_error(grape_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void grape_destroy(grape_handle *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+                    h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
+                    h->d_rho, h->d_flags, h->d_stats};
+    for (void *b : bufs)
+        if (b) hipFree(b);
+    if (h->h_pin) hipHostFree(h->h_pin);
+    for (auto &p : h->ph) {
+        if (p.e0) hipEventDestroy(p.e0);
+        if (p.e1) hipEventDestroy(p.e1);
+    }
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int grape_create(grape_handle **out, const grape_problem *p) {
+    if (!out || !p) { g_create_error = "null argument"; return GRAPE_ERR_INVALID; }
+    *out = nullptr;
+    if (p->abi_version != GRAPE_HIP_ABI_VERSION) { g_create_error = "abi_version mismatch"; return GRAPE_ERR_INVALID; }
+    if (p->L <= 0) { g_create_error = "no controls in trajectories (workspace.jl:155-157)"; return GRAPE_ERR_NO_CONTROLS; }
+    if (p->N <= 0 || p->K <= 0 || p->N_T <= 0 || !p->tlist || !p->H0 || !p->Hc || !p->psi0 || !p->target) {
+        g_create_error = "invalid problem dimensions or null array";
+        return GRAPE_ERR_INVALID;
+    }
+    if (p->N > 64) {
+        g_create_error = "N > 64 is not supported by this build (in-LDS Pade kernel covers N <= 64)";
+        return GRAPE_ERR_INVALID;
+    }
+    if (p->L > 8) { g_create_error = "L > 8 is not supported by this build"; return GRAPE_ERR_INVALID; }
+    if (p->functional < 0 || p->functional > 2) { g_create_error = "unknown functional"; return GRAPE_ERR_INVALID; }
+    for (int n = 0; n < p->N_T; ++n)
+        if (!(p->tlist[n + 1] > p->tlist[n])) { g_create_error = "tlist must be strictly increasing"; return GRAPE_ERR_INVALID; }
+
+    grape_handle *h = new grape_handle();
+    h->p = *p;
+    h->N = p->N; h->L = p->L; h->K = p->K; h->N_T = p->N_T;
+    h->K_total = p->K_total > 0 ? p->K_total : p->K;
+    h->NT = (p->N + 15) / 16; h->NP = 16 * h->NT;
+    if (h->NP == 48) { h->NT = 4; h->NP = 64; }  // sweep/derivative kernels are built for 16/32/64
+    h->device = p->device;
+    if (p->chi_min_norm > 0) h->chi_min_norm = p->chi_min_norm;
+    if (p->taylor_tolerance > 0) h->taylor_tol = p->taylor_tolerance;
+    if (p->taylor_max_order > 0) h->taylor_max_order = p->taylor_max_order;
+    // the gradient-generator route sums the same series until it has converged to rounding
+    if (p->gradient_method == GRAPE_GRAD_GRADGEN) { h->taylor_max_order = 200; h->taylor_tol = 1e-17; }
+
+    auto fail = [&](int code) { g_create_error = h->err; grape_destroy(h); return code; };
+#define CCHK(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(_e); return fail(GRAPE_ERR_HIP); } \
+    } while (0)
+
+    CCHK(hipSetDevice(h->device));
+    CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto &ph : h->ph) { CCHK(hipEventCreate(&ph.e0)); CCHK(hipEventCreate(&ph.e1)); ph.used = false; }
+
+    const int N = h->N, NP = h->NP, L = h->L, K = h->K, N_T = h->N_T;
+    const size_t pp = (size_t)NP * NP, nn = (size_t)N * N;
+    const int Kc = p->hc_per_traj ? K : 1;
+    // ---- host-side layout conversion: column-major interleaved -> planar row-major (and transpose) ----
+    std::vector<double> f((size_t)K * 2 * pp, 0.0), t((size_t)K * 2 * pp, 0.0);
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i < N; ++i) {
+                const double re = p->H0[2 * ((size_t)k * nn + (size_t)j * N + i)];
+                const double im = p->H0[2 * ((size_t)k * nn + (size_t)j * N + i) + 1];
+                f[(size_t)k * 2 * pp + (size_t)i * NP + j] = re;
+                f[(size_t)k * 2 * pp + pp + (size_t)i * NP + j] = im;
+                t[(size_t)k * 2 * pp + (size_t)j * NP + i] = re;
+                t[(size_t)k * 2 * pp + pp + (size_t)j * NP + i] = im;
+            }
+    CCHK(dmalloc(&h->d_H0f, f.size())); CCHK(dmalloc(&h->d_H0t, t.size()));
+    CCHK(hipMemcpy(h->d_H0f, f.data(), f.size() * 8, hipMemcpyHostToDevice));
+    CCHK(hipMemcpy(h->d_H0t, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+    f.assign((size_t)Kc * L * 2 * pp, 0.0); t.assign((size_t)Kc * L * 2 * pp, 0.0);
+    for (int kl = 0; kl < Kc * L; ++kl)
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i < N; ++i) {
+                const double re = p->Hc[2 * ((size_t)kl * nn + (size_t)j * N + i)];
+                const double im = p->Hc[2 * ((size_t)kl * nn + (size_t)j * N + i) + 1];
+                f[(size_t)kl * 2 * pp + (size_t)i * NP + j] = re;
+                f[(size_t)kl * 2 * pp + pp + (size_t)i * NP + j] = im;
+                t[(size_t)kl * 2 * pp + (size_t)j * NP + i] = re;
+                t[(size_t)kl * 2 * pp + pp + (size_t)j * NP + i] = im;
+            }
+    CCHK(dmalloc(&h->d_Hcf, f.size())); CCHK(dmalloc(&h->d_Hct, t.size()));
+    CCHK(hipMemcpy(h->d_Hcf, f.data(), f.size() * 8, hipMemcpyHostToDevice));
+    CCHK(hipMemcpy(h->d_Hct, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+
+    std::vector<double> dts(N_T);
+    for (int n = 0; n < N_T; ++n) dts[n] = p->tlist[n + 1] - p->tlist[n];
+    CCHK(dmalloc(&h->d_dts, (size_t)N_T));
+    CCHK(hipMemcpy(h->d_dts, dts.data(), (size_t)N_T * 8, hipMemcpyHostToDevice));
+    if (p->shape) {
+        CCHK(dmalloc(&h->d_shape, (size_t)L * N_T));
+        CCHK(hipMemcpy(h->d_shape, p->shape, (size_t)L * N_T * 8, hipMemcpyHostToDevice));
+    }
+    if (p->weights) {
+        CCHK(dmalloc(&h->d_weights, (size_t)K));
+        CCHK(hipMemcpy(h->d_weights, p->weights, (size_t)K * 8, hipMemcpyHostToDevice));
+    }
+    CCHK(dmalloc(&h->d_psi0, (size_t)K * N)); CCHK(dmalloc(&h->d_target, (size_t)K * N));
+    CCHK(hipMemcpy(h->d_psi0, p->psi0, (size_t)K * N * 16, hipMemcpyHostToDevice));
+    CCHK(hipMemcpy(h->d_target, p->target, (size_t)K * N * 16, hipMemcpyHostToDevice));
+
+    // ---- per-evaluation buffers ----
+    CCHK(dmalloc(&h->d_eps, (size_t)L * N_T));
+    CCHK(dmalloc(&h->d_U, (size_t)K * N_T * pp));
+    CCHK(dmalloc(&h->d_fw, (size_t)K * (N_T + 1) * NP));
+    CCHK(dmalloc(&h->d_bw, (size_t)K * (N_T + 1) * NP));
+    CCHK(dmalloc(&h->d_tg, (size_t)K * L * N_T));
+    CCHK(dmalloc(&h->d_out, (size_t)2 * K + 4));
+    CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
+    CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, 16));
+    CCHK(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
+    CCHK(hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long)));
+    CCHK(hipMemset(h->d_fw, 0, (size_t)K * (N_T + 1) * NP * 16));
+    CCHK(hipMemset(h->d_bw, 0, (size_t)K * (N_T + 1) * NP * 16));
+    CCHK(hipMemset(h->d_tg, 0, (size_t)K * L * N_T * 16));
+    h->h_pin_doubles = (size_t)L * N_T + 2 * K + 16;
+    CCHK(hipHostMalloc((void **)&h->h_pin, h->h_pin_doubles * 8, hipHostMallocDefault));
+#undef CCHK
+    *out = h;
+    return GRAPE_OK;
+}
+
+int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_out, void *stream_) {
+    if (!h || !d_pulsevals || !d_out) return GRAPE_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream_;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 16 * sizeof(unsigned long long), s));
+    if (d_pulsevals != h->d_eps)
+        HIPCHK(h, hipMemcpyAsync(h->d_eps, d_pulsevals, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToDevice, s));
+    // ---- phase 0: expm of every cell ----
+    ExpmArgs ea{};
+    ea.H0f = h->d_H0f; ea.Hcf = h->d_Hcf; ea.eps = h->d_eps; ea.shape = h->d_shape; ea.dts = h->d_dts;
+    ea.U = h->d_U; ea.flags = h->d_flags; ea.stats = h->d_stats;
+    ea.K = h->K; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
+    phase_begin(h, 0, s);
+    hipError_t e;
+    switch (h->NT) {
+        case 1: e = launch_expm<1>(ea, s); break;
+        case 2: e = launch_expm<2>(ea, s); break;
+        default: e = launch_expm<4>(ea, s); break;
+    }
+    HIPCHK(h, e);
+    phase_end(h, 0, s);
+    // ---- phase 1: forward sweep + tau ----
+    SweepArgs sa{};
+    sa.U = h->d_U; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
+    sa.store = h->d_fw; sa.tau = (double2 *)d_out; sa.f = nullptr; sa.rho = h->d_rho; sa.flags = h->d_flags;
+    sa.chi_min_norm = h->chi_min_norm;
+    sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
+    phase_begin(h, 1, s);
+    switch (h->NP) {
+        case 16: e = launch_sweep<16>(sa, false, s); break;
+        case 32: e = launch_sweep<32>(sa, false, s); break;
+        default: e = launch_sweep<64>(sa, false, s); break;
+    }
+    HIPCHK(h, e);
+    hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(64), 0, s, (const double2 *)d_out, h->d_weights, h->K,
+                       d_out + 2 * (size_t)h->K);
+    HIPCHK(h, hipGetLastError());
+    phase_end(h, 1, s);
+    if (d_out != h->d_out)
+        HIPCHK(h, hipMemcpyAsync(h->d_out, d_out, ((size_t)2 * h->K + 4) * 8, hipMemcpyDeviceToDevice, s));
+    h->have_forward = true;
+    return GRAPE_OK;
+}
+
+int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void *stream_) {
+    if (!h || !d_f || !d_G) return GRAPE_ERR_INVALID;
+    if (!h->have_forward) { h->err = "grape_backward called before grape_forward"; return GRAPE_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream_;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipError_t e;
+    // ---- phase 2: chi boundary + backward sweep ----
+    SweepArgs sa{};
+    sa.U = h->d_U; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
+    sa.store = h->d_bw; sa.tau = (double2 *)h->d_out; sa.f = d_f; sa.rho = h->d_rho; sa.flags = h->d_flags;
+    sa.chi_min_norm = h->chi_min_norm;
+    sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
+    phase_begin(h, 2, s);
+    switch (h->NP) {
+        case 16: e = launch_sweep<16>(sa, true, s); break;
+        case 32: e = launch_sweep<32>(sa, true, s); break;
+        default: e = launch_sweep<64>(sa, true, s); break;
+    }
+    HIPCHK(h, e);
+    phase_end(h, 2, s);
+    // ---- phase 3: per-cell derivative overlaps ----
+    DerivArgs da{};
+    da.H0t = h->d_H0t; da.Hct = h->d_Hct; da.eps = h->d_eps; da.shape = h->d_shape; da.dts = h->d_dts;
+    da.fw = h->d_fw; da.bw = h->d_bw; da.rho = h->d_rho; da.tg = h->d_tg; da.flags = h->d_flags; da.stats = h->d_stats;
+    da.K = h->K; da.L = h->L; da.N_T = h->N_T; da.hc_per_traj = h->p.hc_per_traj;
+    da.max_order = h->taylor_max_order; da.tol = h->taylor_tol;
+    // enough blocks to fill 256 CUs a few times over, but long runs per block to amortise the tile loads
+    int cpb = 16;
+    while (cpb > 1 && (long)h->K * ((h->N_T + cpb - 1) / cpb) < 2048) cpb >>= 1;
+    da.cells_per_block = cpb;
+    const int nblocks = h->K * ((h->N_T + cpb - 1) / cpb);
+    phase_begin(h, 3, s);
+    switch (h->NP) {
+        case 16: e = launch_deriv<16>(da, nblocks, s); break;
+        case 32: e = launch_deriv<32>(da, nblocks, s); break;
+        default: e = launch_deriv<64>(da, nblocks, s); break;
+    }
+    HIPCHK(h, e);
+    phase_end(h, 3, s);
+    // ---- phase 4: sum over trajectories ----
+    phase_begin(h, 4, s);
+    const int LN = h->L * h->N_T;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((LN + 255) / 256), dim3(256), 0, s, (const double2 *)h->d_tg, h->K, LN, d_G);
+    HIPCHK(h, hipGetLastError());
+    phase_end(h, 4, s);
+    return GRAPE_OK;
+}
+
+int grape_check(grape_handle *h, void *stream_) {
+    if (!h) return GRAPE_ERR_INVALID;
+    int flags[4];
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_));
+    HIPCHK(h, hipMemcpy(flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+    return status_from_flags(h, flags[0]);
+}
+
+int grape_forward(grape_handle *h, const double *pulsevals, double *tau) {
+    if (!h || !pulsevals) return GRAPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t nl = (size_t)h->L * h->N_T;
+    memcpy(h->h_pin, pulsevals, nl * 8);
+    HIPCHK(h, hipMemcpyAsync(h->d_eps, h->h_pin, nl * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = grape_forward_device(h, h->d_eps, h->d_out, h->stream);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->h_pin + nl, h->d_out, ((size_t)2 * h->K + 4) * 8, hipMemcpyDeviceToHost, h->stream));
+    rc = grape_check(h, h->stream);
+    if (rc) return rc;
+    if (tau) memcpy(tau, h->h_pin + nl, (size_t)2 * h->K * 8);
+    return GRAPE_OK;
+}
+
+int grape_backward(grape_handle *h, const double f_total[2], double *G_partial) {
+    if (!h || !f_total || !G_partial) return GRAPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_f, f_total, 16, hipMemcpyHostToDevice, h->stream));
+    int rc = grape_backward_device(h, h->d_f, h->d_G, h->stream);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_G, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToHost, h->stream));
+    rc = grape_check(h, h->stream);
+    if (rc) return rc;
+    memcpy(G_partial, h->h_pin, (size_t)h->L * h->N_T * 8);
+    return GRAPE_OK;
+}
+
+int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, double *tau, double *psiT) {
+    if (!h || !pulsevals || !J) return GRAPE_ERR_INVALID;
+    if (h->K != h->K_total) {
+        h->err = "grape_eval needs K == K_total; use grape_forward/grape_backward for shards";
+        return GRAPE_ERR_INVALID;
+    }
+    phase_begin(h, 5, h->stream);
+    int rc = grape_forward(h, pulsevals, tau);
+    if (rc) return rc;
+    const size_t nl = (size_t)h->L * h->N_T;
+    const double *sums = h->h_pin + nl + 2 * (size_t)h->K;  // f_re, f_im, sum w|tau|^2, Re sum w tau
+    const double Kt = (double)h->K_total;
+    if (h->p.functional == GRAPE_J_T_SM) *J = 1.0 - (sums[0] * sums[0] + sums[1] * sums[1]) / (Kt * Kt);
+    else if (h->p.functional == GRAPE_J_T_SS) *J = 1.0 - sums[2] / Kt;
+    else *J = 1.0 - sums[3] / Kt;
+    const double f[2] = {sums[0], sums[1]};
+    if (psiT) {
+        HIPCHK(h, hipMemcpy2D(psiT, (size_t)h->N * 16, h->d_fw + (size_t)h->N_T * h->NP,
+                              (size_t)(h->N_T + 1) * h->NP * 16, (size_t)h->N * 16, h->K, hipMemcpyDeviceToHost));
+    }
+    if (G) {
+        rc = grape_backward(h, f, G);
+        if (rc) return rc;
+    }
+    phase_end(h, 5, h->stream);
+    return GRAPE_OK;
+}
+
+int grape_get_tau_grads(grape_handle *h, double *out) {
+    if (!h || !out) return GRAPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out, h->d_tg, (size_t)h->K * h->L * h->N_T * 16, hipMemcpyDeviceToHost));
+    return GRAPE_OK;
+}
+
+int grape_get_storage(grape_handle *h, int which, double *out) {
+    if (!h || !out || which < 0 || which > 1) return GRAPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const double2 *src = which == 0 ? h->d_fw : h->d_bw;
+    HIPCHK(h, hipMemcpy2D(out, (size_t)h->N * 16, src, (size_t)h->NP * 16, (size_t)h->N * 16,
+                          (size_t)h->K * (h->N_T + 1), hipMemcpyDeviceToHost));
+    return GRAPE_OK;
+}
+
+int grape_get_propagator(grape_handle *h, int k, int n, double *out) {
+    // U_kn as N x N column-major complex (debug / parity of the expm kernel)
+    if (!h || !out || k < 0 || k >= h->K || n < 0 || n >= h->N_T) return GRAPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t pp = (size_t)h->NP * h->NP;
+    std::vector<double> tmp(2 * pp);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->d_U + ((size_t)k * h->N_T + n) * pp, pp * 16, hipMemcpyDeviceToHost));
+    for (int j = 0; j < h->N; ++j)
+        for (int i = 0; i < h->N; ++i) {
+            out[2 * ((size_t)j * h->N + i)] = tmp[2 * ((size_t)i * h->NP + j)];
+            out[2 * ((size_t)j * h->N + i) + 1] = tmp[2 * ((size_t)i * h->NP + j) + 1];
+        }
+    return GRAPE_OK;
+}
+
+int grape_get_timings(grape_handle *h, double *ms, int n) {
+    if (!h || !ms) return GRAPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    int cnt = 0;
+    for (int i = 0; i < 6 && i < n; ++i, ++cnt) {
+        float t = 0.f;
+        if (h->ph[i].used && hipEventElapsedTime(&t, h->ph[i].e0, h->ph[i].e1) == hipSuccess) ms[i] = t;
+        else ms[i] = -1.0;
+    }
+    return cnt;
+}
+
+int grape_get_work(grape_handle *h, double *out, int n) {
+    if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    unsigned long long st[16];
+    HIPCHK(h, hipMemcpy(st, h->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+    const double N3 = (double)h->N * h->N * h->N, N2 = (double)h->N * h->N;
+    const double cells = (double)h->K * h->N_T;
+    // F_exp = (g + s) * 8 N^3 + (32/3) N^3, g = GEMMs of the Pade order (13:6, 9:5, 7:4, 5:3, 3:2)
+    const double gemms = 2.0 * st[3] + 3.0 * st[4] + 4.0 * st[5] + 5.0 * st[6] + 6.0 * st[7];
+    out[0] = cells;
+    out[1] = (double)st[0];
+    out[2] = (gemms + (double)st[0]) * 8.0 * N3 + cells * (32.0 / 3.0) * N3;
+    // derivative series: per order (1 + 2L) complex mat-vecs of 8 N^2 flop
+    out[3] = (double)st[8] * (1.0 + 2.0 * h->L) * 8.0 * N2;
+    if (n > 4) out[4] = (double)st[8];  // sum of series orders
+    return 4;
+}
+
+}  // extern "C"

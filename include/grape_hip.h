@@ -1,0 +1,155 @@
+/*
+ * grape_hip.h -- C ABI of the MI355X-native GRAPE gradient evaluator.
+ *
+ * This is the drop-in boundary for the hot path of JuliaQuantumControl/GRAPE.jl: one call of
+ * grape_eval() replaces the body of
+ *     evaluate_functional(pulsevals, wrk)        /root/reference/src/optimize.jl:696-768
+ *     evaluate_gradient!(G, pulsevals, wrk)      /root/reference/src/optimize.jl:824-1014
+ * i.e. what the closure fg!(F, G, pulsevals) (src/optimize.jl:105-111) does when the optimizer
+ * backend calls it (ext/GRAPELBFGSBExt.jl:99, ext/GRAPEOptimExt.jl:31), for trajectories whose
+ * generator is H_k(t) = H0_k + sum_l eps_l(t) S_l(t) H_l propagated with `prop_method = ExpProp`.
+ * grape_create() replaces the data-layout half of the GrapeWrk constructor
+ * (/root/reference/src/workspace.jl:147-362): it uploads the static problem and allocates the
+ * forward storage (workspace.jl:215), tau_grads (workspace.jl:236-237) and gradient buffers
+ * (workspace.jl:196-198) in HBM.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no torch types; every function returns 0 on success or a negative
+ *     grape_status; the message of the last failure is available from grape_last_error().
+ *   - complex numbers are interleaved (re, im) doubles == Julia ComplexF64 == C double _Complex.
+ *   - matrices are COLUMN-major N x N (Julia Matrix{ComplexF64}); states are length-N vectors.
+ *   - pulsevals / G are CONTROL-major: index (l * N_T + n), l < L, n < N_T
+ *     (workspace.jl:159-162, optimize.jl:579, 935-936).
+ *   - host pointers are owned by the caller and are not retained after the call returns
+ *     (they may be Julia-GC managed: `obj.g`, `wrk.pulsevals`).  One in-flight call per handle.
+ *   - trajectories may be sharded over processes/GPUs: a handle owns K local trajectories out of
+ *     K_total; the two cross-trajectory reductions of the path (sum_k w_k tau_k for J_T_sm/chi_sm,
+ *     sum_k of the gradient, optimize.jl:579) are exposed by the split-phase calls below so that
+ *     the host can all-reduce them (RCCL) between phases.
+ */
+#ifndef GRAPE_HIP_H
+#define GRAPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAPE_HIP_ABI_VERSION 1
+
+typedef struct grape_handle grape_handle;
+
+typedef enum {
+    GRAPE_OK = 0,
+    GRAPE_ERR_INVALID = -1,      /* bad argument / unsupported size                          */
+    GRAPE_ERR_HIP = -2,          /* HIP runtime failure (message has the hipError string)    */
+    GRAPE_ERR_CHI_NORM = -3,     /* ||chi_k|| < chi_min_norm          (optimize.jl:1021-1025)*/
+    GRAPE_ERR_SINGULAR = -4,     /* Pade denominator numerically singular                    */
+    GRAPE_ERR_TAYLOR = -5,       /* Taylor derivative series did not converge (optimize.jl:644-648) */
+    GRAPE_ERR_NO_CONTROLS = -6   /* L == 0                             (workspace.jl:155-157)*/
+} grape_status;
+
+/* J_T of QuantumControl.Functionals (docs/src/tutorial.md:349-356, 402) */
+typedef enum {
+    GRAPE_J_T_SM = 0,  /* 1 - |sum_k w_k tau_k|^2 / K^2 ; chi_k = w_k (sum_j w_j tau_j) / K^2 * tgt_k */
+    GRAPE_J_T_SS = 1,  /* 1 - sum_k w_k |tau_k|^2 / K   ; chi_k = w_k tau_k / K * tgt_k               */
+    GRAPE_J_T_RE = 2   /* 1 - Re sum_k w_k tau_k / K    ; chi_k = w_k / (2K) * tgt_k                  */
+} grape_functional;
+
+/* gradient_method keyword of the reference (workspace.jl:150, optimize.jl:871-998) */
+typedef enum {
+    GRAPE_GRAD_GRADGEN = 0, /* exact derivative of exp (what the gradient generator yields)  */
+    GRAPE_GRAD_TAYLOR = 1   /* Kuprov-Rodgers recursion, taylor_grad_step! (optimize.jl:604) */
+} grape_gradient_method;
+
+typedef struct {
+    int32_t abi_version;     /* GRAPE_HIP_ABI_VERSION                                           */
+    int32_t N;               /* Hilbert-space dimension                                         */
+    int32_t L;               /* number of controls                                              */
+    int32_t K;               /* trajectories owned by this handle (the reference's `N`, :703)   */
+    int32_t K_total;         /* trajectories of the whole job (== K when not sharded; 0 => K)   */
+    int32_t N_T;             /* time intervals = length(tlist) - 1 (optimize.jl:705)            */
+    int32_t functional;      /* grape_functional                                                */
+    int32_t gradient_method; /* grape_gradient_method                                           */
+    int32_t hc_per_traj;     /* 0: Hc is [L][N*N] shared by all k; 1: Hc is [K][L][N*N]         */
+    int32_t device;          /* HIP device ordinal                                              */
+    const double *tlist;     /* [N_T+1] time grid (non-uniform allowed)                         */
+    const double *H0;        /* [K][N*N] complex: drift of trajectory k                         */
+    const double *Hc;        /* control operators mu_l = dH/d eps_l (see hc_per_traj)           */
+    const double *shape;     /* NULL or [L][N_T] real: a_l(eps, t_n) = shape[l][n] * eps_{nl}   */
+    const double *psi0;      /* [K][N] complex initial states                                   */
+    const double *target;    /* [K][N] complex target states                                    */
+    const double *weights;   /* NULL (all 1) or [K]                                             */
+    double chi_min_norm;     /* <= 0 selects the reference default 1e-100 (optimize.jl:846)     */
+    int32_t taylor_max_order;/* <= 0 selects 100   (optimize.jl:915)                            */
+    double taylor_tolerance; /* <= 0 selects 1e-16 (optimize.jl:916)                            */
+} grape_problem;
+
+/* Replaces GrapeWrk(...) data set-up: /root/reference/src/workspace.jl:147-362 */
+int grape_create(grape_handle **out, const grape_problem *problem);
+void grape_destroy(grape_handle *h);
+
+/*
+ * Replaces fg!(F, G, x): /root/reference/src/optimize.jl:105-111.
+ *   G == NULL  -> evaluate_functional only (forward sweep, optimize.jl:696-768)
+ *   G != NULL  -> evaluate_gradient!      (optimize.jl:824-1014); G has L*N_T doubles
+ *   tau  (nullable) [K] complex  -> wrk.result.tau_vals      (optimize.jl:753)
+ *   psiT (nullable) [K][N] complex -> fw_propagators[k].state (optimize.jl:187-189, 752)
+ * Single-handle form: valid only when K == K_total.
+ */
+int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, double *tau,
+               double *psiT);
+
+/*
+ * Split-phase form for trajectory shards (one handle per GPU):
+ *   1. grape_forward      : expm of every local cell + forward sweep; returns local tau[K]
+ *   2. host all-reduces   : f = sum over ALL trajectories of w_k tau_k   (2 doubles)
+ *   3. grape_backward     : chi from (f, local tau), backward sweep, per-cell derivatives and the
+ *                           local sum over k; returns the PARTIAL gradient (L*N_T) and the local
+ *                           partial sums needed for J_T ([0]=sum w|tau|^2, [1]=Re sum w tau)
+ *   4. host all-reduces   : G (sum) -- the sum over k of optimize.jl:579
+ * grape_eval() is exactly 1 + 3 with f computed locally.
+ */
+int grape_forward(grape_handle *h, const double *pulsevals, double *tau /* [K] complex */);
+int grape_backward(grape_handle *h, const double f_total[2], double *G_partial);
+
+/* Device-resident variants used by the bench / RCCL path: same semantics, every pointer is a
+ * device pointer on the handle's device; work is enqueued on `stream` (a hipStream_t passed as
+ * void*) without host synchronisation.
+ *   d_out layout of grape_forward_device : [0..2K) tau, [2K] Re f_local, [2K+1] Im f_local,
+ *                                          [2K+2] sum_k w_k |tau_k|^2, [2K+3] Re sum_k w_k tau_k
+ *   d_f   : 2 doubles, the all-reduced f;  d_G: L*N_T doubles (partial gradient, overwritten) */
+int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_out, void *stream);
+int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void *stream);
+
+/* Synchronise `stream` and translate the device-side error flags of the evaluation in flight
+ * (singular Pade denominator, chi norm guard, series non-convergence) into a grape_status. */
+int grape_check(grape_handle *h, void *stream);
+
+/* U_kn = exp(-i H_kn dt_n) of the last evaluation as an N x N column-major complex matrix
+ * (parity check of the ExpProp step, optimize.jl:732). */
+int grape_get_propagator(grape_handle *h, int k, int n, double *out);
+
+/* Optional outputs of the last evaluation (debug / parity): tau_grads[k][l][n] complex
+ * (workspace.jl:236-237, value of optimize.jl:894), forward storage [k][n][N] complex
+ * (workspace.jl:215; n = 0..N_T) and the backward states chi_k(t_n) [k][n][N]. */
+int grape_get_tau_grads(grape_handle *h, double *out /* K*L*N_T complex */);
+int grape_get_storage(grape_handle *h, int which /*0 fw, 1 bw*/, double *out /* K*(N_T+1)*N complex */);
+
+/* Per-phase device time of the last grape_eval / forward+backward pair, milliseconds, measured
+ * with HIP events on the handle's stream: [0] expm, [1] forward sweep, [2] backward sweep,
+ * [3] cell derivatives, [4] reduction, [5] total.  Returns the number of entries written. */
+int grape_get_timings(grape_handle *h, double *ms, int n);
+/* Algorithmic work of the last evaluation: [0] cells, [1] sum of squarings s over cells,
+ * [2] flop of the expm kernel (SURVEY 8d F_exp), [3] flop of the derivative kernel. */
+int grape_get_work(grape_handle *h, double *out, int n);
+
+const char *grape_last_error(grape_handle *h); /* h may be NULL: error of the last failed create */
+int grape_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPE_HIP_H */

@@ -1,0 +1,401 @@
+/*
+ * oracle/grape_ref.c -- CPU restatement (plain C99 + OpenMP) of the GRAPE hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and the cpu_baseline leg
+ * of bench.py may load this library, and only as the checker / the timed CPU baseline.
+ * The product path (grape.jl_amd/csrc) never links or calls it.
+ *
+ * What it restates (file:line into /root/reference):
+ *   forward sweep, storage, tau, J_T ............. src/optimize.jl:696-768
+ *   chi boundary, rho, normalize_chis! ........... src/optimize.jl:845-869, 1017-1038
+ *   backward sweep with the gradient generator ... src/optimize.jl:873-911
+ *                                                  docs/src/background.md:443-497
+ *   :taylor gradient + taylor_grad_step! ......... src/optimize.jl:913-994, 604-653
+ *   -2 Re sum_k, control-major index ............. src/optimize.jl:574-584
+ *   pulsevals layout ............................. src/workspace.jl:159-162
+ *
+ * Arithmetic the reference delegates to packages that are NOT vendored under
+ * /root/reference (Project.toml:21-30, no Manifest): QuantumPropagators `ExpProp`
+ * (U = exp(-i H dt), state <- U state), QuantumGradientGenerators `GradGenerator`
+ * (block upper-triangular generator, densified by ExpProp) and Julia's stdlib
+ * `LinearAlgebra.exp` (Higham 2005 scaling-and-squaring Pade, orders 3/5/7/9 for
+ * ||A||_1 <= 2.1 and order 13 with s = ceil(log2(||A||_1 / 5.4)) squarings otherwise,
+ * solved with LAPACK gesv = LU with partial pivoting).  They are restated here from their
+ * published algorithms.  Deviation: Julia's `exp!` first balances the matrix (LAPACK
+ * gebal 'B': permutation + power-of-two diagonal scaling); that is an exact similarity
+ * transform, changes results only at rounding level, and is omitted.
+ *
+ * PARITY: no numeric golden vectors exist in the reference and Julia is absent from this
+ * image, so bit-level parity with the Julia run is UNPINNED.  This file is pinned instead
+ * against scipy.linalg.expm, the closed-form two-level result, finite differences and the
+ * numpy oracle (tests/test_oracle.py).
+ *
+ * Layout: complex numbers are interleaved (re,im) doubles; matrices are column-major
+ * (Julia layout); H0 is K x (N x N), Hc is L x (N x N) (shared) or K x L x (N x N).
+ */
+#include <complex.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef double complex cplx;
+
+enum { GRAPE_REF_SM = 0, GRAPE_REF_SS = 1, GRAPE_REF_RE = 2 };
+enum { GRAPE_REF_GRADGEN = 0, GRAPE_REF_TAYLOR = 1, GRAPE_REF_FRECHET = 2 };
+
+/* ---------- dense kernels (column-major) ---------- */
+
+/* C = A*B (n x n) */
+static void zgemm_nn(int n, const cplx *restrict A, const cplx *restrict B, cplx *restrict C) {
+    memset(C, 0, sizeof(cplx) * (size_t)n * n);
+    for (int j = 0; j < n; ++j) {
+        cplx *restrict cj = C + (size_t)j * n;
+        int k = 0;
+        for (; k + 3 < n; k += 4) {
+            const cplx b0 = B[(size_t)j * n + k], b1 = B[(size_t)j * n + k + 1];
+            const cplx b2 = B[(size_t)j * n + k + 2], b3 = B[(size_t)j * n + k + 3];
+            const cplx *restrict a0 = A + (size_t)k * n, *restrict a1 = a0 + n;
+            const cplx *restrict a2 = a1 + n, *restrict a3 = a2 + n;
+            for (int i = 0; i < n; ++i) cj[i] += a0[i] * b0 + a1[i] * b1 + a2[i] * b2 + a3[i] * b3;
+        }
+        for (; k < n; ++k) {
+            const cplx b0 = B[(size_t)j * n + k];
+            const cplx *restrict a0 = A + (size_t)k * n;
+            for (int i = 0; i < n; ++i) cj[i] += a0[i] * b0;
+        }
+    }
+}
+
+/* y = A*x */
+static void zgemv_n(int n, const cplx *restrict A, const cplx *restrict x, cplx *restrict y) {
+    for (int i = 0; i < n; ++i) y[i] = 0;
+    for (int k = 0; k < n; ++k) {
+        const cplx xk = x[k];
+        const cplx *restrict a = A + (size_t)k * n;
+        for (int i = 0; i < n; ++i) y[i] += a[i] * xk;
+    }
+}
+
+static double norm1(int n, const cplx *A) {
+    double m = 0;
+    for (int j = 0; j < n; ++j) {
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += cabs(A[(size_t)j * n + i]);
+        if (s > m) m = s;
+    }
+    return m;
+}
+
+/* Solve Q X = P in place (X overwrites P): LU with partial pivoting (LAPACK gesv). */
+static int zgesv(int n, cplx *restrict Q, cplx *restrict P) {
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = cabs(Q[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; ++i) {
+            double v = cabs(Q[(size_t)k * n + i]);
+            if (v > best) { best = v; p = i; }
+        }
+        if (best == 0.0) return -1;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) {
+                cplx t = Q[(size_t)j * n + k]; Q[(size_t)j * n + k] = Q[(size_t)j * n + p]; Q[(size_t)j * n + p] = t;
+                t = P[(size_t)j * n + k]; P[(size_t)j * n + k] = P[(size_t)j * n + p]; P[(size_t)j * n + p] = t;
+            }
+        }
+        const cplx inv = 1.0 / Q[(size_t)k * n + k];
+        for (int i = k + 1; i < n; ++i) Q[(size_t)k * n + i] *= inv;
+        for (int j = k + 1; j < n; ++j) {
+            const cplx u = Q[(size_t)j * n + k];
+            cplx *restrict qj = Q + (size_t)j * n;
+            const cplx *restrict lk = Q + (size_t)k * n;
+            for (int i = k + 1; i < n; ++i) qj[i] -= lk[i] * u;
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        cplx *restrict x = P + (size_t)j * n;
+        for (int k = 0; k < n; ++k) { /* L y = b (unit lower) */
+            const cplx xk = x[k];
+            const cplx *restrict lk = Q + (size_t)k * n;
+            for (int i = k + 1; i < n; ++i) x[i] -= lk[i] * xk;
+        }
+        for (int k = n - 1; k >= 0; --k) { /* U x = y */
+            x[k] /= Q[(size_t)k * n + k];
+            const cplx xk = x[k];
+            const cplx *restrict uk = Q + (size_t)k * n;
+            for (int i = 0; i < k; ++i) x[i] -= uk[i] * xk;
+        }
+    }
+    return 0;
+}
+
+static const double PADE3[] = {120., 60., 12., 1.};
+static const double PADE5[] = {30240., 15120., 3360., 420., 30., 1.};
+static const double PADE7[] = {17297280., 8648640., 1995840., 277200., 25200., 1512., 56., 1.};
+static const double PADE9[] = {17643225600., 8821612800., 2075673600., 302702400., 30270240.,
+                               2162160., 110880., 3960., 90., 1.};
+static const double PADE13[] = {64764752532480000., 32382376266240000., 7771770303897600.,
+                                1187353796428800., 129060195264000., 10559470521600.,
+                                670442572800., 33522128640., 1323241920., 40840800., 960960.,
+                                16380., 182., 1.};
+
+/* E = exp(A), A is n x n column-major and is destroyed.  Higham (2005) as in Julia's exp!.
+ * work: 6*n*n cplx.  Returns the Pade order used (negative on singular solve);
+ * *squarings receives s. */
+int grape_ref_expm(int n, double *A_, double *E_, double *work_, int *squarings) {
+    cplx *A = (cplx *)A_, *E = (cplx *)E_, *w = (cplx *)work_;
+    const size_t nn = (size_t)n * n;
+    cplx *A2 = w, *U = w + nn, *V = w + 2 * nn, *T = w + 3 * nn, *A4 = w + 4 * nn, *A6 = w + 5 * nn;
+    const double nA = norm1(n, A);
+    int order, s = 0;
+    if (nA <= 2.1) {
+        const double *c; int nc;
+        if (nA > 0.95) { c = PADE9; nc = 10; }
+        else if (nA > 0.25) { c = PADE7; nc = 8; }
+        else if (nA > 0.015) { c = PADE5; nc = 6; }
+        else { c = PADE3; nc = 4; }
+        order = nc - 1;
+        zgemm_nn(n, A, A, A2);
+        /* P = I; U = c1 P; V = c0 P; then P *= A2 ... */
+        cplx *P = A4, *Pn = A6;
+        memset(P, 0, sizeof(cplx) * nn); memset(U, 0, sizeof(cplx) * nn); memset(V, 0, sizeof(cplx) * nn);
+        for (int i = 0; i < n; ++i) { P[(size_t)i * n + i] = 1; U[(size_t)i * n + i] = c[1]; V[(size_t)i * n + i] = c[0]; }
+        for (int k = 1; k <= nc / 2 - 1; ++k) {
+            zgemm_nn(n, P, A2, Pn);
+            cplx *t = P; P = Pn; Pn = t;
+            for (size_t i = 0; i < nn; ++i) { U[i] += c[2 * k + 1] * P[i]; V[i] += c[2 * k] * P[i]; }
+        }
+        zgemm_nn(n, A, U, T); /* U = A*U */
+        for (size_t i = 0; i < nn; ++i) { E[i] = V[i] + T[i]; V[i] = V[i] - T[i]; }
+        if (zgesv(n, V, E)) return -1;
+    } else {
+        const double sl = log2(nA / 5.4);
+        if (sl > 0) {
+            s = (int)ceil(sl);
+            const double f = ldexp(1.0, -s);
+            for (size_t i = 0; i < nn; ++i) A[i] *= f;
+        }
+        order = 13;
+        const double *c = PADE13;
+        zgemm_nn(n, A, A, A2);
+        zgemm_nn(n, A2, A2, A4);
+        zgemm_nn(n, A2, A4, A6);
+        for (size_t i = 0; i < nn; ++i) T[i] = c[13] * A6[i] + c[11] * A4[i] + c[9] * A2[i];
+        zgemm_nn(n, A6, T, U);
+        for (size_t i = 0; i < nn; ++i) U[i] += c[7] * A6[i] + c[5] * A4[i] + c[3] * A2[i];
+        for (int i = 0; i < n; ++i) U[(size_t)i * n + i] += c[1];
+        zgemm_nn(n, A, U, T); /* T = U_final */
+        for (size_t i = 0; i < nn; ++i) U[i] = c[12] * A6[i] + c[10] * A4[i] + c[8] * A2[i];
+        zgemm_nn(n, A6, U, V);
+        for (size_t i = 0; i < nn; ++i) V[i] += c[6] * A6[i] + c[4] * A4[i] + c[2] * A2[i];
+        for (int i = 0; i < n; ++i) V[(size_t)i * n + i] += c[0];
+        for (size_t i = 0; i < nn; ++i) { E[i] = V[i] + T[i]; V[i] = V[i] - T[i]; }
+        if (zgesv(n, V, E)) return -1;
+        for (int t = 0; t < s; ++t) {
+            zgemm_nn(n, E, E, T);
+            memcpy(E, T, sizeof(cplx) * nn);
+        }
+    }
+    if (squarings) *squarings = s;
+    return order;
+}
+
+/* H = H0_k + sum_l eps_l * shape_l * H_l  (ExpProp `evaluate!`) */
+static void build_H(int N, int L, const cplx *H0k, const cplx *Hck, const double *eps, cplx *H) {
+    const size_t nn = (size_t)N * N;
+    memcpy(H, H0k, sizeof(cplx) * nn);
+    for (int l = 0; l < L; ++l) {
+        const double a = eps[l];
+        const cplx *Hl = Hck + (size_t)l * nn;
+        for (size_t i = 0; i < nn; ++i) H[i] += a * Hl[i];
+    }
+}
+
+/* restatement of taylor_grad_step! (src/optimize.jl:604-653); mats column-major; tmp: 4*N */
+static int taylor_grad_step(int N, cplx *out, const cplx *psi, const cplx *H, const cplx *mu,
+                            double dt, cplx *tmp, int max_order, double tol) {
+    cplx *phi = tmp, *phi_prev = tmp + N, *Hn = tmp + 2 * N, *Hn1 = tmp + 3 * N;
+    cplx *scratch = (cplx *)malloc(sizeof(cplx) * N);
+    zgemv_n(N, mu, psi, phi_prev);
+    zgemv_n(N, H, psi, Hn1);
+    cplx alpha = -I * dt;
+    for (int i = 0; i < N; ++i) out[i] = alpha * phi_prev[i];
+    int converged = 0;
+    for (int n = 2; n <= max_order; ++n) {
+        zgemv_n(N, H, phi_prev, phi);
+        zgemv_n(N, mu, Hn1, scratch);
+        double nrm = 0;
+        for (int i = 0; i < N; ++i) { phi[i] += scratch[i]; }
+        alpha *= -I * dt / n;
+        for (int i = 0; i < N; ++i) { out[i] += alpha * phi[i]; nrm += creal(phi[i]) * creal(phi[i]) + cimag(phi[i]) * cimag(phi[i]); }
+        if (cabs(alpha) * sqrt(nrm) < tol) { converged = 1; break; }
+        zgemv_n(N, H, Hn1, Hn);
+        cplx *t = Hn; Hn = Hn1; Hn1 = t;
+        t = phi; phi = phi_prev; phi_prev = t;
+    }
+    free(scratch);
+    return converged ? 0 : -2;
+}
+
+/*
+ * One gradient evaluation (evaluate_gradient!, src/optimize.jl:824-1014, no running costs).
+ * G may be NULL (functional only == evaluate_functional).  psiT/tau_grads may be NULL.
+ * gradient_method: 0 = :gradgen literal ((L+1)N block exponential), 1 = :taylor.
+ * Returns 0, -1 (singular Pade solve), -2 (taylor not converged), -3 (chi norm < 1e-100).
+ */
+int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const double *H0_,
+                   const double *Hc_, int hc_per_traj, const double *psi0_, const double *target_,
+                   const double *weights, int functional, int gradient_method,
+                   const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
+                   double *tau_grads_ /* K*N_T*L cplx, [k][l][n] */, int nthreads) {
+    const size_t nn = (size_t)N * N;
+    const cplx *H0 = (const cplx *)H0_, *Hc = (const cplx *)Hc_;
+    const cplx *psi0 = (const cplx *)psi0_, *target = (const cplx *)target_;
+    cplx *tau = (cplx *)tau_;
+    cplx *storage = (cplx *)malloc(sizeof(cplx) * (size_t)K * (N_T + 1) * N); /* workspace.jl:215 */
+    cplx *tg = (cplx *)calloc((size_t)K * N_T * L, sizeof(cplx));             /* workspace.jl:236 */
+    int err = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+
+    /* ---- forward sweep: optimize.jl:720-754 ---- */
+#pragma omp parallel for schedule(dynamic) reduction(min : err)
+    for (int k = 0; k < K; ++k) {
+        cplx *H = (cplx *)malloc(sizeof(cplx) * nn * 9);
+        cplx *A = H + nn, *U = H + 2 * nn, *work = H + 3 * nn;
+        const cplx *Hck = hc_per_traj ? Hc + (size_t)k * L * nn : Hc;
+        double eps[64];
+        cplx *st = storage + (size_t)k * (N_T + 1) * N;
+        memcpy(st, psi0 + (size_t)k * N, sizeof(cplx) * N);
+        for (int n = 0; n < N_T; ++n) {
+            const double dt = tlist[n + 1] - tlist[n];
+            for (int l = 0; l < L; ++l) eps[l] = pulsevals[(size_t)l * N_T + n];
+            build_H(N, L, H0 + (size_t)k * nn, Hck, eps, H);
+            for (size_t i = 0; i < nn; ++i) A[i] = -I * dt * H[i];
+            if (grape_ref_expm(N, (double *)A, (double *)U, (double *)work, NULL) < 0) err = -1;
+            zgemv_n(N, U, st + (size_t)n * N, st + (size_t)(n + 1) * N); /* :732, :738 */
+        }
+        cplx t = 0;
+        for (int i = 0; i < N; ++i) t += conj(target[(size_t)k * N + i]) * st[(size_t)N_T * N + i]; /* :753 */
+        tau[k] = t;
+        if (psiT_) memcpy((cplx *)psiT_ + (size_t)k * N, st + (size_t)N_T * N, sizeof(cplx) * N);
+        free(H);
+    }
+
+    /* ---- J_T and chi boundary (QuantumControl.Functionals; tutorial.md:349-356, 402) ---- */
+    cplx f = 0;
+    double ss = 0, re = 0;
+    for (int k = 0; k < K; ++k) {
+        const double w = weights ? weights[k] : 1.0;
+        f += w * tau[k];
+        ss += w * (creal(tau[k]) * creal(tau[k]) + cimag(tau[k]) * cimag(tau[k]));
+        re += w * creal(tau[k]);
+    }
+    if (functional == GRAPE_REF_SM) *J = 1.0 - (creal(f) * creal(f) + cimag(f) * cimag(f)) / ((double)K * K);
+    else if (functional == GRAPE_REF_SS) *J = 1.0 - ss / K;
+    else *J = 1.0 - re / K;
+
+    if (G && !err) {
+        const int D = (L + 1) * N;
+        const size_t dd = (size_t)D * D;
+#pragma omp parallel for schedule(dynamic) reduction(min : err)
+        for (int k = 0; k < K; ++k) {
+            const double w = weights ? weights[k] : 1.0;
+            cplx coeff;
+            if (functional == GRAPE_REF_SM) coeff = w * f / ((double)K * K);
+            else if (functional == GRAPE_REF_SS) coeff = w * tau[k] / K;
+            else coeff = w / (2.0 * K);
+            cplx *chi = (cplx *)malloc(sizeof(cplx) * (size_t)(D + D + 6 * N));
+            cplx *ext = chi + N, *ext2 = ext + D, *tmp = ext2 + D; /* tmp: 5*N */
+            double rho = 0;
+            for (int i = 0; i < N; ++i) {
+                chi[i] = coeff * target[(size_t)k * N + i]; /* optimize.jl:848-855 */
+                rho += creal(chi[i]) * creal(chi[i]) + cimag(chi[i]) * cimag(chi[i]);
+            }
+            rho = sqrt(rho);                       /* :867 */
+            if (rho < 1e-100) { err = -3; free(chi); continue; } /* :1021-1025 */
+            for (int i = 0; i < N; ++i) chi[i] /= rho; /* :868 */
+
+            const cplx *Hck = hc_per_traj ? Hc + (size_t)k * L * nn : Hc;
+            const cplx *st = storage + (size_t)k * (N_T + 1) * N;
+            cplx *H = (cplx *)malloc(sizeof(cplx) * (nn * 2 + (size_t)L * nn));
+            cplx *Hdag = H + nn, *mudag = H + 2 * nn;
+            for (int l = 0; l < L; ++l) /* mu_l^dagger */
+                for (int j = 0; j < N; ++j)
+                    for (int i = 0; i < N; ++i)
+                        mudag[(size_t)l * nn + (size_t)j * N + i] = conj(Hck[(size_t)l * nn + (size_t)i * N + j]);
+            cplx *Gm = NULL, *EG = NULL, *workG = NULL;
+            if (gradient_method == GRAPE_REF_GRADGEN) {
+                Gm = (cplx *)malloc(sizeof(cplx) * dd * 8);
+                EG = Gm + dd; workG = Gm + 2 * dd;
+            } else {
+                Gm = (cplx *)malloc(sizeof(cplx) * nn * 8);
+                EG = Gm + nn; workG = Gm + 2 * nn;
+            }
+            double eps[64];
+            for (int n = N_T - 1; n >= 0; --n) { /* reference n = N_T:-1:1 */
+                const double dt = tlist[n + 1] - tlist[n];
+                for (int l = 0; l < L; ++l) eps[l] = pulsevals[(size_t)l * N_T + n];
+                build_H(N, L, H0 + (size_t)k * nn, Hck, eps, H);
+                for (int j = 0; j < N; ++j)
+                    for (int i = 0; i < N; ++i) Hdag[(size_t)j * N + i] = conj(H[(size_t)i * N + j]);
+                const cplx *psi = st + (size_t)n * N; /* storage[k][:, n], :888-892 */
+                if (gradient_method == GRAPE_REF_GRADGEN) {
+                    /* A = -i * G[H^dagger] * (-dt), G block upper triangular (background.md:467-477) */
+                    memset(Gm, 0, sizeof(cplx) * dd);
+                    for (int b = 0; b <= L; ++b)
+                        for (int j = 0; j < N; ++j)
+                            for (int i = 0; i < N; ++i)
+                                Gm[(size_t)(b * N + j) * D + b * N + i] = I * dt * Hdag[(size_t)j * N + i];
+                    for (int l = 0; l < L; ++l)
+                        for (int j = 0; j < N; ++j)
+                            for (int i = 0; i < N; ++i)
+                                Gm[(size_t)(L * N + j) * D + l * N + i] = I * dt * mudag[(size_t)l * nn + (size_t)j * N + i];
+                    if (grape_ref_expm(D, (double *)Gm, (double *)EG, (double *)workG, NULL) < 0) err = -1;
+                    for (int i = 0; i < D; ++i) ext[i] = 0;       /* GradVector / resetgradvec!, :878, :896 */
+                    memcpy(ext + (size_t)L * N, chi, sizeof(cplx) * N);
+                    zgemv_n(D, EG, ext, ext2);                     /* :881 */
+                    for (int l = 0; l < L; ++l) {
+                        cplx d = 0;
+                        for (int i = 0; i < N; ++i) d += conj(ext2[(size_t)l * N + i]) * psi[i];
+                        tg[((size_t)k * L + l) * N_T + n] = rho * d; /* :894 */
+                    }
+                    memcpy(chi, ext2 + (size_t)L * N, sizeof(cplx) * N);
+                } else {
+                    for (int l = 0; l < L; ++l) {
+                        if (taylor_grad_step(N, ext, chi, Hdag, mudag + (size_t)l * nn, -dt, tmp, 100, 1e-16)) err = -2;
+                        cplx d = 0;
+                        for (int i = 0; i < N; ++i) d += conj(ext[i]) * psi[i];
+                        tg[((size_t)k * L + l) * N_T + n] = rho * d; /* :970 */
+                    }
+                    for (size_t i = 0; i < nn; ++i) Gm[i] = I * dt * Hdag[i];
+                    if (grape_ref_expm(N, (double *)Gm, (double *)EG, (double *)workG, NULL) < 0) err = -1;
+                    zgemv_n(N, EG, chi, ext); /* :972 */
+                    memcpy(chi, ext, sizeof(cplx) * N);
+                }
+            }
+            free(Gm); free(H); free(chi);
+        }
+        /* _grad_J_T_via_chi!: optimize.jl:574-584 */
+        for (int l = 0; l < L; ++l)
+            for (int n = 0; n < N_T; ++n) {
+                double s = 0;
+                for (int k = 0; k < K; ++k) s += creal(tg[((size_t)k * L + l) * N_T + n]);
+                G[(size_t)l * N_T + n] = -2.0 * s;
+            }
+        if (tau_grads_) memcpy(tau_grads_, tg, sizeof(cplx) * (size_t)K * N_T * L);
+    }
+    free(storage); free(tg);
+    return err;
+}
+
+int grape_ref_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,88 @@
+"""ctypes wrapper of oracle/libgrape_ref.so (the C restatement, see grape_ref.c).
+
+TEST INFRASTRUCTURE ONLY (checker in tests/ and smoke(); timed CPU baseline in bench.py)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GRADGEN, TAYLOR = 0, 1
+
+
+def build(force=False):
+    out = os.path.join(_HERE, "libgrape_ref.so")
+    src = os.path.join(_HERE, "grape_ref.c")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libgrape_ref.so"], check=True, capture_output=True)
+    return out
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libgrape_ref.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.grape_ref_eval.restype = C.c_int
+        _lib.grape_ref_expm.restype = C.c_int
+        _lib.grape_ref_max_threads.restype = C.c_int
+    return _lib
+
+
+def expm(A):
+    A = np.asarray(A, dtype=np.complex128)
+    n = A.shape[0]
+    Af = np.asfortranarray(A.copy())
+    E = np.zeros((n, n), dtype=np.complex128, order="F")
+    w = np.zeros(6 * n * n, dtype=np.complex128)
+    s = C.c_int(0)
+    order = lib().grape_ref_expm(n, Af.ctypes.data_as(C.c_void_p), E.ctypes.data_as(C.c_void_p),
+                                 w.ctypes.data_as(C.c_void_p), C.byref(s))
+    return np.ascontiguousarray(E), order, s.value
+
+
+def evaluate(H0, Hc, tlist, pulsevals, psi0, target, weights=None, functional=0,
+             gradient_method=GRADGEN, gradient=True, nthreads=0, want_parts=False):
+    """Same array conventions as grape_jl_amd.GrapeHip (H0[k][row, col])."""
+    H0 = np.asarray(H0)
+    K, N = H0.shape[0], H0.shape[1]
+    Hc = np.asarray(Hc)
+    per_traj = Hc.ndim == 4
+    L = Hc.shape[1] if per_traj else Hc.shape[0]
+    tl = np.ascontiguousarray(tlist, dtype=np.float64)
+    N_T = len(tl) - 1
+    H0c = np.ascontiguousarray(np.swapaxes(H0, -1, -2), dtype=np.complex128)  # column-major
+    Hcc = np.ascontiguousarray(np.swapaxes(Hc, -1, -2), dtype=np.complex128)
+    p0 = np.ascontiguousarray(psi0, dtype=np.complex128)
+    tg = np.ascontiguousarray(target, dtype=np.complex128)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    x = np.ascontiguousarray(pulsevals, dtype=np.float64)
+    J = C.c_double(0.0)
+    G = np.zeros(L * N_T) if gradient else None
+    tau = np.zeros(K, dtype=np.complex128)
+    psiT = np.zeros((K, N), dtype=np.complex128)
+    tgr = np.zeros((K, L, N_T), dtype=np.complex128)
+    vp = C.c_void_p
+    rc = lib().grape_ref_eval(
+        C.c_int(N), C.c_int(L), C.c_int(K), C.c_int(N_T), tl.ctypes.data_as(vp), H0c.ctypes.data_as(vp),
+        Hcc.ctypes.data_as(vp), C.c_int(int(per_traj)), p0.ctypes.data_as(vp), tg.ctypes.data_as(vp),
+        None if w is None else w.ctypes.data_as(vp), C.c_int(functional), C.c_int(gradient_method),
+        x.ctypes.data_as(vp), C.byref(J), None if G is None else G.ctypes.data_as(vp),
+        tau.ctypes.data_as(vp), psiT.ctypes.data_as(vp), tgr.ctypes.data_as(vp), C.c_int(nthreads))
+    if rc:
+        raise RuntimeError(f"grape_ref_eval failed with code {rc}")
+    if want_parts:
+        return J.value, G, tau, dict(psiT=psiT, tau_grads=tgr)
+    return J.value, G, tau
+
+
+def max_threads():
+    return lib().grape_ref_max_threads()
