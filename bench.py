@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- GRAPE gradient evaluations per second on MI355X (BASELINE.json metric).
+
+A *step* is one gradient evaluation (``evaluate_gradient!``, /root/reference/src/optimize.jl:824)
+of the headline configuration C3 -- N = 64, L = 2, N_T = 1000, K = 128 trajectories per GPU --
+through the device-pointer C ABI, with the pulse values already resident in HBM.  With N > 1
+GPUs every rank owns its own 128 trajectories of a 128*N-member ensemble (weak scaling, C4 at
+N = 8) and the two cross-trajectory reductions run as RCCL all-reduces on the kernel stream.
+
+``value`` = (number of 128-trajectory shard evaluations completed by all ranks) / time, i.e.
+``n_gpus * steps / seconds``.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # AMD spec for MI355X FP64 matrix; 77.6 measured (profiles/r01_fp64_peak_probe.txt)
+
+
+def cpu_baseline(pr, handle_eval, target_seconds=15.0):
+    """Time the C restatement of the reference's literal ExpProp route (oracle/grape_ref.c,
+    :gradgen = dense (L+1)N block exponential per backward step, OpenMP over trajectories as
+    @threadsif does) on a bounded sample of the same workload and scale linearly in cells."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import grape_ref  # noqa: E402  (timed CPU baseline + parity gate only)
+
+    cores = min(grape_ref.max_threads(), os.cpu_count() or 1)
+    K_s = min(pr["K"], cores)
+    threads = K_s
+
+    def sample(n_s):
+        sl = slice(0, K_s)
+        tl = pr["tlist"][: n_s + 1]
+        x = pr["pulsevals"].reshape(pr["L"], pr["N_T"])[:, :n_s].reshape(-1).copy()
+        t0 = time.perf_counter()
+        Jr, Gr, taur = grape_ref.evaluate(pr["H0"][sl], pr["Hc"], tl, x, pr["psi0"][sl], pr["target"][sl],
+                                          pr["weights"][sl], gradient_method=grape_ref.GRADGEN, nthreads=threads)
+        return time.perf_counter() - t0, (Jr, Gr, taur), (sl, tl, x)
+
+    t1, _, _ = sample(1)
+    n_s = int(max(2, min(pr["N_T"], target_seconds / max(t1, 1e-3))))
+    n_s = min(n_s, 64)
+    t, ref, (sl, tl, x) = sample(n_s)
+    cells_sample = K_s * n_s
+    cells_full = pr["K"] * pr["N_T"]
+    evals_per_s = 1.0 / (t * cells_full / cells_sample)
+    # parity gate on the sample problem
+    Jg, Gg, taug = handle_eval(sl, tl, x)
+    parity = dict(dJ=abs(Jg - ref[0]), dG=float(np.abs(Gg - ref[1]).max()), dtau=float(np.abs(taug - ref[2]).max()),
+                  Gmax=float(np.abs(ref[1]).max()))
+    ok = (parity["dJ"] <= 1e-12 and parity["dtau"] <= 1e-12
+          and parity["dG"] <= 1e-10 * max(parity["Gmax"], 1e-3))
+    return dict(value=evals_per_s, unit="evals/s", cores=threads, kind="port",
+                sample=f"{K_s} trajectories x {n_s} time steps of the same inputs ({cells_sample} of {cells_full} "
+                       f"cells, {t:.1f} s), literal :gradgen route, scaled linearly in cells",
+                parity_ok=bool(ok), parity=parity)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--traj-per-gpu", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import grape_jl_amd as g
+    from grape_jl_amd import synth
+    from grape_jl_amd.sharded import ShardedEvaluator
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    N, L, N_T, K0 = synth.CONFIGS[args.config]
+    K_local = args.traj_per_gpu or K0
+    K_total = K_local * world
+    pr = synth.make_config(args.config, K=K_local, k_offset=rank * K_local)
+    h = g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"],
+                   functional=g.J_T_SM, gradient_method=g.GRAD_GRADGEN, K_total=K_total, device=dev.index)
+    ev = ShardedEvaluator(h, K_total, g.J_T_SM, dist=dist, device=dev)
+    x, out, G = ev.alloc_device(L, N_T, K_local)
+    x.copy_(torch.from_numpy(pr["pulsevals"]))  # inputs resident in HBM before the timed region
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        ev.eval_device(stream)
+    sync()
+    h.check(stream)
+    h.reset_timings()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev.eval_device(stream)
+    sync()
+    elapsed = time.perf_counter() - t0
+    h.check(stream)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tm = h.timings()   # HIP-event averages over the timed region, recorded on the kernel stream
+    work = h.work()
+    J = ev.J_device()
+
+    if rank == 0:
+        expm_ms = tm["expm"]
+        achieved = work["flop_expm"] / (expm_ms * 1e-3) * 1e-12
+        res = {
+            "metric": "GRAPE gradient evals/sec (N=64, 1000 steps, 128 traj)" if args.config == "C3"
+                      else f"GRAPE gradient evals/sec ({args.config})",
+            "value": world * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: N={N}, L={L} controls, N_T={N_T} time steps, "
+                                   f"{K_local} trajectories per GPU ({K_total} total), J_T_sm, ExpProp",
+                       "gradient_method": "gradgen (exact derivative via the series of the gradient-generator "
+                                          "propagator on the extended state)",
+                       "one_eval": "one shard evaluation = functional + full gradient of 128 trajectories; "
+                                   "value counts shard evaluations completed by all ranks per second",
+                       "global_problem_evals_per_s": args.steps / elapsed},
+            "roofline": {"bound": "mfma", "kernel": "expm_pade_kernel<4> (v_mfma_f64_16x16x4_f64)",
+                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "flop_per_launch": work["flop_expm"], "avg_launch_ms": expm_ms,
+                         "flop_model": "SURVEY 8d F_exp = (6+s)*8N^3 + (32/3)N^3 per Pade-13 cell"},
+            "phases_ms": {k: round(v, 4) for k, v in tm.items()},
+            "deriv_kernel": {"flop_per_launch": work["flop_deriv"], "avg_launch_ms": tm["deriv"],
+                             "tflops": work["flop_deriv"] / (tm["deriv"] * 1e-3) * 1e-12 if tm["deriv"] > 0 else None,
+                             "series_orders_per_cell": work["deriv_orders"] / work["cells"]},
+            "J": J,
+        }
+        if not args.no_cpu_baseline:
+            def hip_sample(sl, tl, xs):
+                hs = g.GrapeHip(pr["H0"][sl], pr["Hc"], tl, pr["psi0"][sl], pr["target"][sl], pr["weights"][sl],
+                                functional=g.J_T_SM, device=dev.index)
+                r = hs.eval(xs)
+                hs.close()
+                return r
+            res["cpu_baseline"] = cpu_baseline(pr, hip_sample, args.cpu_seconds)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    h.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAP
 # every symbol include/grape_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = ["grape_create", "grape_destroy", "grape_eval", "grape_forward", "grape_backward",
            "grape_forward_device", "grape_backward_device", "grape_check", "grape_get_propagator",
-           "grape_get_tau_grads", "grape_get_storage", "grape_get_timings", "grape_get_work",
+           "grape_get_tau_grads", "grape_get_storage", "grape_get_timings", "grape_reset_timings", "grape_get_work",
            "grape_last_error", "grape_abi_version"]
 
 
@@ -95,6 +95,7 @@ def load_library():
     lib.grape_get_storage.argtypes = [vp, ip, vp]
     lib.grape_get_timings.argtypes = [vp, vp, ip]
     lib.grape_get_work.argtypes = [vp, vp, ip]
+    lib.grape_reset_timings.argtypes = [vp]
     lib.grape_last_error.argtypes = [vp]
     lib.grape_last_error.restype = C.c_char_p
     lib.grape_abi_version.restype = ip
@@ -236,6 +237,9 @@ class GrapeHip:
         ms = np.zeros(6)
         self._lib.grape_get_timings(self._h, ms.ctypes.data, 6)
         return dict(zip(["expm", "forward", "backward", "deriv", "reduce", "total"], ms.tolist()))
+
+    def reset_timings(self):
+        self._chk(self._lib.grape_reset_timings(self._h))
 
     def work(self):
         w = np.zeros(5)

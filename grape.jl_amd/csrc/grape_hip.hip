@@ -20,6 +20,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
+constexpr int kRing = 64;   // evaluations kept for phase timing
+constexpr int kPhases = 6;
 struct Phase { hipEvent_t e0, e1; bool used; };
 
 }  // namespace
@@ -42,9 +44,10 @@ struct grape_handle {
     unsigned long long *d_stats = nullptr;
     double *h_pin = nullptr;  // pinned staging
     size_t h_pin_doubles = 0;
-    Phase ph[6]{};
+    Phase ph[kRing][kPhases]{};
+    long n_fwd = 0, n_bwd = 0;  // evaluations recorded since the last grape_reset_timings
     std::string err;
-    bool have_forward = false;
+    bool have_forward = false, in_eval = false;
     double chi_min_norm = 1e-100, taylor_tol = 1e-16;
     int taylor_max_order = 100;
 };
@@ -99,8 +102,14 @@ hipError_t launch_deriv(const DerivArgs &a, int nblocks, hipStream_t s) {
     return hipGetLastError();
 }
 
-void phase_begin(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[i].e0, s); }
-void phase_end(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[i].e1, s); h->ph[i].used = true; }
+// phases 0,1 belong to the forward call, 2,3,4 to the backward call, 5 to grape_eval
+long phase_slot(grape_handle *h, int i) { return (i <= 1 ? h->n_fwd : (i <= 4 ? h->n_bwd : h->n_fwd)) % kRing; }
+void phase_begin(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[phase_slot(h, i)][i].e0, s); }
+void phase_end(grape_handle *h, int i, hipStream_t s) {
+    Phase &p = h->ph[phase_slot(h, i)][i];
+    hipEventRecord(p.e1, s);
+    p.used = true;
+}
 
 int status_from_flags(grape_handle *h, int flags) {
     if (flags & 1) { h->err = "Pade denominator numerically singular in at least one cell"; return GRAPE_ERR_SINGULAR; }
@@ -133,10 +142,11 @@ void grape_destroy(grape_handle *h) {
     for (void *b : bufs)
         if (b) hipFree(b);
     if (h->h_pin) hipHostFree(h->h_pin);
-    for (auto &p : h->ph) {
-        if (p.e0) hipEventDestroy(p.e0);
-        if (p.e1) hipEventDestroy(p.e1);
-    }
+    for (auto &ring : h->ph)
+        for (auto &p : ring) {
+            if (p.e0) hipEventDestroy(p.e0);
+            if (p.e1) hipEventDestroy(p.e1);
+        }
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -181,7 +191,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
 
     CCHK(hipSetDevice(h->device));
     CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (auto &ph : h->ph) { CCHK(hipEventCreate(&ph.e0)); CCHK(hipEventCreate(&ph.e1)); ph.used = false; }
+    for (auto &ring : h->ph)
+        for (auto &ph : ring) { CCHK(hipEventCreate(&ph.e0)); CCHK(hipEventCreate(&ph.e1)); ph.used = false; }
 
     const int N = h->N, NP = h->NP, L = h->L, K = h->K, N_T = h->N_T;
     const size_t pp = (size_t)NP * NP, nn = (size_t)N * N;
@@ -295,6 +306,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     if (d_out != h->d_out)
         HIPCHK(h, hipMemcpyAsync(h->d_out, d_out, ((size_t)2 * h->K + 4) * 8, hipMemcpyDeviceToDevice, s));
     h->have_forward = true;
+    if (!h->in_eval) h->n_fwd++;
     return GRAPE_OK;
 }
 
@@ -343,6 +355,7 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((LN + 255) / 256), dim3(256), 0, s, (const double2 *)h->d_tg, h->K, LN, d_G);
     HIPCHK(h, hipGetLastError());
     phase_end(h, 4, s);
+    h->n_bwd++;
     return GRAPE_OK;
 }
 
@@ -390,8 +403,10 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
         return GRAPE_ERR_INVALID;
     }
     phase_begin(h, 5, h->stream);
+    h->in_eval = true;  // keep the forward slot open until the whole evaluation has been recorded
     int rc = grape_forward(h, pulsevals, tau);
-    if (rc) return rc;
+    h->in_eval = false;
+    if (rc) { h->n_fwd++; return rc; }
     const size_t nl = (size_t)h->L * h->N_T;
     const double *sums = h->h_pin + nl + 2 * (size_t)h->K;  // f_re, f_im, sum w|tau|^2, Re sum w tau
     const double Kt = (double)h->K_total;
@@ -405,9 +420,10 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
     }
     if (G) {
         rc = grape_backward(h, f, G);
-        if (rc) return rc;
+        if (rc) { h->n_fwd++; return rc; }
     }
     phase_end(h, 5, h->stream);
+    h->n_fwd++;
     return GRAPE_OK;
 }
 
@@ -450,12 +466,27 @@ int grape_get_timings(grape_handle *h, double *ms, int n) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     int cnt = 0;
-    for (int i = 0; i < 6 && i < n; ++i, ++cnt) {
-        float t = 0.f;
-        if (h->ph[i].used && hipEventElapsedTime(&t, h->ph[i].e0, h->ph[i].e1) == hipSuccess) ms[i] = t;
-        else ms[i] = -1.0;
+    for (int i = 0; i < kPhases && i < n; ++i, ++cnt) {
+        double sum = 0.0;
+        int used = 0;
+        for (int r = 0; r < kRing; ++r) {
+            float t = 0.f;
+            Phase &p = h->ph[r][i];
+            if (p.used && hipEventElapsedTime(&t, p.e0, p.e1) == hipSuccess) { sum += t; ++used; }
+        }
+        ms[i] = used ? sum / used : -1.0;
     }
     return cnt;
+}
+
+int grape_reset_timings(grape_handle *h) {
+    if (!h) return GRAPE_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    for (auto &ring : h->ph)
+        for (auto &p : ring) p.used = false;
+    h->n_fwd = h->n_bwd = 0;
+    return GRAPE_OK;
 }
 
 int grape_get_work(grape_handle *h, double *out, int n) {

@@ -1,0 +1,366 @@
+"""Host-side mirror of the reference interface around the hot path.
+
+Mirrors (names, argument meaning, side effects, error behaviour) of
+/root/reference/src/optimize.jl and /root/reference/src/workspace.jl for the part of the
+interface that touches the accelerated path:
+
+* ``Trajectory`` / ``hamiltonian``   -- QuantumControl.Trajectory, QuantumPropagators.hamiltonian
+* ``GrapeWrk``                       -- src/workspace.jl:78-362 (pulsevals layout :159-162, bounds :199-212)
+* ``evaluate_functional``            -- src/optimize.jl:696-768
+* ``evaluate_gradient_b`` (``evaluate_gradient!``) -- src/optimize.jl:824-1014
+* ``optimize`` / ``GrapeResult``     -- src/optimize.jl:73-144, 185-228, src/result.jl:43-116,
+                                       L-BFGS-B loop of ext/GRAPELBFGSBExt.jl:18-147 (via scipy's
+                                       L-BFGS-B, the same L-BFGS-B 3.0 code family as LBFGSB.jl)
+
+The arithmetic is never done here: every evaluation goes through the C ABI
+(``GrapeHip.eval`` == ``fg!``).  ``backend=`` exists so that CPU-only tests can drive this host
+logic with a stand-in evaluator; the default backend is the HIP library and there is no fallback.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import api
+
+
+# ---- controls / generators ------------------------------------------------------------------
+def discretize_on_midpoints(control, tlist):
+    """QuantumPropagators.Controls.discretize_on_midpoints (docs/src/background.md:55)."""
+    tlist = np.asarray(tlist, dtype=np.float64)
+    nt = len(tlist)
+    if callable(control):
+        tm = np.empty(nt - 1)
+        tm[0], tm[-1] = tlist[0], tlist[-1]
+        if nt > 3:
+            tm[1:-1] = tlist[1:-2] + 0.5 * (tlist[2:-1] - tlist[1:-2])
+        return np.array([float(control(t)) for t in tm])
+    c = np.asarray(control, dtype=np.float64)
+    if len(c) == nt - 1:
+        return c.copy()
+    if len(c) == nt:
+        v = np.empty(nt - 1)
+        v[0], v[-1] = c[0], c[-1]
+        if nt > 3:
+            v[1:-1] = 0.5 * (c[1:-2] + c[2:-1])
+        return v
+    raise ValueError("control array must have length(tlist) or length(tlist)-1 elements")
+
+
+def discretize(vals, tlist):
+    """Pulse values on the intervals -> values on the points of ``tlist`` (finalize_result!, :219-228)."""
+    vals = np.asarray(vals, dtype=np.float64)
+    nt = len(tlist)
+    if len(vals) == nt:
+        return vals.copy()
+    out = np.empty(nt)
+    out[0], out[-1] = vals[0], vals[-1]
+    out[1:-1] = 0.5 * (vals[:-1] + vals[1:])
+    return out
+
+
+def hamiltonian(H0, *terms):
+    """``hamiltonian(H0, (H1, eps1), (H2, eps2), ...)``: H(t) = H0 + sum_l eps_l(t) H_l."""
+    ops, ctrls = [], []
+    for op, ctrl in terms:
+        ops.append(np.asarray(op, dtype=np.complex128))
+        ctrls.append(ctrl)
+    return Generator(np.asarray(H0, dtype=np.complex128), ops, ctrls)
+
+
+@dataclass
+class Generator:
+    drift: np.ndarray
+    ops: List[np.ndarray]
+    controls: list
+
+
+@dataclass
+class Trajectory:
+    initial_state: np.ndarray
+    generator: Generator
+    target_state: Optional[np.ndarray] = None
+    weight: float = 1.0
+
+
+def get_controls(trajectories):
+    """Unique controls (by identity) in order of first appearance."""
+    controls = []
+    for traj in trajectories:
+        for c in traj.generator.controls:
+            if not any(c is d for d in controls):
+                controls.append(c)
+    return controls
+
+
+# ---- functionals (QuantumControl.Functionals) ---------------------------------------------------
+def J_T_sm(Psi, trajectories, tau=None):
+    K = len(trajectories)
+    tau = _taus(Psi, trajectories) if tau is None else tau
+    f = sum(t.weight * tk for t, tk in zip(trajectories, tau))
+    return 1.0 - abs(f) ** 2 / K**2
+
+
+def J_T_ss(Psi, trajectories, tau=None):
+    K = len(trajectories)
+    tau = _taus(Psi, trajectories) if tau is None else tau
+    return 1.0 - sum(t.weight * abs(tk) ** 2 for t, tk in zip(trajectories, tau)) / K
+
+
+def J_T_re(Psi, trajectories, tau=None):
+    K = len(trajectories)
+    tau = _taus(Psi, trajectories) if tau is None else tau
+    return 1.0 - sum(t.weight * np.real(tk) for t, tk in zip(trajectories, tau)) / K
+
+
+def _taus(Psi, trajectories):
+    return [np.vdot(t.target_state, p) for t, p in zip(trajectories, Psi)]
+
+
+_FUNCTIONAL_CODE = {J_T_sm: api.J_T_SM, J_T_ss: api.J_T_SS, J_T_re: api.J_T_RE}
+
+
+# ---- result -----------------------------------------------------------------------------------
+@dataclass
+class GrapeResult:
+    """src/result.jl:43-67."""
+    tlist: np.ndarray
+    iter_start: int = 0
+    iter_stop: int = 5000
+    iter: int = 0
+    secs: float = 0.0
+    tau_vals: np.ndarray = None
+    J_T: float = 0.0
+    J_T_prev: float = 0.0
+    J_a: float = 0.0
+    J_a_prev: float = 0.0
+    J_b: float = 0.0
+    J_b_prev: float = 0.0
+    guess_controls: list = field(default_factory=list)
+    optimized_controls: list = field(default_factory=list)
+    states: list = field(default_factory=list)
+    start_local_time: float = 0.0
+    end_local_time: float = 0.0
+    records: list = field(default_factory=list)
+    converged: bool = False
+    f_calls: int = 0
+    fg_calls: int = 0
+    message: str = "in progress"
+
+    def __repr__(self):
+        return f"GrapeResult<{self.message}>"
+
+
+# ---- workspace --------------------------------------------------------------------------------
+class GrapeWrk:
+    """src/workspace.jl:78-362 -- owns ``pulsevals`` (control-major) and the device handle."""
+
+    def __init__(self, trajectories: Sequence[Trajectory], tlist, backend=None, **kwargs):
+        self.trajectories = list(trajectories)
+        self.tlist = np.asarray(tlist, dtype=np.float64)
+        self.kwargs = dict(kwargs)
+        self.controls = get_controls(self.trajectories)
+        if len(self.controls) == 0:
+            raise ValueError("no controls in trajectories: cannot optimize")  # workspace.jl:155-157
+        if "J_T" not in self.kwargs:
+            raise ValueError("`optimize` for `method=GRAPE` must be passed the functional `J_T`.")  # :298-303
+        L, N_T, K = len(self.controls), len(self.tlist) - 1, len(self.trajectories)
+        self.L, self.N_T, self.K = L, N_T, K
+        # pulsevals = vcat(discretize_on_midpoints(ctrl, tlist)...)   (workspace.jl:159-162)
+        self.pulsevals = np.concatenate([discretize_on_midpoints(c, self.tlist) for c in self.controls])
+        self.pulsevals_guess = self.pulsevals.copy()
+        self.gradient = np.zeros(L * N_T)
+        self.grad_J_Tb = np.zeros(L * N_T)
+        self.grad_J_a = np.zeros(L * N_T)
+        self.J_parts = np.zeros(3)
+        self.fg_count = [0, 0]
+        lo = self.kwargs.get("lower_bound", -np.inf)
+        hi = self.kwargs.get("upper_bound", np.inf)
+        self.lower_bounds = np.full(L * N_T, lo, dtype=np.float64)
+        self.upper_bounds = np.full(L * N_T, hi, dtype=np.float64)
+        pb = self.kwargs.get("pulse_options", None)
+        if pb:  # per-control bounds, written control-major (the reference interleaves: SURVEY.md 8f N1)
+            for l, c in enumerate(self.controls):
+                for key, arr in (("lower_bound", self.lower_bounds), ("upper_bound", self.upper_bounds)):
+                    opt = next((v for k, v in pb if k is c), {})
+                    if key in opt:
+                        arr[l * N_T:(l + 1) * N_T] = opt[key]
+        self.result = GrapeResult(tlist=self.tlist.copy(), iter_start=self.kwargs.get("iter_start", 0),
+                                  iter_stop=self.kwargs.get("iter_stop", 5000))
+        self.result.iter = self.result.iter_start
+        self.result.tau_vals = np.zeros(K, dtype=np.complex128)
+        self.result.guess_controls = [discretize(self.pulsevals[l * N_T:(l + 1) * N_T], self.tlist) for l in range(L)]
+        self.result.optimized_controls = [g.copy() for g in self.result.guess_controls]
+        self.result.states = [np.zeros_like(t.initial_state, dtype=np.complex128) for t in self.trajectories]
+        self.result.start_local_time = self.result.end_local_time = time.time()
+        self.backend = backend if backend is not None else self._make_hip_backend()
+
+    def _make_hip_backend(self):
+        J_T = self.kwargs["J_T"]
+        if J_T not in _FUNCTIONAL_CODE:
+            raise ValueError("the HIP backend implements J_T_sm, J_T_ss and J_T_re")
+        trajs = self.trajectories
+        H0 = np.stack([t.generator.drift for t in trajs])
+        per_traj = []
+        for t in trajs:
+            ops = []
+            for c in self.controls:
+                op = [o for o, cc in zip(t.generator.ops, t.generator.controls) if cc is c]
+                ops.append(sum(op) if op else np.zeros_like(t.generator.drift))
+            per_traj.append(np.stack(ops))
+        Hc = np.stack(per_traj)
+        if all(np.array_equal(Hc[0], h) for h in Hc[1:]):
+            Hc = Hc[0]
+        method = {"gradgen": api.GRAD_GRADGEN, "taylor": api.GRAD_TAYLOR}.get(
+            self.kwargs.get("gradient_method", "gradgen"))
+        if method is None:
+            raise ValueError(f"Invalid gradient_method={self.kwargs.get('gradient_method')!r} not in (gradgen, taylor)")
+        return api.GrapeHip(H0, Hc, self.tlist, np.stack([t.initial_state for t in trajs]),
+                            np.stack([t.target_state for t in trajs]),
+                            weights=np.array([t.weight for t in trajs], dtype=np.float64),
+                            functional=_FUNCTIONAL_CODE[J_T], gradient_method=method,
+                            chi_min_norm=self.kwargs.get("chi_min_norm", 0.0),
+                            taylor_max_order=self.kwargs.get("taylor_grad_max_order", 0),
+                            taylor_tolerance=self.kwargs.get("taylor_grad_tolerance", 0.0),
+                            device=self.kwargs.get("device", 0))
+
+
+def evaluate_functional(pulsevals, wrk: GrapeWrk, count_call=True):
+    """src/optimize.jl:696-768 (side effects on wrk as documented there)."""
+    if pulsevals is not wrk.pulsevals:
+        wrk.pulsevals[:] = pulsevals
+    if count_call:
+        wrk.result.f_calls += 1
+        wrk.fg_count[1] += 1
+    J, _, tau, psiT = wrk.backend.eval(wrk.pulsevals, gradient=False, want_psiT=True)
+    wrk.result.tau_vals[:] = tau
+    wrk._states = psiT
+    wrk.J_parts[0] = J
+    J_a = wrk.kwargs.get("J_a")
+    if J_a is not None:
+        wrk.J_parts[1] = wrk.kwargs.get("lambda_a", 1.0) * J_a(wrk.pulsevals, wrk.tlist)
+    return float(np.sum(wrk.J_parts))
+
+
+def evaluate_gradient_b(G, pulsevals, wrk: GrapeWrk):
+    """``evaluate_gradient!`` -- src/optimize.jl:824-1014."""
+    if pulsevals is not wrk.pulsevals:
+        wrk.pulsevals[:] = pulsevals
+    wrk.result.fg_calls += 1
+    wrk.fg_count[0] += 1
+    J, g, tau, psiT = wrk.backend.eval(wrk.pulsevals, gradient=True, want_psiT=True)
+    wrk.result.tau_vals[:] = tau
+    wrk._states = psiT
+    wrk.J_parts[0] = J
+    wrk.grad_J_Tb[:] = g
+    G[:] = g
+    J_a = wrk.kwargs.get("J_a")
+    if J_a is not None:
+        lam = wrk.kwargs.get("lambda_a", 1.0)
+        wrk.J_parts[1] = lam * J_a(wrk.pulsevals, wrk.tlist)
+        grad_J_a = wrk.kwargs.get("grad_J_a")
+        if grad_J_a is not None:
+            wrk.grad_J_a[:] = grad_J_a(wrk.pulsevals, wrk.tlist)
+            G += lam * wrk.grad_J_a
+    return float(np.sum(wrk.J_parts))
+
+
+def update_result(wrk: GrapeWrk, i: int):
+    """src/optimize.jl:185-216."""
+    res = wrk.result
+    for k in range(wrk.K):
+        res.states[k] = np.array(wrk._states[k])
+    res.J_T_prev, res.J_T = res.J_T, float(wrk.J_parts[0])
+    res.J_a_prev, res.J_a = res.J_a, float(wrk.J_parts[1])
+    if res.J_a > 0.0:
+        res.J_a /= wrk.kwargs.get("lambda_a", 1.0)
+    if i > 0:
+        res.iter = i
+    if i >= res.iter_stop:
+        res.converged = True
+        res.message = "Reached maximum number of iterations"
+    prev = res.end_local_time
+    res.end_local_time = time.time()
+    res.secs = res.end_local_time - prev
+
+
+def _apply_convergence_check(result, check_convergence):
+    """src/optimize.jl:154-182."""
+    if result.converged:
+        return
+    c = check_convergence(result)
+    if isinstance(c, bool):
+        result.converged = c
+        if c:
+            result.message = "Convergence check returned true"
+    elif isinstance(c, str):
+        if c:
+            result.converged = True
+            result.message = c
+
+
+class _Stop(Exception):
+    pass
+
+
+def optimize(trajectories, tlist, backend=None, **kwargs):
+    """``GRAPE.optimize(trajectories, tlist; kwargs...)`` -- src/optimize.jl:73-144."""
+    from scipy.optimize import minimize
+
+    callback = kwargs.get("callback", lambda *a: None)
+    check_convergence = kwargs.get("check_convergence", lambda res: res)
+    wrk = GrapeWrk(trajectories, tlist, backend=backend, **kwargs)
+    G = np.zeros_like(wrk.pulsevals)
+    state = {"first": True}
+
+    def fg(x):
+        J = evaluate_gradient_b(G, x, wrk)
+        if state["first"]:  # FG_START: iteration 0 (ext/GRAPELBFGSBExt.jl:100-109)
+            state["first"] = False
+            wrk.gradient[:] = G
+            update_result(wrk, 0)
+            info = callback(wrk, 0)
+            wrk.fg_count = [0, 0]
+            if info:
+                wrk.result.records.append(info)
+        return J, G.copy()
+
+    def new_x(xk):  # NEW_X (ext/GRAPELBFGSBExt.jl:110-127)
+        wrk.pulsevals[:] = xk
+        update_result(wrk, wrk.result.iter + 1)
+        info = callback(wrk, wrk.result.iter)
+        wrk.fg_count = [0, 0]
+        if info:
+            wrk.result.records.append(info)
+        _apply_convergence_check(wrk.result, check_convergence)
+        if wrk.result.converged:
+            raise _Stop()
+        wrk.pulsevals_guess[:] = xk
+        wrk.gradient[:] = G
+
+    bounds = None
+    if np.any(np.isfinite(wrk.lower_bounds)) or np.any(np.isfinite(wrk.upper_bounds)):
+        bounds = list(zip(np.where(np.isfinite(wrk.lower_bounds), wrk.lower_bounds, None),
+                          np.where(np.isfinite(wrk.upper_bounds), wrk.upper_bounds, None)))
+    try:
+        res = minimize(fg, wrk.pulsevals.copy(), jac=True, method="L-BFGS-B", bounds=bounds, callback=new_x,
+                       options=dict(maxcor=kwargs.get("lbfgsb_m", 10), ftol=kwargs.get("lbfgsb_factr", 1e1) * 2.2e-16,
+                                    gtol=kwargs.get("lbfgsb_pgtol", 1e-15), maxiter=wrk.result.iter_stop + 1,
+                                    maxfun=10 * (wrk.result.iter_stop + 1) + 100, maxls=50))
+        if wrk.result.message == "in progress":
+            wrk.result.message = str(res.message)
+    except _Stop:
+        pass
+    except Exception as exc:  # src/optimize.jl:125-135
+        if kwargs.get("rethrow_exceptions", False):
+            raise
+        wrk.result.message = f"Exception: {exc}"
+    # finalize_result! (src/optimize.jl:219-228)
+    res_ = wrk.result
+    res_.end_local_time = time.time()
+    for l in range(wrk.L):
+        res_.optimized_controls[l] = discretize(wrk.pulsevals[l * wrk.N_T:(l + 1) * wrk.N_T], res_.tlist)
+    return res_

@@ -1,0 +1,87 @@
+"""Trajectory-sharded evaluation: one process per GPU, ``torch.distributed`` for the two
+cross-trajectory reductions of the path:
+
+1. between the forward and the backward sweep: all-reduce(sum) of the four partial sums
+   ``[Re f, Im f, sum_k w_k |tau_k|^2, Re sum_k w_k tau_k]`` with ``f = sum_k w_k tau_k``
+   (needed by chi_sm, docs/src/tutorial.md:402, and by every J_T);
+2. at the end: all-reduce(sum) of the partial gradient -- the sum over k of
+   ``_grad_J_T_via_chi!`` (/root/reference/src/optimize.jl:579).
+
+With the ``nccl`` backend (RCCL on ROCm) both collectives run on device buffers that alias the
+library's inputs/outputs, on the same HIP stream as the kernels; with ``gloo`` (CPU tests) the
+host-pointer split-phase API is used.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def functional_value(functional, sums, K_total):
+    """J_T from the all-reduced sums [Re f, Im f, sum w|tau|^2, Re sum w tau]."""
+    fr, fi, ss, re = (float(v) for v in sums[:4])
+    if functional == 0:
+        return 1.0 - (fr * fr + fi * fi) / (K_total * K_total)
+    if functional == 1:
+        return 1.0 - ss / K_total
+    return 1.0 - re / K_total
+
+
+def shard_range(K_total, world_size, rank):
+    """Contiguous block of trajectories owned by ``rank`` (k in [g K/G, (g+1) K/G))."""
+    base, rem = divmod(K_total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardedEvaluator:
+    """fg! over a trajectory-sharded ensemble.  ``handle`` exposes the split-phase API of
+    ``GrapeHip`` (forward/backward or forward_device/backward_device) for the LOCAL trajectories
+    and was created with ``K_total`` = size of the whole ensemble."""
+
+    def __init__(self, handle, K_total, functional, weights_local=None, dist=None, device=None):
+        self.h = handle
+        self.K_total = int(K_total)
+        self.functional = functional
+        self.w = weights_local
+        self.dist = dist  # torch.distributed module (initialised) or None for a single process
+        self.device = device  # torch.device for the RCCL path, None for the host (gloo) path
+        self._buf = None
+
+    # -- host path (gloo / single process) ---------------------------------------------------
+    def eval_host(self, pulsevals):
+        import torch
+        tau = self.h.forward(pulsevals)
+        w = np.ones(len(tau)) if self.w is None else np.asarray(self.w)
+        f = np.sum(w * tau)
+        sums = torch.tensor([f.real, f.imag, float(np.sum(w * np.abs(tau) ** 2)), f.real], dtype=torch.float64)
+        if self.dist is not None:
+            self.dist.all_reduce(sums)
+        G = torch.from_numpy(self.h.backward(complex(sums[0].item(), sums[1].item())))
+        if self.dist is not None:
+            self.dist.all_reduce(G)
+        return functional_value(self.functional, sums.tolist(), self.K_total), G.numpy(), tau
+
+    # -- device path (nccl == RCCL) ------------------------------------------------------------
+    def alloc_device(self, L, N_T, K_local):
+        import torch
+        self._x = torch.empty(L * N_T, dtype=torch.float64, device=self.device)
+        self._out = torch.zeros(2 * K_local + 4, dtype=torch.float64, device=self.device)
+        self._G = torch.zeros(L * N_T, dtype=torch.float64, device=self.device)
+        self._K = K_local
+        return self._x, self._out, self._G
+
+    def eval_device(self, stream_ptr):
+        """One evaluation with inputs already resident in ``self._x``; everything stays on the
+        device and on ``stream_ptr``.  Returns nothing (results in self._out / self._G)."""
+        K = self._K
+        self.h.forward_device(self._x.data_ptr(), self._out.data_ptr(), stream_ptr)
+        sums = self._out[2 * K:2 * K + 4]
+        if self.dist is not None:
+            self.dist.all_reduce(sums)
+        self.h.backward_device(sums.data_ptr(), self._G.data_ptr(), stream_ptr)
+        if self.dist is not None:
+            self.dist.all_reduce(self._G)
+
+    def J_device(self):
+        K = self._K
+        return functional_value(self.functional, self._out[2 * K:2 * K + 4].tolist(), self.K_total)

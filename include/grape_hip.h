@@ -138,10 +138,13 @@ int grape_get_propagator(grape_handle *h, int k, int n, double *out);
 int grape_get_tau_grads(grape_handle *h, double *out /* K*L*N_T complex */);
 int grape_get_storage(grape_handle *h, int which /*0 fw, 1 bw*/, double *out /* K*(N_T+1)*N complex */);
 
-/* Per-phase device time of the last grape_eval / forward+backward pair, milliseconds, measured
- * with HIP events on the handle's stream: [0] expm, [1] forward sweep, [2] backward sweep,
- * [3] cell derivatives, [4] reduction, [5] total.  Returns the number of entries written. */
+/* Per-phase device time in milliseconds, measured with HIP events recorded on the stream the
+ * kernels were launched on, AVERAGED over the evaluations since the last grape_reset_timings
+ * (at most the 64 most recent): [0] expm kernel, [1] forward sweep, [2] backward sweep,
+ * [3] cell derivatives, [4] reduction, [5] whole grape_eval.  Synchronises the device.
+ * Returns the number of entries written. */
 int grape_get_timings(grape_handle *h, double *ms, int n);
+int grape_reset_timings(grape_handle *h);
 /* Algorithmic work of the last evaluation: [0] cells, [1] sum of squarings s over cells,
  * [2] flop of the expm kernel (SURVEY 8d F_exp), [3] flop of the derivative kernel. */
 int grape_get_work(grape_handle *h, double *out, int n);

@@ -66,16 +66,18 @@ def hamiltonian(H0k, Hck, eps, scale=None):
     return H
 
 
-def J_T_and_chi(functional, tau, target, weights, K_total=None):
+def J_T_and_chi(functional, tau, target, weights, K_total=None, f_total=None):
     """Final-time functional and boundary states chi_k = -dJ_T/d<Psi_k|.
 
     QuantumControl.Functionals J_T_sm/chi_sm, J_T_ss/chi_ss, J_T_re/chi_re
     (/root/reference/docs/src/tutorial.md:349-356 and :402 for the sm pair).
+    ``K_total`` / ``f_total`` describe a shard of a larger ensemble (tests of the sharded path):
+    the normalisation uses all trajectories and f = sum over ALL trajectories of w_k tau_k.
     """
     K = len(tau) if K_total is None else K_total
     w = np.asarray(weights, dtype=np.float64)
     if functional == FUNCTIONAL_SM:
-        f = np.sum(w * tau)
+        f = np.sum(w * tau) if f_total is None else f_total
         J_T = 1.0 - (abs(f) ** 2) / K**2
         coeff = w * f / K**2
     elif functional == FUNCTIONAL_SS:
@@ -121,7 +123,8 @@ def evaluate_functional(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
 
 def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
                       functional=FUNCTIONAL_SM, gradient_method="gradgen", shape=None,
-                      taylor_max_order=100, taylor_tol=1e-16, return_parts=False):
+                      taylor_max_order=100, taylor_tol=1e-16, return_parts=False,
+                      K_total=None, f_total=None):
     """optimize.jl:824-1014 (without running costs).  Returns (J, G, tau[, parts])."""
     K, N = psi0.shape
     L = _hc_of(Hc, 0).shape[0]
@@ -131,7 +134,7 @@ def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
 
     J_T, tau, storage = evaluate_functional(H0, Hc, tlist, pulsevals, psi0, target, weights,
                                             functional, shape)
-    _, chi = J_T_and_chi(functional, tau, target, weights)  # :848-855
+    _, chi = J_T_and_chi(functional, tau, target, weights, K_total, f_total)  # :848-855
     rho = np.array([np.linalg.norm(chi[k]) for k in range(K)])  # :867
     for k in range(K):
         if rho[k] < CHI_MIN_NORM:  # :1021-1025

@@ -1,0 +1,84 @@
+"""world_size-2 gloo test of the trajectory-sharded path (CPU): the ShardedEvaluator protocol
+(all-reduce of the tau partial sums between the sweeps, all-reduce of the partial gradient) must
+reproduce the single-process result.  The per-shard evaluator is an oracle-backed stand-in with the
+split-phase signature of GrapeHip.forward/backward."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import grape_oracle as go
+from grape_jl_amd import synth
+from grape_jl_amd.sharded import ShardedEvaluator, functional_value, shard_range
+
+
+class OracleShard:
+    def __init__(self, pr, lo, hi, K_total, functional):
+        self.pr, self.lo, self.hi, self.K_total, self.functional = pr, lo, hi, K_total, functional
+
+    def _args(self):
+        p = self.pr
+        sl = slice(self.lo, self.hi)
+        return p["H0"][sl], p["Hc"], p["tlist"]
+
+    def forward(self, x):
+        p, sl = self.pr, slice(self.lo, self.hi)
+        self.x = np.array(x)
+        _, tau, _ = go.evaluate_functional(*self._args(), x, p["psi0"][sl], p["target"][sl], p["weights"][sl])
+        return tau
+
+    def backward(self, f_total):
+        p, sl = self.pr, slice(self.lo, self.hi)
+        _, G, _ = go.evaluate_gradient(*self._args(), self.x, p["psi0"][sl], p["target"][sl], p["weights"][sl],
+                                       functional=self.functional, K_total=self.K_total, f_total=f_total)
+        return G
+
+
+def _worker(rank, world, port, functional, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pr = synth.make_problem(6, 2, 5, 5, seed=42)
+    pr["weights"] = np.array([0.5, 1.0, 1.5, 2.0, 0.25])
+    lo, hi = shard_range(5, world, rank)
+    ev = ShardedEvaluator(OracleShard(pr, lo, hi, 5, functional), 5, functional,
+                          weights_local=pr["weights"][lo:hi], dist=dist)
+    J, G, tau = ev.eval_host(pr["pulsevals"])
+    if rank == 0:
+        q.put((J, G, lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("functional", [0, 1, 2])
+def test_two_rank_gloo_matches_single_process(functional):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, functional, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    J, G, lo, hi = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    pr = synth.make_problem(6, 2, 5, 5, seed=42)
+    pr["weights"] = np.array([0.5, 1.0, 1.5, 2.0, 0.25])
+    Jr, Gr, _ = go.evaluate_gradient(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                                     pr["weights"], functional=functional)
+    assert (lo, hi) == (0, 3)
+    assert abs(J - Jr) < 1e-14 and np.abs(G - Gr).max() < 1e-14
+
+
+def test_shard_range_and_functional_value():
+    assert [shard_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert abs(functional_value(0, [3.0, 4.0, 0, 0], 10) - 0.75) < 1e-15
+    assert abs(functional_value(1, [0, 0, 2.0, 0], 4) - 0.5) < 1e-15
+    assert abs(functional_value(2, [0, 0, 0, 1.0], 4) - 0.75) < 1e-15
+    _ = torch

@@ -1,0 +1,138 @@
+"""Pins the oracle (numpy literal restatement + C restatement) -- CPU only.
+
+The reference has no numeric golden vectors and cannot run here: the oracle is
+pinned against closed forms, finite differences, the reference's own cross-route bar
+(test/test_tls_optimization.jl:229: |J_taylor - J_gradgen| < 1e-10) and the in-test oracle of
+test/test_taylor_grad.jl:33-48 (commutator series, tolerance 1e-14)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+from scipy.linalg import expm, expm_frechet
+
+import grape_oracle as go
+from grape_jl_amd import synth
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _pr(z):
+    return dict(H0=z["H0"], Hc=z["Hc"], tlist=z["tlist"], pulsevals=z["pulsevals"], psi0=z["psi0"],
+                target=z["target"], weights=z["weights"])
+
+
+def test_readme_closed_form():
+    pr = synth.readme_tls()
+    J, G, tau = go.evaluate_gradient(**{k: pr[k] for k in ("H0", "Hc", "tlist", "pulsevals", "psi0", "target")})
+    # BASELINE.md section 6
+    assert abs(J - (1 - (0.04 / 1.04) * np.sin(5 * np.sqrt(1.04)) ** 2)) < 1e-14
+    assert abs(tau[0] - 0.1816397911050796j) < 1e-14
+    assert abs(G[0] - 1.3367344501042e-3) < 1e-14 and abs(G[499] - 1.3367344501042e-3) < 1e-14
+    assert abs(G[249] - 3.5455160183374e-3) < 1e-14
+    assert abs(np.linalg.norm(G) - 5.30029505851244e-2) < 1e-14
+    assert np.abs(G - G[::-1]).max() < 1e-13  # symmetry for a constant pulse
+
+
+@pytest.mark.parametrize("functional", [0, 1, 2])
+def test_finite_differences(functional):
+    pr = synth.make_problem(6, 2, 5, 3, seed=7, hermitian=False)
+    pr["weights"] = np.array([0.5, 1.0, 1.5])
+    args = (pr["H0"], pr["Hc"], pr["tlist"])
+    J, G, _ = go.evaluate_gradient(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], functional)
+    h = 1e-6
+    for idx in (0, 3, 7, 9):
+        xp, xm = pr["pulsevals"].copy(), pr["pulsevals"].copy()
+        xp[idx] += h
+        xm[idx] -= h
+        Jp = go.evaluate_functional(*args, xp, pr["psi0"], pr["target"], pr["weights"], functional)[0]
+        Jm = go.evaluate_functional(*args, xm, pr["psi0"], pr["target"], pr["weights"], functional)[0]
+        assert abs((Jp - Jm) / (2 * h) - G[idx]) < 2e-9
+
+
+def test_gradgen_equals_taylor_equals_frechet():
+    pr = synth.make_problem(12, 2, 6, 2, seed=3)
+    a = go.evaluate_gradient(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                             gradient_method="gradgen", return_parts=True)
+    b = go.evaluate_gradient(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                             gradient_method="taylor")
+    assert abs(a[0] - b[0]) < 1e-10 and np.abs(a[1] - b[1]).max() < 1e-13  # reference bar: 1e-10
+    # independent route: Frechet derivative of the N x N exponential
+    parts = a[3]
+    k, n, l = 1, 2, 0
+    eps = pr["pulsevals"].reshape(2, -1)[:, n]
+    H = go.hamiltonian(pr["H0"][k], pr["Hc"], eps)
+    dt = pr["tlist"][n + 1] - pr["tlist"][n]
+    Lf = expm_frechet(-1j * H * dt, -1j * pr["Hc"][l] * dt, compute_expm=False)
+    g = parts["rho"][k] * np.vdot(parts["chi"][k, n + 1], Lf @ parts["storage"][k, n])
+    assert abs(g - parts["tau_grads"][k, n, l]) < 1e-14
+
+
+def test_taylor_grad_step_vs_commutator_series():
+    # mirrors /root/reference/test/test_taylor_grad.jl:13-71 (non-Hermitian N=10, dt = +-1.25)
+    rng = np.random.default_rng(20)
+    N = 10
+    H = (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))) / np.sqrt(N)
+    mu = (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))) / np.sqrt(N)
+    psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi /= np.linalg.norm(psi)
+    for dt in (1.25, -1.25):
+        ref = go.U_grad_commutator_series(H, mu, dt) @ psi
+        got = go.taylor_grad_step(psi, H, mu, dt)
+        assert np.linalg.norm(ref - got) < 1e-13
+        assert np.linalg.norm(expm_frechet(-1j * H * dt, -1j * mu * dt, compute_expm=False) @ psi - got) < 1e-13
+
+
+def test_c_expm_all_branches(ref):
+    rng = np.random.default_rng(1)
+    for n, scale, order in [(5, 0.001, 3), (8, 0.1, 5), (10, 0.5, 7), (16, 1.5, 9), (16, 4.0, 13), (24, 30.0, 13)]:
+        A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        A = A / np.abs(A).sum(0).max() * scale
+        E, o, s = ref.expm(A)
+        assert o == order
+        assert s == max(0, int(np.ceil(np.log2(scale / 5.4)))) if scale > 2.1 else s == 0
+        R = expm(A)
+        assert np.abs(E - R).max() / np.abs(R).max() < 5e-15
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_vs_c_oracle(ref, path):
+    z = np.load(path)
+    pr = _pr(z)
+    f = int(z["functional"])
+    for method in (ref.GRADGEN, ref.TAYLOR):
+        J, G, tau, parts = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                                        pr["weights"], functional=f, gradient_method=method, want_parts=True)
+        assert abs(J - z["J"]) < 1e-13
+        assert np.abs(tau - z["tau"]).max() < 1e-13
+        assert np.abs(G - z["G"]).max() < 1e-12 * max(1.0, np.abs(z["G"]).max())
+        assert np.abs(parts["tau_grads"] - z["tau_grads"]).max() < 1e-13
+        assert np.abs(parts["psiT"] - z["psiT"]).max() < 1e-13
+    if "J_closed_form" in z:
+        assert abs(z["J"] - z["J_closed_form"]) < 1e-14
+
+
+def test_chi_norm_guard(ref):
+    # target orthogonal to everything reachable: tau = 0 -> chi_sm = 0 -> error (optimize.jl:1021-1025)
+    H0 = np.zeros((1, 2, 2), complex)
+    Hc = np.zeros((1, 2, 2), complex)
+    psi0 = np.array([[1, 0]], complex)
+    tgt = np.array([[0, 1]], complex)
+    with pytest.raises(ValueError):
+        go.evaluate_gradient(H0, Hc, np.array([0., 1.]), np.array([0.3]), psi0, tgt)
+    with pytest.raises(RuntimeError):
+        ref.evaluate(H0, Hc, np.array([0., 1.]), np.array([0.3]), psi0, tgt)
+
+
+def test_synth_deterministic():
+    a = synth.make_config("C2", K=2)
+    b = synth.make_config("C2", K=2)
+    assert np.array_equal(a["H0"], b["H0"]) and np.array_equal(a["pulsevals"], b["pulsevals"])
+    # shards regenerate exactly their own members
+    full = synth.make_problem(8, 1, 4, 4, seed=5)
+    sh = synth.make_problem(8, 1, 4, 2, seed=5, k_offset=2)
+    assert np.array_equal(full["H0"][2:], sh["H0"]) and np.array_equal(full["psi0"][2:], sh["psi0"])
+    assert np.allclose(np.linalg.norm(a["psi0"], axis=1), 1.0)
+    assert np.abs(a["H0"][0] - a["H0"][0].conj().T).max() < 1e-15
+    # spectral radius ~ 1 for the GUE scaling of SURVEY.md 8d
+    assert 0.6 < np.abs(np.linalg.eigvalsh(synth.gue(3, 64))).max() < 1.4
