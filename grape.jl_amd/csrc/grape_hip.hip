@@ -96,9 +96,18 @@ hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s) {
 
 template <int NP>
 hipError_t launch_deriv(const DerivArgs &a, int nblocks, hipStream_t s) {
-    if (a.L <= 2) hipLaunchKernelGGL((deriv_kernel<NP, 2>), dim3(nblocks), dim3(256), 0, s, a);
-    else if (a.L <= 4) hipLaunchKernelGGL((deriv_kernel<NP, 4>), dim3(nblocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((deriv_kernel<NP, 8>), dim3(nblocks), dim3(256), 0, s, a);
+    // 512 threads (8 column chunks per row) at N = 64: half the register tile per thread, so that
+    // two blocks (4 waves per SIMD) hide the LDS broadcast latency; 256 threads otherwise.
+    constexpr int NTH = NP == 64 ? 512 : 256;
+    // the series kernel is instantiated per control count: zero-padded controls would cost real FMAs
+    switch (a.L) {
+        case 1: hipLaunchKernelGGL((deriv_kernel<NP, 1, NTH>), dim3(nblocks), dim3(NTH), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((deriv_kernel<NP, 2, NTH>), dim3(nblocks), dim3(NTH), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((deriv_kernel<NP, 3, NTH>), dim3(nblocks), dim3(NTH), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((deriv_kernel<NP, 4, NTH>), dim3(nblocks), dim3(NTH), 0, s, a); break;
+        case 5: case 6: hipLaunchKernelGGL((deriv_kernel<NP, 6, NTH>), dim3(nblocks), dim3(NTH), 0, s, a); break;
+        default: hipLaunchKernelGGL((deriv_kernel<NP, 8, NTH>), dim3(nblocks), dim3(NTH), 0, s, a); break;
+    }
     return hipGetLastError();
 }
 
@@ -277,6 +286,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     ea.H0f = h->d_H0f; ea.Hcf = h->d_Hcf; ea.eps = h->d_eps; ea.shape = h->d_shape; ea.dts = h->d_dts;
     ea.U = h->d_U; ea.flags = h->d_flags; ea.stats = h->d_stats;
     ea.K = h->K; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
+#ifdef GRAPE_DIAG
+    ea.ablate = getenv("GRAPE_DIAG_ABLATE") ? atoi(getenv("GRAPE_DIAG_ABLATE")) : 0;
+#endif
     phase_begin(h, 0, s);
     hipError_t e;
     switch (h->NT) {

@@ -51,6 +51,9 @@ struct ExpmArgs {
     int *flags;          // [0] error flag (|=), [1] max squarings
     unsigned long long *stats; // [0] sum of squarings, [3..7] #cells with Pade order 3/5/7/9/13
     int K, L, N_T, hc_per_traj;
+#ifdef GRAPE_DIAG
+    int ablate;  // diagnostic builds only (tools/ablate.py): bit0 skip invert16, bit1 skip solve, bit2 skip GEMMs
+#endif
 };
 
 // A column strip of an NP x NP complex matrix held by one wave in MFMA C/D layout:
@@ -195,46 +198,47 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 // lane (i = lane&15, g = lane>>4), register c  <->  D[i][4*c + g]
 // (so register c is directly the MFMA A operand of k-step c).  No pivoting: the Pade
 // denominator q(A) = b0*exp(-A/2)(1+O(u)) has a positive definite Hermitian part for the
-// propagators this path is used for; the smallest relative pivot is returned so that the
-// caller can flag numerically unsafe eliminations instead of returning garbage.
-__device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int lane) {
+// propagators this path is used for; the smallest |pivot|^2 relative to b0^2 (inv_scale2 = 1/b0^2)
+// is returned so that the caller can flag numerically unsafe eliminations instead of returning
+// garbage.
+__device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int lane, double inv_scale2) {
     const int i = lane & 15, g = lane >> 4;
     double minrel = 1e300;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int kg = k & 3, kc = k >> 2;
-        const double pr = readlane_f64(ar[kc], 16 * kg + k);
+        // everything this step needs from other lanes is requested first (old values of step k-1)
+        const double pr = readlane_f64(ar[kc], 16 * kg + k);   // pivot D[k][k]
         const double pi = readlane_f64(ai[kc], 16 * kg + k);
-        const double den = pr * pr + pi * pi;
-        const double inv = 1.0 / den;
-        const double qr = pr * inv, qi = -pi * inv;  // 1/pivot
-        // my row's multiplier m = D[i][k] (lives in lane (i, kg), register kc)
-        const double mr = __shfl(ar[kc], 16 * kg + i, 64);
+        const double mr = __shfl(ar[kc], 16 * kg + i, 64);      // my row's multiplier D[i][k]
         const double mi = __shfl(ai[kc], 16 * kg + i, 64);
-        // scale reference: largest |entry| of the pivot row decides "relative" size
-        double rowmax = 0.0;
+        double xr[4], xi[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                           // pivot row entry of my column 4c+g
+            xr[c] = __shfl(ar[c], 16 * g + k, 64);
+            xi[c] = __shfl(ai[c], 16 * g + k, 64);
+        }
+        // 1/pivot: v_rcp_f64 seed + two Newton steps (full fp64 accuracy, no IEEE division sequence)
+        const double den = pr * pr + pi * pi;
+        double inv = __builtin_amdgcn_rcp(den);
+        inv = inv * fma(-den, inv, 2.0);
+        inv = inv * fma(-den, inv, 2.0);
+        const double qr = pr * inv, qi = -pi * inv;
+        minrel = fmin(minrel, den * inv_scale2);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            // pivot row entry of my column 4c+g: lives in lane (k, g), register c
-            double xr = __shfl(ar[c], 16 * g + k, 64);
-            double xi = __shfl(ai[c], 16 * g + k, 64);
-            rowmax = fmax(rowmax, xr * xr + xi * xi);
             const bool pivcol = (c == kc) && (g == kg);
             // scaled pivot row p' = x / pivot  (p'_k = 1/pivot)
-            double sr = pivcol ? qr : (xr * qr - xi * qi);
-            double si = pivcol ? qi : (xr * qi + xi * qr);
+            const double sr = pivcol ? qr : fma(xr[c], qr, -xi[c] * qi);
+            const double si = pivcol ? qi : fma(xr[c], qi, xi[c] * qr);
             // rows i != k: a = (pivcol ? 0 : a) - m * p' ; row k: a = p'
-            double br = pivcol ? 0.0 : ar[c];
-            double bi = pivcol ? 0.0 : ai[c];
-            double nr = br - (mr * sr - mi * si);
-            double ni = bi - (mr * si + mi * sr);
+            const double br = pivcol ? 0.0 : ar[c];
+            const double bi = pivcol ? 0.0 : ai[c];
+            const double nr = fma(-mr, sr, fma(mi, si, br));
+            const double ni = fma(-mr, si, fma(-mi, sr, bi));
             ar[c] = (i == k) ? sr : nr;
             ai[c] = (i == k) ? si : ni;
         }
-        // rowmax over the 4 lane groups of the pivot row
-        rowmax = fmax(rowmax, __shfl_xor(rowmax, 16, 64));
-        rowmax = fmax(rowmax, __shfl_xor(rowmax, 32, 64));
-        minrel = fmin(minrel, den / fmax(rowmax, 1e-300));
     }
     return minrel;
 }
@@ -245,9 +249,17 @@ __device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int
 //     Y      = Dinv * S[jb]             (16x16x16)
 //     S[tr] -= Panel[tr] * Y  (tr != jb),   S[jb] = Y
 // After NT steps Q == I and P == X.  LDS use: panel planes [NP][18] at Pre/Pim, Dinv at Dv.
+#ifdef GRAPE_DIAG
+__device__ int g_ablate_dummy;
+#define g_ablate ablate_flag
+#endif
 template <int NT>
 __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, double *Pre, double *Pim,
-                                               double *Dv, int wave, int lane, double &minrel) {
+                                               double *Dv, int wave, int lane, double &minrel, double inv_scale2
+#ifdef GRAPE_DIAG
+                                               , int ablate_flag
+#endif
+                                               ) {
     constexpr int NP = 16 * NT, PLD = 18;
     const int ai = lane & 15, ak = lane >> 4;
 #pragma unroll
@@ -272,7 +284,12 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
                 dr[c] = Pre[(16 * jb + ai) * PLD + 4 * c + ak];
                 di[c] = Pim[(16 * jb + ai) * PLD + 4 * c + ak];
             }
-            double mr = invert16(dr, di, lane);
+#ifdef GRAPE_DIAG
+            double mr = 1.0;
+            if (!(g_ablate & 1)) mr = invert16(dr, di, lane, inv_scale2);
+#else
+            double mr = invert16(dr, di, lane, inv_scale2);
+#endif
             minrel = fmin(minrel, mr);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -413,8 +430,10 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
 
     Strip<NT> Pn, Qn;  // numerator P = V+U, denominator Q = V-U
     int order;
+    double inv_b0sq;  // 1 / b0^2 of the Pade order in use: scale of the pivots of q(A) ~ b0 exp(-A/2)
     if (nA > 2.1) {
         order = 13;
+        inv_b0sq = 1.0 / (B13_0 * B13_0);
         Strip<NT> A2, A4, A6;
         {
             Strip<NT> As;
@@ -460,6 +479,7 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
         else if (nA > 0.25) { c = c_pade7; order = 7; }
         else if (nA > 0.015) { c = c_pade5; order = 5; }
         else { c = c_pade3; order = 3; }
+        inv_b0sq = 1.0 / (c[0] * c[0]);
         Strip<NT> Pk, Ui, V;
         {
             Strip<NT> As;
@@ -507,7 +527,11 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
 
     // ---- solve (V-U) X = (V+U): block Gauss-Jordan on MFMA; LDS X region doubles as panel ----
     double minrel = 1e300;
-    block_gj_solve<NT>(Qn, Pn, Xre, Xre + NP * 18, Dv, wave, lane, minrel);
+#ifdef GRAPE_DIAG
+    if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, Xre, Xre + NP * 18, Dv, wave, lane, minrel, inv_b0sq, a.ablate);
+#else
+    block_gj_solve<NT>(Qn, Pn, Xre, Xre + NP * 18, Dv, wave, lane, minrel, inv_b0sq);
+#endif
 
     // ---- squarings ----
     for (int it = 0; it < s; ++it) {
@@ -535,7 +559,7 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     // ---- bookkeeping ----
     if (lane == 0 && wave < NT) {
         // min over waves that inverted a diagonal tile
-        if (!(minrel > 1e-24)) atomicOr(&a.flags[0], 1);  // numerically singular denominator
+        if (!(minrel > 1e-20)) atomicOr(&a.flags[0], 1);  // |pivot| < 1e-10 b0: numerically singular denominator
     }
     if (tid == 0) {
         atomicAdd(&a.stats[0], (unsigned long long)s);
@@ -569,6 +593,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// one reduce-scatter step of the forward sweep: lanes l and l^OFF split 2H row sums between them
+template <int H, int OFF, int RWT>
+__device__ __forceinline__ void rs_step(double (&pr)[RWT], double (&pi)[RWT], int lane, int &row) {
+    const bool up = (lane & OFF) != 0;  // upper lanes keep the upper half of the rows
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+        const double sr = up ? pr[r] : pr[r + H], si = up ? pi[r] : pi[r + H];
+        const double kr = up ? pr[r + H] : pr[r], ki = up ? pi[r + H] : pi[r];
+        pr[r] = kr + __shfl_xor(sr, OFF, 64);
+        pi[r] = ki + __shfl_xor(si, OFF, 64);
+    }
+    row += up ? H : 0;
 }
 
 template <int NP, bool BACKWARD>
@@ -621,24 +659,49 @@ __global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
     __syncthreads();
 
     int cur = 0;
+    // software prefetch: the U tile of the NEXT step is requested before the current one is consumed
+    // (the recurrence only couples the steps through the state, never through U)
+    double2 unext[RW];
+    {
+        const double2 *U0 = Uk + (size_t)(BACKWARD ? a.N_T - 1 : 0) * NP * NP;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            unext[r] = lane < NP ? U0[(size_t)(wave * RW + r) * NP + lane] : make_double2(0., 0.);
+    }
     for (int step = 0; step < a.N_T; ++step) {
         const int n = BACKWARD ? a.N_T - 1 - step : step;
-        const double2 *Un = Uk + (size_t)n * NP * NP;
-        if (!BACKWARD) {
-            // y_i = sum_j U[i][j] x_j : lane j, rows of this wave; reduce across lanes
-            const double2 xv = lane < NP ? x[cur][lane] : make_double2(0., 0.);
-            double2 u[RW];
+        double2 ucur[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) ucur[r] = unext[r];
+        if (step + 1 < a.N_T) {
+            const double2 *Un1 = Uk + (size_t)(BACKWARD ? n - 1 : n + 1) * NP * NP;
 #pragma unroll
             for (int r = 0; r < RW; ++r)
-                u[r] = lane < NP ? Un[(size_t)(wave * RW + r) * NP + lane] : make_double2(0., 0.);
+                unext[r] = lane < NP ? Un1[(size_t)(wave * RW + r) * NP + lane] : make_double2(0., 0.);
+        }
+        if (!BACKWARD) {
+            // y_i = sum_j U[i][j] x_j : lane j holds the products of this wave's RW rows; the sums over
+            // lanes are a wavefront reduce-scatter (RW values -> 1 value per lane, then a 64/RW-lane sum)
+            const double2 xv = lane < NP ? x[cur][lane] : make_double2(0., 0.);
+            double pr[RW], pi[RW];
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
-                double pr = u[r].x * xv.x - u[r].y * xv.y;
-                double pi = u[r].x * xv.y + u[r].y * xv.x;
-                pr = wave_sum(pr);
-                pi = wave_sum(pi);
-                if (lane == 0) x[cur ^ 1][wave * RW + r] = make_double2(pr, pi);
+                const double2 u = ucur[r];
+                pr[r] = u.x * xv.x - u.y * xv.y;
+                pi[r] = u.x * xv.y + u.y * xv.x;
             }
+            int row = 0;
+            rs_step<RW / 2, 32>(pr, pi, lane, row);
+            if constexpr (RW >= 4) rs_step<RW / 4, 16>(pr, pi, lane, row);
+            if constexpr (RW >= 8) rs_step<RW / 8, 8>(pr, pi, lane, row);
+            if constexpr (RW >= 16) rs_step<RW / 16, 4>(pr, pi, lane, row);
+            // lanes that share `row` differ in the low log2(64/RW) bits
+#pragma unroll
+            for (int off = 32 / RW; off >= 1; off >>= 1) {
+                pr[0] += __shfl_xor(pr[0], off, 64);
+                pi[0] += __shfl_xor(pi[0], off, 64);
+            }
+            if ((lane & (64 / RW - 1)) == 0) x[cur ^ 1][wave * RW + row] = make_double2(pr[0], pi[0]);
             __syncthreads();
             if (tid < NP) st[(size_t)(n + 1) * NP + tid] = x[cur ^ 1][tid];
         } else {
@@ -647,7 +710,7 @@ __global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
                 const int i = wave * RW + r;
-                const double2 u = lane < NP ? Un[(size_t)i * NP + lane] : make_double2(0., 0.);
+                const double2 u = ucur[r];
                 const double2 xi = x[cur][i];
                 ar += u.x * xi.x + u.y * xi.y;
                 ai += u.x * xi.y - u.y * xi.x;
@@ -719,35 +782,68 @@ struct DerivArgs {
     double tol;
 };
 
-template <int NP, int LMAX>
-__global__ void __launch_bounds__(256) deriv_kernel(DerivArgs a) {
-    constexpr int NCH = 256 / NP;      // column chunks per row (64 -> 4, 32 -> 8, 16 -> 16)
-    constexpr int CW = NP / NCH;       // columns per thread   (64 -> 16, 32 -> 4, 16 -> 1)
-    constexpr int NV = 1 + LMAX;       // vectors: pw, phi_1..phi_L
-    __shared__ double2 vec[NV][NP];        // pw = Hd^(m-1) chi, phi_l of the previous order
-    __shared__ double2 part[NCH][NV][NP];  // partial products of this order
-    __shared__ double2 psi_s[NP];
-    __shared__ int s_done;
+// ---- wavefront-level reductions on DPP (no LDS traffic) ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+#define DPP_QUAD_XOR1 0xB1       // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E       // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+
+// sum over aligned groups of G adjacent lanes (G = 1, 2, 4, 8, 16); every lane of the group gets the sum
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    if (G >= 2) v += dpp_f64<DPP_QUAD_XOR1>(v);
+    if (G >= 4) v += dpp_f64<DPP_QUAD_XOR2>(v);
+    if (G >= 8) v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    if (G >= 16) v += dpp_f64<DPP_ROW_MIRROR>(v);
+    return v;
+}
+// sum over all 64 lanes, result uniform (4 row sums combined through SGPRs)
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = group_sum<16>(v);
+    return readlane_f64(v, 0) + readlane_f64(v, 16) + readlane_f64(v, 32) + readlane_f64(v, 48);
+}
+
+template <int NP, int LMAX, int NTH>
+__global__ void __launch_bounds__(NTH) deriv_kernel(DerivArgs a) {
+    constexpr int NCH = NTH / NP;      // column chunks per row = adjacent lanes (<= 16)
+    constexpr int CW = NP / NCH;       // columns per thread
+    constexpr int NV = 1 + LMAX;       // vectors: pw = Hd^(m-1) chi, phi_1..phi_L
+    constexpr int NW = NTH / 64;       // waves per block
+    constexpr int PAD = CW > 1 ? 1 : 0;  // one double2 of padding per chunk: the NCH broadcast reads of a
+    constexpr int VLEN = NP + NCH * PAD; // wave-instruction then fall on different LDS banks
+    static_assert(NCH <= 16 && NCH * CW == NP, "row chunks must be adjacent lanes of one DPP row");
+    __shared__ double2 vec[2][NV][VLEN];   // ping-pong over series orders
+    __shared__ double red[2][NW][LMAX];    // per wave: ||phi_l||^2 of its rows
+    __shared__ double2 gsum[NW][LMAX];     // per wave: final <chi'_l | psi> of its rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = tid % NP, q = tid / NP;  // row, column chunk
+    const int q = tid % NCH, i = tid / NCH;  // column chunk, row
     const int L = a.L;
     const int nblk_per_k = (a.N_T + a.cells_per_block - 1) / a.cells_per_block;
     const int k = blockIdx.x / nblk_per_k;
     const int n0 = (blockIdx.x - k * nblk_per_k) * a.cells_per_block;
     const int n1 = min(a.N_T, n0 + a.cells_per_block);
-    const bool valid = lane < NP;
+    const int vi = i + (i / CW) * PAD;       // LDS index of row i
+    const int vq = q * (CW + PAD);           // LDS index of this thread's first column
 
-    // register tiles: H0^dagger[i][q*CW + c], mu_l^dagger[i][q*CW + c]
-    double h0r[CW], h0i[CW], mur[LMAX][CW], mui[LMAX][CW];
+    // register tiles (coalesced: the chunks of a row are adjacent lanes):
+    //   hr/hi  = Hd[i][q*CW + c] = (H0_k + sum_l e_l mu_l)^dagger, updated incrementally from cell to cell
+    //   mur/mui = mu_l^dagger[i][q*CW + c]
+    double hr[CW], hi[CW], mur[LMAX][CW], mui[LMAX][CW];
     {
         const double *h0 = a.H0t + (size_t)k * 2 * NP * NP;
         const double *hc = a.Hct + (size_t)(a.hc_per_traj ? k : 0) * L * 2 * NP * NP;
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             const int idx = i * NP + q * CW + c;
-            h0r[c] = h0[idx];
-            h0i[c] = -h0[NP * NP + idx];
+            hr[c] = h0[idx];
+            hi[c] = -h0[NP * NP + idx];
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {
                 mur[l][c] = l < L ? hc[(size_t)l * 2 * NP * NP + idx] : 0.;
@@ -757,90 +853,104 @@ __global__ void __launch_bounds__(256) deriv_kernel(DerivArgs a) {
     }
     const double rho = a.rho[k];
     const int all_done = (1 << L) - 1;
+    double eprev[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) eprev[l] = 0.;
 
     for (int n = n0; n < n1; ++n) {
         const double dt = a.dts[n];
-        double e[LMAX], sh[LMAX];
+        double sh[LMAX];
+        // Hd_n = Hd_{n-1} + sum_l (e_nl - e_{n-1,l}) mu_l^dagger   (first cell of the block: e_{n-1} = 0)
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             sh[l] = (l < L && a.shape) ? a.shape[(size_t)l * a.N_T + n] : 1.0;
-            e[l] = l < L ? a.eps[(size_t)l * a.N_T + n] * sh[l] : 0.;
-        }
-        // Hd = H0^dagger + sum_l e_l mu_l^dagger  (this thread's tile)
-        double hr[CW], hi[CW];
-#pragma unroll
-        for (int c = 0; c < CW; ++c) {
-            hr[c] = h0r[c];
-            hi[c] = h0i[c];
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) { hr[c] += e[l] * mur[l][c]; hi[c] += e[l] * mui[l][c]; }
-        }
-        __syncthreads();  // previous cell done with vec/psi_s/s_done
-        if (tid < NP) {
-            vec[0][tid] = a.bw[((size_t)k * (a.N_T + 1) + n + 1) * NP + tid];  // chi_k(t_n)
-            psi_s[tid] = a.fw[((size_t)k * (a.N_T + 1) + n) * NP + tid];      // Psi_k(t_{n-1})
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) vec[1 + l][tid] = make_double2(0., 0.);
-        }
-        if (tid == 0) s_done = 0;
-        __syncthreads();
-        // series of exp(-i G dtb) on the extended vector, dtb = -dt: alpha_m = (i dt)^m / m!
-        double accr[LMAX], acci[LMAX];  // sum_m conj(alpha_m) <phi_m^l | psi>, valid in the owner wave
-#pragma unroll
-        for (int l = 0; l < LMAX; ++l) { accr[l] = 0.; acci[l] = 0.; }
-        double alr = 0., ali = dt;  // alpha_1 = i dt
-        int done_mask = 0, converged = 0, m_used = a.max_order;
-        for (int m = 1; m <= a.max_order; ++m) {
-            // ---- partial products over this thread's columns ----
-            double pr = 0., pi = 0., gr[LMAX], gi[LMAX];
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) { gr[l] = 0.; gi[l] = 0.; }
+            const double e = l < L ? a.eps[(size_t)l * a.N_T + n] * sh[l] : 0.;
+            const double de = e - eprev[l];
+            eprev[l] = e;
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
-                const double2 x0 = vec[0][q * CW + c];
-                pr += hr[c] * x0.x - hi[c] * x0.y;  // Hd * pw
-                pi += hr[c] * x0.y + hi[c] * x0.x;
+                hr[c] = fma(de, mur[l][c], hr[c]);
+                hi[c] = fma(de, mui[l][c], hi[c]);
+            }
+        }
+        // row owner (q == 0) keeps Psi_k(t_{n-1})[i]; chi_k(t_n) becomes pw of order 0
+        double2 psi = make_double2(0., 0.);
+        __syncthreads();  // previous cell is done with vec[*] / gsum
+        if (q == 0) {
+            psi = a.fw[((size_t)k * (a.N_T + 1) + n) * NP + i];
+            vec[0][0][vi] = a.bw[((size_t)k * (a.N_T + 1) + n + 1) * NP + i];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) vec[0][1 + l][vi] = make_double2(0., 0.);
+        }
+        __syncthreads();
+        // series of exp(-i G dtb) on the extended vector, dtb = -dt: alpha_m = (i dt)^m / m!
+        // row owners accumulate chi'_l[i] = sum_m alpha_m phi_m^l[i]  (the accumulation of taylor_grad_step!)
+        double outr[LMAX], outi[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { outr[l] = 0.; outi[l] = 0.; }
+        double alr = 0., ali = dt;  // alpha_1 = i dt
+        int done_mask = 0, converged = 0, m_used = a.max_order, cur = 0;
+        for (int m = 1; m <= a.max_order; ++m) {
+            // ---- this thread's partial products over its CW columns ----
+            double pr = 0., pi = 0., gr[LMAX], gi[LMAX], ur[LMAX], ui[LMAX];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) { gr[l] = 0.; gi[l] = 0.; ur[l] = 0.; ui[l] = 0.; }
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const double2 x0 = vec[cur][0][vq + c];
+                pr = fma(hr[c], x0.x, pr);   // Hd * pw
+                pr = fma(-hi[c], x0.y, pr);
+                pi = fma(hr[c], x0.y, pi);
+                pi = fma(hi[c], x0.x, pi);
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) {
-                    const double2 xl = vec[1 + l][q * CW + c];
-                    // phi_l(new) = S_l mu_l^d pw + Hd phi_l
-                    gr[l] += sh[l] * (mur[l][c] * x0.x - mui[l][c] * x0.y) + hr[c] * xl.x - hi[c] * xl.y;
-                    gi[l] += sh[l] * (mur[l][c] * x0.y + mui[l][c] * x0.x) + hr[c] * xl.y + hi[c] * xl.x;
+                    const double2 xl = vec[cur][1 + l][vq + c];
+                    ur[l] = fma(mur[l][c], x0.x, ur[l]);   // mu_l^d * pw
+                    ur[l] = fma(-mui[l][c], x0.y, ur[l]);
+                    ui[l] = fma(mur[l][c], x0.y, ui[l]);
+                    ui[l] = fma(mui[l][c], x0.x, ui[l]);
+                    gr[l] = fma(hr[c], xl.x, gr[l]);       // Hd * phi_l
+                    gr[l] = fma(-hi[c], xl.y, gr[l]);
+                    gi[l] = fma(hr[c], xl.y, gi[l]);
+                    gi[l] = fma(hi[c], xl.x, gi[l]);
                 }
             }
-            part[q][0][i] = make_double2(pr, pi);
+            // ---- sum the NCH chunks of each row (adjacent lanes, DPP) ----
+            pr = group_sum<NCH>(pr);
+            pi = group_sum<NCH>(pi);
+            const int nxt = cur ^ 1;
+            if (q == 0) vec[nxt][0][vi] = make_double2(pr, pi);
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) part[q][1 + l][i] = make_double2(gr[l], gi[l]);
-            __syncthreads();
-            // ---- wave (v mod 4) owns vector v: reduce partials, norms, overlaps (lane = row) ----
-            for (int v = wave; v <= L; v += 4) {
-                double sr = 0., si = 0.;
-                if (valid) {
-#pragma unroll
-                    for (int qq = 0; qq < NCH; ++qq) { sr += part[qq][v][lane].x; si += part[qq][v][lane].y; }
-                    vec[v][lane] = make_double2(sr, si);
-                }
-                if (v >= 1) {
-                    const int l = v - 1;
-                    const double2 p = valid ? psi_s[lane] : make_double2(0., 0.);
-                    double orr = sr * p.x + si * p.y;  // conj(phi) * psi
-                    double oi = sr * p.y - si * p.x;
-                    double nn = sr * sr + si * si;
-                    orr = wave_sum(orr); oi = wave_sum(oi); nn = wave_sum(nn);
+            for (int l = 0; l < LMAX; ++l) {
+                // phi_l(new) = S_l mu_l^d pw + Hd phi_l
+                const double fr = group_sum<NCH>(fma(sh[l], ur[l], gr[l]));
+                const double fi = group_sum<NCH>(fma(sh[l], ui[l], gi[l]));
+                double nn = 0.;
+                if (q == 0) {
+                    vec[nxt][1 + l][vi] = make_double2(fr, fi);
                     if (!((done_mask >> l) & 1)) {
-#pragma unroll
-                        for (int ll = 0; ll < LMAX; ++ll)
-                            if (ll == l) {
-                                accr[ll] += alr * orr + ali * oi;  // conj(alpha) * <phi|psi>
-                                acci[ll] += alr * oi - ali * orr;
-                            }
-                        const double r = sqrt(alr * alr + ali * ali) * sqrt(nn);
-                        if (m >= 2 && r < a.tol && lane == 0) atomicOr(&s_done, 1 << l);
+                        outr[l] += alr * fr - ali * fi;   // += alpha_m * phi_m
+                        outi[l] += alr * fi + ali * fr;
                     }
+                    nn = fr * fr + fi * fi;
                 }
+                // ||phi_l||^2 over this wave's rows (wavefront reduction); combined after the barrier
+                nn = wave_sum_dpp(nn);
+                if (lane == 0) red[nxt][wave][l] = nn;
             }
             __syncthreads();
-            done_mask = s_done;
+            const double al2 = alr * alr + ali * ali;
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L) {
+                    double nn = 0.;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) nn += red[nxt][w][l];
+                    // reference stopping rule: |alpha_m| * ||phi_m|| < tolerance (optimize.jl:631-636)
+                    if (m >= 2 && al2 * nn < a.tol * a.tol) done_mask |= 1 << l;
+                }
+            }
+            cur = nxt;
             if (done_mask == all_done) { converged = 1; m_used = m; break; }
             {   // alpha_{m+1} = alpha_m * (i dt) / (m+1)
                 const double f = dt / (double)(m + 1);
@@ -848,17 +958,25 @@ __global__ void __launch_bounds__(256) deriv_kernel(DerivArgs a) {
                 alr = nr; ali = ni;
             }
         }
-        if (!converged && tid == 0) atomicOr(&a.flags[0], 4);
-        if (tid == 0) atomicAdd(&a.stats[8], (unsigned long long)m_used);
-        // tau_grads[k][l][n] = rho_k * <chi'_l | psi>
-        for (int v = wave; v <= L; v += 4)
-            if (v >= 1 && lane == 0) {
-                const int l = v - 1;
-                double gr_ = 0., gi_ = 0.;
+        // tau_grads[k][l][n] = rho_k * <chi'_l | psi> = rho_k sum_i conj(chi'_l[i]) psi[i]
 #pragma unroll
-                for (int ll = 0; ll < LMAX; ++ll) if (ll == l) { gr_ = accr[ll]; gi_ = acci[ll]; }
-                a.tg[((size_t)k * L + l) * a.N_T + n] = make_double2(rho * gr_, rho * gi_);
-            }
+        for (int l = 0; l < LMAX; ++l) {
+            double orr = outr[l] * psi.x + outi[l] * psi.y;
+            double oi = outr[l] * psi.y - outi[l] * psi.x;
+            orr = wave_sum_dpp(orr);
+            oi = wave_sum_dpp(oi);
+            if (lane == 0) gsum[wave][l] = make_double2(orr, oi);
+        }
+        __syncthreads();
+        if (tid < L) {
+            double gr_ = 0., gi_ = 0.;
+            for (int w = 0; w < NW; ++w) { gr_ += gsum[w][tid].x; gi_ += gsum[w][tid].y; }
+            a.tg[((size_t)k * L + tid) * a.N_T + n] = make_double2(rho * gr_, rho * gi_);
+        }
+        if (tid == 0) {
+            if (!converged) atomicOr(&a.flags[0], 4);
+            atomicAdd(&a.stats[8], (unsigned long long)m_used);
+        }
     }
 }
 
