@@ -68,7 +68,9 @@ hipError_t dmalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)
 
 size_t expm_lds_bytes(int NT) {
     const int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
-    return sizeof(double) * (size_t)(4 * NP * LD + 512 + NTH + 8 + NP);
+    const int nslot = NT < 3 ? NT : 3;
+    const int xextra = nslot * 2 * NP * 18 > 2 * NP * LD ? nslot * 2 * NP * 18 - 2 * NP * LD : 0;
+    return sizeof(double) * (size_t)(4 * NP * LD + xextra + 1536 + NTH + 8 + NP);
 }
 
 template <int NT>
@@ -288,6 +290,12 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     ea.K = h->K; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
 #ifdef GRAPE_DIAG
     ea.ablate = getenv("GRAPE_DIAG_ABLATE") ? atoi(getenv("GRAPE_DIAG_ABLATE")) : 0;
+    static unsigned long long *d_stamps = nullptr;
+    if (getenv("GRAPE_DIAG_STAMPS")) {
+        if (!d_stamps) hipMalloc((void **)&d_stamps, (size_t)h->K * h->N_T * 16 * 8);
+        hipMemsetAsync(d_stamps, 0, (size_t)h->K * h->N_T * 16 * 8, s);
+    }
+    ea.stamps = d_stamps;
 #endif
     phase_begin(h, 0, s);
     hipError_t e;
@@ -298,6 +306,24 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     }
     HIPCHK(h, e);
     phase_end(h, 0, s);
+#ifdef GRAPE_DIAG
+    if (ea.stamps) {
+        hipStreamSynchronize(s);
+        const size_t nb = (size_t)h->K * h->N_T;
+        std::vector<unsigned long long> st(nb * 16);
+        hipMemcpy(st.data(), ea.stamps, nb * 16 * 8, hipMemcpyDeviceToHost);
+        const char *names[] = {"form A (global->LDS)", "1-norm", "A2 = A*A", "store A2", "A4, A6", "store A6",
+                               "dual T,V", "U = A*T + P,Q", "solve (block GJ)", "squarings + store U"};
+        for (int i = 0; i < 10; ++i) {
+            double sum = 0;
+            for (size_t b = 0; b < nb; ++b) sum += (double)(st[b * 16 + i + 1] - st[b * 16 + i]);
+            fprintf(stderr, "  stamp %-24s %9.0f ticks\n", names[i], sum / nb);
+        }
+        double tot = 0;
+        for (size_t b = 0; b < nb; ++b) tot += (double)(st[b * 16 + 10] - st[b * 16]);
+        fprintf(stderr, "  stamp %-24s %9.0f ticks (s_memtime = 100 MHz)\n", "TOTAL per cell", tot / nb);
+    }
+#endif
     // ---- phase 1: forward sweep + tau ----
     SweepArgs sa{};
     sa.U = h->d_U; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;

@@ -52,7 +52,8 @@ struct ExpmArgs {
     unsigned long long *stats; // [0] sum of squarings, [3..7] #cells with Pade order 3/5/7/9/13
     int K, L, N_T, hc_per_traj;
 #ifdef GRAPE_DIAG
-    int ablate;  // diagnostic builds only (tools/ablate.py): bit0 skip invert16, bit1 skip solve, bit2 skip GEMMs
+    int ablate;  // diagnostic builds only (tools/ablate.sh): bit0 skip invert16, bit1 skip solve
+    unsigned long long *stamps;  // [nblocks][16] s_memtime at phase boundaries (diagnostic builds only)
 #endif
 };
 
@@ -204,140 +205,178 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 __device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int lane, double inv_scale2) {
     const int i = lane & 15, g = lane >> 4;
     double minrel = 1e300;
+    double myqr = 1.0, myqi = 0.0;  // 1/pivot of this lane's row, applied once at the end
+    // Gauss-Jordan with UNSCALED pivot rows: step k only touches rows i != k,
+    //   a_ij -= (a_ik / p_k) a_kj  (j != k),   a_ik = -(a_ik / p_k),   a_kk = 1,
+    // and every row is divided by its own pivot afterwards.  Per step: one complex reciprocal,
+    // one complex multiply and the 4 complex FMAs of this lane's columns.
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int kg = k & 3, kc = k >> 2;
-        // everything this step needs from other lanes is requested first (old values of step k-1)
-        const double pr = readlane_f64(ar[kc], 16 * kg + k);   // pivot D[k][k]
+        const double pr = readlane_f64(ar[kc], 16 * kg + k);   // pivot p_k = D[k][k]
         const double pi = readlane_f64(ai[kc], 16 * kg + k);
-        const double mr = __shfl(ar[kc], 16 * kg + i, 64);      // my row's multiplier D[i][k]
-        const double mi = __shfl(ai[kc], 16 * kg + i, 64);
+        double mr = __shfl(ar[kc], 16 * kg + i, 64);            // a_ik of this lane's row
+        double mi = __shfl(ai[kc], 16 * kg + i, 64);
         double xr[4], xi[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {                           // pivot row entry of my column 4c+g
+        for (int c = 0; c < 4; ++c) {                           // a_kj of this lane's columns j = 4c+g
             xr[c] = __shfl(ar[c], 16 * g + k, 64);
             xi[c] = __shfl(ai[c], 16 * g + k, 64);
         }
-        // 1/pivot: v_rcp_f64 seed + two Newton steps (full fp64 accuracy, no IEEE division sequence)
-        const double den = pr * pr + pi * pi;
+        // 1/p_k: v_rcp_f64 seed + two Newton steps
+        const double den = fma(pr, pr, pi * pi);
         double inv = __builtin_amdgcn_rcp(den);
         inv = inv * fma(-den, inv, 2.0);
         inv = inv * fma(-den, inv, 2.0);
         const double qr = pr * inv, qi = -pi * inv;
         minrel = fmin(minrel, den * inv_scale2);
+        const bool isk = (i == k);
+        myqr = isk ? qr : myqr;
+        myqi = isk ? qi : myqi;
+        // multiplier m' = a_ik / p_k, zero for the pivot row itself
+        const double tr_ = fma(mr, qr, -mi * qi), ti_ = fma(mr, qi, mi * qr);
+        mr = isk ? 0.0 : tr_;
+        mi = isk ? 0.0 : ti_;
+        // column k of the in-place inverse: the e_k column of [D | I]
+        {
+            const bool pc = (g == kg);
+            xr[kc] = pc ? 1.0 : xr[kc];
+            xi[kc] = pc ? 0.0 : xi[kc];
+            ar[kc] = pc ? (isk ? 1.0 : 0.0) : ar[kc];
+            ai[kc] = pc ? 0.0 : ai[kc];
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const bool pivcol = (c == kc) && (g == kg);
-            // scaled pivot row p' = x / pivot  (p'_k = 1/pivot)
-            const double sr = pivcol ? qr : fma(xr[c], qr, -xi[c] * qi);
-            const double si = pivcol ? qi : fma(xr[c], qi, xi[c] * qr);
-            // rows i != k: a = (pivcol ? 0 : a) - m * p' ; row k: a = p'
-            const double br = pivcol ? 0.0 : ar[c];
-            const double bi = pivcol ? 0.0 : ai[c];
-            const double nr = fma(-mr, sr, fma(mi, si, br));
-            const double ni = fma(-mr, si, fma(-mi, sr, bi));
-            ar[c] = (i == k) ? sr : nr;
-            ai[c] = (i == k) ? si : ni;
+            ar[c] = fma(-mr, xr[c], fma(mi, xi[c], ar[c]));
+            ai[c] = fma(-mr, xi[c], fma(-mi, xr[c], ai[c]));
         }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // row i /= p_i
+        const double r = fma(ar[c], myqr, -ai[c] * myqi);
+        ai[c] = fma(ar[c], myqi, ai[c] * myqr);
+        ar[c] = r;
     }
     return minrel;
 }
 
 // Block Gauss-Jordan solve  Q X = P  on register strips (wave w owns column strip w of Q and P),
-// NT block steps.  Step jb: wave jb publishes its panel (block column jb of the current Q) to
-// LDS and inverts the diagonal tile; every wave then updates its strips with MFMA:
+// NT block steps.  Step jb needs the panel (block column jb of the current Q) and the inverse of
+// its 16x16 diagonal tile; every wave then updates its strips with MFMA:
 //     Y      = Dinv * S[jb]             (16x16x16)
 //     S[tr] -= Panel[tr] * Y  (tr != jb),   S[jb] = Y
-// After NT steps Q == I and P == X.  LDS use: panel planes [NP][18] at Pre/Pim, Dinv at Dv.
-#ifdef GRAPE_DIAG
-__device__ int g_ablate_dummy;
-#define g_ablate ablate_flag
-#endif
+// After NT steps Q == I and P == X.
+// LOOK-AHEAD: the register inversion is serial (one wave, 16 dependent pivot steps), so in step jb
+// wave jb+1 updates only its Q strip, immediately publishes the next panel and inverts the next
+// diagonal tile while the other waves are still issuing their MFMA updates; its own P-strip update of
+// step jb is deferred to step jb+1 (where it has no Q strip left to update).  Panels and inverses
+// live in 3 rotating LDS slots so that the deferred update still finds the operands of step jb.
 template <int NT>
-__device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, double *Pre, double *Pim,
-                                               double *Dv, int wave, int lane, double &minrel, double inv_scale2
-#ifdef GRAPE_DIAG
-                                               , int ablate_flag
-#endif
-                                               ) {
+struct GjLds {
+    static constexpr int NP = 16 * NT, PLD = 18;
+    static constexpr int PAN = 2 * NP * PLD;  // doubles per panel slot (re plane, im plane)
+    static constexpr int DV = 512;            // doubles per inverse slot
+};
+
+template <int NT>
+__device__ __forceinline__ void gj_publish_invert(const Strip<NT> &Q, int jb, double *pan, double *dv, int lane,
+                                                  double &minrel, double inv_scale2, bool do_invert) {
     constexpr int NP = 16 * NT, PLD = 18;
     const int ai = lane & 15, ak = lane >> 4;
+    double *pwr = pan + ak * PLD + ai, *pwi = pan + NP * PLD + ak * PLD + ai;
 #pragma unroll
-    for (int jb = 0; jb < NT; ++jb) {
-        __syncthreads();  // previous users of Pre/Pim/Dv are done
-        if (wave == jb) {
-            // publish panel: rows 16t+4r+rg, cols (lane&15) -> Pan[row][col]
-            double *pwr = Pre + ak * PLD + ai, *pwi = Pim + ak * PLD + ai;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pwr[(16 * t + 4 * r) * PLD] = Q.re[t][r];
-                    pwi[(16 * t + 4 * r) * PLD] = Q.im[t][r];
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            // gather diagonal tile in inversion layout: D[i][4c+g], i = ai, g = ak
-            double dr[4], di[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                dr[c] = Pre[(16 * jb + ai) * PLD + 4 * c + ak];
-                di[c] = Pim[(16 * jb + ai) * PLD + 4 * c + ak];
-            }
-#ifdef GRAPE_DIAG
-            double mr = 1.0;
-            if (!(g_ablate & 1)) mr = invert16(dr, di, lane, inv_scale2);
-#else
-            double mr = invert16(dr, di, lane, inv_scale2);
-#endif
-            minrel = fmin(minrel, mr);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                Dv[c * 64 + lane] = dr[c];
-                Dv[256 + c * 64 + lane] = di[c];
-            }
+        for (int r = 0; r < 4; ++r) {
+            pwr[(16 * t + 4 * r) * PLD] = Q.re[t][r];
+            pwi[(16 * t + 4 * r) * PLD] = Q.im[t][r];
         }
-        __syncthreads();
-        double dvr[4], dvi[4];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // gather the diagonal tile in inversion layout: D[i][4c+g], i = ai, g = ak
+    double dr[4], di[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dr[c] = pan[(16 * jb + ai) * PLD + 4 * c + ak];
+        di[c] = pan[NP * PLD + (16 * jb + ai) * PLD + 4 * c + ak];
+    }
+    double mr = 1.0;
+    if (do_invert) mr = invert16(dr, di, lane, inv_scale2);
+    minrel = fmin(minrel, mr);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dv[c * 64 + lane] = dr[c];
+        dv[256 + c * 64 + lane] = di[c];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void gj_update(Strip<NT> &S, int jb, const double *pan, const double *dv, int lane) {
+    constexpr int NP = 16 * NT, PLD = 18;
+    const int ai = lane & 15, ak = lane >> 4;
+    const double *par = pan + ai * PLD + ak, *pai = pan + NP * PLD + ai * PLD + ak;
+    double dvr[4], dvi[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dvr[c] = dv[c * 64 + lane];
+        dvi[c] = dv[256 + c * 64 + lane];
+    }
+    d4 yr = {0., 0., 0., 0.}, yi = {0., 0., 0., 0.};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t != jb) continue;   // jb is a compile-time constant after unrolling
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            dvr[c] = Dv[c * 64 + lane];
-            dvi[c] = Dv[256 + c * 64 + lane];
-        }
-        const double *par = Pre + ai * PLD + ak, *pai = Pim + ai * PLD + ak;
-        // update P always, Q only for strips right of the panel
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            if (which == 0 && wave <= jb) continue;
-            Strip<NT> &S = which == 0 ? Q : P;
-            d4 yr = {0., 0., 0., 0.}, yi = {0., 0., 0., 0.};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const double bre = S.re[jb][c], bim = S.im[jb][c];
-                yr = MFMA64(dvr[c], bre, yr);
-                yi = MFMA64(dvr[c], bim, yi);
-                yr = MFMA64(dvi[c], -bim, yr);
-                yi = MFMA64(dvi[c], bre, yi);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {  // k-step c: k = 4c + ak within the panel's 16 columns
-                const double bre = yr[c], bim = yi[c];
-#pragma unroll
-                for (int tr = 0; tr < NT; ++tr) {
-                    if (tr == jb) continue;
-                    const double are = par[16 * tr * PLD + 4 * c];
-                    const double aim = pai[16 * tr * PLD + 4 * c];
-                    S.re[tr] = MFMA64(-are, bre, S.re[tr]);
-                    S.im[tr] = MFMA64(-are, bim, S.im[tr]);
-                    S.re[tr] = MFMA64(aim, bim, S.re[tr]);
-                    S.im[tr] = MFMA64(-aim, bre, S.im[tr]);
-                }
-            }
-            S.re[jb] = yr;
-            S.im[jb] = yi;
+            const double bre = S.re[t][c], bim = S.im[t][c];
+            yr = MFMA64(dvr[c], bre, yr);
+            yi = MFMA64(dvr[c], bim, yi);
+            yr = MFMA64(dvi[c], -bim, yr);
+            yi = MFMA64(dvi[c], bre, yi);
         }
     }
-    (void)NP;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // k-step c: k = 4c + ak within the panel's 16 columns
+        const double bre = yr[c], bim = yi[c];
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr) {
+            if (tr == jb) continue;
+            const double are = par[16 * tr * PLD + 4 * c];
+            const double aim = pai[16 * tr * PLD + 4 * c];
+            S.re[tr] = MFMA64(-are, bre, S.re[tr]);
+            S.im[tr] = MFMA64(-are, bim, S.im[tr]);
+            S.re[tr] = MFMA64(aim, bim, S.re[tr]);
+            S.im[tr] = MFMA64(-aim, bre, S.im[tr]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t == jb) { S.re[t] = yr; S.im[t] = yi; }
+}
+
+template <int NT>
+__device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
+                                               int wave, int lane, double &minrel, double inv_scale2,
+                                               bool do_invert) {
+    constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
+    __syncthreads();  // previous users of the staging region are done
+    if (wave == 0) gj_publish_invert<NT>(Q, 0, panbase, dvbase, lane, minrel, inv_scale2, do_invert);
+    __syncthreads();
+#pragma unroll
+    for (int jb = 0; jb < NT; ++jb) {
+        const double *pan = panbase + (jb % 3) * PAN, *dv = dvbase + (jb % 3) * DV;
+        if (jb + 1 < NT && wave == jb + 1) {
+            gj_update<NT>(Q, jb, pan, dv, lane);
+            gj_publish_invert<NT>(Q, jb + 1, panbase + ((jb + 1) % 3) * PAN, dvbase + ((jb + 1) % 3) * DV, lane,
+                                  minrel, inv_scale2, do_invert);
+            // this wave's P update of step jb is deferred to the next step
+        } else {
+            if (jb > 0 && wave == jb)  // deferred P update of step jb-1
+                gj_update<NT>(P, jb - 1, panbase + ((jb - 1) % 3) * PAN, dvbase + ((jb - 1) % 3) * DV, lane);
+            if (wave > jb) gj_update<NT>(Q, jb, pan, dv, lane);
+            gj_update<NT>(P, jb, pan, dv, lane);
+        }
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -353,6 +392,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // in registers as column strips, the left GEMM operand is staged in LDS.
 // Replaces the `exp` inside ExpProp's prop_step! (optimize.jl:732, 881, 972).
 // ---------------------------------------------------------------------------------------
+#ifdef GRAPE_DIAG
+#define STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 template <int NT>
 __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     constexpr int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
@@ -361,33 +406,44 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     double *Aim = Are + NP * LD;
     double *Xre = Aim + NP * LD;  // staging of the current left operand (A2, A6, squarings, panel)
     double *Xim = Xre + NP * LD;
-    double *Dv = Xim + NP * LD;  // 512 doubles
-    double *red = Dv + 512;      // NTH + 8 + NP doubles
+    // the Gauss-Jordan panels (min(NT,3) rotating slots of 2*NP*18 doubles) reuse the X planes
+    constexpr int NSLOT = NT < 3 ? NT : 3;
+    constexpr int XEXTRA = NSLOT * 2 * NP * 18 > 2 * NP * LD ? NSLOT * 2 * NP * 18 - 2 * NP * LD : 0;
+    double *Dv = Xim + NP * LD + XEXTRA;  // 3 x 512 doubles (rotating inverse slots)
+    double *red = Dv + 1536;     // NTH + 8 + NP doubles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ncell = a.K * a.N_T;
     const int cell = xcd_remap(blockIdx.x, ncell);
     const int k = cell / a.N_T, n = cell - k * a.N_T;
     const double dt = a.dts[n];
+    STAMP(0);
 
-    // ---- A = -i dt (H0_k + sum_l a_l H_l) -> LDS X (planar row-major) ----
+    // ---- A = -i dt (H0_k + sum_l a_l H_l) -> LDS (planar row-major); 16-byte coalesced loads ----
     {
-        const double *h0 = a.H0f + (size_t)k * 2 * NP * NP;
-        const double *hc = a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP;
-        for (int idx = tid; idx < NP * NP; idx += NTH) {
-            const int i = idx / NP, j = idx - i * NP;
-            double hr = h0[idx], hi = h0[NP * NP + idx];
+        const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
+        const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
+        constexpr int HALF = NP * NP / 2;  // double2 elements per plane
+        double e[8];
+        for (int l = 0; l < a.L; ++l) {
+            e[l] = a.eps[(size_t)l * a.N_T + n];
+            if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
+        }
+#pragma unroll 4
+        for (int idx = tid; idx < HALF; idx += NTH) {
+            double2 hr = h0[idx], hi = h0[HALF + idx];
             for (int l = 0; l < a.L; ++l) {
-                double e = a.eps[(size_t)l * a.N_T + n];
-                if (a.shape) e *= a.shape[(size_t)l * a.N_T + n];
-                hr += e * hc[(size_t)l * 2 * NP * NP + idx];
-                hi += e * hc[(size_t)l * 2 * NP * NP + NP * NP + idx];
+                const double2 cr = hc[(size_t)l * 2 * HALF + idx], ci = hc[(size_t)l * 2 * HALF + HALF + idx];
+                hr.x = fma(e[l], cr.x, hr.x); hr.y = fma(e[l], cr.y, hr.y);
+                hi.x = fma(e[l], ci.x, hi.x); hi.y = fma(e[l], ci.y, hi.y);
             }
-            Are[i * LD + j] = dt * hi;
-            Aim[i * LD + j] = -dt * hr;
+            const int i = (2 * idx) / NP, j = 2 * idx - i * NP;
+            Are[i * LD + j] = dt * hi.x;  Are[i * LD + j + 1] = dt * hi.y;
+            Aim[i * LD + j] = -dt * hr.x; Aim[i * LD + j + 1] = -dt * hr.y;
         }
     }
     __syncthreads();
+    STAMP(1);
     // ---- ||A||_1 = max_j sum_i |a_ij| ----
     {
         constexpr int PARTS = NTH / NP;  // 4
@@ -399,24 +455,23 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
         }
         red[tid] = s;
         __syncthreads();
-        if (tid < NP) {
+        if (tid < 64) {   // first wave: column sums, then the maximum over columns (wavefront shuffles)
             double c = 0.;
-            for (int p = 0; p < PARTS; ++p) c += red[p * NP + tid];
-            red[NTH + 8 + tid] = c;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double m = 0.;
-            for (int jj = 0; jj < NP; ++jj) m = fmax(m, red[NTH + 8 + jj]);
-            red[NTH] = m;
+            if (tid < NP)
+                for (int p = 0; p < PARTS; ++p) c += red[p * NP + tid];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) c = fmax(c, __shfl_xor(c, off, 64));
+            if (tid == 0) red[NTH] = c;
         }
         __syncthreads();
     }
     const double nA = red[NTH];
-    int s = 0;
-    if (nA > 2.1) {
-        const double sl = log2(nA / 5.4);
-        if (sl > 0.) s = (int)ceil(sl);
+    STAMP(2);
+    int s = 0;  // ceil(log2(nA / 5.4)) for nA > 5.4 (Julia's exp!), from the binary exponent
+    if (nA > 5.4) {
+        const double r = nA / 5.4;
+        const int e = ilogb(r);
+        s = (r == ldexp(1.0, e)) ? e : e + 1;
     }
     if (s > 0) {
         const double f = ldexp(1.0, -s);
@@ -441,15 +496,19 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
             strip_zero(A2);
             gemm_xb<NT, LD>(A2, Are, Aim, As, lane);  // A2 = A*A
         }
+        STAMP(3);
         strip_store_lds<NT, LD>(Xre, Xim, A2, wave, lane);  // X = A2
         __syncthreads();
+        STAMP(4);
         strip_zero(A4);
         gemm_xb<NT, LD>(A4, Xre, Xim, A2, lane);  // A4 = A2*A2
         strip_zero(A6);
         gemm_xb<NT, LD>(A6, Xre, Xim, A4, lane);  // A6 = A2*A4
+        STAMP(5);
         __syncthreads();
         strip_store_lds<NT, LD>(Xre, Xim, A6, wave, lane);  // X = A6
         __syncthreads();
+        STAMP(6);
         // T = A6*(b13 A6 + b11 A4 + b9 A2) + b7 A6 + b5 A4 + b3 A2 + b1 I      (U = A*T)
         // V = A6*(b12 A6 + b10 A4 + b8 A2) + b6 A6 + b4 A4 + b2 A2 + b0 I
         Strip<NT> T, V;
@@ -463,6 +522,7 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
         strip_add_identity<NT>(T, B13_1, wave, lane);
         strip_add_identity<NT>(V, B13_0, wave, lane);
         gemm_dual13<NT, LD>(T, V, Xre, Xim, A2, A4, A6, lane);
+        STAMP(7);
         Strip<NT> Uo;
         strip_zero(Uo);
         gemm_xb<NT, LD>(Uo, Are, Aim, T, lane);  // U = A*T
@@ -526,13 +586,15 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     }
 
     // ---- solve (V-U) X = (V+U): block Gauss-Jordan on MFMA; LDS X region doubles as panel ----
+    STAMP(8);
     double minrel = 1e300;
+    // staging region = the X planes (3 panel slots fit: 3 * 2 * NP * 18 <= 2 * NP * LD); inverses in Dv
 #ifdef GRAPE_DIAG
-    if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, Xre, Xre + NP * 18, Dv, wave, lane, minrel, inv_b0sq, a.ablate);
+    if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, Xre, Dv, wave, lane, minrel, inv_b0sq, !(a.ablate & 1));
 #else
-    block_gj_solve<NT>(Qn, Pn, Xre, Xre + NP * 18, Dv, wave, lane, minrel, inv_b0sq);
+    block_gj_solve<NT>(Qn, Pn, Xre, Dv, wave, lane, minrel, inv_b0sq, true);
 #endif
-
+    STAMP(9);
     // ---- squarings ----
     for (int it = 0; it < s; ++it) {
         __syncthreads();
@@ -556,6 +618,7 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
                 Uc[row * NP + col] = make_double2(Pn.re[t][r], Pn.im[t][r]);
             }
     }
+    STAMP(10);
     // ---- bookkeeping ----
     if (lane == 0 && wave < NT) {
         // min over waves that inverted a diagonal tile

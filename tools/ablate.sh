@@ -1,9 +1,11 @@
 #!/bin/bash
-# Diagnostic only: builds a -DGRAPE_DIAG copy of the library and times the expm kernel with parts
-# of it switched off (results are wrong in those runs; only the phase times are read).
+# Diagnostic only: builds a -DGRAPE_DIAG copy of the library, prints in-kernel s_memtime shares of
+# the expm kernel and times it with parts switched off (results are wrong in ablated runs; only the
+# phase times are read).  The product library is restored afterwards.
 set -e
 cd "$(dirname "$0")/.."
 cp grape.jl_amd/csrc/libgrape_hip.so /tmp/libgrape_hip.prod.so
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -DGRAPE_DIAG grape.jl_amd/csrc/grape_hip.hip -o grape.jl_amd/csrc/libgrape_hip.so
-for ab in 0 1 2; do echo "== ablate=$ab"; GRAPE_DIAG_ABLATE=$ab python tools/time_c3.py C3 2>&1 | tail -1; done
+echo "== stamps"; GRAPE_DIAG_STAMPS=1 python tools/time_c3.py C3 2>&1 | grep -E "stamp|eval" | tail -14
+for ab in ${ABLATE:-1 2}; do echo "== ablate=$ab"; GRAPE_DIAG_ABLATE=$ab python tools/time_c3.py C3 2>&1 | tail -1; done
 cp /tmp/libgrape_hip.prod.so grape.jl_amd/csrc/libgrape_hip.so
