@@ -132,6 +132,16 @@ def main():
     J = ev.J_device()
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes of tools/pmc.sh
+        # (separate run: counters cannot be collected inside the timed bench), see profiles/.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            for kname, d in pmc["kernels"].items():
+                if kname.startswith("void expm_pade_kernel"):
+                    traffic = d.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         expm_ms = tm["expm"]
         achieved = work["flop_expm"] / (expm_ms * 1e-3) * 1e-12
         res = {
@@ -152,7 +162,9 @@ def main():
                        "global_problem_evals_per_s": args.steps / elapsed},
             "roofline": {"bound": "mfma", "kernel": "expm_pade_kernel<4> (v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.json); "
+                                         "algorithmic bytes per launch = K*N_T*N^2*16 (U store) = 8.39e9",
                          "flop_per_launch": work["flop_expm"], "avg_launch_ms": expm_ms,
                          "flop_model": "SURVEY 8d F_exp = (6+s)*8N^3 + (32/3)N^3 per Pade-13 cell"},
             "phases_ms": {k: round(v, 4) for k, v in tm.items()},
