@@ -9,6 +9,7 @@
 #include "../../include/grape_hip.h"
 #include "grape_kernels.hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,8 @@ struct grape_handle {
     hipStream_t stream = nullptr;
     // static problem
     double *d_H0f = nullptr, *d_Hcf = nullptr, *d_H0t = nullptr, *d_Hct = nullptr;
+    double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;  // MFMA-fragment-packed H^dagger, series scratch
+    int deriv_blocks = 0;
     double *d_dts = nullptr, *d_shape = nullptr, *d_weights = nullptr;
     double2 *d_psi0 = nullptr, *d_target = nullptr;
     // per-evaluation
@@ -113,6 +116,26 @@ hipError_t launch_deriv(const DerivArgs &a, int nblocks, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int NP, int LMAX, bool CACHE>
+hipError_t launch_dm(const DerivMfmaArgs &a, int nblocks, hipStream_t s) {
+    constexpr int NW = NP / 16 <= 8 ? NP / 16 : 8;
+    hipLaunchKernelGGL((deriv_mfma_kernel<NP, LMAX, CACHE>), dim3(nblocks), dim3(NW * 64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_deriv_mfma(int NP, const DerivMfmaArgs &a, int nblocks, hipStream_t s) {
+    // the scratch holds (1 + LMAX) vectors per block; LMAX is the instantiated control count
+    switch (NP) {
+        case 64:
+            if (a.L == 1) return launch_dm<64, 1, true>(a, nblocks, s);
+            if (a.L == 2) return launch_dm<64, 2, true>(a, nblocks, s);
+            if (a.L <= 4) return launch_dm<64, 4, false>(a, nblocks, s);
+            return launch_dm<64, 8, false>(a, nblocks, s);
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
 // phases 0,1 belong to the forward call, 2,3,4 to the backward call, 5 to grape_eval
 long phase_slot(grape_handle *h, int i) { return (i <= 1 ? h->n_fwd : (i <= 4 ? h->n_bwd : h->n_fwd)) % kRing; }
 void phase_begin(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[phase_slot(h, i)][i].e0, s); }
@@ -147,7 +170,7 @@ void grape_destroy(grape_handle *h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -237,6 +260,37 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_Hcf, f.size())); CCHK(dmalloc(&h->d_Hct, t.size()));
     CCHK(hipMemcpy(h->d_Hcf, f.data(), f.size() * 8, hipMemcpyHostToDevice));
     CCHK(hipMemcpy(h->d_Hct, t.data(), t.size() * 8, hipMemcpyHostToDevice));
+
+    if (NP >= 64) {
+        // fragment-packed H^dagger for the MFMA series kernel: [mat][rt][ks][plane][lane],
+        // value = conj(H)[col][row] at row = 16 rt + (lane & 15), col = 4 ks + (lane >> 4)
+        const int RT = NP / 16, KS = NP / 4;
+        auto pack = [&](const double *src, int nmat, std::vector<double> &dst) {
+            dst.assign((size_t)nmat * RT * KS * 128, 0.0);
+            for (int mtx = 0; mtx < nmat; ++mtx)
+                for (int rt = 0; rt < RT; ++rt)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int ln = 0; ln < 64; ++ln) {
+                            const int row = 16 * rt + (ln & 15), col = 4 * ks + (ln >> 4);
+                            if (row >= N || col >= N) continue;
+                            // H^dagger[row][col] = conj(H[col][row]); H column-major: H[i][j] at j*N + i
+                            const size_t so = 2 * ((size_t)mtx * nn + (size_t)row * N + col);
+                            const size_t o = (((size_t)mtx * RT + rt) * KS + ks) * 128 + ln;
+                            dst[o] = src[so];
+                            dst[o + 64] = -src[so + 1];
+                        }
+        };
+        std::vector<double> pk;
+        pack(p->H0, K, pk);
+        CCHK(dmalloc(&h->d_H0p, pk.size()));
+        CCHK(hipMemcpy(h->d_H0p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+        pack(p->Hc, Kc * L, pk);
+        CCHK(dmalloc(&h->d_Hcp, pk.size()));
+        CCHK(hipMemcpy(h->d_Hcp, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+        const long nbatch = (long)K * ((N_T + 15) / 16);
+        h->deriv_blocks = (int)std::min<long>(nbatch, 1024);
+        CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + 8) * 2 * NP * 16));
+    }
 
     std::vector<double> dts(N_T);
     for (int n = 0; n < N_T; ++n) dts[n] = p->tlist[n + 1] - p->tlist[n];
@@ -380,10 +434,21 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     da.cells_per_block = cpb;
     const int nblocks = h->K * ((h->N_T + cpb - 1) / cpb);
     phase_begin(h, 3, s);
-    switch (h->NP) {
-        case 16: e = launch_deriv<16>(da, nblocks, s); break;
-        case 32: e = launch_deriv<32>(da, nblocks, s); break;
-        default: e = launch_deriv<64>(da, nblocks, s); break;
+    if (h->NP >= 64) {
+        DerivMfmaArgs dm{};
+        dm.H0p = h->d_H0p; dm.Hcp = h->d_Hcp; dm.eps = h->d_eps; dm.shape = h->d_shape; dm.dts = h->d_dts;
+        dm.fw = h->d_fw; dm.bw = h->d_bw; dm.rho = h->d_rho; dm.tg = h->d_tg; dm.vecs = h->d_vecs;
+        dm.flags = h->d_flags; dm.stats = h->d_stats;
+        dm.K = h->K; dm.L = h->L; dm.N_T = h->N_T; dm.hc_per_traj = h->p.hc_per_traj;
+        dm.max_order = h->taylor_max_order; dm.tol = h->taylor_tol;
+        dm.batches_per_k = (h->N_T + 15) / 16;
+        dm.nbatch_total = h->K * dm.batches_per_k;
+        e = launch_deriv_mfma(h->NP, dm, h->deriv_blocks, s);
+    } else {
+        switch (h->NP) {
+            case 16: e = launch_deriv<16>(da, nblocks, s); break;
+            default: e = launch_deriv<32>(da, nblocks, s); break;
+        }
     }
     HIPCHK(h, e);
     phase_end(h, 3, s);

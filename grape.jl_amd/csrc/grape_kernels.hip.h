@@ -1044,6 +1044,254 @@ __global__ void __launch_bounds__(NTH) deriv_kernel(DerivArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Kernel 5b: the same per-cell derivative overlaps on fp64 MFMA, batched over 16 cells.
+//
+// The series recursion of deriv_kernel multiplies H_kn^dagger = H0_k^dagger + sum_l e_nl mu_l^dagger with
+// vectors; with the 16 consecutive cells n0..n0+15 of one trajectory as the 16 MFMA columns, the
+// cell-dependent part moves into per-column scalars (e_cl multiplies the B operand), so that every
+// product is a *fixed* matrix (H0^dagger or mu_l^dagger) times an NP x 16 block of vectors:
+//     pw'    = H0d pw + sum_l e_l (mud_l pw)
+//     phi_l' = H0d phi_l + sum_l' mud_l' (e_l' phi_l) + S_l (mud_l pw)          ((1+L)^2 products)
+// One wave per 16-row tile (block = NP/16 waves).  A operands come from fragment-packed copies of the
+// operators (one coalesced 512-B load per tile, plane and k-step; cached in registers when they fit),
+// B operands are the current vectors, kept in a block-private global scratch [2][1+L][2][NP][16]
+// (L1/L2 resident) and ping-ponged over the series orders; accumulators are directly the new vectors.
+// Column norms / overlaps: in-lane over the 4 accumulator registers, 2 wavefront shuffles across the
+// row groups, then fp64 LDS atomics across the waves.
+// ---------------------------------------------------------------------------------------
+struct DerivMfmaArgs {
+    const double *H0p;   // [K][RT][KS][2][64] fragment-packed conj-transposed drift (RT = NP/16, KS = NP/4)
+    const double *Hcp;   // [Kc][L][RT][KS][2][64]
+    const double *eps, *shape, *dts;
+    const double2 *fw, *bw;
+    const double *rho;
+    double2 *tg;
+    double *vecs;        // [gridDim.x][2][1+L][2][NP][16] scratch
+    int *flags;
+    unsigned long long *stats;
+    int K, L, N_T, hc_per_traj, max_order, nbatch_total, batches_per_k;
+    double tol;
+};
+
+template <int NP, int LMAX, bool CACHE_A>
+__global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv_mfma_kernel(DerivMfmaArgs a) {
+    constexpr int RT = NP / 16, KS = NP / 4;
+    constexpr int NW = RT <= 8 ? RT : 8;      // waves per block
+    constexpr int TPW = RT / NW;              // row tiles per wave (processed one after the other)
+    constexpr int NTH = NW * 64;
+    constexpr int NV = 1 + LMAX;
+    static_assert(RT % NW == 0, "row tiles must divide evenly over the waves");
+    static_assert(!CACHE_A || TPW == 1, "operand caching only for one tile per wave");
+    // per wave and column: Re/Im <phi_l|psi>, ||phi_l||^2 of the wave's rows; summed in a fixed order
+    // after the barrier (bitwise reproducible, unlike LDS atomics); double-buffered over the orders
+    __shared__ double red[2][NW][LMAX][16][3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, rg = lane >> 4;
+    const int L = a.L;
+    const size_t vplane = (size_t)NP * 16;                      // doubles per vector plane
+    double *vbase = a.vecs + (size_t)blockIdx.x * 2 * NV * 2 * vplane;
+
+    int cached_k = -1;
+    double car[CACHE_A ? NV : 1][CACHE_A ? KS : 1], cai[CACHE_A ? NV : 1][CACHE_A ? KS : 1];
+
+    for (int batch = blockIdx.x; batch < a.nbatch_total; batch += gridDim.x) {
+        const int k = batch / a.batches_per_k;
+        const int n0 = (batch - k * a.batches_per_k) * 16;
+        const int n = n0 + c;
+        const bool valid = n < a.N_T;
+        const int nc = valid ? n : a.N_T - 1;
+        const double *h0k = a.H0p + (size_t)k * RT * KS * 128;
+        const double *hck = a.Hcp + (size_t)(a.hc_per_traj ? k : 0) * L * RT * KS * 128;
+        if (CACHE_A && cached_k != k) {
+#pragma unroll
+            for (int ks = 0; ks < (CACHE_A ? KS : 1); ++ks) {
+                car[0][ks] = h0k[((size_t)wave * KS + ks) * 128 + lane];
+                cai[0][ks] = h0k[((size_t)wave * KS + ks) * 128 + 64 + lane];
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    car[1 + l][ks] = l < L ? hck[(((size_t)l * RT + wave) * KS + ks) * 128 + lane] : 0.;
+                    cai[1 + l][ks] = l < L ? hck[(((size_t)l * RT + wave) * KS + ks) * 128 + 64 + lane] : 0.;
+                }
+            }
+            cached_k = k;
+        }
+        // per-column scalars
+        const double dt = a.dts[nc];
+        double e[LMAX], sh[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            sh[l] = (l < L && a.shape) ? a.shape[(size_t)l * a.N_T + nc] : 1.0;
+            e[l] = l < L ? a.eps[(size_t)l * a.N_T + nc] * sh[l] : 0.;
+        }
+        const double rho = a.rho[k];
+        // psi tiles (rows 16rt + 4r + rg of column c) and initial vectors: pw_0 = chi_k(t_{n+1})
+        double psr[TPW][4], psi_[TPW][4];
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (wave + tt * NW) + 4 * r + rg;
+                const double2 p = a.fw[((size_t)k * (a.N_T + 1) + nc) * NP + row];
+                const double2 x = a.bw[((size_t)k * (a.N_T + 1) + nc + 1) * NP + row];
+                psr[tt][r] = p.x; psi_[tt][r] = p.y;
+                vbase[0 * vplane + (size_t)row * 16 + c] = valid ? x.x : 0.;
+                vbase[1 * vplane + (size_t)row * 16 + c] = valid ? x.y : 0.;
+            }
+        __syncthreads();
+        double accr[LMAX], acci[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { accr[l] = 0.; acci[l] = 0.; }
+        double alr = 0., ali = dt;              // alpha_1 = i dt  (dtb = -dt)
+        const int all_done = (1 << L) - 1;
+        int done_mask = valid ? 0 : all_done;
+        int cur = 0, m_used = a.max_order, converged = 0;
+        for (int m = 1; m <= a.max_order; ++m) {
+            const double *vc = vbase + (size_t)cur * NV * 2 * vplane;
+            double *vn = vbase + (size_t)(cur ^ 1) * NV * 2 * vplane;
+            const int slot = m & 1;
+            double sor[LMAX], soi[LMAX], snn[LMAX];   // this wave's column sums over its row tiles
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) { sor[l] = 0.; soi[l] = 0.; snn[l] = 0.; }
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) {
+                const int rt = wave + tt * NW;
+                const double *h0p = h0k + (size_t)rt * KS * 128;
+                d4 pwr = {0., 0., 0., 0.}, pwi = {0., 0., 0., 0.};
+                d4 mur[LMAX], mui[LMAX], phr[LMAX], phi[LMAX];
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    mur[l] = (d4){0., 0., 0., 0.}; mui[l] = (d4){0., 0., 0., 0.};
+                    phr[l] = (d4){0., 0., 0., 0.}; phi[l] = (d4){0., 0., 0., 0.};
+                }
+                auto ks_step = [&](const int ks) __attribute__((always_inline)) {
+                    // A operands (row tile rt): H0d and mud_l
+                    double ar[NV], ai[NV];
+                    if (CACHE_A) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) { ar[v] = car[v][CACHE_A ? ks : 0]; ai[v] = cai[v][CACHE_A ? ks : 0]; }
+                    } else {
+                        ar[0] = h0p[(size_t)ks * 128 + lane];
+                        ai[0] = h0p[(size_t)ks * 128 + 64 + lane];
+#pragma unroll
+                        for (int l = 0; l < LMAX; ++l) {
+                            ar[1 + l] = l < L ? hck[(((size_t)l * RT + rt) * KS + ks) * 128 + lane] : 0.;
+                            ai[1 + l] = l < L ? hck[(((size_t)l * RT + rt) * KS + ks) * 128 + 64 + lane] : 0.;
+                        }
+                    }
+                    // B operands: rows 4ks + rg of the current vectors, column c
+                    const size_t bo = (size_t)(4 * ks + rg) * 16 + c;
+                    const double bwr = vc[0 * vplane + bo], bwi = vc[1 * vplane + bo];
+                    pwr = MFMA64(ar[0], bwr, pwr);  pwi = MFMA64(ar[0], bwi, pwi);
+                    pwr = MFMA64(ai[0], -bwi, pwr); pwi = MFMA64(ai[0], bwr, pwi);
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        mur[l] = MFMA64(ar[1 + l], bwr, mur[l]);  mui[l] = MFMA64(ar[1 + l], bwi, mui[l]);
+                        mur[l] = MFMA64(ai[1 + l], -bwi, mur[l]); mui[l] = MFMA64(ai[1 + l], bwr, mui[l]);
+                    }
+                    if (m > 1) {
+#pragma unroll
+                        for (int l = 0; l < LMAX; ++l) {
+                            const double br = vc[((1 + l) * 2 + 0) * vplane + bo], bi = vc[((1 + l) * 2 + 1) * vplane + bo];
+                            phr[l] = MFMA64(ar[0], br, phr[l]);  phi[l] = MFMA64(ar[0], bi, phi[l]);
+                            phr[l] = MFMA64(ai[0], -bi, phr[l]); phi[l] = MFMA64(ai[0], br, phi[l]);
+#pragma unroll
+                            for (int l2 = 0; l2 < LMAX; ++l2) {
+                                const double sr = e[l2] * br, si = e[l2] * bi;   // column-scaled B operand
+                                phr[l] = MFMA64(ar[1 + l2], sr, phr[l]);  phi[l] = MFMA64(ar[1 + l2], si, phi[l]);
+                                phr[l] = MFMA64(ai[1 + l2], -si, phr[l]); phi[l] = MFMA64(ai[1 + l2], sr, phi[l]);
+                            }
+                        }
+                    }
+                };
+                if constexpr (CACHE_A) {   // fully unrolled: the cached operand arrays need static indices
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) ks_step(ks);
+                } else {
+#pragma unroll 4
+                    for (int ks = 0; ks < KS; ++ks) ks_step(ks);
+                }
+                // ---- new vectors (accumulator layout: row 16rt + 4r + rg, column c) ----
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    pwr += e[l] * mur[l];
+                    pwi += e[l] * mui[l];
+                    phr[l] += sh[l] * mur[l];
+                    phi[l] += sh[l] * mui[l];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
+                    vn[0 * vplane + o] = pwr[r];
+                    vn[1 * vplane + o] = pwi[r];
+                }
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    double orr = 0., oi = 0., nn = 0.;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
+                        vn[((1 + l) * 2 + 0) * vplane + o] = phr[l][r];
+                        vn[((1 + l) * 2 + 1) * vplane + o] = phi[l][r];
+                        orr += phr[l][r] * psr[tt][r] + phi[l][r] * psi_[tt][r];   // conj(phi) * psi
+                        oi += phr[l][r] * psi_[tt][r] - phi[l][r] * psr[tt][r];
+                        nn += phr[l][r] * phr[l][r] + phi[l][r] * phi[l][r];
+                    }
+                    // the 4 row groups of a column sit 16 lanes apart
+                    orr += __shfl_xor(orr, 16, 64); oi += __shfl_xor(oi, 16, 64); nn += __shfl_xor(nn, 16, 64);
+                    orr += __shfl_xor(orr, 32, 64); oi += __shfl_xor(oi, 32, 64); nn += __shfl_xor(nn, 32, 64);
+                    sor[l] += orr; soi[l] += oi; snn[l] += nn;
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    red[slot][wave][l][c][0] = sor[l];
+                    red[slot][wave][l][c][1] = soi[l];
+                    red[slot][wave][l][c][2] = snn[l];
+                }
+            }
+            __syncthreads();
+            const double al2 = alr * alr + ali * ali;
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L && !((done_mask >> l) & 1)) {
+                    double orr = 0., oi = 0., nn = 0.;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        orr += red[slot][w][l][c][0]; oi += red[slot][w][l][c][1]; nn += red[slot][w][l][c][2];
+                    }
+                    accr[l] += alr * orr + ali * oi;   // conj(alpha) <phi|psi>
+                    acci[l] += alr * oi - ali * orr;
+                    if (m >= 2 && al2 * nn < a.tol * a.tol) done_mask |= 1 << l;
+                }
+            }
+            cur ^= 1;
+            // all 16 columns converged?  (identical decision in every wave: same LDS values)
+            if (__all(done_mask == all_done)) { converged = 1; m_used = m; break; }
+            {
+                const double f = dt / (double)(m + 1);
+                const double nr = -ali * f, ni = alr * f;
+                alr = nr; ali = ni;
+            }
+        }
+        if (tid < 16 && valid) {
+            for (int l = 0; l < L; ++l) {
+                double gr_ = 0., gi_ = 0.;
+#pragma unroll
+                for (int ll = 0; ll < LMAX; ++ll) if (ll == l) { gr_ = accr[ll]; gi_ = acci[ll]; }
+                a.tg[((size_t)k * L + l) * a.N_T + n] = make_double2(rho * gr_, rho * gi_);
+            }
+        }
+        if (tid == 0) {
+            if (!converged) atomicOr(&a.flags[0], 4);
+            atomicAdd(&a.stats[8], (unsigned long long)m_used * (unsigned long long)min(16, a.N_T - n0));
+        }
+        __syncthreads();   // red slots / scratch are reused by the next batch
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Kernel 6: G[l*N_T + n] = -2 Re sum_k tau_grads[k][l][n]   (_grad_J_T_via_chi!, optimize.jl:574-584)
 // ---------------------------------------------------------------------------------------
 __global__ void grad_reduce_kernel(const double2 *tg, int K, int LN, double *G) {
