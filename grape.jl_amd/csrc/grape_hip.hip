@@ -116,21 +116,33 @@ hipError_t launch_deriv(const DerivArgs &a, int nblocks, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int NP, int LMAX, bool CACHE>
+template <int NP, int LMAX, bool CACHE, bool VLDS>
 hipError_t launch_dm(const DerivMfmaArgs &a, int nblocks, hipStream_t s) {
     constexpr int NW = NP / 16 <= 8 ? NP / 16 : 8;
-    hipLaunchKernelGGL((deriv_mfma_kernel<NP, LMAX, CACHE>), dim3(nblocks), dim3(NW * 64), 0, s, a);
+    const size_t lds = VLDS ? sizeof(double) * 2 * (1 + LMAX) * 2 * NP * 16 : 0;
+    if (VLDS) {
+        static bool attr_set[8] = {false};
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (!attr_set[dev & 7]) {
+            hipError_t e = hipFuncSetAttribute((const void *)deriv_mfma_kernel<NP, LMAX, CACHE, VLDS>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set[dev & 7] = true;
+        }
+    }
+    hipLaunchKernelGGL((deriv_mfma_kernel<NP, LMAX, CACHE, VLDS>), dim3(nblocks), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_deriv_mfma(int NP, const DerivMfmaArgs &a, int nblocks, hipStream_t s) {
     // the scratch holds (1 + LMAX) vectors per block; LMAX is the instantiated control count
     switch (NP) {
-        case 64:
-            if (a.L == 1) return launch_dm<64, 1, true>(a, nblocks, s);
-            if (a.L == 2) return launch_dm<64, 2, true>(a, nblocks, s);
-            if (a.L <= 4) return launch_dm<64, 4, false>(a, nblocks, s);
-            return launch_dm<64, 8, false>(a, nblocks, s);
+        case 64:  // L <= 2: vectors in LDS (2 x (1+L) x 16 KB), operators cached in registers
+            if (a.L == 1) return launch_dm<64, 1, true, true>(a, nblocks, s);
+            if (a.L == 2) return launch_dm<64, 2, true, true>(a, nblocks, s);
+            if (a.L <= 4) return launch_dm<64, 4, false, false>(a, nblocks, s);   // 5 vectors x 2 do not fit in LDS
+            return launch_dm<64, 8, false, false>(a, nblocks, s);
         default:
             return hipErrorInvalidValue;
     }

@@ -1073,8 +1073,9 @@ struct DerivMfmaArgs {
     double tol;
 };
 
-template <int NP, int LMAX, bool CACHE_A>
+template <int NP, int LMAX, bool CACHE_A, bool VEC_LDS>
 __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv_mfma_kernel(DerivMfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];   // VEC_LDS: the ping-pong vectors
     constexpr int RT = NP / 16, KS = NP / 4;
     constexpr int NW = RT <= 8 ? RT : 8;      // waves per block
     constexpr int TPW = RT / NW;              // row tiles per wave (processed one after the other)
@@ -1090,7 +1091,8 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv_mfma_
     const int c = lane & 15, rg = lane >> 4;
     const int L = a.L;
     const size_t vplane = (size_t)NP * 16;                      // doubles per vector plane
-    double *vbase = a.vecs + (size_t)blockIdx.x * 2 * NV * 2 * vplane;
+    double *vbase;
+    if constexpr (VEC_LDS) vbase = dsm; else vbase = a.vecs + (size_t)blockIdx.x * 2 * NV * 2 * vplane;
 
     int cached_k = -1;
     double car[CACHE_A ? NV : 1][CACHE_A ? KS : 1], cai[CACHE_A ? NV : 1][CACHE_A ? KS : 1];
