@@ -8,6 +8,7 @@
 // No CPU fallback exists: every entry point fails loudly when HIP does.
 #include "../../include/grape_hip.h"
 #include "grape_kernels.hip.h"
+#include "grape_large.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -36,6 +37,12 @@ struct grape_handle {
     double *d_H0f = nullptr, *d_Hcf = nullptr, *d_H0t = nullptr, *d_Hct = nullptr;
     double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;  // MFMA-fragment-packed H^dagger, series scratch
     int deriv_blocks = 0;
+    // blocked path (64 < N <= 256): per-chunk scratch matrices, planar [cell][2][NP*NP]
+    bool large = false;
+    int chunk = 0;
+    double *d_lg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *d_dinv = nullptr;
+    int *d_scell = nullptr;
     double *d_dts = nullptr, *d_shape = nullptr, *d_weights = nullptr;
     double2 *d_psi0 = nullptr, *d_target = nullptr;
     // per-evaluation
@@ -143,6 +150,14 @@ hipError_t launch_deriv_mfma(int NP, const DerivMfmaArgs &a, int nblocks, hipStr
             if (a.L == 2) return launch_dm<64, 2, true, true>(a, nblocks, s);
             if (a.L <= 4) return launch_dm<64, 4, false, false>(a, nblocks, s);   // 5 vectors x 2 do not fit in LDS
             return launch_dm<64, 8, false, false>(a, nblocks, s);
+        case 128:
+            if (a.L == 1) return launch_dm<128, 1, false, false>(a, nblocks, s);
+            if (a.L == 2) return launch_dm<128, 2, false, false>(a, nblocks, s);
+            return launch_dm<128, 4, false, false>(a, nblocks, s);
+        case 256:
+            if (a.L == 1) return launch_dm<256, 1, false, false>(a, nblocks, s);
+            if (a.L == 2) return launch_dm<256, 2, false, false>(a, nblocks, s);
+            return launch_dm<256, 4, false, false>(a, nblocks, s);
         default:
             return hipErrorInvalidValue;
     }
@@ -155,6 +170,115 @@ void phase_end(grape_handle *h, int i, hipStream_t s) {
     Phase &p = h->ph[phase_slot(h, i)][i];
     hipEventRecord(p.e1, s);
     p.used = true;
+}
+
+
+// ---- blocked Pade-13 for 64 < N <= 256: one launch per product, cells in chunks ----
+LgView lg_full(double *p, int NP) { return LgView{p, (size_t)2 * NP * NP, (size_t)NP * NP, NP, 0, 0}; }
+
+hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, LgView C, int kblocks, double alpha,
+                   double beta, int nadd = 0, const LgView *add = nullptr, const double *coef = nullptr,
+                   double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0) {
+    if (nbi <= 0 || nbj <= 0) return hipSuccess;
+    LgGemmArgs a{};
+    a.X = X; a.Y = Y; a.C = C; a.kblocks = kblocks; a.alpha = alpha; a.beta = beta; a.cI = cI;
+    a.nadd = nadd;
+    for (int i = 0; i < nadd; ++i) { a.Add[i] = add[i]; a.coef[i] = coef[i]; }
+    a.s_cell = s_cell; a.sq_iter = sq_iter;
+    hipLaunchKernelGGL(lg_gemm_kernel, dim3(nbj, nbi, nc), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t lg_lincomb(hipStream_t s, double *out, size_t n, int nin, const double *const *in, const double *coef) {
+    LgLincombArgs a{};
+    a.out = out; a.n = n; a.nin = nin;
+    for (int i = 0; i < nin; ++i) { a.in[i] = in[i]; a.coef[i] = coef[i]; }
+    hipLaunchKernelGGL(lg_lincomb_kernel, dim3(2048), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+#define LGCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
+
+hipError_t expm_large(grape_handle *h, hipStream_t s) {
+    const int NP = h->NP, NB = NP / 64;
+    const size_t pp = (size_t)NP * NP;
+    const long ncell = (long)h->K * h->N_T;
+    static bool attr_set[8] = {false};
+    const size_t inv_lds = sizeof(double) * (3 * 2 * 64 * 18 + 1536);
+    if (!attr_set[h->device & 7]) {
+        LGCHK(hipFuncSetAttribute((const void *)lg_inv64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+        attr_set[h->device & 7] = true;
+    }
+    double *A = h->d_lg[0], *A2 = h->d_lg[1], *A4 = h->d_lg[2], *A6 = h->d_lg[3], *W = h->d_lg[4], *Z = h->d_lg[5],
+           *T = h->d_lg[6], *V = h->d_lg[7], *Uo = h->d_lg[8];
+    for (long c0 = 0; c0 < ncell; c0 += h->chunk) {
+        const int nc = (int)std::min<long>(h->chunk, ncell - c0);
+        const size_t nel = (size_t)nc * 2 * pp;
+        LGCHK(hipMemsetAsync(h->d_scell + h->chunk, 0, sizeof(int), s));
+        LgFormArgs fa{};
+        fa.H0f = h->d_H0f; fa.Hcf = h->d_Hcf; fa.eps = h->d_eps; fa.shape = h->d_shape; fa.dts = h->d_dts;
+        fa.A = A; fa.s_cell = h->d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
+        fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0;
+        hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(256), 0, s, fa);
+        LGCHK(hipGetLastError());
+        const LgView vA = lg_full(A, NP), vA2 = lg_full(A2, NP), vA4 = lg_full(A4, NP), vA6 = lg_full(A6, NP),
+                     vW = lg_full(W, NP), vZ = lg_full(Z, NP), vT = lg_full(T, NP), vV = lg_full(V, NP), vU = lg_full(Uo, NP);
+        LGCHK(lg_gemm(s, nc, NB, NB, vA, vA, vA2, NB, 1.0, 0.0));
+        LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA2, vA4, NB, 1.0, 0.0));
+        LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA4, vA6, NB, 1.0, 0.0));
+        {
+            const double *in[3] = {A6, A4, A2};
+            const double cw[3] = {B13_13, B13_11, B13_9}, cz[3] = {B13_12, B13_10, B13_8};
+            LGCHK(lg_lincomb(s, W, nel, 3, in, cw));
+            LGCHK(lg_lincomb(s, Z, nel, 3, in, cz));
+            const LgView add[3] = {vA6, vA4, vA2};
+            const double ct[3] = {B13_7, B13_5, B13_3}, cv[3] = {B13_6, B13_4, B13_2};
+            LGCHK(lg_gemm(s, nc, NB, NB, vA6, vW, vT, NB, 1.0, 0.0, 3, add, ct, B13_1));   // T = A6 W1 + T0
+            LGCHK(lg_gemm(s, nc, NB, NB, vA6, vZ, vV, NB, 1.0, 0.0, 3, add, cv, B13_0));   // V = A6 Z1 + V0
+        }
+        LGCHK(lg_gemm(s, nc, NB, NB, vA, vT, vU, NB, 1.0, 0.0));                           // U = A T
+        {
+            const double *in[2] = {V, Uo};
+            const double cp[2] = {1.0, 1.0}, cq[2] = {1.0, -1.0};
+            LGCHK(lg_lincomb(s, W, nel, 2, in, cp));   // P = V + U   (buffer W)
+            LGCHK(lg_lincomb(s, Z, nel, 2, in, cq));   // Q = V - U   (buffer Z)
+        }
+        // block Gauss-Jordan on 64-blocks: Q X = P
+        const LgView vD{h->d_dinv, (size_t)2 * 4096, (size_t)4096, 64, 0, 0};
+        for (int jb = 0; jb < NB; ++jb) {
+            LgInvArgs ia{};
+            ia.Q = vZ; ia.Q.rb = jb; ia.Q.cb = jb; ia.Dinv = h->d_dinv; ia.flags = h->d_flags;
+            ia.inv_scale2 = 1.0 / (B13_0 * B13_0);
+            hipLaunchKernelGGL(lg_inv64_kernel, dim3(nc), dim3(256), inv_lds, s, ia);
+            LGCHK(hipGetLastError());
+            LgView qrow = vZ; qrow.rb = jb; qrow.cb = jb + 1;
+            LgView prow = vW; prow.rb = jb; prow.cb = 0;
+            LGCHK(lg_gemm(s, nc, 1, NB - 1 - jb, vD, qrow, qrow, 1, 1.0, 0.0));   // Q[jb][jb+1..] = Dinv Q[jb][..]
+            LGCHK(lg_gemm(s, nc, 1, NB, vD, prow, prow, 1, 1.0, 0.0));             // P[jb][:]      = Dinv P[jb][:]
+            for (int tr = 0; tr < NB; ++tr) {
+                if (tr == jb) continue;
+                LgView x = vZ; x.rb = tr; x.cb = jb;                    // Q[tr][jb]
+                LgView cq = vZ; cq.rb = tr; cq.cb = jb + 1;
+                LgView cp = vW; cp.rb = tr; cp.cb = 0;
+                LGCHK(lg_gemm(s, nc, 1, NB - 1 - jb, x, qrow, cq, 1, -1.0, 1.0));  // Q[tr][..] -= Q[tr][jb] Q[jb][..]
+                LGCHK(lg_gemm(s, nc, 1, NB, x, prow, cp, 1, -1.0, 1.0));            // P[tr][:]  -= Q[tr][jb] P[jb][:]
+            }
+        }
+        // squarings (per-cell count; cells that are done are copied through)
+        int smax = 0;
+        LGCHK(hipMemcpyAsync(&smax, h->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        LGCHK(hipStreamSynchronize(s));
+        double *X = W, *Y = T;
+        for (int it = 0; it < smax; ++it) {
+            LGCHK(lg_gemm(s, nc, NB, NB, lg_full(X, NP), lg_full(X, NP), lg_full(Y, NP), NB, 1.0, 0.0, 0, nullptr, nullptr,
+                          0.0, h->d_scell, it));
+            std::swap(X, Y);
+        }
+        hipLaunchKernelGGL(lg_store_u_kernel, dim3(2048), dim3(256), 0, s, (const double *)X,
+                           h->d_U + (size_t)c0 * pp, NP, (size_t)nc * pp);
+        LGCHK(hipGetLastError());
+    }
+    return hipSuccess;
 }
 
 int status_from_flags(grape_handle *h, int flags) {
@@ -182,7 +306,9 @@ void grape_destroy(grape_handle *h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    for (double *b : h->d_lg)
+        if (b) hipFree(b);
+    void *bufs[] = {h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -206,8 +332,12 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         g_create_error = "invalid problem dimensions or null array";
         return GRAPE_ERR_INVALID;
     }
-    if (p->N > 64) {
-        g_create_error = "N > 64 is not supported by this build (in-LDS Pade kernel covers N <= 64)";
+    if (p->N > 256) {
+        g_create_error = "N > 256 is not supported by this build (fused kernel: N <= 64, blocked path: N <= 256)";
+        return GRAPE_ERR_INVALID;
+    }
+    if (p->N > 64 && p->L > 4) {
+        g_create_error = "L > 4 with N > 64 is not supported by this build";
         return GRAPE_ERR_INVALID;
     }
     if (p->L > 8) { g_create_error = "L > 8 is not supported by this build"; return GRAPE_ERR_INVALID; }
@@ -221,6 +351,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     h->K_total = p->K_total > 0 ? p->K_total : p->K;
     h->NT = (p->N + 15) / 16; h->NP = 16 * h->NT;
     if (h->NP == 48) { h->NT = 4; h->NP = 64; }  // sweep/derivative kernels are built for 16/32/64
+    if (p->N > 64) { h->large = true; h->NP = p->N <= 128 ? 128 : 256; h->NT = h->NP / 16; }
     h->device = p->device;
     if (p->chi_min_norm > 0) h->chi_min_norm = p->chi_min_norm;
     if (p->taylor_tolerance > 0) h->taylor_tol = p->taylor_tolerance;
@@ -301,7 +432,15 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         CCHK(hipMemcpy(h->d_Hcp, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
         const long nbatch = (long)K * ((N_T + 15) / 16);
         h->deriv_blocks = (int)std::min<long>(nbatch, 1024);
-        CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + 8) * 2 * NP * 16));
+        CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + (h->large ? 4 : 8)) * 2 * NP * 16));
+    }
+    if (h->large) {
+        const long ncell = (long)K * N_T;
+        const long cap = std::max<long>(1, (long)(6.0e9 / (9.0 * 2.0 * pp * 8.0)));
+        h->chunk = (int)std::min<long>(ncell, std::min<long>(cap, 4096));
+        for (auto &b : h->d_lg) CCHK(dmalloc(&b, (size_t)h->chunk * 2 * pp));
+        CCHK(dmalloc(&h->d_dinv, (size_t)h->chunk * 2 * 4096));
+        CCHK(dmalloc(&h->d_scell, (size_t)h->chunk + 1));
     }
 
     std::vector<double> dts(N_T);
@@ -365,10 +504,14 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
 #endif
     phase_begin(h, 0, s);
     hipError_t e;
-    switch (h->NT) {
-        case 1: e = launch_expm<1>(ea, s); break;
-        case 2: e = launch_expm<2>(ea, s); break;
-        default: e = launch_expm<4>(ea, s); break;
+    if (h->large) {
+        e = expm_large(h, s);
+    } else {
+        switch (h->NT) {
+            case 1: e = launch_expm<1>(ea, s); break;
+            case 2: e = launch_expm<2>(ea, s); break;
+            default: e = launch_expm<4>(ea, s); break;
+        }
     }
     HIPCHK(h, e);
     phase_end(h, 0, s);
@@ -400,7 +543,10 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, false, s); break;
         case 32: e = launch_sweep<32>(sa, false, s); break;
-        default: e = launch_sweep<64>(sa, false, s); break;
+        case 64: e = launch_sweep<64>(sa, false, s); break;
+        default:
+            hipLaunchKernelGGL((sweep_lg_kernel<false>), dim3(sa.K), dim3(1024), 0, s, sa, h->NP);
+            e = hipGetLastError();
     }
     HIPCHK(h, e);
     hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(64), 0, s, (const double2 *)d_out, h->d_weights, h->K,
@@ -430,7 +576,10 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, true, s); break;
         case 32: e = launch_sweep<32>(sa, true, s); break;
-        default: e = launch_sweep<64>(sa, true, s); break;
+        case 64: e = launch_sweep<64>(sa, true, s); break;
+        default:
+            hipLaunchKernelGGL((sweep_lg_kernel<true>), dim3(sa.K), dim3(1024), 0, s, sa, h->NP);
+            e = hipGetLastError();
     }
     HIPCHK(h, e);
     phase_end(h, 2, s);

@@ -1,0 +1,345 @@
+// grape_large.hip.h -- blocked variant of the path for 64 < N <= 256 (NP = 128 or 256).
+//
+// Same algorithm as grape_kernels.hip.h, but a cell's matrices no longer fit one workgroup's
+// registers/LDS: they live in HBM/L2 as planar (re plane | im plane) row-major NP x NP arrays, cells
+// are processed in chunks, and every product of the Pade evaluation is one launch of a batched,
+// MFMA-tiled block GEMM (64x64 output block per workgroup, K loop over 64-wide blocks, the same
+// LDS-left-operand / register-strip-right-operand tile engine `gemm_xb<4,66>` as the fused kernel).
+// The Pade system is solved by block Gauss-Jordan at 64-block granularity: the 64x64 diagonal block is
+// inverted by the fused kernel's in-register solver (P = I), row scaling and rank-64 updates are block
+// GEMMs.  Sweeps use 1024-thread workgroups; the derivative overlaps use deriv_mfma_kernel.
+#pragma once
+#include "grape_kernels.hip.h"
+
+struct LgView {          // a block view into a batch of planar matrices
+    double *p;           // re plane of cell 0; the im plane follows at +plane
+    size_t cell_stride;  // doubles between consecutive cells
+    size_t plane;        // doubles between re and im plane
+    int ld;              // leading dimension (row stride)
+    int rb, cb;          // block offset of the view (units of 64 rows / columns)
+};
+
+struct LgGemmArgs {
+    LgView X, Y, C;      // C[bi][bj] = alpha * sum_kb X[bi][kb] Y[kb][bj] + beta * C[bi][bj] + sum_i coef[i] Add_i + cI * I
+    LgView Add[3];
+    double coef[3];
+    double alpha, beta, cI;
+    int nadd, kblocks;
+    const int *s_cell;   // optional: squarings per cell; cells with s_cell[cell] <= sq_iter copy X instead
+    int sq_iter;
+};
+
+__device__ __forceinline__ double *lg_ptr(const LgView &v, int cell, int brow, int bcol) {
+    return v.p + (size_t)cell * v.cell_stride + (size_t)(v.rb + brow) * 64 * v.ld + (size_t)(v.cb + bcol) * 64;
+}
+
+__global__ void __launch_bounds__(256) lg_gemm_kernel(LgGemmArgs a) {
+    constexpr int LD = 66;
+    __shared__ double Xre[64 * LD], Xim[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bj = blockIdx.x, bi = blockIdx.y, cell = blockIdx.z;
+    const int col = 16 * wave + (lane & 15), rg = lane >> 4;
+    double *c = lg_ptr(a.C, cell, bi, bj);
+    if (a.s_cell && a.s_cell[cell] <= a.sq_iter) {   // no (further) squaring for this cell: C = X
+        const double *x = lg_ptr(a.X, cell, bi, bj);
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int i = idx >> 6, j = idx & 63;
+            c[(size_t)i * a.C.ld + j] = x[(size_t)i * a.X.ld + j];
+            c[a.C.plane + (size_t)i * a.C.ld + j] = x[a.X.plane + (size_t)i * a.X.ld + j];
+        }
+        return;
+    }
+    Strip<4> acc;
+    strip_zero(acc);
+    for (int kb = 0; kb < a.kblocks; ++kb) {
+        const double *x = lg_ptr(a.X, cell, bi, kb);
+        const double *y = lg_ptr(a.Y, cell, kb, bj);
+        __syncthreads();
+        for (int idx = tid; idx < 64 * 32; idx += 256) {   // 16-byte loads: 2 columns at a time
+            const int i = idx >> 5, j = (idx & 31) * 2;
+            const double2 vr = *(const double2 *)(x + (size_t)i * a.X.ld + j);
+            const double2 vi = *(const double2 *)(x + a.X.plane + (size_t)i * a.X.ld + j);
+            Xre[i * LD + j] = vr.x; Xre[i * LD + j + 1] = vr.y;
+            Xim[i * LD + j] = vi.x; Xim[i * LD + j + 1] = vi.y;
+        }
+        Strip<4> B;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = (size_t)(16 * t + 4 * r + rg) * a.Y.ld + col;
+                B.re[t][r] = y[o];
+                B.im[t][r] = y[a.Y.plane + o];
+            }
+        __syncthreads();
+        gemm_xb<4, LD>(acc, Xre, Xim, B, lane);
+    }
+    const int grow0 = (a.C.rb + bi) * 64, gcol = (a.C.cb + bj) * 64 + col;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * r + rg;
+            const size_t o = (size_t)row * a.C.ld + col;
+            double vr = a.alpha * acc.re[t][r], vi = a.alpha * acc.im[t][r];
+            if (a.beta != 0.0) { vr += a.beta * c[o]; vi += a.beta * c[a.C.plane + o]; }
+            for (int q = 0; q < a.nadd; ++q) {
+                const double *ad = lg_ptr(a.Add[q], cell, bi, bj);
+                const size_t oa = (size_t)row * a.Add[q].ld + col;
+                vr += a.coef[q] * ad[oa];
+                vi += a.coef[q] * ad[a.Add[q].plane + oa];
+            }
+            if (a.cI != 0.0 && grow0 + row == gcol) vr += a.cI;
+            c[o] = vr;
+            c[a.C.plane + o] = vi;
+        }
+}
+
+// out = sum_i coef[i] * In_i  (whole NP x NP matrices, both planes)
+struct LgLincombArgs {
+    double *out;
+    const double *in[3];
+    double coef[3];
+    int nin;
+    size_t n;   // doubles per cell (2 * NP * NP) * cells
+};
+__global__ void lg_lincomb_kernel(LgLincombArgs a) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = 0.;
+        for (int q = 0; q < a.nin; ++q) v += a.coef[q] * a.in[q][i];
+        a.out[i] = v;
+    }
+}
+
+// A = -i dt (H0_k + sum_l e_l H_l) for the cells [cell0, cell0 + ncell) of the chunk; then ||A||_1,
+// squaring count s and the scaling A *= 2^-s.  One 256-thread workgroup per cell.
+struct LgFormArgs {
+    const double *H0f, *Hcf, *eps, *shape, *dts;
+    double *A;            // [ncell][2][NP*NP]
+    int *s_cell;          // [ncell]
+    unsigned long long *stats;
+    int *flags;
+    int NP, L, N_T, hc_per_traj, cell0;
+};
+__global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
+    __shared__ double colsum[256];
+    __shared__ double snorm;
+    const int tid = threadIdx.x, NP = a.NP;
+    const int cell = a.cell0 + blockIdx.x;
+    const int k = cell / a.N_T, n = cell - k * a.N_T;
+    const double dt = a.dts[n];
+    const size_t pp = (size_t)NP * NP;
+    const double *h0 = a.H0f + (size_t)k * 2 * pp;
+    const double *hc = a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * pp;
+    double *A = a.A + (size_t)blockIdx.x * 2 * pp;
+    double e[8];
+    for (int l = 0; l < a.L; ++l) {
+        e[l] = a.eps[(size_t)l * a.N_T + n];
+        if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
+    }
+    // thread j owns column j (NP <= 256): column sums need no reduction; rows are walked serially
+    double cs = 0.;
+    for (int i = 0; i < NP; ++i) {
+        if (tid < NP) {
+            const size_t o = (size_t)i * NP + tid;
+            double hr = h0[o], hi = h0[pp + o];
+            for (int l = 0; l < a.L; ++l) {
+                hr = fma(e[l], hc[(size_t)l * 2 * pp + o], hr);
+                hi = fma(e[l], hc[(size_t)l * 2 * pp + pp + o], hi);
+            }
+            const double ar = dt * hi, ai = -dt * hr;
+            A[o] = ar;
+            A[pp + o] = ai;
+            cs += sqrt(ar * ar + ai * ai);
+        }
+    }
+    colsum[tid] = tid < NP ? cs : 0.;
+    __syncthreads();
+    if (tid == 0) {
+        double m = 0.;
+        for (int j = 0; j < NP; ++j) m = fmax(m, colsum[j]);
+        snorm = m;
+    }
+    __syncthreads();
+    const double nA = snorm;
+    int s = 0;
+    if (nA > 5.4) {
+        const double r = nA / 5.4;
+        const int ex = ilogb(r);
+        s = (r == ldexp(1.0, ex)) ? ex : ex + 1;
+    }
+    if (s > 0) {
+        const double f = ldexp(1.0, -s);
+        for (size_t i = tid; i < 2 * pp; i += 256) A[i] *= f;
+    }
+    if (tid == 0) {
+        a.s_cell[blockIdx.x] = s;
+        atomicAdd(&a.stats[0], (unsigned long long)s);
+        atomicAdd(&a.stats[7], 1ull);   // the blocked path always evaluates the order-13 approximant
+        atomicMax(&a.flags[1], s);
+    }
+}
+
+// Dinv = inverse of the 64x64 block (jb, jb) of Q, one workgroup per cell (fused-kernel solver, P = I)
+struct LgInvArgs {
+    LgView Q;         // view positioned at block (jb, jb)
+    double *Dinv;     // [ncell][2][64*64]
+    int *flags;
+    double inv_scale2;
+};
+__global__ void __launch_bounds__(256) lg_inv64_kernel(LgInvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem_inv[];
+    double *pan = smem_inv;                    // 3 panel slots of 2*64*18 doubles
+    double *dv = pan + 3 * 2 * 64 * 18;        // 3 x 512 doubles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cell = blockIdx.x;
+    const double *q = lg_ptr(a.Q, cell, 0, 0);
+    const int col = 16 * wave + (lane & 15), rg = lane >> 4;
+    Strip<4> Q, P;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * r + rg;
+            Q.re[t][r] = q[(size_t)row * a.Q.ld + col];
+            Q.im[t][r] = q[a.Q.plane + (size_t)row * a.Q.ld + col];
+            P.re[t][r] = row == col ? 1.0 : 0.0;
+            P.im[t][r] = 0.0;
+        }
+    double minrel = 1e300;
+    block_gj_solve<4>(Q, P, pan, dv, wave, lane, minrel, a.inv_scale2, true);
+    double *d = a.Dinv + (size_t)cell * 2 * 4096;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + 4 * r + rg;
+            d[row * 64 + col] = P.re[t][r];
+            d[4096 + row * 64 + col] = P.im[t][r];
+        }
+    if (lane == 0 && !(minrel > 1e-20)) atomicOr(&a.flags[0], 1);
+}
+
+// planar chunk result -> U[cell0 + i] (row-major interleaved complex)
+__global__ void lg_store_u_kernel(const double *X, double2 *U, int NP, size_t ncell_elems) {
+    const size_t pp = (size_t)NP * NP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ncell_elems; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t cell = i / pp, o = i - cell * pp;
+        U[i] = make_double2(X[cell * 2 * pp + o], X[cell * 2 * pp + pp + o]);
+    }
+}
+
+// ---- sweeps for NP in {128, 256}: one 1024-thread workgroup per trajectory ----
+template <bool BACKWARD>
+__global__ void __launch_bounds__(1024) sweep_lg_kernel(SweepArgs a, int NP) {
+    constexpr int NW = 16;
+    __shared__ double2 x[2][256];
+    __shared__ double2 part[8][256];
+    __shared__ double sc[2];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double2 *Uk = a.U + (size_t)k * a.N_T * NP * NP;
+    double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
+    if (!BACKWARD) {
+        if (tid < NP) {
+            const double2 v = tid < a.N ? a.psi0[(size_t)k * a.N + tid] : make_double2(0., 0.);
+            x[0][tid] = v;
+            st[tid] = v;
+        }
+    } else {
+        const double w = a.weights ? a.weights[k] : 1.0;
+        const double Kt = (double)a.K_total;
+        double cr, ci;
+        if (a.functional == 0) { cr = w * a.f[0] / (Kt * Kt); ci = w * a.f[1] / (Kt * Kt); }
+        else if (a.functional == 1) { const double2 t = a.tau[k]; cr = w * t.x / Kt; ci = w * t.y / Kt; }
+        else { cr = w / (2.0 * Kt); ci = 0.; }
+        double2 v = make_double2(0., 0.);
+        if (tid < a.N) {
+            const double2 t = a.target[(size_t)k * a.N + tid];
+            v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+        }
+        if (tid < 256) part[0][tid] = make_double2(v.x * v.x + v.y * v.y, 0.);
+        __syncthreads();
+        if (tid == 0) {
+            double n2 = 0.;
+            for (int i = 0; i < NP; ++i) n2 += part[0][i].x;
+            sc[0] = sqrt(n2);
+        }
+        __syncthreads();
+        const double rho = sc[0];
+        if (tid == 0) {
+            a.rho[k] = rho;
+            if (rho < a.chi_min_norm) atomicOr(&a.flags[0], 2);
+        }
+        if (tid < NP) {
+            const double ir = rho > 0. ? 1.0 / rho : 0.;
+            v.x *= ir; v.y *= ir;
+            x[0][tid] = v;
+            st[(size_t)a.N_T * NP + tid] = v;
+        }
+    }
+    __syncthreads();
+    const int CHN = NP / 64;      // column chunks per lane
+    const int RW = NP / NW;       // rows per wave (forward)
+    int cur = 0;
+    for (int step = 0; step < a.N_T; ++step) {
+        const int n = BACKWARD ? a.N_T - 1 - step : step;
+        const double2 *Un = Uk + (size_t)n * NP * NP;
+        if (!BACKWARD) {
+            for (int r = 0; r < RW; ++r) {
+                const int row = wave * RW + r;
+                double pr = 0., pi = 0.;
+                for (int cc = 0; cc < CHN; ++cc) {
+                    const double2 u = Un[(size_t)row * NP + cc * 64 + lane];
+                    const double2 xv = x[cur][cc * 64 + lane];
+                    pr += u.x * xv.x - u.y * xv.y;
+                    pi += u.x * xv.y + u.y * xv.x;
+                }
+                pr = wave_sum_dpp(pr);
+                pi = wave_sum_dpp(pi);
+                if (lane == 0) x[cur ^ 1][row] = make_double2(pr, pi);
+            }
+            __syncthreads();
+            if (tid < NP) st[(size_t)(n + 1) * NP + tid] = x[cur ^ 1][tid];
+        } else {
+            const int j = tid % NP, q = tid / NP, NQ = 1024 / NP;   // column, row part
+            double ar = 0., ai = 0.;
+            for (int i = q; i < NP; i += NQ) {
+                const double2 u = Un[(size_t)i * NP + j];
+                const double2 xi = x[cur][i];
+                ar += u.x * xi.x + u.y * xi.y;
+                ai += u.x * xi.y - u.y * xi.x;
+            }
+            part[q][j] = make_double2(ar, ai);
+            __syncthreads();
+            if (tid < NP) {
+                double2 s = part[0][tid];
+                for (int qq = 1; qq < NQ; ++qq) { s.x += part[qq][tid].x; s.y += part[qq][tid].y; }
+                x[cur ^ 1][tid] = s;
+                st[(size_t)n * NP + tid] = s;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (!BACKWARD) {
+        if (tid < 256) {
+            double pr = 0., pi = 0.;
+            if (tid < a.N) {
+                const double2 t = a.target[(size_t)k * a.N + tid];
+                const double2 p = x[cur][tid];
+                pr = t.x * p.x + t.y * p.y;
+                pi = t.x * p.y - t.y * p.x;
+            }
+            part[0][tid] = make_double2(pr, pi);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sr = 0., si = 0.;
+            for (int i = 0; i < NP; ++i) { sr += part[0][i].x; si += part[0][i].y; }
+            a.tau[k] = make_double2(sr, si);
+        }
+    }
+}

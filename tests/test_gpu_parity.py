@@ -82,10 +82,37 @@ def test_random_problems_vs_c_oracle(g, ref, case):
     assert np.abs(tg - parts["tau_grads"]).max() <= 1e-10 * max(np.abs(parts["tau_grads"]).max(), 1e-3)
 
 
+LARGE = [  # blocked path (64 < N <= 256): N, L, N_T, K, dt, hermitian, functional
+    (65, 1, 3, 2, 1.0, True, 0),
+    (100, 2, 4, 2, 1.0, False, 1),
+    (128, 2, 3, 2, 3.0, True, 2),
+    (200, 3, 3, 1, 1.0, True, 0),
+    (256, 4, 3, 2, 1.0, True, 0),     # C5-like
+]
+
+
+@pytest.mark.parametrize("case", LARGE, ids=[f"N{c[0]}_L{c[1]}_dt{c[4]}_{'h' if c[5] else 'nh'}_f{c[6]}" for c in LARGE])
+def test_blocked_path_vs_c_oracle(g, ref, case):
+    """N > 64 runs the blocked (batched block-GEMM) variant; the oracle's :taylor route is the checker
+    (the literal (L+1)N block exponential is too slow at these sizes; both oracle routes are pinned
+    against each other in tests/test_oracle.py)."""
+    from grape_jl_amd import synth
+    N, L, N_T, K, dt, herm, f = case
+    pr = synth.make_problem(N, L, N_T, K, seed=2000 + N, dt=dt, hermitian=herm)
+    J, G, tau, psiT, tg = hip_eval(g, pr, f, 0)
+    Jr, Gr, taur, parts = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                                       pr["weights"], functional=f, gradient_method=ref.TAYLOR, want_parts=True)
+    assert abs(J - Jr) <= TOL_J
+    assert np.abs(tau - taur).max() <= TOL_TAU
+    assert np.abs(G - Gr).max() <= tol_G(Gr)
+    assert np.abs(psiT - parts["psiT"]).max() <= 1e-12
+
+
 def test_expm_kernel_vs_scipy(g):
     """The ExpProp step itself (optimize.jl:732): U_kn = exp(-i H_kn dt_n), every Pade branch."""
     from grape_jl_amd import synth
-    for N, dt in [(16, 0.002), (16, 0.05), (32, 0.3), (64, 0.45), (64, 1.0), (64, 3.0), (64, 25.0)]:
+    for N, dt in [(16, 0.002), (16, 0.05), (32, 0.3), (64, 0.45), (64, 1.0), (64, 3.0), (64, 25.0), (96, 1.0),
+                  (256, 0.02), (256, 1.0), (256, 6.0)]:
         pr = synth.make_problem(N, 2, 3, 2, seed=77, dt=dt)
         with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"]) as h:
             h.eval(pr["pulsevals"], gradient=False)
@@ -140,8 +167,8 @@ def test_error_behaviour(g):
         with pytest.raises(g.GrapeHipError) as ei:
             h.eval(pr["pulsevals"])
         assert ei.value.code == -5
-    with pytest.raises(g.GrapeHipError):  # N > 64 is refused loudly, not emulated
-        pr = synth.make_problem(65, 1, 2, 1, seed=1)
+    with pytest.raises(g.GrapeHipError):  # N > 256 is refused loudly, not emulated
+        pr = synth.make_problem(257, 1, 2, 1, seed=1)
         g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"])
 
 
