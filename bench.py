@@ -85,7 +85,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with a single rank)
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -93,7 +93,7 @@ def main():
         dist = dist_mod
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if dist is not None else 0)
 
     N, L, N_T, K0 = synth.CONFIGS[args.config]
     K_local = args.traj_per_gpu or K0
