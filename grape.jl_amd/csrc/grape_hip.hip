@@ -35,7 +35,10 @@ struct grape_handle {
     hipStream_t stream = nullptr;
     // static problem
     double *d_H0f = nullptr, *d_Hcf = nullptr, *d_H0t = nullptr, *d_Hct = nullptr;
-    double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;  // MFMA-fragment-packed H^dagger, series scratch
+    double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;
+    int *d_lowflag = nullptr;   // cells the two-workgroup order-13 kernel leaves to the general kernel
+    double *d_spill = nullptr;  // its strip spill area [512][5][32][256]
+    bool use_2wg = false;  // MFMA-fragment-packed H^dagger, series scratch
     int deriv_blocks = 0;
     // blocked path (64 < N <= 256): per-chunk scratch matrices, planar [cell][2][NP*NP]
     bool large = false;
