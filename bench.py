@@ -96,7 +96,8 @@ def main():
     dev = torch.device("cuda", local_rank if dist is not None else 0)
 
     N, L, N_T, K0 = synth.CONFIGS[args.config]
-    K_local = args.traj_per_gpu or K0
+    per_gpu_default = {"C4": 128, "C5": 8}   # BASELINE.json: C4 = 1024 and C5 = 64 trajectories over 8 GPUs
+    K_local = args.traj_per_gpu or per_gpu_default.get(args.config, K0)
     K_total = K_local * world
     pr = synth.make_config(args.config, K=K_local, k_offset=rank * K_local)
     h = g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"],
@@ -160,7 +161,8 @@ def main():
                        "one_eval": "one shard evaluation = functional + full gradient of 128 trajectories; "
                                    "value counts shard evaluations completed by all ranks per second",
                        "global_problem_evals_per_s": args.steps / elapsed},
-            "roofline": {"bound": "mfma", "kernel": "expm_pade_kernel<4> (v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": ("expm_pade_kernel<%d>" % ((N + 15) // 16 if N <= 32 else 4) if N <= 64
+                                                     else "lg_gemm_kernel chain (blocked Pade-13)") + " (v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.json); "
