@@ -188,7 +188,9 @@ hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, 
     a.nadd = nadd;
     for (int i = 0; i < nadd; ++i) { a.Add[i] = add[i]; a.coef[i] = coef[i]; }
     a.s_cell = s_cell; a.sq_iter = sq_iter;
-    hipLaunchKernelGGL(lg_gemm_kernel, dim3(nbj, nbi, nc), dim3(256), 0, s, a);
+    a.nbi = nbi; a.nbj = nbj; a.ncell = nc;
+    const int groups = (nc + 7) / 8;   // cells are dealt to the 8 XCDs in groups
+    hipLaunchKernelGGL(lg_gemm_kernel, dim3(groups * 8 * nbi * nbj), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

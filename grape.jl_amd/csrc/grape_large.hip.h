@@ -25,6 +25,7 @@ struct LgGemmArgs {
     double coef[3];
     double alpha, beta, cI;
     int nadd, kblocks;
+    int nbi, nbj, ncell; // output blocks per cell and cells in this launch
     const int *s_cell;   // optional: squarings per cell; cells with s_cell[cell] <= sq_iter copy X instead
     int sq_iter;
 };
@@ -33,12 +34,19 @@ __device__ __forceinline__ double *lg_ptr(const LgView &v, int cell, int brow, i
     return v.p + (size_t)cell * v.cell_stride + (size_t)(v.rb + brow) * 64 * v.ld + (size_t)(v.cb + bcol) * 64;
 }
 
-__global__ void __launch_bounds__(256) lg_gemm_kernel(LgGemmArgs a) {
+__global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 workgroups per CU: one loads while the other issues MFMAs
     constexpr int LD = 66;
     __shared__ double Xre[64 * LD], Xim[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bj = blockIdx.x, bi = blockIdx.y, cell = blockIdx.z;
+    // XCD-aware 1-D grid: the nbi*nbj blocks of one cell share blockIdx % 8, i.e. one XCD and its L2,
+    // so that the row panels of X and the column panels of Y are fetched from HBM once per cell.
+    const int per_cell = a.nbi * a.nbj;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int cell = (q / per_cell) * 8 + xcd;
+    if (cell >= a.ncell) return;
+    const int rem = q % per_cell;
+    const int bi = rem / a.nbj, bj = rem - bi * a.nbj;
     const int col = 16 * wave + (lane & 15), rg = lane >> 4;
     double *c = lg_ptr(a.C, cell, bi, bj);
     if (a.s_cell && a.s_cell[cell] <= a.sq_iter) {   // no (further) squaring for this cell: C = X
