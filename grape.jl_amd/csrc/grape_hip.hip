@@ -54,6 +54,7 @@ struct grape_handle {
     double *d_out = nullptr;  // [2K + 4] tau + partial sums (host API)
     double *d_f = nullptr, *d_G = nullptr, *d_rho = nullptr;
     int *d_flags = nullptr;
+    int *d_cellflag = nullptr;   // [K*N_T] cells flagged for the pivoted Pade solve
     unsigned long long *d_stats = nullptr;
     double *h_pin = nullptr;  // pinned staging
     size_t h_pin_doubles = 0;
@@ -93,12 +94,20 @@ hipError_t launch_expm(const ExpmArgs &a, hipStream_t s) {
     int dev = 0;
     hipGetDevice(&dev);
     if (!attr_set[dev & 7]) {
-        hipError_t e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT>,
+        hipError_t e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev & 7] = true;
     }
-    hipLaunchKernelGGL(expm_pade_kernel<NT>, dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
+    hipError_t e = hipMemsetAsync(a.cellflag, 0, (size_t)a.K * a.N_T * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    // fast pass: unpivoted block Gauss-Jordan, flags the cells it cannot solve safely
+    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
+    // pivoted pass over the flagged cells (all other workgroups exit at once)
+    hipLaunchKernelGGL((expm_pade_kernel<NT, true>), dim3(std::min(a.K * a.N_T, 1024)), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -313,7 +322,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -473,6 +482,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_out, (size_t)2 * K + 4));
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, 16));
+    CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
     CCHK(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
     CCHK(hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long)));
     CCHK(hipMemset(h->d_fw, 0, (size_t)K * (N_T + 1) * NP * 16));
@@ -496,7 +506,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     // ---- phase 0: expm of every cell ----
     ExpmArgs ea{};
     ea.H0f = h->d_H0f; ea.Hcf = h->d_Hcf; ea.eps = h->d_eps; ea.shape = h->d_shape; ea.dts = h->d_dts;
-    ea.U = h->d_U; ea.flags = h->d_flags; ea.stats = h->d_stats;
+    ea.U = h->d_U; ea.flags = h->d_flags; ea.stats = h->d_stats; ea.cellflag = h->d_cellflag;
     ea.K = h->K; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
 #ifdef GRAPE_DIAG
     ea.ablate = getenv("GRAPE_DIAG_ABLATE") ? atoi(getenv("GRAPE_DIAG_ABLATE")) : 0;
@@ -774,6 +784,7 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     // derivative series: per order (1 + 2L) complex mat-vecs of 8 N^2 flop
     out[3] = (double)st[8] * (1.0 + 2.0 * h->L) * 8.0 * N2;
     if (n > 4) out[4] = (double)st[8];  // sum of series orders
+    if (n > 5) out[5] = (double)st[9];  // cells solved by the pivoted fallback
     return 4;
 }
 

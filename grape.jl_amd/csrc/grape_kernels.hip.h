@@ -51,6 +51,7 @@ struct ExpmArgs {
     int *flags;          // [0] error flag (|=), [1] max squarings
     unsigned long long *stats; // [0] sum of squarings, [3..7] #cells with Pade order 3/5/7/9/13
     int K, L, N_T, hc_per_traj;
+    int *cellflag;       // [K*N_T] set by the fast kernel for cells that need the pivoted solve
 #ifdef GRAPE_DIAG
     int ablate;  // diagnostic builds only (tools/ablate.sh): bit0 skip invert16, bit1 skip solve
     unsigned long long *stamps;  // [nblocks][16] s_memtime at phase boundaries (diagnostic builds only)
@@ -398,6 +399,81 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
     }
 }
 
+// Robust fallback: Q X = P by Gaussian elimination with partial pivoting (LAPACK gesv semantics),
+// both matrices in LDS (planar, leading dimension LD), all NTH threads.  X overwrites P.
+// `scr` needs 2 * NP + 8 doubles.  Returns false when a pivot is exactly zero.  Slow (hundreds of
+// barriers) by design: it only runs for cells whose unpivoted elimination was flagged.
+template <int NP, int LD, int NTH>
+__device__ __forceinline__ bool pivoted_solve_lds(double *Qre, double *Qim, double *Pre, double *Pim, double *scr, int tid) {
+    double *mr = scr, *mi = scr + NP;   // multipliers of the current step
+    int *piv = (int *)(scr + 2 * NP);
+    bool ok = true;
+    for (int k = 0; k < NP; ++k) {
+        if (tid == 0) {   // pivot search down column k
+            int p = k;
+            double best = Qre[k * LD + k] * Qre[k * LD + k] + Qim[k * LD + k] * Qim[k * LD + k];
+            for (int i = k + 1; i < NP; ++i) {
+                const double v = Qre[i * LD + k] * Qre[i * LD + k] + Qim[i * LD + k] * Qim[i * LD + k];
+                if (v > best) { best = v; p = i; }
+            }
+            piv[0] = p;
+            piv[1] = best > 0. ? 1 : 0;
+        }
+        __syncthreads();
+        const int p = piv[0];
+        if (!piv[1]) ok = false;
+        if (p != k) {
+            for (int j = tid; j < 2 * NP; j += NTH) {
+                double *re = j < NP ? Qre : Pre, *im = j < NP ? Qim : Pim;
+                const int c = j < NP ? j : j - NP;
+                const double tr_ = re[k * LD + c], ti_ = im[k * LD + c];
+                re[k * LD + c] = re[p * LD + c]; im[k * LD + c] = im[p * LD + c];
+                re[p * LD + c] = tr_; im[p * LD + c] = ti_;
+            }
+            __syncthreads();
+        }
+        {   // multipliers m_i = q_ik / q_kk
+            const double pr = Qre[k * LD + k], pi = Qim[k * LD + k];
+            const double den = pr * pr + pi * pi, inv = den > 0. ? 1.0 / den : 0.;
+            for (int i = k + 1 + tid; i < NP; i += NTH) {
+                const double ar = Qre[i * LD + k], ai = Qim[i * LD + k];
+                mr[i] = (ar * pr + ai * pi) * inv;
+                mi[i] = (ai * pr - ar * pi) * inv;
+            }
+        }
+        __syncthreads();
+        // row_i -= m_i * row_k over the remaining columns of Q and all columns of P
+        const int ncol = (NP - 1 - k) + NP;
+        for (int idx = tid; idx < (NP - 1 - k) * ncol; idx += NTH) {
+            const int i = k + 1 + idx / ncol, cc = idx % ncol;
+            double *re = cc < NP - 1 - k ? Qre : Pre, *im = cc < NP - 1 - k ? Qim : Pim;
+            const int c = cc < NP - 1 - k ? k + 1 + cc : cc - (NP - 1 - k);
+            const double xr = re[k * LD + c], xi = im[k * LD + c];
+            re[i * LD + c] -= mr[i] * xr - mi[i] * xi;
+            im[i * LD + c] -= mr[i] * xi + mi[i] * xr;
+        }
+        __syncthreads();
+    }
+    // back substitution, one thread per right-hand-side column
+    for (int j = tid; j < NP; j += NTH) {
+        for (int k = NP - 1; k >= 0; --k) {
+            double sr = Pre[k * LD + j], si = Pim[k * LD + j];
+            for (int i = k + 1; i < NP; ++i) {
+                const double qr = Qre[k * LD + i], qi = Qim[k * LD + i];
+                const double xr = Pre[i * LD + j], xi = Pim[i * LD + j];
+                sr -= qr * xr - qi * xi;
+                si -= qr * xi + qi * xr;
+            }
+            const double pr = Qre[k * LD + k], pi = Qim[k * LD + k];
+            const double den = pr * pr + pi * pi, inv = den > 0. ? 1.0 / den : 0.;
+            Pre[k * LD + j] = (sr * pr + si * pi) * inv;
+            Pim[k * LD + j] = (si * pr - sr * pi) * inv;
+        }
+    }
+    __syncthreads();
+    return ok;
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     // bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous run of cells
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
@@ -417,8 +493,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 #define STAMP(i) do {} while (0)
 #endif
 
-template <int NT>
-__global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
+template <int NT, bool PIVOTED>
+__device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
     constexpr int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *Are = smem;          // A = -i dt H stays resident (left operand of A*A and A*T)
@@ -432,8 +508,6 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     double *red = Dv + 1536;     // NTH + 8 + NP doubles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ncell = a.K * a.N_T;
-    const int cell = xcd_remap(blockIdx.x, ncell);
     const int k = cell / a.N_T, n = cell - k * a.N_T;
     const double dt = a.dts[n];
     STAMP(0);
@@ -505,6 +579,11 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     Strip<NT> Pn, Qn;  // numerator P = V+U, denominator Q = V-U
     int order;
     double inv_b0sq;  // 1 / b0^2 of the Pade order in use: scale of the pivots of q(A) ~ b0 exp(-A/2)
+    // The fast instantiation (PIVOTED = false) solves the Pade system with the unpivoted block
+    // Gauss-Jordan; if a pivot turns out numerically unsafe (e.g. a pi-pulse in one step: q(A) has a zero
+    // diagonal) it flags the cell, and the PIVOTED instantiation, launched afterwards over the flagged
+    // cells only, re-evaluates P and Q and solves with full partial pivoting in LDS (what LAPACK gesv
+    // does in the reference).
     if (nA > 2.1) {
         order = 13;
         inv_b0sq = 1.0 / (B13_0 * B13_0);
@@ -604,15 +683,29 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
         }
     }
 
-    // ---- solve (V-U) X = (V+U): block Gauss-Jordan on MFMA; LDS X region doubles as panel ----
+    // ---- solve (V-U) X = (V+U) ----
     STAMP(8);
-    double minrel = 1e300;
-    // staging region = the X planes (3 panel slots fit: 3 * 2 * NP * 18 <= 2 * NP * LD); inverses in Dv
+    if constexpr (!PIVOTED) {
+        // block Gauss-Jordan on MFMA; the X planes double as panel slots (3 * 2 * NP * 18 <= 2 * NP * LD)
+        double minrel = 1e300;
 #ifdef GRAPE_DIAG
-    if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, Xre, Dv, wave, lane, minrel, inv_b0sq, !(a.ablate & 1));
+        if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, Xre, Dv, wave, lane, minrel, inv_b0sq, !(a.ablate & 1));
 #else
-    block_gj_solve<NT>(Qn, Pn, Xre, Dv, wave, lane, minrel, inv_b0sq, true);
+        block_gj_solve<NT>(Qn, Pn, Xre, Dv, wave, lane, minrel, inv_b0sq, true);
 #endif
+        // |pivot| < 1e-3 b0 (or NaN) in any of the diagonal tiles -> flag the cell for the pivoted pass
+        if (lane == 0 && !(minrel > 1e-6)) a.cellflag[cell] = 1;
+    } else {
+        __syncthreads();
+        strip_store_lds<NT, LD>(Xre, Xim, Qn, wave, lane);   // Q -> X planes
+        strip_store_lds<NT, LD>(Are, Aim, Pn, wave, lane);   // P -> A planes (A is dead by now)
+        __syncthreads();
+        const bool ok = pivoted_solve_lds<NP, LD, NTH>(Xre, Xim, Are, Aim, red, tid);
+        strip_load_lds<NT, LD>(Are, Aim, Pn, wave, lane);    // X = Q^-1 P
+        if (!ok && tid == 0) atomicOr(&a.flags[0], 1);       // exactly singular denominator
+        if (tid == 0) atomicAdd(&a.stats[9], 1ull);          // cells that needed the pivoted solve
+        __syncthreads();
+    }
     STAMP(9);
     // ---- squarings ----
     for (int it = 0; it < s; ++it) {
@@ -639,14 +732,25 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     }
     STAMP(10);
     // ---- bookkeeping ----
-    if (lane == 0 && wave < NT) {
-        // min over waves that inverted a diagonal tile
-        if (!(minrel > 1e-20)) atomicOr(&a.flags[0], 1);  // |pivot| < 1e-10 b0: numerically singular denominator
-    }
-    if (tid == 0) {
+    if (!PIVOTED && tid == 0) {
         atomicAdd(&a.stats[0], (unsigned long long)s);
         atomicAdd(&a.stats[3 + (order == 13 ? 4 : (order - 3) / 2)], 1ull);
         atomicMax(&a.flags[1], s);
+    }
+}
+
+template <int NT, bool PIVOTED>
+__global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
+    const int ncell = a.K * a.N_T;
+    if constexpr (!PIVOTED) {
+        expm_cell<NT, false>(a, xcd_remap(blockIdx.x, ncell));   // one workgroup per cell
+    } else {
+        // second pass, small grid: every workgroup scans a slice of the flags and re-solves flagged cells
+        for (int cell = blockIdx.x; cell < ncell; cell += gridDim.x) {
+            if (!a.cellflag[cell]) continue;
+            __syncthreads();
+            expm_cell<NT, true>(a, cell);
+        }
     }
 }
 

@@ -246,3 +246,34 @@ def test_device_pointer_api_matches_host_api(g):
         assert tm["expm"] > 0 and tm["deriv"] > 0
         w = h.work()
         assert w["cells"] == 36 and w["flop_expm"] > 0
+
+
+def test_pivoted_fallback_for_unsafe_pade_denominators(g, ref):
+    """Cells whose Pade denominator q(A) defeats unpivoted elimination (a pi-pulse in ONE time step makes
+    its diagonal vanish) are re-solved with partial pivoting (LAPACK gesv semantics of the reference)."""
+    sx = np.array([[0, 1], [1, 0]], complex)
+    sz = np.array([[1, 0], [0, -1]], complex)
+    H0 = 1e-3 * sz[None]
+    Hc = sx[None]
+    tlist = np.array([0.0, 1.0, 2.0, 3.0])
+    x = np.array([np.pi, 0.3, np.pi / 2 * 2])     # A = -i pi sigma_x (+ tiny drift) on steps 0 and 2
+    psi0 = np.array([[1, 0]], complex)
+    tgt = np.array([[0.6, 0.8j]], complex)
+    with g.GrapeHip(H0, Hc, tlist, psi0, tgt) as h:
+        J, G, tau = h.eval(x)
+        assert h.work()["pivoted_cells"] >= 2
+    Jr, Gr, taur = ref.evaluate(H0, Hc, tlist, x, psi0, tgt, gradient_method=ref.GRADGEN)
+    assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr)
+    # N = 64: a cyclic-shift generator (every diagonal tile of q(A) is badly conditioned)
+    N = 64
+    S = np.roll(np.eye(N), 1, axis=1)
+    Hs = (S + S.T).astype(complex)
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, 1, 3, 1, seed=5)
+    pr["H0"] = (2.0 * Hs + 0.01 * pr["H0"][0])[None]
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"]) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        npiv = h.work()["pivoted_cells"]
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                                gradient_method=ref.TAYLOR)
+    assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr), npiv
