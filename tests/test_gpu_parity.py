@@ -277,3 +277,17 @@ def test_pivoted_fallback_for_unsafe_pade_denominators(g, ref):
     Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
                                 gradient_method=ref.TAYLOR)
     assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr), npiv
+
+
+def test_two_rank_sharded_device_path(g):
+    """Two processes, each with its own trajectory shard and handle, real collectives (gloo on CUDA
+    tensors: both ranks share the one GPU of this box) through ShardedEvaluator.eval_device -- the exact
+    loop bench.py runs per rank with RCCL."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "tools", "two_rank_gpu.py")]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "two-rank sharded device path OK" in res.stdout
