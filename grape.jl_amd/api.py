@@ -19,7 +19,7 @@ _LIBNAME = "libgrape_hip.so"
 
 J_T_SM, J_T_SS, J_T_RE = 0, 1, 2
 GRAD_GRADGEN, GRAD_TAYLOR = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAPE_ERR_CHI_NORM",
           -4: "GRAPE_ERR_SINGULAR", -5: "GRAPE_ERR_TAYLOR", -6: "GRAPE_ERR_NO_CONTROLS"}
@@ -44,7 +44,8 @@ class _Problem(C.Structure):
                 ("tlist", C.c_void_p), ("H0", C.c_void_p), ("Hc", C.c_void_p), ("shape", C.c_void_p),
                 ("psi0", C.c_void_p), ("target", C.c_void_p), ("weights", C.c_void_p),
                 ("chi_min_norm", C.c_double), ("taylor_max_order", C.c_int32),
-                ("taylor_tolerance", C.c_double)]
+                ("taylor_tolerance", C.c_double),
+                ("Dpen", C.c_void_p), ("dpen_per_traj", C.c_int32), ("lambda_b", C.c_double)]
 
 
 def library_path() -> str:
@@ -120,7 +121,7 @@ class GrapeHip:
 
     def __init__(self, H0, Hc, tlist, psi0, target, weights=None, functional=J_T_SM,
                  gradient_method=GRAD_GRADGEN, shape=None, K_total=None, device=0,
-                 chi_min_norm=0.0, taylor_max_order=0, taylor_tolerance=0.0):
+                 chi_min_norm=0.0, taylor_max_order=0, taylor_tolerance=0.0, D=None, lambda_b=0.0):
         self._lib = load_library()
         H0 = np.asarray(H0)
         K, N = H0.shape[0], H0.shape[1]
@@ -152,6 +153,15 @@ class GrapeHip:
         p.target = self._target.ctypes.data
         p.weights = None if self._weights is None else self._weights.ctypes.data
         p.chi_min_norm, p.taylor_max_order, p.taylor_tolerance = chi_min_norm, taylor_max_order, taylor_tolerance
+        # state running cost g_b = <Psi|D|Psi> (D: [N, N] shared or [K, N, N]), weight lambda_b
+        self._D = None
+        self.lambda_b = float(lambda_b) if D is not None else 0.0
+        if D is not None:
+            D = np.asarray(D)
+            self._D = _c128(np.swapaxes(D, -1, -2))
+            p.Dpen = self._D.ctypes.data
+            p.dpen_per_traj = int(D.ndim == 3)
+            p.lambda_b = self.lambda_b
         self._h = C.c_void_p()
         rc = self._lib.grape_create(C.byref(self._h), C.byref(p))
         if rc:

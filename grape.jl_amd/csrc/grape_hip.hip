@@ -55,6 +55,10 @@ struct grape_handle {
     double *d_f = nullptr, *d_G = nullptr, *d_rho = nullptr;
     int *d_flags = nullptr;
     int *d_cellflag = nullptr;   // [K*N_T] cells flagged for the pivoted Pade solve
+    // state running cost (g_b = <Psi|D|Psi>): transposed D, trapezoid weights, xi and g per stored state
+    double2 *d_Dt = nullptr, *d_xi = nullptr;
+    double *d_wq = nullptr, *d_gb = nullptr;
+    bool have_gb = false;
     unsigned long long *d_stats = nullptr;
     double *h_pin = nullptr;  // pinned staging
     size_t h_pin_doubles = 0;
@@ -322,7 +326,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -479,7 +483,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_fw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_bw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_tg, (size_t)K * L * N_T));
-    CCHK(dmalloc(&h->d_out, (size_t)2 * K + 4));
+    CCHK(dmalloc(&h->d_out, (size_t)2 * K + 8));
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, 16));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
@@ -489,6 +493,27 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(hipMemset(h->d_bw, 0, (size_t)K * (N_T + 1) * NP * 16));
     CCHK(hipMemset(h->d_tg, 0, (size_t)K * L * N_T * 16));
     h->h_pin_doubles = (size_t)L * N_T + 2 * K + 16;
+    if (p->Dpen && p->lambda_b != 0.0) {
+        h->have_gb = true;
+        const int Kd = p->dpen_per_traj ? K : 1;
+        std::vector<double> dt_((size_t)Kd * pp * 2, 0.0);   // Dt[j][i] = D[i][j]; D column-major: D[i][j] at j*N + i
+        for (int kd = 0; kd < Kd; ++kd)
+            for (int j = 0; j < N; ++j)
+                for (int i = 0; i < N; ++i) {
+                    dt_[2 * ((size_t)kd * pp + (size_t)j * NP + i)] = p->Dpen[2 * ((size_t)kd * nn + (size_t)j * N + i)];
+                    dt_[2 * ((size_t)kd * pp + (size_t)j * NP + i) + 1] = p->Dpen[2 * ((size_t)kd * nn + (size_t)j * N + i) + 1];
+                }
+        CCHK(dmalloc(&h->d_Dt, (size_t)Kd * pp));
+        CCHK(hipMemcpy(h->d_Dt, dt_.data(), dt_.size() * 8, hipMemcpyHostToDevice));
+        std::vector<double> wq(N_T + 1);
+        for (int m = 0; m <= N_T; ++m)   // trapezoid weights of optimize.jl:727-750
+            wq[m] = m == 0 ? (p->tlist[1] - p->tlist[0]) / 2.0
+                           : (m < N_T ? 0.5 * (p->tlist[m + 1] - p->tlist[m - 1]) : (p->tlist[N_T] - p->tlist[N_T - 1]) / 2.0);
+        CCHK(dmalloc(&h->d_wq, (size_t)N_T + 1));
+        CCHK(hipMemcpy(h->d_wq, wq.data(), wq.size() * 8, hipMemcpyHostToDevice));
+        CCHK(dmalloc(&h->d_xi, (size_t)K * (N_T + 1) * NP));
+        CCHK(dmalloc(&h->d_gb, (size_t)K * (N_T + 1)));
+    }
     CCHK(hipHostMalloc((void **)&h->h_pin, h->h_pin_doubles * 8, hipHostMallocDefault));
 #undef CCHK
     *out = h;
@@ -567,9 +592,18 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(64), 0, s, (const double2 *)d_out, h->d_weights, h->K,
                        d_out + 2 * (size_t)h->K);
     HIPCHK(h, hipGetLastError());
+    if (h->have_gb) {   // xi_k(t_n) = -D Psi_k(t_n), g_b values and their trapezoid sum (optimize.jl:727-750)
+        GbArgs ga{};
+        ga.Dt = h->d_Dt; ga.fw = h->d_fw; ga.xi = h->d_xi; ga.gb = h->d_gb;
+        ga.NP = h->NP; ga.N_T = h->N_T; ga.d_per_traj = h->p.dpen_per_traj;
+        hipLaunchKernelGGL(gb_kernel, dim3(h->K * (h->N_T + 1)), dim3(256), 0, s, ga);
+        hipLaunchKernelGGL(jb_reduce_kernel, dim3(1), dim3(256), 0, s, (const double *)h->d_gb, (const double *)h->d_wq,
+                           h->K, h->N_T, d_out + 2 * (size_t)h->K + 4);
+        HIPCHK(h, hipGetLastError());
+    }
     phase_end(h, 1, s);
     if (d_out != h->d_out)
-        HIPCHK(h, hipMemcpyAsync(h->d_out, d_out, ((size_t)2 * h->K + 4) * 8, hipMemcpyDeviceToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->d_out, d_out, ((size_t)2 * h->K + 8) * 8, hipMemcpyDeviceToDevice, s));
     h->have_forward = true;
     if (!h->in_eval) h->n_fwd++;
     return GRAPE_OK;
@@ -585,6 +619,7 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     SweepArgs sa{};
     sa.U = h->d_U; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
     sa.store = h->d_bw; sa.tau = (double2 *)h->d_out; sa.f = d_f; sa.rho = h->d_rho; sa.flags = h->d_flags;
+    sa.xi = h->have_gb ? h->d_xi : nullptr; sa.wq = h->d_wq; sa.lambda_b = h->p.lambda_b;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
     phase_begin(h, 2, s);
@@ -655,7 +690,7 @@ int grape_forward(grape_handle *h, const double *pulsevals, double *tau) {
     HIPCHK(h, hipMemcpyAsync(h->d_eps, h->h_pin, nl * 8, hipMemcpyHostToDevice, h->stream));
     int rc = grape_forward_device(h, h->d_eps, h->d_out, h->stream);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->h_pin + nl, h->d_out, ((size_t)2 * h->K + 4) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_pin + nl, h->d_out, ((size_t)2 * h->K + 8) * 8, hipMemcpyDeviceToHost, h->stream));
     rc = grape_check(h, h->stream);
     if (rc) return rc;
     if (tau) memcpy(tau, h->h_pin + nl, (size_t)2 * h->K * 8);
@@ -692,6 +727,7 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
     if (h->p.functional == GRAPE_J_T_SM) *J = 1.0 - (sums[0] * sums[0] + sums[1] * sums[1]) / (Kt * Kt);
     else if (h->p.functional == GRAPE_J_T_SS) *J = 1.0 - sums[2] / Kt;
     else *J = 1.0 - sums[3] / Kt;
+    if (h->have_gb) *J += h->p.lambda_b * sums[4];   // J_parts[3] = lambda_b * sum(J_b_trajectory), optimize.jl:764-766
     const double f[2] = {sums[0], sums[1]};
     if (psiT) {
         HIPCHK(h, hipMemcpy2D(psiT, (size_t)h->N * 16, h->d_fw + (size_t)h->N_T * h->NP,

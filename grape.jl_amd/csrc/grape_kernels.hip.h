@@ -773,6 +773,11 @@ struct SweepArgs {
     int *flags;
     double chi_min_norm;
     int K, K_total, N, N_T, functional;
+    // state running cost g_b = <Psi|D|Psi> (optimize.jl:856-866, 897-908): xi_k(t_n) = -D Psi_k(t_n),
+    // trapezoid weights wq[n]; nullptr / 0 when off
+    const double2 *xi;    // [K][N_T+1][NP]
+    const double *wq;     // [N_T+1]
+    double lambda_b;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -824,6 +829,11 @@ __global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
         if (tid < a.N) {
             double2 t = a.target[(size_t)k * a.N + tid];
             v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+            if (a.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)   (optimize.jl:856-866)
+                const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + a.N_T) * NP + tid];
+                const double c = a.lambda_b * a.wq[a.N_T];
+                v.x += c * x_.x; v.y += c * x_.y;
+            }
         }
         if (wave == 0) {
             double n2 = wave_sum(lane < NP ? v.x * v.x + v.y * v.y : 0.);
@@ -907,6 +917,11 @@ __global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
                 double2 s = part[0][tid];
 #pragma unroll
                 for (int q = 1; q < NW; ++q) { s.x += part[q][tid].x; s.y += part[q][tid].y; }
+                if (a.xi && n > 0) {   // chi(t_n) += lambda_b Dt_n / rho_k xi_k(t_n)   (optimize.jl:897-908)
+                    const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + n) * NP + tid];
+                    const double c = a.lambda_b * a.wq[n] / sc[0];
+                    s.x += c * x_.x; s.y += c * x_.y;
+                }
                 x[cur ^ 1][tid] = s;
                 st[(size_t)n * NP + tid] = s;
             }
@@ -940,7 +955,7 @@ __global__ void tau_reduce_kernel(const double2 *tau, const double *weights, int
         fr += w * t.x; fi += w * t.y; ss += w * (t.x * t.x + t.y * t.y);
     }
     fr = wave_sum(fr); fi = wave_sum(fi); ss = wave_sum(ss);
-    if (threadIdx.x == 0) { out[0] = fr; out[1] = fi; out[2] = ss; out[3] = fr; }
+    if (threadIdx.x == 0) { out[0] = fr; out[1] = fi; out[2] = ss; out[3] = fr; out[4] = 0.; out[5] = 0.; out[6] = 0.; out[7] = 0.; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1414,6 +1429,58 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv_mfma_
         }
         __syncthreads();   // red slots / scratch are reused by the next batch
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// State-dependent running cost of the family g_b(Psi) = <Psi|D|Psi> (test_state_running_cost.jl:32-40):
+// xi_k(t_n) = -D_k Psi_k(t_n) and g_kn for every stored state (cell-parallel), then the trapezoid sum
+// J_b = sum_k sum_n wq[n] g_kn (optimize.jl:727-750).
+// ---------------------------------------------------------------------------------------
+struct GbArgs {
+    const double2 *Dt;   // [Kd][NP][NP] interleaved, TRANSPOSED (Dt[j][i] = D[i][j]: lane i reads contiguously)
+    const double2 *fw;   // [K][N_T+1][NP]
+    double2 *xi;         // [K][N_T+1][NP]
+    double *gb;          // [K][N_T+1]
+    int NP, N_T, d_per_traj;
+};
+__global__ void __launch_bounds__(256) gb_kernel(GbArgs a) {
+    __shared__ double2 psi[256];
+    __shared__ double part[256];
+    const int NP = a.NP, tid = threadIdx.x;
+    const int cell = blockIdx.x;                 // k * (N_T+1) + n
+    const int k = cell / (a.N_T + 1);
+    const double2 *Dt = a.Dt + (size_t)(a.d_per_traj ? k : 0) * NP * NP;
+    if (tid < NP) psi[tid] = a.fw[(size_t)cell * NP + tid];
+    __syncthreads();
+    double ar = 0., ai = 0.;
+    if (tid < NP) {
+        for (int j = 0; j < NP; ++j) {
+            const double2 d = Dt[(size_t)j * NP + tid], p = psi[j];
+            ar += d.x * p.x - d.y * p.y;
+            ai += d.x * p.y + d.y * p.x;
+        }
+        a.xi[(size_t)cell * NP + tid] = make_double2(-ar, -ai);
+    }
+    part[tid] = tid < NP ? psi[tid].x * ar + psi[tid].y * ai : 0.;   // Re conj(psi_i) (D psi)_i
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) a.gb[cell] = part[0];
+}
+__global__ void __launch_bounds__(256) jb_reduce_kernel(const double *gb, const double *wq, int K, int N_T, double *out) {
+    __shared__ double part[256];
+    double s = 0.;
+    const size_t tot = (size_t)K * (N_T + 1);
+    for (size_t i = threadIdx.x; i < tot; i += 256) s += wq[i % (N_T + 1)] * gb[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
 }
 
 // ---------------------------------------------------------------------------------------

@@ -267,6 +267,11 @@ __global__ void __launch_bounds__(1024) sweep_lg_kernel(SweepArgs a, int NP) {
         if (tid < a.N) {
             const double2 t = a.target[(size_t)k * a.N + tid];
             v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+            if (a.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)
+                const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + a.N_T) * NP + tid];
+                const double c = a.lambda_b * a.wq[a.N_T];
+                v.x += c * x_.x; v.y += c * x_.y;
+            }
         }
         if (tid < 256) part[0][tid] = make_double2(v.x * v.x + v.y * v.y, 0.);
         __syncthreads();
@@ -325,6 +330,11 @@ __global__ void __launch_bounds__(1024) sweep_lg_kernel(SweepArgs a, int NP) {
             if (tid < NP) {
                 double2 s = part[0][tid];
                 for (int qq = 1; qq < NQ; ++qq) { s.x += part[qq][tid].x; s.y += part[qq][tid].y; }
+                if (a.xi && n > 0) {   // chi(t_n) += lambda_b Dt_n / rho_k xi_k(t_n)
+                    const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + n) * NP + tid];
+                    const double c = a.lambda_b * a.wq[n] / sc[0];
+                    s.x += c * x_.x; s.y += c * x_.y;
+                }
                 x[cur ^ 1][tid] = s;
                 st[(size_t)n * NP + tid] = s;
             }

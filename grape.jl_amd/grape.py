@@ -225,7 +225,10 @@ class GrapeWrk:
                             chi_min_norm=self.kwargs.get("chi_min_norm", 0.0),
                             taylor_max_order=self.kwargs.get("taylor_grad_max_order", 0),
                             taylor_tolerance=self.kwargs.get("taylor_grad_tolerance", 0.0),
-                            device=self.kwargs.get("device", 0))
+                            device=self.kwargs.get("device", 0),
+                            # g_b / xi of the expectation-value family (test_state_running_cost.jl:32-40):
+                            # g_b = <Psi|D|Psi>, xi = -D Psi, given as the operator D itself
+                            D=self.kwargs.get("state_penalty"), lambda_b=self.kwargs.get("lambda_b", 1.0))
 
 
 def evaluate_functional(pulsevals, wrk: GrapeWrk, count_call=True):

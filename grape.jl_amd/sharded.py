@@ -16,14 +16,15 @@ from __future__ import annotations
 import numpy as np
 
 
-def functional_value(functional, sums, K_total):
-    """J_T from the all-reduced sums [Re f, Im f, sum w|tau|^2, Re sum w tau]."""
+def functional_value(functional, sums, K_total, lambda_b=0.0):
+    """J from the all-reduced sums [Re f, Im f, sum w|tau|^2, Re sum w tau, sum_k J_b,k, ...]."""
     fr, fi, ss, re = (float(v) for v in sums[:4])
+    jb = lambda_b * float(sums[4]) if len(sums) > 4 else 0.0
     if functional == 0:
-        return 1.0 - (fr * fr + fi * fi) / (K_total * K_total)
+        return 1.0 - (fr * fr + fi * fi) / (K_total * K_total) + jb
     if functional == 1:
-        return 1.0 - ss / K_total
-    return 1.0 - re / K_total
+        return 1.0 - ss / K_total + jb
+    return 1.0 - re / K_total + jb
 
 
 def shard_range(K_total, world_size, rank):
@@ -65,7 +66,7 @@ class ShardedEvaluator:
     def alloc_device(self, L, N_T, K_local):
         import torch
         self._x = torch.empty(L * N_T, dtype=torch.float64, device=self.device)
-        self._out = torch.zeros(2 * K_local + 4, dtype=torch.float64, device=self.device)
+        self._out = torch.zeros(2 * K_local + 8, dtype=torch.float64, device=self.device)
         self._G = torch.zeros(L * N_T, dtype=torch.float64, device=self.device)
         self._K = K_local
         return self._x, self._out, self._G
@@ -75,7 +76,7 @@ class ShardedEvaluator:
         device and on ``stream_ptr``.  Returns nothing (results in self._out / self._G)."""
         K = self._K
         self.h.forward_device(self._x.data_ptr(), self._out.data_ptr(), stream_ptr)
-        sums = self._out[2 * K:2 * K + 4]
+        sums = self._out[2 * K:2 * K + 8]   # f, sum w|tau|^2, Re sum w tau, sum J_b (+ padding)
         if self.dist is not None:
             self.dist.all_reduce(sums)
         self.h.backward_device(sums.data_ptr(), self._G.data_ptr(), stream_ptr)
@@ -84,4 +85,5 @@ class ShardedEvaluator:
 
     def J_device(self):
         K = self._K
-        return functional_value(self.functional, self._out[2 * K:2 * K + 4].tolist(), self.K_total)
+        return functional_value(self.functional, self._out[2 * K:2 * K + 8].tolist(), self.K_total,
+                                getattr(self.h, "lambda_b", 0.0))

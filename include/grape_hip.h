@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_HIP_ABI_VERSION 1
+#define GRAPE_HIP_ABI_VERSION 2
 
 typedef struct grape_handle grape_handle;
 
@@ -85,6 +85,13 @@ typedef struct {
     double chi_min_norm;     /* <= 0 selects the reference default 1e-100 (optimize.jl:846)     */
     int32_t taylor_max_order;/* <= 0 selects 100   (optimize.jl:915)                            */
     double taylor_tolerance; /* <= 0 selects 1e-16 (optimize.jl:916)                            */
+    /* State-dependent running cost of the family g_b(Psi) = <Psi|D|Psi> with xi = -D Psi
+     * (optimize.jl:727-750, 764-766, 856-866, 897-908; test/test_state_running_cost.jl:32-40):
+     * J gains lambda_b * sum_k trapezoid_n g_b(Psi_k(t_n)), chi the inhomogeneity of
+     * docs/src/background.md:771-775.  Dpen == NULL or lambda_b == 0 switches it off.          */
+    const double *Dpen;      /* NULL, [N*N] (shared) or [K][N*N] complex Hermitian, column-major */
+    int32_t dpen_per_traj;   /* 0: one D for all trajectories; 1: one per trajectory            */
+    double lambda_b;
 } grape_problem;
 
 /* Replaces GrapeWrk(...) data set-up: /root/reference/src/workspace.jl:147-362 */
@@ -108,7 +115,7 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
  *   2. host all-reduces   : f = sum over ALL trajectories of w_k tau_k   (2 doubles)
  *   3. grape_backward     : chi from (f, local tau), backward sweep, per-cell derivatives and the
  *                           local sum over k; returns the PARTIAL gradient (L*N_T) and the local
- *                           partial sums needed for J_T ([0]=sum w|tau|^2, [1]=Re sum w tau)
+ *                           partial sums needed for J ([2]=sum w|tau|^2, [3]=Re sum w tau, [4]=sum J_b)
  *   4. host all-reduces   : G (sum) -- the sum over k of optimize.jl:579
  * grape_eval() is exactly 1 + 3 with f computed locally.
  */
@@ -118,8 +125,9 @@ int grape_backward(grape_handle *h, const double f_total[2], double *G_partial);
 /* Device-resident variants used by the bench / RCCL path: same semantics, every pointer is a
  * device pointer on the handle's device; work is enqueued on `stream` (a hipStream_t passed as
  * void*) without host synchronisation.
- *   d_out layout of grape_forward_device : [0..2K) tau, [2K] Re f_local, [2K+1] Im f_local,
- *                                          [2K+2] sum_k w_k |tau_k|^2, [2K+3] Re sum_k w_k tau_k
+ *   d_out layout of grape_forward_device (2K + 8 doubles): [0..2K) tau, then the shard sums
+ *        [2K] Re f, [2K+1] Im f (f = sum_k w_k tau_k), [2K+2] sum_k w_k |tau_k|^2,
+ *        [2K+3] Re sum_k w_k tau_k, [2K+4] sum_k J_b,k (state running cost), [2K+5..2K+7] 0
  *   d_f   : 2 doubles, the all-reduced f;  d_G: L*N_T doubles (partial gradient, overwritten) */
 int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_out, void *stream);
 int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void *stream);

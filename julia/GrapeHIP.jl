@@ -33,6 +33,9 @@ struct GrapeProblem
     chi_min_norm::Float64
     taylor_max_order::Int32
     taylor_tolerance::Float64
+    Dpen::Ptr{ComplexF64}    # state running cost g_b = <Psi|D|Psi> (C_NULL = off)
+    dpen_per_traj::Int32
+    lambda_b::Float64
 end
 
 mutable struct Handle
@@ -60,9 +63,9 @@ function Handle(H0::Vector{Matrix{ComplexF64}}, Hc::Vector{Matrix{ComplexF64}}, 
     H0f = reduce(hcat, vec.(H0)); Hcf = reduce(hcat, vec.(Hc))
     p0 = reduce(hcat, psi0); tg = reduce(hcat, target)
     keep = Any[H0f, Hcf, p0, tg, tlist, weights]
-    prob = Ref(GrapeProblem(1, N, L, K, K_total, length(tlist) - 1, functional, gradient_method, 0, device,
+    prob = Ref(GrapeProblem(2, N, L, K, K_total, length(tlist) - 1, functional, gradient_method, 0, device,
                             pointer(tlist), pointer(H0f), pointer(Hcf), C_NULL, pointer(p0), pointer(tg),
-                            pointer(weights), 0.0, 0, 0.0))
+                            pointer(weights), 0.0, 0, 0.0, C_NULL, 0, 0.0))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = GC.@preserve keep ccall((:grape_create, libgrape), Cint, (Ref{Ptr{Cvoid}}, Ref{GrapeProblem}), out, prob)
     h = Handle(out[], keep)

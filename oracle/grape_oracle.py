@@ -110,21 +110,46 @@ def forward(H0, Hc, tlist, pulsevals, psi0, shape=None):
     return storage
 
 
+def _dop_of(D, k):
+    return D if D.ndim == 2 else D[k]
+
+
+def g_b_expectation(D, psi):
+    """State-dependent running cost of the family g_b(Psi) = <Psi|D|Psi> (Hermitian D), the one used by
+    /root/reference/test/test_state_running_cost.jl:32-39; xi = -dg_b/d<Psi| = -D Psi (:38-40)."""
+    return float(np.real(np.vdot(psi, D @ psi)))
+
+
+def J_b_trajectory(D, storage_k, tlist):
+    """Trapezoid rule of optimize.jl:727-750 for one trajectory."""
+    N_T = len(tlist) - 1
+    Jb = g_b_expectation(D, storage_k[0]) * (tlist[1] - tlist[0]) / 2.0          # :728-730
+    for n_tl in range(1, N_T + 1):                                               # :739-749
+        if n_tl < N_T:
+            dt = 0.5 * (tlist[n_tl + 1] - tlist[n_tl - 1])
+        else:
+            dt = (tlist[-1] - tlist[-2]) / 2.0
+        Jb += g_b_expectation(D, storage_k[n_tl]) * dt
+    return Jb
+
+
 def evaluate_functional(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
-                        functional=FUNCTIONAL_SM, shape=None):
-    """optimize.jl:696-768.  Returns (J, tau, storage)."""
+                        functional=FUNCTIONAL_SM, shape=None, D=None, lambda_b=1.0):
+    """optimize.jl:696-768.  Returns (J, tau, storage); J = J_T + lambda_b J_b when D is given."""
     K = psi0.shape[0]
     weights = np.ones(K) if weights is None else weights
     storage = forward(H0, Hc, tlist, pulsevals, psi0, shape)
     tau = np.array([np.vdot(target[k], storage[k, -1]) for k in range(K)])  # :753
     J_T, _ = J_T_and_chi(functional, tau, target, weights)
+    if D is not None:  # :764-766
+        J_T += lambda_b * sum(J_b_trajectory(_dop_of(np.asarray(D), k), storage[k], tlist) for k in range(K))
     return J_T, tau, storage
 
 
 def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
                       functional=FUNCTIONAL_SM, gradient_method="gradgen", shape=None,
                       taylor_max_order=100, taylor_tol=1e-16, return_parts=False,
-                      K_total=None, f_total=None):
+                      K_total=None, f_total=None, D=None, lambda_b=1.0):
     """optimize.jl:824-1014 (without running costs).  Returns (J, G, tau[, parts])."""
     K, N = psi0.shape
     L = _hc_of(Hc, 0).shape[0]
@@ -133,8 +158,12 @@ def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
     eps = np.asarray(pulsevals, dtype=np.float64).reshape(L, N_T)
 
     J_T, tau, storage = evaluate_functional(H0, Hc, tlist, pulsevals, psi0, target, weights,
-                                            functional, shape)
+                                            functional, shape, D, lambda_b)
     _, chi = J_T_and_chi(functional, tau, target, weights, K_total, f_total)  # :848-855
+    if D is not None and lambda_b != 0.0:  # :856-866  chi_k += lambda_b dt/2 xi_k(T), xi = -D Psi
+        dtl = tlist[-1] - tlist[-2]
+        for k in range(K):
+            chi[k] = chi[k] + (lambda_b * dtl / 2.0) * (-(_dop_of(np.asarray(D), k) @ storage[k, -1]))
     rho = np.array([np.linalg.norm(chi[k]) for k in range(K)])  # :867
     for k in range(K):
         if rho[k] < CHI_MIN_NORM:  # :1021-1025
@@ -155,14 +184,14 @@ def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
             psi = storage[k, n]  # Psi_k(t_{n-1}) = storage[k][:, n], optimize.jl:888-892
             if gradient_method == "gradgen":
                 # GradGenerator(H^dagger): background.md:467-477, densified by ExpProp
-                D = (L + 1) * N
-                G = np.zeros((D, D), dtype=np.complex128)
+                DG = (L + 1) * N
+                G = np.zeros((DG, DG), dtype=np.complex128)
                 for l in range(L + 1):
                     G[l * N:(l + 1) * N, l * N:(l + 1) * N] = Hdag
                 for l in range(L):
                     mu = Hck[l] if sc is None else sc[l] * Hck[l]
                     G[l * N:(l + 1) * N, L * N:] = mu.conj().T
-                ext = np.zeros(D, dtype=np.complex128)  # GradVector(chi, L), :878 / resetgradvec! :896
+                ext = np.zeros(DG, dtype=np.complex128)  # GradVector(chi, L), :878 / resetgradvec! :896
                 ext[L * N:] = chik
                 ext = expm(-1j * G * (-dt)) @ ext  # backward prop_step!, :881
                 for l in range(L):
@@ -177,6 +206,9 @@ def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
                 chik = expm(-1j * Hdag * (-dt)) @ chik  # :972
             else:
                 raise ValueError(f"Invalid gradient_method={gradient_method!r}")
+            if D is not None and lambda_b != 0.0 and n > 0:  # :897-908 (reference n > 1, 1-based)
+                dtn = 0.5 * (tlist[n + 1] - tlist[n - 1])
+                chik = chik + (lambda_b * dtn / rho[k]) * (-(_dop_of(np.asarray(D), k) @ psi))
             chi_store[k, n] = chik
 
     G_out = np.zeros(L * N_T)

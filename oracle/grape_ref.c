@@ -245,11 +245,42 @@ static int taylor_grad_step(int N, cplx *out, const cplx *psi, const cplx *H, co
  * gradient_method: 0 = :gradgen literal ((L+1)N block exponential), 1 = :taylor.
  * Returns 0, -1 (singular Pade solve), -2 (taylor not converged), -3 (chi norm < 1e-100).
  */
+static int grape_ref_eval_gb(int N, int L, int K, int N_T, const double *tlist, const double *H0_,
+                   const double *Hc_, int hc_per_traj, const double *psi0_, const double *target_,
+                   const double *weights, int functional, int gradient_method,
+                   const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
+                   double *tau_grads_ /* K*N_T*L cplx, [k][l][n] */, int nthreads,
+                   const double *D_ /* NULL or [Kd][N*N] column-major Hermitian penalty operator */,
+                   int d_per_traj, double lambda_b);
+
 int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const double *H0_,
                    const double *Hc_, int hc_per_traj, const double *psi0_, const double *target_,
                    const double *weights, int functional, int gradient_method,
                    const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
-                   double *tau_grads_ /* K*N_T*L cplx, [k][l][n] */, int nthreads) {
+                   double *tau_grads_, int nthreads) {
+    return grape_ref_eval_gb(N, L, K, N_T, tlist, H0_, Hc_, hc_per_traj, psi0_, target_, weights, functional,
+                             gradient_method, pulsevals, J, G, tau_, psiT_, tau_grads_, nthreads, NULL, 0, 0.0);
+}
+
+/* same with the state-dependent running cost g_b(Psi) = <Psi|D|Psi>, xi = -D Psi
+ * (src/optimize.jl:727-750, 764-766, 856-866, 897-908; test/test_state_running_cost.jl:32-40) */
+int grape_ref_eval_b(int N, int L, int K, int N_T, const double *tlist, const double *H0_,
+                     const double *Hc_, int hc_per_traj, const double *psi0_, const double *target_,
+                     const double *weights, int functional, int gradient_method,
+                     const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
+                     double *tau_grads_, int nthreads, const double *D_, int d_per_traj, double lambda_b) {
+    return grape_ref_eval_gb(N, L, K, N_T, tlist, H0_, Hc_, hc_per_traj, psi0_, target_, weights, functional,
+                             gradient_method, pulsevals, J, G, tau_, psiT_, tau_grads_, nthreads, D_, d_per_traj, lambda_b);
+}
+
+static int grape_ref_eval_gb(int N, int L, int K, int N_T, const double *tlist, const double *H0_,
+                   const double *Hc_, int hc_per_traj, const double *psi0_, const double *target_,
+                   const double *weights, int functional, int gradient_method,
+                   const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
+                   double *tau_grads_ /* K*N_T*L cplx, [k][l][n] */, int nthreads,
+                   const double *D_, int d_per_traj, double lambda_b) {
+    const cplx *Dop = (const cplx *)D_;
+    double *Jb_traj = (double *)calloc((size_t)K, sizeof(double));
     const size_t nn = (size_t)N * N;
     const cplx *H0 = (const cplx *)H0_, *Hc = (const cplx *)Hc_;
     const cplx *psi0 = (const cplx *)psi0_, *target = (const cplx *)target_;
@@ -278,6 +309,23 @@ int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const doub
             if (grape_ref_expm(N, (double *)A, (double *)U, (double *)work, NULL) < 0) err = -1;
             zgemv_n(N, U, st + (size_t)n * N, st + (size_t)(n + 1) * N); /* :732, :738 */
         }
+        if (Dop) { /* J_b trapezoid, optimize.jl:727-750 */
+            const cplx *Dk = Dop + (d_per_traj ? (size_t)k * nn : 0);
+            cplx *dps = (cplx *)malloc(sizeof(cplx) * N);
+            double jb = 0;
+            for (int m = 0; m <= N_T; ++m) {
+                double wq;
+                if (m == 0) wq = (tlist[1] - tlist[0]) / 2.0;
+                else if (m < N_T) wq = 0.5 * (tlist[m + 1] - tlist[m - 1]);
+                else wq = (tlist[N_T] - tlist[N_T - 1]) / 2.0;
+                zgemv_n(N, Dk, st + (size_t)m * N, dps);
+                double g = 0;
+                for (int i = 0; i < N; ++i) g += creal(conj(st[(size_t)m * N + i]) * dps[i]);
+                jb += wq * g;
+            }
+            Jb_traj[k] = jb;
+            free(dps);
+        }
         cplx t = 0;
         for (int i = 0; i < N; ++i) t += conj(target[(size_t)k * N + i]) * st[(size_t)N_T * N + i]; /* :753 */
         tau[k] = t;
@@ -297,6 +345,11 @@ int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const doub
     if (functional == GRAPE_REF_SM) *J = 1.0 - (creal(f) * creal(f) + cimag(f) * cimag(f)) / ((double)K * K);
     else if (functional == GRAPE_REF_SS) *J = 1.0 - ss / K;
     else *J = 1.0 - re / K;
+    if (Dop) { /* :764-766 */
+        double jb = 0;
+        for (int k = 0; k < K; ++k) jb += Jb_traj[k];
+        *J += lambda_b * jb;
+    }
 
     if (G && !err) {
         const int D = (L + 1) * N;
@@ -311,12 +364,18 @@ int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const doub
             cplx *chi = (cplx *)malloc(sizeof(cplx) * (size_t)(D + D + 6 * N));
             cplx *ext = chi + N, *ext2 = ext + D, *tmp = ext2 + D; /* tmp: 5*N */
             double rho = 0;
-            for (int i = 0; i < N; ++i) {
-                chi[i] = coeff * target[(size_t)k * N + i]; /* optimize.jl:848-855 */
-                rho += creal(chi[i]) * creal(chi[i]) + cimag(chi[i]) * cimag(chi[i]);
+            const cplx *stT = storage + (size_t)k * (N_T + 1) * N + (size_t)N_T * N;
+            const cplx *Dk = Dop ? Dop + (d_per_traj ? (size_t)k * nn : 0) : NULL;
+            cplx *xi = (cplx *)malloc(sizeof(cplx) * N);
+            for (int i = 0; i < N; ++i) chi[i] = coeff * target[(size_t)k * N + i]; /* optimize.jl:848-855 */
+            if (Dk && lambda_b != 0.0) { /* :856-866 chi += lambda_b dt/2 xi(T), xi = -D Psi */
+                const double dtl = tlist[N_T] - tlist[N_T - 1];
+                zgemv_n(N, Dk, stT, xi);
+                for (int i = 0; i < N; ++i) chi[i] -= (lambda_b * dtl / 2.0) * xi[i];
             }
+            for (int i = 0; i < N; ++i) rho += creal(chi[i]) * creal(chi[i]) + cimag(chi[i]) * cimag(chi[i]);
             rho = sqrt(rho);                       /* :867 */
-            if (rho < 1e-100) { err = -3; free(chi); continue; } /* :1021-1025 */
+            if (rho < 1e-100) { err = -3; free(chi); free(xi); continue; } /* :1021-1025 */
             for (int i = 0; i < N; ++i) chi[i] /= rho; /* :868 */
 
             const cplx *Hck = hc_per_traj ? Hc + (size_t)k * L * nn : Hc;
@@ -376,8 +435,13 @@ int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const doub
                     zgemv_n(N, EG, chi, ext); /* :972 */
                     memcpy(chi, ext, sizeof(cplx) * N);
                 }
+                if (Dk && lambda_b != 0.0 && n > 0) { /* :897-908 inhomogeneity at interior grid points */
+                    const double dtn = 0.5 * (tlist[n + 1] - tlist[n - 1]);
+                    zgemv_n(N, Dk, psi, xi);
+                    for (int i = 0; i < N; ++i) chi[i] -= (lambda_b * dtn / rho) * xi[i];
+                }
             }
-            free(Gm); free(H); free(chi);
+            free(Gm); free(H); free(chi); free(xi);
         }
         /* _grad_J_T_via_chi!: optimize.jl:574-584 */
         for (int l = 0; l < L; ++l)
@@ -388,7 +452,7 @@ int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const doub
             }
         if (tau_grads_) memcpy(tau_grads_, tg, sizeof(cplx) * (size_t)K * N_T * L);
     }
-    free(storage); free(tg);
+    free(storage); free(tg); free(Jb_traj);
     return err;
 }
 

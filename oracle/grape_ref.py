@@ -50,7 +50,7 @@ def expm(A):
 
 
 def evaluate(H0, Hc, tlist, pulsevals, psi0, target, weights=None, functional=0,
-             gradient_method=GRADGEN, gradient=True, nthreads=0, want_parts=False):
+             gradient_method=GRADGEN, gradient=True, nthreads=0, want_parts=False, D=None, lambda_b=1.0):
     """Same array conventions as grape_jl_amd.GrapeHip (H0[k][row, col])."""
     H0 = np.asarray(H0)
     K, N = H0.shape[0], H0.shape[1]
@@ -71,6 +71,23 @@ def evaluate(H0, Hc, tlist, pulsevals, psi0, target, weights=None, functional=0,
     psiT = np.zeros((K, N), dtype=np.complex128)
     tgr = np.zeros((K, L, N_T), dtype=np.complex128)
     vp = C.c_void_p
+    if D is not None:
+        D = np.asarray(D)
+        dper = D.ndim == 3
+        Dc = np.ascontiguousarray(np.swapaxes(D, -1, -2), dtype=np.complex128)
+        lib().grape_ref_eval_b.restype = C.c_int
+        rc = lib().grape_ref_eval_b(
+            C.c_int(N), C.c_int(L), C.c_int(K), C.c_int(N_T), tl.ctypes.data_as(vp), H0c.ctypes.data_as(vp),
+            Hcc.ctypes.data_as(vp), C.c_int(int(per_traj)), p0.ctypes.data_as(vp), tg.ctypes.data_as(vp),
+            None if w is None else w.ctypes.data_as(vp), C.c_int(functional), C.c_int(gradient_method),
+            x.ctypes.data_as(vp), C.byref(J), None if G is None else G.ctypes.data_as(vp),
+            tau.ctypes.data_as(vp), psiT.ctypes.data_as(vp), tgr.ctypes.data_as(vp), C.c_int(nthreads),
+            Dc.ctypes.data_as(vp), C.c_int(int(dper)), C.c_double(lambda_b))
+        if rc:
+            raise RuntimeError(f"grape_ref_eval_b failed with code {rc}")
+        if want_parts:
+            return J.value, G, tau, dict(psiT=psiT, tau_grads=tgr)
+        return J.value, G, tau
     rc = lib().grape_ref_eval(
         C.c_int(N), C.c_int(L), C.c_int(K), C.c_int(N_T), tl.ctypes.data_as(vp), H0c.ctypes.data_as(vp),
         Hcc.ctypes.data_as(vp), C.c_int(int(per_traj)), p0.ctypes.data_as(vp), tg.ctypes.data_as(vp),

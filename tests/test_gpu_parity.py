@@ -291,3 +291,34 @@ def test_two_rank_sharded_device_path(g):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "two-rank sharded device path OK" in res.stdout
+
+
+@pytest.mark.parametrize("N,L,per_traj,functional", [(6, 2, False, 0), (16, 1, True, 2), (64, 2, False, 0), (100, 2, True, 1)])
+def test_state_running_cost_expectation_family(g, ref, N, L, per_traj, functional):
+    """g_b(Psi) = <Psi|D|Psi>, xi = -D Psi (test/test_state_running_cost.jl:32-40): J gains
+    lambda_b * trapezoid(g_b) (optimize.jl:727-750, 764-766) and chi the inhomogeneity of :856-866,
+    :897-908.  Checked against the C oracle and by finite differences of the GPU functional."""
+    from grape_jl_amd import synth
+    K, N_T, lam = 3, 7, 0.5
+    pr = synth.make_problem(N, L, N_T, K, seed=500 + N, hermitian=(N != 6))
+    pr["tlist"] = np.cumsum(np.concatenate([[0.0], 0.8 + 0.05 * np.arange(N_T)]))   # non-uniform grid
+    rng = np.random.default_rng(N)
+    def penalty():
+        A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        return A @ A.conj().T / N
+    D = np.stack([penalty() for _ in range(K)]) if per_traj else penalty()
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], functional=functional,
+                    D=D, lambda_b=lam) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        eps, fd = 1e-6, []
+        for idx in (0, L * N_T - 1):
+            xp, xm = pr["pulsevals"].copy(), pr["pulsevals"].copy()
+            xp[idx] += eps
+            xm[idx] -= eps
+            fd.append((h.eval(xp, gradient=False)[0] - h.eval(xm, gradient=False)[0]) / (2 * eps) - G[idx])
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                functional=functional, gradient_method=ref.TAYLOR, D=D, lambda_b=lam)
+    assert abs(J - Jr) <= 1e-12 * max(1.0, abs(Jr))
+    assert np.abs(tau - taur).max() <= TOL_TAU
+    assert np.abs(G - Gr).max() <= tol_G(Gr)
+    assert np.abs(fd).max() <= 1e-7 * max(1.0, np.abs(Gr).max())

@@ -136,3 +136,35 @@ def test_synth_deterministic():
     assert np.abs(a["H0"][0] - a["H0"][0].conj().T).max() < 1e-15
     # spectral radius ~ 1 for the GUE scaling of SURVEY.md 8d
     assert 0.6 < np.abs(np.linalg.eigvalsh(synth.gue(3, 64))).max() < 1.4
+
+
+def test_state_running_cost_oracles_agree_and_match_finite_differences(ref):
+    """g_b = <Psi|D|Psi>, xi = -D Psi (test/test_state_running_cost.jl:32-40; optimize.jl:727-750, 856-866,
+    897-908): numpy oracle == C oracle (both gradient routes) == finite differences of J_T + lambda_b J_b."""
+    pr = synth.make_problem(6, 2, 7, 3, seed=12, hermitian=False)
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((6, 6)) + 1j * rng.standard_normal((6, 6))
+    D = A @ A.conj().T / 6
+    args = (pr["H0"], pr["Hc"], pr["tlist"])
+    for f in (0, 2):
+        J, G, tau = go.evaluate_gradient(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], f, D=D, lambda_b=0.5)
+        for method in (ref.GRADGEN, ref.TAYLOR):
+            Jc, Gc, _ = ref.evaluate(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], f,
+                                     gradient_method=method, D=D, lambda_b=0.5)
+            assert abs(J - Jc) < 1e-13 and np.abs(G - Gc).max() < 1e-13
+        h = 1e-6
+        for idx in (0, 9, 13):
+            xp, xm = pr["pulsevals"].copy(), pr["pulsevals"].copy()
+            xp[idx] += h
+            xm[idx] -= h
+            Jp = go.evaluate_functional(*args, xp, pr["psi0"], pr["target"], pr["weights"], f, D=D, lambda_b=0.5)[0]
+            Jm = go.evaluate_functional(*args, xm, pr["psi0"], pr["target"], pr["weights"], f, D=D, lambda_b=0.5)[0]
+            assert abs((Jp - Jm) / (2 * h) - G[idx]) < 2e-8
+    # J_b is the accumulated trapezoid of the stored states (test_state_running_cost.jl:41-48)
+    _, _, st = go.evaluate_functional(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], 0)
+    tl = pr["tlist"]
+    w = np.concatenate([[(tl[1] - tl[0]) / 2], 0.5 * (tl[2:] - tl[:-2]), [(tl[-1] - tl[-2]) / 2]])
+    Jb = sum(w[n] * go.g_b_expectation(D, st[k, n]) for k in range(3) for n in range(8))
+    J0 = go.evaluate_functional(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], 0)[0]
+    J1 = go.evaluate_functional(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], 0, D=D, lambda_b=0.5)[0]
+    assert abs(J1 - J0 - 0.5 * Jb) < 1e-13
