@@ -52,6 +52,7 @@ struct ExpmArgs {
     unsigned long long *stats; // [0] sum of squarings, [3..7] #cells with Pade order 3/5/7/9/13
     int K, L, N_T, hc_per_traj;
     int *cellflag;       // [K*N_T] set by the fast kernel for cells that need the pivoted solve
+    double *park;        // [gridDim][NT*64 threads][16*NT] parking area of the fast kernel (P, Q of the first cell of a pair)
 #ifdef GRAPE_DIAG
     int ablate;  // diagnostic builds only (tools/ablate.sh): bit0 skip invert16, bit1 skip solve
     unsigned long long *stamps;  // [nblocks][16] s_memtime at phase boundaries (diagnostic builds only)
@@ -171,6 +172,58 @@ __device__ __forceinline__ void gemm_dual13(Strip<NT> &T, Strip<NT> &V, const do
     }
 }
 
+// Fused pair of products sharing the left operand:  T += X * W,  V += X * Z  (software pipelined like
+// gemm_xb: the LDS reads of k-step ks+1 are issued before the MFMAs of k-step ks).
+template <int NT, int LD>
+__device__ __forceinline__ void gemm_dual(Strip<NT> &T, Strip<NT> &V, const double *__restrict__ Xre,
+                                          const double *__restrict__ Xim, const Strip<NT> &W, const Strip<NT> &Z,
+                                          int lane) {
+    const double *__restrict__ xr = Xre + (lane & 15) * LD + (lane >> 4);
+    const double *__restrict__ xi = Xim + (lane & 15) * LD + (lane >> 4);
+    double are[NT], aim[NT];
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr) {
+        are[tr] = xr[16 * tr * LD];
+        aim[tr] = xi[16 * tr * LD];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ks = 4 * t + r;
+            double nre[NT], nim[NT];
+            if (ks + 1 < 4 * NT) {
+#pragma unroll
+                for (int tr = 0; tr < NT; ++tr) {
+                    nre[tr] = xr[16 * tr * LD + 4 * (ks + 1)];
+                    nim[tr] = xi[16 * tr * LD + 4 * (ks + 1)];
+                }
+            }
+            const double wr = W.re[t][r], wi = W.im[t][r], zr = Z.re[t][r], zi = Z.im[t][r];
+            const double nwi = -wi, nzi = -zi;
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) {
+                T.re[tr] = MFMA64(are[tr], wr, T.re[tr]);
+                T.im[tr] = MFMA64(are[tr], wi, T.im[tr]);
+                V.re[tr] = MFMA64(are[tr], zr, V.re[tr]);
+                V.im[tr] = MFMA64(are[tr], zi, V.im[tr]);
+            }
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) {
+                T.re[tr] = MFMA64(aim[tr], nwi, T.re[tr]);
+                T.im[tr] = MFMA64(aim[tr], wr, T.im[tr]);
+                V.re[tr] = MFMA64(aim[tr], nzi, V.re[tr]);
+                V.im[tr] = MFMA64(aim[tr], zr, V.im[tr]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < 4 * NT) {
+#pragma unroll
+                for (int tr = 0; tr < NT; ++tr) { are[tr] = nre[tr]; aim[tr] = nim[tr]; }
+            }
+        }
+    }
+}
+
 template <int NT, int LD>
 __device__ __forceinline__ void strip_store_lds(double *Xre, double *Xim, const Strip<NT> &s, int wave, int lane) {
     double *xr = Xre + (lane >> 4) * LD + 16 * wave + (lane & 15);
@@ -214,6 +267,27 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
     return __hiloint2double(hi, lo);
 }
 
+// Broadcast of lane K of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+): a VALU-rate
+// move, no trip through the LDS crossbar like ds_bpermute.
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_bcast_k(double v, int k) {
+    switch (k) {   // k is a compile-time constant after unrolling
+        case 0: return row_bcast<0>(v);   case 1: return row_bcast<1>(v);
+        case 2: return row_bcast<2>(v);   case 3: return row_bcast<3>(v);
+        case 4: return row_bcast<4>(v);   case 5: return row_bcast<5>(v);
+        case 6: return row_bcast<6>(v);   case 7: return row_bcast<7>(v);
+        case 8: return row_bcast<8>(v);   case 9: return row_bcast<9>(v);
+        case 10: return row_bcast<10>(v); case 11: return row_bcast<11>(v);
+        case 12: return row_bcast<12>(v); case 13: return row_bcast<13>(v);
+        case 14: return row_bcast<14>(v); default: return row_bcast<15>(v);
+    }
+}
+
 // In-place Gauss-Jordan inverse of one 16x16 complex tile held by ONE wave in the layout
 // lane (i = lane&15, g = lane>>4), register c  <->  D[i][4*c + g]
 // (so register c is directly the MFMA A operand of k-step c).  No pivoting: the Pade
@@ -238,9 +312,9 @@ __device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int
         double mi = __shfl(ai[kc], 16 * kg + i, 64);
         double xr[4], xi[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {                           // a_kj of this lane's columns j = 4c+g
-            xr[c] = __shfl(ar[c], 16 * g + k, 64);
-            xi[c] = __shfl(ai[c], 16 * g + k, 64);
+        for (int c = 0; c < 4; ++c) {                           // a_kj of this lane's columns j = 4c+g:
+            xr[c] = row_bcast_k(ar[c], k);                      // lane k of this lane's own 16-lane row
+            xi[c] = row_bcast_k(ai[c], k);
         }
         // 1/p_k: v_rcp_f64 seed + two Newton steps
         const double den = fma(pr, pr, pi * pi);
@@ -290,6 +364,14 @@ __device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int
 // diagonal tile while the other waves are still issuing their MFMA updates; its own P-strip update of
 // step jb is deferred to step jb+1 (where it has no Q strip left to update).  Panels and inverses
 // live in 3 rotating LDS slots so that the deferred update still finds the operands of step jb.
+#ifdef GRAPE_DIAG
+__device__ unsigned long long *g_diag_slot_base = nullptr;
+#define g_diag_slot (g_diag_slot_base ? g_diag_slot_base + (size_t)blockIdx.x * 32 + 10 : nullptr)
+#define STAMP(i) do { if (threadIdx.x == 0 && g_diag_slot_base) g_diag_slot_base[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+#define GJSTAMP(i) STAMP(i)
 template <int NT>
 struct GjLds {
     static constexpr int NP = 16 * NT, PLD = 18;
@@ -320,7 +402,13 @@ __device__ __forceinline__ void gj_publish_invert(const Strip<NT> &Q, int jb, do
         di[c] = pan[NP * PLD + (16 * jb + ai) * PLD + 4 * c + ak];
     }
     double mr = 1.0;
+#ifdef GRAPE_DIAG
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
     if (do_invert) mr = invert16(dr, di, lane, inv_scale2);
+#ifdef GRAPE_DIAG
+    if (lane == 0 && g_diag_slot) atomicAdd(g_diag_slot, __builtin_amdgcn_s_memtime() - t0_);
+#endif
     minrel = fmin(minrel, mr);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -396,6 +484,30 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
             gj_update<NT>(P, jb, pan, dv, lane);
         }
         __syncthreads();
+    }
+}
+
+// One block step of the solve for one cell, seen from the wave that owns column strip `sw`.
+template <int NT>
+__device__ __forceinline__ void gj_step(Strip<NT> &Q, Strip<NT> &P, int sw, int jb, double *panbase, double *dvbase,
+                                        int lane, double &minrel, double inv_scale2) {
+    constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
+    const double *pan = panbase + (jb % 3) * PAN, *dv = dvbase + (jb % 3) * DV;
+    if (jb + 1 < NT && sw == jb + 1) {
+        gj_update<NT>(Q, jb, pan, dv, lane);
+#ifdef EXP_NO_INV
+        gj_publish_invert<NT>(Q, jb + 1, panbase + ((jb + 1) % 3) * PAN, dvbase + ((jb + 1) % 3) * DV, lane, minrel,
+                              inv_scale2, false);
+#else
+        gj_publish_invert<NT>(Q, jb + 1, panbase + ((jb + 1) % 3) * PAN, dvbase + ((jb + 1) % 3) * DV, lane, minrel,
+                              inv_scale2, true);
+#endif
+        // this wave's P update of step jb is deferred to the next step
+    } else {
+        if (jb > 0 && sw == jb)  // deferred P update of step jb-1
+            gj_update<NT>(P, jb - 1, panbase + ((jb - 1) % 3) * PAN, dvbase + ((jb - 1) % 3) * DV, lane);
+        if (sw > jb) gj_update<NT>(Q, jb, pan, dv, lane);
+        gj_update<NT>(P, jb, pan, dv, lane);
     }
 }
 
@@ -487,31 +599,39 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // in registers as column strips, the left GEMM operand is staged in LDS.
 // Replaces the `exp` inside ExpProp's prop_step! (optimize.jl:732, 881, 972).
 // ---------------------------------------------------------------------------------------
-#ifdef GRAPE_DIAG
-#define STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
 
-template <int NT, bool PIVOTED>
-__device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
-    constexpr int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+// LDS carve shared by the device code and the host (expm_lds_bytes): two regions that hold a plane
+// pair (A, or the staged left operand X) during the polynomial phase and the Gauss-Jordan panel slots of
+// one cell each during the solve, then the inverse slots of both cells and the reduction scratch.
+template <int NT>
+struct ExpmLds {
+    static constexpr int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
+    static constexpr int PLANES = 2 * NP * LD;
+    static constexpr int NSLOT = NT < 3 ? NT : 3;
+    static constexpr int SLOTS = NSLOT * 2 * NP * 18;
+    static constexpr int REG = PLANES > SLOTS ? PLANES : SLOTS;   // doubles per region
+    static constexpr int DV = 2 * 1536;                           // 2 cells x 3 rotating inverse slots
+    static constexpr int RED = NTH + 8 + NP;
+    static constexpr int TOTAL = 2 * REG + DV + RED;              // doubles
+};
+
+// Polynomial phase of one cell: A = -i dt H -> LDS, ||A||_1, Pade order / squaring count, and the
+// numerator P = V+U and denominator Q = V-U as register strips (strip index `wave` = column strip
+// this wave owns; it need not be the hardware wave id).  The caller guarantees that the LDS regions are
+// free on entry; on return other waves may still be reading them.
+template <int NT>
+__device__ __forceinline__ void expm_numden(const ExpmArgs &a, const int cell, const int wave, const int lane,
+                                            const int tid, double *smem, Strip<NT> &Pn, Strip<NT> &Qn, int &s,
+                                            int &order, double &inv_b0sq, const int stamp0 = 11) {
+    using LY = ExpmLds<NT>;
+    constexpr int NP = LY::NP, LD = LY::LD, NTH = LY::NTH;
     double *Are = smem;          // A = -i dt H stays resident (left operand of A*A and A*T)
     double *Aim = Are + NP * LD;
-    double *Xre = Aim + NP * LD;  // staging of the current left operand (A2, A6, squarings, panel)
+    double *Xre = smem + LY::REG;  // staging of the current left operand (A2, A6)
     double *Xim = Xre + NP * LD;
-    // the Gauss-Jordan panels (min(NT,3) rotating slots of 2*NP*18 doubles) reuse the X planes
-    constexpr int NSLOT = NT < 3 ? NT : 3;
-    constexpr int XEXTRA = NSLOT * 2 * NP * 18 > 2 * NP * LD ? NSLOT * 2 * NP * 18 - 2 * NP * LD : 0;
-    double *Dv = Xim + NP * LD + XEXTRA;  // 3 x 512 doubles (rotating inverse slots)
-    double *red = Dv + 1536;     // NTH + 8 + NP doubles
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *red = smem + 2 * LY::REG + LY::DV;
     const int k = cell / a.N_T, n = cell - k * a.N_T;
     const double dt = a.dts[n];
-    STAMP(0);
-
     // ---- A = -i dt (H0_k + sum_l a_l H_l) -> LDS (planar row-major); 16-byte coalesced loads ----
     {
         const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
@@ -536,7 +656,7 @@ __device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
         }
     }
     __syncthreads();
-    STAMP(1);
+    STAMP(stamp0 + 0);
     // ---- ||A||_1 = max_j sum_i |a_ij| ----
     {
         constexpr int PARTS = NTH / NP;  // 4
@@ -559,8 +679,8 @@ __device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
         __syncthreads();
     }
     const double nA = red[NTH];
-    STAMP(2);
-    int s = 0;  // ceil(log2(nA / 5.4)) for nA > 5.4 (Julia's exp!), from the binary exponent
+    STAMP(stamp0 + 1);
+    s = 0;  // ceil(log2(nA / 5.4)) for nA > 5.4 (Julia's exp!), from the binary exponent
     if (nA > 5.4) {
         const double r = nA / 5.4;
         const int e = ilogb(r);
@@ -576,15 +696,17 @@ __device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
         __syncthreads();
     }
 
-    Strip<NT> Pn, Qn;  // numerator P = V+U, denominator Q = V-U
-    int order;
-    double inv_b0sq;  // 1 / b0^2 of the Pade order in use: scale of the pivots of q(A) ~ b0 exp(-A/2)
+    // inv_b0sq = 1 / b0^2 of the Pade order in use: scale of the pivots of q(A) ~ b0 exp(-A/2)
     // The fast instantiation (PIVOTED = false) solves the Pade system with the unpivoted block
     // Gauss-Jordan; if a pivot turns out numerically unsafe (e.g. a pi-pulse in one step: q(A) has a zero
     // diagonal) it flags the cell, and the PIVOTED instantiation, launched afterwards over the flagged
     // cells only, re-evaluates P and Q and solves with full partial pivoting in LDS (what LAPACK gesv
     // does in the reference).
+#ifdef EXP_ONLY13
+    if (true) {
+#else
     if (nA > 2.1) {
+#endif
         order = 13;
         inv_b0sq = 1.0 / (B13_0 * B13_0);
         Strip<NT> A2, A4, A6;
@@ -594,19 +716,17 @@ __device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
             strip_zero(A2);
             gemm_xb<NT, LD>(A2, Are, Aim, As, lane);  // A2 = A*A
         }
-        STAMP(3);
+        STAMP(stamp0 + 2);
         strip_store_lds<NT, LD>(Xre, Xim, A2, wave, lane);  // X = A2
         __syncthreads();
-        STAMP(4);
         strip_zero(A4);
         gemm_xb<NT, LD>(A4, Xre, Xim, A2, lane);  // A4 = A2*A2
         strip_zero(A6);
         gemm_xb<NT, LD>(A6, Xre, Xim, A4, lane);  // A6 = A2*A4
-        STAMP(5);
+        STAMP(stamp0 + 3);
         __syncthreads();
         strip_store_lds<NT, LD>(Xre, Xim, A6, wave, lane);  // X = A6
         __syncthreads();
-        STAMP(6);
         // T = A6*(b13 A6 + b11 A4 + b9 A2) + b7 A6 + b5 A4 + b3 A2 + b1 I      (U = A*T)
         // V = A6*(b12 A6 + b10 A4 + b8 A2) + b6 A6 + b4 A4 + b2 A2 + b0 I
         Strip<NT> T, V;
@@ -619,11 +739,13 @@ __device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
         }
         strip_add_identity<NT>(T, B13_1, wave, lane);
         strip_add_identity<NT>(V, B13_0, wave, lane);
+        STAMP(stamp0 + 4);
         gemm_dual13<NT, LD>(T, V, Xre, Xim, A2, A4, A6, lane);
-        STAMP(7);
+        STAMP(stamp0 + 5);
         Strip<NT> Uo;
         strip_zero(Uo);
         gemm_xb<NT, LD>(Uo, Are, Aim, T, lane);  // U = A*T
+        STAMP(stamp0 + 6);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             Pn.re[t] = V.re[t] + Uo.re[t];
@@ -683,30 +805,15 @@ __device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
         }
     }
 
-    // ---- solve (V-U) X = (V+U) ----
-    STAMP(8);
-    if constexpr (!PIVOTED) {
-        // block Gauss-Jordan on MFMA; the X planes double as panel slots (3 * 2 * NP * 18 <= 2 * NP * LD)
-        double minrel = 1e300;
-#ifdef GRAPE_DIAG
-        if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, Xre, Dv, wave, lane, minrel, inv_b0sq, !(a.ablate & 1));
-#else
-        block_gj_solve<NT>(Qn, Pn, Xre, Dv, wave, lane, minrel, inv_b0sq, true);
-#endif
-        // |pivot| < 1e-3 b0 (or NaN) in any of the diagonal tiles -> flag the cell for the pivoted pass
-        if (lane == 0 && !(minrel > 1e-6)) a.cellflag[cell] = 1;
-    } else {
-        __syncthreads();
-        strip_store_lds<NT, LD>(Xre, Xim, Qn, wave, lane);   // Q -> X planes
-        strip_store_lds<NT, LD>(Are, Aim, Pn, wave, lane);   // P -> A planes (A is dead by now)
-        __syncthreads();
-        const bool ok = pivoted_solve_lds<NP, LD, NTH>(Xre, Xim, Are, Aim, red, tid);
-        strip_load_lds<NT, LD>(Are, Aim, Pn, wave, lane);    // X = Q^-1 P
-        if (!ok && tid == 0) atomicOr(&a.flags[0], 1);       // exactly singular denominator
-        if (tid == 0) atomicAdd(&a.stats[9], 1ull);          // cells that needed the pivoted solve
-        __syncthreads();
-    }
-    STAMP(9);
+}
+
+// Squarings and the store of U_kn (row-major interleaved complex) for one cell.
+template <int NT>
+__device__ __forceinline__ void expm_finish(const ExpmArgs &a, const int cell, const int wave, const int lane,
+                                            double *smem, Strip<NT> &Pn, const int s) {
+    using LY = ExpmLds<NT>;
+    constexpr int NP = LY::NP, LD = LY::LD;
+    double *Xre = smem + LY::REG, *Xim = Xre + NP * LD;
     // ---- squarings ----
     for (int it = 0; it < s; ++it) {
         __syncthreads();
@@ -730,26 +837,214 @@ __device__ __forceinline__ void expm_cell(const ExpmArgs &a, const int cell) {
                 Uc[row * NP + col] = make_double2(Pn.re[t][r], Pn.im[t][r]);
             }
     }
-    STAMP(10);
-    // ---- bookkeeping ----
-    if (!PIVOTED && tid == 0) {
-        atomicAdd(&a.stats[0], (unsigned long long)s);
-        atomicAdd(&a.stats[3 + (order == 13 ? 4 : (order - 3) / 2)], 1ull);
-        atomicMax(&a.flags[1], s);
+}
+
+template <int NT>
+__device__ __forceinline__ void expm_stats(const ExpmArgs &a, const int s, const int order) {
+    atomicAdd(&a.stats[0], (unsigned long long)s);
+    atomicAdd(&a.stats[3 + (order == 13 ? 4 : (order - 3) / 2)], 1ull);
+    atomicMax(&a.flags[1], s);
+}
+
+// Robust single-cell path (second pass over flagged cells): P and Q are re-evaluated and the system is
+// solved with full partial pivoting in LDS (what LAPACK gesv does in the reference).
+template <int NT>
+__device__ __forceinline__ void expm_cell_pivoted(const ExpmArgs &a, const int cell) {
+    using LY = ExpmLds<NT>;
+    constexpr int NP = LY::NP, LD = LY::LD, NTH = LY::NTH;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *Are = smem, *Aim = Are + NP * LD, *Xre = smem + LY::REG, *Xim = Xre + NP * LD;
+    double *red = smem + 2 * LY::REG + LY::DV;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Strip<NT> Pn, Qn;
+    int s, order;
+    double inv_b0sq;
+    expm_numden<NT>(a, cell, wave, lane, tid, smem, Pn, Qn, s, order, inv_b0sq);
+    __syncthreads();
+    strip_store_lds<NT, LD>(Xre, Xim, Qn, wave, lane);   // Q -> X planes
+    strip_store_lds<NT, LD>(Are, Aim, Pn, wave, lane);   // P -> A planes (A is dead by now)
+    __syncthreads();
+    const bool ok = pivoted_solve_lds<NP, LD, NTH>(Xre, Xim, Are, Aim, red, tid);
+    strip_load_lds<NT, LD>(Are, Aim, Pn, wave, lane);    // X = Q^-1 P
+    if (!ok && tid == 0) atomicOr(&a.flags[0], 1);       // exactly singular denominator
+    if (tid == 0) atomicAdd(&a.stats[9], 1ull);          // cells that needed the pivoted solve
+    __syncthreads();
+    expm_finish<NT>(a, cell, wave, lane, smem, Pn, s);
+}
+
+// Fast path: one workgroup evaluates TWO cells.  Their polynomial phases run back to back (the
+// finished P, Q strips of the first cell stay parked in registers), then both Pade systems are solved
+// together: the serial part of the block Gauss-Jordan (the register inversion of a 16x16 diagonal tile by
+// one wave) belongs to different waves for the two cells -- the second cell's strips are owned with the
+// wave index rotated by NT/2 -- so two SIMDs invert while the other two issue the MFMA updates of both
+// cells, instead of three SIMDs waiting for one.  If a pivot of the unpivoted elimination is
+// numerically unsafe (e.g. a pi-pulse in one step: q(A) has a zero diagonal) the cell is flagged for the
+// pivoted pass.
+// The finished P, Q strips of the first cell of a pair wait in a per-workgroup global parking area
+// (L2 resident: 128 KB per workgroup at N = 64) while the second cell's polynomials use the whole register
+// file; 32-byte vectors, consecutive lanes consecutive.
+template <int NT>
+__device__ __forceinline__ void strips_park(double *area, const Strip<NT> &P, const Strip<NT> &Q, int tid) {
+    double2 *p = (double2 *)area + tid;   // 16-byte vectors, consecutive lanes consecutive: 1 KB per wave store
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            p[((8 * t + 0 + h) * NT) * 64] = make_double2(P.re[t][2 * h], P.re[t][2 * h + 1]);
+            p[((8 * t + 2 + h) * NT) * 64] = make_double2(P.im[t][2 * h], P.im[t][2 * h + 1]);
+            p[((8 * t + 4 + h) * NT) * 64] = make_double2(Q.re[t][2 * h], Q.re[t][2 * h + 1]);
+            p[((8 * t + 6 + h) * NT) * 64] = make_double2(Q.im[t][2 * h], Q.im[t][2 * h + 1]);
+        }
     }
+}
+template <int NT>
+__device__ __forceinline__ void strips_unpark(const double *area, Strip<NT> &P, Strip<NT> &Q, int tid) {
+    const double2 *p = (const double2 *)area + tid;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double2 a = p[((8 * t + 0 + h) * NT) * 64], b = p[((8 * t + 2 + h) * NT) * 64];
+            const double2 c = p[((8 * t + 4 + h) * NT) * 64], d = p[((8 * t + 6 + h) * NT) * 64];
+            P.re[t][2 * h] = a.x; P.re[t][2 * h + 1] = a.y;
+            P.im[t][2 * h] = b.x; P.im[t][2 * h + 1] = b.y;
+            Q.re[t][2 * h] = c.x; Q.re[t][2 * h + 1] = c.y;
+            Q.im[t][2 * h] = d.x; Q.im[t][2 * h + 1] = d.y;
+        }
+    }
+}
+
+// Two independent systems Qa Xa = Pa, Qb Xb = Pb solved in lockstep (one barrier per block step for
+// both).  SA / SB are the strip indices this wave owns in the two cells; with SB = SA + NT/2 the
+// inverting waves of the two cells are always different, so the two serial inversions of a step run on
+// different SIMDs at the same time.  The role of a wave is a template parameter: every wave runs its own
+// straight-line specialisation from the moment the first cell's strips come back from the parking area
+// until both propagators are stored (no strip-sized phi nodes or copies at the role branches, which
+// cost registers); all specialisations execute the same number of barriers.
+template <int NT, int SA>
+__device__ __forceinline__ void pair_tail_role(const ExpmArgs &a, const int cellA, const int cellB, const bool dupB,
+                                               const double *area, Strip<NT> &Pb, Strip<NT> &Qb, double *smem,
+                                               int tid, int lane, int s_a, int s_b, double isc_a, double isc_b) {
+    using LY = ExpmLds<NT>;
+    constexpr int SB = (SA + NT / 2) % NT;
+    double *panA = smem + LY::REG, *panB = smem, *dvA = smem + 2 * LY::REG, *dvB = dvA + 3 * GjLds<NT>::DV;
+    Strip<NT> Pa, Qa;
+    strips_unpark<NT>(area, Pa, Qa, tid);
+    double minrel_a = 1e300, minrel_b = 1e300;
+    if constexpr (SA == 0) gj_publish_invert<NT>(Qa, 0, panA, dvA, lane, minrel_a, isc_a, true);
+    if constexpr (SB == 0) gj_publish_invert<NT>(Qb, 0, panB, dvB, lane, minrel_b, isc_b, true);
+    __syncthreads();
+    GJSTAMP(5);
+#pragma unroll
+    for (int jb = 0; jb < NT; ++jb) {
+        gj_step<NT>(Qa, Pa, SA, jb, panA, dvA, lane, minrel_a, isc_a);
+        gj_step<NT>(Qb, Pb, SB, jb, panB, dvB, lane, minrel_b, isc_b);
+        __syncthreads();
+        GJSTAMP(6 + jb);
+    }
+    // |pivot| < 1e-3 b0 (or NaN) in any of the diagonal tiles -> flag the cell for the pivoted pass
+    if (lane == 0 && !(minrel_a > 1e-6)) a.cellflag[cellA] = 1;
+    if (lane == 0 && !(minrel_b > 1e-6)) a.cellflag[cellB] = 1;
+    GJSTAMP(3);
+    expm_finish<NT>(a, cellA, SA, lane, smem, Pa, s_a);
+    if (!dupB) expm_finish<NT>(a, cellB, SB, lane, smem, Pb, s_b);
+}
+
+// Fast path: one workgroup evaluates TWO cells at a time.  Their polynomial phases run back to back
+// (the finished P, Q strips of the first cell are parked), then both Pade systems are solved together:
+// the serial part of the block Gauss-Jordan (the register inversion of a 16x16 diagonal tile by one wave)
+// belongs to different waves for the two cells -- the second cell's strips are owned with the wave index
+// rotated by NT/2 -- so two SIMDs invert while the other two issue the MFMA updates of both cells,
+// instead of three SIMDs waiting for one.  If a pivot of the unpivoted elimination is numerically unsafe
+// (e.g. a pi-pulse in one step: q(A) has a zero diagonal) the cell is flagged for the pivoted pass.
+template <int NT>
+__device__ __forceinline__ void expm_pair(const ExpmArgs &a, const int cellA, const int cellB, const bool dupB,
+                                          const int tid) {
+    using LY = ExpmLds<NT>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sa = wave, sb = (wave + NT / 2) % NT;
+    double *area = a.park + (size_t)blockIdx.x * (NT * 64) * (16 * NT);
+    Strip<NT> Pb, Qb;
+    int s_a, s_b, order_a, order_b;
+    double isc_a, isc_b;
+    STAMP(0);
+    {
+        Strip<NT> Pa, Qa;
+        expm_numden<NT>(a, cellA, sa, lane, tid, smem, Pa, Qa, s_a, order_a, isc_a);
+        STAMP(27);
+        strips_park<NT>(area, Pa, Qa, tid);
+        STAMP(28);
+    }
+    __syncthreads();   // every wave is done reading A and X of the first cell
+    STAMP(1);
+    expm_numden<NT>(a, cellB, sb, lane, tid, smem, Pb, Qb, s_b, order_b, isc_b, 19);
+    __syncthreads();   // the plane regions are free for the panels; also pins the unpark loads after the GEMMs
+    STAMP(2);
+    if (wave == 0) pair_tail_role<NT, 0>(a, cellA, cellB, dupB, area, Pb, Qb, smem, tid, lane, s_a, s_b, isc_a, isc_b);
+    if constexpr (NT > 1)
+        if (wave == 1) pair_tail_role<NT, 1>(a, cellA, cellB, dupB, area, Pb, Qb, smem, tid, lane, s_a, s_b, isc_a, isc_b);
+    if constexpr (NT > 2) {
+        if (wave == 2) pair_tail_role<NT, 2>(a, cellA, cellB, dupB, area, Pb, Qb, smem, tid, lane, s_a, s_b, isc_a, isc_b);
+        if (wave == 3) pair_tail_role<NT, 3>(a, cellA, cellB, dupB, area, Pb, Qb, smem, tid, lane, s_a, s_b, isc_a, isc_b);
+    }
+    STAMP(4);
+    if (tid == 0) {
+        expm_stats<NT>(a, s_a, order_a);
+        if (!dupB) expm_stats<NT>(a, s_b, order_b);
+    }
+}
+
+// Fast single-cell path: one workgroup per cell, unpivoted block Gauss-Jordan with look-ahead.
+template <int NT>
+__device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell) {
+    using LY = ExpmLds<NT>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Strip<NT> Pn, Qn;
+    int s, order;
+    double inv_b0sq;
+    STAMP(0);
+    expm_numden<NT>(a, cell, wave, lane, tid, smem, Pn, Qn, s, order, inv_b0sq);
+    STAMP(2);
+    double minrel = 1e300;
+    block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true);
+    // |pivot| < 1e-3 b0 (or NaN) in any of the diagonal tiles -> flag the cell for the pivoted pass
+    if (lane == 0 && !(minrel > 1e-6)) a.cellflag[cell] = 1;
+    STAMP(3);
+    expm_finish<NT>(a, cell, wave, lane, smem, Pn, s);
+    STAMP(4);
+    if (tid == 0) expm_stats<NT>(a, s, order);
 }
 
 template <int NT, bool PIVOTED>
 __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     const int ncell = a.K * a.N_T;
     if constexpr (!PIVOTED) {
-        expm_cell<NT, false>(a, xcd_remap(blockIdx.x, ncell));   // one workgroup per cell
+#ifdef GRAPE_EXPM_PAIR
+        // persistent: the grid is one workgroup per CU (a multiple of 8, so that virtual block ids keep
+        // their XCD), each walks its share of the cell pairs
+        const int npair = (ncell + 1) >> 1;
+        for (int v = blockIdx.x; v < npair; v += gridDim.x) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));   // keep per-thread address arithmetic inside the loop (registers)
+            const int c0 = 2 * xcd_remap(v, npair);
+            const bool dup = c0 + 1 >= ncell;   // odd cell count: the last pair repeats its cell
+            expm_pair<NT>(a, c0, dup ? c0 : c0 + 1, dup, tid);
+            __syncthreads();
+        }
+#else
+        expm_single<NT>(a, xcd_remap(blockIdx.x, ncell));   // one workgroup per cell
+#endif
     } else {
         // second pass, small grid: every workgroup scans a slice of the flags and re-solves flagged cells
         for (int cell = blockIdx.x; cell < ncell; cell += gridDim.x) {
             if (!a.cellflag[cell]) continue;
             __syncthreads();
-            expm_cell<NT, true>(a, cell);
+            expm_cell_pivoted<NT>(a, cell);
         }
     }
 }
