@@ -55,8 +55,6 @@ struct grape_handle {
     double *d_f = nullptr, *d_G = nullptr, *d_rho = nullptr;
     int *d_flags = nullptr;
     int *d_cellflag = nullptr;   // [K*N_T] cells flagged for the pivoted Pade solve
-    double *d_park = nullptr;    // parking area of the persistent expm kernel (expm_grid workgroups)
-    int expm_grid = 0;           // workgroups of the persistent expm kernel: one per CU, a multiple of 8
     // state running cost (g_b = <Psi|D|Psi>): transposed D, trapezoid weights, xi and g per stored state
     double2 *d_Dt = nullptr, *d_xi = nullptr;
     double *d_wq = nullptr, *d_gb = nullptr;
@@ -92,7 +90,7 @@ size_t expm_lds_bytes(int NT) {
 }
 
 template <int NT>
-hipError_t launch_expm(const ExpmArgs &a, int grid, hipStream_t s) {
+hipError_t launch_expm(const ExpmArgs &a, hipStream_t s) {
     static bool attr_set[8] = {false};
     const size_t lds = expm_lds_bytes(NT);
     int dev = 0;
@@ -109,11 +107,7 @@ hipError_t launch_expm(const ExpmArgs &a, int grid, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.cellflag, 0, (size_t)a.K * a.N_T * sizeof(int), s);
     if (e != hipSuccess) return e;
     // fast pass: unpivoted block Gauss-Jordan, flags the cells it cannot solve safely
-    #ifdef GRAPE_EXPM_PAIR
-    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(std::min((a.K * a.N_T + 1) / 2, grid)), dim3(NT * 64), lds, s, a);  // persistent, cell pairs
-#else
-    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);  // one WG per cell
-#endif
+        hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);  // one WG per cell
     // pivoted pass over the flagged cells (all other workgroups exit at once)
     hipLaunchKernelGGL((expm_pade_kernel<NT, true>), dim3(std::min(a.K * a.N_T, 1024)), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
@@ -330,7 +324,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_park, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -491,12 +485,6 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, 16));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
-    {
-        hipDeviceProp_t prop;
-        CCHK(hipGetDeviceProperties(&prop, h->device));
-        h->expm_grid = std::max(8, (prop.multiProcessorCount / 8) * 8);
-        if (!h->large) CCHK(dmalloc(&h->d_park, (size_t)h->expm_grid * (h->NT * 64) * (16 * h->NT)));
-    }
     CCHK(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
     CCHK(hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long)));
     CCHK(hipMemset(h->d_fw, 0, (size_t)K * (N_T + 1) * NP * 16));
@@ -541,7 +529,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     // ---- phase 0: expm of every cell ----
     ExpmArgs ea{};
     ea.H0f = h->d_H0f; ea.Hcf = h->d_Hcf; ea.eps = h->d_eps; ea.shape = h->d_shape; ea.dts = h->d_dts;
-    ea.U = h->d_U; ea.flags = h->d_flags; ea.stats = h->d_stats; ea.cellflag = h->d_cellflag; ea.park = h->d_park;
+    ea.U = h->d_U; ea.flags = h->d_flags; ea.stats = h->d_stats; ea.cellflag = h->d_cellflag;
     ea.K = h->K; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
 #ifdef GRAPE_DIAG
     ea.ablate = getenv("GRAPE_DIAG_ABLATE") ? atoi(getenv("GRAPE_DIAG_ABLATE")) : 0;
@@ -559,9 +547,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         e = expm_large(h, s);
     } else {
         switch (h->NT) {
-            case 1: e = launch_expm<1>(ea, h->expm_grid, s); break;
-            case 2: e = launch_expm<2>(ea, h->expm_grid, s); break;
-            default: e = launch_expm<4>(ea, h->expm_grid, s); break;
+            case 1: e = launch_expm<1>(ea, s); break;
+            case 2: e = launch_expm<2>(ea, s); break;
+            default: e = launch_expm<4>(ea, s); break;
         }
     }
     HIPCHK(h, e);
@@ -569,48 +557,20 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
 #ifdef GRAPE_DIAG
     if (ea.stamps) {
         hipStreamSynchronize(s);
-        const size_t nb = std::min(((size_t)h->K * h->N_T + 1) / 2, (size_t)h->expm_grid);   // last pair of every workgroup
+        const size_t nb = (size_t)h->K * h->N_T;
         std::vector<unsigned long long> st(nb * 32);
         hipMemcpy(st.data(), ea.stamps, nb * 32 * 8, hipMemcpyDeviceToHost);
-        const char *names[] = {"polynomials, cell a", "polynomials, cell b", "pair solve (block GJ)", "squarings + store U"};
-        for (int i = 0; i < 4; ++i) {
+        auto avg = [&](int i1, int i0) {
             double sum = 0;
-            for (size_t b = 0; b < nb; ++b) sum += (double)(st[b * 32 + i + 1] - st[b * 32 + i]);
-            fprintf(stderr, "  stamp %-24s %9.0f ticks\n", names[i], sum / nb);
-        }
-        double tot = 0;
-        for (size_t b = 0; b < nb; ++b) tot += (double)(st[b * 32 + 4] - st[b * 16]);
-        fprintf(stderr, "  stamp %-24s %9.0f ticks\n", "TOTAL per cell pair", tot / nb);
-        {
-            double v[8] = {0};
-            for (size_t b = 0; b < nb; ++b) {
-                v[0] += (double)(st[b * 32 + 5] - st[b * 32 + 2]);
-                for (int j = 0; j < 4; ++j) v[1 + j] += (double)(st[b * 32 + 6 + j] - st[b * 32 + 5 + j]);
-                v[5] += (double)st[b * 32 + 10];
-            }
-            const char *pn[] = {"form A", "norm", "A2", "A4,A6 (+store A2)", "store A6 + combos", "dual", "U=A*T"};
-            for (int c = 0; c < 2; ++c) {
-                const int s0 = c ? 19 : 11, first = c ? 1 : 0;
-                fprintf(stderr, "  cell %c:", 'a' + c);
-                for (int j = 0; j < 7; ++j) {
-                    double sum = 0;
-                    for (size_t b = 0; b < nb; ++b) sum += (double)(st[b * 32 + s0 + j] - st[b * 32 + (j ? s0 + j - 1 : first)]);
-                    fprintf(stderr, " %s %.0f;", pn[j], sum / nb);
-                }
-                fprintf(stderr, "\n");
-            }
-            {
-                double v0 = 0, v1 = 0, v2 = 0;
-                for (size_t b = 0; b < nb; ++b) {
-                    v0 += (double)(st[b * 32 + 27] - st[b * 32 + 17]);
-                    v1 += (double)(st[b * 32 + 28] - st[b * 32 + 27]);
-                    v2 += (double)(st[b * 32 + 1] - st[b * 32 + 28]);
-                }
-                fprintf(stderr, "  cell a: P,Q formation %.0f; park stores %.0f; barrier %.0f\n", v0 / nb, v1 / nb, v2 / nb);
-            }
-            fprintf(stderr, "  solve: initial inversions %.0f, steps %.0f %.0f %.0f %.0f; sum of all 8 invert16 %.0f\n",
-                    v[0] / nb, v[1] / nb, v[2] / nb, v[3] / nb, v[4] / nb, v[5] / nb);
-        }
+            for (size_t b = 0; b < nb; ++b) sum += (double)(st[b * 32 + i1] - st[b * 32 + i0]);
+            return sum / nb;
+        };
+        const char *pn[] = {"form A", "norm", "A2", "A4,A6 (+store A2)", "store A6 + combos", "dual", "U=A*T"};
+        for (int j = 0; j < 7; ++j) fprintf(stderr, "  stamp %-24s %9.0f cycles\n", pn[j], avg(11 + j, j ? 10 + j : 0));
+        fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "P,Q + first inversion", avg(5, 17));
+        for (int j = 0; j < 4; ++j) fprintf(stderr, "  stamp solve step %d             %9.0f cycles\n", j, avg(6 + j, 5 + j));
+        fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "squarings + store U", avg(4, 3));
+        fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "TOTAL per cell", avg(4, 0));
     }
 #endif
     // ---- phase 1: forward sweep + tau ----

@@ -52,7 +52,6 @@ struct ExpmArgs {
     unsigned long long *stats; // [0] sum of squarings, [3..7] #cells with Pade order 3/5/7/9/13
     int K, L, N_T, hc_per_traj;
     int *cellflag;       // [K*N_T] set by the fast kernel for cells that need the pivoted solve
-    double *park;        // [gridDim][NT*64 threads][16*NT] parking area of the fast kernel (P, Q of the first cell of a pair)
 #ifdef GRAPE_DIAG
     int ablate;  // diagnostic builds only (tools/ablate.sh): bit0 skip invert16, bit1 skip solve
     unsigned long long *stamps;  // [nblocks][16] s_memtime at phase boundaries (diagnostic builds only)
@@ -172,58 +171,6 @@ __device__ __forceinline__ void gemm_dual13(Strip<NT> &T, Strip<NT> &V, const do
     }
 }
 
-// Fused pair of products sharing the left operand:  T += X * W,  V += X * Z  (software pipelined like
-// gemm_xb: the LDS reads of k-step ks+1 are issued before the MFMAs of k-step ks).
-template <int NT, int LD>
-__device__ __forceinline__ void gemm_dual(Strip<NT> &T, Strip<NT> &V, const double *__restrict__ Xre,
-                                          const double *__restrict__ Xim, const Strip<NT> &W, const Strip<NT> &Z,
-                                          int lane) {
-    const double *__restrict__ xr = Xre + (lane & 15) * LD + (lane >> 4);
-    const double *__restrict__ xi = Xim + (lane & 15) * LD + (lane >> 4);
-    double are[NT], aim[NT];
-#pragma unroll
-    for (int tr = 0; tr < NT; ++tr) {
-        are[tr] = xr[16 * tr * LD];
-        aim[tr] = xi[16 * tr * LD];
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ks = 4 * t + r;
-            double nre[NT], nim[NT];
-            if (ks + 1 < 4 * NT) {
-#pragma unroll
-                for (int tr = 0; tr < NT; ++tr) {
-                    nre[tr] = xr[16 * tr * LD + 4 * (ks + 1)];
-                    nim[tr] = xi[16 * tr * LD + 4 * (ks + 1)];
-                }
-            }
-            const double wr = W.re[t][r], wi = W.im[t][r], zr = Z.re[t][r], zi = Z.im[t][r];
-            const double nwi = -wi, nzi = -zi;
-#pragma unroll
-            for (int tr = 0; tr < NT; ++tr) {
-                T.re[tr] = MFMA64(are[tr], wr, T.re[tr]);
-                T.im[tr] = MFMA64(are[tr], wi, T.im[tr]);
-                V.re[tr] = MFMA64(are[tr], zr, V.re[tr]);
-                V.im[tr] = MFMA64(are[tr], zi, V.im[tr]);
-            }
-#pragma unroll
-            for (int tr = 0; tr < NT; ++tr) {
-                T.re[tr] = MFMA64(aim[tr], nwi, T.re[tr]);
-                T.im[tr] = MFMA64(aim[tr], wr, T.im[tr]);
-                V.re[tr] = MFMA64(aim[tr], nzi, V.re[tr]);
-                V.im[tr] = MFMA64(aim[tr], zr, V.im[tr]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < 4 * NT) {
-#pragma unroll
-                for (int tr = 0; tr < NT; ++tr) { are[tr] = nre[tr]; aim[tr] = nim[tr]; }
-            }
-        }
-    }
-}
-
 template <int NT, int LD>
 __device__ __forceinline__ void strip_store_lds(double *Xre, double *Xim, const Strip<NT> &s, int wave, int lane) {
     double *xr = Xre + (lane >> 4) * LD + 16 * wave + (lane & 15);
@@ -295,6 +242,60 @@ __device__ __forceinline__ double row_bcast_k(double v, int k) {
 // propagators this path is used for; the smallest |pivot|^2 relative to b0^2 (inv_scale2 = 1/b0^2)
 // is returned so that the caller can flag numerically unsafe eliminations instead of returning
 // garbage.
+// acc += m * (value of src in lane K of this lane's 16-lane row): one DP-ALU DPP instruction
+// (v_fmac_f64 with row_newbcast, gfx90a+), i.e. the broadcast of the pivot row is folded into the FMA.
+// The s_nop covers the VALU-write -> DPP-read hazard the compiler cannot see inside inline assembly.
+template <int K>
+__device__ __forceinline__ void fmac_rowbcast(double &acc, double src, double m) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc) : "v"(src), "v"(m), "n"(K));
+}
+
+// one pivot step of invert16 (K is a template parameter: the DPP lane select is an immediate)
+template <int K>
+__device__ __forceinline__ void invert16_step(double (&ar)[4], double (&ai)[4], const int i, const int g,
+                                              double &minrel, double &myqr, double &myqi, double inv_scale2) {
+    constexpr int kg = K & 3, kc = K >> 2;
+    const double pr = readlane_f64(ar[kc], 16 * kg + K);   // pivot p_k = D[k][k]
+    const double pi = readlane_f64(ai[kc], 16 * kg + K);
+    const double mr = __shfl(ar[kc], 16 * kg + i, 64);      // a_ik of this lane's row
+    const double mi = __shfl(ai[kc], 16 * kg + i, 64);
+    // 1/p_k: v_rcp_f64 seed + two Newton steps
+    const double den = fma(pr, pr, pi * pi);
+    double inv = __builtin_amdgcn_rcp(den);
+    inv = inv * fma(-den, inv, 2.0);
+    inv = inv * fma(-den, inv, 2.0);
+    const double qr = pr * inv, qi = -pi * inv;
+    minrel = fmin(minrel, den * inv_scale2);
+    const bool isk = (i == K);
+    myqr = isk ? qr : myqr;
+    myqi = isk ? qi : myqi;
+    // multiplier m' = a_ik / p_k, zero for the pivot row itself (which therefore stays untouched and can
+    // be read by the row broadcasts while the other rows are being updated)
+    const double tr_ = fma(mr, qr, -mi * qi), ti_ = fma(mr, qi, mi * qr);
+    const double nmr = isk ? 0.0 : -tr_, nmi = isk ? 0.0 : -ti_, pmi = -nmi;
+    // column k of the in-place inverse: the e_k column of [D | I]
+    const bool pc = (g == kg);
+    ar[kc] = pc ? (isk ? 1.0 : 0.0) : ar[kc];
+    ai[kc] = pc ? 0.0 : ai[kc];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // a_ij -= m' a_kj for this lane's columns j = 4c+g
+        fmac_rowbcast<K>(ar[c], ar[c], nmr);
+        fmac_rowbcast<K>(ar[c], ai[c], pmi);
+        fmac_rowbcast<K>(ai[c], ai[c], nmr);
+        fmac_rowbcast<K>(ai[c], ar[c], nmi);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void invert16_steps(double (&ar)[4], double (&ai)[4], const int i, const int g,
+                                               double &minrel, double &myqr, double &myqi, double inv_scale2) {
+    if constexpr (K < 16) {
+        invert16_step<K>(ar, ai, i, g, minrel, myqr, myqi, inv_scale2);
+        invert16_steps<K + 1>(ar, ai, i, g, minrel, myqr, myqi, inv_scale2);
+    }
+}
+
 __device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int lane, double inv_scale2) {
     const int i = lane & 15, g = lane >> 4;
     double minrel = 1e300;
@@ -303,47 +304,7 @@ __device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int
     //   a_ij -= (a_ik / p_k) a_kj  (j != k),   a_ik = -(a_ik / p_k),   a_kk = 1,
     // and every row is divided by its own pivot afterwards.  Per step: one complex reciprocal,
     // one complex multiply and the 4 complex FMAs of this lane's columns.
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int kg = k & 3, kc = k >> 2;
-        const double pr = readlane_f64(ar[kc], 16 * kg + k);   // pivot p_k = D[k][k]
-        const double pi = readlane_f64(ai[kc], 16 * kg + k);
-        double mr = __shfl(ar[kc], 16 * kg + i, 64);            // a_ik of this lane's row
-        double mi = __shfl(ai[kc], 16 * kg + i, 64);
-        double xr[4], xi[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {                           // a_kj of this lane's columns j = 4c+g:
-            xr[c] = row_bcast_k(ar[c], k);                      // lane k of this lane's own 16-lane row
-            xi[c] = row_bcast_k(ai[c], k);
-        }
-        // 1/p_k: v_rcp_f64 seed + two Newton steps
-        const double den = fma(pr, pr, pi * pi);
-        double inv = __builtin_amdgcn_rcp(den);
-        inv = inv * fma(-den, inv, 2.0);
-        inv = inv * fma(-den, inv, 2.0);
-        const double qr = pr * inv, qi = -pi * inv;
-        minrel = fmin(minrel, den * inv_scale2);
-        const bool isk = (i == k);
-        myqr = isk ? qr : myqr;
-        myqi = isk ? qi : myqi;
-        // multiplier m' = a_ik / p_k, zero for the pivot row itself
-        const double tr_ = fma(mr, qr, -mi * qi), ti_ = fma(mr, qi, mi * qr);
-        mr = isk ? 0.0 : tr_;
-        mi = isk ? 0.0 : ti_;
-        // column k of the in-place inverse: the e_k column of [D | I]
-        {
-            const bool pc = (g == kg);
-            xr[kc] = pc ? 1.0 : xr[kc];
-            xi[kc] = pc ? 0.0 : xi[kc];
-            ar[kc] = pc ? (isk ? 1.0 : 0.0) : ar[kc];
-            ai[kc] = pc ? 0.0 : ai[kc];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            ar[c] = fma(-mr, xr[c], fma(mi, xi[c], ar[c]));
-            ai[c] = fma(-mr, xi[c], fma(-mi, xr[c], ai[c]));
-        }
-    }
+    invert16_steps<0>(ar, ai, i, g, minrel, myqr, myqi, inv_scale2);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {   // row i /= p_i
         const double r = fma(ar[c], myqr, -ai[c] * myqi);
@@ -469,6 +430,7 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
     __syncthreads();  // previous users of the staging region are done
     if (wave == 0) gj_publish_invert<NT>(Q, 0, panbase, dvbase, lane, minrel, inv_scale2, do_invert);
     __syncthreads();
+    STAMP(5);
 #pragma unroll
     for (int jb = 0; jb < NT; ++jb) {
         const double *pan = panbase + (jb % 3) * PAN, *dv = dvbase + (jb % 3) * DV;
@@ -484,30 +446,7 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
             gj_update<NT>(P, jb, pan, dv, lane);
         }
         __syncthreads();
-    }
-}
-
-// One block step of the solve for one cell, seen from the wave that owns column strip `sw`.
-template <int NT>
-__device__ __forceinline__ void gj_step(Strip<NT> &Q, Strip<NT> &P, int sw, int jb, double *panbase, double *dvbase,
-                                        int lane, double &minrel, double inv_scale2) {
-    constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
-    const double *pan = panbase + (jb % 3) * PAN, *dv = dvbase + (jb % 3) * DV;
-    if (jb + 1 < NT && sw == jb + 1) {
-        gj_update<NT>(Q, jb, pan, dv, lane);
-#ifdef EXP_NO_INV
-        gj_publish_invert<NT>(Q, jb + 1, panbase + ((jb + 1) % 3) * PAN, dvbase + ((jb + 1) % 3) * DV, lane, minrel,
-                              inv_scale2, false);
-#else
-        gj_publish_invert<NT>(Q, jb + 1, panbase + ((jb + 1) % 3) * PAN, dvbase + ((jb + 1) % 3) * DV, lane, minrel,
-                              inv_scale2, true);
-#endif
-        // this wave's P update of step jb is deferred to the next step
-    } else {
-        if (jb > 0 && sw == jb)  // deferred P update of step jb-1
-            gj_update<NT>(P, jb - 1, panbase + ((jb - 1) % 3) * PAN, dvbase + ((jb - 1) % 3) * DV, lane);
-        if (sw > jb) gj_update<NT>(Q, jb, pan, dv, lane);
-        gj_update<NT>(P, jb, pan, dv, lane);
+        STAMP(6 + jb);
     }
 }
 
@@ -601,8 +540,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // ---------------------------------------------------------------------------------------
 
 // LDS carve shared by the device code and the host (expm_lds_bytes): two regions that hold a plane
-// pair (A, or the staged left operand X) during the polynomial phase and the Gauss-Jordan panel slots of
-// one cell each during the solve, then the inverse slots of both cells and the reduction scratch.
+// pair (A, and the staged left operand X) during the polynomial phase -- the X region doubles as the
+// Gauss-Jordan panel slots during the solve -- then the inverse slots and the reduction scratch.
+// sqrt for the 1-norm estimate: v_rsq_f64 seed (about 2^-24) and one coupled Newton step, relative error
+// about 1e-14.  The norm only selects the Pade order and the number of squarings, so the few ulps saved
+// by the full IEEE sequence (three times the instructions) buy nothing.
+__device__ __forceinline__ double fast_sqrt(double v) {
+    const double y = __builtin_amdgcn_rsq(v);
+    double g = v * y;
+    const double h = 0.5 * y;
+    g = fma(fma(-h, g, 0.5), g, g);
+    return v > 0. ? g : 0.;
+}
+
 template <int NT>
 struct ExpmLds {
     static constexpr int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
@@ -610,7 +560,7 @@ struct ExpmLds {
     static constexpr int NSLOT = NT < 3 ? NT : 3;
     static constexpr int SLOTS = NSLOT * 2 * NP * 18;
     static constexpr int REG = PLANES > SLOTS ? PLANES : SLOTS;   // doubles per region
-    static constexpr int DV = 2 * 1536;                           // 2 cells x 3 rotating inverse slots
+    static constexpr int DV = 1536;                               // 3 rotating inverse slots
     static constexpr int RED = NTH + 8 + NP;
     static constexpr int TOTAL = 2 * REG + DV + RED;              // doubles
 };
@@ -664,7 +614,7 @@ __device__ __forceinline__ void expm_numden(const ExpmArgs &a, const int cell, c
         double s = 0.;
         for (int i = part; i < NP; i += PARTS) {
             const double xr = Are[i * LD + j], xi = Aim[i * LD + j];
-            s += sqrt(xr * xr + xi * xi);
+            s += fast_sqrt(xr * xr + xi * xi);
         }
         red[tid] = s;
         __syncthreads();
@@ -881,122 +831,6 @@ __device__ __forceinline__ void expm_cell_pivoted(const ExpmArgs &a, const int c
 // cells, instead of three SIMDs waiting for one.  If a pivot of the unpivoted elimination is
 // numerically unsafe (e.g. a pi-pulse in one step: q(A) has a zero diagonal) the cell is flagged for the
 // pivoted pass.
-// The finished P, Q strips of the first cell of a pair wait in a per-workgroup global parking area
-// (L2 resident: 128 KB per workgroup at N = 64) while the second cell's polynomials use the whole register
-// file; 32-byte vectors, consecutive lanes consecutive.
-template <int NT>
-__device__ __forceinline__ void strips_park(double *area, const Strip<NT> &P, const Strip<NT> &Q, int tid) {
-    double2 *p = (double2 *)area + tid;   // 16-byte vectors, consecutive lanes consecutive: 1 KB per wave store
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            p[((8 * t + 0 + h) * NT) * 64] = make_double2(P.re[t][2 * h], P.re[t][2 * h + 1]);
-            p[((8 * t + 2 + h) * NT) * 64] = make_double2(P.im[t][2 * h], P.im[t][2 * h + 1]);
-            p[((8 * t + 4 + h) * NT) * 64] = make_double2(Q.re[t][2 * h], Q.re[t][2 * h + 1]);
-            p[((8 * t + 6 + h) * NT) * 64] = make_double2(Q.im[t][2 * h], Q.im[t][2 * h + 1]);
-        }
-    }
-}
-template <int NT>
-__device__ __forceinline__ void strips_unpark(const double *area, Strip<NT> &P, Strip<NT> &Q, int tid) {
-    const double2 *p = (const double2 *)area + tid;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const double2 a = p[((8 * t + 0 + h) * NT) * 64], b = p[((8 * t + 2 + h) * NT) * 64];
-            const double2 c = p[((8 * t + 4 + h) * NT) * 64], d = p[((8 * t + 6 + h) * NT) * 64];
-            P.re[t][2 * h] = a.x; P.re[t][2 * h + 1] = a.y;
-            P.im[t][2 * h] = b.x; P.im[t][2 * h + 1] = b.y;
-            Q.re[t][2 * h] = c.x; Q.re[t][2 * h + 1] = c.y;
-            Q.im[t][2 * h] = d.x; Q.im[t][2 * h + 1] = d.y;
-        }
-    }
-}
-
-// Two independent systems Qa Xa = Pa, Qb Xb = Pb solved in lockstep (one barrier per block step for
-// both).  SA / SB are the strip indices this wave owns in the two cells; with SB = SA + NT/2 the
-// inverting waves of the two cells are always different, so the two serial inversions of a step run on
-// different SIMDs at the same time.  The role of a wave is a template parameter: every wave runs its own
-// straight-line specialisation from the moment the first cell's strips come back from the parking area
-// until both propagators are stored (no strip-sized phi nodes or copies at the role branches, which
-// cost registers); all specialisations execute the same number of barriers.
-template <int NT, int SA>
-__device__ __forceinline__ void pair_tail_role(const ExpmArgs &a, const int cellA, const int cellB, const bool dupB,
-                                               const double *area, Strip<NT> &Pb, Strip<NT> &Qb, double *smem,
-                                               int tid, int lane, int s_a, int s_b, double isc_a, double isc_b) {
-    using LY = ExpmLds<NT>;
-    constexpr int SB = (SA + NT / 2) % NT;
-    double *panA = smem + LY::REG, *panB = smem, *dvA = smem + 2 * LY::REG, *dvB = dvA + 3 * GjLds<NT>::DV;
-    Strip<NT> Pa, Qa;
-    strips_unpark<NT>(area, Pa, Qa, tid);
-    double minrel_a = 1e300, minrel_b = 1e300;
-    if constexpr (SA == 0) gj_publish_invert<NT>(Qa, 0, panA, dvA, lane, minrel_a, isc_a, true);
-    if constexpr (SB == 0) gj_publish_invert<NT>(Qb, 0, panB, dvB, lane, minrel_b, isc_b, true);
-    __syncthreads();
-    GJSTAMP(5);
-#pragma unroll
-    for (int jb = 0; jb < NT; ++jb) {
-        gj_step<NT>(Qa, Pa, SA, jb, panA, dvA, lane, minrel_a, isc_a);
-        gj_step<NT>(Qb, Pb, SB, jb, panB, dvB, lane, minrel_b, isc_b);
-        __syncthreads();
-        GJSTAMP(6 + jb);
-    }
-    // |pivot| < 1e-3 b0 (or NaN) in any of the diagonal tiles -> flag the cell for the pivoted pass
-    if (lane == 0 && !(minrel_a > 1e-6)) a.cellflag[cellA] = 1;
-    if (lane == 0 && !(minrel_b > 1e-6)) a.cellflag[cellB] = 1;
-    GJSTAMP(3);
-    expm_finish<NT>(a, cellA, SA, lane, smem, Pa, s_a);
-    if (!dupB) expm_finish<NT>(a, cellB, SB, lane, smem, Pb, s_b);
-}
-
-// Fast path: one workgroup evaluates TWO cells at a time.  Their polynomial phases run back to back
-// (the finished P, Q strips of the first cell are parked), then both Pade systems are solved together:
-// the serial part of the block Gauss-Jordan (the register inversion of a 16x16 diagonal tile by one wave)
-// belongs to different waves for the two cells -- the second cell's strips are owned with the wave index
-// rotated by NT/2 -- so two SIMDs invert while the other two issue the MFMA updates of both cells,
-// instead of three SIMDs waiting for one.  If a pivot of the unpivoted elimination is numerically unsafe
-// (e.g. a pi-pulse in one step: q(A) has a zero diagonal) the cell is flagged for the pivoted pass.
-template <int NT>
-__device__ __forceinline__ void expm_pair(const ExpmArgs &a, const int cellA, const int cellB, const bool dupB,
-                                          const int tid) {
-    using LY = ExpmLds<NT>;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sa = wave, sb = (wave + NT / 2) % NT;
-    double *area = a.park + (size_t)blockIdx.x * (NT * 64) * (16 * NT);
-    Strip<NT> Pb, Qb;
-    int s_a, s_b, order_a, order_b;
-    double isc_a, isc_b;
-    STAMP(0);
-    {
-        Strip<NT> Pa, Qa;
-        expm_numden<NT>(a, cellA, sa, lane, tid, smem, Pa, Qa, s_a, order_a, isc_a);
-        STAMP(27);
-        strips_park<NT>(area, Pa, Qa, tid);
-        STAMP(28);
-    }
-    __syncthreads();   // every wave is done reading A and X of the first cell
-    STAMP(1);
-    expm_numden<NT>(a, cellB, sb, lane, tid, smem, Pb, Qb, s_b, order_b, isc_b, 19);
-    __syncthreads();   // the plane regions are free for the panels; also pins the unpark loads after the GEMMs
-    STAMP(2);
-    if (wave == 0) pair_tail_role<NT, 0>(a, cellA, cellB, dupB, area, Pb, Qb, smem, tid, lane, s_a, s_b, isc_a, isc_b);
-    if constexpr (NT > 1)
-        if (wave == 1) pair_tail_role<NT, 1>(a, cellA, cellB, dupB, area, Pb, Qb, smem, tid, lane, s_a, s_b, isc_a, isc_b);
-    if constexpr (NT > 2) {
-        if (wave == 2) pair_tail_role<NT, 2>(a, cellA, cellB, dupB, area, Pb, Qb, smem, tid, lane, s_a, s_b, isc_a, isc_b);
-        if (wave == 3) pair_tail_role<NT, 3>(a, cellA, cellB, dupB, area, Pb, Qb, smem, tid, lane, s_a, s_b, isc_a, isc_b);
-    }
-    STAMP(4);
-    if (tid == 0) {
-        expm_stats<NT>(a, s_a, order_a);
-        if (!dupB) expm_stats<NT>(a, s_b, order_b);
-    }
-}
-
 // Fast single-cell path: one workgroup per cell, unpivoted block Gauss-Jordan with look-ahead.
 template <int NT>
 __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell) {
@@ -1024,21 +858,7 @@ template <int NT, bool PIVOTED>
 __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     const int ncell = a.K * a.N_T;
     if constexpr (!PIVOTED) {
-#ifdef GRAPE_EXPM_PAIR
-        // persistent: the grid is one workgroup per CU (a multiple of 8, so that virtual block ids keep
-        // their XCD), each walks its share of the cell pairs
-        const int npair = (ncell + 1) >> 1;
-        for (int v = blockIdx.x; v < npair; v += gridDim.x) {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));   // keep per-thread address arithmetic inside the loop (registers)
-            const int c0 = 2 * xcd_remap(v, npair);
-            const bool dup = c0 + 1 >= ncell;   // odd cell count: the last pair repeats its cell
-            expm_pair<NT>(a, c0, dup ? c0 : c0 + 1, dup, tid);
-            __syncthreads();
-        }
-#else
         expm_single<NT>(a, xcd_remap(blockIdx.x, ncell));   // one workgroup per cell
-#endif
     } else {
         // second pass, small grid: every workgroup scans a slice of the flags and re-solves flagged cells
         for (int cell = blockIdx.x; cell < ncell; cell += gridDim.x) {
