@@ -55,6 +55,9 @@ struct grape_handle {
     double *d_f = nullptr, *d_G = nullptr, *d_rho = nullptr;
     int *d_flags = nullptr;
     int *d_cellflag = nullptr;   // [K*N_T] cells flagged for the pivoted Pade solve
+    unsigned *d_coop = nullptr;  // [2][K] step counters of the cooperative sweeps (forward, backward)
+    int coop_S = 0;              // workgroups per trajectory in the cooperative sweeps (0: one-workgroup kernel)
+    int coop_rpw = 0, coop_nw = 0;  // rows per wave and waves of a cooperative workgroup (R = nw * rpw state rows)
     // state running cost (g_b = <Psi|D|Psi>): transposed D, trapezoid weights, xi and g per stored state
     double2 *d_Dt = nullptr, *d_xi = nullptr;
     double *d_wq = nullptr, *d_gb = nullptr;
@@ -111,6 +114,22 @@ hipError_t launch_expm(const ExpmArgs &a, hipStream_t s) {
     // pivoted pass over the flagged cells (all other workgroups exit at once)
     hipLaunchKernelGGL((expm_pade_kernel<NT, true>), dim3(std::min(a.K * a.N_T, 1024)), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
+}
+
+template <int CPL>
+hipError_t launch_coop(const SweepArgs &a, bool backward, int S, int rpw, int nw, unsigned *cnt, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)a.K * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    const dim3 grid(8 * ((a.K + 7) / 8) * S), block(64 * nw);
+#define COOP_CASE(NW_, RPW_)                                                                                          \
+    if (nw == NW_ && rpw == RPW_) {                                                                                   \
+        if (backward) hipLaunchKernelGGL((sweep_coop_kernel<CPL, RPW_, NW_, true>), grid, block, 0, s, a, S, cnt);    \
+        else hipLaunchKernelGGL((sweep_coop_kernel<CPL, RPW_, NW_, false>), grid, block, 0, s, a, S, cnt);            \
+        return hipGetLastError();                                                                                     \
+    }
+    COOP_CASE(4, 1) COOP_CASE(8, 1) COOP_CASE(16, 1) COOP_CASE(16, 2) COOP_CASE(16, 4)
+#undef COOP_CASE
+    return hipErrorInvalidValue;
 }
 
 template <int NP>
@@ -303,6 +322,7 @@ int status_from_flags(grape_handle *h, int flags) {
         h->err = "The chi state of at least one trajectory has norm < chi_min_norm (optimize.jl:1021-1025)";
         return GRAPE_ERR_CHI_NORM;
     }
+    if (flags & 8) { h->err = "cooperative sweep: a sibling workgroup did not arrive (spin limit reached)"; return GRAPE_ERR_HIP; }
     if (flags & 4) {
         h->err = "taylor_grad_step! did not converge within max_order iterations (optimize.jl:644-648)";
         return GRAPE_ERR_TAYLOR;
@@ -324,7 +344,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -485,6 +505,24 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, 16));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
+    if (h->large) {
+        // cooperative sweeps when the trajectories alone cannot fill the chip: S siblings per trajectory,
+        // all siblings of a trajectory on one XCD, at most one workgroup per CU (see sweep_coop_kernel).
+        // A workgroup of NW waves owns R = NP / S = NW * RPW state rows, R in {4, 8, 16, 32, 64}.
+        hipDeviceProp_t prop;
+        CCHK(hipGetDeviceProperties(&prop, h->device));
+        const int per_xcd = std::max(1, prop.multiProcessorCount / 8), groups = (K + 7) / 8;
+        int S = 1;
+        while (S * 2 * groups <= per_xcd && h->NP / (S * 2) >= 4) S *= 2;
+        const int R = h->NP / S;
+        const char *env = getenv("GRAPE_SWEEP_COOP");
+        if (S >= 2 && R <= 64 && !(env && atoi(env) == 0)) {
+            h->coop_S = S;
+            h->coop_nw = R >= 16 ? 16 : R;
+            h->coop_rpw = R / h->coop_nw;
+            CCHK(dmalloc(&h->d_coop, (size_t)2 * K));
+        }
+    }
     CCHK(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
     CCHK(hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long)));
     CCHK(hipMemset(h->d_fw, 0, (size_t)K * (N_T + 1) * NP * 16));
@@ -585,8 +623,13 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         case 32: e = launch_sweep<32>(sa, false, s); break;
         case 64: e = launch_sweep<64>(sa, false, s); break;
         default:
-            hipLaunchKernelGGL((sweep_lg_kernel<false>), dim3(sa.K), dim3(1024), 0, s, sa, h->NP);
-            e = hipGetLastError();
+            if (h->coop_S)
+                e = h->NP == 128 ? launch_coop<2>(sa, false, h->coop_S, h->coop_rpw, h->coop_nw, h->d_coop, s)
+                                 : launch_coop<4>(sa, false, h->coop_S, h->coop_rpw, h->coop_nw, h->d_coop, s);
+            else {
+                hipLaunchKernelGGL((sweep_lg_kernel<false>), dim3(sa.K), dim3(1024), 0, s, sa, h->NP);
+                e = hipGetLastError();
+            }
     }
     HIPCHK(h, e);
     hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(64), 0, s, (const double2 *)d_out, h->d_weights, h->K,
@@ -628,8 +671,13 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
         case 32: e = launch_sweep<32>(sa, true, s); break;
         case 64: e = launch_sweep<64>(sa, true, s); break;
         default:
-            hipLaunchKernelGGL((sweep_lg_kernel<true>), dim3(sa.K), dim3(1024), 0, s, sa, h->NP);
-            e = hipGetLastError();
+            if (h->coop_S)
+                e = h->NP == 128 ? launch_coop<2>(sa, true, h->coop_S, h->coop_rpw, h->coop_nw, h->d_coop + h->K, s)
+                                 : launch_coop<4>(sa, true, h->coop_S, h->coop_rpw, h->coop_nw, h->d_coop + h->K, s);
+            else {
+                hipLaunchKernelGGL((sweep_lg_kernel<true>), dim3(sa.K), dim3(1024), 0, s, sa, h->NP);
+                e = hipGetLastError();
+            }
     }
     HIPCHK(h, e);
     phase_end(h, 2, s);

@@ -361,3 +361,197 @@ __global__ void __launch_bounds__(1024) sweep_lg_kernel(SweepArgs a, int NP) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// Cooperative sweeps for few, large trajectories (K * NP small against the chip: C5 has 8 trajectories
+// of N = 256 per GPU, i.e. 8 workgroups on 256 CUs with the kernel above).  S workgroups share one
+// trajectory: each owns R = NP / S rows of the state (forward: rows of U_n; backward: columns of U_n,
+// i.e. rows of U_n^dagger), reads only its 16 * R * NP bytes of U_n per step and publishes its slice of
+// the new state straight into the storage array, which is what the next step of every sibling reads.
+// One counter per trajectory orders the steps (agent-scope fences around a relaxed atomic); the U slice
+// of the next step is requested before the wait, so the exchange latency overlaps the HBM stream.
+// Placement: block b runs on XCD b % 8 (round-robin dispatch), so all siblings of a trajectory are given
+// the same b % 8 and meet in one L2.  The grid never exceeds one workgroup per CU: all siblings are
+// resident, and the spin is bounded anyway (flag bit 8 -> GRAPE_ERR_HIP) so that the grid always drains.
+//   forward : Psi_n     = U_n Psi_{n-1}      (optimize.jl:731-738), tau_k (:753)
+//   backward: chi_{n-1} = U_n^dagger chi_n   (optimize.jl:881), boundary :848-868, xi inhomogeneity :897-908
+// ---------------------------------------------------------------------------------------
+// Slice exchange without whole-cache maintenance: the slices are written and read with agent-scope relaxed
+// atomics (write-through / cache-bypassing accesses), a release is then just "my stores are acknowledged"
+// (s_waitcnt vmcnt(0)) before the barrier that precedes the counter increment.  Agent-scope FENCES would
+// write back and invalidate the whole L2 on every step.
+__device__ __forceinline__ void coop_store(double2 *p, double2 v) {
+    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double2 coop_load(const double2 *p) {
+    double2 v;
+    v.x = __hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+__device__ __forceinline__ bool coop_wait(unsigned *cnt, unsigned target, int *flags) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    atomicOr(&flags[0], 8);
+    return false;
+}
+
+template <int CPL, int RPW, int NW, bool BACKWARD>
+__global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S, unsigned *cnt) {
+    constexpr int NP = 64 * CPL, T = 64 * NW, R = NW * RPW, E = CPL * RPW, NG = T / R;
+    __shared__ double2 x[NP];
+    __shared__ double2 part[T > NP ? T : NP];
+    __shared__ double sc[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int k = (slot / S) * 8 + xcd, s = slot % S;
+    if (k >= a.K) return;
+    const int r0 = s * R;   // first row (forward) / column (backward) of this workgroup's slice
+    const double2 *Uk = a.U + (size_t)k * a.N_T * NP * NP;
+    double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
+    unsigned *ck = cnt + k;
+
+    // ---- initial state: every sibling forms it redundantly (N elements), sibling 0 stores it ----
+    double rho = 1.0;
+    if (!BACKWARD) {
+        if (tid < NP) {
+            const double2 v = tid < a.N ? a.psi0[(size_t)k * a.N + tid] : make_double2(0., 0.);
+            x[tid] = v;
+            if (s == 0) st[tid] = v;
+        }
+    } else {
+        const double w = a.weights ? a.weights[k] : 1.0;
+        const double Kt = (double)a.K_total;
+        double cr, ci;
+        if (a.functional == 0) { cr = w * a.f[0] / (Kt * Kt); ci = w * a.f[1] / (Kt * Kt); }
+        else if (a.functional == 1) { const double2 t = a.tau[k]; cr = w * t.x / Kt; ci = w * t.y / Kt; }
+        else { cr = w / (2.0 * Kt); ci = 0.; }
+        double2 v = make_double2(0., 0.);
+        if (tid < a.N) {
+            const double2 t = a.target[(size_t)k * a.N + tid];
+            v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+            if (a.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)
+                const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + a.N_T) * NP + tid];
+                const double c = a.lambda_b * a.wq[a.N_T];
+                v.x += c * x_.x; v.y += c * x_.y;
+            }
+        }
+        if (tid < NP) part[tid] = make_double2(v.x * v.x + v.y * v.y, 0.);
+        __syncthreads();
+        if (tid == 0) {   // same summation order as sweep_lg_kernel
+            double n2 = 0.;
+            for (int i = 0; i < NP; ++i) n2 += part[i].x;
+            sc[0] = sqrt(n2);
+        }
+        __syncthreads();
+        rho = sc[0];
+        if (tid == 0 && s == 0) {
+            a.rho[k] = rho;
+            if (rho < a.chi_min_norm) atomicOr(&a.flags[0], 2);
+        }
+        if (tid < NP) {
+            const double ir = rho > 0. ? 1.0 / rho : 0.;
+            v.x *= ir; v.y *= ir;
+            x[tid] = v;
+            if (s == 0) st[(size_t)a.N_T * NP + tid] = v;
+        }
+    }
+    __syncthreads();
+
+    // thread -> element map (T = 64 NW threads, R = NW * RPW slice rows).  forward: wave w owns rows
+    // r0 + w*RPW + r, lane covers columns c*64 + lane; backward: thread (ig = tid / R, jj = tid % R) owns
+    // column r0 + jj over rows ig + NG * m
+    const int jj = tid % R, ig = tid / R;
+    double2 u[E];
+    auto load_u = [&](int n) {
+        const double2 *Un = Uk + (size_t)n * NP * NP;
+        if (!BACKWARD) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) u[r * CPL + c] = Un[(size_t)(r0 + wave * RPW + r) * NP + c * 64 + lane];
+        } else {
+#pragma unroll
+            for (int m = 0; m < E; ++m) u[m] = Un[(size_t)(ig + NG * m) * NP + r0 + jj];
+        }
+    };
+    load_u(BACKWARD ? a.N_T - 1 : 0);
+
+    for (int step = 0; step < a.N_T; ++step) {
+        const int n = BACKWARD ? a.N_T - 1 - step : step;
+        const int nout = BACKWARD ? n : n + 1;       // storage row of the new state
+        if (step > 0) {
+            // wait until all S siblings have published step - 1, then fetch the full state
+            if (tid == 0) coop_wait(ck, (unsigned)(S * step), a.flags);
+            __syncthreads();
+            const int nin = BACKWARD ? n + 1 : n;
+            if (tid < NP) x[tid] = coop_load(&st[(size_t)nin * NP + tid]);
+            __syncthreads();
+        }
+        double2 y = make_double2(0., 0.);
+        if (!BACKWARD) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                double pr = 0., pi = 0.;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const double2 uu = u[r * CPL + c], xv = x[c * 64 + lane];
+                    pr += uu.x * xv.x - uu.y * xv.y;
+                    pi += uu.x * xv.y + uu.y * xv.x;
+                }
+                pr = wave_sum_dpp(pr);
+                pi = wave_sum_dpp(pi);
+                if (lane == 0) coop_store(&st[(size_t)nout * NP + r0 + wave * RPW + r], make_double2(pr, pi));
+            }
+        } else {
+            double ar = 0., ai = 0.;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const double2 uu = u[m], xv = x[ig + NG * m];
+                ar += uu.x * xv.x + uu.y * xv.y;
+                ai += uu.x * xv.y - uu.y * xv.x;
+            }
+            part[tid] = make_double2(ar, ai);
+            __syncthreads();
+            if (tid < R) {
+                double2 sum = part[tid];
+                for (int q = 1; q < NG; ++q) { sum.x += part[q * R + tid].x; sum.y += part[q * R + tid].y; }
+                if (a.xi && n > 0) {   // chi(t_n) += lambda_b Dt_n / rho_k xi_k(t_n)
+                    const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + n) * NP + r0 + tid];
+                    const double c = a.lambda_b * a.wq[n] / rho;
+                    sum.x += c * x_.x; sum.y += c * x_.y;
+                }
+                coop_store(&st[(size_t)nout * NP + r0 + tid], sum);
+            }
+            (void)y;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this thread's slice elements are acknowledged ...
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the count
+        // request the next U slice now: it does not depend on the state and streams in during the exchange
+        if (step + 1 < a.N_T) load_u(BACKWARD ? n - 1 : n + 1);
+    }
+
+    if (!BACKWARD && s == 0) {   // tau_k = <target_k | Psi_k(T)>
+        if (tid == 0) coop_wait(ck, (unsigned)(S * a.N_T), a.flags);
+        __syncthreads();
+        double pr = 0., pi = 0.;
+        if (tid < a.N) {
+            const double2 t = a.target[(size_t)k * a.N + tid];
+            const double2 p = coop_load(&st[(size_t)a.N_T * NP + tid]);
+            pr = t.x * p.x + t.y * p.y;
+            pi = t.x * p.y - t.y * p.x;
+        }
+        if (tid < NP) part[tid] = make_double2(pr, pi);
+        __syncthreads();
+        if (tid == 0) {
+            double sr = 0., si = 0.;
+            for (int i = 0; i < NP; ++i) { sr += part[i].x; si += part[i].y; }
+            a.tau[k] = make_double2(sr, si);
+        }
+    }
+}

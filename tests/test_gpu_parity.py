@@ -322,3 +322,27 @@ def test_state_running_cost_expectation_family(g, ref, N, L, per_traj, functiona
     assert np.abs(tau - taur).max() <= TOL_TAU
     assert np.abs(G - Gr).max() <= tol_G(Gr)
     assert np.abs(fd).max() <= 1e-7 * max(1.0, np.abs(Gr).max())
+
+
+@pytest.mark.parametrize("N,K", [(256, 3), (256, 9), (256, 17), (256, 33), (128, 2), (128, 20), (100, 40)])
+def test_cooperative_sweeps_all_slice_shapes(g, ref, N, K, monkeypatch):
+    """Few large trajectories: S workgroups share one trajectory in the sweeps (sweep_coop_kernel); K selects
+    the slice height R = NP/S in {4, 8, 16, 32, 64}.  Same parity bar as everywhere (optimize.jl:731-738, 881),
+    and agreement with the one-workgroup-per-trajectory kernel."""
+    from grape_jl_amd import synth
+    L, N_T = 2, 5
+    pr = synth.make_problem(N, L, N_T, K, seed=900 + N + K, hermitian=(K % 2 == 1))
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args, functional=1) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        fw = h.storage(0)
+    monkeypatch.setenv("GRAPE_SWEEP_COOP", "0")
+    with g.GrapeHip(*args, functional=1) as h:
+        J1, G1, tau1 = h.eval(pr["pulsevals"])
+        fw1 = h.storage(0)
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                functional=1, gradient_method=ref.TAYLOR)
+    assert np.abs(fw - fw1).max() <= 1e-14
+    assert abs(J - J1) <= 1e-14 and np.abs(G - G1).max() <= 1e-13 * max(1.0, np.abs(G1).max())
+    assert abs(J - Jr) <= 1e-12 and np.abs(tau - taur).max() <= TOL_TAU
+    assert np.abs(G - Gr).max() <= tol_G(Gr)
