@@ -250,6 +250,7 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
         const int nc = (int)std::min<long>(h->chunk, ncell - c0);
         const size_t nel = (size_t)nc * 2 * pp;
         LGCHK(hipMemsetAsync(h->d_scell + h->chunk, 0, sizeof(int), s));
+        LGCHK(hipMemsetAsync(h->d_cellflag, 0, (size_t)nc * sizeof(int), s));
         LgFormArgs fa{};
         fa.H0f = h->d_H0f; fa.Hcf = h->d_Hcf; fa.eps = h->d_eps; fa.shape = h->d_shape; fa.dts = h->d_dts;
         fa.A = A; fa.s_cell = h->d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
@@ -283,7 +284,7 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
         for (int jb = 0; jb < NB; ++jb) {
             LgInvArgs ia{};
             ia.Q = vZ; ia.Q.rb = jb; ia.Q.cb = jb; ia.Dinv = h->d_dinv; ia.flags = h->d_flags;
-            ia.inv_scale2 = 1.0 / (B13_0 * B13_0);
+            ia.inv_scale2 = 1.0 / (B13_0 * B13_0); ia.cellflag = h->d_cellflag;
             hipLaunchKernelGGL(lg_inv64_kernel, dim3(nc), dim3(256), inv_lds, s, ia);
             LGCHK(hipGetLastError());
             LgView qrow = vZ; qrow.rb = jb; qrow.cb = jb + 1;
@@ -298,6 +299,13 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
                 LGCHK(lg_gemm(s, nc, 1, NB - 1 - jb, x, qrow, cq, 1, -1.0, 1.0));  // Q[tr][..] -= Q[tr][jb] Q[jb][..]
                 LGCHK(lg_gemm(s, nc, 1, NB, x, prow, cp, 1, -1.0, 1.0));            // P[tr][:]  -= Q[tr][jb] P[jb][:]
             }
+        }
+        {   // cells whose unpivoted elimination was unsafe: partial pivoting from the intact V, U
+            LgPivArgs pa{};
+            pa.V = V; pa.Uo = Uo; pa.P = W; pa.Q = Z; pa.cellflag = h->d_cellflag; pa.flags = h->d_flags;
+            pa.stats = h->d_stats; pa.NP = NP; pa.ncell = nc;
+            hipLaunchKernelGGL(lg_pivoted_kernel, dim3(std::min(nc, 256)), dim3(1024), 0, s, pa);
+            LGCHK(hipGetLastError());
         }
         // squarings (per-cell count; cells that are done are copied through)
         int smax = 0;

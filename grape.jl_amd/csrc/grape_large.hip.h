@@ -195,6 +195,7 @@ struct LgInvArgs {
     double *Dinv;     // [ncell][2][64*64]
     int *flags;
     double inv_scale2;
+    int *cellflag;    // [chunk cells] set when a pivot of the unpivoted elimination is numerically unsafe
 };
 __global__ void __launch_bounds__(256) lg_inv64_kernel(LgInvArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem_inv[];
@@ -227,7 +228,127 @@ __global__ void __launch_bounds__(256) lg_inv64_kernel(LgInvArgs a) {
             d[row * 64 + col] = P.re[t][r];
             d[4096 + row * 64 + col] = P.im[t][r];
         }
-    if (lane == 0 && !(minrel > 1e-20)) atomicOr(&a.flags[0], 1);
+    // |pivot| < 1e-3 b0 (or NaN): the cell is re-solved with partial pivoting by lg_pivoted_kernel
+    if (lane == 0 && !(minrel > 1e-6)) a.cellflag[cell] = 1;
+}
+
+// Robust fallback of the blocked path: cells flagged by lg_inv64_kernel are re-solved from V and U with
+// Gaussian elimination with partial pivoting over the whole NP x NP system (LAPACK gesv semantics of the
+// reference), in place in global memory (2 MB per cell, L2 resident), one 1024-thread workgroup per
+// flagged cell.  Slow by design: it only runs for cells whose unpivoted block elimination was unsafe.
+struct LgPivArgs {
+    const double *V, *Uo;   // [ncell][2][NP*NP]
+    double *P, *Q;          // [ncell][2][NP*NP]: P <- X = (V-U)^-1 (V+U); Q is scratch
+    const int *cellflag;
+    int *flags;
+    unsigned long long *stats;
+    int NP, ncell;
+};
+__global__ void __launch_bounds__(1024) lg_pivoted_kernel(LgPivArgs a) {
+    __shared__ double mre[256], mim[256];
+    __shared__ double best[16];
+    __shared__ int bestrow[16];
+    __shared__ int piv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NP = a.NP;
+    const size_t pp = (size_t)NP * NP;
+    for (int cell = blockIdx.x; cell < a.ncell; cell += gridDim.x) {
+        if (!a.cellflag[cell]) continue;
+        __syncthreads();
+        const double *Vr = a.V + (size_t)cell * 2 * pp, *Vi = Vr + pp, *Ur = a.Uo + (size_t)cell * 2 * pp, *Ui = Ur + pp;
+        double *Pr = a.P + (size_t)cell * 2 * pp, *Pi = Pr + pp, *Qr = a.Q + (size_t)cell * 2 * pp, *Qi = Qr + pp;
+        for (size_t i = tid; i < pp; i += 1024) {
+            const double vr = Vr[i], vi = Vi[i], ur = Ur[i], ui = Ui[i];
+            Pr[i] = vr + ur; Pi[i] = vi + ui;
+            Qr[i] = vr - ur; Qi[i] = vi - ui;
+        }
+        __syncthreads();
+        bool ok = true;
+        for (int k = 0; k < NP; ++k) {
+            // pivot search down column k (first maximum, like izamax on |re|^2 + |im|^2)
+            double b = -1.0; int br = k;
+            for (int i = k + tid; i < NP; i += 1024) {
+                const double v = Qr[(size_t)i * NP + k] * Qr[(size_t)i * NP + k] + Qi[(size_t)i * NP + k] * Qi[(size_t)i * NP + k];
+                if (v > b) { b = v; br = i; }
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ob = __shfl_xor(b, off, 64);
+                const int orow = __shfl_xor(br, off, 64);
+                if (ob > b || (ob == b && orow < br)) { b = ob; br = orow; }
+            }
+            if (lane == 0) { best[wave] = b; bestrow[wave] = br; }
+            __syncthreads();
+            if (tid == 0) {
+                double bb = best[0]; int rr = bestrow[0];
+                for (int w = 1; w < 16; ++w)
+                    if (best[w] > bb || (best[w] == bb && bestrow[w] < rr)) { bb = best[w]; rr = bestrow[w]; }
+                piv = bb > 0. ? rr : -1;
+            }
+            __syncthreads();
+            const int p = piv;
+            if (p < 0) { ok = false; break; }
+            if (p != k) {   // swap rows k and p of [Q | P]
+                for (int j = tid; j < 2 * NP; j += 1024) {
+                    double *re = j < NP ? Qr : Pr, *im = j < NP ? Qi : Pi;
+                    const int c = j < NP ? j : j - NP;
+                    const double tr_ = re[(size_t)k * NP + c], ti_ = im[(size_t)k * NP + c];
+                    re[(size_t)k * NP + c] = re[(size_t)p * NP + c]; im[(size_t)k * NP + c] = im[(size_t)p * NP + c];
+                    re[(size_t)p * NP + c] = tr_; im[(size_t)p * NP + c] = ti_;
+                }
+                __syncthreads();
+            }
+            {   // multipliers m_i = q_ik / q_kk
+                const double pr = Qr[(size_t)k * NP + k], pi = Qi[(size_t)k * NP + k];
+                const double inv = 1.0 / (pr * pr + pi * pi);
+                for (int i = k + 1 + tid; i < NP; i += 1024) {
+                    const double ar = Qr[(size_t)i * NP + k], ai = Qi[(size_t)i * NP + k];
+                    mre[i] = (ar * pr + ai * pi) * inv;
+                    mim[i] = (ai * pr - ar * pi) * inv;
+                }
+            }
+            __syncthreads();
+            // row_i -= m_i row_k over the remaining columns of Q and all columns of P (lanes along columns)
+            for (int i = k + 1 + wave; i < NP; i += 16) {
+                const double mr = mre[i], mi = mim[i];
+                for (int j = k + 1 + lane; j < NP; j += 64) {
+                    const double xr = Qr[(size_t)k * NP + j], xi = Qi[(size_t)k * NP + j];
+                    Qr[(size_t)i * NP + j] -= mr * xr - mi * xi;
+                    Qi[(size_t)i * NP + j] -= mr * xi + mi * xr;
+                }
+                for (int j = lane; j < NP; j += 64) {
+                    const double xr = Pr[(size_t)k * NP + j], xi = Pi[(size_t)k * NP + j];
+                    Pr[(size_t)i * NP + j] -= mr * xr - mi * xi;
+                    Pi[(size_t)i * NP + j] -= mr * xi + mi * xr;
+                }
+            }
+            __syncthreads();
+        }
+        if (ok) {
+            // back substitution, column oriented: X[k][:] = P[k][:] / q_kk, then P[i][:] -= q_ik X[k][:] for i < k
+            for (int k = NP - 1; k >= 0; --k) {
+                const double pr = Qr[(size_t)k * NP + k], pi = Qi[(size_t)k * NP + k];
+                const double inv = 1.0 / (pr * pr + pi * pi);
+                for (int j = tid; j < NP; j += 1024) {
+                    const double sr = Pr[(size_t)k * NP + j], si = Pi[(size_t)k * NP + j];
+                    Pr[(size_t)k * NP + j] = (sr * pr + si * pi) * inv;
+                    Pi[(size_t)k * NP + j] = (si * pr - sr * pi) * inv;
+                }
+                __syncthreads();
+                for (int i = wave; i < k; i += 16) {
+                    const double qr = Qr[(size_t)i * NP + k], qi = Qi[(size_t)i * NP + k];
+                    for (int j = lane; j < NP; j += 64) {
+                        const double xr = Pr[(size_t)k * NP + j], xi = Pi[(size_t)k * NP + j];
+                        Pr[(size_t)i * NP + j] -= qr * xr - qi * xi;
+                        Pi[(size_t)i * NP + j] -= qr * xi + qi * xr;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            if (!ok) atomicOr(&a.flags[0], 1);   // exactly singular denominator
+            atomicAdd(&a.stats[9], 1ull);
+        }
+    }
 }
 
 // planar chunk result -> U[cell0 + i] (row-major interleaved complex)

@@ -277,6 +277,23 @@ def test_pivoted_fallback_for_unsafe_pade_denominators(g, ref):
     Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
                                 gradient_method=ref.TAYLOR)
     assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr), npiv
+    # blocked path (N > 64): a two-level pi-pulse embedded in a 70-level system zeroes two diagonal entries of q(A)
+    N = 70
+    pr = synth.make_problem(N, 1, 3, 2, seed=6)
+    H0 = 0.3 * pr["H0"]
+    H0[:, :2, :] = 0
+    H0[:, :, :2] = 0
+    H0[:, 0, 0], H0[:, 1, 1] = 1e-3, -1e-3
+    Hc = np.zeros((1, N, N), complex)
+    Hc[0, 0, 1] = Hc[0, 1, 0] = 1.0
+    Hc[0, 2:, 2:] = 0.05 * pr["Hc"][0, 2:, 2:]
+    x = np.array([np.pi, 0.3, np.pi])
+    with g.GrapeHip(H0, Hc, pr["tlist"], pr["psi0"], pr["target"]) as h:
+        J, G, tau = h.eval(x)
+        npiv = h.work()["pivoted_cells"]
+    assert npiv >= 4
+    Jr, Gr, taur = ref.evaluate(H0, Hc, pr["tlist"], x, pr["psi0"], pr["target"], gradient_method=ref.TAYLOR)
+    assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr), npiv
 
 
 def test_two_rank_sharded_device_path(g):
