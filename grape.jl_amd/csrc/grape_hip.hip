@@ -110,7 +110,11 @@ hipError_t launch_expm(const ExpmArgs &a, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.cellflag, 0, (size_t)a.K * a.N_T * sizeof(int), s);
     if (e != hipSuccess) return e;
     // fast pass: unpivoted block Gauss-Jordan, flags the cells it cannot solve safely
-        hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);  // one WG per cell
+    #ifdef GRAPE_EXPM_PERSISTENT
+    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(std::min(a.K * a.N_T, 256)), dim3(NT * 64), lds, s, a);
+#else
+    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);  // one WG per cell
+#endif
     // pivoted pass over the flagged cells (all other workgroups exit at once)
     hipLaunchKernelGGL((expm_pade_kernel<NT, true>), dim3(std::min(a.K * a.N_T, 1024)), dim3(NT * 64), lds, s, a);
     return hipGetLastError();

@@ -247,8 +247,16 @@ __device__ __forceinline__ double row_bcast_k(double v, int k) {
 // The s_nop covers the VALU-write -> DPP-read hazard the compiler cannot see inside inline assembly.
 template <int K>
 __device__ __forceinline__ void fmac_rowbcast(double &acc, double src, double m) {
+#ifdef GRAPE_DPP_FUSED
     asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
         : "+v"(acc) : "v"(src), "v"(m), "n"(K));
+#else
+    // two full-rate 32-bit DPP moves + a plain FMA: the DP-ALU DPP form of v_fmac_f64 costs 16 cycles per
+    // instruction (tools/latency_probe.hip), this sequence about 13
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(src), 0x150 + K, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(src), 0x150 + K, 0xf, 0xf, true);
+    acc = fma(__hiloint2double(hi, lo), m, acc);
+#endif
 }
 
 // one pivot step of invert16 (K is a template parameter: the DPP lane select is an immediate)
@@ -258,13 +266,21 @@ __device__ __forceinline__ void invert16_step(double (&ar)[4], double (&ai)[4], 
     constexpr int kg = K & 3, kc = K >> 2;
     const double pr = readlane_f64(ar[kc], 16 * kg + K);   // pivot p_k = D[k][k]
     const double pi = readlane_f64(ai[kc], 16 * kg + K);
+#ifdef ABL_NO_BPERM
+    const double mr = ar[kc], mi = ai[kc];
+#else
     const double mr = __shfl(ar[kc], 16 * kg + i, 64);      // a_ik of this lane's row
     const double mi = __shfl(ai[kc], 16 * kg + i, 64);
+#endif
     // 1/p_k: v_rcp_f64 seed + two Newton steps
     const double den = fma(pr, pr, pi * pi);
+#ifdef ABL_NO_RCP
+    double inv = den;
+#else
     double inv = __builtin_amdgcn_rcp(den);
     inv = inv * fma(-den, inv, 2.0);
     inv = inv * fma(-den, inv, 2.0);
+#endif
     const double qr = pr * inv, qi = -pi * inv;
     minrel = fmin(minrel, den * inv_scale2);
     const bool isk = (i == K);
@@ -833,10 +849,10 @@ __device__ __forceinline__ void expm_cell_pivoted(const ExpmArgs &a, const int c
 // pivoted pass.
 // Fast single-cell path: one workgroup per cell, unpivoted block Gauss-Jordan with look-ahead.
 template <int NT>
-__device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell) {
+__device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, const int tid) {
     using LY = ExpmLds<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     Strip<NT> Pn, Qn;
     int s, order;
@@ -858,7 +874,16 @@ template <int NT, bool PIVOTED>
 __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     const int ncell = a.K * a.N_T;
     if constexpr (!PIVOTED) {
-        expm_single<NT>(a, xcd_remap(blockIdx.x, ncell));   // one workgroup per cell
+#ifdef GRAPE_EXPM_PERSISTENT
+        for (int v = blockIdx.x; v < ncell; v += gridDim.x) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));   // keep per-thread address arithmetic inside the loop
+            expm_single<NT>(a, xcd_remap(v, ncell), tid);
+            __syncthreads();
+        }
+#else
+        expm_single<NT>(a, xcd_remap(blockIdx.x, ncell), threadIdx.x);   // one workgroup per cell
+#endif
     } else {
         // second pass, small grid: every workgroup scans a slice of the flags and re-solves flagged cells
         for (int cell = blockIdx.x; cell < ncell; cell += gridDim.x) {
