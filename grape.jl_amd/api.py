@@ -252,7 +252,7 @@ class GrapeHip:
         self._chk(self._lib.grape_reset_timings(self._h))
 
     def work(self):
-        w = np.zeros(6)
-        self._lib.grape_get_work(self._h, w.ctypes.data, 6)
+        w = np.zeros(7)
+        self._lib.grape_get_work(self._h, w.ctypes.data, 7)
         return dict(cells=w[0], squarings=w[1], flop_expm=w[2], flop_deriv=w[3], deriv_orders=w[4],
-                    pivoted_cells=w[5])
+                    pivoted_cells=w[5], expm_cells=w[6])

@@ -55,6 +55,11 @@ struct grape_handle {
     double *d_f = nullptr, *d_G = nullptr, *d_rho = nullptr;
     int *d_flags = nullptr;
     int *d_cellflag = nullptr;   // [K*N_T] cells flagged for the pivoted Pade solve
+    // generator classes: trajectories with bit-identical H0 (and control operators) share one set of
+    // propagators U_cn; KC == K (d_cls == nullptr) for ensembles of distinct generators
+    int KC = 0;
+    std::vector<int> cls;        // [K] class of trajectory k
+    int *d_cls = nullptr, *d_rep = nullptr;
     unsigned *d_coop = nullptr;  // [2][K] step counters of the cooperative sweeps (forward, backward)
     int coop_S = 0;              // workgroups per trajectory in the cooperative sweeps (0: one-workgroup kernel)
     int coop_rpw = 0, coop_nw = 0;  // rows per wave and waves of a cooperative workgroup (R = nw * rpw state rows)
@@ -241,7 +246,7 @@ hipError_t lg_lincomb(hipStream_t s, double *out, size_t n, int nin, const doubl
 hipError_t expm_large(grape_handle *h, hipStream_t s) {
     const int NP = h->NP, NB = NP / 64;
     const size_t pp = (size_t)NP * NP;
-    const long ncell = (long)h->K * h->N_T;
+    const long ncell = (long)h->KC * h->N_T;
     static bool attr_set[8] = {false};
     const size_t inv_lds = sizeof(double) * (3 * 2 * 64 * 18 + 1536);
     if (!attr_set[h->device & 7]) {
@@ -258,7 +263,7 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
         LgFormArgs fa{};
         fa.H0f = h->d_H0f; fa.Hcf = h->d_Hcf; fa.eps = h->d_eps; fa.shape = h->d_shape; fa.dts = h->d_dts;
         fa.A = A; fa.s_cell = h->d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
-        fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0;
+        fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0; fa.rep = h->d_rep;
         hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(256), 0, s, fa);
         LGCHK(hipGetLastError());
         const LgView vA = lg_full(A, NP), vA2 = lg_full(A2, NP), vA4 = lg_full(A4, NP), vA6 = lg_full(A6, NP),
@@ -356,7 +361,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -416,6 +421,45 @@ int grape_create(grape_handle **out, const grape_problem *p) {
 
     CCHK(hipSetDevice(h->device));
     CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {   // generator classes: bit-identical (H0_k, control operators of k) -> one set of propagators
+        const size_t nb0 = (size_t)p->N * p->N * 16, nbc = p->hc_per_traj ? (size_t)p->L * p->N * p->N * 16 : 0;
+        auto hash = [](const unsigned char *b, size_t n, unsigned long long hsh) {
+            for (size_t i = 0; i < n; ++i) { hsh ^= b[i]; hsh *= 1099511628211ull; }
+            return hsh;
+        };
+        std::vector<unsigned long long> hv(p->K);
+        std::vector<int> rep;
+        h->cls.assign(p->K, 0);
+        const char *env = getenv("GRAPE_NO_DEDUP");
+        for (int k = 0; k < p->K; ++k) {
+            const unsigned char *b0 = (const unsigned char *)p->H0 + (size_t)k * nb0;
+            const unsigned char *bc = nbc ? (const unsigned char *)p->Hc + (size_t)k * nbc : nullptr;
+            hv[k] = hash(b0, nb0, 14695981039346656037ull);
+            if (bc) hv[k] = hash(bc, nbc, hv[k]);
+            int found = -1;
+            if (!(env && atoi(env)))
+                for (size_t c = 0; c < rep.size() && found < 0; ++c) {
+                    const int r = rep[c];
+                    if (hv[r] != hv[k]) continue;
+                    if (memcmp(b0, (const unsigned char *)p->H0 + (size_t)r * nb0, nb0)) continue;
+                    if (bc && memcmp(bc, (const unsigned char *)p->Hc + (size_t)r * nbc, nbc)) continue;
+                    found = (int)c;
+                }
+            if (found < 0) { found = (int)rep.size(); rep.push_back(k); }
+            h->cls[k] = found;
+        }
+        h->KC = (int)rep.size();
+        if (h->KC < p->K) {
+            if (hipSetDevice(h->device) != hipSuccess || hipMalloc((void **)&h->d_cls, p->K * sizeof(int)) != hipSuccess ||
+                hipMalloc((void **)&h->d_rep, h->KC * sizeof(int)) != hipSuccess ||
+                hipMemcpy(h->d_cls, h->cls.data(), p->K * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(h->d_rep, rep.data(), h->KC * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                h->err = "generator class tables: HIP allocation/copy failed";
+                return fail(GRAPE_ERR_HIP);
+            }
+        }
+    }
+
     for (auto &ring : h->ph)
         for (auto &ph : ring) { CCHK(hipEventCreate(&ph.e0)); CCHK(hipEventCreate(&ph.e1)); ph.used = false; }
 
@@ -483,7 +527,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + (h->large ? 4 : 8)) * 2 * NP * 16));
     }
     if (h->large) {
-        const long ncell = (long)K * N_T;
+        const long ncell = (long)h->KC * N_T;
         const long cap = std::max<long>(1, (long)(6.0e9 / (9.0 * 2.0 * pp * 8.0)));
         h->chunk = (int)std::min<long>(ncell, std::min<long>(cap, 4096));
         for (auto &b : h->d_lg) CCHK(dmalloc(&b, (size_t)h->chunk * 2 * pp));
@@ -509,7 +553,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
 
     // ---- per-evaluation buffers ----
     CCHK(dmalloc(&h->d_eps, (size_t)L * N_T));
-    CCHK(dmalloc(&h->d_U, (size_t)K * N_T * pp));
+    CCHK(dmalloc(&h->d_U, (size_t)h->KC * N_T * pp));
     CCHK(dmalloc(&h->d_fw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_bw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_tg, (size_t)K * L * N_T));
@@ -580,7 +624,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     ExpmArgs ea{};
     ea.H0f = h->d_H0f; ea.Hcf = h->d_Hcf; ea.eps = h->d_eps; ea.shape = h->d_shape; ea.dts = h->d_dts;
     ea.U = h->d_U; ea.flags = h->d_flags; ea.stats = h->d_stats; ea.cellflag = h->d_cellflag;
-    ea.K = h->K; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
+    ea.K = h->KC; ea.rep = h->d_rep; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
 #ifdef GRAPE_DIAG
     ea.ablate = getenv("GRAPE_DIAG_ABLATE") ? atoi(getenv("GRAPE_DIAG_ABLATE")) : 0;
     static unsigned long long *d_stamps = nullptr;
@@ -625,7 +669,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
 #endif
     // ---- phase 1: forward sweep + tau ----
     SweepArgs sa{};
-    sa.U = h->d_U; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
+    sa.U = h->d_U; sa.cls = h->d_cls; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
     sa.store = h->d_fw; sa.tau = (double2 *)d_out; sa.f = nullptr; sa.rho = h->d_rho; sa.flags = h->d_flags;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
@@ -672,7 +716,7 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     hipError_t e;
     // ---- phase 2: chi boundary + backward sweep ----
     SweepArgs sa{};
-    sa.U = h->d_U; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
+    sa.U = h->d_U; sa.cls = h->d_cls; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
     sa.store = h->d_bw; sa.tau = (double2 *)h->d_out; sa.f = d_f; sa.rho = h->d_rho; sa.flags = h->d_flags;
     sa.xi = h->have_gb ? h->d_xi : nullptr; sa.wq = h->d_wq; sa.lambda_b = h->p.lambda_b;
     sa.chi_min_norm = h->chi_min_norm;
@@ -827,7 +871,7 @@ int grape_get_propagator(grape_handle *h, int k, int n, double *out) {
     HIPCHK(h, hipDeviceSynchronize());
     const size_t pp = (size_t)h->NP * h->NP;
     std::vector<double> tmp(2 * pp);
-    HIPCHK(h, hipMemcpy(tmp.data(), h->d_U + ((size_t)k * h->N_T + n) * pp, pp * 16, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(tmp.data(), h->d_U + ((size_t)h->cls[k] * h->N_T + n) * pp, pp * 16, hipMemcpyDeviceToHost));
     for (int j = 0; j < h->N; ++j)
         for (int i = 0; i < h->N; ++i) {
             out[2 * ((size_t)j * h->N + i)] = tmp[2 * ((size_t)i * h->NP + j)];
@@ -871,16 +915,17 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     unsigned long long st[16];
     HIPCHK(h, hipMemcpy(st, h->d_stats, sizeof(st), hipMemcpyDeviceToHost));
     const double N3 = (double)h->N * h->N * h->N, N2 = (double)h->N * h->N;
-    const double cells = (double)h->K * h->N_T;
+    const double cells = (double)h->K * h->N_T, ecells = (double)h->KC * h->N_T;
     // F_exp = (g + s) * 8 N^3 + (32/3) N^3, g = GEMMs of the Pade order (13:6, 9:5, 7:4, 5:3, 3:2)
     const double gemms = 2.0 * st[3] + 3.0 * st[4] + 4.0 * st[5] + 5.0 * st[6] + 6.0 * st[7];
     out[0] = cells;
     out[1] = (double)st[0];
-    out[2] = (gemms + (double)st[0]) * 8.0 * N3 + cells * (32.0 / 3.0) * N3;
+    out[2] = (gemms + (double)st[0]) * 8.0 * N3 + ecells * (32.0 / 3.0) * N3;
     // derivative series: per order (1 + 2L) complex mat-vecs of 8 N^2 flop
     out[3] = (double)st[8] * (1.0 + 2.0 * h->L) * 8.0 * N2;
     if (n > 4) out[4] = (double)st[8];  // sum of series orders
     if (n > 5) out[5] = (double)st[9];  // cells solved by the pivoted fallback
+    if (n > 6) out[6] = ecells;          // propagators actually exponentiated (generator classes x time steps)
     return 4;
 }
 

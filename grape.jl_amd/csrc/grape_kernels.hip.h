@@ -50,7 +50,9 @@ struct ExpmArgs {
     double2 *U;          // [K][N_T][NP*NP] row-major interleaved complex  U_kn = exp(-i H_kn dt_n)
     int *flags;          // [0] error flag (|=), [1] max squarings
     unsigned long long *stats; // [0] sum of squarings, [3..7] #cells with Pade order 3/5/7/9/13
-    int K, L, N_T, hc_per_traj;
+    int K, L, N_T, hc_per_traj;   // K = number of generator classes (cells = K * N_T)
+    const int *rep;      // nullptr or [K]: representative trajectory of every generator class (trajectories with
+                         // identical H0 / control operators share their propagators)
     int *cellflag;       // [K*N_T] set by the fast kernel for cells that need the pivoted solve
 #ifdef GRAPE_DIAG
     int ablate;  // diagnostic builds only (tools/ablate.sh): bit0 skip invert16, bit1 skip solve
@@ -606,7 +608,8 @@ __device__ __forceinline__ void expm_numden(const ExpmArgs &a, const int cell, c
     double *Xre = smem + LY::REG;  // staging of the current left operand (A2, A6)
     double *Xim = Xre + NP * LD;
     double *red = smem + 2 * LY::REG + LY::DV;
-    const int k = cell / a.N_T, n = cell - k * a.N_T;
+    const int kc = cell / a.N_T, n = cell - kc * a.N_T;
+    const int k = a.rep ? a.rep[kc] : kc;
     const double dt = a.dts[n];
     // ---- A = -i dt (H0_k + sum_l a_l H_l) -> LDS (planar row-major); 16-byte coalesced loads ----
     {
@@ -923,6 +926,7 @@ struct SweepArgs {
     int *flags;
     double chi_min_norm;
     int K, K_total, N, N_T, functional;
+    const int *cls;       // nullptr or [K]: generator class of trajectory k (row of U it reads)
     // state running cost g_b = <Psi|D|Psi> (optimize.jl:856-866, 897-908): xi_k(t_n) = -D Psi_k(t_n),
     // trapezoid weights wq[n]; nullptr / 0 when off
     const double2 *xi;    // [K][N_T+1][NP]
@@ -957,7 +961,7 @@ __global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
     __shared__ double2 part[NW][NP];  // cross-wave partials (backward)
     __shared__ double sc[4];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double2 *Uk = a.U + (size_t)k * a.N_T * NP * NP;
+    const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
     double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
 
     // ---- initial state ----

@@ -129,13 +129,15 @@ struct LgFormArgs {
     unsigned long long *stats;
     int *flags;
     int NP, L, N_T, hc_per_traj, cell0;
+    const int *rep;       // nullptr or representative trajectory per generator class
 };
 __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
     __shared__ double colsum[256];
     __shared__ double snorm;
     const int tid = threadIdx.x, NP = a.NP;
     const int cell = a.cell0 + blockIdx.x;
-    const int k = cell / a.N_T, n = cell - k * a.N_T;
+    const int kc = cell / a.N_T, n = cell - kc * a.N_T;
+    const int k = a.rep ? a.rep[kc] : kc;
     const double dt = a.dts[n];
     const size_t pp = (size_t)NP * NP;
     const double *h0 = a.H0f + (size_t)k * 2 * pp;
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(1024) sweep_lg_kernel(SweepArgs a, int NP) {
     __shared__ double sc[2];
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const double2 *Uk = a.U + (size_t)k * a.N_T * NP * NP;
+    const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
     double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
     if (!BACKWARD) {
         if (tid < NP) {
@@ -532,7 +534,7 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
     const int k = (slot / S) * 8 + xcd, s = slot % S;
     if (k >= a.K) return;
     const int r0 = s * R;   // first row (forward) / column (backward) of this workgroup's slice
-    const double2 *Uk = a.U + (size_t)k * a.N_T * NP * NP;
+    const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
     double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
     unsigned *ck = cnt + k;
 

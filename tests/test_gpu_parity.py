@@ -363,3 +363,31 @@ def test_cooperative_sweeps_all_slice_shapes(g, ref, N, K, monkeypatch):
     assert abs(J - J1) <= 1e-14 and np.abs(G - G1).max() <= 1e-13 * max(1.0, np.abs(G1).max())
     assert abs(J - Jr) <= 1e-12 and np.abs(tau - taur).max() <= TOL_TAU
     assert np.abs(G - Gr).max() <= tol_G(Gr)
+
+
+@pytest.mark.parametrize("N", [6, 64, 100])
+def test_trajectories_with_identical_generators_share_propagators(g, ref, N, monkeypatch):
+    """Gate-optimisation layout: several initial states under the SAME Hamiltonian (reference: one Trajectory
+    per basis state with the same generator, docs/src/tutorial.md:365-372).  The exponentials depend on
+    (generator, time step) only, so they are computed once per distinct generator; results are unchanged."""
+    from grape_jl_amd import synth
+    K, L, N_T = 6, 2, 5
+    pr = synth.make_problem(N, L, N_T, K, seed=77 + N)
+    pr["H0"][2] = pr["H0"][0]
+    pr["H0"][3] = pr["H0"][0]
+    pr["H0"][5] = pr["H0"][1]          # classes: {0,2,3}, {1,5}, {4}
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        w = h.work()
+        U3, U0 = h.propagator(3, 2), h.propagator(0, 2)
+    assert w["expm_cells"] == 3 * N_T and w["cells"] == K * N_T
+    assert np.array_equal(U3, U0)
+    monkeypatch.setenv("GRAPE_NO_DEDUP", "1")
+    with g.GrapeHip(*args) as h:
+        J1, G1, tau1 = h.eval(pr["pulsevals"])
+        assert h.work()["expm_cells"] == K * N_T
+    assert J == J1 and np.array_equal(G, G1) and np.array_equal(tau, tau1)
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                gradient_method=ref.TAYLOR)
+    assert abs(J - Jr) <= TOL_J and np.abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr)
