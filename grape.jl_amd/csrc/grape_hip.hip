@@ -114,12 +114,8 @@ hipError_t launch_expm(const ExpmArgs &a, hipStream_t s) {
     }
     hipError_t e = hipMemsetAsync(a.cellflag, 0, (size_t)a.K * a.N_T * sizeof(int), s);
     if (e != hipSuccess) return e;
-    // fast pass: unpivoted block Gauss-Jordan, flags the cells it cannot solve safely
-    #ifdef GRAPE_EXPM_PERSISTENT
-    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(std::min(a.K * a.N_T, 256)), dim3(NT * 64), lds, s, a);
-#else
-    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);  // one WG per cell
-#endif
+    // fast pass: unpivoted block Gauss-Jordan, flags the cells it cannot solve safely; one workgroup per cell
+    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
     // pivoted pass over the flagged cells (all other workgroups exit at once)
     hipLaunchKernelGGL((expm_pade_kernel<NT, true>), dim3(std::min(a.K * a.N_T, 1024)), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
@@ -651,7 +647,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
 #ifdef GRAPE_DIAG
     if (ea.stamps) {
         hipStreamSynchronize(s);
-        const size_t nb = (size_t)h->K * h->N_T;
+        const size_t nb = (size_t)h->KC * h->N_T;
         std::vector<unsigned long long> st(nb * 32);
         hipMemcpy(st.data(), ea.stamps, nb * 32 * 8, hipMemcpyDeviceToHost);
         auto avg = [&](int i1, int i0) {

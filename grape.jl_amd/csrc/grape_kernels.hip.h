@@ -450,10 +450,14 @@ __device__ __forceinline__ void gj_update(Strip<NT> &S, int jb, const double *pa
         if (t == jb) { S.re[t] = yr; S.im[t] = yi; }
 }
 
-template <int NT>
+struct GjNoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// `hook(jb)` runs in every wave after its own work of block step jb and before the barrier that ends the step:
+// the place for work that is independent of the solve (the waves that do not invert are otherwise waiting).
+template <int NT, class Hook = GjNoHook>
 __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
                                                int wave, int lane, double &minrel, double inv_scale2,
-                                               bool do_invert) {
+                                               bool do_invert, const Hook &hook = Hook()) {
     constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
     __syncthreads();  // previous users of the staging region are done
     if (wave == 0) gj_publish_invert<NT>(Q, 0, panbase, dvbase, lane, minrel, inv_scale2, do_invert);
@@ -473,6 +477,7 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
             if (wave > jb) gj_update<NT>(Q, jb, pan, dv, lane);
             gj_update<NT>(P, jb, pan, dv, lane);
         }
+        hook(jb);
         __syncthreads();
         STAMP(6 + jb);
     }
@@ -593,14 +598,99 @@ struct ExpmLds {
     static constexpr int TOTAL = 2 * REG + DV + RED;              // doubles
 };
 
-// Polynomial phase of one cell: A = -i dt H -> LDS, ||A||_1, Pade order / squaring count, and the
-// numerator P = V+U and denominator Q = V-U as register strips (strip index `wave` = column strip
-// this wave owns; it need not be the hardware wave id).  The caller guarantees that the LDS regions are
-// free on entry; on return other waves may still be reading them.
+// A = -i dt (H0_k + sum_l a_l H_l) -> LDS (planar row-major), 16-byte coalesced loads: the element pairs
+// idx in [i0, i1) (of NP*NP/2 per plane) are formed by threads t = 0..nt-1.
 template <int NT>
-__device__ __forceinline__ void expm_numden(const ExpmArgs &a, const int cell, const int wave, const int lane,
-                                            const int tid, double *smem, Strip<NT> &Pn, Strip<NT> &Qn, int &s,
-                                            int &order, double &inv_b0sq, const int stamp0 = 11) {
+__device__ __forceinline__ void expm_form_a(const ExpmArgs &a, const int cell, double *smem, const int t, const int nt,
+                                            const int i0, const int i1) {
+    using LY = ExpmLds<NT>;
+    constexpr int NP = LY::NP, LD = LY::LD;
+    double *Are = smem, *Aim = Are + NP * LD;
+    const int kc = cell / a.N_T, n = cell - kc * a.N_T;
+    const int k = a.rep ? a.rep[kc] : kc;
+    const double dt = a.dts[n];
+    const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
+    const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
+    constexpr int HALF = NP * NP / 2;  // double2 elements per plane
+    double e[8];
+    for (int l = 0; l < a.L; ++l) {
+        e[l] = a.eps[(size_t)l * a.N_T + n];
+        if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
+    }
+    // chunks of 8 element pairs per thread, all 16 loads of one operator in flight at once: the time of this
+    // routine is load latency times the number of dependent batches, whatever the number of threads
+    for (int base = i0 + t; base < i1; base += 8 * nt) {
+        double2 hr[8], hi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * nt;
+            if (idx < i1) { hr[u] = h0[idx]; hi[u] = h0[HALF + idx]; }
+        }
+        for (int l = 0; l < a.L; ++l) {
+            double2 cr[8], ci[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * nt;
+                if (idx < i1) { cr[u] = hc[(size_t)l * 2 * HALF + idx]; ci[u] = hc[(size_t)l * 2 * HALF + HALF + idx]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                hr[u].x = fma(e[l], cr[u].x, hr[u].x); hr[u].y = fma(e[l], cr[u].y, hr[u].y);
+                hi[u].x = fma(e[l], ci[u].x, hi[u].x); hi[u].y = fma(e[l], ci[u].y, hi[u].y);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * nt;
+            if (idx < i1) {
+                const int i = (2 * idx) / NP, j = 2 * idx - i * NP;
+                Are[i * LD + j] = dt * hi[u].x;  Are[i * LD + j + 1] = dt * hi[u].y;
+                Aim[i * LD + j] = -dt * hr[u].x; Aim[i * LD + j + 1] = -dt * hr[u].y;
+            }
+        }
+    }
+}
+
+// partial column sums of |a_ij| for ||A||_1 = max_j sum_i |a_ij|: thread t of NP * parts threads covers column
+// t % NP over the rows i = t / NP (mod parts); red[t] receives the partial sum
+template <int NT>
+__device__ __forceinline__ void expm_norm_partial(double *smem, const int t, const int parts) {
+    using LY = ExpmLds<NT>;
+    constexpr int NP = LY::NP, LD = LY::LD;
+    const double *Are = smem, *Aim = Are + NP * LD;
+    double *red = smem + 2 * LY::REG + LY::DV;
+    const int j = t % NP, part = t / NP;
+    double sum = 0.;
+    for (int i = part; i < NP; i += parts) {
+        const double xr = Are[i * LD + j], xi = Aim[i * LD + j];
+        sum += fast_sqrt(xr * xr + xi * xi);
+    }
+    red[t] = sum;
+}
+
+// first wave: column sums of the partials, then the maximum over the columns (wavefront shuffles) -> red[NTH]
+template <int NT>
+__device__ __forceinline__ void expm_norm_combine(double *smem, const int tid, const int parts) {
+    using LY = ExpmLds<NT>;
+    constexpr int NP = LY::NP, NTH = LY::NTH;
+    double *red = smem + 2 * LY::REG + LY::DV;
+    if (tid < 64) {
+        double c = 0.;
+        if (tid < NP)
+            for (int p = 0; p < parts; ++p) c += red[p * NP + tid];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c = fmax(c, __shfl_xor(c, off, 64));
+        if (tid == 0) red[NTH] = c;
+    }
+}
+
+// Polynomial phase of one cell: Pade order / squaring count from ||A||_1 (in red[NTH]; A = -i dt H in LDS)
+// and the numerator P = V+U and denominator Q = V-U as register strips (strip index `wave` = column strip
+// this wave owns).  On return other waves may still be reading the LDS regions.
+template <int NT>
+__device__ __forceinline__ void expm_poly(const ExpmArgs &a, const int wave, const int lane, const int tid,
+                                          double *smem, Strip<NT> &Pn, Strip<NT> &Qn, int &s, int &order,
+                                          double &inv_b0sq, const int stamp0 = 11) {
     using LY = ExpmLds<NT>;
     constexpr int NP = LY::NP, LD = LY::LD, NTH = LY::NTH;
     double *Are = smem;          // A = -i dt H stays resident (left operand of A*A and A*T)
@@ -608,55 +698,6 @@ __device__ __forceinline__ void expm_numden(const ExpmArgs &a, const int cell, c
     double *Xre = smem + LY::REG;  // staging of the current left operand (A2, A6)
     double *Xim = Xre + NP * LD;
     double *red = smem + 2 * LY::REG + LY::DV;
-    const int kc = cell / a.N_T, n = cell - kc * a.N_T;
-    const int k = a.rep ? a.rep[kc] : kc;
-    const double dt = a.dts[n];
-    // ---- A = -i dt (H0_k + sum_l a_l H_l) -> LDS (planar row-major); 16-byte coalesced loads ----
-    {
-        const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
-        const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
-        constexpr int HALF = NP * NP / 2;  // double2 elements per plane
-        double e[8];
-        for (int l = 0; l < a.L; ++l) {
-            e[l] = a.eps[(size_t)l * a.N_T + n];
-            if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
-        }
-#pragma unroll 4
-        for (int idx = tid; idx < HALF; idx += NTH) {
-            double2 hr = h0[idx], hi = h0[HALF + idx];
-            for (int l = 0; l < a.L; ++l) {
-                const double2 cr = hc[(size_t)l * 2 * HALF + idx], ci = hc[(size_t)l * 2 * HALF + HALF + idx];
-                hr.x = fma(e[l], cr.x, hr.x); hr.y = fma(e[l], cr.y, hr.y);
-                hi.x = fma(e[l], ci.x, hi.x); hi.y = fma(e[l], ci.y, hi.y);
-            }
-            const int i = (2 * idx) / NP, j = 2 * idx - i * NP;
-            Are[i * LD + j] = dt * hi.x;  Are[i * LD + j + 1] = dt * hi.y;
-            Aim[i * LD + j] = -dt * hr.x; Aim[i * LD + j + 1] = -dt * hr.y;
-        }
-    }
-    __syncthreads();
-    STAMP(stamp0 + 0);
-    // ---- ||A||_1 = max_j sum_i |a_ij| ----
-    {
-        constexpr int PARTS = NTH / NP;  // 4
-        const int j = tid % NP, part = tid / NP;
-        double s = 0.;
-        for (int i = part; i < NP; i += PARTS) {
-            const double xr = Are[i * LD + j], xi = Aim[i * LD + j];
-            s += fast_sqrt(xr * xr + xi * xi);
-        }
-        red[tid] = s;
-        __syncthreads();
-        if (tid < 64) {   // first wave: column sums, then the maximum over columns (wavefront shuffles)
-            double c = 0.;
-            if (tid < NP)
-                for (int p = 0; p < PARTS; ++p) c += red[p * NP + tid];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) c = fmax(c, __shfl_xor(c, off, 64));
-            if (tid == 0) red[NTH] = c;
-        }
-        __syncthreads();
-    }
     const double nA = red[NTH];
     STAMP(stamp0 + 1);
     s = 0;  // ceil(log2(nA / 5.4)) for nA > 5.4 (Julia's exp!), from the binary exponent
@@ -786,6 +827,23 @@ __device__ __forceinline__ void expm_numden(const ExpmArgs &a, const int cell, c
 
 }
 
+// form A, norm and polynomial phase of one cell by the whole workgroup (the caller guarantees that the LDS
+// regions are free on entry)
+template <int NT>
+__device__ __forceinline__ void expm_numden(const ExpmArgs &a, const int cell, const int wave, const int lane,
+                                            const int tid, double *smem, Strip<NT> &Pn, Strip<NT> &Qn, int &s,
+                                            int &order, double &inv_b0sq, const int stamp0 = 11) {
+    using LY = ExpmLds<NT>;
+    expm_form_a<NT>(a, cell, smem, tid, LY::NTH, 0, LY::NP * LY::NP / 2);
+    __syncthreads();
+    STAMP(stamp0 + 0);
+    expm_norm_partial<NT>(smem, tid, LY::NTH / LY::NP);
+    __syncthreads();
+    expm_norm_combine<NT>(smem, tid, LY::NTH / LY::NP);
+    __syncthreads();
+    expm_poly<NT>(a, wave, lane, tid, smem, Pn, Qn, s, order, inv_b0sq, stamp0);
+}
+
 // Squarings and the store of U_kn (row-major interleaved complex) for one cell.
 template <int NT>
 __device__ __forceinline__ void expm_finish(const ExpmArgs &a, const int cell, const int wave, const int lane,
@@ -887,16 +945,7 @@ template <int NT, bool PIVOTED>
 __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
     const int ncell = a.K * a.N_T;
     if constexpr (!PIVOTED) {
-#ifdef GRAPE_EXPM_PERSISTENT
-        for (int v = blockIdx.x; v < ncell; v += gridDim.x) {
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));   // keep per-thread address arithmetic inside the loop
-            expm_single<NT>(a, xcd_remap(v, ncell), tid);
-            __syncthreads();
-        }
-#else
         expm_single<NT>(a, xcd_remap(blockIdx.x, ncell), threadIdx.x);   // one workgroup per cell
-#endif
     } else {
         // second pass, small grid: every workgroup scans a slice of the flags and re-solves flagged cells
         for (int cell = blockIdx.x; cell < ncell; cell += gridDim.x) {
