@@ -36,6 +36,8 @@ struct grape_handle {
     // static problem
     double *d_H0f = nullptr, *d_Hcf = nullptr, *d_H0t = nullptr, *d_Hct = nullptr;
     double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;
+    double *d_H0q = nullptr, *d_Hcq = nullptr, *d_park2 = nullptr;   // two-pass series kernel: untransposed fragments, parking area
+    int deriv2 = 0, deriv2_maxm = 0;
     int *d_lowflag = nullptr;   // cells the two-workgroup order-13 kernel leaves to the general kernel
     double *d_spill = nullptr;  // its strip spill area [512][5][32][256]
     bool use_2wg = false;  // MFMA-fragment-packed H^dagger, series scratch
@@ -201,6 +203,42 @@ hipError_t launch_deriv_mfma(int NP, const DerivMfmaArgs &a, int nblocks, hipStr
     }
 }
 
+template <int NP, int LMAX, bool CACHE>
+hipError_t launch_d2(const Deriv2Args &a, int nblocks, hipStream_t s) {
+    constexpr int NW = NP / 16 <= 8 ? NP / 16 : 8;
+    const size_t lds = sizeof(double) * 2 * 2 * NP * 16;
+    static bool attr_set[8] = {false};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (lds > 48 * 1024 && !attr_set[dev & 7]) {
+        hipError_t e = hipFuncSetAttribute((const void *)deriv2_kernel<NP, LMAX, CACHE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 7] = true;
+    }
+    hipLaunchKernelGGL((deriv2_kernel<NP, LMAX, CACHE>), dim3(nblocks), dim3(NW * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_deriv2(int NP, const Deriv2Args &a, int nblocks, hipStream_t s) {
+    switch (NP) {
+        case 64:
+            if (a.L == 1) return launch_d2<64, 1, true>(a, nblocks, s);
+            if (a.L == 2) return launch_d2<64, 2, true>(a, nblocks, s);
+            return launch_d2<64, 4, false>(a, nblocks, s);
+        case 128:
+            if (a.L == 1) return launch_d2<128, 1, false>(a, nblocks, s);
+            if (a.L == 2) return launch_d2<128, 2, false>(a, nblocks, s);
+            return launch_d2<128, 4, false>(a, nblocks, s);
+        case 256:
+            if (a.L == 1) return launch_d2<256, 1, false>(a, nblocks, s);
+            if (a.L == 2) return launch_d2<256, 2, false>(a, nblocks, s);
+            return launch_d2<256, 4, false>(a, nblocks, s);
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
 // phases 0,1 belong to the forward call, 2,3,4 to the backward call, 5 to grape_eval
 long phase_slot(grape_handle *h, int i) { return (i <= 1 ? h->n_fwd : (i <= 4 ? h->n_bwd : h->n_fwd)) % kRing; }
 void phase_begin(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[phase_slot(h, i)][i].e0, s); }
@@ -357,7 +395,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -496,7 +534,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         // fragment-packed H^dagger for the MFMA series kernel: [mat][rt][ks][plane][lane],
         // value = conj(H)[col][row] at row = 16 rt + (lane & 15), col = 4 ks + (lane >> 4)
         const int RT = NP / 16, KS = NP / 4;
-        auto pack = [&](const double *src, int nmat, std::vector<double> &dst) {
+        auto pack = [&](const double *src, int nmat, std::vector<double> &dst, bool dagger = true) {
             dst.assign((size_t)nmat * RT * KS * 128, 0.0);
             for (int mtx = 0; mtx < nmat; ++mtx)
                 for (int rt = 0; rt < RT; ++rt)
@@ -505,10 +543,11 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                             const int row = 16 * rt + (ln & 15), col = 4 * ks + (ln >> 4);
                             if (row >= N || col >= N) continue;
                             // H^dagger[row][col] = conj(H[col][row]); H column-major: H[i][j] at j*N + i
-                            const size_t so = 2 * ((size_t)mtx * nn + (size_t)row * N + col);
+                            const size_t so = dagger ? 2 * ((size_t)mtx * nn + (size_t)row * N + col)
+                                                     : 2 * ((size_t)mtx * nn + (size_t)col * N + row);   // H[row][col]
                             const size_t o = (((size_t)mtx * RT + rt) * KS + ks) * 128 + ln;
                             dst[o] = src[so];
-                            dst[o + 64] = -src[so + 1];
+                            dst[o + 64] = dagger ? -src[so + 1] : src[so + 1];
                         }
         };
         std::vector<double> pk;
@@ -520,6 +559,20 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         CCHK(hipMemcpy(h->d_Hcp, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
         const long nbatch = (long)K * ((N_T + 15) / 16);
         h->deriv_blocks = (int)std::min<long>(nbatch, 1024);
+        {   // two-pass series kernel (deriv2_kernel): untransposed fragments and the u_a parking area
+            const char *env = getenv("GRAPE_DERIV2");
+            h->deriv2 = !(env && atoi(env) == 0) && L <= 4;
+            if (h->deriv2) {
+                pack(p->H0, K, pk, false);
+                CCHK(dmalloc(&h->d_H0q, pk.size()));
+                CCHK(hipMemcpy(h->d_H0q, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+                pack(p->Hc, Kc * L, pk, false);
+                CCHK(dmalloc(&h->d_Hcq, pk.size()));
+                CCHK(hipMemcpy(h->d_Hcq, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
+                h->deriv2_maxm = 64;
+                CCHK(dmalloc(&h->d_park2, (size_t)h->deriv_blocks * h->deriv2_maxm * 2 * NP * 16));
+            }
+        }
         CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + (h->large ? 4 : 8)) * 2 * NP * 16));
     }
     if (h->large) {
@@ -745,7 +798,18 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     da.cells_per_block = cpb;
     const int nblocks = h->K * ((h->N_T + cpb - 1) / cpb);
     phase_begin(h, 3, s);
-    if (h->NP >= 64) {
+    if (h->NP >= 64 && h->deriv2) {
+        Deriv2Args d2{};
+        d2.H0p = h->d_H0p; d2.Hcp = h->d_Hcp; d2.H0q = h->d_H0q; d2.Hcq = h->d_Hcq;
+        d2.eps = h->d_eps; d2.shape = h->d_shape; d2.dts = h->d_dts;
+        d2.fw = h->d_fw; d2.bw = h->d_bw; d2.rho = h->d_rho; d2.tg = h->d_tg; d2.park = h->d_park2;
+        d2.flags = h->d_flags; d2.stats = h->d_stats;
+        d2.K = h->K; d2.L = h->L; d2.N_T = h->N_T; d2.hc_per_traj = h->p.hc_per_traj;
+        d2.max_order = h->taylor_max_order; d2.maxm = h->deriv2_maxm; d2.tol = h->taylor_tol;
+        d2.batches_per_k = (h->N_T + 15) / 16;
+        d2.nbatch_total = h->K * d2.batches_per_k;
+        e = launch_deriv2(h->NP, d2, h->deriv_blocks, s);
+    } else if (h->NP >= 64) {
         DerivMfmaArgs dm{};
         dm.H0p = h->d_H0p; dm.Hcp = h->d_Hcp; dm.eps = h->d_eps; dm.shape = h->d_shape; dm.dts = h->d_dts;
         dm.fw = h->d_fw; dm.bw = h->d_bw; dm.rho = h->d_rho; dm.tg = h->d_tg; dm.vecs = h->d_vecs;

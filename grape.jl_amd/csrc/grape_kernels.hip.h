@@ -1635,6 +1635,263 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv_mfma_
 }
 
 // ---------------------------------------------------------------------------------------
+// Kernel 5c: the same overlaps <chi'_l | Psi> with 2 (1+L) instead of (1+L)^2 products per series order.
+//
+// chi'_l = L(B, E_l) chi with B = i dt H^dagger, E_l = i dt s_l mu_l^dagger (Frechet derivative of the backward
+// step), so <chi'_l|Psi> = sum_{a,b} <B^a E_l B^b chi | Psi> / (a+b+1)!.  Moving B^a to the other side,
+//     <chi'_l|Psi> = -i dt s_l  sum_a  < mu_l^dagger w_a | u_a > / (a+1),
+//     u_a = A^a Psi / a!  (A = B^dagger = -i dt H),      w_a = chi + B w_{a+1} / (a+2)   (Horner, descending),
+// i.e. ONE Krylov sequence on either side instead of 1+L coupled ones: pass 1 builds u_0, u_1, ... (products
+// H0 u, mu_l u; stops when ||u_a|| has dropped below the tolerance for all 16 cells, which fixes the order M)
+// and parks every u_a (16 KB per order at N = 64) in a block-private global area; pass 2 walks w_a down from
+// a = M-1 (products H0^dagger w, mu_l^dagger w -- the mu_l^dagger w_a ARE the vectors the overlaps need),
+// re-reading u_a as it goes.  The products are the batched fixed-matrix MFMA products of deriv_mfma_kernel
+// (16 consecutive cells of a trajectory are the 16 MFMA columns, the cell-dependent pulse values scale
+// accumulators per column).  Overlaps accumulate per lane over all orders; one reduction at the end.
+// ---------------------------------------------------------------------------------------
+struct Deriv2Args {
+    const double *H0p, *Hcp;   // fragment-packed H0^dagger, mu_l^dagger   [K][RT][KS][2][64], [Kc][L][RT][KS][2][64]
+    const double *H0q, *Hcq;   // fragment-packed H0, mu_l (not transposed)
+    const double *eps, *shape, *dts;
+    const double2 *fw, *bw;
+    const double *rho;
+    double2 *tg;
+    double *park;              // [gridDim.x][maxm][2][NP][16]
+    int *flags;
+    unsigned long long *stats;
+    int K, L, N_T, hc_per_traj, max_order, maxm, nbatch_total, batches_per_k;
+    double tol;
+};
+
+template <int NP, int LMAX, bool CACHE_A>
+__global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kernel(Deriv2Args a) {
+    extern __shared__ __attribute__((aligned(16))) double dsm2[];   // [2][2][NP*16] ping-pong vector block
+    constexpr int RT = NP / 16, KS = NP / 4;
+    constexpr int NW = RT <= 8 ? RT : 8, TPW = RT / NW, NV = 1 + LMAX;
+    static_assert(RT % NW == 0, "row tiles must divide evenly over the waves");
+    static_assert(!CACHE_A || TPW == 1, "operand caching only for one tile per wave");
+    __shared__ double redn[2][NW][16];
+    __shared__ double redo[NW][LMAX][16][2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, rg = lane >> 4;
+    const int L = a.L;
+    constexpr size_t vplane = (size_t)NP * 16;
+    double *park = a.park + (size_t)blockIdx.x * a.maxm * 2 * vplane;
+
+    for (int batch = blockIdx.x; batch < a.nbatch_total; batch += gridDim.x) {
+        const int k = batch / a.batches_per_k;
+        const int n0 = (batch - k * a.batches_per_k) * 16;
+        const int n = n0 + c;
+        const bool valid = n < a.N_T;
+        const int nc = valid ? n : a.N_T - 1;
+        const size_t kc = (size_t)(a.hc_per_traj ? k : 0) * L * RT * KS * 128;
+        const double dt = a.dts[nc];
+        double e[LMAX], sh[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            sh[l] = (l < L && a.shape) ? a.shape[(size_t)l * a.N_T + nc] : 1.0;
+            e[l] = l < L ? a.eps[(size_t)l * a.N_T + nc] * sh[l] : 0.;
+        }
+        double car[CACHE_A ? NV : 1][CACHE_A ? KS : 1], cai[CACHE_A ? NV : 1][CACHE_A ? KS : 1];
+        auto load_frags = [&](const double *h0k, const double *hck) __attribute__((always_inline)) {
+            if constexpr (CACHE_A) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    car[0][ks] = h0k[((size_t)wave * KS + ks) * 128 + lane];
+                    cai[0][ks] = h0k[((size_t)wave * KS + ks) * 128 + 64 + lane];
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        car[1 + l][ks] = l < L ? hck[(((size_t)l * RT + wave) * KS + ks) * 128 + lane] : 0.;
+                        cai[1 + l][ks] = l < L ? hck[(((size_t)l * RT + wave) * KS + ks) * 128 + 64 + lane] : 0.;
+                    }
+                }
+            }
+        };
+        // products of the (1+L) fixed matrices with the vector block `vc` for row tile rt: acc[v] (re, im)
+        auto products = [&](const double *h0k, const double *hck, const double *vc, const int rt, d4 (&pr)[NV],
+                            d4 (&pi)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { pr[v] = (d4){0., 0., 0., 0.}; pi[v] = (d4){0., 0., 0., 0.}; }
+            const double *vb = vc + (size_t)rg * 16 + c;
+            double bwr = vb[0], bwi = vb[vplane];
+            auto ks_step = [&](const int ks) __attribute__((always_inline)) {
+                double ar[NV], ai[NV];
+                if constexpr (CACHE_A) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) { ar[v] = car[v][CACHE_A ? ks : 0]; ai[v] = cai[v][CACHE_A ? ks : 0]; }
+                } else {
+                    ar[0] = h0k[((size_t)rt * KS + ks) * 128 + lane];
+                    ai[0] = h0k[((size_t)rt * KS + ks) * 128 + 64 + lane];
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        ar[1 + l] = l < L ? hck[(((size_t)l * RT + rt) * KS + ks) * 128 + lane] : 0.;
+                        ai[1 + l] = l < L ? hck[(((size_t)l * RT + rt) * KS + ks) * 128 + 64 + lane] : 0.;
+                    }
+                }
+                const double br = bwr, bi = bwi, nbi = -bwi;
+                if (ks + 1 < KS) {   // B operands of the next k-step: rows 4(ks+1) + rg of the block, column c
+                    bwr = vb[(size_t)(4 * (ks + 1)) * 16];
+                    bwi = vb[vplane + (size_t)(4 * (ks + 1)) * 16];
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    pr[v] = MFMA64(ar[v], br, pr[v]);  pi[v] = MFMA64(ar[v], bi, pi[v]);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    pr[v] = MFMA64(ai[v], nbi, pr[v]); pi[v] = MFMA64(ai[v], br, pi[v]);
+                }
+            };
+            if constexpr (CACHE_A) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) ks_step(ks);
+            } else {
+#pragma unroll 4
+                for (int ks = 0; ks < KS; ++ks) ks_step(ks);
+            }
+        };
+
+        // ---- pass 1: u_0 = Psi(t_n), u_{a+1} = (-i dt / (a+1)) H u_a ----
+        const double *h0q = a.H0q + (size_t)k * RT * KS * 128, *hcq = a.Hcq + kc;
+        load_frags(h0q, hcq);
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (wave + tt * NW) + 4 * r + rg;
+                const double2 p = a.fw[((size_t)k * (a.N_T + 1) + nc) * NP + row];
+                const double pr_ = valid ? p.x : 0., pi_ = valid ? p.y : 0.;
+                const size_t o = (size_t)row * 16 + c;
+                dsm2[o] = pr_; dsm2[vplane + o] = pi_;
+                park[o] = pr_; park[vplane + o] = pi_;
+            }
+        __syncthreads();
+        int cur = 0, M = 0, converged = 0;
+        const int mcap = a.max_order < a.maxm ? a.max_order : a.maxm;
+        for (int m = 1; m <= mcap; ++m) {   // forms u_m
+            const double *vc = dsm2 + (size_t)cur * 2 * vplane;
+            double *vn = dsm2 + (size_t)(cur ^ 1) * 2 * vplane;
+            const double sfac = dt / (double)m;
+            double nn = 0.;
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) {
+                const int rt = wave + tt * NW;
+                d4 pr[NV], pi[NV];
+                products(h0q, hcq, vc, rt, pr, pi);
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) { pr[0] += e[l] * pr[1 + l]; pi[0] += e[l] * pi[1 + l]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
+                    const double ur = sfac * pi[0][r], ui = -sfac * pr[0][r];   // (-i s)(x + i y) = s y - i s x
+                    vn[o] = ur; vn[vplane + o] = ui;
+                    if (m < a.maxm) { park[(size_t)m * 2 * vplane + o] = ur; park[(size_t)m * 2 * vplane + vplane + o] = ui; }
+                    nn += ur * ur + ui * ui;
+                }
+            }
+            nn += __shfl_xor(nn, 16, 64);
+            nn += __shfl_xor(nn, 32, 64);
+            if (lane < 16) redn[m & 1][wave][c] = nn;
+            __syncthreads();
+            double tot = 0.;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += redn[m & 1][w][c];
+            cur ^= 1;
+            M = m;
+            // ||u_m|| < tol for every cell of the batch (identical decision in every wave: same LDS values)
+            if (m >= 2 && __all(tot < a.tol * a.tol)) { converged = 1; break; }
+        }
+        // orders a = 0..M-1 enter the sum; u_M is below the tolerance (or the cap was hit: flagged below)
+
+        // ---- pass 2: w_{M-1} = chi(t_{n+1}), w_{a-1} = chi + (i dt / (a+1)) H^dagger w_a ----
+        const double *h0p = a.H0p + (size_t)k * RT * KS * 128, *hcp = a.Hcp + kc;
+        load_frags(h0p, hcp);
+        double chr[TPW][4], chi_[TPW][4];
+        __syncthreads();   // pass 1 is done with the vector block
+        cur = 0;
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (wave + tt * NW) + 4 * r + rg;
+                const double2 x = a.bw[((size_t)k * (a.N_T + 1) + nc + 1) * NP + row];
+                chr[tt][r] = valid ? x.x : 0.; chi_[tt][r] = valid ? x.y : 0.;
+                dsm2[(size_t)row * 16 + c] = chr[tt][r];
+                dsm2[vplane + (size_t)row * 16 + c] = chi_[tt][r];
+            }
+        __syncthreads();
+        double dr[LMAX], di[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { dr[l] = 0.; di[l] = 0.; }
+        for (int aa = M - 1; aa >= 0; --aa) {
+            const double *vc = dsm2 + (size_t)cur * 2 * vplane;
+            double *vn = dsm2 + (size_t)(cur ^ 1) * 2 * vplane;
+            const double inv = 1.0 / (double)(aa + 1), sfac = dt * inv;
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) {
+                const int rt = wave + tt * NW;
+                double ur[4], ui[4];   // u_aa tile of this wave (requested before the products)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = (size_t)aa * 2 * vplane + (size_t)(16 * rt + 4 * r + rg) * 16 + c;
+                    ur[r] = park[o]; ui[r] = park[vplane + o];
+                }
+                d4 pr[NV], pi[NV];
+                products(h0p, hcp, vc, rt, pr, pi);
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    double sr = 0., si = 0.;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {   // conj(mu_l^dagger w) * u
+                        sr += pr[1 + l][r] * ur[r] + pi[1 + l][r] * ui[r];
+                        si += pr[1 + l][r] * ui[r] - pi[1 + l][r] * ur[r];
+                    }
+                    dr[l] += inv * sr; di[l] += inv * si;
+                    pr[0] += e[l] * pr[1 + l]; pi[0] += e[l] * pi[1 + l];
+                }
+                if (aa > 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {   // chi + (i s)(x + i y) = chi - s y + i s x
+                        const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
+                        vn[o] = chr[tt][r] - sfac * pi[0][r];
+                        vn[vplane + o] = chi_[tt][r] + sfac * pr[0][r];
+                    }
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        // ---- tau_grads = rho (-i dt s_l) sum_a <mu_l^dagger w_a | u_a> / (a+1) ----
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            dr[l] += __shfl_xor(dr[l], 16, 64); di[l] += __shfl_xor(di[l], 16, 64);
+            dr[l] += __shfl_xor(dr[l], 32, 64); di[l] += __shfl_xor(di[l], 32, 64);
+            if (lane < 16) { redo[wave][l][c][0] = dr[l]; redo[wave][l][c][1] = di[l]; }
+        }
+        __syncthreads();
+        if (tid < 16 && valid) {
+            const double rho = a.rho[k];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L) {
+                    double Dr = 0., Di = 0.;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) { Dr += redo[w][l][c][0]; Di += redo[w][l][c][1]; }
+                    const double f = rho * dt * sh[l];   // (-i f)(Dr + i Di) = f Di - i f Dr
+                    a.tg[((size_t)k * L + l) * a.N_T + n] = make_double2(f * Di, -f * Dr);
+                }
+            }
+        }
+        if (tid == 0) {
+            if (!converged) atomicOr(&a.flags[0], 4);
+            atomicAdd(&a.stats[8], (unsigned long long)M * (unsigned long long)min(16, a.N_T - n0));
+        }
+        __syncthreads();   // LDS block, reduction slots and parking area are reused by the next batch
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // State-dependent running cost of the family g_b(Psi) = <Psi|D|Psi> (test_state_running_cost.jl:32-40):
 // xi_k(t_n) = -D_k Psi_k(t_n) and g_kn for every stored state (cell-parallel), then the trapezoid sum
 // J_b = sum_k sum_n wq[n] g_kn (optimize.jl:727-750).
