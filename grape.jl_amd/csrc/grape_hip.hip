@@ -225,7 +225,8 @@ hipError_t launch_deriv2(int NP, const Deriv2Args &a, int nblocks, hipStream_t s
         case 64:
             if (a.L == 1) return launch_d2<64, 1, true>(a, nblocks, s);
             if (a.L == 2) return launch_d2<64, 2, true>(a, nblocks, s);
-            return launch_d2<64, 4, false>(a, nblocks, s);
+            if (a.L <= 4) return launch_d2<64, 4, false>(a, nblocks, s);
+            return launch_d2<64, 8, false>(a, nblocks, s);
         case 128:
             if (a.L == 1) return launch_d2<128, 1, false>(a, nblocks, s);
             if (a.L == 2) return launch_d2<128, 2, false>(a, nblocks, s);
@@ -561,7 +562,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         h->deriv_blocks = (int)std::min<long>(nbatch, 1024);
         {   // two-pass series kernel (deriv2_kernel): untransposed fragments and the u_a parking area
             const char *env = getenv("GRAPE_DERIV2");
-            h->deriv2 = !(env && atoi(env) == 0) && L <= 4;
+            h->deriv2 = !(env && atoi(env) == 0);
             if (h->deriv2) {
                 pack(p->H0, K, pk, false);
                 CCHK(dmalloc(&h->d_H0q, pk.size()));
