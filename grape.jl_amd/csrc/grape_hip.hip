@@ -60,6 +60,7 @@ struct grape_handle {
     // generator classes: trajectories with bit-identical H0 (and control operators) share one set of
     // propagators U_cn; KC == K (d_cls == nullptr) for ensembles of distinct generators
     int KC = 0;
+    bool herm = false;           // all generators Hermitian: A = -i dt H is skew-Hermitian (expm uses the symmetry)
     std::vector<int> cls;        // [K] class of trajectory k
     int *d_cls = nullptr, *d_rep = nullptr;
     unsigned *d_coop = nullptr;  // [2][K] step counters of the cooperative sweeps (forward, backward)
@@ -100,7 +101,7 @@ size_t expm_lds_bytes(int NT) {
 }
 
 template <int NT>
-hipError_t launch_expm(const ExpmArgs &a, hipStream_t s) {
+hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s) {
     static bool attr_set[8] = {false};
     const size_t lds = expm_lds_bytes(NT);
     int dev = 0;
@@ -111,13 +112,19 @@ hipError_t launch_expm(const ExpmArgs &a, hipStream_t s) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && NT == 4)
+            e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, false, NT == 4>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev & 7] = true;
     }
     hipError_t e = hipMemsetAsync(a.cellflag, 0, (size_t)a.K * a.N_T * sizeof(int), s);
     if (e != hipSuccess) return e;
     // fast pass: unpivoted block Gauss-Jordan, flags the cells it cannot solve safely; one workgroup per cell
-    hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
+    if (herm && NT == 4)   // Hermitian generators: three of four row tiles per strip from the MFMAs
+        hipLaunchKernelGGL((expm_pade_kernel<NT, false, NT == 4>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
+    else
+        hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
     // pivoted pass over the flagged cells (all other workgroups exit at once)
     hipLaunchKernelGGL((expm_pade_kernel<NT, true>), dim3(std::min(a.K * a.N_T, 1024)), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
@@ -484,6 +491,22 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             h->cls[k] = found;
         }
         h->KC = (int)rep.size();
+        {   // Hermitian generators?  (exact conjugate symmetry of every H0_k and H_l, as built by the caller)
+            bool herm = true;
+            auto is_herm = [&](const double *m) {
+                for (int i = 0; i < p->N && herm; ++i)
+                    for (int j = i; j < p->N; ++j) {
+                        const double ar = m[2 * ((size_t)j * p->N + i)], ai = m[2 * ((size_t)j * p->N + i) + 1];
+                        const double br = m[2 * ((size_t)i * p->N + j)], bi = m[2 * ((size_t)i * p->N + j) + 1];
+                        if (ar != br || ai != -bi) { herm = false; break; }
+                    }
+            };
+            for (int k = 0; k < p->K && herm; ++k) is_herm(p->H0 + (size_t)k * 2 * p->N * p->N);
+            const int nhc = (p->hc_per_traj ? p->K : 1) * p->L;
+            for (int q = 0; q < nhc && herm; ++q) is_herm(p->Hc + (size_t)q * 2 * p->N * p->N);
+            const char *envh = getenv("GRAPE_NO_HERM");
+            h->herm = herm && !(envh && atoi(envh));
+        }
         if (h->KC < p->K) {
             if (hipSetDevice(h->device) != hipSuccess || hipMalloc((void **)&h->d_cls, p->K * sizeof(int)) != hipSuccess ||
                 hipMalloc((void **)&h->d_rep, h->KC * sizeof(int)) != hipSuccess ||
@@ -691,9 +714,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         e = expm_large(h, s);
     } else {
         switch (h->NT) {
-            case 1: e = launch_expm<1>(ea, s); break;
-            case 2: e = launch_expm<2>(ea, s); break;
-            default: e = launch_expm<4>(ea, s); break;
+            case 1: e = launch_expm<1>(ea, h->herm, s); break;
+            case 2: e = launch_expm<2>(ea, h->herm, s); break;
+            default: e = launch_expm<4>(ea, h->herm, s); break;
         }
     }
     HIPCHK(h, e);
