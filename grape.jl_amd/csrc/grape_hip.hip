@@ -262,16 +262,17 @@ LgView lg_full(double *p, int NP) { return LgView{p, (size_t)2 * NP * NP, (size_
 
 hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, LgView C, int kblocks, double alpha,
                    double beta, int nadd = 0, const LgView *add = nullptr, const double *coef = nullptr,
-                   double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0) {
+                   double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0, int herm = 0) {
     if (nbi <= 0 || nbj <= 0) return hipSuccess;
     LgGemmArgs a{};
     a.X = X; a.Y = Y; a.C = C; a.kblocks = kblocks; a.alpha = alpha; a.beta = beta; a.cI = cI;
     a.nadd = nadd;
     for (int i = 0; i < nadd; ++i) { a.Add[i] = add[i]; a.coef[i] = coef[i]; }
-    a.s_cell = s_cell; a.sq_iter = sq_iter;
+    a.s_cell = s_cell; a.sq_iter = sq_iter; a.herm = (nbi == nbj) ? herm : 0;
     a.nbi = nbi; a.nbj = nbj; a.ncell = nc;
     const int groups = (nc + 7) / 8;   // cells are dealt to the 8 XCDs in groups
-    hipLaunchKernelGGL(lg_gemm_kernel, dim3(groups * 8 * nbi * nbj), dim3(256), 0, s, a);
+    const int per_cell = a.herm ? nbi * (nbi + 1) / 2 : nbi * nbj;
+    hipLaunchKernelGGL(lg_gemm_kernel, dim3(groups * 8 * per_cell), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -310,9 +311,11 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
         LGCHK(hipGetLastError());
         const LgView vA = lg_full(A, NP), vA2 = lg_full(A2, NP), vA4 = lg_full(A4, NP), vA6 = lg_full(A6, NP),
                      vW = lg_full(W, NP), vZ = lg_full(Z, NP), vT = lg_full(T, NP), vV = lg_full(V, NP), vU = lg_full(Uo, NP);
-        LGCHK(lg_gemm(s, nc, NB, NB, vA, vA, vA2, NB, 1.0, 0.0));
-        LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA2, vA4, NB, 1.0, 0.0));
-        LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA4, vA6, NB, 1.0, 0.0));
+        // Hermitian generators: A2, A4, A6, T, V are Hermitian and U = A T skew-Hermitian -> upper block triangle only
+        const int hm = h->herm ? 1 : 0;
+        LGCHK(lg_gemm(s, nc, NB, NB, vA, vA, vA2, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm));
+        LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA2, vA4, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm));
+        LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA4, vA6, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm));
         {
             const double *in[3] = {A6, A4, A2};
             const double cw[3] = {B13_13, B13_11, B13_9}, cz[3] = {B13_12, B13_10, B13_8};
@@ -320,10 +323,10 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
             LGCHK(lg_lincomb(s, Z, nel, 3, in, cz));
             const LgView add[3] = {vA6, vA4, vA2};
             const double ct[3] = {B13_7, B13_5, B13_3}, cv[3] = {B13_6, B13_4, B13_2};
-            LGCHK(lg_gemm(s, nc, NB, NB, vA6, vW, vT, NB, 1.0, 0.0, 3, add, ct, B13_1));   // T = A6 W1 + T0
-            LGCHK(lg_gemm(s, nc, NB, NB, vA6, vZ, vV, NB, 1.0, 0.0, 3, add, cv, B13_0));   // V = A6 Z1 + V0
+            LGCHK(lg_gemm(s, nc, NB, NB, vA6, vW, vT, NB, 1.0, 0.0, 3, add, ct, B13_1, nullptr, 0, hm));   // T = A6 W1 + T0
+            LGCHK(lg_gemm(s, nc, NB, NB, vA6, vZ, vV, NB, 1.0, 0.0, 3, add, cv, B13_0, nullptr, 0, hm));   // V = A6 Z1 + V0
         }
-        LGCHK(lg_gemm(s, nc, NB, NB, vA, vT, vU, NB, 1.0, 0.0));                           // U = A T
+        LGCHK(lg_gemm(s, nc, NB, NB, vA, vT, vU, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, -hm));   // U = A T
         {
             const double *in[2] = {V, Uo};
             const double cp[2] = {1.0, 1.0}, cq[2] = {1.0, -1.0};

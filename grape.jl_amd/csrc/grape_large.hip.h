@@ -28,6 +28,8 @@ struct LgGemmArgs {
     int nbi, nbj, ncell; // output blocks per cell and cells in this launch
     const int *s_cell;   // optional: squarings per cell; cells with s_cell[cell] <= sq_iter copy X instead
     int sq_iter;
+    int herm;            // +1 / -1: the product is Hermitian / skew-Hermitian (nbi == nbj): only the blocks bi <= bj are
+                         // computed, each workgroup also stores the (signed) conjugate transpose of its block at (bj, bi)
 };
 
 __device__ __forceinline__ double *lg_ptr(const LgView &v, int cell, int brow, int bcol) {
@@ -41,12 +43,20 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware 1-D grid: the nbi*nbj blocks of one cell share blockIdx % 8, i.e. one XCD and its L2,
     // so that the row panels of X and the column panels of Y are fetched from HBM once per cell.
-    const int per_cell = a.nbi * a.nbj;
+    const int per_cell = a.herm ? a.nbi * (a.nbi + 1) / 2 : a.nbi * a.nbj;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int cell = (q / per_cell) * 8 + xcd;
     if (cell >= a.ncell) return;
     const int rem = q % per_cell;
-    const int bi = rem / a.nbj, bj = rem - bi * a.nbj;
+    int bi, bj;
+    if (a.herm) {   // upper triangle, row by row
+        int r = rem;
+        bi = 0;
+        while (r >= a.nbi - bi) { r -= a.nbi - bi; ++bi; }
+        bj = bi + r;
+    } else {
+        bi = rem / a.nbj; bj = rem - bi * a.nbj;
+    }
     const int col = 16 * wave + (lane & 15), rg = lane >> 4;
     double *c = lg_ptr(a.C, cell, bi, bj);
     if (a.s_cell && a.s_cell[cell] <= a.sq_iter) {   // no (further) squaring for this cell: C = X
@@ -101,7 +111,34 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
             if (a.cI != 0.0 && grow0 + row == gcol) vr += a.cI;
             c[o] = vr;
             c[a.C.plane + o] = vi;
+            acc.re[t][r] = vr;   // kept for the mirrored block
+            acc.im[t][r] = vi;
         }
+    if (a.herm && bi != bj) {
+        // mirrored block (bj, bi) = sgn * conj(transpose): staged through the (now idle) LDS tile so that the
+        // global stores stay row-contiguous
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + 4 * r + rg;
+                Xre[row * LD + col] = acc.re[t][r];
+                Xim[row * LD + col] = acc.im[t][r];
+            }
+        __syncthreads();
+        double *c2 = lg_ptr(a.C, cell, bj, bi);
+        const double sg = (double)a.herm;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + 4 * r + rg;   // element (row, col) of the mirrored block = conj of (col, row)
+                const size_t o = (size_t)row * a.C.ld + col;
+                c2[o] = sg * Xre[col * LD + row];
+                c2[a.C.plane + o] = -sg * Xim[col * LD + row];
+            }
+    }
 }
 
 // out = sum_i coef[i] * In_i  (whole NP x NP matrices, both planes)
