@@ -135,12 +135,13 @@ def main():
     if rank == 0:
         # HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes of tools/pmc.sh
         # (separate run: counters cannot be collected inside the timed bench), see profiles/.
-        traffic = None
+        traffic, hw_util = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             for kname, d in pmc["kernels"].items():
-                if kname.startswith("void expm_pade_kernel"):
+                if kname.startswith("void expm_pade_kernel") and d.get("MfmaUtil_percent", 0) > 0:   # the fast pass
                     traffic = d.get("hbm_bytes_per_launch")
+                    hw_util = d.get("MfmaUtil_percent")
         except Exception:
             pass
         expm_ms = tm["expm"]
@@ -161,15 +162,19 @@ def main():
                        "one_eval": "one shard evaluation = functional + full gradient of 128 trajectories; "
                                    "value counts shard evaluations completed by all ranks per second",
                        "global_problem_evals_per_s": args.steps / elapsed},
-            "roofline": {"bound": "mfma", "kernel": ("expm_pade_kernel<%d>" % ((N + 15) // 16 if N <= 32 else 4) if N <= 64
+            "roofline": {"bound": "mfma", "kernel": ("expm_pade_kernel<%d,...>" % ((N + 15) // 16 if N <= 32 else 4) if N <= 64
                                                      else "lg_gemm_kernel chain (blocked Pade-13)") + " (v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.json); "
                                          "algorithmic bytes per launch = K*N_T*N^2*16 (U store) = 8.39e9",
                          "flop_per_launch": work["flop_expm"], "avg_launch_ms": expm_ms,
+                         "hw_mfma_busy_percent": hw_util,
+                         "note": "achieved = ALGORITHMIC flops (SURVEY 8d model of the Pade evaluation) per second; for "
+                                 "Hermitian generators the kernel skips a quarter of the product MFMAs by symmetry, so "
+                                 "the hardware MFMA-busy fraction (PMC, profiles/) is lower than achieved/peak",
                          "flop_model": "SURVEY 8d F_exp = (6+s)*8N^3 + (32/3)N^3 per Pade-13 cell"},
-            "phases_ms": {k: round(v, 4) for k, v in tm.items()},
+            "phases_ms": {k: round(v, 4) for k, v in tm.items() if v >= 0},
             "deriv_kernel": {"flop_per_launch": work["flop_deriv"], "avg_launch_ms": tm["deriv"],
                              "tflops": work["flop_deriv"] / (tm["deriv"] * 1e-3) * 1e-12 if tm["deriv"] > 0 else None,
                              "series_orders_per_cell": work["deriv_orders"] / work["cells"]},
