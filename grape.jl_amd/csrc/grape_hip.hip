@@ -284,6 +284,15 @@ hipError_t lg_lincomb(hipStream_t s, double *out, size_t n, int nin, const doubl
     return hipGetLastError();
 }
 
+hipError_t lg_lincomb2(hipStream_t s, double *out0, double *out1, size_t n, int nin, const double *const *in,
+                       const double *c0, const double *c1) {
+    LgLincomb2Args a{};
+    a.out0 = out0; a.out1 = out1; a.n = n; a.nin = nin;
+    for (int i = 0; i < nin; ++i) { a.in[i] = in[i]; a.c0[i] = c0[i]; a.c1[i] = c1[i]; }
+    hipLaunchKernelGGL(lg_lincomb2_kernel, dim3(2048), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 #define LGCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
 hipError_t expm_large(grape_handle *h, hipStream_t s) {
@@ -319,8 +328,7 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
         {
             const double *in[3] = {A6, A4, A2};
             const double cw[3] = {B13_13, B13_11, B13_9}, cz[3] = {B13_12, B13_10, B13_8};
-            LGCHK(lg_lincomb(s, W, nel, 3, in, cw));
-            LGCHK(lg_lincomb(s, Z, nel, 3, in, cz));
+            LGCHK(lg_lincomb2(s, W, Z, nel, 3, in, cw, cz));
             const LgView add[3] = {vA6, vA4, vA2};
             const double ct[3] = {B13_7, B13_5, B13_3}, cv[3] = {B13_6, B13_4, B13_2};
             LGCHK(lg_gemm(s, nc, NB, NB, vA6, vW, vT, NB, 1.0, 0.0, 3, add, ct, B13_1, nullptr, 0, hm));   // T = A6 W1 + T0
@@ -330,8 +338,7 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
         {
             const double *in[2] = {V, Uo};
             const double cp[2] = {1.0, 1.0}, cq[2] = {1.0, -1.0};
-            LGCHK(lg_lincomb(s, W, nel, 2, in, cp));   // P = V + U   (buffer W)
-            LGCHK(lg_lincomb(s, Z, nel, 2, in, cq));   // Q = V - U   (buffer Z)
+            LGCHK(lg_lincomb2(s, W, Z, nel, 2, in, cp, cq));   // P = V + U (buffer W), Q = V - U (buffer Z)
         }
         // block Gauss-Jordan on 64-blocks: Q X = P
         const LgView vD{h->d_dinv, (size_t)2 * 4096, (size_t)4096, 64, 0, 0};

@@ -149,6 +149,26 @@ struct LgLincombArgs {
     int nin;
     size_t n;   // doubles per cell (2 * NP * NP) * cells
 };
+// two combinations of the same inputs in one pass (W and Z of the order-13 polynomials; P = V+U and Q = V-U)
+struct LgLincomb2Args {
+    double *out0, *out1;
+    const double *in[3];
+    double c0[3], c1[3];
+    int nin;
+    size_t n;
+};
+__global__ void lg_lincomb2_kernel(LgLincomb2Args a) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        double v0 = 0., v1 = 0.;
+        for (int q = 0; q < a.nin; ++q) {
+            const double x = a.in[q][i];
+            v0 += a.c0[q] * x;
+            v1 += a.c1[q] * x;
+        }
+        a.out0[i] = v0;
+        a.out1[i] = v1;
+    }
+}
 __global__ void lg_lincomb_kernel(LgLincombArgs a) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
         double v = 0.;
@@ -185,19 +205,25 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
         e[l] = a.eps[(size_t)l * a.N_T + n];
         if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
     }
-    // thread j owns column j (NP <= 256): column sums need no reduction; rows are walked serially
+    // thread j owns column j (NP <= 256): column sums need no reduction.  Two passes over the (L2-resident)
+    // operators: the first only takes the column sums of |a_ij| for the 1-norm, the second writes A already
+    // scaled by 2^-s -- A is written once and never read back here.  Rows are unrolled by 8 so that 8 (1 + L)
+    // independent loads per plane are in flight (the loop is otherwise bound by one load latency per row).
+    auto element = [&](int i, double &ar, double &ai) __attribute__((always_inline)) {
+        const size_t o = (size_t)i * NP + tid;
+        double hr = h0[o], hi = h0[pp + o];
+        for (int l = 0; l < a.L; ++l) {
+            hr = fma(e[l], hc[(size_t)l * 2 * pp + o], hr);
+            hi = fma(e[l], hc[(size_t)l * 2 * pp + pp + o], hi);
+        }
+        ar = dt * hi; ai = -dt * hr;
+    };
     double cs = 0.;
-    for (int i = 0; i < NP; ++i) {
-        if (tid < NP) {
-            const size_t o = (size_t)i * NP + tid;
-            double hr = h0[o], hi = h0[pp + o];
-            for (int l = 0; l < a.L; ++l) {
-                hr = fma(e[l], hc[(size_t)l * 2 * pp + o], hr);
-                hi = fma(e[l], hc[(size_t)l * 2 * pp + pp + o], hi);
-            }
-            const double ar = dt * hi, ai = -dt * hr;
-            A[o] = ar;
-            A[pp + o] = ai;
+    if (tid < NP) {
+#pragma unroll 8
+        for (int i = 0; i < NP; ++i) {
+            double ar, ai;
+            element(i, ar, ai);
             cs += sqrt(ar * ar + ai * ai);
         }
     }
@@ -216,9 +242,16 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
         const int ex = ilogb(r);
         s = (r == ldexp(1.0, ex)) ? ex : ex + 1;
     }
-    if (s > 0) {
-        const double f = ldexp(1.0, -s);
-        for (size_t i = tid; i < 2 * pp; i += 256) A[i] *= f;
+    const double f = ldexp(1.0, -s);
+    if (tid < NP) {
+#pragma unroll 8
+        for (int i = 0; i < NP; ++i) {
+            double ar, ai;
+            element(i, ar, ai);
+            const size_t o = (size_t)i * NP + tid;
+            A[o] = f * ar;
+            A[pp + o] = f * ai;
+        }
     }
     if (tid == 0) {
         a.s_cell[blockIdx.x] = s;
