@@ -397,6 +397,41 @@ __device__ __forceinline__ void gj_publish_invert(const Strip<NT> &Q, int jb, do
     }
 }
 
+// the two halves of gj_publish_invert for the split schedule: the owner of strip jb publishes its panel, another
+// wave gathers the diagonal tile from the panel, inverts it and publishes the inverse
+template <int NT>
+__device__ __forceinline__ void gj_publish(const Strip<NT> &Q, double *pan, int lane) {
+    constexpr int NP = 16 * NT, PLD = 18;
+    const int ai = lane & 15, ak = lane >> 4;
+    double *pwr = pan + ak * PLD + ai, *pwi = pan + NP * PLD + ak * PLD + ai;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pwr[(16 * t + 4 * r) * PLD] = Q.re[t][r];
+            pwi[(16 * t + 4 * r) * PLD] = Q.im[t][r];
+        }
+}
+template <int NT>
+__device__ __forceinline__ void gj_invert_panel(int jb, const double *pan, double *dv, int lane, double &minrel,
+                                                double inv_scale2) {
+    constexpr int NP = 16 * NT, PLD = 18;
+    const int ai = lane & 15, ak = lane >> 4;
+    double dr[4], di[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dr[c] = pan[(16 * jb + ai) * PLD + 4 * c + ak];
+        di[c] = pan[NP * PLD + (16 * jb + ai) * PLD + 4 * c + ak];
+    }
+    const double mr = invert16(dr, di, lane, inv_scale2);
+    minrel = fmin(minrel, mr);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dv[c * 64 + lane] = dr[c];
+        dv[256 + c * 64 + lane] = di[c];
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void gj_update(Strip<NT> &S, int jb, const double *pan, const double *dv, int lane) {
     constexpr int NP = 16 * NT, PLD = 18;
@@ -463,19 +498,32 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
     if (wave == 0) gj_publish_invert<NT>(Q, 0, panbase, dvbase, lane, minrel, inv_scale2, do_invert);
     __syncthreads();
     STAMP(5);
+    // SPLIT SCHEDULE.  The register inversion of the next diagonal tile is serial (one wave, 16 dependent pivot
+    // steps, ~6 K cycles) and each strip update is ~5 K cycles of MFMAs.  Block step jb runs in two halves:
+    //   first half : every wave does ONE update -- the owner of strip jb+1 and the waves behind it update their
+    //                Q strip (the owner then publishes the next panel), the waves whose Q strip is finished
+    //                (w <= jb) update their P strip;
+    //   second half: wave jb (its Q strip is finished, its P strip is up to date) inverts the next diagonal
+    //                tile out of the published panel while the waves w > jb update their P strips.
+    // A step therefore costs max(update) + max(inversion, update) instead of update + inversion + update for
+    // the owner, and nobody carries a deferred update into the last step.
 #pragma unroll
     for (int jb = 0; jb < NT; ++jb) {
         const double *pan = panbase + (jb % 3) * PAN, *dv = dvbase + (jb % 3) * DV;
-        if (jb + 1 < NT && wave == jb + 1) {
+        double *pan_next = panbase + ((jb + 1) % 3) * PAN, *dv_next = dvbase + ((jb + 1) % 3) * DV;
+        if (wave > jb) {
             gj_update<NT>(Q, jb, pan, dv, lane);
-            gj_publish_invert<NT>(Q, jb + 1, panbase + ((jb + 1) % 3) * PAN, dvbase + ((jb + 1) % 3) * DV, lane,
-                                  minrel, inv_scale2, do_invert);
-            // this wave's P update of step jb is deferred to the next step
+            if (jb + 1 < NT && wave == jb + 1) gj_publish<NT>(Q, pan_next, lane);
         } else {
-            if (jb > 0 && wave == jb)  // deferred P update of step jb-1
-                gj_update<NT>(P, jb - 1, panbase + ((jb - 1) % 3) * PAN, dvbase + ((jb - 1) % 3) * DV, lane);
-            if (wave > jb) gj_update<NT>(Q, jb, pan, dv, lane);
             gj_update<NT>(P, jb, pan, dv, lane);
+        }
+        if (jb + 1 < NT) {
+            __syncthreads();
+            if (wave == jb) {
+                if (do_invert) gj_invert_panel<NT>(jb + 1, pan_next, dv_next, lane, minrel, inv_scale2);
+            } else if (wave > jb) {
+                gj_update<NT>(P, jb, pan, dv, lane);
+            }
         }
         hook(jb);
         __syncthreads();
