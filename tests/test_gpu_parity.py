@@ -63,6 +63,8 @@ CASES = [  # N, L, N_T, K, dt, hermitian, functional
     (64, 2, 4, 2, 4.0, True, 1),      # s = 2
     (64, 3, 4, 2, 9.0, False, 2),     # s = 3..4, non-Hermitian
     (64, 6, 3, 1, 1.0, True, 0),      # L = 6 (two-qubit-gate-like control count)
+    (64, 2, 5, 2, 0.3, True, 2),      # Hermitian, low orders (9/7): the symmetric fast path falls back per cell
+    (100, 2, 4, 2, 2.5, True, 0),     # blocked path, Hermitian upper-triangle products, s >= 1
 ]
 
 
@@ -391,3 +393,23 @@ def test_trajectories_with_identical_generators_share_propagators(g, ref, N, mon
     Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
                                 gradient_method=ref.TAYLOR)
     assert abs(J - Jr) <= TOL_J and np.abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr)
+
+
+@pytest.mark.parametrize("N", [40, 64, 130])
+def test_hermitian_fast_path_matches_general_path(g, N, monkeypatch):
+    """Hermitian generators let phase A skip the mirrored tiles / blocks of A^2, A^4, A^6, T, V, U; the general
+    path (GRAPE_NO_HERM=1) must give the same propagators and gradient to rounding."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, 2, 6, 3, seed=4242 + N, dt=1.7)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        U = h.propagator(1, 3)
+    monkeypatch.setenv("GRAPE_NO_HERM", "1")
+    with g.GrapeHip(*args) as h:
+        J1, G1, tau1 = h.eval(pr["pulsevals"])
+        U1 = h.propagator(1, 3)
+    assert np.abs(U - U1).max() <= 5e-15
+    assert np.abs(U.conj().T @ U - np.eye(N)).max() <= 1e-13
+    assert abs(J - J1) <= 1e-14 and np.abs(tau - tau1).max() <= 1e-13
+    assert np.abs(G - G1).max() <= 1e-13 * max(1.0, np.abs(G1).max())
