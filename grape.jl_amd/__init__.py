@@ -12,7 +12,7 @@ Only what the path needs:
 """
 from . import synth  # noqa: F401
 from .api import (GrapeHip, GrapeHipError, build_library, library_path,  # noqa: F401
-                  J_T_SM, J_T_SS, J_T_RE, GRAD_GRADGEN, GRAD_TAYLOR)
+                  J_T_SM, J_T_SS, J_T_RE, GRAD_GRADGEN, GRAD_TAYLOR, PROP_EXP, PROP_SERIES)
 
 __all__ = ["GrapeHip", "GrapeHipError", "build_library", "library_path", "synth",
-           "J_T_SM", "J_T_SS", "J_T_RE", "GRAD_GRADGEN", "GRAD_TAYLOR"]
+           "J_T_SM", "J_T_SS", "J_T_RE", "GRAD_GRADGEN", "GRAD_TAYLOR", "PROP_EXP", "PROP_SERIES"]

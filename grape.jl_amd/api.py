@@ -19,7 +19,8 @@ _LIBNAME = "libgrape_hip.so"
 
 J_T_SM, J_T_SS, J_T_RE = 0, 1, 2
 GRAD_GRADGEN, GRAD_TAYLOR = 0, 1
-ABI_VERSION = 2
+PROP_EXP, PROP_SERIES = 0, 1
+ABI_VERSION = 3
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAPE_ERR_CHI_NORM",
           -4: "GRAPE_ERR_SINGULAR", -5: "GRAPE_ERR_TAYLOR", -6: "GRAPE_ERR_NO_CONTROLS"}
@@ -28,7 +29,7 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAP
 EXPORTS = ["grape_create", "grape_destroy", "grape_eval", "grape_forward", "grape_backward",
            "grape_forward_device", "grape_backward_device", "grape_check", "grape_get_propagator",
            "grape_get_tau_grads", "grape_get_storage", "grape_get_timings", "grape_reset_timings", "grape_get_work",
-           "grape_last_error", "grape_abi_version"]
+           "grape_last_error", "grape_abi_version", "grape_set_fused_sweeps"]
 
 
 class GrapeHipError(RuntimeError):
@@ -45,7 +46,8 @@ class _Problem(C.Structure):
                 ("psi0", C.c_void_p), ("target", C.c_void_p), ("weights", C.c_void_p),
                 ("chi_min_norm", C.c_double), ("taylor_max_order", C.c_int32),
                 ("taylor_tolerance", C.c_double),
-                ("Dpen", C.c_void_p), ("dpen_per_traj", C.c_int32), ("lambda_b", C.c_double)]
+                ("Dpen", C.c_void_p), ("dpen_per_traj", C.c_int32), ("lambda_b", C.c_double),
+                ("prop_method", C.c_int32), ("prop_tolerance", C.c_double)]
 
 
 def library_path() -> str:
@@ -55,7 +57,8 @@ def library_path() -> str:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     out = library_path()
-    srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_kernels.hip.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_kernels.hip.h", "grape_large.hip.h",
+                                             "grape_series.hip.h")]
     hdr = os.path.join(_HERE, "..", "include", "grape_hip.h")
     if (not force and os.path.exists(out)
             and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs + [hdr])):
@@ -97,6 +100,7 @@ def load_library():
     lib.grape_get_timings.argtypes = [vp, vp, ip]
     lib.grape_get_work.argtypes = [vp, vp, ip]
     lib.grape_reset_timings.argtypes = [vp]
+    lib.grape_set_fused_sweeps.argtypes = [vp, ip]
     lib.grape_last_error.argtypes = [vp]
     lib.grape_last_error.restype = C.c_char_p
     lib.grape_abi_version.restype = ip
@@ -121,7 +125,8 @@ class GrapeHip:
 
     def __init__(self, H0, Hc, tlist, psi0, target, weights=None, functional=J_T_SM,
                  gradient_method=GRAD_GRADGEN, shape=None, K_total=None, device=0,
-                 chi_min_norm=0.0, taylor_max_order=0, taylor_tolerance=0.0, D=None, lambda_b=0.0):
+                 chi_min_norm=0.0, taylor_max_order=0, taylor_tolerance=0.0, D=None, lambda_b=0.0,
+                 prop_method=PROP_EXP, prop_tolerance=0.0):
         self._lib = load_library()
         H0 = np.asarray(H0)
         K, N = H0.shape[0], H0.shape[1]
@@ -153,6 +158,8 @@ class GrapeHip:
         p.target = self._target.ctypes.data
         p.weights = None if self._weights is None else self._weights.ctypes.data
         p.chi_min_norm, p.taylor_max_order, p.taylor_tolerance = chi_min_norm, taylor_max_order, taylor_tolerance
+        p.prop_method, p.prop_tolerance = int(prop_method), float(prop_tolerance)
+        self.prop_method = int(prop_method)
         # state running cost g_b = <Psi|D|Psi> (D: [N, N] shared or [K, N, N]), weight lambda_b
         self._D = None
         self.lambda_b = float(lambda_b) if D is not None else 0.0
@@ -224,6 +231,10 @@ class GrapeHip:
     def backward_device(self, d_f_ptr, d_G_ptr, stream=0):
         self._chk(self._lib.grape_backward_device(self._h, d_f_ptr, d_G_ptr, stream))
 
+    def set_fused_sweeps(self, on=True):
+        """Concurrent forward/backward sweeps (include/grape_hip.h); returns whether they are active."""
+        return bool(self._lib.grape_set_fused_sweeps(self._h, int(bool(on))))
+
     def check(self, stream=0):
         self._chk(self._lib.grape_check(self._h, stream))
 
@@ -252,7 +263,7 @@ class GrapeHip:
         self._chk(self._lib.grape_reset_timings(self._h))
 
     def work(self):
-        w = np.zeros(7)
-        self._lib.grape_get_work(self._h, w.ctypes.data, 7)
+        w = np.zeros(9)
+        self._lib.grape_get_work(self._h, w.ctypes.data, 9)
         return dict(cells=w[0], squarings=w[1], flop_expm=w[2], flop_deriv=w[3], deriv_orders=w[4],
-                    pivoted_cells=w[5], expm_cells=w[6])
+                    pivoted_cells=w[5], expm_cells=w[6], series_terms=w[7], series_steps=w[8])

@@ -9,6 +9,7 @@
 #include "../../include/grape_hip.h"
 #include "grape_kernels.hip.h"
 #include "grape_large.hip.h"
+#include "grape_series.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -79,6 +80,18 @@ struct grape_handle {
     bool have_forward = false, in_eval = false;
     double chi_min_norm = 1e-100, taylor_tol = 1e-16;
     int taylor_max_order = 100;
+    // matrix-free polynomial propagator (prop_method = GRAPE_PROP_SERIES): no U is materialised
+    // concurrent sweeps: the backward sweep starts from the unit targets in the same launch as the forward sweep
+    bool fuse = false;           // capability (no state running cost, N <= 64) and not switched off
+    bool fuse_on = true;         // grape_set_fused_sweeps
+    bool want_bw = true;         // the evaluation in flight wants a gradient (grape_eval with G == NULL clears it)
+    bool bw_done = false;        // the last forward call already ran the (unit) backward sweep
+    bool bw_unit = false;        // d_bw holds the unit backward states chi~ (storage getter applies the phase)
+    double *d_inv_tnorm = nullptr, *d_ones = nullptr;
+    double2 *d_z = nullptr;
+    bool series = false;
+    double *d_rb = nullptr;      // [K + Kc*L] 2-norm estimates of H0_k and of the control operators
+    double series_tol = 1e-17, series_theta = 3.0;
 };
 
 namespace {
@@ -151,6 +164,79 @@ hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s) {
     if (backward) hipLaunchKernelGGL((sweep_kernel<NP, true>), dim3(a.K), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((sweep_kernel<NP, false>), dim3(a.K), dim3(256), 0, s, a);
     return hipGetLastError();
+}
+
+template <int NP>
+hipError_t launch_sweep_pair(const SweepArgs &af, const SweepArgs &ab, hipStream_t s) {
+    hipLaunchKernelGGL((sweep_pair_kernel<NP>), dim3(2 * af.K), dim3(256), 0, s, af, ab);
+    return hipGetLastError();
+}
+
+template <int NP>
+hipError_t launch_series_pair(const SeriesArgs &af, const SeriesArgs &ab, hipStream_t s) {
+    const dim3 grid(2 * af.s.K), block(NP * 16 / SERIES_RPT);
+    if (af.L == 1) hipLaunchKernelGGL((series_pair_kernel<NP, 1>), grid, block, 0, s, af, ab);
+    else if (af.L == 2) hipLaunchKernelGGL((series_pair_kernel<NP, 2>), grid, block, 0, s, af, ab);
+    else hipLaunchKernelGGL((series_pair_kernel<NP, 0>), grid, block, 0, s, af, ab);
+    return hipGetLastError();
+}
+
+template <int NP>
+hipError_t launch_series(const SeriesArgs &a, bool backward, hipStream_t s) {
+    // control tiles stay in registers for L <= 2 (instantiated per count), otherwise they stream from L2
+    const dim3 grid(a.s.K), block(NP * 16 / SERIES_RPT);
+#define SERIES_CASE(LR_)                                                                              \
+    do {                                                                                              \
+        if (backward) hipLaunchKernelGGL((series_sweep_kernel<NP, true, LR_>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((series_sweep_kernel<NP, false, LR_>), grid, block, 0, s, a);         \
+    } while (0)
+    if (a.L == 1) SERIES_CASE(1);
+    else if (a.L == 2) SERIES_CASE(2);
+    else SERIES_CASE(0);
+#undef SERIES_CASE
+    return hipGetLastError();
+}
+
+// 2-norm estimate of an N x N complex column-major matrix: power iteration on M^dagger M (deterministic start),
+// inflated by 10 %.  Used only to choose the number of sub-steps of the matrix-free propagator.
+double norm2_estimate(const double *M, int N) {
+    std::vector<double> v(2 * (size_t)N), w(2 * (size_t)N), y(2 * (size_t)N);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    for (int j = 0; j < 2 * N; ++j) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        v[j] = (double)((st >> 11) & 0xFFFFF) / 1048576.0 - 0.5;
+    }
+    double sigma2 = 0.0;
+    for (int it = 0; it < 40; ++it) {
+        double nv = 0.0;
+        for (int j = 0; j < 2 * N; ++j) nv += v[j] * v[j];
+        nv = std::sqrt(nv);
+        if (!(nv > 0.0)) return 0.0;
+        for (int j = 0; j < 2 * N; ++j) v[j] /= nv;
+        std::fill(w.begin(), w.end(), 0.0);
+        for (int j = 0; j < N; ++j) {   // w = M v   (column j of M times v_j)
+            const double vr = v[2 * j], vi = v[2 * j + 1];
+            const double *col = M + 2 * (size_t)j * N;
+            for (int i = 0; i < N; ++i) {
+                w[2 * i] += col[2 * i] * vr - col[2 * i + 1] * vi;
+                w[2 * i + 1] += col[2 * i] * vi + col[2 * i + 1] * vr;
+            }
+        }
+        for (int j = 0; j < N; ++j) {   // y = M^dagger w
+            const double *col = M + 2 * (size_t)j * N;
+            double yr = 0.0, yi = 0.0;
+            for (int i = 0; i < N; ++i) {
+                yr += col[2 * i] * w[2 * i] + col[2 * i + 1] * w[2 * i + 1];
+                yi += col[2 * i] * w[2 * i + 1] - col[2 * i + 1] * w[2 * i];
+            }
+            y[2 * j] = yr; y[2 * j + 1] = yi;
+        }
+        double ny = 0.0;
+        for (int j = 0; j < 2 * N; ++j) ny += y[j] * y[j];
+        sigma2 = std::sqrt(ny);   // ||M^dagger M v|| with ||v|| = 1 -> largest eigenvalue of M^dagger M
+        v = y;
+    }
+    return 1.1 * std::sqrt(sigma2);
 }
 
 template <int NP>
@@ -385,6 +471,17 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
     return hipSuccess;
 }
 
+SeriesArgs series_args(grape_handle *h, const SweepArgs &sa, bool backward) {
+    SeriesArgs ra{};
+    ra.s = sa;
+    ra.H0 = backward ? h->d_H0t : h->d_H0f;
+    ra.Hc = backward ? h->d_Hct : h->d_Hcf;
+    ra.eps = h->d_eps; ra.shape = h->d_shape; ra.dts = h->d_dts; ra.rb = h->d_rb; ra.stats = h->d_stats;
+    ra.tol = h->series_tol; ra.theta = h->series_theta;
+    ra.L = h->L; ra.hc_per_traj = h->p.hc_per_traj; ra.max_order = 200;
+    return ra;
+}
+
 int status_from_flags(grape_handle *h, int flags) {
     if (flags & 1) { h->err = "Pade denominator numerically singular in at least one cell"; return GRAPE_ERR_SINGULAR; }
     if (flags & 2) {
@@ -392,6 +489,10 @@ int status_from_flags(grape_handle *h, int flags) {
         return GRAPE_ERR_CHI_NORM;
     }
     if (flags & 8) { h->err = "cooperative sweep: a sibling workgroup did not arrive (spin limit reached)"; return GRAPE_ERR_HIP; }
+    if (flags & 16) {
+        h->err = "matrix-free propagator: the series of exp(-i H dt) did not converge within the order limit";
+        return GRAPE_ERR_TAYLOR;
+    }
     if (flags & 4) {
         h->err = "taylor_grad_step! did not converge within max_order iterations (optimize.jl:644-648)";
         return GRAPE_ERR_TAYLOR;
@@ -413,7 +514,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -447,6 +548,14 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     }
     if (p->L > 8) { g_create_error = "L > 8 is not supported by this build"; return GRAPE_ERR_INVALID; }
     if (p->functional < 0 || p->functional > 2) { g_create_error = "unknown functional"; return GRAPE_ERR_INVALID; }
+    if (p->prop_method != GRAPE_PROP_EXP && p->prop_method != GRAPE_PROP_SERIES) {
+        g_create_error = "unknown prop_method";
+        return GRAPE_ERR_INVALID;
+    }
+    if (p->prop_method == GRAPE_PROP_SERIES && p->N > 64) {
+        g_create_error = "prop_method = GRAPE_PROP_SERIES is built for N <= 64 (one workgroup holds the generator tile)";
+        return GRAPE_ERR_INVALID;
+    }
     for (int n = 0; n < p->N_T; ++n)
         if (!(p->tlist[n + 1] > p->tlist[n])) { g_create_error = "tlist must be strictly increasing"; return GRAPE_ERR_INVALID; }
 
@@ -463,6 +572,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     if (p->taylor_max_order > 0) h->taylor_max_order = p->taylor_max_order;
     // the gradient-generator route sums the same series until it has converged to rounding
     if (p->gradient_method == GRAPE_GRAD_GRADGEN) { h->taylor_max_order = 200; h->taylor_tol = 1e-17; }
+    h->series = p->prop_method == GRAPE_PROP_SERIES;
+    if (p->prop_tolerance > 0) h->series_tol = p->prop_tolerance;
 
     auto fail = [&](int code) { g_create_error = h->err; grape_destroy(h); return code; };
 #define CCHK(expr)                                                                              \
@@ -633,10 +744,34 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_psi0, (size_t)K * N)); CCHK(dmalloc(&h->d_target, (size_t)K * N));
     CCHK(hipMemcpy(h->d_psi0, p->psi0, (size_t)K * N * 16, hipMemcpyHostToDevice));
     CCHK(hipMemcpy(h->d_target, p->target, (size_t)K * N * 16, hipMemcpyHostToDevice));
+    {   // concurrent sweeps (see SweepArgs::unit_chi)
+        const char *env = getenv("GRAPE_FUSED_SWEEPS");
+        const bool have_gb = p->Dpen && p->lambda_b != 0.0;
+        h->fuse = !h->large && !have_gb && !(env && atoi(env) == 0);
+        std::vector<double> itn(K), ones(K, 1.0);
+        for (int k = 0; k < K; ++k) {
+            double n2 = 0.0;
+            for (int i = 0; i < 2 * N; ++i) n2 += p->target[(size_t)k * 2 * N + i] * p->target[(size_t)k * 2 * N + i];
+            itn[k] = n2 > 0.0 ? 1.0 / std::sqrt(n2) : 0.0;
+            if (!(n2 > 0.0)) h->fuse = false;   // a zero target has no direction: the sequential path reports the chi norm
+        }
+        CCHK(dmalloc(&h->d_inv_tnorm, (size_t)K)); CCHK(dmalloc(&h->d_ones, (size_t)K)); CCHK(dmalloc(&h->d_z, (size_t)K));
+        CCHK(hipMemcpy(h->d_inv_tnorm, itn.data(), (size_t)K * 8, hipMemcpyHostToDevice));
+        CCHK(hipMemcpy(h->d_ones, ones.data(), (size_t)K * 8, hipMemcpyHostToDevice));
+    }
 
     // ---- per-evaluation buffers ----
     CCHK(dmalloc(&h->d_eps, (size_t)L * N_T));
-    CCHK(dmalloc(&h->d_U, (size_t)h->KC * N_T * pp));
+    if (!h->series) CCHK(dmalloc(&h->d_U, (size_t)h->KC * N_T * pp));
+    if (h->series) {
+        std::vector<double> rb((size_t)K + (size_t)Kc * L);
+        for (int k = 0; k < K; ++k) rb[k] = norm2_estimate(p->H0 + 2 * (size_t)k * nn, N);
+        for (int kl = 0; kl < Kc * L; ++kl) rb[K + kl] = norm2_estimate(p->Hc + 2 * (size_t)kl * nn, N);
+        CCHK(dmalloc(&h->d_rb, rb.size()));
+        CCHK(hipMemcpy(h->d_rb, rb.data(), rb.size() * 8, hipMemcpyHostToDevice));
+        const char *env = getenv("GRAPE_SERIES_THETA");
+        if (env && atof(env) > 0) h->series_theta = atof(env);
+    }
     CCHK(dmalloc(&h->d_fw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_bw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_tg, (size_t)K * L * N_T));
@@ -718,19 +853,21 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     ea.stamps = d_stamps;
     hipMemcpyToSymbolAsync(HIP_SYMBOL(g_diag_slot_base), &d_stamps, sizeof(d_stamps), 0, hipMemcpyHostToDevice, s);
 #endif
-    phase_begin(h, 0, s);
-    hipError_t e;
-    if (h->large) {
-        e = expm_large(h, s);
-    } else {
-        switch (h->NT) {
-            case 1: e = launch_expm<1>(ea, h->herm, s); break;
-            case 2: e = launch_expm<2>(ea, h->herm, s); break;
-            default: e = launch_expm<4>(ea, h->herm, s); break;
+    hipError_t e = hipSuccess;
+    if (!h->series) {
+        phase_begin(h, 0, s);
+        if (h->large) {
+            e = expm_large(h, s);
+        } else {
+            switch (h->NT) {
+                case 1: e = launch_expm<1>(ea, h->herm, s); break;
+                case 2: e = launch_expm<2>(ea, h->herm, s); break;
+                default: e = launch_expm<4>(ea, h->herm, s); break;
+            }
         }
+        HIPCHK(h, e);
+        phase_end(h, 0, s);
     }
-    HIPCHK(h, e);
-    phase_end(h, 0, s);
 #ifdef GRAPE_DIAG
     if (ea.stamps) {
         hipStreamSynchronize(s);
@@ -757,6 +894,25 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
     phase_begin(h, 1, s);
+    const bool pair = h->fuse && h->fuse_on && h->want_bw;
+    h->bw_done = h->bw_unit = pair;
+    if (pair) {
+        // backward sweep from the unit targets in the same launch: K more workgroups on the other CUs
+        SweepArgs sb = sa;
+        sb.store = h->d_bw; sb.tau = (double2 *)h->d_out; sb.f = nullptr; sb.unit_chi = 1; sb.inv_tnorm = h->d_inv_tnorm;
+        if (h->series) {
+            const SeriesArgs rf = series_args(h, sa, false), rb = series_args(h, sb, true);
+            e = h->NP == 16 ? launch_series_pair<16>(rf, rb, s) : h->NP == 32 ? launch_series_pair<32>(rf, rb, s)
+                                                                             : launch_series_pair<64>(rf, rb, s);
+        } else {
+            e = h->NP == 16 ? launch_sweep_pair<16>(sa, sb, s) : h->NP == 32 ? launch_sweep_pair<32>(sa, sb, s)
+                                                                            : launch_sweep_pair<64>(sa, sb, s);
+        }
+    } else if (h->series) {
+        const SeriesArgs ra = series_args(h, sa, false);
+        e = h->NP == 16 ? launch_series<16>(ra, false, s) : h->NP == 32 ? launch_series<32>(ra, false, s)
+                                                                       : launch_series<64>(ra, false, s);
+    } else
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, false, s); break;
         case 32: e = launch_sweep<32>(sa, false, s); break;
@@ -805,6 +961,19 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
     phase_begin(h, 2, s);
+    const bool unit = h->bw_done;
+    h->bw_done = false;
+    if (unit) {
+        // the backward states are already there (unit targets): only rho_k and the factors z_k are left
+        ChiCoeffArgs ca{};
+        ca.s = sa; ca.s.inv_tnorm = h->d_inv_tnorm; ca.rho = h->d_rho; ca.z = h->d_z;
+        hipLaunchKernelGGL(chi_coeff_kernel, dim3((h->K + 63) / 64), dim3(64), 0, s, ca);
+        e = hipGetLastError();
+    } else if (h->series) {
+        const SeriesArgs ra = series_args(h, sa, true);
+        e = h->NP == 16 ? launch_series<16>(ra, true, s) : h->NP == 32 ? launch_series<32>(ra, true, s)
+                                                                      : launch_series<64>(ra, true, s);
+    } else
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, true, s); break;
         case 32: e = launch_sweep<32>(sa, true, s); break;
@@ -823,7 +992,7 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     // ---- phase 3: per-cell derivative overlaps ----
     DerivArgs da{};
     da.H0t = h->d_H0t; da.Hct = h->d_Hct; da.eps = h->d_eps; da.shape = h->d_shape; da.dts = h->d_dts;
-    da.fw = h->d_fw; da.bw = h->d_bw; da.rho = h->d_rho; da.tg = h->d_tg; da.flags = h->d_flags; da.stats = h->d_stats;
+    da.fw = h->d_fw; da.bw = h->d_bw; da.rho = unit ? h->d_ones : h->d_rho; da.tg = h->d_tg; da.flags = h->d_flags; da.stats = h->d_stats;
     da.K = h->K; da.L = h->L; da.N_T = h->N_T; da.hc_per_traj = h->p.hc_per_traj;
     da.max_order = h->taylor_max_order; da.tol = h->taylor_tol;
     // enough blocks to fill 256 CUs a few times over, but long runs per block to amortise the tile loads
@@ -836,7 +1005,7 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
         Deriv2Args d2{};
         d2.H0p = h->d_H0p; d2.Hcp = h->d_Hcp; d2.H0q = h->d_H0q; d2.Hcq = h->d_Hcq;
         d2.eps = h->d_eps; d2.shape = h->d_shape; d2.dts = h->d_dts;
-        d2.fw = h->d_fw; d2.bw = h->d_bw; d2.rho = h->d_rho; d2.tg = h->d_tg; d2.park = h->d_park2;
+        d2.fw = h->d_fw; d2.bw = h->d_bw; d2.rho = unit ? h->d_ones : h->d_rho; d2.tg = h->d_tg; d2.park = h->d_park2;
         d2.flags = h->d_flags; d2.stats = h->d_stats;
         d2.K = h->K; d2.L = h->L; d2.N_T = h->N_T; d2.hc_per_traj = h->p.hc_per_traj;
         d2.max_order = h->taylor_max_order; d2.maxm = h->deriv2_maxm; d2.tol = h->taylor_tol;
@@ -846,7 +1015,7 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     } else if (h->NP >= 64) {
         DerivMfmaArgs dm{};
         dm.H0p = h->d_H0p; dm.Hcp = h->d_Hcp; dm.eps = h->d_eps; dm.shape = h->d_shape; dm.dts = h->d_dts;
-        dm.fw = h->d_fw; dm.bw = h->d_bw; dm.rho = h->d_rho; dm.tg = h->d_tg; dm.vecs = h->d_vecs;
+        dm.fw = h->d_fw; dm.bw = h->d_bw; dm.rho = unit ? h->d_ones : h->d_rho; dm.tg = h->d_tg; dm.vecs = h->d_vecs;
         dm.flags = h->d_flags; dm.stats = h->d_stats;
         dm.K = h->K; dm.L = h->L; dm.N_T = h->N_T; dm.hc_per_traj = h->p.hc_per_traj;
         dm.max_order = h->taylor_max_order; dm.tol = h->taylor_tol;
@@ -864,11 +1033,18 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     // ---- phase 4: sum over trajectories ----
     phase_begin(h, 4, s);
     const int LN = h->L * h->N_T;
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((LN + 255) / 256), dim3(256), 0, s, (const double2 *)h->d_tg, h->K, LN, d_G);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((LN + 255) / 256), dim3(256), 0, s, h->d_tg, h->K, LN, d_G,
+                       unit ? (const double2 *)h->d_z : (const double2 *)nullptr);
     HIPCHK(h, hipGetLastError());
     phase_end(h, 4, s);
     h->n_bwd++;
     return GRAPE_OK;
+}
+
+int grape_set_fused_sweeps(grape_handle *h, int on) {
+    if (!h) return GRAPE_ERR_INVALID;
+    h->fuse_on = on != 0;
+    return (h->fuse && h->fuse_on) ? 1 : 0;
 }
 
 int grape_check(grape_handle *h, void *stream_) {
@@ -916,7 +1092,9 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
     }
     phase_begin(h, 5, h->stream);
     h->in_eval = true;  // keep the forward slot open until the whole evaluation has been recorded
+    h->want_bw = G != nullptr;   // functional only: no backward sweep alongside the forward one
     int rc = grape_forward(h, pulsevals, tau);
+    h->want_bw = true;
     h->in_eval = false;
     if (rc) { h->n_fwd++; return rc; }
     const size_t nl = (size_t)h->L * h->N_T;
@@ -955,12 +1133,28 @@ int grape_get_storage(grape_handle *h, int which, double *out) {
     const double2 *src = which == 0 ? h->d_fw : h->d_bw;
     HIPCHK(h, hipMemcpy2D(out, (size_t)h->N * 16, src, (size_t)h->NP * 16, (size_t)h->N * 16,
                           (size_t)h->K * (h->N_T + 1), hipMemcpyDeviceToHost));
+    if (which == 1 && h->bw_unit) {
+        // concurrent sweeps stored chi~_k(t_n); chi_k(t_n) = (c_k / |c_k|) chi~_k(t_n) with z_k = conj(c_k) ||target_k||
+        std::vector<double> z(2 * (size_t)h->K);
+        HIPCHK(h, hipMemcpy(z.data(), h->d_z, z.size() * 8, hipMemcpyDeviceToHost));
+        for (int k = 0; k < h->K; ++k) {
+            const double a = std::hypot(z[2 * k], z[2 * k + 1]);
+            const double pr = a > 0 ? z[2 * k] / a : 1.0, pi = a > 0 ? -z[2 * k + 1] / a : 0.0;
+            double *o = out + (size_t)k * (h->N_T + 1) * h->N * 2;
+            for (size_t j = 0; j < (size_t)(h->N_T + 1) * h->N; ++j) {
+                const double xr = o[2 * j], xi = o[2 * j + 1];
+                o[2 * j] = pr * xr - pi * xi;
+                o[2 * j + 1] = pr * xi + pi * xr;
+            }
+        }
+    }
     return GRAPE_OK;
 }
 
 int grape_get_propagator(grape_handle *h, int k, int n, double *out) {
     // U_kn as N x N column-major complex (debug / parity of the expm kernel)
     if (!h || !out || k < 0 || k >= h->K || n < 0 || n >= h->N_T) return GRAPE_ERR_INVALID;
+    if (h->series) { h->err = "prop_method = GRAPE_PROP_SERIES is matrix-free: no propagator is materialised"; return GRAPE_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     const size_t pp = (size_t)h->NP * h->NP;
@@ -1019,7 +1213,9 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     out[3] = (double)st[8] * (1.0 + 2.0 * h->L) * 8.0 * N2;
     if (n > 4) out[4] = (double)st[8];  // sum of series orders
     if (n > 5) out[5] = (double)st[9];  // cells solved by the pivoted fallback
-    if (n > 6) out[6] = ecells;          // propagators actually exponentiated (generator classes x time steps)
+    if (n > 6) out[6] = h->series ? 0.0 : ecells;   // propagators actually exponentiated (generator classes x time steps)
+    if (n > 7) out[7] = (double)st[10];  // matrix-free propagator: series terms summed over both sweeps
+    if (n > 8) out[8] = (double)st[11];  // ... and (sub-)steps
     return 4;
 }
 

@@ -1297,7 +1297,44 @@ struct SweepArgs {
     const double2 *xi;    // [K][N_T+1][NP]
     const double *wq;     // [N_T+1]
     double lambda_b;
+    // unit_chi: the backward sweep starts from target_k / ||target_k|| instead of chi_k(T) = c_k target_k, so that it
+    // does not depend on the forward sweep (both run concurrently); the recursion is linear in chi, and
+    // chi_coeff_kernel supplies z_k = rho_k conj(c_k / |c_k|) afterwards (tau_grads, gradient) -- only without the
+    // xi inhomogeneity of the state running cost
+    const double *inv_tnorm;   // [K] 1 / ||target_k||
+    int unit_chi;
 };
+
+// c_k of chi_k(T) = c_k target_k for the three functionals (docs/src/tutorial.md:349-356, 402)
+__device__ __forceinline__ void chi_coefficient(const SweepArgs &a, const int k, double &cr, double &ci) {
+    if (a.unit_chi) { cr = a.inv_tnorm[k]; ci = 0.; return; }
+    const double w = a.weights ? a.weights[k] : 1.0;
+    const double Kt = (double)a.K_total;
+    if (a.functional == 0) { cr = w * a.f[0] / (Kt * Kt); ci = w * a.f[1] / (Kt * Kt); }
+    else if (a.functional == 1) { const double2 t = a.tau[k]; cr = w * t.x / Kt; ci = w * t.y / Kt; }
+    else { cr = w / (2.0 * Kt); ci = 0.; }
+}
+
+// after concurrent sweeps: true rho_k = |c_k| ||target_k|| (optimize.jl:867-868, guard :1021-1025) and
+// z_k = conj(c_k) ||target_k||, the factor that turns <chi~'_l|Psi> of the unit backward states into tau_grads
+struct ChiCoeffArgs {
+    SweepArgs s;      // weights, tau, f, functional, K_total, flags, chi_min_norm, inv_tnorm
+    double *rho;      // [K]
+    double2 *z;       // [K]
+};
+__global__ void chi_coeff_kernel(ChiCoeffArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.s.K) return;
+    SweepArgs s = a.s;
+    s.unit_chi = 0;
+    double cr, ci;
+    chi_coefficient(s, k, cr, ci);
+    const double tn = 1.0 / a.s.inv_tnorm[k];
+    const double rho = sqrt(cr * cr + ci * ci) * tn;
+    a.rho[k] = rho;
+    a.z[k] = make_double2(cr * tn, -ci * tn);
+    if (rho < a.s.chi_min_norm) atomicOr(&a.s.flags[0], 2);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -1320,12 +1357,12 @@ __device__ __forceinline__ void rs_step(double (&pr)[RWT], double (&pi)[RWT], in
 }
 
 template <int NP, bool BACKWARD>
-__global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
+__device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
     constexpr int NW = 4, RW = NP / NW;  // rows per wave (NP = 16 -> 4)
     __shared__ double2 x[2][NP];      // state ping-pong
     __shared__ double2 part[NW][NP];  // cross-wave partials (backward)
     __shared__ double sc[4];
-    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
     double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
 
@@ -1338,12 +1375,8 @@ __global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
         }
     } else {
         // chi_k(T) = coeff_k * target_k, rho_k = ||chi_k||, chi_k /= rho_k (optimize.jl:848-868)
-        const double w = a.weights ? a.weights[k] : 1.0;
-        const double Kt = (double)a.K_total;
         double cr, ci;
-        if (a.functional == 0) { cr = w * a.f[0] / (Kt * Kt); ci = w * a.f[1] / (Kt * Kt); }
-        else if (a.functional == 1) { double2 t = a.tau[k]; cr = w * t.x / Kt; ci = w * t.y / Kt; }
-        else { cr = w / (2.0 * Kt); ci = 0.; }
+        chi_coefficient(a, k, cr, ci);
         double2 v = make_double2(0., 0.);
         if (tid < a.N) {
             double2 t = a.target[(size_t)k * a.N + tid];
@@ -1360,7 +1393,7 @@ __global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
         }
         __syncthreads();
         const double rho = sc[0];
-        if (tid == 0) {
+        if (tid == 0 && !a.unit_chi) {
             a.rho[k] = rho;
             if (rho < a.chi_min_norm) atomicOr(&a.flags[0], 2);
         }
@@ -1470,6 +1503,19 @@ __global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
             if (lane == 0) a.tau[k] = make_double2(pr, pi);
         }
     }
+}
+
+template <int NP, bool BACKWARD>
+__global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
+    sweep_body<NP, BACKWARD>(a, blockIdx.x);
+}
+
+// Both sweeps in one launch (blocks [0, K): forward, [K, 2K): backward with unit_chi, see SweepArgs): with one
+// workgroup per trajectory a sweep occupies K of the 256 CUs, and the backward recursion is linear in chi.
+template <int NP>
+__global__ void __launch_bounds__(256) sweep_pair_kernel(SweepArgs af, SweepArgs ab) {
+    if ((int)blockIdx.x < af.K) sweep_body<NP, false>(af, blockIdx.x);
+    else sweep_body<NP, true>(ab, blockIdx.x - af.K);
 }
 
 // tau partial sums of this shard: out[0..1] = sum w tau, out[2] = sum w |tau|^2, out[3] = Re sum w tau
@@ -2269,10 +2315,20 @@ __global__ void __launch_bounds__(256) jb_reduce_kernel(const double *gb, const 
 // ---------------------------------------------------------------------------------------
 // Kernel 6: G[l*N_T + n] = -2 Re sum_k tau_grads[k][l][n]   (_grad_J_T_via_chi!, optimize.jl:574-584)
 // ---------------------------------------------------------------------------------------
-__global__ void grad_reduce_kernel(const double2 *tg, int K, int LN, double *G) {
+__global__ void grad_reduce_kernel(double2 *tg, int K, int LN, double *G, const double2 *z) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= LN) return;
     double s = 0.;
-    for (int k = 0; k < K; ++k) s += tg[(size_t)k * LN + idx].x;
+    if (z) {
+        // concurrent sweeps: the derivative kernels saw the unit backward states; tau_grads = z_k <chi~'_l|Psi>
+        for (int k = 0; k < K; ++k) {
+            const double2 t = tg[(size_t)k * LN + idx], zk = z[k];
+            const double2 v = make_double2(zk.x * t.x - zk.y * t.y, zk.x * t.y + zk.y * t.x);
+            tg[(size_t)k * LN + idx] = v;
+            s += v.x;
+        }
+    } else {
+        for (int k = 0; k < K; ++k) s += tg[(size_t)k * LN + idx].x;
+    }
     G[idx] = -2.0 * s;
 }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_HIP_ABI_VERSION 2
+#define GRAPE_HIP_ABI_VERSION 3
 
 typedef struct grape_handle grape_handle;
 
@@ -63,6 +63,14 @@ typedef enum {
     GRAPE_GRAD_GRADGEN = 0, /* exact derivative of exp (what the gradient generator yields)  */
     GRAPE_GRAD_TAYLOR = 1   /* Kuprov-Rodgers recursion, taylor_grad_step! (optimize.jl:604) */
 } grape_gradient_method;
+
+/* prop_method keyword of the reference (workspace.jl:222-232 -> QuantumPropagators.init_prop) */
+typedef enum {
+    GRAPE_PROP_EXP = 0,    /* ExpProp: U_n = exp(-i H_n dt_n) materialised (Pade scaling and squaring on MFMA) */
+    GRAPE_PROP_SERIES = 1  /* matrix-free polynomial propagator on the state vector (the role of the reference's
+                              Cheby / Newton methods, README.md:55): power series of exp(-i H_n dt_n) Psi summed to
+                              prop_tolerance, O(N^2) per term, no U; N <= 64                                      */
+} grape_prop_method;
 
 typedef struct {
     int32_t abi_version;     /* GRAPE_HIP_ABI_VERSION                                           */
@@ -92,6 +100,8 @@ typedef struct {
     const double *Dpen;      /* NULL, [N*N] (shared) or [K][N*N] complex Hermitian, column-major */
     int32_t dpen_per_traj;   /* 0: one D for all trajectories; 1: one per trajectory            */
     double lambda_b;
+    int32_t prop_method;     /* grape_prop_method (ABI v3)                                      */
+    double prop_tolerance;   /* GRAPE_PROP_SERIES: stop at ||term|| < tol ||state||; <= 0 selects 1e-17 */
 } grape_problem;
 
 /* Replaces GrapeWrk(...) data set-up: /root/reference/src/workspace.jl:147-362 */
@@ -132,6 +142,15 @@ int grape_backward(grape_handle *h, const double f_total[2], double *G_partial);
 int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_out, void *stream);
 int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void *stream);
 
+/* Concurrent sweeps.  With one workgroup per trajectory a sweep occupies K of the 256 CUs, and the backward
+ * recursion chi_{n-1} = U_n^dagger chi_n (optimize.jl:881) is linear in chi; so, unless the state running cost adds its
+ * inhomogeneity, grape_forward[_device] also runs the backward sweep, from the unit targets, in the same launch, and
+ * grape_backward[_device] only applies the boundary coefficient of chi_k(T) = c_k target_k (docs/src/tutorial.md:402)
+ * to the overlaps.  Results are identical to rounding.  on = 0 restores the sequential order (a caller that only wants
+ * tau from the split-phase API should do that; grape_eval with G == NULL never runs the backward sweep).  Returns 1 if
+ * the concurrent path is active for this handle afterwards, 0 if not.  Default: on (env GRAPE_FUSED_SWEEPS=0: off). */
+int grape_set_fused_sweeps(grape_handle *h, int on);
+
 /* Synchronise `stream` and translate the device-side error flags of the evaluation in flight
  * (singular Pade denominator, chi norm guard, series non-convergence) into a grape_status. */
 int grape_check(grape_handle *h, void *stream);
@@ -154,7 +173,9 @@ int grape_get_storage(grape_handle *h, int which /*0 fw, 1 bw*/, double *out /* 
 int grape_get_timings(grape_handle *h, double *ms, int n);
 int grape_reset_timings(grape_handle *h);
 /* Algorithmic work of the last evaluation: [0] cells, [1] sum of squarings s over cells,
- * [2] flop of the expm kernel (SURVEY 8d F_exp), [3] flop of the derivative kernel. */
+ * [2] flop of the expm kernel (SURVEY 8d F_exp), [3] flop of the derivative kernel, [4] derivative series orders,
+ * [5] cells solved by the pivoted fallback, [6] propagators exponentiated, [7] terms and [8] (sub-)steps of the
+ * matrix-free propagator (entries beyond n are not written). */
 int grape_get_work(grape_handle *h, double *out, int n);
 
 const char *grape_last_error(grape_handle *h); /* h may be NULL: error of the last failed create */

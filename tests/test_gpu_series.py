@@ -1,0 +1,174 @@
+"""Matrix-free propagator (prop_method = PROP_SERIES) through the C ABI -- needs an MI355X.
+
+The reference selects the short-time propagator with `prop_method` (src/workspace.jl:222-232); its polynomial
+methods (Cheby / Newton, README.md:55) apply a polynomial of H_n to the state instead of forming exp(-i H_n dt).
+PROP_SERIES is that family here (power series summed to rounding), so its results must agree with the oracle's
+exact exponential at the same bar as the ExpProp path:
+    |dJ| <= 1e-12,   |dtau_k| <= 1e-12,   ||dG||_inf <= 1e-10 * max(||G||_inf, 1e-3)
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_J = 1e-12
+TOL_TAU = 1e-12
+
+
+def tol_G(Gref):
+    return 1e-10 * max(np.abs(Gref).max(), 1e-3)
+
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def g():
+    import grape_jl_amd as mod
+    assert os.path.exists(mod.library_path()), "HIP extension missing: the product path has no fallback"
+    return mod
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+@pytest.mark.parametrize("method", [0, 1], ids=["gradgen", "taylor"])
+def test_golden_fixtures_series(g, path, method):
+    z = np.load(path)
+    with g.GrapeHip(z["H0"], z["Hc"], z["tlist"], z["psi0"], z["target"], z["weights"], functional=int(z["functional"]),
+                    gradient_method=method, prop_method=g.PROP_SERIES) as h:
+        J, G, tau, psiT = h.eval(z["pulsevals"], want_psiT=True)
+        tg = h.tau_grads()
+    assert abs(J - z["J"]) <= TOL_J
+    assert np.abs(tau - z["tau"]).max() <= TOL_TAU
+    assert np.abs(G - z["G"]).max() <= tol_G(z["G"])
+    assert np.abs(psiT - z["psiT"]).max() <= 1e-12
+    assert np.abs(tg - z["tau_grads"]).max() <= 1e-12
+
+
+CASES = [  # N, L, N_T, K, dt, hermitian, functional
+    (2, 1, 40, 1, 0.01, True, 0),
+    (3, 2, 9, 2, 0.2, False, 1),      # ragged N, non-Hermitian: the backward sweep uses H^dagger
+    (16, 1, 25, 4, 1.0, True, 0),     # C2-like
+    (17, 2, 6, 2, 1.0, False, 2),     # pads to 32
+    (32, 4, 5, 3, 1.0, True, 0),      # L = 4: control tiles streamed from L2
+    (33, 1, 4, 2, 1.0, True, 1),      # pads to 64
+    (48, 2, 4, 2, 1.0, True, 0),
+    (64, 2, 8, 3, 1.0, True, 0),      # C3-like
+    (64, 2, 4, 2, 4.0, True, 1),      # ||H dt|| large: sub-steps
+    (64, 3, 4, 2, 9.0, False, 2),     # non-Hermitian, many sub-steps
+    (64, 6, 3, 1, 1.0, True, 0),      # L = 6
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"N{c[0]}_L{c[1]}_dt{c[4]}_{'h' if c[5] else 'nh'}_f{c[6]}" for c in CASES])
+def test_series_propagator_vs_c_oracle_and_expprop(g, ref, case):
+    from grape_jl_amd import synth
+    N, L, N_T, K, dt, herm, f = case
+    pr = synth.make_problem(N, L, N_T, K, seed=1000 + N + L, dt=dt, hermitian=herm)
+    pr["weights"] = 0.5 + np.arange(K) * 0.25
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args, functional=f, prop_method=g.PROP_SERIES) as h:
+        J, G, tau, psiT = h.eval(pr["pulsevals"], want_psiT=True)
+        tg, fw, bw, w = h.tau_grads(), h.storage(0), h.storage(1), h.work()
+        with pytest.raises(g.GrapeHipError):     # nothing is materialised in this mode
+            h.propagator(0, 0)
+    Jr, Gr, taur, parts = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], functional=f,
+                                       gradient_method=ref.GRADGEN, want_parts=True)
+    assert abs(J - Jr) <= TOL_J
+    assert np.abs(tau - taur).max() <= TOL_TAU
+    assert np.abs(G - Gr).max() <= tol_G(Gr)
+    assert np.abs(psiT - parts["psiT"]).max() <= 1e-12
+    assert np.abs(tg - parts["tau_grads"]).max() <= 1e-10 * max(np.abs(parts["tau_grads"]).max(), 1e-3)
+    assert w["series_steps"] >= 2 * K * N_T and w["series_terms"] > w["series_steps"]
+    # stored forward / backward states agree with the ExpProp path of the same library
+    with g.GrapeHip(*args, functional=f) as h:
+        h.eval(pr["pulsevals"])
+        assert np.abs(h.storage(0) - fw).max() <= 1e-12
+        assert np.abs(h.storage(1) - bw).max() <= 1e-12
+
+
+@pytest.mark.parametrize("N,L,per_traj,functional", [(6, 2, False, 0), (16, 1, True, 2), (64, 2, False, 0)])
+def test_series_state_running_cost(g, ref, N, L, per_traj, functional):
+    """The xi inhomogeneity of the backward recursion (optimize.jl:856-866, 897-908) in the matrix-free sweep."""
+    from grape_jl_amd import synth
+    K, N_T, lam = 3, 7, 0.5
+    pr = synth.make_problem(N, L, N_T, K, seed=500 + N, hermitian=(N != 6))
+    pr["tlist"] = np.cumsum(np.concatenate([[0.0], 0.8 + 0.05 * np.arange(N_T)]))   # non-uniform grid
+    rng = np.random.default_rng(N)
+
+    def penalty():
+        A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        return A @ A.conj().T / N
+    D = np.stack([penalty() for _ in range(K)]) if per_traj else penalty()
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], functional=functional,
+                    D=D, lambda_b=lam, prop_method=g.PROP_SERIES) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                functional=functional, gradient_method=ref.TAYLOR, D=D, lambda_b=lam)
+    assert abs(J - Jr) <= 1e-12 * max(1.0, abs(Jr))
+    assert np.abs(tau - taur).max() <= TOL_TAU
+    assert np.abs(G - Gr).max() <= tol_G(Gr)
+
+
+def test_series_shaped_amplitudes_per_trajectory_controls_and_shards(g):
+    import grape_oracle as go
+    from grape_jl_amd import synth
+    N, L, N_T, K = 20, 2, 12, 4
+    pr = synth.make_problem(N, L, N_T, K, seed=77, hermitian=True)
+    rng = np.random.default_rng(5)
+    Hc = np.stack([pr["Hc"] * (1.0 + 0.1 * k) for k in range(K)])          # [K, L, N, N]
+    shape = 0.5 + rng.random((L, N_T))
+    with g.GrapeHip(pr["H0"], Hc, pr["tlist"], pr["psi0"], pr["target"], pr["weights"], shape=shape,
+                    prop_method=g.PROP_SERIES) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+    Jr, Gr, taur = go.evaluate_gradient(pr["H0"], Hc, pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                                        pr["weights"], shape=shape)
+    assert abs(J - Jr) <= TOL_J and np.abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr)
+    # two shards (split-phase ABI) add up to the single handle
+    hs = [g.GrapeHip(pr["H0"][s], Hc[s], pr["tlist"], pr["psi0"][s], pr["target"][s], pr["weights"][s], shape=shape,
+                     K_total=K, prop_method=g.PROP_SERIES) for s in (slice(0, 1), slice(1, 4))]
+    taus = [h.forward(pr["pulsevals"]) for h in hs]
+    f = sum((pr["weights"][s] * t).sum() for s, t in zip((slice(0, 1), slice(1, 4)), taus))
+    Gs = sum(h.backward(f) for h in hs)
+    for h in hs:
+        h.close()
+    assert np.abs(Gs - G).max() <= 1e-13
+
+
+def test_series_rejects_large_n(g):
+    from grape_jl_amd import synth
+    pr = synth.make_problem(65, 1, 2, 1, seed=1)
+    with pytest.raises(g.GrapeHipError):
+        g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], prop_method=g.PROP_SERIES)
+
+
+@pytest.mark.parametrize("prop", [0, 1], ids=["exp", "series"])
+@pytest.mark.parametrize("functional", [0, 1, 2])
+def test_concurrent_sweeps_equal_sequential_sweeps(g, ref, prop, functional):
+    """Forward and backward sweep in one launch (backward from the unit targets, boundary coefficient applied to the
+    overlaps afterwards; include/grape_hip.h: grape_set_fused_sweeps) against the sequential order of
+    optimize.jl:824-911, and both against the oracle -- gradient, tau_grads and the stored chi states."""
+    from grape_jl_amd import synth
+    N, L, N_T, K = 24, 2, 9, 5
+    pr = synth.make_problem(N, L, N_T, K, seed=31 + functional, hermitian=(functional != 1))
+    pr["weights"] = 0.5 + 0.3 * np.arange(K)
+    pr["target"] = pr["target"] * (1.0 + 0.5 * np.arange(K))[:, None]     # unnormalised targets: ||target_k|| enters rho_k
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    out = []
+    for fused in (True, False):
+        with g.GrapeHip(*args, functional=functional, prop_method=prop) as h:
+            assert h.set_fused_sweeps(fused) == fused
+            J, G, tau = h.eval(pr["pulsevals"])
+            out.append((J, G, tau, h.tau_grads(), h.storage(1)))
+            Jf = h.eval(pr["pulsevals"], gradient=False)[0]       # functional only: no backward sweep at all
+            assert Jf == J
+    Jr, Gr, taur, parts = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], functional=functional,
+                                       gradient_method=ref.GRADGEN, want_parts=True)
+    for J, G, tau, tg, bw in out:
+        assert abs(J - Jr) <= TOL_J and np.abs(tau - taur).max() <= TOL_TAU
+        assert np.abs(G - Gr).max() <= tol_G(Gr)
+        assert np.abs(tg - parts["tau_grads"]).max() <= 1e-10 * max(np.abs(parts["tau_grads"]).max(), 1e-3)
+    assert np.abs(out[0][4] - out[1][4]).max() <= 1e-13      # chi_k(t_n): phase restored by the storage getter
+    assert np.abs(out[0][3] - out[1][3]).max() <= 1e-13 * max(1.0, np.abs(out[1][3]).max())
