@@ -59,10 +59,24 @@ def cpu_baseline(pr, handle_eval, target_seconds=15.0):
                   Gmax=float(np.abs(ref[1]).max()))
     ok = (parity["dJ"] <= 1e-12 and parity["dtau"] <= 1e-12
           and parity["dG"] <= 1e-10 * max(parity["Gmax"], 1e-3))
+    # the structure-exploiting CPU variant (N x N exponential + Taylor recursion on vectors, the reference's
+    # gradient_method = :taylor) on the same sample, so that the GPU/CPU ratio is not inflated by the (L+1)^3
+    # redundancy of the literal route
+    t0 = time.perf_counter()
+    grape_ref.evaluate(pr["H0"][sl], pr["Hc"], tl, x, pr["psi0"][sl], pr["target"][sl], pr["weights"][sl],
+                       gradient_method=grape_ref.TAYLOR, nthreads=threads)
+    t_tay = time.perf_counter() - t0
     return dict(value=evals_per_s, unit="evals/s", cores=threads, kind="port",
                 sample=f"{K_s} trajectories x {n_s} time steps of the same inputs ({cells_sample} of {cells_full} "
                        f"cells, {t:.1f} s), literal :gradgen route, scaled linearly in cells",
-                parity_ok=bool(ok), parity=parity)
+                parity_ok=bool(ok), parity=parity,
+                structured_variant=dict(value=1.0 / (t_tay * cells_full / cells_sample), unit="evals/s",
+                                        route=":taylor (N x N exp + vector recursion), same sample and threads"))
+
+
+def g_eval_host(h, x):
+    """One host-pointer evaluation of an (unsharded) handle: (J, G, tau)."""
+    return h.eval(x)
 
 
 def main():
@@ -73,6 +87,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--traj-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-matrix-free", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -180,6 +195,28 @@ def main():
                              "series_orders_per_cell": work["deriv_orders"] / work["cells"]},
             "J": J,
         }
+        if not args.no_matrix_free and N <= 64 and world == 1:
+            # secondary line, NOT `value`: the same evaluation with prop_method = GRAPE_PROP_SERIES (matrix-free
+            # polynomial propagator, the role of the reference's Cheby/Newton methods), rank 0's shard only
+            hm = g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"],
+                            functional=g.J_T_SM, gradient_method=g.GRAD_GRADGEN, device=dev.index,
+                            prop_method=g.PROP_SERIES)
+            xh = pr["pulsevals"]
+            Jm, Gm, _ = hm.eval(xh)
+            Je, Ge, _ = g_eval_host(h, xh)
+            hm.reset_timings()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                hm.eval(xh)
+            tm_mf = (time.perf_counter() - t1) / args.steps
+            wm = hm.work()
+            res["matrix_free"] = {"prop_method": "GRAPE_PROP_SERIES", "evals_per_s": 1.0 / tm_mf, "ms_per_eval": tm_mf * 1e3,
+                                  "phases_ms": {k: round(v, 4) for k, v in hm.timings().items() if v >= 0},
+                                  "series_terms_per_step": wm["series_terms"] / max(wm["series_steps"], 1.0),
+                                  "dJ_vs_expprop": abs(Jm - Je), "dG_vs_expprop": float(np.abs(Gm - Ge).max()),
+                                  "note": "host-pointer grape_eval (16 KB H2D + D2H per call included); secondary, "
+                                          "not the headline metric"}
+            hm.close()
         if not args.no_cpu_baseline:
             def hip_sample(sl, tl, xs):
                 hs = g.GrapeHip(pr["H0"][sl], pr["Hc"], tl, pr["psi0"][sl], pr["target"][sl], pr["weights"][sl],

@@ -218,8 +218,17 @@ class GrapeWrk:
             self.kwargs.get("gradient_method", "gradgen"))
         if method is None:
             raise ValueError(f"Invalid gradient_method={self.kwargs.get('gradient_method')!r} not in (gradgen, taylor)")
+        # prop_method keyword of the reference (src/workspace.jl:222-232): ExpProp materialises the propagators;
+        # the polynomial methods (Cheby / Newton, README.md:55) are served by the matrix-free series kernel
+        pm = self.kwargs.get("prop_method", "ExpProp")
+        pm = getattr(pm, "__name__", pm)
+        prop = {"expprop": api.PROP_EXP, "exp": api.PROP_EXP, "cheby": api.PROP_SERIES, "newton": api.PROP_SERIES,
+                "series": api.PROP_SERIES}.get(str(pm).lower().lstrip(":"))
+        if prop is None:
+            raise ValueError(f"prop_method={pm!r} not in (ExpProp, Cheby, Newton, series)")
         return api.GrapeHip(H0, Hc, self.tlist, np.stack([t.initial_state for t in trajs]),
                             np.stack([t.target_state for t in trajs]),
+                            prop_method=prop, prop_tolerance=self.kwargs.get("prop_tolerance", 0.0),
                             weights=np.array([t.weight for t in trajs], dtype=np.float64),
                             functional=_FUNCTIONAL_CODE[J_T], gradient_method=method,
                             chi_min_norm=self.kwargs.get("chi_min_norm", 0.0),

@@ -36,6 +36,8 @@ struct GrapeProblem
     Dpen::Ptr{ComplexF64}    # state running cost g_b = <Psi|D|Psi> (C_NULL = off)
     dpen_per_traj::Int32
     lambda_b::Float64
+    prop_method::Int32       # 0 = ExpProp (materialised Pade propagators), 1 = matrix-free series (Cheby/Newton role)
+    prop_tolerance::Float64  # <= 0: 1e-17
 end
 
 mutable struct Handle
@@ -58,14 +60,15 @@ Uploads the static problem (replaces the buffer set-up of GrapeWrk, src/workspac
 """
 function Handle(H0::Vector{Matrix{ComplexF64}}, Hc::Vector{Matrix{ComplexF64}}, tlist::Vector{Float64},
                 psi0::Vector{Vector{ComplexF64}}, target::Vector{Vector{ComplexF64}};
-                weights = ones(length(H0)), functional = 0, gradient_method = 0, device = 0, K_total = 0)
+                weights = ones(length(H0)), functional = 0, gradient_method = 0, device = 0, K_total = 0,
+                prop_method = 0)
     K, N, L = length(H0), size(H0[1], 1), length(Hc)
     H0f = reduce(hcat, vec.(H0)); Hcf = reduce(hcat, vec.(Hc))
     p0 = reduce(hcat, psi0); tg = reduce(hcat, target)
     keep = Any[H0f, Hcf, p0, tg, tlist, weights]
-    prob = Ref(GrapeProblem(2, N, L, K, K_total, length(tlist) - 1, functional, gradient_method, 0, device,
+    prob = Ref(GrapeProblem(3, N, L, K, K_total, length(tlist) - 1, functional, gradient_method, 0, device,
                             pointer(tlist), pointer(H0f), pointer(Hcf), C_NULL, pointer(p0), pointer(tg),
-                            pointer(weights), 0.0, 0, 0.0, C_NULL, 0, 0.0))
+                            pointer(weights), 0.0, 0, 0.0, C_NULL, 0, 0.0, prop_method, 0.0))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = GC.@preserve keep ccall((:grape_create, libgrape), Cint, (Ref{Ptr{Cvoid}}, Ref{GrapeProblem}), out, prob)
     h = Handle(out[], keep)

@@ -27,6 +27,12 @@ def test_tls_optimization_hip_backend():
     # taylor route reaches the same functional (test_tls_optimization.jl:204-233: |dJ_T| < 1e-10)
     res_t = G.optimize([traj], tlist, J_T=G.J_T_sm, iter_stop=5, gradient_method="taylor")
     assert abs(res.J_T - res_t.J_T) < 1e-10
+    # prop_method keyword (src/workspace.jl:222-232): the polynomial propagators map to the matrix-free series kernel
+    res_c = G.optimize([traj], tlist, J_T=G.J_T_sm, iter_stop=5, prop_method="Cheby")
+    assert abs(res.J_T - res_c.J_T) < 1e-10
+    assert np.abs(res.optimized_controls[0] - res_c.optimized_controls[0]).max() < 1e-8
+    with pytest.raises(ValueError):
+        G.optimize([traj], tlist, J_T=G.J_T_sm, iter_stop=1, prop_method="RK4")
 
 
 def test_readme_example_converges():

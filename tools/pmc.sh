@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 tag=${1:-r01}
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES"; do
   name=${pass%%:*}; ctrs=${pass#*:}
-  rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/pmc_${tag}_${name} -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${tag}_${name}.log 2>&1
+  rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/pmc_${tag}_${name} -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-matrix-free > gpurun_out/pmc_${tag}_${name}.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
