@@ -92,6 +92,9 @@ struct grape_handle {
     bool series = false;
     double *d_rb = nullptr;      // [K + Kc*L] 2-norm estimates of H0_k and of the control operators
     double series_tol = 1e-17, series_theta = 3.0;
+    double2 *d_gpark = nullptr;  // [K][N_T][maxp][NP] terms of the forward series, consumed by deriv2_kernel
+    int *d_morder = nullptr;     // [K][N_T]
+    int maxp = 0;
 };
 
 namespace {
@@ -479,6 +482,7 @@ SeriesArgs series_args(grape_handle *h, const SweepArgs &sa, bool backward) {
     ra.eps = h->d_eps; ra.shape = h->d_shape; ra.dts = h->d_dts; ra.rb = h->d_rb; ra.stats = h->d_stats;
     ra.tol = h->series_tol; ra.theta = h->series_theta;
     ra.L = h->L; ra.hc_per_traj = h->p.hc_per_traj; ra.max_order = 200;
+    if (!backward) { ra.park = h->d_gpark; ra.morder = h->d_morder; ra.maxp = h->maxp; }
     return ra;
 }
 
@@ -514,7 +518,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -771,6 +775,17 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         CCHK(hipMemcpy(h->d_rb, rb.data(), rb.size() * 8, hipMemcpyHostToDevice));
         const char *env = getenv("GRAPE_SERIES_THETA");
         if (env && atof(env) > 0) h->series_theta = atof(env);
+        // parked terms for the two-pass derivative kernel (N > 32, deriv2 on, series at least as tight as the
+        // derivative series, and the area fits a modest share of HBM)
+        const char *envp = getenv("GRAPE_SERIES_PARK");
+        const size_t bytes = (size_t)K * N_T * 32 * NP * 16;
+        if (NP >= 64 && h->deriv2 && h->series_tol <= h->taylor_tol && bytes <= ((size_t)24 << 30) &&
+            !(envp && atoi(envp) == 0)) {
+            h->maxp = 32;
+            CCHK(dmalloc(&h->d_gpark, (size_t)K * N_T * h->maxp * NP));
+            CCHK(dmalloc(&h->d_morder, (size_t)K * N_T));
+            CCHK(hipMemset(h->d_morder, 0xFF, (size_t)K * N_T * sizeof(int)));
+        }
     }
     CCHK(dmalloc(&h->d_fw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_bw, (size_t)K * (N_T + 1) * NP));
@@ -1011,6 +1026,7 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
         d2.max_order = h->taylor_max_order; d2.maxm = h->deriv2_maxm; d2.tol = h->taylor_tol;
         d2.batches_per_k = (h->N_T + 15) / 16;
         d2.nbatch_total = h->K * d2.batches_per_k;
+        if (h->series) { d2.gpark = h->d_gpark; d2.morder = h->d_morder; d2.maxp = h->maxp; }
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s);
     } else if (h->NP >= 64) {
         DerivMfmaArgs dm{};

@@ -2030,6 +2030,11 @@ struct Deriv2Args {
     unsigned long long *stats;
     int K, L, N_T, hc_per_traj, max_order, maxm, nbatch_total, batches_per_k;
     double tol;
+    // matrix-free propagator: the forward sweep already summed u_a = A^a Psi / a! for every cell and parked the
+    // terms (series_sweep_body); pass 1 is skipped for every batch whose 16 cells have a usable record
+    const double2 *gpark;      // nullptr or [K][N_T][maxp][NP]
+    const int *morder;         // [K][N_T] number of terms M of the cell (u_M below the tolerance), < 0: not usable
+    int maxp;
 };
 
 template <int NP, int LMAX, bool CACHE_A>
@@ -2121,6 +2126,22 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
             }
         };
 
+        // ---- terms already parked by the forward sweep? (same 16 cells in every wave: uniform decision) ----
+        int Mc = 0;
+        bool use_g = false;
+        const int mcap = a.max_order < a.maxm ? a.max_order : a.maxm;
+        if (a.gpark) {
+            Mc = valid ? a.morder[(size_t)k * a.N_T + n] : 0;
+            use_g = !__any(valid && (Mc < 2 || Mc > mcap));
+        }
+        int cur = 0, M = 0, converged = 0;
+        if (use_g) {
+            int mm = Mc;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) mm = max(mm, __shfl_xor(mm, off, 64));
+            M = __builtin_amdgcn_readfirstlane(mm);
+            converged = 1;
+        } else {
         // ---- pass 1: u_0 = Psi(t_n), u_{a+1} = (-i dt / (a+1)) H u_a ----
         const double *h0q = a.H0q + (size_t)k * RT * KS * 128, *hcq = a.Hcq + kc;
         load_frags(h0q, hcq);
@@ -2136,8 +2157,6 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                 park[o] = pr_; park[vplane + o] = pi_;
             }
         __syncthreads();
-        int cur = 0, M = 0, converged = 0;
-        const int mcap = a.max_order < a.maxm ? a.max_order : a.maxm;
         for (int m = 1; m <= mcap; ++m) {   // forms u_m
             const double *vc = dsm2 + (size_t)cur * 2 * vplane;
             double *vn = dsm2 + (size_t)(cur ^ 1) * 2 * vplane;
@@ -2171,6 +2190,7 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
             // ||u_m|| < tol for every cell of the batch (identical decision in every wave: same LDS values)
             if (m >= 2 && __all(tot < a.tol * a.tol)) { converged = 1; break; }
         }
+        }   // !use_g
         // orders a = 0..M-1 enter the sum; u_M is below the tolerance (or the cap was hit: flagged below)
 
         // ---- pass 2: w_{M-1} = chi(t_{n+1}), w_{a-1} = chi + (i dt / (a+1)) H^dagger w_a ----
@@ -2203,8 +2223,14 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                 double ur[4], ui[4];   // u_aa tile of this wave (requested before the products)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const size_t o = (size_t)aa * 2 * vplane + (size_t)(16 * rt + 4 * r + rg) * 16 + c;
-                    ur[r] = park[o]; ui[r] = park[vplane + o];
+                    if (use_g) {   // the cell's own record; terms past its M are below the tolerance: zero
+                        const double2 u = a.gpark[(((size_t)k * a.N_T + nc) * a.maxp + aa) * NP + 16 * rt + 4 * r + rg];
+                        const bool in = valid && aa < Mc;
+                        ur[r] = in ? u.x : 0.; ui[r] = in ? u.y : 0.;
+                    } else {
+                        const size_t o = (size_t)aa * 2 * vplane + (size_t)(16 * rt + 4 * r + rg) * 16 + c;
+                        ur[r] = park[o]; ui[r] = park[vplane + o];
+                    }
                 }
                 d4 pr[NV], pi[NV];
                 products(h0p, hcp, vc, rt, pr, pi);

@@ -36,6 +36,11 @@ struct SeriesArgs {
     unsigned long long *stats;   // [10] += series terms summed over (sub-)steps, [11] += sub-steps
     double tol, theta;
     int L, hc_per_traj, max_order;
+    // forward sweep only: the terms u_a of every cell, parked for the derivative kernel (deriv2_kernel skips its
+    // first pass): park[k][n][a][NP], a < maxp, and the number of terms of the cell (-1: sub-steps or too many)
+    double2 *park;
+    int *morder;
+    int maxp;
 };
 
 // 1 / (a + 1) of the series coefficients (scalar loads; an IEEE division costs a dozen dependent fp64 instructions)
@@ -226,6 +231,13 @@ __device__ __forceinline__ void series_sweep_body(const SeriesArgs &a, const int
         for (int sub = 0; sub < msub; ++sub) {
             // row owners accumulate the sum of the series, starting from u_0 = current state
             if (owner) { const double2 v = vec[cur][slot(myrow)]; sr = v.x; si = v.y; }
+            double2 *pk = nullptr;
+            if constexpr (!BACKWARD) {
+                if (a.park && msub == 1) {
+                    pk = a.park + ((size_t)k * N_T + n) * a.maxp * NP + myrow;
+                    if (owner) pk[0] = make_double2(sr, si);
+                }
+            }
             const double thr_el = a.tol * a.tol * nrm2 / (double)NP;
             bool conv = false;
             int aord = 0;
@@ -279,6 +291,9 @@ __device__ __forceinline__ void series_sweep_body(const SeriesArgs &a, const int
                 if (owner) {
                     vec[cur ^ 1][slot(myrow)] = make_double2(ur, ui);
                     sr += ur; si += ui;
+                    if constexpr (!BACKWARD) {
+                        if (pk && aord + 1 < a.maxp) pk[(size_t)(aord + 1) * NP] = make_double2(ur, ui);
+                    }
                 }
                 // eight lanes hold a copy of each row's term: the ballot covers every row eight times, harmless
                 const unsigned long long bal = __ballot(ur * ur + ui * ui > thr_el);
@@ -289,6 +304,10 @@ __device__ __forceinline__ void series_sweep_body(const SeriesArgs &a, const int
                 cur ^= 1;
             }
             if (!conv) failed = true;
+            if constexpr (!BACKWARD) {
+                // u_0 .. u_aord were summed and u_aord is below the tolerance: M = aord terms for the derivative
+                if (a.morder && tid == 0) a.morder[(size_t)k * N_T + n] = (pk && conv && aord < a.maxp) ? aord : -1;
+            }
             terms += (unsigned long long)aord;
             ++substeps;
             // publish the new state as u_0 of the next (sub-)step; vec[cur ^ 1] is no longer read by anyone
