@@ -87,6 +87,7 @@ struct grape_handle {
     bool want_bw = true;         // the evaluation in flight wants a gradient (grape_eval with G == NULL clears it)
     bool bw_done = false;        // the last forward call already ran the (unit) backward sweep
     bool bw_unit = false;        // d_bw holds the unit backward states chi~ (storage getter applies the phase)
+    bool z_valid = false;        // d_z belongs to the states in d_bw (grape_backward ran after the fused forward)
     double *d_inv_tnorm = nullptr, *d_ones = nullptr;
     double2 *d_z = nullptr;
     bool series = false;
@@ -911,6 +912,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     phase_begin(h, 1, s);
     const bool pair = h->fuse && h->fuse_on && h->want_bw;
     h->bw_done = h->bw_unit = pair;
+    h->z_valid = false;
     if (pair) {
         // backward sweep from the unit targets in the same launch: K more workgroups on the other CUs
         SweepArgs sb = sa;
@@ -984,6 +986,7 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
         ca.s = sa; ca.s.inv_tnorm = h->d_inv_tnorm; ca.rho = h->d_rho; ca.z = h->d_z;
         hipLaunchKernelGGL(chi_coeff_kernel, dim3((h->K + 63) / 64), dim3(64), 0, s, ca);
         e = hipGetLastError();
+        h->z_valid = true;
     } else if (h->series) {
         const SeriesArgs ra = series_args(h, sa, true);
         e = h->NP == 16 ? launch_series<16>(ra, true, s) : h->NP == 32 ? launch_series<32>(ra, true, s)
@@ -1144,6 +1147,11 @@ int grape_get_tau_grads(grape_handle *h, double *out) {
 
 int grape_get_storage(grape_handle *h, int which, double *out) {
     if (!h || !out || which < 0 || which > 1) return GRAPE_ERR_INVALID;
+    if (which == 1 && h->bw_unit && !h->z_valid) {
+        h->err = "backward states requested between grape_forward and grape_backward (concurrent sweeps: the boundary "
+                 "coefficient of chi is applied by grape_backward)";
+        return GRAPE_ERR_INVALID;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     const double2 *src = which == 0 ? h->d_fw : h->d_bw;
