@@ -93,6 +93,7 @@ struct grape_handle {
     bool series = false;
     double *d_rb = nullptr;      // [K + Kc*L] 2-norm estimates of H0_k and of the control operators
     double series_tol = 1e-17, series_theta = 3.0;
+    double *d_n1 = nullptr;      // 1-norms of H0_k and of the control operators (order-13 certificate of the expm kernel)
     double2 *d_gpark = nullptr;  // [K][N_T][maxp][NP] terms of the forward series, consumed by deriv2_kernel
     int *d_morder = nullptr;     // [K][N_T]
     int maxp = 0;
@@ -519,7 +520,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -768,6 +769,26 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     // ---- per-evaluation buffers ----
     CCHK(dmalloc(&h->d_eps, (size_t)L * N_T));
     if (!h->series) CCHK(dmalloc(&h->d_U, (size_t)h->KC * N_T * pp));
+    if (!h->series && !h->large) {
+        // 1-norms (max column sum; the input is column-major) for the order-13 certificate of expm_single
+        const char *env = getenv("GRAPE_NORM_BOUND");
+        if (!(env && atoi(env) == 0)) {
+            std::vector<double> n1((size_t)K + (size_t)Kc * L);
+            auto norm1 = [&](const double *m) {
+                double best = 0.0;
+                for (int j = 0; j < N; ++j) {
+                    double cs = 0.0;
+                    for (int i = 0; i < N; ++i) cs += std::hypot(m[2 * ((size_t)j * N + i)], m[2 * ((size_t)j * N + i) + 1]);
+                    best = std::max(best, cs);
+                }
+                return best;
+            };
+            for (int k = 0; k < K; ++k) n1[k] = norm1(p->H0 + 2 * (size_t)k * nn);
+            for (int kl = 0; kl < Kc * L; ++kl) n1[K + kl] = norm1(p->Hc + 2 * (size_t)kl * nn);
+            CCHK(dmalloc(&h->d_n1, n1.size()));
+            CCHK(hipMemcpy(h->d_n1, n1.data(), n1.size() * 8, hipMemcpyHostToDevice));
+        }
+    }
     if (h->series) {
         std::vector<double> rb((size_t)K + (size_t)Kc * L);
         for (int k = 0; k < K; ++k) rb[k] = norm2_estimate(p->H0 + 2 * (size_t)k * nn, N);
@@ -859,6 +880,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     ea.H0f = h->d_H0f; ea.Hcf = h->d_Hcf; ea.eps = h->d_eps; ea.shape = h->d_shape; ea.dts = h->d_dts;
     ea.U = h->d_U; ea.flags = h->d_flags; ea.stats = h->d_stats; ea.cellflag = h->d_cellflag;
     ea.K = h->KC; ea.rep = h->d_rep; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
+    ea.n1 = h->d_n1; ea.n1_k = h->K;
 #ifdef GRAPE_DIAG
     ea.ablate = getenv("GRAPE_DIAG_ABLATE") ? atoi(getenv("GRAPE_DIAG_ABLATE")) : 0;
     static unsigned long long *d_stamps = nullptr;

@@ -54,6 +54,8 @@ struct ExpmArgs {
     const int *rep;      // nullptr or [K]: representative trajectory of every generator class (trajectories with
                          // identical H0 / control operators share their propagators)
     int *cellflag;       // [K*N_T] set by the fast kernel for cells that need the pivoted solve
+    const double *n1;    // nullptr or 1-norms: [n1_k] of H0_k (per trajectory), then [Kc][L] of the control operators
+    int n1_k;
 #ifdef GRAPE_DIAG
     int ablate;  // diagnostic builds only (tools/ablate.sh): bit0 skip invert16, bit1 skip solve
     unsigned long long *stamps;  // [nblocks][16] s_memtime at phase boundaries (diagnostic builds only)
@@ -850,7 +852,33 @@ __device__ __forceinline__ void expm_form_a(const ExpmArgs &a, const int cell, d
             const int idx = base + u * nt;
             if (idx < i1) { hr[u] = h0[idx]; hi[u] = h0[HALF + idx]; }
         }
-        for (int l = 0; l < a.L; ++l) {
+        // the first two control operators are requested together with the drift (one latency, not three)
+        double2 c0r[8], c0i[8], c1r[8], c1i[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * nt;
+            if (idx < i1) { c0r[u] = hc[idx]; c0i[u] = hc[HALF + idx]; }
+        }
+        if (a.L > 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * nt;
+                if (idx < i1) { c1r[u] = hc[(size_t)2 * HALF + idx]; c1i[u] = hc[(size_t)2 * HALF + HALF + idx]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            hr[u].x = fma(e[0], c0r[u].x, hr[u].x); hr[u].y = fma(e[0], c0r[u].y, hr[u].y);
+            hi[u].x = fma(e[0], c0i[u].x, hi[u].x); hi[u].y = fma(e[0], c0i[u].y, hi[u].y);
+        }
+        if (a.L > 1) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                hr[u].x = fma(e[1], c1r[u].x, hr[u].x); hr[u].y = fma(e[1], c1r[u].y, hr[u].y);
+                hi[u].x = fma(e[1], c1i[u].x, hi[u].x); hi[u].y = fma(e[1], c1i[u].y, hi[u].y);
+            }
+        }
+        for (int l = 2; l < a.L; ++l) {
             double2 cr[8], ci[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1237,20 +1265,38 @@ __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, c
     STAMP(0);
     {
         using LYY = ExpmLds<NT>;
+        // ||A||_1 <= dt (||H0_k||_1 + sum_l |eps_l| ||H_l||_1): when this bound already lies in (2.1, 5.4] it certifies
+        // order 13 without squaring and the norm of the cell is not needed (a cell whose true norm is below 2.1 then
+        // gets order 13 instead of Julia's 9: same result to rounding); every other case measures the norm
+        double bound = -1.0;
+        if (a.n1) {
+            const int kc = cell / a.N_T, n = cell - kc * a.N_T, k = a.rep ? a.rep[kc] : kc;
+            const double *n1c = a.n1 + a.n1_k + (size_t)(a.hc_per_traj ? k : 0) * a.L;
+            bound = a.n1[k];
+            for (int l = 0; l < a.L; ++l)
+                bound += fabs(a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0)) * n1c[l];
+            bound *= a.dts[n] * (1.0 + 1e-12);
+        }
         expm_form_a<NT>(a, cell, smem, tid, LYY::NTH, 0, LYY::NP * LYY::NP / 2);
-        __syncthreads();
-        STAMP(11);
-        expm_norm_partial<NT>(smem, tid, LYY::NTH / LYY::NP);
-        __syncthreads();
-        expm_norm_combine<NT>(smem, tid, LYY::NTH / LYY::NP);
-        __syncthreads();
+        if (bound > 2.1 && bound <= 5.4) {
+            if (tid == 0) (smem + 2 * LYY::REG + LYY::DV)[LYY::NTH] = bound;
+            __syncthreads();
+            STAMP(11);
+        } else {
+            __syncthreads();
+            STAMP(11);
+            expm_norm_partial<NT>(smem, tid, LYY::NTH / LYY::NP);
+            __syncthreads();
+            expm_norm_combine<NT>(smem, tid, LYY::NTH / LYY::NP);
+            __syncthreads();
+        }
         expm_poly<NT, HERM>(a, wave, lane, tid, smem, Pn, Qn, s, order, inv_b0sq);
     }
     STAMP(2);
     double minrel = 1e300;
     block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true);
     // |pivot| < 1e-3 b0 (or NaN) in any of the diagonal tiles -> flag the cell for the pivoted pass
-    if (lane == 0 && !(minrel > 1e-6)) a.cellflag[cell] = 1;
+    if (lane == 0 && !(minrel > 1e-6)) { a.cellflag[cell] = 1; atomicAdd(&a.flags[2], 1); }   // flags[2]: flagged cells
     STAMP(3);
     expm_finish<NT>(a, cell, wave, lane, smem, Pn, s);
     STAMP(4);
@@ -1264,6 +1310,8 @@ __global__ void __launch_bounds__(NT * 64) expm_pade_kernel(ExpmArgs a) {
         expm_single<NT, HERM>(a, xcd_remap(blockIdx.x, ncell), threadIdx.x);   // one workgroup per cell
     } else {
         // second pass, small grid: every workgroup scans a slice of the flags and re-solves flagged cells
+        // (flags[2] counts them: the usual evaluation has none and the pass ends here)
+        if (a.flags[2] == 0) return;
         for (int cell = blockIdx.x; cell < ncell; cell += gridDim.x) {
             if (!a.cellflag[cell]) continue;
             __syncthreads();
