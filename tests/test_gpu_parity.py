@@ -194,14 +194,21 @@ def test_split_phase_shards_equal_single_handle(g):
     assert abs(1 - abs(f) ** 2 / 36 - J) <= 1e-15
 
 
-def test_headline_size_properties(g):
+@pytest.mark.parametrize("prop", [0, 1], ids=["expprop", "series"])
+def test_headline_size_properties(g, prop):
     """Full C3 size (N=64, L=2, N_T=1000, K=128): size-independent properties --
     (i) central finite differences of the GPU functional, (ii) norm conservation of the stored
-    states (Hermitian H), (iii) shard additivity of the gradient, (iv) J from tau."""
+    states (Hermitian H), (iii) shard additivity of the gradient, (iv) J from tau -- for the ExpProp path
+    and for the matrix-free propagator, and (v) both paths agree with each other."""
     from grape_jl_amd import synth
     pr = synth.make_config("C3")
-    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+    if prop == 1:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+            Je, Ge, taue = h.eval(pr["pulsevals"])
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], prop_method=prop) as h:
         J, G, tau = h.eval(pr["pulsevals"])
+        if prop == 1:
+            assert abs(J - Je) <= TOL_J and np.abs(tau - taue).max() <= TOL_TAU and np.abs(G - Ge).max() <= tol_G(Ge)
         assert abs(J - (1 - abs(tau.sum()) ** 2 / 128**2)) <= 1e-14
         fw = h.storage(0)
         assert np.abs(np.linalg.norm(fw, axis=2) - 1.0).max() <= 1e-11
@@ -215,7 +222,8 @@ def test_headline_size_properties(g):
             fd = (h.eval(xp, gradient=False)[0] - h.eval(xm, gradient=False)[0]) / (2 * eps)
             assert abs(fd - G[idx]) <= 5e-10 + 1e-5 * abs(G[idx])
     # shard additivity at full size
-    hs = [g.GrapeHip(pr["H0"][s], pr["Hc"], pr["tlist"], pr["psi0"][s], pr["target"][s], pr["weights"][s], K_total=128)
+    hs = [g.GrapeHip(pr["H0"][s], pr["Hc"], pr["tlist"], pr["psi0"][s], pr["target"][s], pr["weights"][s], K_total=128,
+                     prop_method=prop)
           for s in (slice(0, 64), slice(64, 128))]
     taus = [h.forward(pr["pulsevals"]) for h in hs]
     f = sum(t.sum() for t in taus)
@@ -413,3 +421,22 @@ def test_hermitian_fast_path_matches_general_path(g, N, monkeypatch):
     assert np.abs(U.conj().T @ U - np.eye(N)).max() <= 1e-13
     assert abs(J - J1) <= 1e-14 and np.abs(tau - tau1).max() <= 1e-13
     assert np.abs(G - G1).max() <= 1e-13 * max(1.0, np.abs(G1).max())
+
+
+def test_order13_certificate_matches_measured_norm_path(g, monkeypatch):
+    """expm_single skips the 1-norm of a cell when dt (||H0_k||_1 + sum_l |eps_l| ||H_l||_1) already certifies order 13
+    without squaring; GRAPE_NORM_BOUND=0 always measures the norm.  Cells whose true norm is below 2.1 while the bound
+    is above it get order 13 instead of 9 -- the propagators agree to rounding."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 2, 12, 3, seed=21, dt=0.55)        # ||A||_1 around the 2.1 threshold
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        U = h.propagator(1, 5)
+    monkeypatch.setenv("GRAPE_NORM_BOUND", "0")
+    with g.GrapeHip(*args) as h:
+        J0, G0, tau0 = h.eval(pr["pulsevals"])
+        U0 = h.propagator(1, 5)
+    assert np.abs(U - U0).max() <= 5e-15
+    assert abs(J - J0) <= 1e-14 and np.abs(tau - tau0).max() <= 1e-14
+    assert np.abs(G - G0).max() <= 1e-13 * max(np.abs(G0).max(), 1e-3)
