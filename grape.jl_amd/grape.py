@@ -62,13 +62,30 @@ def discretize(vals, tlist):
     return out
 
 
+class ShapedAmplitude:
+    """``QuantumPropagators.Amplitudes.ShapedAmplitude(control; shape)``: the physical amplitude a(t) = S(t) eps(t) of
+    an optimisable control eps(t) under a static shape S(t) (docs/src/tutorial.md:75-107).  GRAPE optimises the pulse
+    values of ``control``; the shape reaches the kernels as ``grape_problem.shape[l][n]`` (it scales H_l in the
+    propagator and mu_l = dH/d eps_l in the gradient)."""
+
+    def __init__(self, control, shape):
+        self.control = control
+        self.shape = shape
+
+
 def hamiltonian(H0, *terms):
-    """``hamiltonian(H0, (H1, eps1), (H2, eps2), ...)``: H(t) = H0 + sum_l eps_l(t) H_l."""
-    ops, ctrls = [], []
+    """``hamiltonian(H0, (H1, eps1), (H2, eps2), ...)``: H(t) = H0 + sum_l a_l(t) H_l, a_l a control or a
+    ``ShapedAmplitude`` of one."""
+    ops, ctrls, shapes = [], [], []
     for op, ctrl in terms:
         ops.append(np.asarray(op, dtype=np.complex128))
-        ctrls.append(ctrl)
-    return Generator(np.asarray(H0, dtype=np.complex128), ops, ctrls)
+        if isinstance(ctrl, ShapedAmplitude):
+            ctrls.append(ctrl.control)
+            shapes.append(ctrl.shape)
+        else:
+            ctrls.append(ctrl)
+            shapes.append(None)
+    return Generator(np.asarray(H0, dtype=np.complex128), ops, ctrls, shapes)
 
 
 @dataclass
@@ -76,6 +93,7 @@ class Generator:
     drift: np.ndarray
     ops: List[np.ndarray]
     controls: list
+    shapes: list = None   # per term: None or the static shape S(t) of a ShapedAmplitude
 
 
 @dataclass
@@ -214,6 +232,21 @@ class GrapeWrk:
         Hc = np.stack(per_traj)
         if all(np.array_equal(Hc[0], h) for h in Hc[1:]):
             Hc = Hc[0]
+        # static shapes of ShapedAmplitudes: one S_l per control (the ABI scales H_l and mu_l by shape[l][n])
+        shape = None
+        for l, c in enumerate(self.controls):
+            found = []
+            for t in trajs:
+                shp = t.generator.shapes or [None] * len(t.generator.controls)
+                found += [sh for sh, cc in zip(shp, t.generator.controls) if cc is c]
+            shaped = [sh for sh in found if sh is not None]
+            if shaped:
+                vals = [discretize_on_midpoints(sh, self.tlist) for sh in found if sh is not None]
+                if len(shaped) != len(found) or any(not np.array_equal(vals[0], v) for v in vals[1:]):
+                    raise ValueError("a control must enter every term with the same shape")
+                if shape is None:
+                    shape = np.ones((self.L, self.N_T))
+                shape[l] = vals[0]
         method = {"gradgen": api.GRAD_GRADGEN, "taylor": api.GRAD_TAYLOR}.get(
             self.kwargs.get("gradient_method", "gradgen"))
         if method is None:
@@ -228,7 +261,7 @@ class GrapeWrk:
             raise ValueError(f"prop_method={pm!r} not in (ExpProp, Cheby, Newton, series)")
         return api.GrapeHip(H0, Hc, self.tlist, np.stack([t.initial_state for t in trajs]),
                             np.stack([t.target_state for t in trajs]),
-                            prop_method=prop, prop_tolerance=self.kwargs.get("prop_tolerance", 0.0),
+                            prop_method=prop, prop_tolerance=self.kwargs.get("prop_tolerance", 0.0), shape=shape,
                             weights=np.array([t.weight for t in trajs], dtype=np.float64),
                             functional=_FUNCTIONAL_CODE[J_T], gradient_method=method,
                             chi_min_norm=self.kwargs.get("chi_min_norm", 0.0),

@@ -74,3 +74,28 @@ def test_cnot_saddle_point_with_polynomial_propagator():
     # the ExpProp path walks the same landscape
     res_e = G.optimize(trajs, tlist, J_T=G.J_T_sm, iter_stop=50, prop_method="ExpProp")
     assert res_e.converged and res_e.J_T < 1e-2
+
+
+def test_shaped_amplitude_optimization():
+    """ShapedAmplitude(control; shape) of the reference (docs/src/tutorial.md:75-107): Omega(t) = S(t) eps(t) with a
+    flattop S; GRAPE optimises eps, the physical amplitude keeps the smooth switch-on/off.  The gradient handed to
+    L-BFGS-B is checked against the numpy oracle (which applies the same shape) at the guess."""
+    import grape_oracle as go
+    from grape_jl_amd import grape as G
+    sx, sz = np.array([[0, 1], [1, 0]], complex), np.array([[1, 0], [0, -1]], complex)
+    tlist = np.linspace(0, 5, 501)
+    eps = lambda t: 0.2                                           # noqa: E731
+    H = G.hamiltonian(-0.5 * sz, (sx, G.ShapedAmplitude(eps, shape=flattop)))
+    traj = G.Trajectory(np.array([1, 0], complex), H, target_state=np.array([0, 1], complex))
+    wrk = G.GrapeWrk([traj], tlist, J_T=G.J_T_sm)
+    Gv = np.zeros_like(wrk.pulsevals)
+    J = G.evaluate_gradient_b(Gv, wrk.pulsevals, wrk)
+    S = G.discretize_on_midpoints(flattop, tlist)[None, :]
+    Jr, Gr, _ = go.evaluate_gradient((-0.5 * sz)[None], sx[None], tlist, wrk.pulsevals, traj.initial_state[None],
+                                     traj.target_state[None], shape=S)
+    assert abs(J - Jr) <= 1e-12 and np.abs(Gv - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)
+    assert Gv[0] == 0.0 and Gv[-1] == 0.0                         # S = 0 on the first and last interval
+    res = G.optimize([traj], tlist, J_T=G.J_T_sm, iter_stop=10)
+    assert res.J_T < 1e-3
+    amp = S[0] * G.discretize_on_midpoints(res.optimized_controls[0], tlist)
+    assert abs(amp[0]) < 1e-12 and abs(amp[-1]) < 1e-12 and 0.5 < np.abs(amp).max() < 1.5
