@@ -2133,8 +2133,12 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
         // products of the (1+L) fixed matrices with the vector block `vc` for row tile rt: acc[v] (re, im)
         auto products = [&](const double *h0k, const double *hck, const double *vc, const int rt, d4 (&pr)[NV],
                             d4 (&pi)[NV]) __attribute__((always_inline)) {
+            // complex products by the 3M scheme: P1 = Ar Br, P2 = Ai Bi, P3 = (Ar + Ai)(Br + Bi);
+            // re = P1 - P2, im = P3 - P1 - P2 -- three real MFMA products instead of four (normwise stable; the
+            // operand sums cost one VALU add each per k-step against 3 NV MFMAs of 64 cycles)
+            d4 p3[NV];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) { pr[v] = (d4){0., 0., 0., 0.}; pi[v] = (d4){0., 0., 0., 0.}; }
+            for (int v = 0; v < NV; ++v) { pr[v] = (d4){0., 0., 0., 0.}; pi[v] = (d4){0., 0., 0., 0.}; p3[v] = (d4){0., 0., 0., 0.}; }
             const double *vb = vc + (size_t)rg * 16 + c;
             double bwr = vb[0], bwi = vb[vplane];
             auto ks_step = [&](const int ks) __attribute__((always_inline)) {
@@ -2151,19 +2155,17 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                         ai[1 + l] = l < L ? hck[(((size_t)l * RT + rt) * KS + ks) * 128 + 64 + lane] : 0.;
                     }
                 }
-                const double br = bwr, bi = bwi, nbi = -bwi;
+                const double br = bwr, bi = bwi, bs = bwr + bwi;
                 if (ks + 1 < KS) {   // B operands of the next k-step: rows 4(ks+1) + rg of the block, column c
                     bwr = vb[(size_t)(4 * (ks + 1)) * 16];
                     bwi = vb[vplane + (size_t)(4 * (ks + 1)) * 16];
                 }
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    pr[v] = MFMA64(ar[v], br, pr[v]);  pi[v] = MFMA64(ar[v], bi, pi[v]);
+                    pr[v] = MFMA64(ar[v], br, pr[v]);  pi[v] = MFMA64(ai[v], bi, pi[v]);   // P1, P2
                 }
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    pr[v] = MFMA64(ai[v], nbi, pr[v]); pi[v] = MFMA64(ai[v], br, pi[v]);
-                }
+                for (int v = 0; v < NV; ++v) p3[v] = MFMA64(ar[v] + ai[v], bs, p3[v]);
             };
             if constexpr (CACHE_A) {
 #pragma unroll
@@ -2171,6 +2173,12 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
             } else {
 #pragma unroll 4
                 for (int ks = 0; ks < KS; ++ks) ks_step(ks);
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const d4 p1 = pr[v], p2 = pi[v];
+                pr[v] = p1 - p2;
+                pi[v] = p3[v] - p1 - p2;
             }
         };
 
