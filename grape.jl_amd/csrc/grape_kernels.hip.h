@@ -769,7 +769,8 @@ __device__ __forceinline__ void gemm_rot(Strip<4> &acc, const double *__restrict
     }
 }
 
-// rotated version of gemm_dual13: T[0..2] += X (b13 A6 + b11 A4 + b9 A2),  V[0..2] += X (b12 A6 + b10 A4 + b8 A2)
+// rotated version of gemm_dual13: T[0..2] += X (b13 A6 + b11 A4 + b9 A2),  V[0..2] += X (b12 A6 + b10 A4 + b8 A2),
+// both by the 3M scheme (see gemm_rot): 18 instead of 24 MFMAs per k-step, the operand sums of X are shared.
 template <int LD>
 __device__ __forceinline__ void gemm_dual13_rot(Strip<4> &T, Strip<4> &V, const double *__restrict__ Xre,
                                                 const double *__restrict__ Xim, const Strip<4> &A2, const Strip<4> &A4,
@@ -780,6 +781,12 @@ __device__ __forceinline__ void gemm_dual13_rot(Strip<4> &T, Strip<4> &V, const 
     int rowoff[NS];
 #pragma unroll
     for (int so = 0; so < NS; ++so) rowoff[so] = 16 * ((wave + so) & 3) * LD;
+    d4 t1[NS], t2[NS], t3[NS], v1[NS], v2[NS], v3[NS];
+#pragma unroll
+    for (int so = 0; so < NS; ++so) {
+        t1[so] = (d4){0., 0., 0., 0.}; t2[so] = (d4){0., 0., 0., 0.}; t3[so] = (d4){0., 0., 0., 0.};
+        v1[so] = (d4){0., 0., 0., 0.}; v2[so] = (d4){0., 0., 0., 0.}; v3[so] = (d4){0., 0., 0., 0.};
+    }
 #pragma unroll
     for (int sk = 0; sk < 4; ++sk) {
 #pragma unroll
@@ -789,25 +796,35 @@ __device__ __forceinline__ void gemm_dual13_rot(Strip<4> &T, Strip<4> &V, const 
             const double wi = B13_13 * A6.im[sk][r] + B13_11 * A4.im[sk][r] + B13_9 * A2.im[sk][r];
             const double zr = B13_12 * A6.re[sk][r] + B13_10 * A4.re[sk][r] + B13_8 * A2.re[sk][r];
             const double zi = B13_12 * A6.im[sk][r] + B13_10 * A4.im[sk][r] + B13_8 * A2.im[sk][r];
-            const double nwi = -wi, nzi = -zi;
-            double are[NS], aim[NS];
+            const double ws = wr + wi, zs = zr + zi;
+            double are[NS], aim[NS], as[NS];
 #pragma unroll
             for (int so = 0; so < NS; ++so) { are[so] = xr[rowoff[so] + kc]; aim[so] = xi[rowoff[so] + kc]; }
 #pragma unroll
             for (int so = 0; so < NS; ++so) {
-                T.re[so] = MFMA64(are[so], wr, T.re[so]);
-                T.im[so] = MFMA64(are[so], wi, T.im[so]);
-                V.re[so] = MFMA64(are[so], zr, V.re[so]);
-                V.im[so] = MFMA64(are[so], zi, V.im[so]);
+                t1[so] = MFMA64(are[so], wr, t1[so]);
+                v1[so] = MFMA64(are[so], zr, v1[so]);
             }
 #pragma unroll
             for (int so = 0; so < NS; ++so) {
-                T.re[so] = MFMA64(aim[so], nwi, T.re[so]);
-                T.im[so] = MFMA64(aim[so], wr, T.im[so]);
-                V.re[so] = MFMA64(aim[so], nzi, V.re[so]);
-                V.im[so] = MFMA64(aim[so], zr, V.im[so]);
+                t2[so] = MFMA64(aim[so], wi, t2[so]);
+                v2[so] = MFMA64(aim[so], zi, v2[so]);
+            }
+#pragma unroll
+            for (int so = 0; so < NS; ++so) as[so] = are[so] + aim[so];
+#pragma unroll
+            for (int so = 0; so < NS; ++so) {
+                t3[so] = MFMA64(as[so], ws, t3[so]);
+                v3[so] = MFMA64(as[so], zs, v3[so]);
             }
         }
+    }
+#pragma unroll
+    for (int so = 0; so < NS; ++so) {
+        T.re[so] += t1[so] - t2[so];
+        T.im[so] += t3[so] - t1[so] - t2[so];
+        V.re[so] += v1[so] - v2[so];
+        V.im[so] += v3[so] - v1[so] - v2[so];
     }
 }
 
