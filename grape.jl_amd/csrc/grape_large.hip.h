@@ -68,8 +68,8 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
         }
         return;
     }
-    Strip<4> acc;
-    strip_zero(acc);
+    Strip3<4> acc3;   // 3M partial products, combined once after the K loop
+    strip3_zero(acc3);
     for (int kb = 0; kb < a.kblocks; ++kb) {
         const double *x = lg_ptr(a.X, cell, bi, kb);
         const double *y = lg_ptr(a.Y, cell, kb, bj);
@@ -91,8 +91,11 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
                 B.im[t][r] = y[a.Y.plane + o];
             }
         __syncthreads();
-        gemm_xb<4, LD>(acc, Xre, Xim, B, lane);
+        gemm_xb3<4, LD>(acc3, Xre, Xim, B, lane);
     }
+    Strip<4> acc;
+    strip_zero(acc);
+    strip3_add_to(acc3, acc);
     const int grow0 = (a.C.rb + bi) * 64, gcol = (a.C.cb + bj) * 64 + col;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
