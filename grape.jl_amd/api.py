@@ -83,6 +83,13 @@ def load_library():
     path = library_path()
     if not os.path.exists(path):
         raise GrapeHipError(-2, f"{path} not built; run __graft_entry__.build() (no CPU fallback exists)")
+    # PyTorch-ROCm bundles its own libamdhip64: when both end up in one process (device tensors, RCCL) the library
+    # must bind to the runtime torch uses -- a second HIP runtime initialised later sees no GPU ("No HIP GPUs are
+    # available").  Importing torch first makes the loader resolve libamdhip64.so to torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.c_int
     lib.grape_create.argtypes = [C.POINTER(vp), C.POINTER(_Problem)]

@@ -329,6 +329,7 @@ __device__ __forceinline__ void invert16_step(double (&ar)[4], double (&ai)[4], 
     const bool pc = (g == kg);
     ar[kc] = pc ? (isk ? 1.0 : 0.0) : ar[kc];
     ai[kc] = pc ? 0.0 : ai[kc];
+#ifdef GRAPE_DPP_FUSED
 #pragma unroll
     for (int c = 0; c < 4; ++c) {   // a_ij -= m' a_kj for this lane's columns j = 4c+g
         fmac_rowbcast<K>(ar[c], ar[c], nmr);
@@ -336,6 +337,25 @@ __device__ __forceinline__ void invert16_step(double (&ar)[4], double (&ai)[4], 
         fmac_rowbcast<K>(ai[c], ai[c], nmr);
         fmac_rowbcast<K>(ai[c], ar[c], nmi);
     }
+#else
+    // the pivot row (untouched by its own step) is broadcast once per register -- 16 DPP moves -- and feeds the
+    // 16 FMAs of the step (a broadcast per FMA costs twice the moves)
+    double kr[4], ki[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        kr[c] = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(ar[c]), 0x150 + K, 0xf, 0xf, true),
+                                 __builtin_amdgcn_mov_dpp(__double2loint(ar[c]), 0x150 + K, 0xf, 0xf, true));
+        ki[c] = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(ai[c]), 0x150 + K, 0xf, 0xf, true),
+                                 __builtin_amdgcn_mov_dpp(__double2loint(ai[c]), 0x150 + K, 0xf, 0xf, true));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // a_ij -= m' a_kj for this lane's columns j = 4c+g
+        ar[c] = fma(kr[c], nmr, ar[c]);
+        ar[c] = fma(ki[c], pmi, ar[c]);
+        ai[c] = fma(ki[c], nmr, ai[c]);
+        ai[c] = fma(kr[c], nmi, ai[c]);
+    }
+#endif
 }
 
 template <int K>
