@@ -353,13 +353,15 @@ LgView lg_full(double *p, int NP) { return LgView{p, (size_t)2 * NP * NP, (size_
 
 hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, LgView C, int kblocks, double alpha,
                    double beta, int nadd = 0, const LgView *add = nullptr, const double *coef = nullptr,
-                   double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0, int herm = 0) {
+                   double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0, int herm = 0,
+                   const int *scale_s = nullptr, int scale_pow = 0, double2 *Uout = nullptr, int u_np = 0) {
     if (nbi <= 0 || nbj <= 0) return hipSuccess;
     LgGemmArgs a{};
     a.X = X; a.Y = Y; a.C = C; a.kblocks = kblocks; a.alpha = alpha; a.beta = beta; a.cI = cI;
     a.nadd = nadd;
     for (int i = 0; i < nadd; ++i) { a.Add[i] = add[i]; a.coef[i] = coef[i]; }
     a.s_cell = s_cell; a.sq_iter = sq_iter; a.herm = (nbi == nbj) ? herm : 0;
+    a.scale_s = scale_s; a.scale_pow = scale_pow; a.Uout = Uout; a.u_np = u_np;
     a.nbi = nbi; a.nbj = nbj; a.ncell = nc;
     const int groups = (nc + 7) / 8;   // cells are dealt to the 8 XCDs in groups
     const int per_cell = a.herm ? nbi * (nbi + 1) / 2 : nbi * nbj;
@@ -413,7 +415,8 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
                      vW = lg_full(W, NP), vZ = lg_full(Z, NP), vT = lg_full(T, NP), vV = lg_full(V, NP), vU = lg_full(Uo, NP);
         // Hermitian generators: A2, A4, A6, T, V are Hermitian and U = A T skew-Hermitian -> upper block triangle only
         const int hm = h->herm ? 1 : 0;
-        LGCHK(lg_gemm(s, nc, NB, NB, vA, vA, vA2, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm));
+        // A is stored unscaled (lg_form_kernel): A2 = (A / 2^s)^2 and U = (A / 2^s) T take the power of two as a factor
+        LGCHK(lg_gemm(s, nc, NB, NB, vA, vA, vA2, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm, h->d_scell, 2));
         LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA2, vA4, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm));
         LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA4, vA6, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm));
         {
@@ -425,7 +428,7 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
             LGCHK(lg_gemm(s, nc, NB, NB, vA6, vW, vT, NB, 1.0, 0.0, 3, add, ct, B13_1, nullptr, 0, hm));   // T = A6 W1 + T0
             LGCHK(lg_gemm(s, nc, NB, NB, vA6, vZ, vV, NB, 1.0, 0.0, 3, add, cv, B13_0, nullptr, 0, hm));   // V = A6 Z1 + V0
         }
-        LGCHK(lg_gemm(s, nc, NB, NB, vA, vT, vU, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, -hm));   // U = A T
+        LGCHK(lg_gemm(s, nc, NB, NB, vA, vT, vU, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, -hm, h->d_scell, 1));   // U = A T
         {
             const double *in[2] = {V, Uo};
             const double cp[2] = {1.0, 1.0}, cq[2] = {1.0, -1.0};
@@ -465,13 +468,17 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
         LGCHK(hipStreamSynchronize(s));
         double *X = W, *Y = T;
         for (int it = 0; it < smax; ++it) {
+            // the last squaring writes U_kn (interleaved complex) itself; cells that are done are copied through
+            double2 *uout = it == smax - 1 ? h->d_U + (size_t)c0 * pp : nullptr;
             LGCHK(lg_gemm(s, nc, NB, NB, lg_full(X, NP), lg_full(X, NP), lg_full(Y, NP), NB, 1.0, 0.0, 0, nullptr, nullptr,
-                          0.0, h->d_scell, it));
+                          0.0, h->d_scell, it, 0, nullptr, 0, uout, NP));
             std::swap(X, Y);
         }
-        hipLaunchKernelGGL(lg_store_u_kernel, dim3(2048), dim3(256), 0, s, (const double *)X,
-                           h->d_U + (size_t)c0 * pp, NP, (size_t)nc * pp);
-        LGCHK(hipGetLastError());
+        if (smax == 0) {
+            hipLaunchKernelGGL(lg_store_u_kernel, dim3(2048), dim3(256), 0, s, (const double *)X,
+                               h->d_U + (size_t)c0 * pp, NP, (size_t)nc * pp);
+            LGCHK(hipGetLastError());
+        }
     }
     return hipSuccess;
 }

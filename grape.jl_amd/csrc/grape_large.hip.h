@@ -30,6 +30,10 @@ struct LgGemmArgs {
     int sq_iter;
     int herm;            // +1 / -1: the product is Hermitian / skew-Hermitian (nbi == nbj): only the blocks bi <= bj are
                          // computed, each workgroup also stores the (signed) conjugate transpose of its block at (bj, bi)
+    const int *scale_s;  // optional: alpha *= 2^(-scale_pow * scale_s[cell]) -- the scaling A / 2^s of scaling and squaring
+    int scale_pow;       //   applied where A is consumed (A*A: 2, A*T: 1) instead of in a pass over A; exact in binary
+    double2 *Uout;       // optional: the result goes to U[cell][row][col] (interleaved complex) instead of C
+    int u_np;
 };
 
 __device__ __forceinline__ double *lg_ptr(const LgView &v, int cell, int brow, int bcol) {
@@ -63,11 +67,17 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
         const double *x = lg_ptr(a.X, cell, bi, bj);
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int i = idx >> 6, j = idx & 63;
-            c[(size_t)i * a.C.ld + j] = x[(size_t)i * a.X.ld + j];
-            c[a.C.plane + (size_t)i * a.C.ld + j] = x[a.X.plane + (size_t)i * a.X.ld + j];
+            const double vr = x[(size_t)i * a.X.ld + j], vi = x[a.X.plane + (size_t)i * a.X.ld + j];
+            if (a.Uout) {
+                a.Uout[(size_t)cell * a.u_np * a.u_np + (size_t)(bi * 64 + i) * a.u_np + bj * 64 + j] = make_double2(vr, vi);
+            } else {
+                c[(size_t)i * a.C.ld + j] = vr;
+                c[a.C.plane + (size_t)i * a.C.ld + j] = vi;
+            }
         }
         return;
     }
+    const double alpha = a.scale_s ? ldexp(a.alpha, -a.scale_pow * a.scale_s[cell]) : a.alpha;
     Strip3<4> acc3;   // 3M partial products, combined once after the K loop
     strip3_zero(acc3);
     for (int kb = 0; kb < a.kblocks; ++kb) {
@@ -103,7 +113,7 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * t + 4 * r + rg;
             const size_t o = (size_t)row * a.C.ld + col;
-            double vr = a.alpha * acc.re[t][r], vi = a.alpha * acc.im[t][r];
+            double vr = alpha * acc.re[t][r], vi = alpha * acc.im[t][r];
             if (a.beta != 0.0) { vr += a.beta * c[o]; vi += a.beta * c[a.C.plane + o]; }
             for (int q = 0; q < a.nadd; ++q) {
                 const double *ad = lg_ptr(a.Add[q], cell, bi, bj);
@@ -112,8 +122,12 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
                 vi += a.coef[q] * ad[a.Add[q].plane + oa];
             }
             if (a.cI != 0.0 && grow0 + row == gcol) vr += a.cI;
-            c[o] = vr;
-            c[a.C.plane + o] = vi;
+            if (a.Uout) {
+                a.Uout[(size_t)cell * a.u_np * a.u_np + (size_t)(bi * 64 + row) * a.u_np + bj * 64 + col] = make_double2(vr, vi);
+            } else {
+                c[o] = vr;
+                c[a.C.plane + o] = vi;
+            }
             acc.re[t][r] = vr;   // kept for the mirrored block
             acc.im[t][r] = vi;
         }
@@ -208,9 +222,10 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
         e[l] = a.eps[(size_t)l * a.N_T + n];
         if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
     }
-    // thread j owns column j (NP <= 256): column sums need no reduction.  Two passes over the (L2-resident)
-    // operators: the first only takes the column sums of |a_ij| for the 1-norm, the second writes A already
-    // scaled by 2^-s -- A is written once and never read back here.  Rows are unrolled by 8 so that 8 (1 + L)
+    // thread j owns column j (NP <= 256): column sums need no reduction.  ONE pass over the (L2-resident) operators:
+    // A is written unscaled together with the column sums of |a_ij| for the 1-norm; the scaling A / 2^s of scaling and
+    // squaring is applied as a per-cell power of two where A is consumed (LgGemmArgs::scale_s: A*A and A*T) --
+    // exact in binary, and the operators are read once instead of twice.  Rows are unrolled by 8 so that 8 (1 + L)
     // independent loads per plane are in flight (the loop is otherwise bound by one load latency per row).
     auto element = [&](int i, double &ar, double &ai) __attribute__((always_inline)) {
         const size_t o = (size_t)i * NP + tid;
@@ -228,6 +243,9 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
             double ar, ai;
             element(i, ar, ai);
             cs += sqrt(ar * ar + ai * ai);
+            const size_t o = (size_t)i * NP + tid;
+            A[o] = ar;
+            A[pp + o] = ai;
         }
     }
     colsum[tid] = tid < NP ? cs : 0.;
@@ -244,17 +262,6 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
         const double r = nA / 5.4;
         const int ex = ilogb(r);
         s = (r == ldexp(1.0, ex)) ? ex : ex + 1;
-    }
-    const double f = ldexp(1.0, -s);
-    if (tid < NP) {
-#pragma unroll 8
-        for (int i = 0; i < NP; ++i) {
-            double ar, ai;
-            element(i, ar, ai);
-            const size_t o = (size_t)i * NP + tid;
-            A[o] = f * ar;
-            A[pp + o] = f * ai;
-        }
     }
     if (tid == 0) {
         a.s_cell[blockIdx.x] = s;
