@@ -354,14 +354,15 @@ LgView lg_full(double *p, int NP) { return LgView{p, (size_t)2 * NP * NP, (size_
 hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, LgView C, int kblocks, double alpha,
                    double beta, int nadd = 0, const LgView *add = nullptr, const double *coef = nullptr,
                    double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0, int herm = 0,
-                   const int *scale_s = nullptr, int scale_pow = 0, double2 *Uout = nullptr, int u_np = 0) {
+                   const int *scale_s = nullptr, int scale_pow = 0, double2 *Uout = nullptr, int u_np = 0,
+                   int skip_bi = -1) {
     if (nbi <= 0 || nbj <= 0) return hipSuccess;
     LgGemmArgs a{};
     a.X = X; a.Y = Y; a.C = C; a.kblocks = kblocks; a.alpha = alpha; a.beta = beta; a.cI = cI;
     a.nadd = nadd;
     for (int i = 0; i < nadd; ++i) { a.Add[i] = add[i]; a.coef[i] = coef[i]; }
     a.s_cell = s_cell; a.sq_iter = sq_iter; a.herm = (nbi == nbj) ? herm : 0;
-    a.scale_s = scale_s; a.scale_pow = scale_pow; a.Uout = Uout; a.u_np = u_np;
+    a.scale_s = scale_s; a.scale_pow = scale_pow; a.Uout = Uout; a.u_np = u_np; a.skip_bi = skip_bi;
     a.nbi = nbi; a.nbj = nbj; a.ncell = nc;
     const int groups = (nc + 7) / 8;   // cells are dealt to the 8 XCDs in groups
     const int per_cell = a.herm ? nbi * (nbi + 1) / 2 : nbi * nbj;
@@ -446,13 +447,15 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
             LgView prow = vW; prow.rb = jb; prow.cb = 0;
             LGCHK(lg_gemm(s, nc, 1, NB - 1 - jb, vD, qrow, qrow, 1, 1.0, 0.0));   // Q[jb][jb+1..] = Dinv Q[jb][..]
             LGCHK(lg_gemm(s, nc, 1, NB, vD, prow, prow, 1, 1.0, 0.0));             // P[jb][:]      = Dinv P[jb][:]
-            for (int tr = 0; tr < NB; ++tr) {
-                if (tr == jb) continue;
-                LgView x = vZ; x.rb = tr; x.cb = jb;                    // Q[tr][jb]
-                LgView cq = vZ; cq.rb = tr; cq.cb = jb + 1;
-                LgView cp = vW; cp.rb = tr; cp.cb = 0;
-                LGCHK(lg_gemm(s, nc, 1, NB - 1 - jb, x, qrow, cq, 1, -1.0, 1.0));  // Q[tr][..] -= Q[tr][jb] Q[jb][..]
-                LGCHK(lg_gemm(s, nc, 1, NB, x, prow, cp, 1, -1.0, 1.0));            // P[tr][:]  -= Q[tr][jb] P[jb][:]
+            {   // trailing update of every block row tr != jb in one launch per matrix (the launch skips row jb):
+                // Q[tr][jb+1..] -= Q[tr][jb] Q[jb][jb+1..],  P[tr][:] -= Q[tr][jb] P[jb][:]
+                LgView x = vZ; x.rb = 0; x.cb = jb;
+                LgView cq = vZ; cq.rb = 0; cq.cb = jb + 1;
+                LgView cp = vW; cp.rb = 0; cp.cb = 0;
+                LGCHK(lg_gemm(s, nc, NB, NB - 1 - jb, x, qrow, cq, 1, -1.0, 1.0, 0, nullptr, nullptr, 0.0, nullptr, 0, 0,
+                              nullptr, 0, nullptr, 0, jb));
+                LGCHK(lg_gemm(s, nc, NB, NB, x, prow, cp, 1, -1.0, 1.0, 0, nullptr, nullptr, 0.0, nullptr, 0, 0,
+                              nullptr, 0, nullptr, 0, jb));
             }
         }
         {   // cells whose unpivoted elimination was unsafe: partial pivoting from the intact V, U

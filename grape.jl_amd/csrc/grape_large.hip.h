@@ -34,6 +34,8 @@ struct LgGemmArgs {
     int scale_pow;       //   applied where A is consumed (A*A: 2, A*T: 1) instead of in a pass over A; exact in binary
     double2 *Uout;       // optional: the result goes to U[cell][row][col] (interleaved complex) instead of C
     int u_np;
+    int skip_bi;         // block row that is left alone (-1: none): the trailing update of a Gauss-Jordan step covers all
+                         // block rows but the pivot row in ONE launch
 };
 
 __device__ __forceinline__ double *lg_ptr(const LgView &v, int cell, int brow, int bcol) {
@@ -61,6 +63,7 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
     } else {
         bi = rem / a.nbj; bj = rem - bi * a.nbj;
     }
+    if (bi == a.skip_bi) return;
     const int col = 16 * wave + (lane & 15), rg = lane >> 4;
     double *c = lg_ptr(a.C, cell, bi, bj);
     if (a.s_cell && a.s_cell[cell] <= a.sq_iter) {   // no (further) squaring for this cell: C = X
