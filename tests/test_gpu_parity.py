@@ -440,3 +440,46 @@ def test_order13_certificate_matches_measured_norm_path(g, monkeypatch):
     assert np.abs(U - U0).max() <= 5e-15
     assert abs(J - J0) <= 1e-14 and np.abs(tau - tau0).max() <= 1e-14
     assert np.abs(G - G0).max() <= 1e-13 * max(np.abs(G0).max(), 1e-3)
+
+
+@pytest.mark.parametrize("prop", [0, 1], ids=["expprop", "series"])
+@pytest.mark.parametrize("cid", ["C1", "C2"])
+def test_baseline_configs_c1_c2_full_parity(g, ref, cid, prop):
+    """BASELINE.json configs 1 and 2 at full size against the C oracle's literal :gradgen route: the README two-level
+    problem (500 steps, closed form J_T = 1 - (0.04/1.04) sin^2(5 sqrt(1.04))) and N = 16, 1 control, 500 steps,
+    32 trajectories -- every stored quantity, both propagators."""
+    from grape_jl_amd import synth
+    pr = synth.make_config(cid)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args, prop_method=prop) as h:
+        J, G, tau, psiT = h.eval(pr["pulsevals"], want_psiT=True)
+        tg = h.tau_grads()
+    Jr, Gr, taur, parts = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], gradient_method=ref.GRADGEN, want_parts=True)
+    assert abs(J - Jr) <= TOL_J and np.abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr)
+    assert np.abs(psiT - parts["psiT"]).max() <= 1e-12
+    assert np.abs(tg - parts["tau_grads"]).max() <= 1e-10 * max(np.abs(parts["tau_grads"]).max(), 1e-3)
+    if cid == "C1":
+        assert abs(J - (1.0 - (0.04 / 1.04) * np.sin(5.0 * np.sqrt(1.04)) ** 2)) <= 1e-12
+        assert abs(G[0] - 1.3367344501042e-3) <= 1e-13 and abs(G[249] - 3.5455160183374e-3) <= 1e-13   # SURVEY 8c probe
+
+
+def test_baseline_config_c5_shard_properties(g):
+    """BASELINE.json config 5 (N = 256, 4 controls, 2000 steps) on a 2-trajectory slice of a GPU's shard (the oracle
+    is far too slow at this size): J from tau, norm conservation of all stored states, gradient vs central finite
+    differences of the GPU functional, and repeatability."""
+    from grape_jl_amd import synth
+    pr = synth.make_config("C5", K=2)
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        assert abs(J - (1 - abs(tau.sum()) ** 2 / 4)) <= 1e-14
+        assert np.abs(np.linalg.norm(h.storage(0), axis=2) - 1.0).max() <= 1e-11
+        assert np.abs(np.linalg.norm(h.storage(1), axis=2) - 1.0).max() <= 1e-11
+        eps = 1e-5
+        for idx in (3, 2000 + 1234, 4 * 2000 - 1):
+            xp, xm = pr["pulsevals"].copy(), pr["pulsevals"].copy()
+            xp[idx] += eps
+            xm[idx] -= eps
+            fd = (h.eval(xp, gradient=False)[0] - h.eval(xm, gradient=False)[0]) / (2 * eps)
+            assert abs(fd - G[idx]) <= 5e-10 + 1e-5 * abs(G[idx])
+        J2, G2, _ = h.eval(pr["pulsevals"])
+        assert J2 == J and np.array_equal(G2, G)
