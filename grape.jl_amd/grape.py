@@ -273,6 +273,15 @@ class GrapeWrk:
                             D=self.kwargs.get("state_penalty"), lambda_b=self.kwargs.get("lambda_b", 1.0))
 
 
+def _split_functional(wrk, J, tau):
+    """J_parts[1] = J_T from the overlaps, J_parts[3] = lambda_b * sum_k J_b,k (src/optimize.jl:757-766): the backend
+    returns their sum; J_T is a closed form of tau for the three functionals the backend implements."""
+    J_T = wrk.kwargs["J_T"](None, wrk.trajectories, tau=list(tau))
+    wrk.J_parts[0] = float(J_T)
+    on = wrk.kwargs.get("state_penalty") is not None and wrk.kwargs.get("lambda_b", 1.0) != 0.0
+    wrk.J_parts[2] = float(J - J_T) if on else 0.0
+
+
 def evaluate_functional(pulsevals, wrk: GrapeWrk, count_call=True):
     """src/optimize.jl:696-768 (side effects on wrk as documented there)."""
     if pulsevals is not wrk.pulsevals:
@@ -283,7 +292,7 @@ def evaluate_functional(pulsevals, wrk: GrapeWrk, count_call=True):
     J, _, tau, psiT = wrk.backend.eval(wrk.pulsevals, gradient=False, want_psiT=True)
     wrk.result.tau_vals[:] = tau
     wrk._states = psiT
-    wrk.J_parts[0] = J
+    _split_functional(wrk, J, tau)
     J_a = wrk.kwargs.get("J_a")
     if J_a is not None:
         wrk.J_parts[1] = wrk.kwargs.get("lambda_a", 1.0) * J_a(wrk.pulsevals, wrk.tlist)
@@ -299,7 +308,7 @@ def evaluate_gradient_b(G, pulsevals, wrk: GrapeWrk):
     J, g, tau, psiT = wrk.backend.eval(wrk.pulsevals, gradient=True, want_psiT=True)
     wrk.result.tau_vals[:] = tau
     wrk._states = psiT
-    wrk.J_parts[0] = J
+    _split_functional(wrk, J, tau)
     wrk.grad_J_Tb[:] = g
     G[:] = g
     J_a = wrk.kwargs.get("J_a")
@@ -322,6 +331,10 @@ def update_result(wrk: GrapeWrk, i: int):
     res.J_a_prev, res.J_a = res.J_a, float(wrk.J_parts[1])
     if res.J_a > 0.0:
         res.J_a /= wrk.kwargs.get("lambda_a", 1.0)
+    res.J_b_prev, res.J_b = res.J_b, float(wrk.J_parts[2])     # src/optimize.jl:199-204
+    lam_b = wrk.kwargs.get("lambda_b", 1.0)
+    if res.J_b != 0.0 and lam_b != 0.0:
+        res.J_b /= lam_b
     if i > 0:
         res.iter = i
     if i >= res.iter_stop:

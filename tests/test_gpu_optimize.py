@@ -162,3 +162,56 @@ def test_fluence_running_cost_shrinks_the_pulses():
     res = G.optimize(trajs, tlist, J_T=G.J_T_re, J_a=fluence, grad_J_a=grad_fluence, iter_stop=2)
     assert res0.converged and res.converged
     assert sum(np.linalg.norm(c) for c in res.optimized_controls) < sum(np.linalg.norm(c) for c in res0.optimized_controls)
+
+
+def test_stirap_state_running_cost_suppresses_intermediate_population():
+    """/root/reference/test/test_state_running_cost.jl:183-350 (STIRAP): three-level Lambda system, pump and Stokes pulses
+    with real and imaginary parts (four controls, Blackman guesses), |1> -> |3> with J_T_ss.  Without the running cost the
+    optimised dynamics put more than half of the population into the intermediate level |2>; with
+    g_b = |<2|Psi>|^2 (D = |2><2|, xi = -D Psi) and lambda_b = 0.4 the optimisation converges by the reference's check
+    (J_T <= 1e-2 and J_b <= 1e-2), takes at least ten iterations more, decreases J monotonically and suppresses the
+    maximum population of |2> by more than a factor of ten; the :taylor gradient route agrees within 15 %."""
+    from grape_jl_amd import grape as G
+
+    def blackman(t, t0, T, a=0.16):
+        if t < t0 or t > T:
+            return 0.0
+        x = (t - t0) / (T - t0)
+        return 0.5 * (1.0 - a - np.cos(2 * np.pi * x) + a * np.cos(4 * np.pi * x))
+
+    H0 = np.diag([0.0, 0.5, 0.0]).astype(complex)          # Delta_P = Delta_S = 0.5
+    P_re = 0.5 * np.array([[0, 1, 0], [1, 0, 0], [0, 0, 0]], complex)
+    P_im = 0.5 * np.array([[0, 1j, 0], [-1j, 0, 0], [0, 0, 0]], complex)
+    S_re = 0.5 * np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0]], complex)
+    S_im = 0.5 * np.array([[0, 0, 0], [0, 0, 1j], [0, -1j, 0]], complex)
+    H = G.hamiltonian(H0, (P_re, lambda t: blackman(t, 1.0, 5.0)), (P_im, lambda t: 0.0),
+                      (S_re, lambda t: blackman(t, 0.0, 4.0)), (S_im, lambda t: 0.0))
+    tlist = np.linspace(0, 5, 501)
+    traj = G.Trajectory(np.array([1, 0, 0], complex), H, target_state=np.array([0, 0, 1], complex))
+    D = np.diag([0.0, 1.0, 0.0]).astype(complex)
+
+    def pmax2(res, **kw):
+        """max_t |<2|Psi(t)>|^2 under the optimised controls: stored forward states of one more evaluation."""
+        wrk = G.GrapeWrk([traj], tlist, J_T=G.J_T_ss, **kw)
+        x = np.concatenate([G.discretize_on_midpoints(c, tlist) for c in res.optimized_controls])
+        wrk.backend.eval(x, gradient=False)
+        return float((np.abs(wrk.backend.storage(0)[0, :, 1]) ** 2).max())
+
+    res1 = G.optimize([traj], tlist, J_T=G.J_T_ss, iter_stop=50, state_penalty=D, lambda_b=0.0, prop_method="Cheby",
+                      check_convergence=lambda r: "J_T < 10^-2" if r.J_T <= 1e-2 else "")
+    assert res1.converged and res1.J_b == 0.0 and res1.J_b_prev == 0.0
+    P1 = pmax2(res1)
+    assert P1 > 0.5
+    records = []
+    kw2 = dict(J_T=G.J_T_ss, iter_stop=100, state_penalty=D, lambda_b=0.4, prop_method="Cheby",
+               check_convergence=lambda r: (r.J_T <= 1e-2) and (r.J_b <= 1e-2))
+    res2 = G.optimize([traj], tlist, callback=lambda wrk, i: records.append(float(np.sum(wrk.J_parts))) or None, **kw2)
+    assert res2.converged and res2.message == "Convergence check returned true"
+    assert res2.iter > res1.iter + 10 and res2.J_b > 0.0 and res2.J_b_prev > 0.0
+    assert np.max(np.diff(records)) < 0.0                       # monotonic decrease of J = J_T + lambda_b J_b
+    P2 = pmax2(res2)
+    assert P2 / P1 < 1e-1
+    res3 = G.optimize([traj], tlist, gradient_method="taylor", **kw2)
+    assert res3.converged and res3.iter > res1.iter + 10 and res3.J_b > 0.0
+    P3 = pmax2(res3)
+    assert abs(P3 - P2) / P3 < 0.15
