@@ -99,6 +99,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank code path on a box with ONE GPU (tests only): every rank on device 0, gloo collectives
+    rehearsal = os.environ.get("GRAPE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     dist = None
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also with a single rank)
         import torch.distributed as dist_mod
@@ -110,7 +114,11 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if rehearsal:
+                dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist_mod.init_process_group("nccl", rank=rank, world_size=world,
+                                            device_id=torch.device("cuda", local_rank))
             warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
             dist_mod.all_reduce(warm)
             torch.cuda.synchronize()

@@ -483,3 +483,28 @@ def test_baseline_config_c5_shard_properties(g):
             assert abs(fd - G[idx]) <= 5e-10 + 1e-5 * abs(G[idx])
         J2, G2, _ = h.eval(pr["pulsevals"])
         assert J2 == J and np.array_equal(G2, G)
+
+
+def test_bench_contract_two_rank_rehearsal(g):
+    """bench.py under torch.distributed.run with two ranks (rehearsal mode: both ranks on this box's one GPU, gloo
+    collectives; the driver's N > 1 runs use RCCL on one GPU per rank): stdout carries exactly ONE line, a JSON object
+    with the contract's keys, the whole-job value counts both shards, and the roofline block is present."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAPE_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29543", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[:2000]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0
