@@ -238,7 +238,7 @@ def main():
                                   "note": "host-pointer grape_eval (16 KB H2D + D2H per call included); secondary, "
                                           "not the headline metric"}
             hm.close()
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the N = 1 run only
             def hip_sample(sl, tl, xs):
                 hs = g.GrapeHip(pr["H0"][sl], pr["Hc"], tl, pr["psi0"][sl], pr["target"][sl], pr["weights"][sl],
                                 functional=g.J_T_SM, device=dev.index)
