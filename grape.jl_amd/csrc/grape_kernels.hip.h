@@ -170,9 +170,16 @@ __device__ __forceinline__ void gemm_xb(Strip<NT> &acc, const double *__restrict
 template <int NT, int LD>
 __device__ __forceinline__ void gemm_dual13(Strip<NT> &T, Strip<NT> &V, const double *__restrict__ Xre,
                                             const double *__restrict__ Xim, const Strip<NT> &A2,
-                                            const Strip<NT> &A4, const Strip<NT> &A6, int lane) {
+                                            const Strip<NT> &A4, const Strip<NT> &A6, int wave, int lane) {
+    // 3M scheme (see gemm_xb3) without a third accumulator set per product: T and V arrive holding T0 and V0, and
+    //   T.re accumulates T0.re + sum P1,   T.im accumulates T0.im + sum P3,   t2 = sum P2   (likewise V, v2);
+    // at the end re = T.re - t2 and im = T.im - (T.re - T0.re) - t2, with T0.re formed again from the A2/A4/A6 strips
+    // that are live anyway.  6 NT instead of 8 NT MFMAs per k-step for 2 NT extra accumulator tiles.
     const double *__restrict__ xr = Xre + (lane & 15) * LD + (lane >> 4);
     const double *__restrict__ xi = Xim + (lane & 15) * LD + (lane >> 4);
+    d4 t2[NT], v2[NT];
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr) { t2[tr] = (d4){0., 0., 0., 0.}; v2[tr] = (d4){0., 0., 0., 0.}; }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -181,7 +188,7 @@ __device__ __forceinline__ void gemm_dual13(Strip<NT> &T, Strip<NT> &V, const do
             const double wi = B13_13 * A6.im[t][r] + B13_11 * A4.im[t][r] + B13_9 * A2.im[t][r];
             const double zr = B13_12 * A6.re[t][r] + B13_10 * A4.re[t][r] + B13_8 * A2.re[t][r];
             const double zi = B13_12 * A6.im[t][r] + B13_10 * A4.im[t][r] + B13_8 * A2.im[t][r];
-            const double nwi = -wi, nzi = -zi;
+            const double ws = wr + wi, zs = zr + zi;
             double are[NT], aim[NT];
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr) {
@@ -191,18 +198,33 @@ __device__ __forceinline__ void gemm_dual13(Strip<NT> &T, Strip<NT> &V, const do
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr) {
                 T.re[tr] = MFMA64(are[tr], wr, T.re[tr]);
-                T.im[tr] = MFMA64(are[tr], wi, T.im[tr]);
                 V.re[tr] = MFMA64(are[tr], zr, V.re[tr]);
-                V.im[tr] = MFMA64(are[tr], zi, V.im[tr]);
             }
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr) {
-                T.re[tr] = MFMA64(aim[tr], nwi, T.re[tr]);
-                T.im[tr] = MFMA64(aim[tr], wr, T.im[tr]);
-                V.re[tr] = MFMA64(aim[tr], nzi, V.re[tr]);
-                V.im[tr] = MFMA64(aim[tr], zr, V.im[tr]);
+                t2[tr] = MFMA64(aim[tr], wi, t2[tr]);
+                v2[tr] = MFMA64(aim[tr], zi, v2[tr]);
+            }
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) {
+                const double as = are[tr] + aim[tr];
+                T.im[tr] = MFMA64(as, ws, T.im[tr]);
+                V.im[tr] = MFMA64(as, zs, V.im[tr]);
             }
         }
+    }
+    const int cl = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr) {
+        d4 t0 = B13_7 * A6.re[tr] + B13_5 * A4.re[tr] + B13_3 * A2.re[tr];   // T0.re, V0.re once more
+        d4 v0 = B13_6 * A6.re[tr] + B13_4 * A4.re[tr] + B13_2 * A2.re[tr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (tr == wave && (4 * r + rg) == cl) { t0[r] += B13_1; v0[r] += B13_0; }
+        T.im[tr] = T.im[tr] - T.re[tr] + t0 - t2[tr];
+        T.re[tr] = T.re[tr] - t2[tr];
+        V.im[tr] = V.im[tr] - V.re[tr] + v0 - v2[tr];
+        V.re[tr] = V.re[tr] - v2[tr];
     }
 }
 
@@ -1186,7 +1208,7 @@ __device__ __forceinline__ void expm_poly(const ExpmArgs &a, const int wave, con
         strip_add_identity<NT>(T, B13_1, wave, lane);
         strip_add_identity<NT>(V, B13_0, wave, lane);
         STAMP(stamp0 + 4);
-        gemm_dual13<NT, LD>(T, V, Xre, Xim, A2, A4, A6, lane);
+        gemm_dual13<NT, LD>(T, V, Xre, Xim, A2, A4, A6, wave, lane);
         STAMP(stamp0 + 5);
         Strip<NT> Uo;
         strip_zero(Uo);
