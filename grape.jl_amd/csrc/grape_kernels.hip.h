@@ -1018,6 +1018,80 @@ __device__ __forceinline__ void expm_form_a(const ExpmArgs &a, const int cell, d
     }
 }
 
+// Hermitian generators, NP = 64: A = -i dt H is skew-Hermitian, so only the 10 tiles (16 x 16) on and above the block
+// diagonal are fetched (1280 instead of 2048 element pairs per plane and operator: the routine is bound by what a CU
+// can pull from L2 per cell) and every off-diagonal tile is written twice, a_ji = -conj(a_ij).
+__device__ __forceinline__ void expm_form_a_herm64(const ExpmArgs &a, const int cell, double *smem, const int t) {
+    using LY = ExpmLds<4>;
+    constexpr int NP = LY::NP, LD = LY::LD, NTH = LY::NTH;
+    double *Are = smem, *Aim = Are + NP * LD;
+    const int kc = cell / a.N_T, n = cell - kc * a.N_T;
+    const int k = a.rep ? a.rep[kc] : kc;
+    const double dt = a.dts[n];
+    const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
+    const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
+    constexpr int HALF = NP * NP / 2;  // double2 elements per plane
+    double e[8];
+    for (int l = 0; l < a.L; ++l) {
+        e[l] = a.eps[(size_t)l * a.N_T + n];
+        if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
+    }
+    // 10 tiles x 128 element pairs = 1280 = 5 per thread; tile q -> (ti, tj), ti <= tj, row by row
+    constexpr int NU = 5;
+    int off[NU], ii[NU], jj[NU];
+    bool diag[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int ep = t + u * NTH, q = ep >> 7, idx = ep & 127;
+        const int ti = q < 4 ? 0 : (q < 7 ? 1 : (q < 9 ? 2 : 3));
+        const int tj = q < 4 ? q : (q < 7 ? q - 3 : (q < 9 ? q - 5 : 3));
+        ii[u] = 16 * ti + (idx >> 3);
+        jj[u] = 16 * tj + 2 * (idx & 7);
+        off[u] = (ii[u] * NP + jj[u]) >> 1;
+        diag[u] = ti == tj;
+    }
+    double2 hr[NU], hi[NU], c0r[NU], c0i[NU], c1r[NU], c1i[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { hr[u] = h0[off[u]]; hi[u] = h0[HALF + off[u]]; }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { c0r[u] = hc[off[u]]; c0i[u] = hc[HALF + off[u]]; }
+    if (a.L > 1) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { c1r[u] = hc[(size_t)2 * HALF + off[u]]; c1i[u] = hc[(size_t)2 * HALF + HALF + off[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        hr[u].x = fma(e[0], c0r[u].x, hr[u].x); hr[u].y = fma(e[0], c0r[u].y, hr[u].y);
+        hi[u].x = fma(e[0], c0i[u].x, hi[u].x); hi[u].y = fma(e[0], c0i[u].y, hi[u].y);
+    }
+    if (a.L > 1) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            hr[u].x = fma(e[1], c1r[u].x, hr[u].x); hr[u].y = fma(e[1], c1r[u].y, hr[u].y);
+            hi[u].x = fma(e[1], c1i[u].x, hi[u].x); hi[u].y = fma(e[1], c1i[u].y, hi[u].y);
+        }
+    }
+    for (int l = 2; l < a.L; ++l) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const double2 cr = hc[(size_t)l * 2 * HALF + off[u]], ci = hc[(size_t)l * 2 * HALF + HALF + off[u]];
+            hr[u].x = fma(e[l], cr.x, hr[u].x); hr[u].y = fma(e[l], cr.y, hr[u].y);
+            hi[u].x = fma(e[l], ci.x, hi[u].x); hi[u].y = fma(e[l], ci.y, hi[u].y);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = ii[u], j = jj[u];
+        const double ar0 = dt * hi[u].x, ar1 = dt * hi[u].y, ai0 = -dt * hr[u].x, ai1 = -dt * hr[u].y;
+        Are[i * LD + j] = ar0;  Are[i * LD + j + 1] = ar1;
+        Aim[i * LD + j] = ai0;  Aim[i * LD + j + 1] = ai1;
+        if (!diag[u]) {   // mirrored tile: a_ji = -conj(a_ij)
+            Are[j * LD + i] = -ar0;  Are[(j + 1) * LD + i] = -ar1;
+            Aim[j * LD + i] = ai0;   Aim[(j + 1) * LD + i] = ai1;
+        }
+    }
+}
+
 // partial column sums of |a_ij| for ||A||_1 = max_j sum_i |a_ij|: thread t of NP * parts threads covers column
 // t % NP over the rows i = t / NP (mod parts); red[t] receives the partial sum
 template <int NT>
@@ -1392,7 +1466,8 @@ __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, c
                 bound += fabs(a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0)) * n1c[l];
             bound *= a.dts[n] * (1.0 + 1e-12);
         }
-        expm_form_a<NT>(a, cell, smem, tid, LYY::NTH, 0, LYY::NP * LYY::NP / 2);
+        if constexpr (HERM && NT == 4) expm_form_a_herm64(a, cell, smem, tid);
+        else expm_form_a<NT>(a, cell, smem, tid, LYY::NTH, 0, LYY::NP * LYY::NP / 2);
         if (bound > 2.1 && bound <= 5.4) {
             if (tid == 0) (smem + 2 * LYY::REG + LYY::DV)[LYY::NTH] = bound;
             __syncthreads();
