@@ -167,6 +167,16 @@ def main():
     tm = h.timings()   # HIP-event averages over the timed region, recorded on the kernel stream
     work = h.work()
     J = ev.J_device()
+    allreduce_us = None
+    if dist is not None and world > 1:
+        # latency of the gradient all-reduce (L*N_T doubles): the collective is latency-bound,
+        # its bandwidth over xGMI is irrelevant at 16 KB
+        sync()
+        t_ar = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(G)
+        torch.cuda.synchronize(dev)
+        allreduce_us = (time.perf_counter() - t_ar) / 20 * 1e6
 
     if rank == 0:
         # HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes of tools/pmc.sh
@@ -211,6 +221,16 @@ def main():
                                  "the hardware MFMA-busy fraction (PMC, profiles/) is lower than achieved/peak",
                          "flop_model": "SURVEY 8d F_exp = (6+s)*8N^3 + (32/3)N^3 per Pade-13 cell"},
             "phases_ms": {k: round(v, 4) for k, v in tm.items() if v >= 0},
+            "phase_b": {"kernel": "sweep_pair_kernel (forward and backward sweep in one launch)",
+                        "algorithmic_bytes": 2.0 * K_local * N_T * (N * N * 16 + 3 * N * 16),
+                        "GB_per_s": 2.0 * K_local * N_T * (N * N * 16 + 3 * N * 16) / (tm["forward"] * 1e-3) * 1e-9
+                        if tm.get("forward", -1) > 0 else None, "bound": "hbm"},
+            "gradient_allreduce_latency_us": allreduce_us,
+            "w_eval_model": {"flop_per_eval": (170.0 + 2.0 / 3.0 + 24.0 * work["squarings"] / max(work["cells"], 1.0))
+                                              * float(N) ** 3 * work["cells"],
+                             "note": "BASELINE.md section 4 model (Pade exponential + one Frechet derivative of O(N^3) per "
+                                     "cell); this build obtains the derivative from O(N^2) series terms on the vectors, so "
+                                     "model flop / time is not a hardware rate and is not used for the roofline"},
             "deriv_kernel": {"flop_per_launch": work["flop_deriv"], "avg_launch_ms": tm["deriv"],
                              "tflops": work["flop_deriv"] / (tm["deriv"] * 1e-3) * 1e-12 if tm["deriv"] > 0 else None,
                              "series_orders_per_cell": work["deriv_orders"] / work["cells"]},
