@@ -90,6 +90,7 @@ struct grape_handle {
     bool z_valid = false;        // d_z belongs to the states in d_bw (grape_backward ran after the fused forward)
     double *d_inv_tnorm = nullptr, *d_ones = nullptr;
     double2 *d_z = nullptr;
+    int num_cus = 256;
     bool series = false;
     double *d_rb = nullptr;      // [K + Kc*L] 2-norm estimates of H0_k and of the control operators
     double series_tol = 1e-17, series_theta = 3.0;
@@ -178,9 +179,13 @@ hipError_t launch_sweep_pair(const SweepArgs &af, const SweepArgs &ab, hipStream
 }
 
 template <int NP>
-hipError_t launch_series_pair(const SeriesArgs &af, const SeriesArgs &ab, hipStream_t s) {
+hipError_t launch_series_pair(const SeriesArgs &af, const SeriesArgs &ab, bool stream_controls, hipStream_t s) {
     const dim3 grid(2 * af.s.K), block(NP * 16 / SERIES_RPT);
-    if (af.L == 1) hipLaunchKernelGGL((series_pair_kernel<NP, 1>), grid, block, 0, s, af, ab);
+    // more workgroups than CUs: the variant that streams the control operators from L2 needs half the registers, two
+    // workgroups share a CU and fill each other's latencies (K = 512 at N = 64: 29 instead of 38 ms); with a CU per
+    // workgroup the register-resident operators are faster (K = 128: 10.1 vs 11.6 ms)
+    if (stream_controls) hipLaunchKernelGGL((series_pair_kernel<NP, 0>), grid, block, 0, s, af, ab);
+    else if (af.L == 1) hipLaunchKernelGGL((series_pair_kernel<NP, 1>), grid, block, 0, s, af, ab);
     else if (af.L == 2) hipLaunchKernelGGL((series_pair_kernel<NP, 2>), grid, block, 0, s, af, ab);
     else hipLaunchKernelGGL((series_pair_kernel<NP, 0>), grid, block, 0, s, af, ab);
     return hipGetLastError();
@@ -600,6 +605,11 @@ int grape_create(grape_handle **out, const grape_problem *p) {
 
     CCHK(hipSetDevice(h->device));
     CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu > 0)
+            h->num_cus = ncu;
+    }
     {   // generator classes: bit-identical (H0_k, control operators of k) -> one set of propagators
         const size_t nb0 = (size_t)p->N * p->N * 16, nbc = p->hc_per_traj ? (size_t)p->L * p->N * p->N * 16 : 0;
         auto hash = [](const unsigned char *b, size_t n, unsigned long long hsh) {
@@ -951,8 +961,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         sb.store = h->d_bw; sb.tau = (double2 *)h->d_out; sb.f = nullptr; sb.unit_chi = 1; sb.inv_tnorm = h->d_inv_tnorm;
         if (h->series) {
             const SeriesArgs rf = series_args(h, sa, false), rb = series_args(h, sb, true);
-            e = h->NP == 16 ? launch_series_pair<16>(rf, rb, s) : h->NP == 32 ? launch_series_pair<32>(rf, rb, s)
-                                                                             : launch_series_pair<64>(rf, rb, s);
+            const bool sc = 2 * h->K > h->num_cus;
+            e = h->NP == 16 ? launch_series_pair<16>(rf, rb, sc, s) : h->NP == 32 ? launch_series_pair<32>(rf, rb, sc, s)
+                                                                                 : launch_series_pair<64>(rf, rb, sc, s);
         } else {
             e = h->NP == 16 ? launch_sweep_pair<16>(sa, sb, s) : h->NP == 32 ? launch_sweep_pair<32>(sa, sb, s)
                                                                             : launch_sweep_pair<64>(sa, sb, s);
