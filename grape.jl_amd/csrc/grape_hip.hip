@@ -249,11 +249,17 @@ double norm2_estimate(const double *M, int N) {
     return 1.1 * std::sqrt(sigma2);
 }
 
+#ifndef DERIV32_NTH
+#define DERIV32_NTH 128
+#endif
+#ifndef DERIV16_NTH
+#define DERIV16_NTH 64   // N <= 16: one wave per cell chain (4 columns per thread, quad reductions), many chains per CU
+#endif
 template <int NP>
 hipError_t launch_deriv(const DerivArgs &a, int nblocks, hipStream_t s) {
     // 512 threads (8 column chunks per row) at N = 64: half the register tile per thread, so that
     // two blocks (4 waves per SIMD) hide the LDS broadcast latency; 256 threads otherwise.
-    constexpr int NTH = NP == 64 ? 512 : 256;
+    constexpr int NTH = NP == 64 ? 512 : (NP == 16 ? DERIV16_NTH : DERIV32_NTH);
     // the series kernel is instantiated per control count: zero-padded controls would cost real FMAs
     switch (a.L) {
         case 1: hipLaunchKernelGGL((deriv_kernel<NP, 1, NTH>), dim3(nblocks), dim3(NTH), 0, s, a); break;
