@@ -934,7 +934,9 @@ struct ExpmLds {
     static constexpr int NSLOT = NT < 3 ? NT : 3;
     static constexpr int SLOTS = NSLOT * 2 * NP * 18;
     static constexpr int REG = PLANES > SLOTS ? PLANES : SLOTS;   // doubles per region
-    static constexpr int DV = 2048;                               // 3 rotating inverse slots (1536); exchange area of the Hermitian path (2048)
+    // inverse slots of the Gauss-Jordan solve (512 doubles each, min(NT, 3) in use); NT = 4 also keeps the exchange
+    // area of the Hermitian path here (2048).  The small kernels are latency-bound: less LDS = more cells per CU.
+    static constexpr int DV = NT < 4 ? NSLOT * 512 : 2048;
     static constexpr int RED = NTH + 8 + NP;
     static constexpr int TOTAL = 2 * REG + DV + RED;              // doubles
 };
