@@ -73,19 +73,63 @@ class ShapedAmplitude:
         self.shape = shape
 
 
+class NonlinearAmplitude:
+    """Control amplitude a(eps, t) = S(t) f(eps(t)) with a non-linear dependence on the optimisable control (the
+    reference obtains mu = dH/d eps from ``get_control_derivs``, src/workspace.jl:286; docs/src/background.md:402).
+    The kernels see the values f(eps_nl) as their pulse (and S as the shape); the gradient with respect to eps
+    follows from the chain rule, dJ/d eps_nl = f'(eps_nl) dJ/d f_nl, applied on the host."""
+
+    def __init__(self, control, func, dfunc, shape=None):
+        self.control = control
+        self.func = func
+        self.dfunc = dfunc
+        self.shape = shape
+
+
+class _AmplitudeBackend:
+    """Wraps a backend whose pulse values are the amplitudes f_l(eps): maps eps -> f(eps) on the way in and applies
+    the chain rule to the gradient on the way out."""
+
+    def __init__(self, inner, funcs, dfuncs, N_T):
+        self.inner, self.funcs, self.dfuncs, self.N_T = inner, funcs, dfuncs, N_T
+
+    def _map(self, x, fs):
+        out = np.array(x, dtype=np.float64, copy=True)
+        for l, f in enumerate(fs):
+            if f is not None:
+                seg = slice(l * self.N_T, (l + 1) * self.N_T)
+                out[seg] = np.vectorize(f, otypes=[np.float64])(x[seg])
+        return out
+
+    def eval(self, x, gradient=True, want_psiT=False):
+        res = list(self.inner.eval(self._map(x, self.funcs), gradient=gradient, want_psiT=want_psiT))
+        if gradient and res[1] is not None:
+            d = self._map(x, self.dfuncs)
+            for l, f in enumerate(self.dfuncs):
+                if f is None:
+                    d[l * self.N_T:(l + 1) * self.N_T] = 1.0
+            res[1] = res[1] * d
+        return tuple(res)
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+
 def hamiltonian(H0, *terms):
     """``hamiltonian(H0, (H1, eps1), (H2, eps2), ...)``: H(t) = H0 + sum_l a_l(t) H_l, a_l a control or a
     ``ShapedAmplitude`` of one."""
-    ops, ctrls, shapes = [], [], []
+    ops, ctrls, shapes, nonlinear = [], [], [], {}
     for op, ctrl in terms:
         ops.append(np.asarray(op, dtype=np.complex128))
-        if isinstance(ctrl, ShapedAmplitude):
+        if isinstance(ctrl, (ShapedAmplitude, NonlinearAmplitude)):
             ctrls.append(ctrl.control)
             shapes.append(ctrl.shape)
+            if isinstance(ctrl, NonlinearAmplitude):
+                nonlinear[id(ctrl.control)] = (ctrl.func, ctrl.dfunc)
         else:
             ctrls.append(ctrl)
             shapes.append(None)
-    return Generator(np.asarray(H0, dtype=np.complex128), ops, ctrls, shapes)
+    return Generator(np.asarray(H0, dtype=np.complex128), ops, ctrls, shapes, nonlinear)
 
 
 @dataclass
@@ -94,6 +138,7 @@ class Generator:
     ops: List[np.ndarray]
     controls: list
     shapes: list = None   # per term: None or the static shape S(t) of a ShapedAmplitude
+    nonlinear: dict = None  # id(control) -> (f, f') for controls that enter through a NonlinearAmplitude
 
 
 @dataclass
@@ -259,7 +304,13 @@ class GrapeWrk:
                 "series": api.PROP_SERIES}.get(str(pm).lower().lstrip(":"))
         if prop is None:
             raise ValueError(f"prop_method={pm!r} not in (ExpProp, Cheby, Newton, series)")
-        return api.GrapeHip(H0, Hc, self.tlist, np.stack([t.initial_state for t in trajs]),
+        funcs, dfuncs = [], []
+        for c in self.controls:
+            fd = [t.generator.nonlinear[id(c)] for t in trajs if t.generator.nonlinear and id(c) in t.generator.nonlinear]
+            funcs.append(fd[0][0] if fd else None)
+            dfuncs.append(fd[0][1] if fd else None)
+        wrap = (lambda b: _AmplitudeBackend(b, funcs, dfuncs, self.N_T)) if any(f is not None for f in funcs) else (lambda b: b)
+        return wrap(api.GrapeHip(H0, Hc, self.tlist, np.stack([t.initial_state for t in trajs]),
                             np.stack([t.target_state for t in trajs]),
                             prop_method=prop, prop_tolerance=self.kwargs.get("prop_tolerance", 0.0), shape=shape,
                             weights=np.array([t.weight for t in trajs], dtype=np.float64),
@@ -270,7 +321,7 @@ class GrapeWrk:
                             device=self.kwargs.get("device", 0),
                             # g_b / xi of the expectation-value family (test_state_running_cost.jl:32-40):
                             # g_b = <Psi|D|Psi>, xi = -D Psi, given as the operator D itself
-                            D=self.kwargs.get("state_penalty"), lambda_b=self.kwargs.get("lambda_b", 1.0))
+                            D=self.kwargs.get("state_penalty"), lambda_b=self.kwargs.get("lambda_b", 1.0)))
 
 
 def _split_functional(wrk, J, tau):

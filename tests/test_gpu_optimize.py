@@ -215,3 +215,32 @@ def test_stirap_state_running_cost_suppresses_intermediate_population():
     assert res3.converged and res3.iter > res1.iter + 10 and res3.J_b > 0.0
     P3 = pmax2(res3)
     assert abs(P3 - P2) / P3 < 0.15
+
+
+def test_nonlinear_amplitude_chain_rule_and_optimization():
+    """A control that enters the Hamiltonian non-linearly, a(eps) = A tanh(eps / A) (a saturating drive; the reference
+    handles mu = dH/d eps of non-linear controls through get_control_derivs, src/workspace.jl:286): the gradient with
+    respect to eps (chain rule on the host over the kernels' dJ/da) against central finite differences, then an
+    optimisation whose physical amplitude never exceeds the saturation value."""
+    from grape_jl_amd import grape as G
+    sx, sz = np.array([[0, 1], [1, 0]], complex), np.array([[1, 0], [0, -1]], complex)
+    A = 0.6
+    amp = G.NonlinearAmplitude(lambda t: 0.2 * flattop(t), func=lambda e: A * np.tanh(e / A),
+                               dfunc=lambda e: 1.0 / np.cosh(e / A) ** 2)
+    tlist = np.linspace(0, 5, 201)
+    traj = G.Trajectory(np.array([1, 0], complex), G.hamiltonian(-0.5 * sz, (sx, amp)), target_state=np.array([0, 1], complex))
+    wrk = G.GrapeWrk([traj], tlist, J_T=G.J_T_sm)
+    x = wrk.pulsevals + 0.3                                   # away from the linear regime
+    Gv = np.zeros_like(x)
+    G.evaluate_gradient_b(Gv, x, wrk)
+    for idx in (0, 57, 199):
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += 1e-6
+        xm[idx] -= 1e-6
+        fd = (G.evaluate_functional(xp, wrk) - G.evaluate_functional(xm, wrk)) / 2e-6
+        assert abs(fd - Gv[idx]) <= 1e-8 + 1e-6 * abs(Gv[idx])
+    res = G.optimize([traj], tlist, J_T=G.J_T_sm, iter_stop=30,
+                     check_convergence=lambda r: "J_T < 10^-3" if r.J_T < 1e-3 else "")
+    assert res.converged and res.J_T < 1e-3
+    phys = A * np.tanh(np.asarray(res.optimized_controls[0]) / A)
+    assert np.abs(phys).max() < A
