@@ -167,6 +167,11 @@ hipError_t launch_coop(const SweepArgs &a, bool backward, int S, int rpw, int nw
 
 template <int NP>
 hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s) {
+    if (NP == 16) {   // one wave per trajectory, no barriers in the time loop
+        if (backward) hipLaunchKernelGGL((sweep16_kernel<true>), dim3(a.K), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((sweep16_kernel<false>), dim3(a.K), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
     if (backward) hipLaunchKernelGGL((sweep_kernel<NP, true>), dim3(a.K), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((sweep_kernel<NP, false>), dim3(a.K), dim3(256), 0, s, a);
     return hipGetLastError();
@@ -174,7 +179,8 @@ hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s) {
 
 template <int NP>
 hipError_t launch_sweep_pair(const SweepArgs &af, const SweepArgs &ab, hipStream_t s) {
-    hipLaunchKernelGGL((sweep_pair_kernel<NP>), dim3(2 * af.K), dim3(256), 0, s, af, ab);
+    if (NP == 16) hipLaunchKernelGGL(sweep16_pair_kernel, dim3(2 * af.K), dim3(64), 0, s, af, ab);
+    else hipLaunchKernelGGL((sweep_pair_kernel<NP>), dim3(2 * af.K), dim3(256), 0, s, af, ab);
     return hipGetLastError();
 }
 

@@ -1822,6 +1822,121 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return readlane_f64(v, 0) + readlane_f64(v, 16) + readlane_f64(v, 32) + readlane_f64(v, 48);
 }
 
+// ---------------------------------------------------------------------------------------
+// Sweeps for N <= 16 (NP = 16): ONE wave per trajectory and direction, no workgroup barrier in the time loop.
+// A step of the general sweep_kernel costs two barriers and an LDS round trip for 256 threads of which 16 lanes
+// carry data -- 1.1 us per step whatever the size; here lane (row r = lane >> 2, chunk c = lane & 3) holds four
+// entries of U_n (forward: U[r][4c..4c+3]; backward: U[4c..4c+3][r], so that both directions are "4 products per
+// lane, quad sum"), the four chunks of a row meet through two DPP quad permutes, and the state goes through 256 bytes
+// of LDS that only this wave touches (a wave's LDS operations are ordered: no barrier).  The tile of step n+1 and
+// n+2 is requested while step n is reduced.
+// ---------------------------------------------------------------------------------------
+template <bool BACKWARD>
+__device__ __forceinline__ void sweep16_body(const SweepArgs &a, const int k, double2 *xs /* [16] LDS, this wave's */) {
+    constexpr int NP = 16;
+    const int lane = threadIdx.x & 63;
+    const int r = lane >> 2, c = lane & 3;
+    const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
+    double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
+    // ---- boundary state: lanes 0..15 hold element `lane` ----
+    double rho = 1.0;
+    {
+        double2 v = make_double2(0., 0.);
+        if (!BACKWARD) {
+            if (lane < a.N) v = a.psi0[(size_t)k * a.N + lane];
+        } else {
+            double cr, ci;
+            chi_coefficient(a, k, cr, ci);
+            if (lane < a.N) {
+                const double2 t = a.target[(size_t)k * a.N + lane];
+                v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+                if (a.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)   (optimize.jl:856-866)
+                    const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + a.N_T) * NP + lane];
+                    const double cc = a.lambda_b * a.wq[a.N_T];
+                    v.x += cc * x_.x; v.y += cc * x_.y;
+                }
+            }
+            rho = sqrt(wave_sum(lane < NP ? v.x * v.x + v.y * v.y : 0.));
+            if (lane == 0 && !a.unit_chi) {
+                a.rho[k] = rho;
+                if (rho < a.chi_min_norm) atomicOr(&a.flags[0], 2);
+            }
+            const double ir = rho > 0. ? 1.0 / rho : 0.;
+            v.x *= ir; v.y *= ir;
+        }
+        if (lane < NP) {
+            xs[lane] = v;
+            st[(size_t)(BACKWARD ? a.N_T : 0) * NP + lane] = v;
+        }
+    }
+    // tile loads: forward row r, columns 4c..4c+3 (64 contiguous bytes); backward rows 4c..4c+3 of column r
+    auto load_tile = [&](double2 (&dst)[4], int step) __attribute__((always_inline)) {
+        const int nn = BACKWARD ? a.N_T - 1 - step : step;
+        const double2 *Un = Uk + (size_t)nn * NP * NP;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dst[m] = BACKWARD ? Un[(4 * c + m) * NP + r] : Un[r * NP + 4 * c + m];
+    };
+    double2 u0[4], u1[4], u2[4];
+    load_tile(u1, 0);
+    if (a.N_T > 1) load_tile(u2, 1);
+    double2 y = make_double2(0., 0.);
+    for (int step = 0; step < a.N_T; ++step) {
+        const int n = BACKWARD ? a.N_T - 1 - step : step;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { u0[m] = u1[m]; u1[m] = u2[m]; }
+        if (step + 2 < a.N_T) load_tile(u2, step + 2);
+        double pr = 0., pi = 0.;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const double2 x = xs[4 * c + m];
+            if (!BACKWARD) {   // U x
+                pr = fma(u0[m].x, x.x, pr); pr = fma(-u0[m].y, x.y, pr);
+                pi = fma(u0[m].x, x.y, pi); pi = fma(u0[m].y, x.x, pi);
+            } else {           // conj(U) x
+                pr = fma(u0[m].x, x.x, pr); pr = fma(u0[m].y, x.y, pr);
+                pi = fma(u0[m].x, x.y, pi); pi = fma(-u0[m].y, x.x, pi);
+            }
+        }
+        pr = group_sum<4>(pr);
+        pi = group_sum<4>(pi);
+        if (BACKWARD && a.xi && n > 0) {   // chi(t_n) += lambda_b Dt_n / rho_k xi_k(t_n)   (optimize.jl:897-908)
+            const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + n) * NP + r];
+            const double cc = a.lambda_b * a.wq[n] / rho;
+            pr += cc * x_.x; pi += cc * x_.y;
+        }
+        y = make_double2(pr, pi);
+        if (c == 0) {
+            xs[r] = y;     // in order behind this wave's reads of the previous state
+            st[(size_t)(BACKWARD ? n : n + 1) * NP + r] = y;
+        }
+    }
+    if (!BACKWARD) {
+        // tau_k = <target_k | Psi_k(T)>  (optimize.jl:753)
+        double pr = 0., pi = 0.;
+        if (lane < a.N) {
+            const double2 t = a.target[(size_t)k * a.N + lane];
+            const double2 p = xs[lane];
+            pr = t.x * p.x + t.y * p.y;
+            pi = t.x * p.y - t.y * p.x;
+        }
+        pr = wave_sum(pr);
+        pi = wave_sum(pi);
+        if (lane == 0) a.tau[k] = make_double2(pr, pi);
+    }
+}
+
+template <bool BACKWARD>
+__global__ void __launch_bounds__(64) sweep16_kernel(SweepArgs a) {
+    __shared__ double2 xs[16];
+    sweep16_body<BACKWARD>(a, blockIdx.x, xs);
+}
+__global__ void __launch_bounds__(64) sweep16_pair_kernel(SweepArgs af, SweepArgs ab) {
+    __shared__ double2 xs[16];
+    if ((int)blockIdx.x < af.K) sweep16_body<false>(af, blockIdx.x, xs);
+    else sweep16_body<true>(ab, blockIdx.x - af.K, xs);
+}
+
+
 template <int NP, int LMAX, int NTH>
 __global__ void __launch_bounds__(NTH) deriv_kernel(DerivArgs a) {
     constexpr int NCH = NTH / NP;      // column chunks per row = adjacent lanes (<= 16)
