@@ -93,3 +93,29 @@ def test_exception_is_captured_in_message():
     assert res.message.startswith("Exception:") and "boom" in res.message  # src/optimize.jl:125-135
     with pytest.raises(RuntimeError):
         G.optimize(trajs, tl, backend=Boom(), J_T=G.J_T_sm, rethrow_exceptions=True)
+
+
+def test_amplitude_wrapper_chain_rule_and_j_parts_split():
+    """Host logic of the non-linear amplitudes (chain rule over the evaluator's gradient) and of the J_T / J_b
+    bookkeeping, with the oracle standing in for the HIP library."""
+    trajs, tl, be = tls(lambda t: 0.2, nt=41)
+    N_T = len(tl) - 1
+    A = 0.5
+    wrapped = G._AmplitudeBackend(be, [lambda e: A * np.tanh(e / A)], [lambda e: 1.0 / np.cosh(e / A) ** 2], N_T)
+    x = 0.4 + 0.1 * np.sin(np.arange(N_T))
+    J, g, tau = wrapped.eval(x)
+    for idx in (0, 17, N_T - 1):
+        xp, xm = x.copy(), x.copy()
+        xp[idx] += 1e-6
+        xm[idx] -= 1e-6
+        fd = (wrapped.eval(xp, gradient=False)[0] - wrapped.eval(xm, gradient=False)[0]) / 2e-6
+        assert abs(fd - g[idx]) <= 1e-8
+    # the amplitudes the evaluator sees never exceed the saturation value
+    assert np.abs(wrapped._map(x * 100, wrapped.funcs)).max() <= A
+    # J_parts: J_T from tau, nothing attributed to a state running cost that is not there
+    wrk = G.GrapeWrk(trajs, tl, backend=be, J_T=G.J_T_sm)
+    Gv = np.zeros(N_T)
+    Jtot = G.evaluate_gradient_b(Gv, wrk.pulsevals, wrk)
+    assert abs(wrk.J_parts[0] - Jtot) <= 1e-14 and wrk.J_parts[2] == 0.0
+    G.update_result(wrk, 0)
+    assert wrk.result.J_b == 0.0 and abs(wrk.result.J_T - Jtot) <= 1e-14
