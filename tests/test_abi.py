@@ -54,3 +54,35 @@ def test_product_path_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "grape_oracle" not in text and "grape_ref" not in text and "oracle/" not in text.replace(
                     "oracle/ ", ""), f"{f} references the oracle"
+
+
+def test_problem_struct_layout_matches_the_header(tmp_path):
+    """sizeof / offsetof of every grape_problem field as the C compiler lays it out (include/grape_hip.h) against the
+    ctypes mirror in api.py, and the field list of the Julia mirror (julia/GrapeHIP.jl) against both."""
+    import subprocess
+    from grape_jl_amd import api
+    fields = [f[0] for f in api._Problem._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "grape_hip.h")}"',
+             'int main(void) {', '  printf("%zu\\n", sizeof(grape_problem));']
+    lines += [f'  printf("{f} %zu\\n", offsetof(grape_problem, {f}));' for f in fields]
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert int(out[0]) == ctypes.sizeof(api._Problem)
+    for line in out[1:]:
+        if line.strip():
+            name, off = line.split()
+            assert getattr(api._Problem, name).offset == int(off), name
+    # header field order == ctypes field order == Julia struct field order
+    hdr = open(os.path.join(ROOT, "include", "grape_hip.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", hdr[hdr.index("typedef struct {"):hdr.index("} grape_problem;")], flags=re.S)
+    hdr_fields = re.findall(r"\b(\w+)\s*;", body)
+    assert hdr_fields == fields
+    jl = open(os.path.join(ROOT, "julia", "GrapeHIP.jl")).read()
+    jbody = jl[jl.index("struct GrapeProblem"):]
+    jbody = jbody[:jbody.index("\nend")]
+    jl_fields = re.findall(r"^\s+(\w+)::", jbody, flags=re.M)
+    assert jl_fields == fields
