@@ -7,7 +7,7 @@ Only what the path needs:
 * ``grape``      host-side mirror of the reference interface for this path
                  (``Trajectory``, ``GrapeWrk``, ``evaluate_functional``, ``evaluate_gradient_b``,
                  ``optimize``; /root/reference/src/optimize.jl, src/workspace.jl)
-* ``functionals`` ``J_T_sm / J_T_ss / J_T_re`` + ``chi`` constructors used by the mirror
+* ``sharded``   trajectory shards over ``torch.distributed`` (one process per GPU, RCCL)
 * ``synth``      deterministic synthetic problems of BASELINE.json (SplitMix64 + Box-Muller)
 """
 from . import synth  # noqa: F401

@@ -20,7 +20,7 @@ _LIBNAME = "libgrape_hip.so"
 J_T_SM, J_T_SS, J_T_RE = 0, 1, 2
 GRAD_GRADGEN, GRAD_TAYLOR = 0, 1
 PROP_EXP, PROP_SERIES = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAPE_ERR_CHI_NORM",
           -4: "GRAPE_ERR_SINGULAR", -5: "GRAPE_ERR_TAYLOR", -6: "GRAPE_ERR_NO_CONTROLS"}
@@ -29,7 +29,8 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAP
 EXPORTS = ["grape_create", "grape_destroy", "grape_eval", "grape_forward", "grape_backward",
            "grape_forward_device", "grape_backward_device", "grape_check", "grape_get_propagator",
            "grape_get_tau_grads", "grape_get_storage", "grape_get_timings", "grape_reset_timings", "grape_get_work",
-           "grape_last_error", "grape_abi_version", "grape_set_fused_sweeps"]
+           "grape_last_error", "grape_abi_version", "grape_set_fused_sweeps", "grape_get_sums",
+           "grape_get_final_states", "grape_backward_chi"]
 
 
 class GrapeHipError(RuntimeError):
@@ -47,7 +48,8 @@ class _Problem(C.Structure):
                 ("chi_min_norm", C.c_double), ("taylor_max_order", C.c_int32),
                 ("taylor_tolerance", C.c_double),
                 ("Dpen", C.c_void_p), ("dpen_per_traj", C.c_int32), ("lambda_b", C.c_double),
-                ("prop_method", C.c_int32), ("prop_tolerance", C.c_double)]
+                ("prop_method", C.c_int32), ("prop_tolerance", C.c_double),
+                ("ndev", C.c_int32), ("devices", C.c_void_p)]
 
 
 def library_path() -> str:
@@ -108,6 +110,9 @@ def load_library():
     lib.grape_get_work.argtypes = [vp, vp, ip]
     lib.grape_reset_timings.argtypes = [vp]
     lib.grape_set_fused_sweeps.argtypes = [vp, ip]
+    lib.grape_get_sums.argtypes = [vp, vp]
+    lib.grape_get_final_states.argtypes = [vp, vp]
+    lib.grape_backward_chi.argtypes = [vp, vp, vp]
     lib.grape_last_error.argtypes = [vp]
     lib.grape_last_error.restype = C.c_char_p
     lib.grape_abi_version.restype = ip
@@ -128,20 +133,32 @@ class GrapeHip:
     H0: [K, N, N] complex, ``H0[k][i, j]`` (row, column);  Hc: [L, N, N] or [K, L, N, N];
     psi0/target: [K, N];  tlist: [N_T+1];  pulsevals: control-major [L*N_T].
     The C ABI wants Julia's column-major matrices, so matrices are transposed on the way in.
+    ``devices``: a list of HIP device ordinals puts contiguous blocks of the K trajectories on several GPUs behind this
+    one handle (``grape_problem.ndev``); the host-pointer calls then drive all of them.
     """
 
     def __init__(self, H0, Hc, tlist, psi0, target, weights=None, functional=J_T_SM,
                  gradient_method=GRAD_GRADGEN, shape=None, K_total=None, device=0,
                  chi_min_norm=0.0, taylor_max_order=0, taylor_tolerance=0.0, D=None, lambda_b=0.0,
-                 prop_method=PROP_EXP, prop_tolerance=0.0):
+                 prop_method=PROP_EXP, prop_tolerance=0.0, devices=None):
         self._lib = load_library()
         H0 = np.asarray(H0)
+        if H0.ndim != 3 or H0.shape[1] != H0.shape[2]:
+            raise ValueError(f"H0 must be [K, N, N], got {H0.shape}")
         K, N = H0.shape[0], H0.shape[1]
         Hc = np.asarray(Hc)
         per_traj = Hc.ndim == 4
+        if Hc.ndim not in (3, 4) or Hc.shape[-2:] != (N, N) or (per_traj and Hc.shape[0] != K):
+            raise ValueError(f"Hc must be [L, N, N] or [K, L, N, N] with N = {N}, K = {K}, got {Hc.shape}")
         L = Hc.shape[1] if per_traj else Hc.shape[0]
         tlist = np.ascontiguousarray(tlist, dtype=np.float64)
+        if tlist.ndim != 1 or len(tlist) < 2:
+            raise ValueError("tlist must hold at least two time points")
         N_T = len(tlist) - 1
+        if weights is not None and np.shape(weights) != (K,):
+            raise ValueError(f"weights must be [K] = [{K}], got {np.shape(weights)}")
+        if D is not None and np.shape(D) not in ((N, N), (K, N, N)):
+            raise ValueError(f"D must be [N, N] or [K, N, N] with N = {N}, K = {K}, got {np.shape(D)}")
         self.N, self.L, self.K, self.N_T = N, L, K, N_T
         self.K_total = K if K_total is None else int(K_total)
         self.functional = functional
@@ -176,6 +193,11 @@ class GrapeHip:
             p.Dpen = self._D.ctypes.data
             p.dpen_per_traj = int(D.ndim == 3)
             p.lambda_b = self.lambda_b
+        self._devices = None
+        if devices is not None and len(devices) > 1:
+            self._devices = np.ascontiguousarray(devices, dtype=np.int32)
+            p.ndev = len(self._devices)
+            p.devices = self._devices.ctypes.data
         self._h = C.c_void_p()
         rc = self._lib.grape_create(C.byref(self._h), C.byref(p))
         if rc:
@@ -229,6 +251,27 @@ class GrapeHip:
         f = np.array([np.real(f_total), np.imag(f_total)], dtype=np.float64)
         G = np.empty(self.L * self.N_T)
         self._chk(self._lib.grape_backward(self._h, f.ctypes.data, G.ctypes.data))
+        return G
+
+    def sums(self):
+        """Partial sums of this handle's trajectories after ``forward``: [Re f, Im f, sum w|tau|^2, Re sum w tau,
+        sum_k J_b,k, 0, 0, 0] (grape_get_sums)."""
+        out = np.zeros(8)
+        self._chk(self._lib.grape_get_sums(self._h, out.ctypes.data))
+        return out
+
+    def final_states(self):
+        """Psi_k(T) of the last forward sweep, [K, N] (grape_get_final_states)."""
+        out = np.empty((self.K, self.N), dtype=np.complex128)
+        self._chk(self._lib.grape_get_final_states(self._h, out.ctypes.data))
+        return out
+
+    def backward_chi(self, chi):
+        """Backward half from caller-supplied boundary states chi_k(T) = -dJ_T/d<Psi_k(T)| ([K, N], not normalised;
+        the return value of the reference's ``chi(Psi, trajectories; tau)``, optimize.jl:845-855)."""
+        chi = _c128(chi, (self.K, self.N))
+        G = np.empty(self.L * self.N_T)
+        self._chk(self._lib.grape_backward_chi(self._h, chi.ctypes.data, G.ctypes.data))
         return G
 
     # -- device-pointer API (torch tensors on the handle's device) -----------------------------

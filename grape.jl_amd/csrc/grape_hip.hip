@@ -39,9 +39,6 @@ struct grape_handle {
     double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;
     double *d_H0q = nullptr, *d_Hcq = nullptr, *d_park2 = nullptr;   // two-pass series kernel: untransposed fragments, parking area
     int deriv2 = 0, deriv2_maxm = 0;
-    int *d_lowflag = nullptr;   // cells the two-workgroup order-13 kernel leaves to the general kernel
-    double *d_spill = nullptr;  // its strip spill area [512][5][32][256]
-    bool use_2wg = false;  // MFMA-fragment-packed H^dagger, series scratch
     int deriv_blocks = 0;
     // blocked path (64 < N <= 256): per-chunk scratch matrices, planar [cell][2][NP*NP]
     bool large = false;
@@ -98,6 +95,13 @@ struct grape_handle {
     double2 *d_gpark = nullptr;  // [K][N_T][maxp][NP] terms of the forward series, consumed by deriv2_kernel
     int *d_morder = nullptr;     // [K][N_T]
     int maxp = 0;
+    double2 *d_chi_in = nullptr; // [K][N] host-supplied boundary states of grape_backward_chi (allocated on first use)
+    // several GPUs behind one handle (grape_problem.ndev > 1): this handle owns no device memory, its trajectories
+    // are dealt to the child handles in contiguous blocks [shard_lo[g], shard_lo[g+1])
+    std::vector<grape_handle *> shards;
+    std::vector<int> shard_lo;
+    std::vector<int> shard_dev;
+    std::vector<double> h_multi;   // host scratch of the composite: pulses, per-shard gradients
 };
 
 namespace {
@@ -533,6 +537,23 @@ int status_from_flags(grape_handle *h, int flags) {
     return GRAPE_OK;
 }
 
+// several GPUs behind one handle (defined at the end of this file)
+int multi_create(grape_handle **out, const grape_problem *p);
+int multi_fail(grape_handle *h, grape_handle *c, int rc);
+int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStream_t s, const double2 *d_chi);
+
+// J from the (all-)reduced sums [Re f, Im f, sum w|tau|^2, Re sum w tau, sum_k J_b,k]: J_parts[1] + J_parts[3],
+// optimize.jl:757-766
+double functional_from_sums(const grape_handle *h, const double *sums) {
+    const double Kt = (double)h->K_total;
+    double J;
+    if (h->p.functional == GRAPE_J_T_SM) J = 1.0 - (sums[0] * sums[0] + sums[1] * sums[1]) / (Kt * Kt);
+    else if (h->p.functional == GRAPE_J_T_SS) J = 1.0 - sums[2] / Kt;
+    else J = 1.0 - sums[3] / Kt;
+    if (h->p.Dpen && h->p.lambda_b != 0.0) J += h->p.lambda_b * sums[4];
+    return J;
+}
+
 }  // namespace
 
 extern "C" {
@@ -543,11 +564,16 @@ const char *grape_last_error(grape_handle *h) { return h ? h->err.c_str() : g_cr
 
 void grape_destroy(grape_handle *h) {
     if (!h) return;
+    if (!h->shards.empty()) {
+        for (grape_handle *c : h->shards) grape_destroy(c);
+        delete h;
+        return;
+    }
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -591,6 +617,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     }
     for (int n = 0; n < p->N_T; ++n)
         if (!(p->tlist[n + 1] > p->tlist[n])) { g_create_error = "tlist must be strictly increasing"; return GRAPE_ERR_INVALID; }
+    if (p->ndev < 0 || p->ndev > 64) { g_create_error = "ndev out of range (0..64)"; return GRAPE_ERR_INVALID; }
+    if (p->ndev > 1) return multi_create(out, p);
 
     grape_handle *h = new grape_handle();
     h->p = *p;
@@ -901,6 +929,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
 
 int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_out, void *stream_) {
     if (!h || !d_pulsevals || !d_out) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) { h->err = "device-pointer entry points need a single-device handle (ndev <= 1)"; return GRAPE_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream_;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
@@ -1021,8 +1050,17 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
 
 int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void *stream_) {
     if (!h || !d_f || !d_G) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) { h->err = "device-pointer entry points need a single-device handle (ndev <= 1)"; return GRAPE_ERR_INVALID; }
+    return backward_device_impl(h, d_f, d_G, (hipStream_t)stream_, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+// d_chi != nullptr: the boundary states are the caller's (grape_backward_chi); the sequential backward sweep runs
+// from them whatever the forward call did
+int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStream_t s, const double2 *d_chi) {
     if (!h->have_forward) { h->err = "grape_backward called before grape_forward"; return GRAPE_ERR_INVALID; }
-    hipStream_t s = (hipStream_t)stream_;
     HIPCHK(h, hipSetDevice(h->device));
     hipError_t e;
     // ---- phase 2: chi boundary + backward sweep ----
@@ -1032,9 +1070,11 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     sa.xi = h->have_gb ? h->d_xi : nullptr; sa.wq = h->d_wq; sa.lambda_b = h->p.lambda_b;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
+    sa.chi_in = d_chi;
     phase_begin(h, 2, s);
-    const bool unit = h->bw_done;
+    const bool unit = h->bw_done && !d_chi;
     h->bw_done = false;
+    if (d_chi) h->bw_unit = false;   // d_bw is about to hold the true (normalised) backward states
     if (unit) {
         // the backward states are already there (unit targets): only rho_k and the factors z_k are left
         ChiCoeffArgs ca{};
@@ -1114,15 +1154,30 @@ int grape_backward_device(grape_handle *h, const double *d_f, double *d_G, void 
     h->n_bwd++;
     return GRAPE_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int grape_set_fused_sweeps(grape_handle *h, int on) {
     if (!h) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) {
+        int r = 1;
+        for (grape_handle *c : h->shards) r &= grape_set_fused_sweeps(c, on);
+        return r;
+    }
     h->fuse_on = on != 0;
     return (h->fuse && h->fuse_on) ? 1 : 0;
 }
 
 int grape_check(grape_handle *h, void *stream_) {
     if (!h) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) {
+        for (grape_handle *c : h->shards) {
+            const int rc = grape_check(c, c->stream);
+            if (rc) { h->err = c->err; return rc; }
+        }
+        return GRAPE_OK;
+    }
     int flags[4];
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_));
@@ -1130,31 +1185,155 @@ int grape_check(grape_handle *h, void *stream_) {
     return status_from_flags(h, flags[0]);
 }
 
-int grape_forward(grape_handle *h, const double *pulsevals, double *tau) {
-    if (!h || !pulsevals) return GRAPE_ERR_INVALID;
+}  // extern "C"
+
+namespace {
+
+// The host-pointer calls are split into an asynchronous half (copies and launches on the handle's stream) and a
+// half that waits and reads the pinned staging area, so that a handle with several devices can put all of them to work
+// from one host thread before it waits for the first.
+int forward_enqueue(grape_handle *h, const double *pulsevals) {
     HIPCHK(h, hipSetDevice(h->device));
     const size_t nl = (size_t)h->L * h->N_T;
     memcpy(h->h_pin, pulsevals, nl * 8);
     HIPCHK(h, hipMemcpyAsync(h->d_eps, h->h_pin, nl * 8, hipMemcpyHostToDevice, h->stream));
-    int rc = grape_forward_device(h, h->d_eps, h->d_out, h->stream);
+    const int rc = grape_forward_device(h, h->d_eps, h->d_out, h->stream);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->h_pin + nl, h->d_out, ((size_t)2 * h->K + 8) * 8, hipMemcpyDeviceToHost, h->stream));
-    rc = grape_check(h, h->stream);
-    if (rc) return rc;
-    if (tau) memcpy(tau, h->h_pin + nl, (size_t)2 * h->K * 8);
     return GRAPE_OK;
+}
+int forward_finish(grape_handle *h, double *tau) {
+    const int rc = grape_check(h, h->stream);
+    if (rc) return rc;
+    if (tau) memcpy(tau, h->h_pin + (size_t)h->L * h->N_T, (size_t)2 * h->K * 8);
+    return GRAPE_OK;
+}
+const double *forward_sums(const grape_handle *h) { return h->h_pin + (size_t)h->L * h->N_T + 2 * (size_t)h->K; }
+
+int backward_enqueue(grape_handle *h, const double f_total[2], const double *chi) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const double2 *d_chi = nullptr;
+    if (chi) {
+        if (!h->d_chi_in) HIPCHK(h, dmalloc(&h->d_chi_in, (size_t)h->K * h->N));
+        HIPCHK(h, hipMemcpyAsync(h->d_chi_in, chi, (size_t)h->K * h->N * 16, hipMemcpyHostToDevice, h->stream));
+        d_chi = h->d_chi_in;
+    }
+    const double f0[2] = {0.0, 0.0};
+    HIPCHK(h, hipMemcpyAsync(h->d_f, f_total ? f_total : f0, 16, hipMemcpyHostToDevice, h->stream));
+    const int rc = backward_device_impl(h, h->d_f, h->d_G, h->stream, d_chi);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_G, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToHost, h->stream));
+    return GRAPE_OK;
+}
+int backward_finish(grape_handle *h, double *G, bool accumulate) {
+    const int rc = grape_check(h, h->stream);
+    if (rc) return rc;
+    const size_t nl = (size_t)h->L * h->N_T;
+    if (accumulate) for (size_t i = 0; i < nl; ++i) G[i] += h->h_pin[i];
+    else memcpy(G, h->h_pin, nl * 8);
+    return GRAPE_OK;
+}
+
+// ---- several devices behind one handle: every call walks the shards twice (enqueue, then wait) ----
+int multi_fail(grape_handle *h, grape_handle *c, int rc) { h->err = c->err; return rc; }
+
+int multi_forward(grape_handle *h, const double *pulsevals, double *tau) {
+    for (grape_handle *c : h->shards) {
+        c->want_bw = h->want_bw;
+        const int rc = forward_enqueue(c, pulsevals);
+        c->want_bw = true;
+        if (rc) return multi_fail(h, c, rc);
+    }
+    double *sums = h->h_multi.data();   // [8]: shard sums added in shard order (fixed: reproducible)
+    std::fill(sums, sums + 8, 0.0);
+    for (size_t g = 0; g < h->shards.size(); ++g) {
+        grape_handle *c = h->shards[g];
+        const int rc = forward_finish(c, tau ? tau + 2 * (size_t)h->shard_lo[g] : nullptr);
+        if (rc) return multi_fail(h, c, rc);
+        const double *cs = forward_sums(c);
+        for (int i = 0; i < 8; ++i) sums[i] += cs[i];
+    }
+    h->have_forward = true;
+    return GRAPE_OK;
+}
+
+int multi_backward(grape_handle *h, const double f_total[2], const double *chi, double *G) {
+    for (size_t g = 0; g < h->shards.size(); ++g) {
+        grape_handle *c = h->shards[g];
+        const int rc = backward_enqueue(c, f_total, chi ? chi + 2 * (size_t)h->shard_lo[g] * h->N : nullptr);
+        if (rc) return multi_fail(h, c, rc);
+    }
+    for (size_t g = 0; g < h->shards.size(); ++g) {   // sum over k of optimize.jl:579 across the shards, in shard order
+        grape_handle *c = h->shards[g];
+        const int rc = backward_finish(c, G, g > 0);
+        if (rc) return multi_fail(h, c, rc);
+    }
+    return GRAPE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int grape_forward(grape_handle *h, const double *pulsevals, double *tau) {
+    if (!h || !pulsevals) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) return multi_forward(h, pulsevals, tau);
+    int rc = forward_enqueue(h, pulsevals);
+    if (rc) return rc;
+    return forward_finish(h, tau);
 }
 
 int grape_backward(grape_handle *h, const double f_total[2], double *G_partial) {
     if (!h || !f_total || !G_partial) return GRAPE_ERR_INVALID;
+    if (!h->have_forward) { h->err = "grape_backward called before grape_forward"; return GRAPE_ERR_INVALID; }
+    if (!h->shards.empty()) return multi_backward(h, f_total, nullptr, G_partial);
+    int rc = backward_enqueue(h, f_total, nullptr);
+    if (rc) return rc;
+    return backward_finish(h, G_partial, false);
+}
+
+int grape_backward_chi(grape_handle *h, const double *chi, double *G) {
+    if (!h || !chi || !G) return GRAPE_ERR_INVALID;
+    if (!h->have_forward) { h->err = "grape_backward_chi called before grape_forward"; return GRAPE_ERR_INVALID; }
+    if (!h->shards.empty()) return multi_backward(h, nullptr, chi, G);
+    int rc = backward_enqueue(h, nullptr, chi);
+    if (rc) return rc;
+    return backward_finish(h, G, false);
+}
+
+int grape_get_sums(grape_handle *h, double sums[8]) {
+    if (!h || !sums) return GRAPE_ERR_INVALID;
+    if (!h->have_forward) { h->err = "grape_get_sums called before grape_forward"; return GRAPE_ERR_INVALID; }
+    if (!h->shards.empty()) {
+        std::fill(sums, sums + 8, 0.0);
+        for (grape_handle *c : h->shards) {
+            double cs[8];
+            const int rc = grape_get_sums(c, cs);
+            if (rc) return multi_fail(h, c, rc);
+            for (int i = 0; i < 8; ++i) sums[i] += cs[i];
+        }
+        return GRAPE_OK;
+    }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(h->d_f, f_total, 16, hipMemcpyHostToDevice, h->stream));
-    int rc = grape_backward_device(h, h->d_f, h->d_G, h->stream);
-    if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_G, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToHost, h->stream));
-    rc = grape_check(h, h->stream);
-    if (rc) return rc;
-    memcpy(G_partial, h->h_pin, (size_t)h->L * h->N_T * 8);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(sums, h->d_out + 2 * (size_t)h->K, 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return GRAPE_OK;
+}
+
+int grape_get_final_states(grape_handle *h, double *psiT) {
+    if (!h || !psiT) return GRAPE_ERR_INVALID;
+    if (!h->have_forward) { h->err = "grape_get_final_states called before grape_forward"; return GRAPE_ERR_INVALID; }
+    if (!h->shards.empty()) {
+        for (size_t g = 0; g < h->shards.size(); ++g) {
+            const int rc = grape_get_final_states(h->shards[g], psiT + 2 * (size_t)h->shard_lo[g] * h->N);
+            if (rc) return multi_fail(h, h->shards[g], rc);
+        }
+        return GRAPE_OK;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy2D(psiT, (size_t)h->N * 16, h->d_fw + (size_t)h->N_T * h->NP,
+                          (size_t)(h->N_T + 1) * h->NP * 16, (size_t)h->N * 16, h->K, hipMemcpyDeviceToHost));
     return GRAPE_OK;
 }
 
@@ -1164,36 +1343,39 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
         h->err = "grape_eval needs K == K_total; use grape_forward/grape_backward for shards";
         return GRAPE_ERR_INVALID;
     }
-    phase_begin(h, 5, h->stream);
+    const bool multi = !h->shards.empty();
+    if (!multi) phase_begin(h, 5, h->stream);
     h->in_eval = true;  // keep the forward slot open until the whole evaluation has been recorded
     h->want_bw = G != nullptr;   // functional only: no backward sweep alongside the forward one
     int rc = grape_forward(h, pulsevals, tau);
     h->want_bw = true;
     h->in_eval = false;
     if (rc) { h->n_fwd++; return rc; }
-    const size_t nl = (size_t)h->L * h->N_T;
-    const double *sums = h->h_pin + nl + 2 * (size_t)h->K;  // f_re, f_im, sum w|tau|^2, Re sum w tau
-    const double Kt = (double)h->K_total;
-    if (h->p.functional == GRAPE_J_T_SM) *J = 1.0 - (sums[0] * sums[0] + sums[1] * sums[1]) / (Kt * Kt);
-    else if (h->p.functional == GRAPE_J_T_SS) *J = 1.0 - sums[2] / Kt;
-    else *J = 1.0 - sums[3] / Kt;
-    if (h->have_gb) *J += h->p.lambda_b * sums[4];   // J_parts[3] = lambda_b * sum(J_b_trajectory), optimize.jl:764-766
+    const double *sums = multi ? h->h_multi.data() : forward_sums(h);  // f_re, f_im, sum w|tau|^2, Re sum w tau, sum J_b
+    *J = functional_from_sums(h, sums);   // J_parts[1] (+ J_parts[3] = lambda_b * sum(J_b_trajectory), optimize.jl:764-766)
     const double f[2] = {sums[0], sums[1]};
     if (psiT) {
-        HIPCHK(h, hipMemcpy2D(psiT, (size_t)h->N * 16, h->d_fw + (size_t)h->N_T * h->NP,
-                              (size_t)(h->N_T + 1) * h->NP * 16, (size_t)h->N * 16, h->K, hipMemcpyDeviceToHost));
+        rc = grape_get_final_states(h, psiT);
+        if (rc) { h->n_fwd++; return rc; }
     }
     if (G) {
         rc = grape_backward(h, f, G);
         if (rc) { h->n_fwd++; return rc; }
     }
-    phase_end(h, 5, h->stream);
+    if (!multi) phase_end(h, 5, h->stream);
     h->n_fwd++;
     return GRAPE_OK;
 }
 
 int grape_get_tau_grads(grape_handle *h, double *out) {
     if (!h || !out) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) {   // [k][l][n]: the shards are contiguous blocks of k
+        for (size_t g = 0; g < h->shards.size(); ++g) {
+            const int rc = grape_get_tau_grads(h->shards[g], out + 2 * (size_t)h->shard_lo[g] * h->L * h->N_T);
+            if (rc) return multi_fail(h, h->shards[g], rc);
+        }
+        return GRAPE_OK;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out, h->d_tg, (size_t)h->K * h->L * h->N_T * 16, hipMemcpyDeviceToHost));
@@ -1202,6 +1384,13 @@ int grape_get_tau_grads(grape_handle *h, double *out) {
 
 int grape_get_storage(grape_handle *h, int which, double *out) {
     if (!h || !out || which < 0 || which > 1) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) {
+        for (size_t g = 0; g < h->shards.size(); ++g) {
+            const int rc = grape_get_storage(h->shards[g], which, out + 2 * (size_t)h->shard_lo[g] * (h->N_T + 1) * h->N);
+            if (rc) return multi_fail(h, h->shards[g], rc);
+        }
+        return GRAPE_OK;
+    }
     if (which == 1 && h->bw_unit && !h->z_valid) {
         h->err = "backward states requested between grape_forward and grape_backward (concurrent sweeps: the boundary "
                  "coefficient of chi is applied by grape_backward)";
@@ -1233,6 +1422,12 @@ int grape_get_storage(grape_handle *h, int which, double *out) {
 int grape_get_propagator(grape_handle *h, int k, int n, double *out) {
     // U_kn as N x N column-major complex (debug / parity of the expm kernel)
     if (!h || !out || k < 0 || k >= h->K || n < 0 || n >= h->N_T) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) {
+        size_t g = 0;
+        while (g + 1 < h->shards.size() && k >= h->shard_lo[g + 1]) ++g;
+        const int rc = grape_get_propagator(h->shards[g], k - h->shard_lo[g], n, out);
+        return rc ? multi_fail(h, h->shards[g], rc) : GRAPE_OK;
+    }
     if (h->series) { h->err = "prop_method = GRAPE_PROP_SERIES is matrix-free: no propagator is materialised"; return GRAPE_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
@@ -1249,6 +1444,16 @@ int grape_get_propagator(grape_handle *h, int k, int n, double *out) {
 
 int grape_get_timings(grape_handle *h, double *ms, int n) {
     if (!h || !ms) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) {   // the devices work side by side: a phase takes as long as its slowest shard
+        int cnt = 0;
+        for (size_t g = 0; g < h->shards.size(); ++g) {
+            double cm[kPhases];
+            cnt = grape_get_timings(h->shards[g], cm, n < kPhases ? n : kPhases);
+            if (cnt < 0) return multi_fail(h, h->shards[g], cnt);
+            for (int i = 0; i < cnt; ++i) ms[i] = g == 0 ? cm[i] : std::max(ms[i], cm[i]);
+        }
+        return cnt;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     int cnt = 0;
@@ -1267,6 +1472,13 @@ int grape_get_timings(grape_handle *h, double *ms, int n) {
 
 int grape_reset_timings(grape_handle *h) {
     if (!h) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) {
+        for (grape_handle *c : h->shards) {
+            const int rc = grape_reset_timings(c);
+            if (rc) return multi_fail(h, c, rc);
+        }
+        return GRAPE_OK;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     for (auto &ring : h->ph)
@@ -1277,6 +1489,17 @@ int grape_reset_timings(grape_handle *h) {
 
 int grape_get_work(grape_handle *h, double *out, int n) {
     if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
+    if (!h->shards.empty()) {   // every entry is a count: the shards add up
+        const int m = n < 9 ? n : 9;
+        std::fill(out, out + m, 0.0);
+        for (grape_handle *c : h->shards) {
+            double cw[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+            const int rc = grape_get_work(c, cw, m);
+            if (rc < 0) return multi_fail(h, c, rc);
+            for (int i = 0; i < m; ++i) out[i] += cw[i];
+        }
+        return 4;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     unsigned long long st[16];
@@ -1299,3 +1522,45 @@ int grape_get_work(grape_handle *h, double *out, int n) {
 }
 
 }  // extern "C"
+
+namespace {
+// grape_problem.ndev > 1: the trajectories are dealt to the devices in contiguous blocks whose sizes differ by at most
+// one (the partition of SURVEY 8e), every block is an ordinary single-device handle created with the job's K_total.
+int multi_create(grape_handle **out, const grape_problem *p) {
+    const int G = std::min<int>(p->ndev, p->K);
+    grape_handle *h = new grape_handle();
+    h->p = *p;
+    h->N = p->N; h->L = p->L; h->K = p->K; h->N_T = p->N_T;
+    h->K_total = p->K_total > 0 ? p->K_total : p->K;
+    h->device = p->devices ? p->devices[0] : p->device;
+    h->h_multi.assign(8, 0.0);
+    const size_t nn2 = (size_t)2 * p->N * p->N;
+    const int base = p->K / G, rem = p->K % G;
+    for (int g = 0; g < G; ++g) {
+        const int lo = g * base + std::min(g, rem), Kg = base + (g < rem ? 1 : 0);
+        grape_problem cp = *p;
+        cp.ndev = 0; cp.devices = nullptr;
+        cp.device = p->devices ? p->devices[g] : p->device + g;
+        cp.K = Kg; cp.K_total = h->K_total;
+        cp.H0 = p->H0 + (size_t)lo * nn2;
+        if (p->hc_per_traj) cp.Hc = p->Hc + (size_t)lo * p->L * nn2;
+        cp.psi0 = p->psi0 + (size_t)lo * 2 * p->N;
+        cp.target = p->target + (size_t)lo * 2 * p->N;
+        if (p->weights) cp.weights = p->weights + lo;
+        if (p->Dpen && p->dpen_per_traj) cp.Dpen = p->Dpen + (size_t)lo * nn2;
+        grape_handle *c = nullptr;
+        const int rc = grape_create(&c, &cp);
+        if (rc) {   // g_create_error already holds the child's message
+            g_create_error = "device shard " + std::to_string(g) + " (device " + std::to_string(cp.device) + "): " + g_create_error;
+            grape_destroy(h);
+            return rc;
+        }
+        h->shards.push_back(c);
+        h->shard_lo.push_back(lo);
+        h->shard_dev.push_back(cp.device);
+    }
+    h->shard_lo.push_back(p->K);
+    *out = h;
+    return GRAPE_OK;
+}
+}  // namespace

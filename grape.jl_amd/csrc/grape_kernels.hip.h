@@ -1543,6 +1543,8 @@ struct SweepArgs {
     // xi inhomogeneity of the state running cost
     const double *inv_tnorm;   // [K] 1 / ||target_k||
     int unit_chi;
+    // host-supplied boundary states chi_k(T) of grape_backward_chi ([K][N], not normalised): replace c_k target_k
+    const double2 *chi_in;
 };
 
 // c_k of chi_k(T) = c_k target_k for the three functionals (docs/src/tutorial.md:349-356, 402)
@@ -1553,6 +1555,16 @@ __device__ __forceinline__ void chi_coefficient(const SweepArgs &a, const int k,
     if (a.functional == 0) { cr = w * a.f[0] / (Kt * Kt); ci = w * a.f[1] / (Kt * Kt); }
     else if (a.functional == 1) { const double2 t = a.tau[k]; cr = w * t.x / Kt; ci = w * t.y / Kt; }
     else { cr = w / (2.0 * Kt); ci = 0.; }
+}
+
+// element i of the boundary state chi_k(T) before the running-cost term: the user's chi (grape_backward_chi,
+// optimize.jl:845-855) or c_k target_k of the built-in functionals
+__device__ __forceinline__ double2 chi_boundary(const SweepArgs &a, const int k, const int i) {
+    if (a.chi_in) return a.chi_in[(size_t)k * a.N + i];
+    double cr, ci;
+    chi_coefficient(a, k, cr, ci);
+    const double2 t = a.target[(size_t)k * a.N + i];
+    return make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
 }
 
 // after concurrent sweeps: true rho_k = |c_k| ||target_k|| (optimize.jl:867-868, guard :1021-1025) and
@@ -1615,12 +1627,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
         }
     } else {
         // chi_k(T) = coeff_k * target_k, rho_k = ||chi_k||, chi_k /= rho_k (optimize.jl:848-868)
-        double cr, ci;
-        chi_coefficient(a, k, cr, ci);
         double2 v = make_double2(0., 0.);
         if (tid < a.N) {
-            double2 t = a.target[(size_t)k * a.N + tid];
-            v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+            v = chi_boundary(a, k, tid);
             if (a.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)   (optimize.jl:856-866)
                 const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + a.N_T) * NP + tid];
                 const double c = a.lambda_b * a.wq[a.N_T];
@@ -1845,11 +1854,8 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs &a, const int k, do
         if (!BACKWARD) {
             if (lane < a.N) v = a.psi0[(size_t)k * a.N + lane];
         } else {
-            double cr, ci;
-            chi_coefficient(a, k, cr, ci);
             if (lane < a.N) {
-                const double2 t = a.target[(size_t)k * a.N + lane];
-                v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+                v = chi_boundary(a, k, lane);
                 if (a.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)   (optimize.jl:856-866)
                     const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + a.N_T) * NP + lane];
                     const double cc = a.lambda_b * a.wq[a.N_T];

@@ -463,16 +463,9 @@ __global__ void __launch_bounds__(1024) sweep_lg_kernel(SweepArgs a, int NP) {
             st[tid] = v;
         }
     } else {
-        const double w = a.weights ? a.weights[k] : 1.0;
-        const double Kt = (double)a.K_total;
-        double cr, ci;
-        if (a.functional == 0) { cr = w * a.f[0] / (Kt * Kt); ci = w * a.f[1] / (Kt * Kt); }
-        else if (a.functional == 1) { const double2 t = a.tau[k]; cr = w * t.x / Kt; ci = w * t.y / Kt; }
-        else { cr = w / (2.0 * Kt); ci = 0.; }
         double2 v = make_double2(0., 0.);
         if (tid < a.N) {
-            const double2 t = a.target[(size_t)k * a.N + tid];
-            v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+            v = chi_boundary(a, k, tid);
             if (a.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)
                 const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + a.N_T) * NP + tid];
                 const double c = a.lambda_b * a.wq[a.N_T];
@@ -630,16 +623,9 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
             if (s == 0) st[tid] = v;
         }
     } else {
-        const double w = a.weights ? a.weights[k] : 1.0;
-        const double Kt = (double)a.K_total;
-        double cr, ci;
-        if (a.functional == 0) { cr = w * a.f[0] / (Kt * Kt); ci = w * a.f[1] / (Kt * Kt); }
-        else if (a.functional == 1) { const double2 t = a.tau[k]; cr = w * t.x / Kt; ci = w * t.y / Kt; }
-        else { cr = w / (2.0 * Kt); ci = 0.; }
         double2 v = make_double2(0., 0.);
         if (tid < a.N) {
-            const double2 t = a.target[(size_t)k * a.N + tid];
-            v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+            v = chi_boundary(a, k, tid);
             if (a.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)
                 const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + a.N_T) * NP + tid];
                 const double c = a.lambda_b * a.wq[a.N_T];

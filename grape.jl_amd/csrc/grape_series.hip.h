@@ -139,12 +139,9 @@ __device__ __forceinline__ void series_sweep_body(const SeriesArgs &a, const int
         if (tid == 0) sc[0] = 1.0;
     } else {
         // chi_k(T) = coeff_k * target_k, rho_k = ||chi_k||, chi_k /= rho_k (optimize.jl:848-868)
-        double cr, ci;
-        chi_coefficient(sa, k, cr, ci);
         double2 v = make_double2(0., 0.);
         if (tid < sa.N) {
-            const double2 t = sa.target[(size_t)k * sa.N + tid];
-            v = make_double2(cr * t.x - ci * t.y, cr * t.y + ci * t.x);
+            v = chi_boundary(sa, k, tid);
             if (sa.xi) {   // chi_k(T) += lambda_b dt/2 xi_k(T)   (optimize.jl:856-866)
                 const double2 x_ = sa.xi[((size_t)k * (N_T + 1) + N_T) * NP + tid];
                 const double c = sa.lambda_b * sa.wq[N_T];

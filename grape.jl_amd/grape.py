@@ -245,12 +245,24 @@ class GrapeWrk:
         self.lower_bounds = np.full(L * N_T, lo, dtype=np.float64)
         self.upper_bounds = np.full(L * N_T, hi, dtype=np.float64)
         pb = self.kwargs.get("pulse_options", None)
-        if pb:  # per-control bounds, written control-major (the reference interleaves: SURVEY.md 8f N1)
+        if pb:
+            # per-control bounds: pulse_options[control][:upper_bounds / :lower_bounds] (workspace.jl:204-214; the
+            # singular keys are accepted as well).  The reference writes them through the views `[l:L:end]`, i.e.
+            # INTERLEAVED, although pulsevals is control-major (workspace.jl:159-162) -- for L > 1 the bounds of
+            # control l land on every L-th value of the whole vector.  Default here: the evident intent (the values
+            # of control l); `reference_bounds_layout=True` reproduces the reference's stride literally
+            # (INTEGRATION.md section 5).  For L = 1 both are the same.
+            literal = bool(self.kwargs.get("reference_bounds_layout", False))
             for l, c in enumerate(self.controls):
-                for key, arr in (("lower_bound", self.lower_bounds), ("upper_bound", self.upper_bounds)):
-                    opt = next((v for k, v in pb if k is c), {})
-                    if key in opt:
-                        arr[l * N_T:(l + 1) * N_T] = opt[key]
+                opt = next((v for k, v in pb if k is c), {})
+                for keys, arr in ((("lower_bounds", "lower_bound"), self.lower_bounds),
+                                  (("upper_bounds", "upper_bound"), self.upper_bounds)):
+                    for key in keys:
+                        if key in opt:
+                            if literal:
+                                arr[l::L] = opt[key]
+                            else:
+                                arr[l * N_T:(l + 1) * N_T] = opt[key]
         self.result = GrapeResult(tlist=self.tlist.copy(), iter_start=self.kwargs.get("iter_start", 0),
                                   iter_stop=self.kwargs.get("iter_stop", 5000))
         self.result.iter = self.result.iter_start
@@ -263,8 +275,11 @@ class GrapeWrk:
 
     def _make_hip_backend(self):
         J_T = self.kwargs["J_T"]
-        if J_T not in _FUNCTIONAL_CODE:
-            raise ValueError("the HIP backend implements J_T_sm, J_T_ss and J_T_re")
+        custom = J_T not in _FUNCTIONAL_CODE
+        if custom and not callable(self.kwargs.get("chi")):
+            # the reference derives chi by automatic differentiation when it is missing (workspace.jl:306-308);
+            # here a user-defined J_T has to come with its chi
+            raise ValueError("a user-defined J_T needs the matching `chi(Psi, trajectories; tau)` (optimize.jl:845-855)")
         trajs = self.trajectories
         H0 = np.stack([t.generator.drift for t in trajs])
         per_traj = []
@@ -310,11 +325,16 @@ class GrapeWrk:
             funcs.append(fd[0][0] if fd else None)
             dfuncs.append(fd[0][1] if fd else None)
         wrap = (lambda b: _AmplitudeBackend(b, funcs, dfuncs, self.N_T)) if any(f is not None for f in funcs) else (lambda b: b)
+        if custom:
+            inner_wrap = wrap
+            wrap = lambda b: inner_wrap(_CustomChiBackend(b, J_T, self.kwargs["chi"], trajs))  # noqa: E731
+        targets = [t.target_state if t.target_state is not None else np.zeros_like(t.initial_state) for t in trajs]
         return wrap(api.GrapeHip(H0, Hc, self.tlist, np.stack([t.initial_state for t in trajs]),
-                            np.stack([t.target_state for t in trajs]),
+                            np.stack(targets),
                             prop_method=prop, prop_tolerance=self.kwargs.get("prop_tolerance", 0.0), shape=shape,
                             weights=np.array([t.weight for t in trajs], dtype=np.float64),
-                            functional=_FUNCTIONAL_CODE[J_T], gradient_method=method,
+                            functional=_FUNCTIONAL_CODE.get(J_T, api.J_T_SM), gradient_method=method,
+                            devices=self.kwargs.get("devices"),
                             chi_min_norm=self.kwargs.get("chi_min_norm", 0.0),
                             taylor_max_order=self.kwargs.get("taylor_grad_max_order", 0),
                             taylor_tolerance=self.kwargs.get("taylor_grad_tolerance", 0.0),
@@ -324,10 +344,34 @@ class GrapeWrk:
                             D=self.kwargs.get("state_penalty"), lambda_b=self.kwargs.get("lambda_b", 1.0)))
 
 
+class _CustomChiBackend:
+    """A user-defined functional on the HIP path (optimize.jl:757-760, 845-855): the forward sweep runs on the device,
+    ``J_T(Psi, trajectories; tau)`` and ``chi(Psi, trajectories; tau)`` are evaluated on the host from the final
+    states, and the backward sweep + gradient run on the device from the chi the user's function returned
+    (``grape_forward`` / ``grape_get_final_states`` / ``grape_backward_chi``)."""
+
+    def __init__(self, inner, J_T, chi, trajectories):
+        self.inner, self.J_T, self.chi, self.trajectories = inner, J_T, chi, trajectories
+
+    def eval(self, x, gradient=True, want_psiT=False):
+        tau = self.inner.forward(x)
+        psiT = self.inner.final_states()
+        J = float(self.J_T(list(psiT), self.trajectories, tau=list(tau)))
+        J += getattr(self.inner, "lambda_b", 0.0) * float(self.inner.sums()[4])
+        G = None
+        if gradient:
+            chi = np.stack([np.asarray(c, dtype=np.complex128) for c in self.chi(list(psiT), self.trajectories, tau=list(tau))])
+            G = self.inner.backward_chi(chi)
+        return (J, G, tau, psiT) if want_psiT else (J, G, tau)
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+
 def _split_functional(wrk, J, tau):
     """J_parts[1] = J_T from the overlaps, J_parts[3] = lambda_b * sum_k J_b,k (src/optimize.jl:757-766): the backend
-    returns their sum; J_T is a closed form of tau for the three functionals the backend implements."""
-    J_T = wrk.kwargs["J_T"](None, wrk.trajectories, tau=list(tau))
+    returns their sum; J_T is evaluated again on the host from the final states / tau."""
+    J_T = wrk.kwargs["J_T"](getattr(wrk, "_states", None), wrk.trajectories, tau=list(tau))
     wrk.J_parts[0] = float(J_T)
     on = wrk.kwargs.get("state_penalty") is not None and wrk.kwargs.get("lambda_b", 1.0) != 0.0
     wrk.J_parts[2] = float(J - J_T) if on else 0.0

@@ -1,9 +1,9 @@
 """Trajectory-sharded evaluation: one process per GPU, ``torch.distributed`` for the two
 cross-trajectory reductions of the path:
 
-1. between the forward and the backward sweep: all-reduce(sum) of the four partial sums
-   ``[Re f, Im f, sum_k w_k |tau_k|^2, Re sum_k w_k tau_k]`` with ``f = sum_k w_k tau_k``
-   (needed by chi_sm, docs/src/tutorial.md:402, and by every J_T);
+1. between the forward and the backward sweep: all-reduce(sum) of the partial sums
+   ``[Re f, Im f, sum_k w_k |tau_k|^2, Re sum_k w_k tau_k, sum_k J_b,k]`` with ``f = sum_k w_k tau_k``
+   (needed by chi_sm, docs/src/tutorial.md:402, by every J_T and by the state running cost);
 2. at the end: all-reduce(sum) of the partial gradient -- the sum over k of
    ``_grad_J_T_via_chi!`` (/root/reference/src/optimize.jl:579).
 
@@ -43,24 +43,29 @@ class ShardedEvaluator:
         self.h = handle
         self.K_total = int(K_total)
         self.functional = functional
-        self.w = weights_local
+        # the handle owns the weights (they enter chi on the device): ``weights_local`` is only cross-checked
+        hw = getattr(handle, "_weights", None)
+        if weights_local is not None and hw is not None and not np.array_equal(np.asarray(weights_local), hw):
+            raise ValueError("weights_local differs from the weights the handle was created with")
         self.dist = dist  # torch.distributed module (initialised) or None for a single process
         self.device = device  # torch.device for the RCCL path, None for the host (gloo) path
         self._buf = None
 
     # -- host path (gloo / single process) ---------------------------------------------------
     def eval_host(self, pulsevals):
+        """fg! over all shards with host buffers: J (including lambda_b * J_b of the state running cost), the full
+        gradient and this shard's tau."""
         import torch
         tau = self.h.forward(pulsevals)
-        w = np.ones(len(tau)) if self.w is None else np.asarray(self.w)
-        f = np.sum(w * tau)
-        sums = torch.tensor([f.real, f.imag, float(np.sum(w * np.abs(tau) ** 2)), f.real], dtype=torch.float64)
+        # the shard's partial sums as the library formed them (its weights, and sum_k J_b,k): grape_get_sums
+        sums = torch.from_numpy(np.array(self.h.sums(), dtype=np.float64))
         if self.dist is not None:
             self.dist.all_reduce(sums)
         G = torch.from_numpy(self.h.backward(complex(sums[0].item(), sums[1].item())))
         if self.dist is not None:
             self.dist.all_reduce(G)
-        return functional_value(self.functional, sums.tolist(), self.K_total), G.numpy(), tau
+        J = functional_value(self.functional, sums.tolist(), self.K_total, getattr(self.h, "lambda_b", 0.0))
+        return J, G.numpy(), tau
 
     # -- device path (nccl == RCCL) ------------------------------------------------------------
     def alloc_device(self, L, N_T, K_local):

@@ -26,6 +26,11 @@
  *     K_total; the two cross-trajectory reductions of the path (sum_k w_k tau_k for J_T_sm/chi_sm,
  *     sum_k of the gradient, optimize.jl:579) are exposed by the split-phase calls below so that
  *     the host can all-reduce them (RCCL) between phases.
+ *   - several GPUs behind ONE handle (ABI v4, grape_problem.ndev / .devices): the K trajectories of the
+ *     handle are dealt to the devices in contiguous blocks, every host-pointer entry point drives all of
+ *     them from the calling thread (asynchronous launches on one stream per device) and performs the two
+ *     reductions itself in a fixed order -- the caller never sees the devices, exactly like the
+ *     transparent `@threadsif` loops over k of optimize.jl:720, 876.
  */
 #ifndef GRAPE_HIP_H
 #define GRAPE_HIP_H
@@ -37,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_HIP_ABI_VERSION 3
+#define GRAPE_HIP_ABI_VERSION 4
 
 typedef struct grape_handle grape_handle;
 
@@ -102,6 +107,11 @@ typedef struct {
     double lambda_b;
     int32_t prop_method;     /* grape_prop_method (ABI v3)                                      */
     double prop_tolerance;   /* GRAPE_PROP_SERIES: stop at ||term|| < tol ||state||; <= 0 selects 1e-17 */
+    /* ABI v4: GPUs behind one handle.  ndev <= 1: the single device `device`.  ndev > 1: trajectory
+     * block g (contiguous, sizes differ by at most one) lives on devices[g]; devices == NULL selects
+     * device, device+1, ...  An ordinal may repeat (several shards on one GPU).                  */
+    int32_t ndev;
+    const int32_t *devices;  /* NULL or [ndev] HIP device ordinals                              */
 } grape_problem;
 
 /* Replaces GrapeWrk(...) data set-up: /root/reference/src/workspace.jl:147-362 */
@@ -132,9 +142,30 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
 int grape_forward(grape_handle *h, const double *pulsevals, double *tau /* [K] complex */);
 int grape_backward(grape_handle *h, const double f_total[2], double *G_partial);
 
+/* The partial sums of this handle's trajectories after grape_forward -- what the host all-reduces in step 2 and what
+ * every J_T and the state running cost need (J_parts[1], J_parts[3], optimize.jl:757-766):
+ *   sums[0..1] = f = sum_k w_k tau_k, [2] = sum_k w_k |tau_k|^2, [3] = Re sum_k w_k tau_k,
+ *   [4] = sum_k J_b,k (trapezoid sum of g_b, optimize.jl:727-750; multiply by lambda_b), [5..7] = 0. */
+int grape_get_sums(grape_handle *h, double sums[8]);
+
+/* Final states Psi_k(T) of the last forward sweep ([K][N] complex): `fw_propagators[k].state`, the argument of a
+ * user-supplied J_T / chi (optimize.jl:752-760, 849-855). */
+int grape_get_final_states(grape_handle *h, double *psiT);
+
+/*
+ * Backward half with HOST-SUPPLIED boundary states: chi[k] = chi_k(T) = -d J_T / d <Psi_k(T)| exactly as the user's
+ * `chi(Psi, trajectories; tau)` returns them (optimize.jl:845-855; default constructor workspace.jl:306-308) --
+ * [K][N] complex, NOT normalised.  The library adds the xi(T) term of the state running cost (:856-866), forms
+ * rho_k = ||chi_k||, applies the chi_min_norm guard (:1021-1025), normalises (:867-868) and runs the backward sweep,
+ * the per-cell derivatives and the sum over k.  Together with grape_forward + grape_get_final_states this keeps an
+ * arbitrary J_T / chi pair on the caller's side: the three built-in functionals are only a fast path.
+ * Returns the (partial, if sharded) gradient in G [L*N_T].
+ */
+int grape_backward_chi(grape_handle *h, const double *chi, double *G);
+
 /* Device-resident variants used by the bench / RCCL path: same semantics, every pointer is a
  * device pointer on the handle's device; work is enqueued on `stream` (a hipStream_t passed as
- * void*) without host synchronisation.
+ * void*) without host synchronisation (single-device handles only).
  *   d_out layout of grape_forward_device (2K + 8 doubles): [0..2K) tau, then the shard sums
  *        [2K] Re f, [2K+1] Im f (f = sum_k w_k tau_k), [2K+2] sum_k w_k |tau_k|^2,
  *        [2K+3] Re sum_k w_k tau_k, [2K+4] sum_k J_b,k (state running cost), [2K+5..2K+7] 0

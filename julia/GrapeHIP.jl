@@ -1,4 +1,4 @@
-# GrapeHIP.jl -- thin `ccall` glue between GRAPE.jl and libgrape_hip.so (include/grape_hip.h).
+# GrapeHIP.jl -- thin `ccall` glue between GRAPE.jl and libgrape_hip.so (include/grape_hip.h, ABI v4).
 #
 # NOT EXECUTED in this repository's CI: the build image has no Julia toolchain.  It is written
 # against the C ABI and the reference's own interfaces and shows exactly what a GRAPE.jl maintainer
@@ -8,10 +8,17 @@
 module GrapeHIP
 
 using LinearAlgebra
+import QuantumControl
+import QuantumControl.QuantumPropagators
+using QuantumControl.QuantumPropagators.Controls: discretize_on_midpoints
+using QuantumControl.QuantumPropagators.Amplitudes: ShapedAmplitude
+using QuantumControl.Functionals: J_T_sm, J_T_ss, J_T_re
 
 const libgrape = get(ENV, "GRAPE_HIP_LIB", "libgrape_hip.so")
+const ABI_VERSION = 4
 
 # mirror of `grape_problem` (include/grape_hip.h); field order and types must match the C struct
+# (tests/test_abi.py compares the field lists)
 struct GrapeProblem
     abi_version::Int32
     N::Int32
@@ -38,75 +45,212 @@ struct GrapeProblem
     lambda_b::Float64
     prop_method::Int32       # 0 = ExpProp (materialised Pade propagators), 1 = matrix-free series (Cheby/Newton role)
     prop_tolerance::Float64  # <= 0: 1e-17
+    ndev::Int32              # > 1: the trajectories are dealt to several GPUs behind this one handle
+    devices::Ptr{Int32}      # C_NULL: device, device+1, ...
 end
 
 mutable struct Handle
     ptr::Ptr{Cvoid}
     keepalive::Vector{Any}   # arrays whose pointers were handed over during grape_create
+    K::Int
+    N::Int
+    functional::Int          # -1: user-supplied J_T / chi (split-phase calls + grape_backward_chi)
 end
+
+last_error(ptr) = unsafe_string(ccall((:grape_last_error, libgrape), Cstring, (Ptr{Cvoid},), ptr))
 
 function check(h::Handle, rc::Integer)
-    if rc != 0
-        msg = unsafe_string(ccall((:grape_last_error, libgrape), Cstring, (Ptr{Cvoid},), h.ptr))
-        error(msg)  # becomes result.message = "Exception: ..." via src/optimize.jl:125-135
-    end
+    # becomes result.message = "Exception: ..." via src/optimize.jl:125-135 (or is rethrown with rethrow_exceptions)
+    rc == 0 || error(last_error(h.ptr))
 end
 
-"""
-    Handle(trajectories, tlist, controls, pulse_ops; functional, gradient_method, device)
 
-Uploads the static problem (replaces the buffer set-up of GrapeWrk, src/workspace.jl:147-362).
-`H0[k]` is the drift of trajectory `k`, `Hc[l]` the operator multiplying control `l`.
+# ---- the static problem out of the reference's own types -----------------------------------------------------------
+
 """
-function Handle(H0::Vector{Matrix{ComplexF64}}, Hc::Vector{Matrix{ComplexF64}}, tlist::Vector{Float64},
-                psi0::Vector{Vector{ComplexF64}}, target::Vector{Vector{ComplexF64}};
-                weights = ones(length(H0)), functional = 0, gradient_method = 0, device = 0, K_total = 0,
-                prop_method = 0)
-    K, N, L = length(H0), size(H0[1], 1), length(Hc)
-    H0f = reduce(hcat, vec.(H0)); Hcf = reduce(hcat, vec.(Hc))
-    p0 = reduce(hcat, psi0); tg = reduce(hcat, target)
-    keep = Any[H0f, Hcf, p0, tg, tlist, weights]
-    prob = Ref(GrapeProblem(3, N, L, K, K_total, length(tlist) - 1, functional, gradient_method, 0, device,
-                            pointer(tlist), pointer(H0f), pointer(Hcf), C_NULL, pointer(p0), pointer(tg),
-                            pointer(weights), 0.0, 0, 0.0, C_NULL, 0, 0.0, prop_method, 0.0))
+    drift, control_ops, amplitudes = split_generator(generator)
+
+`QuantumPropagators.Generators.Generator` keeps `ops` (drift terms first, then one operator per amplitude) and
+`amplitudes` (`hamiltonian(H0, (H1, ϵ1), ...)`, docs/src/tutorial.md:55-73).
+"""
+function split_generator(gen)
+    ops, amps = gen.ops, gen.amplitudes
+    nd = length(ops) - length(amps)
+    n = size(ops[1], 1)
+    drift = zeros(ComplexF64, n, n)
+    for op in ops[1:nd]
+        drift .+= Matrix{ComplexF64}(op)
+    end
+    return drift, [Matrix{ComplexF64}(op) for op in ops[nd+1:end]], collect(amps)
+end
+
+control_of(a) = a
+control_of(a::ShapedAmplitude) = a.control
+
+"""
+    H0, Hc, hc_per_traj, shape = problem_arrays(wrk)
+
+Drift `H0[k]` of every trajectory, the operator `Hc[k][l]` = ∂H_k/∂ϵ_l multiplying control `l` of `wrk.controls`
+(src/workspace.jl:152-157; a control that enters a generator through several amplitudes gets the sum of their
+operators), and the static shapes `S_l(t_n)` of `ShapedAmplitude`s discretised on the midpoints of the time grid
+(docs/src/tutorial.md:75-107) -- `nothing` if no amplitude is shaped.  Control amplitudes that depend non-linearly on
+their control are not expressible in `grape_problem` (INTEGRATION.md: host-side chain rule).
+"""
+function problem_arrays(wrk)
+    tlist, controls = wrk.result.tlist, wrk.controls
+    K, L, N_T = length(wrk.trajectories), length(controls), length(tlist) - 1
+    H0 = Matrix{ComplexF64}[]
+    Hc = Vector{Matrix{ComplexF64}}[]
+    shape = ones(Float64, N_T, L)
+    shaped = false
+    for traj in wrk.trajectories
+        drift, ops, amps = split_generator(traj.generator)
+        n = size(drift, 1)
+        per_l = [zeros(ComplexF64, n, n) for _ = 1:L]
+        for (op, a) in zip(ops, amps)
+            l = findfirst(c -> c === control_of(a), controls)
+            isnothing(l) && error("GrapeHIP: amplitude of type $(typeof(a)) is not a (shaped) control of the problem")
+            per_l[l] .+= op
+            if a isa ShapedAmplitude
+                shape[:, l] .= discretize_on_midpoints(a.shape, tlist)
+                shaped = true
+            end
+        end
+        push!(H0, drift)
+        push!(Hc, per_l)
+    end
+    hc_per_traj = any(Hc[k] != Hc[1] for k = 2:K)
+    return H0, Hc, hc_per_traj, (shaped ? shape : nothing)
+end
+
+"""J_T_sm / J_T_ss / J_T_re have a device-side χ (fast path); any other functional goes through `grape_backward_chi`."""
+function functional_code(J_T)
+    J_T === J_T_sm && return 0
+    J_T === J_T_ss && return 1
+    J_T === J_T_re && return 2
+    return -1
+end
+
+
+"""
+    Handle(wrk; device = 0, devices = nothing, prop_method = 0, D = nothing)
+
+Uploads the static problem of a `GrapeWrk` (replaces the buffer set-up of src/workspace.jl:147-362).  Options are
+taken from `wrk.kwargs` exactly where the reference reads them: `gradient_method` (workspace.jl:150), `chi_min_norm`
+(optimize.jl:846), `taylor_grad_max_order` / `taylor_grad_tolerance` (optimize.jl:915-916), `lambda_b` (:833).
+`D` (one matrix or one per trajectory) selects the state running cost of the family `g_b(Ψ) = ⟨Ψ|D|Ψ⟩`, `ξ = −DΨ`
+(test/test_state_running_cost.jl:32-40).  `devices = [0, 1, ...]` spreads the trajectories over several GPUs behind this
+one handle -- the analogue of `use_threads` (optimize.jl:720, 876).
+"""
+function Handle(wrk; device = 0, devices = nothing, prop_method = 0, D = nothing)
+    tlist = Vector{Float64}(wrk.result.tlist)
+    kw = wrk.kwargs
+    H0, Hc, hc_per_traj, shape = problem_arrays(wrk)
+    K, N, L, N_T = length(H0), size(H0[1], 1), length(wrk.controls), length(tlist) - 1
+    H0f = reduce(hcat, vec.(H0))                                            # [N*N, K]: K column-major matrices
+    Hcf = hc_per_traj ? reduce(hcat, [reduce(hcat, vec.(Hc[k])) for k = 1:K]) : reduce(hcat, vec.(Hc[1]))
+    p0 = reduce(hcat, [Vector{ComplexF64}(t.initial_state) for t in wrk.trajectories])
+    tg = reduce(hcat, [Vector{ComplexF64}(t.target_state) for t in wrk.trajectories])
+    weights = Float64[hasproperty(t, :weight) ? t.weight : 1.0 for t in wrk.trajectories]
+    shp = isnothing(shape) ? nothing : Matrix{Float64}(shape)               # [N_T, L] column-major == [l][n]
+    Df = isnothing(D) ? nothing : (D isa AbstractMatrix ? Matrix{ComplexF64}(D) : reduce(hcat, vec.(Matrix{ComplexF64}.(D))))
+    devs = isnothing(devices) ? nothing : Vector{Int32}(devices)
+    functional = functional_code(kw[:J_T])
+    keep = Any[H0f, Hcf, p0, tg, tlist, weights, shp, Df, devs]
+    prob = Ref(GrapeProblem(
+        ABI_VERSION, N, L, K, 0, N_T, max(functional, 0),
+        get(kw, :gradient_method, :gradgen) == :taylor ? 1 : 0, hc_per_traj ? 1 : 0, device,
+        pointer(tlist), pointer(H0f), pointer(Hcf), isnothing(shp) ? C_NULL : pointer(shp), pointer(p0), pointer(tg),
+        pointer(weights), get(kw, :chi_min_norm, 0.0), get(kw, :taylor_grad_max_order, 0),
+        get(kw, :taylor_grad_tolerance, 0.0), isnothing(Df) ? C_NULL : pointer(Df),
+        (D isa AbstractMatrix || isnothing(D)) ? 0 : 1, isnothing(D) ? 0.0 : get(kw, :lambda_b, 1.0), prop_method, 0.0,
+        isnothing(devs) ? 0 : length(devs), isnothing(devs) ? C_NULL : pointer(devs)))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = GC.@preserve keep ccall((:grape_create, libgrape), Cint, (Ref{Ptr{Cvoid}}, Ref{GrapeProblem}), out, prob)
-    h = Handle(out[], keep)
-    rc == 0 || error(unsafe_string(ccall((:grape_last_error, libgrape), Cstring, (Ptr{Cvoid},), C_NULL)))
+    rc == 0 || error(last_error(C_NULL))
+    h = Handle(out[], keep, K, N, functional)
     finalizer(x -> ccall((:grape_destroy, libgrape), Cvoid, (Ptr{Cvoid},), x.ptr), h)
     return h
 end
 
-"""
-    fg!(h, wrk)(F, G, pulsevals) -> J
 
-Replacement for the closure at src/optimize.jl:105-111.  Keeps the side effects callers rely on
-(SURVEY.md 8b): wrk.pulsevals, counters, wrk.result.tau_vals, wrk.J_parts[1], wrk.grad_J_Tb and
-the final states for update_result! (src/optimize.jl:187-189).
+"""
+    fg! = make_fg!(h, wrk)
+
+Replacement for the closure at src/optimize.jl:105-111.  Keeps the side effects callers rely on (SURVEY.md 8b):
+`wrk.pulsevals`, the call counters, `wrk.result.tau_vals`, `wrk.J_parts[1:3]`, `wrk.grad_J_Tb`, `wrk.grad_J_a` and the
+final states that `update_result!` reads (src/optimize.jl:187-189).
 """
 function make_fg!(h::Handle, wrk)
-    K = length(wrk.trajectories)
-    N = length(wrk.trajectories[1].initial_state)
+    K, N = h.K, h.N
+    kw = wrk.kwargs
+    tlist = wrk.result.tlist
     psiT = Matrix{ComplexF64}(undef, N, K)
+    chiT = Matrix{ComplexF64}(undef, N, K)
+    sums = zeros(Float64, 8)
+    J_T, chi = kw[:J_T], kw[:chi]
+    J_a, grad_J_a = get(kw, :J_a, nothing), get(kw, :grad_J_a, nothing)
+    λₐ, λ_b = get(kw, :lambda_a, 1.0), get(kw, :lambda_b, 1.0)
+    has_gb = !isnothing(get(kw, :g_b, nothing))
+    states() = [view(psiT, :, k) for k = 1:K]
+
     return function fg!(F, G, pulsevals)
         (pulsevals !== wrk.pulsevals) && (wrk.pulsevals .= pulsevals)      # src/optimize.jl:706-713
-        J = Ref{Float64}(0.0)
         if isnothing(G)
             wrk.result.f_calls += 1; wrk.fg_count[2] += 1                  # :715-716
-            Gp = Ptr{Float64}(C_NULL)
         else
             wrk.result.fg_calls += 1; wrk.fg_count[1] += 1                 # :838-839
-            Gp = pointer(wrk.grad_J_Tb)
         end
-        rc = GC.@preserve pulsevals psiT ccall((:grape_eval, libgrape), Cint,
-            (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}),
-            h.ptr, pointer(wrk.pulsevals), J, Gp, pointer(wrk.result.tau_vals), pointer(psiT))
-        check(h, rc)
-        wrk.J_parts[1] = J[]                                               # :757-760
+        x, tau = wrk.pulsevals, wrk.result.tau_vals
+        if h.functional >= 0
+            # built-in functional: one call, χ is formed on the device
+            J = Ref{Float64}(0.0)
+            Gp = isnothing(G) ? Ptr{Float64}(C_NULL) : pointer(wrk.grad_J_Tb)
+            rc = GC.@preserve x tau psiT wrk ccall((:grape_eval, libgrape), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}),
+                h.ptr, pointer(x), J, Gp, pointer(tau), pointer(psiT))
+            check(h, rc)
+            J_b = 0.0
+            if has_gb                                                      # J_parts[3] = λ_b Σ_k J_b,k, :764-766
+                check(h, ccall((:grape_get_sums, libgrape), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, sums))
+                J_b = λ_b * sums[5]
+                wrk.J_parts[3] = J_b
+            end
+            wrk.J_parts[1] = J[] - J_b                                     # :757-760
+        else
+            # user-supplied J_T / chi (optimize.jl:757-760, 845-855): forward on the device, J_T and χ(T) on the host,
+            # backward sweep and gradient on the device from the χ the user's function returns
+            check(h, GC.@preserve x tau ccall((:grape_forward, libgrape), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}), h.ptr, pointer(x), pointer(tau)))
+            check(h, ccall((:grape_get_final_states, libgrape), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), h.ptr, psiT))
+            Ψ = states()
+            wrk.J_parts[1] = wrk.J_T_takes_tau ? J_T(Ψ, wrk.trajectories; tau = tau) : J_T(Ψ, wrk.trajectories)
+            if has_gb
+                check(h, ccall((:grape_get_sums, libgrape), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, sums))
+                wrk.J_parts[3] = λ_b * sums[5]
+            end
+            if !isnothing(G)
+                χ = wrk.chi_takes_tau ? chi(Ψ, wrk.trajectories; tau = tau) : chi(Ψ, wrk.trajectories)
+                for k = 1:K
+                    chiT[:, k] .= χ[k]
+                end
+                check(h, GC.@preserve chiT wrk ccall((:grape_backward_chi, libgrape), Cint,
+                    (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}), h.ptr, pointer(chiT), pointer(wrk.grad_J_Tb)))
+            end
+        end
+        if !isnothing(J_a)
+            wrk.J_parts[2] = λₐ * J_a(wrk.pulsevals, tlist)                # :761-763
+        end
         for k = 1:K
             copyto!(wrk.fw_propagators[k].state, view(psiT, :, k))         # read by update_result! :187-189
         end
-        isnothing(G) || copyto!(G, wrk.grad_J_Tb)                          # :1002-1003
+        if !isnothing(G)
+            copyto!(G, wrk.grad_J_Tb)                                      # :1002-1003
+            if !isnothing(grad_J_a)                                        # :1004-1011
+                wrk.grad_J_a = grad_J_a(wrk.pulsevals, tlist)
+                axpy!(λₐ, wrk.grad_J_a, G)
+            end
+        end
         return sum(wrk.J_parts)
     end
 end

@@ -251,7 +251,8 @@ static int grape_ref_eval_gb(int N, int L, int K, int N_T, const double *tlist, 
                    const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
                    double *tau_grads_ /* K*N_T*L cplx, [k][l][n] */, int nthreads,
                    const double *D_ /* NULL or [Kd][N*N] column-major Hermitian penalty operator */,
-                   int d_per_traj, double lambda_b);
+                   int d_per_traj, double lambda_b,
+                   const double *chi_in_ /* NULL or [K][N]: chi_k(T) of a user-supplied chi(), optimize.jl:845-855 */);
 
 int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const double *H0_,
                    const double *Hc_, int hc_per_traj, const double *psi0_, const double *target_,
@@ -259,7 +260,7 @@ int grape_ref_eval(int N, int L, int K, int N_T, const double *tlist, const doub
                    const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
                    double *tau_grads_, int nthreads) {
     return grape_ref_eval_gb(N, L, K, N_T, tlist, H0_, Hc_, hc_per_traj, psi0_, target_, weights, functional,
-                             gradient_method, pulsevals, J, G, tau_, psiT_, tau_grads_, nthreads, NULL, 0, 0.0);
+                             gradient_method, pulsevals, J, G, tau_, psiT_, tau_grads_, nthreads, NULL, 0, 0.0, NULL);
 }
 
 /* same with the state-dependent running cost g_b(Psi) = <Psi|D|Psi>, xi = -D Psi
@@ -270,7 +271,20 @@ int grape_ref_eval_b(int N, int L, int K, int N_T, const double *tlist, const do
                      const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
                      double *tau_grads_, int nthreads, const double *D_, int d_per_traj, double lambda_b) {
     return grape_ref_eval_gb(N, L, K, N_T, tlist, H0_, Hc_, hc_per_traj, psi0_, target_, weights, functional,
-                             gradient_method, pulsevals, J, G, tau_, psiT_, tau_grads_, nthreads, D_, d_per_traj, lambda_b);
+                             gradient_method, pulsevals, J, G, tau_, psiT_, tau_grads_, nthreads, D_, d_per_traj, lambda_b, NULL);
+}
+
+/* same with the boundary states chi_k(T) handed in by the caller: the result of the user's
+ * `chi(Psi, trajectories; tau)` (src/optimize.jl:845-855), any functional.  J is J_T_sm of the inputs (the caller
+ * evaluates its own J_T from psiT / tau); everything downstream of chi (:856-1014) is unchanged. */
+int grape_ref_eval_chi(int N, int L, int K, int N_T, const double *tlist, const double *H0_,
+                       const double *Hc_, int hc_per_traj, const double *psi0_, const double *target_,
+                       const double *weights, int gradient_method, const double *pulsevals, double *J, double *G,
+                       double *tau_, double *psiT_, double *tau_grads_, int nthreads, const double *D_, int d_per_traj,
+                       double lambda_b, const double *chi_in_) {
+    return grape_ref_eval_gb(N, L, K, N_T, tlist, H0_, Hc_, hc_per_traj, psi0_, target_, weights, GRAPE_REF_SM,
+                             gradient_method, pulsevals, J, G, tau_, psiT_, tau_grads_, nthreads, D_, d_per_traj, lambda_b,
+                             chi_in_);
 }
 
 static int grape_ref_eval_gb(int N, int L, int K, int N_T, const double *tlist, const double *H0_,
@@ -278,7 +292,7 @@ static int grape_ref_eval_gb(int N, int L, int K, int N_T, const double *tlist, 
                    const double *weights, int functional, int gradient_method,
                    const double *pulsevals, double *J, double *G, double *tau_, double *psiT_,
                    double *tau_grads_ /* K*N_T*L cplx, [k][l][n] */, int nthreads,
-                   const double *D_, int d_per_traj, double lambda_b) {
+                   const double *D_, int d_per_traj, double lambda_b, const double *chi_in_) {
     const cplx *Dop = (const cplx *)D_;
     double *Jb_traj = (double *)calloc((size_t)K, sizeof(double));
     const size_t nn = (size_t)N * N;
@@ -367,7 +381,8 @@ static int grape_ref_eval_gb(int N, int L, int K, int N_T, const double *tlist, 
             const cplx *stT = storage + (size_t)k * (N_T + 1) * N + (size_t)N_T * N;
             const cplx *Dk = Dop ? Dop + (d_per_traj ? (size_t)k * nn : 0) : NULL;
             cplx *xi = (cplx *)malloc(sizeof(cplx) * N);
-            for (int i = 0; i < N; ++i) chi[i] = coeff * target[(size_t)k * N + i]; /* optimize.jl:848-855 */
+            for (int i = 0; i < N; ++i) /* optimize.jl:848-855 */
+                chi[i] = chi_in_ ? ((const cplx *)chi_in_)[(size_t)k * N + i] : coeff * target[(size_t)k * N + i];
             if (Dk && lambda_b != 0.0) { /* :856-866 chi += lambda_b dt/2 xi(T), xi = -D Psi */
                 const double dtl = tlist[N_T] - tlist[N_T - 1];
                 zgemv_n(N, Dk, stT, xi);

@@ -101,5 +101,48 @@ def evaluate(H0, Hc, tlist, pulsevals, psi0, target, weights=None, functional=0,
     return J.value, G, tau
 
 
+def evaluate_chi(H0, Hc, tlist, pulsevals, psi0, target, chi, weights=None, gradient_method=GRADGEN, nthreads=0,
+                 D=None, lambda_b=1.0):
+    """Gradient from caller-supplied boundary states chi[k] = chi_k(T) (user-defined J_T / chi pair,
+    src/optimize.jl:845-855).  Returns (G, tau, psiT, tau_grads)."""
+    H0 = np.asarray(H0)
+    K, N = H0.shape[0], H0.shape[1]
+    Hc = np.asarray(Hc)
+    per_traj = Hc.ndim == 4
+    L = Hc.shape[1] if per_traj else Hc.shape[0]
+    tl = np.ascontiguousarray(tlist, dtype=np.float64)
+    N_T = len(tl) - 1
+    H0c = np.ascontiguousarray(np.swapaxes(H0, -1, -2), dtype=np.complex128)
+    Hcc = np.ascontiguousarray(np.swapaxes(Hc, -1, -2), dtype=np.complex128)
+    p0 = np.ascontiguousarray(psi0, dtype=np.complex128)
+    tg = np.ascontiguousarray(target, dtype=np.complex128)
+    ch = np.ascontiguousarray(chi, dtype=np.complex128)
+    assert ch.shape == (K, N)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    x = np.ascontiguousarray(pulsevals, dtype=np.float64)
+    J = C.c_double(0.0)
+    G = np.zeros(L * N_T)
+    tau = np.zeros(K, dtype=np.complex128)
+    psiT = np.zeros((K, N), dtype=np.complex128)
+    tgr = np.zeros((K, L, N_T), dtype=np.complex128)
+    vp = C.c_void_p
+    Dc, dper = None, False
+    if D is not None:
+        D = np.asarray(D)
+        dper = D.ndim == 3
+        Dc = np.ascontiguousarray(np.swapaxes(D, -1, -2), dtype=np.complex128)
+    lib().grape_ref_eval_chi.restype = C.c_int
+    rc = lib().grape_ref_eval_chi(
+        C.c_int(N), C.c_int(L), C.c_int(K), C.c_int(N_T), tl.ctypes.data_as(vp), H0c.ctypes.data_as(vp),
+        Hcc.ctypes.data_as(vp), C.c_int(int(per_traj)), p0.ctypes.data_as(vp), tg.ctypes.data_as(vp),
+        None if w is None else w.ctypes.data_as(vp), C.c_int(gradient_method), x.ctypes.data_as(vp), C.byref(J),
+        G.ctypes.data_as(vp), tau.ctypes.data_as(vp), psiT.ctypes.data_as(vp), tgr.ctypes.data_as(vp),
+        C.c_int(nthreads), None if Dc is None else Dc.ctypes.data_as(vp), C.c_int(int(dper)), C.c_double(lambda_b),
+        ch.ctypes.data_as(vp))
+    if rc:
+        raise RuntimeError(f"grape_ref_eval_chi failed with code {rc}")
+    return G, tau, psiT, tgr
+
+
 def max_threads():
     return lib().grape_ref_max_threads()

@@ -29,7 +29,13 @@ class OracleShard:
         p, sl = self.pr, slice(self.lo, self.hi)
         self.x = np.array(x)
         _, tau, _ = go.evaluate_functional(*self._args(), x, p["psi0"][sl], p["target"][sl], p["weights"][sl])
+        self.tau = tau
         return tau
+
+    def sums(self):   # grape_get_sums: the shard's partial sums with the handle's own weights
+        w, tau = self.pr["weights"][self.lo:self.hi], self.tau
+        f = np.sum(w * tau)
+        return np.array([f.real, f.imag, np.sum(w * np.abs(tau) ** 2), f.real, 0.0, 0.0, 0.0, 0.0])
 
     def backward(self, f_total):
         p, sl = self.pr, slice(self.lo, self.hi)
@@ -44,8 +50,7 @@ def _worker(rank, world, port, functional, q):
     pr = synth.make_problem(6, 2, 5, 5, seed=42)
     pr["weights"] = np.array([0.5, 1.0, 1.5, 2.0, 0.25])
     lo, hi = shard_range(5, world, rank)
-    ev = ShardedEvaluator(OracleShard(pr, lo, hi, 5, functional), 5, functional,
-                          weights_local=pr["weights"][lo:hi], dist=dist)
+    ev = ShardedEvaluator(OracleShard(pr, lo, hi, 5, functional), 5, functional, dist=dist)
     J, G, tau = ev.eval_host(pr["pulsevals"])
     if rank == 0:
         q.put((J, G, lo, hi))

@@ -14,6 +14,7 @@ from scipy.linalg import expm, expm_frechet
 import grape_oracle as go
 from grape_jl_amd import synth
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
 
@@ -68,19 +69,42 @@ def test_gradgen_equals_taylor_equals_frechet():
     assert abs(g - parts["tau_grads"][k, n, l]) < 1e-14
 
 
+def random_matrix(N, rng, radius=1.0):
+    """QuantumControlTestUtils.RandomObjects.random_matrix with its defaults: dense complex non-Hermitian matrix
+    scaled to spectral radius 1 (the generator of /root/reference/test/test_taylor_grad.jl:17-19)."""
+    X = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    return X * (radius / np.abs(np.linalg.eigvals(X)).max())
+
+
 def test_taylor_grad_step_vs_commutator_series():
-    # mirrors /root/reference/test/test_taylor_grad.jl:13-71 (non-Hermitian N=10, dt = +-1.25)
-    rng = np.random.default_rng(20)
-    N = 10
-    H = (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))) / np.sqrt(N)
-    mu = (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))) / np.sqrt(N)
-    psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
-    psi /= np.linalg.norm(psi)
-    for dt in (1.25, -1.25):
-        ref = go.U_grad_commutator_series(H, mu, dt) @ psi
-        got = go.taylor_grad_step(psi, H, mu, dt)
-        assert np.linalg.norm(ref - got) < 1e-13
-        assert np.linalg.norm(expm_frechet(-1j * H * dt, -1j * mu * dt, compute_expm=False) @ psi - got) < 1e-13
+    # mirrors /root/reference/test/test_taylor_grad.jl:13-71 at the reference's own bar: non-Hermitian N = 10,
+    # H = H0 + H1 + H2 (each of spectral radius 1), dt = +-1.25, norm(delta) < 1e-14 for both control operators
+    for seed in (3991576559, 1, 2):
+        rng = np.random.default_rng(seed)
+        N = 10
+        H0, H1, H2 = (random_matrix(N, rng) for _ in range(3))
+        H = H0 + H1 + H2
+        psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+        psi /= np.linalg.norm(psi)
+        for dt in (1.25, -1.25):
+            for mu in (H1, H2):
+                ref = go.U_grad_commutator_series(H, mu, dt) @ psi
+                got = go.taylor_grad_step(psi, H, mu, dt)
+                assert np.linalg.norm(ref - got) < 1e-14
+                assert np.linalg.norm(expm_frechet(-1j * H * dt, -1j * mu * dt, compute_expm=False) @ psi - got) < 1e-14
+
+
+def test_c_restatement_under_address_and_ub_sanitizers():
+    """ASan/UBSan on the CPU restatement.  `make -C oracle asan` builds grape_ref.c with its driver
+    (oracle/asan_driver.c: every entry point, all Pade branches, ragged sizes, exactly-sized heap buffers) under
+    -fsanitize=address,undefined; any report aborts the binary."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.run(["make", "-C", odir, "asan"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    res = subprocess.run([os.path.join(odir, "_build", "asan_driver")], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "asan-driver OK" in res.stdout and "runtime error" not in res.stderr and "AddressSanitizer" not in res.stderr
 
 
 def test_c_expm_all_branches(ref):
