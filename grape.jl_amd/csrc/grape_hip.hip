@@ -636,7 +636,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     h->series = p->prop_method == GRAPE_PROP_SERIES;
     if (p->prop_tolerance > 0) h->series_tol = p->prop_tolerance;
 
-    auto fail = [&](int code) { g_create_error = h->err; grape_destroy(h); return code; };
+    auto fail = [&](int code) { g_create_error = h->err; grape_destroy(h); (void)hipGetLastError(); return code; };
 #define CCHK(expr)                                                                              \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \
@@ -932,6 +932,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     if (!h->shards.empty()) { h->err = "device-pointer entry points need a single-device handle (ndev <= 1)"; return GRAPE_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream_;
     HIPCHK(h, hipSetDevice(h->device));
+    // HIP's last-error is sticky per host thread: a failure elsewhere in the process (another handle's failed
+    // allocation, a bad device ordinal) must not be reported by the launch checks of this evaluation
+    (void)hipGetLastError();
     HIPCHK(h, hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 16 * sizeof(unsigned long long), s));
     if (d_pulsevals != h->d_eps)
@@ -1062,6 +1065,7 @@ namespace {
 int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStream_t s, const double2 *d_chi) {
     if (!h->have_forward) { h->err = "grape_backward called before grape_forward"; return GRAPE_ERR_INVALID; }
     HIPCHK(h, hipSetDevice(h->device));
+    (void)hipGetLastError();   // see grape_forward_device
     hipError_t e;
     // ---- phase 2: chi boundary + backward sweep ----
     SweepArgs sa{};

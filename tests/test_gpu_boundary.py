@@ -162,7 +162,7 @@ def test_device_shards_behind_one_handle(g, ref, N, L, K, N_T, functional, ndev,
         assert np.array_equal(hm.storage(0), fw1)
         assert np.array_equal(hm.propagator(K - 1, N_T - 1), U1)
         wm = hm.work()
-        assert wm["cells"] == w1["cells"] and wm["flop_expm"] == w1["flop_expm"]
+        assert wm["cells"] == w1["cells"] and abs(wm["flop_expm"] - w1["flop_expm"]) <= 1e-12 * w1["flop_expm"]
         Jf, Gf, _ = hm.eval(x, gradient=False)
         assert Gf is None and Jf == Jm
         J2, G2, _ = hm.eval(x)
@@ -199,6 +199,10 @@ def test_more_devices_than_trajectories_and_bad_ordinal(g):
     with pytest.raises(g.GrapeHipError) as ei:
         g.GrapeHip(*args, devices=[0, 99])
     assert ei.value.code == -2 and "device shard 1" in str(ei.value)
+    # the failed create leaves no sticky HIP error behind: the next evaluation of a healthy handle works
+    with g.GrapeHip(*args) as h1:
+        J2, G2, _ = h1.eval(pr["pulsevals"])
+    assert J2 == J1 and np.array_equal(G2, G1)
 
 
 def test_box_bounds_through_the_hip_backend(g):
@@ -209,6 +213,7 @@ def test_box_bounds_through_the_hip_backend(g):
     traj = G.Trajectory(np.array([1, 0], complex), H, target_state=np.array([0, 1], complex))
     res = G.optimize([traj], tlist, J_T=G.J_T_sm, iter_stop=10, upper_bound=0.7, lower_bound=-0.7,
                      check_convergence=lambda r: "J_T < 10^-10" if r.J_T < 1e-10 else "")
+    assert not res.message.startswith("Exception"), res.message
     assert res.J_T < 1e-3
     assert 0.65 < np.max(np.abs(res.optimized_controls[0])) < 0.700001
     # per-control bounds with the reference's pulse_options keys (workspace.jl:204-214); L = 1: both layouts coincide

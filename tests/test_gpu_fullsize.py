@@ -105,27 +105,28 @@ def test_baseline_config_c5_full_problem_and_gpu_shard(g):
         J2, G2, _ = h.eval(x)
         assert J2 == J and np.array_equal(G2, G)
         tm_full = h.timings()
-        # (b) one GPU's shard of the 8-GPU job, and the sum over all 8 shards, while the full handle is still alive
-        taus, sums, Gsum, tm_shard = [], np.zeros(8), None, None
-        fs = []
-        for s in range(8):
-            sl = slice(8 * s, 8 * s + 8)
-            hs = g.GrapeHip(pr["H0"][sl], pr["Hc"], pr["tlist"], pr["psi0"][sl], pr["target"][sl], pr["weights"][sl],
-                            K_total=K)
-            taus.append(hs.forward(x))
-            sums += hs.sums()
-            fs.append(hs)
-        for s, hs in enumerate(fs):
-            Gp = hs.backward(complex(sums[0], sums[1]))
-            Gsum = Gp if Gsum is None else Gsum + Gp
-            if s == 0:
-                tm_shard = hs.timings()
-                if True:   # the shard alone: finite differences need the job-wide sums, so check linearity instead --
-                    # twice the boundary coefficient gives twice the partial gradient (chi_sm is linear in f)
-                    Gp2 = hs.backward(complex(2 * sums[0], 2 * sums[1]))
-                    assert np.abs(Gp2 - 2 * Gp).max() <= 1e-13 * max(np.abs(Gp).max(), 1e-3)
-            hs.close()
-        assert np.array_equal(np.concatenate(taus), tau)
-        assert abs(functional_value(0, sums, K) - J) <= 1e-14
-        assert np.abs(Gsum - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
+    # (b) the 8 GPU shards of the 8-GPU job, all alive between the two reductions as on 8 ranks (8 x 23 GB; the full
+    # handle above is closed first: 140 + 182 GB would not fit), and the sum over them
+    taus, sums, Gsum, tm_shard = [], np.zeros(8), None, None
+    fs = []
+    for s in range(8):
+        sl = slice(8 * s, 8 * s + 8)
+        hs = g.GrapeHip(pr["H0"][sl], pr["Hc"], pr["tlist"], pr["psi0"][sl], pr["target"][sl], pr["weights"][sl],
+                        K_total=K)
+        taus.append(hs.forward(x))
+        sums += hs.sums()
+        fs.append(hs)
+    for s, hs in enumerate(fs):
+        Gp = hs.backward(complex(sums[0], sums[1]))
+        Gsum = Gp if Gsum is None else Gsum + Gp
+        if s == 0:
+            tm_shard = hs.timings()
+            # the shard alone: finite differences need the job-wide sums, so check linearity instead -- twice the
+            # boundary coefficient gives twice the partial gradient (chi_sm is linear in f)
+            Gp2 = hs.backward(complex(2 * sums[0], 2 * sums[1]))
+            assert np.abs(Gp2 - 2 * Gp).max() <= 1e-13 * max(np.abs(Gp).max(), 1e-3)
+        hs.close()
+    assert np.array_equal(np.concatenate(taus), tau)
+    assert abs(functional_value(0, sums, K) - J) <= 1e-14
+    assert np.abs(Gsum - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
     print(f"C5 full (K = 64) on one GPU: {tm_full}\nC5 shard (K = 8): {tm_shard}")

@@ -22,6 +22,7 @@ def test_tls_optimization_hip_backend():
     tlist = np.linspace(0, 5, 501)
     traj = G.Trajectory(np.array([1, 0], complex), H, target_state=np.array([0, 1], complex))
     res = G.optimize([traj], tlist, J_T=G.J_T_sm, iter_stop=5)
+    assert not res.message.startswith("Exception"), res.message
     assert res.J_T < 1e-3
     assert 0.75 < np.max(np.abs(res.optimized_controls[0])) < 0.85
     # taylor route reaches the same functional (test_tls_optimization.jl:204-233: |dJ_T| < 1e-10)
