@@ -187,11 +187,17 @@ def main():
         """One evaluation at the boundary: fresh pulses in, (J, G) out on the host, errors checked."""
         if dist is None:
             return h.eval(xs[i])   # grape_eval(h, pulsevals, &J, G, tau, NULL): synchronous
-        x.copy_(xs_pinned[i], non_blocking=True)
-        ev.eval_device(stream)
-        G_host.copy_(G, non_blocking=True)
-        sums_host.copy_(out[2 * K_local:2 * K_local + 8], non_blocking=True)
-        h.check(stream)            # synchronises the stream and raises on a device-side error flag
+        for attempt in (0, 1):
+            x.copy_(xs_pinned[i], non_blocking=True)
+            ev.eval_device(stream)
+            G_host.copy_(G, non_blocking=True)
+            sums_host.copy_(out[2 * K_local:2 * K_local + 8], non_blocking=True)
+            try:
+                h.check(stream)    # synchronises the stream and raises on a device-side error flag
+                break
+            except g.GrapeHipError as exc:   # GRAPE_ERR_AGAIN (N > 64): the launch plan was adapted, repeat once
+                if exc.code != -7 or attempt:
+                    raise
         return None
 
     for i in range(args.warmup):

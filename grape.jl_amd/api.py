@@ -23,7 +23,7 @@ PROP_EXP, PROP_SERIES = 0, 1
 ABI_VERSION = 4
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAPE_ERR_CHI_NORM",
-          -4: "GRAPE_ERR_SINGULAR", -5: "GRAPE_ERR_TAYLOR", -6: "GRAPE_ERR_NO_CONTROLS"}
+          -4: "GRAPE_ERR_SINGULAR", -5: "GRAPE_ERR_TAYLOR", -6: "GRAPE_ERR_NO_CONTROLS", -7: "GRAPE_ERR_AGAIN"}
 
 # every symbol include/grape_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = ["grape_create", "grape_destroy", "grape_eval", "grape_forward", "grape_backward",

@@ -95,6 +95,7 @@ struct grape_handle {
     double2 *d_gpark = nullptr;  // [K][N_T][maxp][NP] terms of the forward series, consumed by deriv2_kernel
     int *d_morder = nullptr;     // [K][N_T]
     int maxp = 0;
+    int sq_plan = 2;             // blocked path: squaring launches issued per chunk (adapted by grape_check, see expm_large)
     double2 *d_chi_in = nullptr; // [K][N] host-supplied boundary states of grape_backward_chi (allocated on first use)
     // several GPUs behind one handle (grape_problem.ndev > 1): this handle owns no device memory, its trajectories
     // are dealt to the child handles in contiguous blocks [shard_lo[g], shard_lo[g+1])
@@ -376,7 +377,7 @@ hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, 
                    double beta, int nadd = 0, const LgView *add = nullptr, const double *coef = nullptr,
                    double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0, int herm = 0,
                    const int *scale_s = nullptr, int scale_pow = 0, double2 *Uout = nullptr, int u_np = 0,
-                   int skip_bi = -1) {
+                   int skip_bi = -1, const int *smax_ptr = nullptr) {
     if (nbi <= 0 || nbj <= 0) return hipSuccess;
     LgGemmArgs a{};
     a.X = X; a.Y = Y; a.C = C; a.kblocks = kblocks; a.alpha = alpha; a.beta = beta; a.cI = cI;
@@ -384,6 +385,7 @@ hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, 
     for (int i = 0; i < nadd; ++i) { a.Add[i] = add[i]; a.coef[i] = coef[i]; }
     a.s_cell = s_cell; a.sq_iter = sq_iter; a.herm = (nbi == nbj) ? herm : 0;
     a.scale_s = scale_s; a.scale_pow = scale_pow; a.Uout = Uout; a.u_np = u_np; a.skip_bi = skip_bi;
+    a.smax_ptr = smax_ptr;
     a.nbi = nbi; a.nbj = nbj; a.ncell = nc;
     const int groups = (nc + 7) / 8;   // cells are dealt to the 8 XCDs in groups
     const int per_cell = a.herm ? nbi * (nbi + 1) / 2 : nbi * nbj;
@@ -486,24 +488,24 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
             hipLaunchKernelGGL(lg_pivoted_kernel, dim3(std::min(nc, 256)), dim3(1024), 0, s, pa);
             LGCHK(hipGetLastError());
         }
-        // squarings (per-cell count; cells that are done are copied through)
-        int smax = 0;
-        LGCHK(hipMemcpyAsync(&smax, h->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        LGCHK(hipStreamSynchronize(s));
+        // squarings (per-cell count; cells that are done are copied through).  The largest count is only known on the
+        // device (flags[1]); instead of reading it back -- a host synchronisation per chunk -- the host issues a PLAN of
+        // h->sq_plan squaring launches: every launch compares its index with the device-side count, exits at once when
+        // it is not needed, and the last needed one writes U_kn (interleaved complex) itself.  A plan that turns out
+        // too short flags the evaluation (bit 5): grape_check adapts the plan and the call is repeated.
+        const int *smax_ptr = h->d_flags + 1;
         double *X = W, *Y = T;
-        for (int it = 0; it < smax; ++it) {
-            // the last squaring writes U_kn (interleaved complex) itself; cells that are done are copied through
-            double2 *uout = it == smax - 1 ? h->d_U + (size_t)c0 * pp : nullptr;
+        for (int it = 0; it < h->sq_plan; ++it) {
             LGCHK(lg_gemm(s, nc, NB, NB, lg_full(X, NP), lg_full(X, NP), lg_full(Y, NP), NB, 1.0, 0.0, 0, nullptr, nullptr,
-                          0.0, h->d_scell, it, 0, nullptr, 0, uout, NP));
+                          0.0, h->d_scell, it, 0, nullptr, 0, h->d_U + (size_t)c0 * pp, NP, -1, smax_ptr));
             std::swap(X, Y);
         }
-        if (smax == 0) {
-            hipLaunchKernelGGL(lg_store_u_kernel, dim3(2048), dim3(256), 0, s, (const double *)X,
-                               h->d_U + (size_t)c0 * pp, NP, (size_t)nc * pp);
-            LGCHK(hipGetLastError());
-        }
+        hipLaunchKernelGGL(lg_store_u_kernel, dim3(2048), dim3(256), 0, s, (const double *)W,
+                           h->d_U + (size_t)c0 * pp, NP, (size_t)nc * pp, smax_ptr);
+        LGCHK(hipGetLastError());
     }
+    hipLaunchKernelGGL(lg_plan_check_kernel, dim3(1), dim3(1), 0, s, h->d_flags, h->sq_plan);
+    LGCHK(hipGetLastError());
     return hipSuccess;
 }
 
@@ -520,6 +522,12 @@ SeriesArgs series_args(grape_handle *h, const SweepArgs &sa, bool backward) {
 }
 
 int status_from_flags(grape_handle *h, int flags) {
+    // first: an evaluation whose propagators were never finished raises every other flag as a consequence
+    if (flags & 32) {
+        h->err = "the squaring plan of the blocked exponential was too short for this evaluation; the plan has been "
+                 "adapted: repeat the call (the host-pointer entry points do so themselves)";
+        return GRAPE_ERR_AGAIN;
+    }
     if (flags & 1) { h->err = "Pade denominator numerically singular in at least one cell"; return GRAPE_ERR_SINGULAR; }
     if (flags & 2) {
         h->err = "The chi state of at least one trajectory has norm < chi_min_norm (optimize.jl:1021-1025)";
@@ -1186,6 +1194,8 @@ int grape_check(grape_handle *h, void *stream_) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_));
     HIPCHK(h, hipMemcpy(flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
+    // blocked path: the squaring plan follows the counts seen on the device (one spare launch costs microseconds)
+    if (h->large && !h->series) h->sq_plan = std::max(2, flags[1] + 1);
     return status_from_flags(h, flags[0]);
 }
 
@@ -1250,13 +1260,16 @@ int multi_forward(grape_handle *h, const double *pulsevals, double *tau) {
     }
     double *sums = h->h_multi.data();   // [8]: shard sums added in shard order (fixed: reproducible)
     std::fill(sums, sums + 8, 0.0);
+    int again = 0;
     for (size_t g = 0; g < h->shards.size(); ++g) {
         grape_handle *c = h->shards[g];
         const int rc = forward_finish(c, tau ? tau + 2 * (size_t)h->shard_lo[g] : nullptr);
+        if (rc == GRAPE_ERR_AGAIN) { again = 1; h->err = c->err; continue; }   // every shard adapts its own plan
         if (rc) return multi_fail(h, c, rc);
         const double *cs = forward_sums(c);
         for (int i = 0; i < 8; ++i) sums[i] += cs[i];
     }
+    if (again) return GRAPE_ERR_AGAIN;
     h->have_forward = true;
     return GRAPE_OK;
 }
@@ -1281,10 +1294,20 @@ extern "C" {
 
 int grape_forward(grape_handle *h, const double *pulsevals, double *tau) {
     if (!h || !pulsevals) return GRAPE_ERR_INVALID;
-    if (!h->shards.empty()) return multi_forward(h, pulsevals, tau);
+    if (!h->shards.empty()) {
+        int rc = multi_forward(h, pulsevals, tau);
+        if (rc == GRAPE_ERR_AGAIN) rc = multi_forward(h, pulsevals, tau);   // launch plan adapted: once more
+        return rc;
+    }
     int rc = forward_enqueue(h, pulsevals);
     if (rc) return rc;
-    return forward_finish(h, tau);
+    rc = forward_finish(h, tau);
+    if (rc == GRAPE_ERR_AGAIN) {   // the squaring plan was too short and has been adapted by grape_check
+        rc = forward_enqueue(h, pulsevals);
+        if (rc) return rc;
+        rc = forward_finish(h, tau);
+    }
+    return rc;
 }
 
 int grape_backward(grape_handle *h, const double f_total[2], double *G_partial) {

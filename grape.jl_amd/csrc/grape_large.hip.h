@@ -36,6 +36,9 @@ struct LgGemmArgs {
     int u_np;
     int skip_bi;         // block row that is left alone (-1: none): the trailing update of a Gauss-Jordan step covers all
                          // block rows but the pivot row in ONE launch
+    const int *smax_ptr; // squarings only: the launch belongs to iteration sq_iter of a plan of fixed length; it exits at
+                         // once when sq_iter >= *smax_ptr (the largest squaring count so far, known only on the device)
+                         // and writes U when it is the last one -- no host read-back of the count between launches
 };
 
 __device__ __forceinline__ double *lg_ptr(const LgView &v, int cell, int brow, int bcol) {
@@ -64,6 +67,12 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
         bi = rem / a.nbj; bj = rem - bi * a.nbj;
     }
     if (bi == a.skip_bi) return;
+    double2 *Uout = a.Uout;
+    if (a.smax_ptr) {
+        const int sm = *a.smax_ptr;
+        if (a.sq_iter >= sm) return;
+        if (a.sq_iter != sm - 1) Uout = nullptr;
+    }
     const int col = 16 * wave + (lane & 15), rg = lane >> 4;
     double *c = lg_ptr(a.C, cell, bi, bj);
     if (a.s_cell && a.s_cell[cell] <= a.sq_iter) {   // no (further) squaring for this cell: C = X
@@ -71,8 +80,8 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int i = idx >> 6, j = idx & 63;
             const double vr = x[(size_t)i * a.X.ld + j], vi = x[a.X.plane + (size_t)i * a.X.ld + j];
-            if (a.Uout) {
-                a.Uout[(size_t)cell * a.u_np * a.u_np + (size_t)(bi * 64 + i) * a.u_np + bj * 64 + j] = make_double2(vr, vi);
+            if (Uout) {
+                Uout[(size_t)cell * a.u_np * a.u_np + (size_t)(bi * 64 + i) * a.u_np + bj * 64 + j] = make_double2(vr, vi);
             } else {
                 c[(size_t)i * a.C.ld + j] = vr;
                 c[a.C.plane + (size_t)i * a.C.ld + j] = vi;
@@ -125,8 +134,8 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
                 vi += a.coef[q] * ad[a.Add[q].plane + oa];
             }
             if (a.cI != 0.0 && grow0 + row == gcol) vr += a.cI;
-            if (a.Uout) {
-                a.Uout[(size_t)cell * a.u_np * a.u_np + (size_t)(bi * 64 + row) * a.u_np + bj * 64 + col] = make_double2(vr, vi);
+            if (Uout) {
+                Uout[(size_t)cell * a.u_np * a.u_np + (size_t)(bi * 64 + row) * a.u_np + bj * 64 + col] = make_double2(vr, vi);
             } else {
                 c[o] = vr;
                 c[a.C.plane + o] = vi;
@@ -437,12 +446,20 @@ __global__ void __launch_bounds__(1024) lg_pivoted_kernel(LgPivArgs a) {
 }
 
 // planar chunk result -> U[cell0 + i] (row-major interleaved complex)
-__global__ void lg_store_u_kernel(const double *X, double2 *U, int NP, size_t ncell_elems) {
+// smax_ptr: the store only happens when no cell needed a squaring (otherwise the last squaring launch wrote U)
+__global__ void lg_store_u_kernel(const double *X, double2 *U, int NP, size_t ncell_elems, const int *smax_ptr) {
+    if (smax_ptr && *smax_ptr != 0) return;
     const size_t pp = (size_t)NP * NP;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ncell_elems; i += (size_t)gridDim.x * blockDim.x) {
         const size_t cell = i / pp, o = i - cell * pp;
         U[i] = make_double2(X[cell * 2 * pp + o], X[cell * 2 * pp + pp + o]);
     }
+}
+
+// the squaring plan of the launch sequence was too short for the counts found on the device: flag the evaluation
+// (bit 5) so that the host repeats it with a longer plan
+__global__ void lg_plan_check_kernel(int *flags, int cap) {
+    if (flags[1] > cap) atomicOr(&flags[0], 32);
 }
 
 // ---- sweeps for NP in {128, 256}: one 1024-thread workgroup per trajectory ----

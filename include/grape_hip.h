@@ -53,7 +53,10 @@ typedef enum {
     GRAPE_ERR_CHI_NORM = -3,     /* ||chi_k|| < chi_min_norm          (optimize.jl:1021-1025)*/
     GRAPE_ERR_SINGULAR = -4,     /* Pade denominator numerically singular                    */
     GRAPE_ERR_TAYLOR = -5,       /* Taylor derivative series did not converge (optimize.jl:644-648) */
-    GRAPE_ERR_NO_CONTROLS = -6   /* L == 0                             (workspace.jl:155-157)*/
+    GRAPE_ERR_NO_CONTROLS = -6,  /* L == 0                             (workspace.jl:155-157)*/
+    GRAPE_ERR_AGAIN = -7         /* device-pointer API, N > 64 only: the asynchronous launch plan (number of squaring
+                                    launches) was too short for this evaluation and has been adapted -- repeat the call.
+                                    The host-pointer entry points repeat internally and never return this.          */
 } grape_status;
 
 /* J_T of QuantumControl.Functionals (docs/src/tutorial.md:349-356, 402) */

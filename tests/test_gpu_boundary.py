@@ -221,3 +221,42 @@ def test_box_bounds_through_the_hip_backend(g):
     res2 = G.optimize([traj], tlist, J_T=G.J_T_sm, iter_stop=10,
                       pulse_options=[(ctrl, {"upper_bounds": 0.6, "lower_bounds": -0.6})])
     assert res2.J_T < 1e-2 and np.max(np.abs(res2.optimized_controls[0])) < 0.600001
+
+
+def test_blocked_path_squaring_plan_without_host_synchronisation(g, ref):
+    """64 < N <= 256: the squaring count of scaling and squaring is only known on the device; the host issues a plan of
+    launches that exit when they are not needed instead of reading the count back between launches (no
+    hipStreamSynchronize inside grape_forward_device).  A plan that is too short flags the evaluation: the host-pointer
+    calls repeat internally (results identical to the oracle), the device-pointer call reports GRAPE_ERR_AGAIN once and
+    succeeds on the repeat."""
+    import torch
+    from grape_jl_amd import synth
+    from grape_jl_amd.sharded import ShardedEvaluator
+    pr = synth.make_problem(100, 1, 3, 2, seed=5, dt=5.0)    # ||A||_1 ~ 26: s = 3 > the initial plan of 2 launches
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    x = pr["pulsevals"]
+    Jr, Gr, taur = ref.evaluate(*args[:3], x, *args[3:])
+    with g.GrapeHip(*args) as h:
+        J, G, tau = h.eval(x)                     # plan too short -> adapted -> repeated inside grape_forward
+        w = h.work()
+        assert w["squarings"] / w["cells"] >= 3
+        assert abs(J - Jr) <= 1e-12 and np.abs(tau - taur).max() <= 1e-12 and np.abs(G - Gr).max() <= tol_G(Gr)
+        J2, G2, _ = h.eval(x)                     # the adapted plan fits: same numbers
+        assert J2 == J and np.array_equal(G2, G)
+    with g.GrapeHip(*args) as h:                  # fresh handle, device-pointer API
+        dev = torch.device("cuda", 0)
+        ev = ShardedEvaluator(h, 2, g.J_T_SM, dist=None, device=dev)
+        xd, out, Gd = ev.alloc_device(1, 3, 2)
+        xd.copy_(torch.from_numpy(x))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ev.eval_device(stream)
+        with pytest.raises(g.GrapeHipError) as ei:
+            h.check(stream)
+        assert ei.value.code == -7
+        ev.eval_device(stream)
+        h.check(stream)
+        assert ev.J_device() == J and np.array_equal(Gd.cpu().numpy(), G)
+    # composite handle: every shard adapts its own plan, one internal repeat
+    with g.GrapeHip(*args, devices=[0, 0]) as hm:
+        Jm, Gm, _ = hm.eval(x)
+        assert abs(Jm - J) <= 1e-14 and np.abs(Gm - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Bench lines and rocprofv3 kernel statistics of one build: tools/profile_round.sh <tag>
+#   gpurun_out/<tag>_bench_{C3,C2,C5}.json, gpurun_out/<tag>_{C3,C5}_kernel_stats.csv
+# (the summaries that are to be judged are copied to profiles/ and committed by hand)
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+tag=${1:-r02}
+python3 bench.py > gpurun_out/${tag}_bench_C3.json 2> gpurun_out/${tag}_bench_C3.err &&
+python3 bench.py --config C2 --steps 50 --warmup 5 > gpurun_out/${tag}_bench_C2.json 2> gpurun_out/${tag}_bench_C2.err &&
+python3 bench.py --config C5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_C5.json 2> gpurun_out/${tag}_bench_C5.err &&
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_C3 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_prof_C3.log 2>&1 &&
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_C5 -- python3 bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_prof_C5.log 2>&1
+rc=$?
+for c in C3 C5; do
+  f=$(find gpurun_out/${tag}_prof_$c -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" gpurun_out/${tag}_${c}_kernel_stats.csv
+done
+exit $rc
