@@ -1137,6 +1137,9 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         d2.batches_per_k = (h->N_T + 15) / 16;
         d2.nbatch_total = h->K * d2.batches_per_k;
         if (h->series) { d2.gpark = h->d_gpark; d2.morder = h->d_morder; d2.maxp = h->maxp; }
+#ifdef GRAPE_DIAG
+        d2.ablate = getenv("GRAPE_DIAG_ABLATE_D2") ? atoi(getenv("GRAPE_DIAG_ABLATE_D2")) : 0;
+#endif
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s);
     } else if (h->NP >= 64) {
         DerivMfmaArgs dm{};

@@ -1141,6 +1141,7 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
         strip_zero(A2);
         gemm_rot<LD, 3>(A2, Are, Aim, As, wave, lane);                 // A2 = A*A (slots 0..2)
     }
+    STAMP(13);
     rot_store_slots<LD, 3>(Xre, Xim, A2, wave, lane);                  // X = A2, with the mirrored tiles
     rot_store_adjoint<LD>(Xre, Xim, A2.re[1], A2.im[1], wave, lane, 1.0);
     __syncthreads();
@@ -1152,6 +1153,7 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     rot_exch_read(exch, A4, wave, lane);
     strip_zero(A6);
     gemm_rot<LD, 3>(A6, Xre, Xim, A4, wave, lane);                     // A6 = A2*A4
+    STAMP(14);
     __syncthreads();                                                   // everybody is done reading X = A2
     rot_store_slots<LD, 3>(Xre, Xim, A6, wave, lane);                  // X = A6
     rot_store_adjoint<LD>(Xre, Xim, A6.re[1], A6.im[1], wave, lane, 1.0);
@@ -1173,7 +1175,9 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
         for (int r = 0; r < 4; ++r)
             if (4 * r + rg == c) { T.re[0][r] += B13_1; V.re[0][r] += B13_0; }
     }
+    STAMP(15);
     gemm_dual13_rot<LD>(T, V, Xre, Xim, A2, A4, A6, wave, lane);
+    STAMP(16);
     __syncthreads();                                                   // everybody is done reading X = A6
     rot_exch_write(exch, T.re[1], T.im[1], wave, lane, 1.0);          // T through the exchange area,
     rot_store_adjoint<LD>(Xre, Xim, V.re[1], V.im[1], wave, lane, 1.0);   // V through the (now free) X planes
@@ -1183,6 +1187,7 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     Strip<4> Uo;
     strip_zero(Uo);
     gemm_rot<LD, 3>(Uo, Are, Aim, T, wave, lane);                      // U = A*T, skew-Hermitian
+    STAMP(17);
     __syncthreads();                                                   // V's mirrored tiles have been read; A is dead
     rot_store_adjoint<LD>(Xre, Xim, Uo.re[1], Uo.im[1], wave, lane, -1.0);
     __syncthreads();
@@ -1486,7 +1491,12 @@ __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, c
     }
     STAMP(2);
     double minrel = 1e300;
+#ifdef GRAPE_DIAG
+    if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, !(a.ablate & 1));
+    if (a.ablate & 3) minrel = 1.0;
+#else
     block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true);
+#endif
     // |pivot| < 1e-3 b0 (or NaN) in any of the diagonal tiles -> flag the cell for the pivoted pass
     if (lane == 0 && !(minrel > 1e-6)) { a.cellflag[cell] = 1; atomicAdd(&a.flags[2], 1); }   // flags[2]: flagged cells
     STAMP(3);
@@ -2396,6 +2406,9 @@ struct Deriv2Args {
     const double2 *gpark;      // nullptr or [K][N_T][maxp][NP]
     const int *morder;         // [K][N_T] number of terms M of the cell (u_M below the tolerance), < 0: not usable
     int maxp;
+#ifdef GRAPE_DIAG
+    int ablate;                // diagnostic builds only: bit0 no parking traffic (results wrong)
+#endif
 };
 
 template <int NP, int LMAX, bool CACHE_A>
@@ -2543,6 +2556,9 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                     const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
                     const double ur = sfac * pi[0][r], ui = -sfac * pr[0][r];   // (-i s)(x + i y) = s y - i s x
                     vn[o] = ur; vn[vplane + o] = ui;
+#ifdef GRAPE_DIAG
+                    if (!(a.ablate & 1))
+#endif
                     if (m < a.maxm) { park[(size_t)m * 2 * vplane + o] = ur; park[(size_t)m * 2 * vplane + vplane + o] = ui; }
                     nn += ur * ur + ui * ui;
                 }
@@ -2598,7 +2614,10 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                         ur[r] = in ? u.x : 0.; ui[r] = in ? u.y : 0.;
                     } else {
                         const size_t o = (size_t)aa * 2 * vplane + (size_t)(16 * rt + 4 * r + rg) * 16 + c;
-                        ur[r] = park[o]; ui[r] = park[vplane + o];
+#ifdef GRAPE_DIAG
+                        if (a.ablate & 1) { ur[r] = chr[tt][r]; ui[r] = chi_[tt][r]; } else
+#endif
+                        { ur[r] = park[o]; ui[r] = park[vplane + o]; }
                     }
                 }
                 d4 pr[NV], pi[NV];
