@@ -120,7 +120,7 @@ template <typename T>
 hipError_t dmalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
 
 size_t expm_lds_bytes(int NT) {
-    const int total = NT == 1 ? ExpmLds<1>::TOTAL : NT == 2 ? ExpmLds<2>::TOTAL : ExpmLds<4>::TOTAL;
+    const int total = NT == 1 ? ExpmLds<1>::TOTAL : NT == 2 ? ExpmLds<2>::TOTAL : NT == 3 ? ExpmLds<3>::TOTAL : ExpmLds<4>::TOTAL;
     return sizeof(double) * (size_t)total;
 }
 
@@ -177,15 +177,16 @@ hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s) {
         else hipLaunchKernelGGL((sweep16_kernel<false>), dim3(a.K), dim3(64), 0, s, a);
         return hipGetLastError();
     }
-    if (backward) hipLaunchKernelGGL((sweep_kernel<NP, true>), dim3(a.K), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((sweep_kernel<NP, false>), dim3(a.K), dim3(256), 0, s, a);
+    constexpr int NTH = NP == 48 ? 192 : 256;   // NP = 48: three waves of 16 rows
+    if (backward) hipLaunchKernelGGL((sweep_kernel<NP, true>), dim3(a.K), dim3(NTH), 0, s, a);
+    else hipLaunchKernelGGL((sweep_kernel<NP, false>), dim3(a.K), dim3(NTH), 0, s, a);
     return hipGetLastError();
 }
 
 template <int NP>
 hipError_t launch_sweep_pair(const SweepArgs &af, const SweepArgs &ab, hipStream_t s) {
     if (NP == 16) hipLaunchKernelGGL(sweep16_pair_kernel, dim3(2 * af.K), dim3(64), 0, s, af, ab);
-    else hipLaunchKernelGGL((sweep_pair_kernel<NP>), dim3(2 * af.K), dim3(256), 0, s, af, ab);
+    else hipLaunchKernelGGL((sweep_pair_kernel<NP>), dim3(2 * af.K), dim3(NP == 48 ? 192 : 256), 0, s, af, ab);
     return hipGetLastError();
 }
 
@@ -305,6 +306,11 @@ hipError_t launch_dm(const DerivMfmaArgs &a, int nblocks, hipStream_t s) {
 hipError_t launch_deriv_mfma(int NP, const DerivMfmaArgs &a, int nblocks, hipStream_t s) {
     // the scratch holds (1 + LMAX) vectors per block; LMAX is the instantiated control count
     switch (NP) {
+        case 48:
+            if (a.L == 1) return launch_dm<48, 1, true, true>(a, nblocks, s);
+            if (a.L == 2) return launch_dm<48, 2, true, true>(a, nblocks, s);
+            if (a.L <= 4) return launch_dm<48, 4, false, false>(a, nblocks, s);
+            return launch_dm<48, 8, false, false>(a, nblocks, s);
         case 64:  // L <= 2: vectors in LDS (2 x (1+L) x 16 KB), operators cached in registers
             if (a.L == 1) return launch_dm<64, 1, true, true>(a, nblocks, s);
             if (a.L == 2) return launch_dm<64, 2, true, true>(a, nblocks, s);
@@ -342,6 +348,11 @@ hipError_t launch_d2(const Deriv2Args &a, int nblocks, hipStream_t s) {
 
 hipError_t launch_deriv2(int NP, const Deriv2Args &a, int nblocks, hipStream_t s) {
     switch (NP) {
+        case 48:
+            if (a.L == 1) return launch_d2<48, 1, true>(a, nblocks, s);
+            if (a.L == 2) return launch_d2<48, 2, true>(a, nblocks, s);
+            if (a.L <= 4) return launch_d2<48, 4, false>(a, nblocks, s);
+            return launch_d2<48, 8, false>(a, nblocks, s);
         case 64:
             if (a.L == 1) return launch_d2<64, 1, true>(a, nblocks, s);
             if (a.L == 2) return launch_d2<64, 2, true>(a, nblocks, s);
@@ -633,7 +644,10 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     h->N = p->N; h->L = p->L; h->K = p->K; h->N_T = p->N_T;
     h->K_total = p->K_total > 0 ? p->K_total : p->K;
     h->NT = (p->N + 15) / 16; h->NP = 16 * h->NT;
-    if (h->NP == 48) { h->NT = 4; h->NP = 64; }  // sweep/derivative kernels are built for 16/32/64
+    // 33 <= N <= 48 runs on three 16-wide tiles (NP = 48); the matrix-free series kernels are built for 16/32/64 only
+    if (h->NP == 48 && (p->prop_method == GRAPE_PROP_SERIES || (getenv("GRAPE_NO_NT3") && atoi(getenv("GRAPE_NO_NT3"))))) {
+        h->NT = 4; h->NP = 64;
+    }
     if (p->N > 64) { h->large = true; h->NP = p->N <= 128 ? 128 : 256; h->NT = h->NP / 16; }
     h->device = p->device;
     if (p->chi_min_norm > 0) h->chi_min_norm = p->chi_min_norm;
@@ -749,7 +763,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(hipMemcpy(h->d_Hcf, f.data(), f.size() * 8, hipMemcpyHostToDevice));
     CCHK(hipMemcpy(h->d_Hct, t.data(), t.size() * 8, hipMemcpyHostToDevice));
 
-    if (NP >= 64) {
+    if (NP >= 48) {
         // fragment-packed H^dagger for the MFMA series kernel: [mat][rt][ks][plane][lane],
         // value = conj(H)[col][row] at row = 16 rt + (lane & 15), col = 4 ks + (lane >> 4)
         const int RT = NP / 16, KS = NP / 4;
@@ -869,7 +883,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         // derivative series, and the area fits a modest share of HBM)
         const char *envp = getenv("GRAPE_SERIES_PARK");
         const size_t bytes = (size_t)K * N_T * 32 * NP * 16;
-        if (NP >= 64 && h->deriv2 && h->series_tol <= h->taylor_tol && bytes <= ((size_t)24 << 30) &&
+        if (NP >= 48 && h->deriv2 && h->series_tol <= h->taylor_tol && bytes <= ((size_t)24 << 30) &&
             !(envp && atoi(envp) == 0)) {
             h->maxp = 32;
             CCHK(dmalloc(&h->d_gpark, (size_t)K * N_T * h->maxp * NP));
@@ -972,6 +986,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             switch (h->NT) {
                 case 1: e = launch_expm<1>(ea, h->herm, s); break;
                 case 2: e = launch_expm<2>(ea, h->herm, s); break;
+                case 3: e = launch_expm<3>(ea, h->herm, s); break;
                 default: e = launch_expm<4>(ea, h->herm, s); break;
             }
         }
@@ -1018,7 +1033,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                                                                                  : launch_series_pair<64>(rf, rb, sc, s);
         } else {
             e = h->NP == 16 ? launch_sweep_pair<16>(sa, sb, s) : h->NP == 32 ? launch_sweep_pair<32>(sa, sb, s)
-                                                                            : launch_sweep_pair<64>(sa, sb, s);
+                : h->NP == 48 ? launch_sweep_pair<48>(sa, sb, s) : launch_sweep_pair<64>(sa, sb, s);
         }
     } else if (h->series) {
         const SeriesArgs ra = series_args(h, sa, false);
@@ -1028,6 +1043,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, false, s); break;
         case 32: e = launch_sweep<32>(sa, false, s); break;
+        case 48: e = launch_sweep<48>(sa, false, s); break;
         case 64: e = launch_sweep<64>(sa, false, s); break;
         default:
             if (h->coop_S)
@@ -1102,6 +1118,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, true, s); break;
         case 32: e = launch_sweep<32>(sa, true, s); break;
+        case 48: e = launch_sweep<48>(sa, true, s); break;
         case 64: e = launch_sweep<64>(sa, true, s); break;
         default:
             if (h->coop_S)
@@ -1126,7 +1143,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
     da.cells_per_block = cpb;
     const int nblocks = h->K * ((h->N_T + cpb - 1) / cpb);
     phase_begin(h, 3, s);
-    if (h->NP >= 64 && h->deriv2) {
+    if (h->NP >= 48 && h->deriv2) {
         Deriv2Args d2{};
         d2.H0p = h->d_H0p; d2.Hcp = h->d_Hcp; d2.H0q = h->d_H0q; d2.Hcq = h->d_Hcq;
         d2.eps = h->d_eps; d2.shape = h->d_shape; d2.dts = h->d_dts;
@@ -1141,7 +1158,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         d2.ablate = getenv("GRAPE_DIAG_ABLATE_D2") ? atoi(getenv("GRAPE_DIAG_ABLATE_D2")) : 0;
 #endif
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s);
-    } else if (h->NP >= 64) {
+    } else if (h->NP >= 48) {
         DerivMfmaArgs dm{};
         dm.H0p = h->d_H0p; dm.Hcp = h->d_Hcp; dm.eps = h->d_eps; dm.shape = h->d_shape; dm.dts = h->d_dts;
         dm.fw = h->d_fw; dm.bw = h->d_bw; dm.rho = unit ? h->d_ones : h->d_rho; dm.tg = h->d_tg; dm.vecs = h->d_vecs;

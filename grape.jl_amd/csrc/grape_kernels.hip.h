@@ -1620,7 +1620,7 @@ __device__ __forceinline__ void rs_step(double (&pr)[RWT], double (&pi)[RWT], in
 
 template <int NP, bool BACKWARD>
 __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
-    constexpr int NW = 4, RW = NP / NW;  // rows per wave (NP = 16 -> 4)
+    constexpr int NW = NP == 48 ? 3 : 4, RW = NP / NW;  // waves and rows per wave (NP = 16 -> 4; NP = 48: 3 x 16)
     __shared__ double2 x[2][NP];      // state ping-pong
     __shared__ double2 part[NW][NP];  // cross-wave partials (backward)
     __shared__ double sc[4];
@@ -1765,14 +1765,14 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
 }
 
 template <int NP, bool BACKWARD>
-__global__ void __launch_bounds__(256) sweep_kernel(SweepArgs a) {
+__global__ void __launch_bounds__(NP == 48 ? 192 : 256) sweep_kernel(SweepArgs a) {
     sweep_body<NP, BACKWARD>(a, blockIdx.x);
 }
 
 // Both sweeps in one launch (blocks [0, K): forward, [K, 2K): backward with unit_chi, see SweepArgs): with one
 // workgroup per trajectory a sweep occupies K of the 256 CUs, and the backward recursion is linear in chi.
 template <int NP>
-__global__ void __launch_bounds__(256) sweep_pair_kernel(SweepArgs af, SweepArgs ab) {
+__global__ void __launch_bounds__(NP == 48 ? 192 : 256) sweep_pair_kernel(SweepArgs af, SweepArgs ab) {
     if ((int)blockIdx.x < af.K) sweep_body<NP, false>(af, blockIdx.x);
     else sweep_body<NP, true>(ab, blockIdx.x - af.K);
 }

@@ -508,3 +508,28 @@ def test_bench_contract_two_rank_rehearsal(g):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
     assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0
+
+
+@pytest.mark.parametrize("N,herm", [(33, True), (40, False), (48, True)])
+def test_three_tile_instantiation_matches_padded_four_tile_path(g, ref, N, herm, monkeypatch):
+    """33 <= N <= 48 runs on three 16-wide tiles (NP = 48: expm_pade_kernel<3>, three-wave sweeps, deriv2_kernel<48>)
+    instead of being padded to 64 (GRAPE_NO_NT3=1 restores the padding): same results to rounding, and the oracle's."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, 2, 9, 3, seed=300 + N, hermitian=herm, dt=1.3)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args) as h3:
+        J3, G3, tau3 = h3.eval(pr["pulsevals"])
+        U3 = h3.propagator(1, 4)
+        fw3, bw3 = h3.storage(0), h3.storage(1)
+    monkeypatch.setenv("GRAPE_NO_NT3", "1")
+    with g.GrapeHip(*args) as h4:
+        J4, G4, tau4 = h4.eval(pr["pulsevals"])
+        U4 = h4.propagator(1, 4)
+        fw4 = h4.storage(0)
+    monkeypatch.delenv("GRAPE_NO_NT3")
+    assert np.abs(U3 - U4).max() <= 5e-15
+    assert abs(J3 - J4) <= 1e-14 and np.abs(tau3 - tau4).max() <= 1e-14 and np.abs(fw3 - fw4).max() <= 1e-13
+    assert np.abs(G3 - G4).max() <= 1e-13 * max(np.abs(G4).max(), 1e-3)
+    Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:])
+    assert abs(J3 - Jr) <= TOL_J and np.abs(tau3 - taur).max() <= TOL_TAU and np.abs(G3 - Gr).max() <= tol_G(Gr)
+    assert np.abs(np.linalg.norm(bw3, axis=2) - 1.0).max() <= 1e-12 or not herm
