@@ -125,7 +125,7 @@ size_t expm_lds_bytes(int NT) {
 }
 
 template <int NT>
-hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s) {
+hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persistent_blocks = 0) {
     static bool attr_set[8] = {false};
     const size_t lds = expm_lds_bytes(NT);
     int dev = 0;
@@ -145,6 +145,20 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.cellflag, 0, (size_t)a.K * a.N_T * sizeof(int), s);
     if (e != hipSuccess) return e;
     // fast pass: unpivoted block Gauss-Jordan, flags the cells it cannot solve safely; one workgroup per cell
+    if (NT == 4 && persistent_blocks > 0) {   // one workgroup per CU walks its cells (see expm_persistent)
+        static bool attr_p[8] = {false};
+        if (!attr_p[dev & 7]) {
+            hipError_t ep = hipFuncSetAttribute((const void *)expm_persistent_kernel<NT, false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ep == hipSuccess)
+                ep = hipFuncSetAttribute((const void *)expm_persistent_kernel<NT, NT == 4>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ep != hipSuccess) return ep;
+            attr_p[dev & 7] = true;
+        }
+        if (herm) hipLaunchKernelGGL((expm_persistent_kernel<NT, NT == 4>), dim3(persistent_blocks), dim3(NT * 64), lds, s, a);
+        else hipLaunchKernelGGL((expm_persistent_kernel<NT, false>), dim3(persistent_blocks), dim3(NT * 64), lds, s, a);
+    } else
     if (herm && NT == 4)   // Hermitian generators: three of four row tiles per strip from the MFMAs
         hipLaunchKernelGGL((expm_pade_kernel<NT, false, NT == 4>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
     else
@@ -987,7 +1001,14 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                 case 1: e = launch_expm<1>(ea, h->herm, s); break;
                 case 2: e = launch_expm<2>(ea, h->herm, s); break;
                 case 3: e = launch_expm<3>(ea, h->herm, s); break;
-                default: e = launch_expm<4>(ea, h->herm, s); break;
+                default: {
+                    // persistent variant (one workgroup per CU) when every CU gets at least a few cells
+                    const char *envp = getenv("GRAPE_EXPM_PERSIST");
+                    const int nb = 8 * (h->num_cus / 8);
+                    const bool persist = (envp ? atoi(envp) != 0 : true) && nb >= 8 && (long)ea.K * ea.N_T >= 4L * nb;
+                    e = launch_expm<4>(ea, h->herm, s, persist ? nb : 0);
+                    break;
+                }
             }
         }
         HIPCHK(h, e);

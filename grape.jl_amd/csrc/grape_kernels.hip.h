@@ -572,10 +572,15 @@ __device__ __forceinline__ void gj_update(Strip<NT> &S, int jb, const double *pa
         if (t == jb) { S.re[t] = yr; S.im[t] = yi; }
 }
 
-struct GjNoHook { __device__ __forceinline__ void operator()(int) const {} };
+struct GjNoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+    __device__ __forceinline__ void first_inversion_idle() const {}
+};
 
 // `hook(jb)` runs in every wave after its own work of block step jb and before the barrier that ends the step:
 // the place for work that is independent of the solve (the waves that do not invert are otherwise waiting).
+// `hook.first_inversion_idle()` runs in the waves 1..NT-1 while wave 0 inverts the first diagonal tile: the one stretch
+// of the solve in which they have nothing else to do (6-7 K cycles).
 template <int NT, class Hook = GjNoHook>
 __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
                                                int wave, int lane, double &minrel, double inv_scale2,
@@ -583,6 +588,7 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
     constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
     __syncthreads();  // previous users of the staging region are done
     if (wave == 0) gj_publish_invert<NT>(Q, 0, panbase, dvbase, lane, minrel, inv_scale2, do_invert);
+    else hook.first_inversion_idle();
     __syncthreads();
     STAMP(5);
     // SPLIT SCHEDULE.  The register inversion of the next diagonal tile is serial (one wave, 16 dependent pivot
@@ -1023,9 +1029,11 @@ __device__ __forceinline__ void expm_form_a(const ExpmArgs &a, const int cell, d
 // Hermitian generators, NP = 64: A = -i dt H is skew-Hermitian, so only the 10 tiles (16 x 16) on and above the block
 // diagonal are fetched (1280 instead of 2048 element pairs per plane and operator: the routine is bound by what a CU
 // can pull from L2 per cell) and every off-diagonal tile is written twice, a_ji = -conj(a_ij).
+template <int NTH = 256>   // threads that take part (t = 0..NTH-1): the whole workgroup, or the three waves that
+                           // wait for the first tile inversion of the previous cell (persistent kernel)
 __device__ __forceinline__ void expm_form_a_herm64(const ExpmArgs &a, const int cell, double *smem, const int t) {
     using LY = ExpmLds<4>;
-    constexpr int NP = LY::NP, LD = LY::LD, NTH = LY::NTH;
+    constexpr int NP = LY::NP, LD = LY::LD;
     double *Are = smem, *Aim = Are + NP * LD;
     const int kc = cell / a.N_T, n = cell - kc * a.N_T;
     const int k = a.rep ? a.rep[kc] : kc;
@@ -1038,13 +1046,13 @@ __device__ __forceinline__ void expm_form_a_herm64(const ExpmArgs &a, const int 
         e[l] = a.eps[(size_t)l * a.N_T + n];
         if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
     }
-    // 10 tiles x 128 element pairs = 1280 = 5 per thread; tile q -> (ti, tj), ti <= tj, row by row
-    constexpr int NU = 5;
+    // 10 tiles x 128 element pairs = 1280 = 5 per thread (256 threads); tile q -> (ti, tj), ti <= tj, row by row
+    constexpr int NU = (1280 + NTH - 1) / NTH;
     int off[NU], ii[NU], jj[NU];
     bool diag[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int ep = t + u * NTH, q = ep >> 7, idx = ep & 127;
+        const int ep = min(t + u * NTH, 1279), q = ep >> 7, idx = ep & 127;   // (surplus threads repeat the last pair)
         const int ti = q < 4 ? 0 : (q < 7 ? 1 : (q < 9 ? 2 : 3));
         const int tj = q < 4 ? q : (q < 7 ? q - 3 : (q < 9 ? q - 5 : 3));
         ii[u] = 16 * ti + (idx >> 3);
@@ -1440,14 +1448,17 @@ __device__ __forceinline__ void expm_cell_pivoted(const ExpmArgs &a, const int c
     expm_finish<NT>(a, cell, wave, lane, smem, Pn, s);
 }
 
-// Fast path: one workgroup evaluates TWO cells.  Their polynomial phases run back to back (the
-// finished P, Q strips of the first cell stay parked in registers), then both Pade systems are solved
-// together: the serial part of the block Gauss-Jordan (the register inversion of a 16x16 diagonal tile by
-// one wave) belongs to different waves for the two cells -- the second cell's strips are owned with the
-// wave index rotated by NT/2 -- so two SIMDs invert while the other two issue the MFMA updates of both
-// cells, instead of three SIMDs waiting for one.  If a pivot of the unpivoted elimination is
-// numerically unsafe (e.g. a pi-pulse in one step: q(A) has a zero diagonal) the cell is flagged for the
-// pivoted pass.
+// ||A||_1 <= dt (||H0_k||_1 + sum_l |eps_l| ||H_l||_1), -1 without the operator norms
+__device__ __forceinline__ double expm_norm_bound(const ExpmArgs &a, const int cell) {
+    if (!a.n1) return -1.0;
+    const int kc = cell / a.N_T, n = cell - kc * a.N_T, k = a.rep ? a.rep[kc] : kc;
+    const double *n1c = a.n1 + a.n1_k + (size_t)(a.hc_per_traj ? k : 0) * a.L;
+    double bound = a.n1[k];
+    for (int l = 0; l < a.L; ++l)
+        bound += fabs(a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0)) * n1c[l];
+    return bound * a.dts[n] * (1.0 + 1e-12);
+}
+
 // Fast single-cell path: one workgroup per cell, unpivoted block Gauss-Jordan with look-ahead.
 template <int NT, bool HERM>
 __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, const int tid) {
@@ -1464,15 +1475,7 @@ __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, c
         // ||A||_1 <= dt (||H0_k||_1 + sum_l |eps_l| ||H_l||_1): when this bound already lies in (2.1, 5.4] it certifies
         // order 13 without squaring and the norm of the cell is not needed (a cell whose true norm is below 2.1 then
         // gets order 13 instead of Julia's 9: same result to rounding); every other case measures the norm
-        double bound = -1.0;
-        if (a.n1) {
-            const int kc = cell / a.N_T, n = cell - kc * a.N_T, k = a.rep ? a.rep[kc] : kc;
-            const double *n1c = a.n1 + a.n1_k + (size_t)(a.hc_per_traj ? k : 0) * a.L;
-            bound = a.n1[k];
-            for (int l = 0; l < a.L; ++l)
-                bound += fabs(a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0)) * n1c[l];
-            bound *= a.dts[n] * (1.0 + 1e-12);
-        }
+        const double bound = expm_norm_bound(a, cell);
         if constexpr (HERM && NT == 4) expm_form_a_herm64(a, cell, smem, tid);
         else expm_form_a<NT>(a, cell, smem, tid, LYY::NTH, 0, LYY::NP * LYY::NP / 2);
         if (bound > 2.1 && bound <= 5.4) {
@@ -1503,6 +1506,102 @@ __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, c
     expm_finish<NT>(a, cell, wave, lane, smem, Pn, s);
     STAMP(4);
     if (tid == 0) expm_stats<NT>(a, s, order);
+}
+
+// PERSISTENT variant of the fast path (NT = 4): one workgroup per CU walks its cells, and while wave 0 inverts the
+// first diagonal tile of cell c -- the one stretch of the solve in which the other three waves have nothing to do --
+// those waves form A of the workgroup's NEXT cell in the (by then dead) A region of the LDS, so that the 7-8 K cycles
+// of operand fetch + norm at the front of a cell run underneath the 6.6 K cycles of the previous cell's inversion.
+// The cells of an XCD are dealt to its workgroups round-robin: concurrently running workgroups touch neighbouring
+// cells of the same trajectories (H0_k stays in that XCD's L2).
+template <int NT, bool HERM>
+struct ExpmPrefetchHook {
+    const ExpmArgs &a;
+    double *smem;
+    int next_cell, tid;   // next_cell < 0: nothing to prefetch
+    __device__ __forceinline__ void operator()(int) const {}
+    __device__ __forceinline__ void first_inversion_idle() const {
+        using LY = ExpmLds<NT>;
+        if (next_cell < 0) return;
+        const int t = tid - 64;   // waves 1..NT-1
+        if constexpr (HERM && NT == 4) expm_form_a_herm64<192>(a, next_cell, smem, t);
+        else expm_form_a<NT>(a, next_cell, smem, t, LY::NTH - 64, 0, LY::NP * LY::NP / 2);
+        if (t == 0) {
+            double *red = smem + 2 * LY::REG + LY::DV;
+            const double bound = expm_norm_bound(a, next_cell);
+            const bool cert = bound > 2.1 && bound <= 5.4;
+            red[LY::NTH] = cert ? bound : 0.0;
+            red[LY::NTH + 1] = cert ? 0.0 : 1.0;   // 1: the norm of the prefetched A has to be measured
+        }
+    }
+};
+
+template <int NT, bool HERM>
+__device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid_in) {
+    using LY = ExpmLds<NT>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *red = smem + 2 * LY::REG + LY::DV;
+    const int tid = tid_in, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncell = a.K * a.N_T;
+    const int x = blockIdx.x & 7, per_x = gridDim.x >> 3;
+    const int lo = (int)((long)x * ncell / 8), hi = (int)((long)(x + 1) * ncell / 8);
+    bool have_a = false;
+    const int lane0 = lane, tid0 = tid;
+    int st_s = 0, st_max = 0, st_ord[5] = {0, 0, 0, 0, 0};
+    for (int cell = lo + ((int)blockIdx.x >> 3); cell < hi; cell += per_x) {
+        // the per-lane LDS addresses are recomputed in every iteration: hoisted out of the cell loop they would stay
+        // live through the whole body (several dozen registers, i.e. spills at the 512-register limit)
+        int lane = lane0, tid = tid0;
+        asm volatile("" : "+v"(lane), "+v"(tid));
+        Strip<NT> Pn, Qn;
+        int s, order;
+        double inv_b0sq;
+        bool measure;
+        if (!have_a) {
+            const double bound = expm_norm_bound(a, cell);
+            if constexpr (HERM && NT == 4) expm_form_a_herm64<256>(a, cell, smem, tid);
+            else expm_form_a<NT>(a, cell, smem, tid, LY::NTH, 0, LY::NP * LY::NP / 2);
+            measure = !(bound > 2.1 && bound <= 5.4);
+            if (!measure && tid == 0) red[LY::NTH] = bound;
+            __syncthreads();
+        } else {
+            measure = red[LY::NTH + 1] != 0.0;   // written before the barriers of the previous cell's solve
+        }
+        if (measure) {
+            __syncthreads();   // (everybody has read the flag)
+            expm_norm_partial<NT>(smem, tid, LY::NTH / LY::NP);
+            __syncthreads();
+            expm_norm_combine<NT>(smem, tid, LY::NTH / LY::NP);
+            __syncthreads();
+        }
+        expm_poly<NT, HERM>(a, wave, lane, tid, smem, Pn, Qn, s, order, inv_b0sq);
+        const int next = cell + per_x;
+        // only cells without squarings leave the A region alone until the end of the solve: with s > 0 nothing
+        // changes either (the squarings use the X region), so the prefetch is unconditional
+        const ExpmPrefetchHook<NT, HERM> hook{a, smem, next < hi ? next : -1, tid};
+        double minrel = 1e300;
+        block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true, hook);
+        have_a = next < hi;
+        if (lane == 0 && !(minrel > 1e-6)) { a.cellflag[cell] = 1; atomicAdd(&a.flags[2], 1); }
+        expm_finish<NT>(a, cell, wave, lane, smem, Pn, s);
+        // statistics are accumulated per workgroup and published once (three atomics per cell otherwise)
+        st_s += s; st_max = max(st_max, s);
+        st_ord[order == 13 ? 4 : (order - 3) / 2] += 1;
+        if (s > 0) __syncthreads();   // the last squaring read the X region, which the next cell writes after its first product
+    }
+    if (tid0 == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)st_s);
+#pragma unroll
+        for (int o = 0; o < 5; ++o)
+            if (st_ord[o]) atomicAdd(&a.stats[3 + o], (unsigned long long)st_ord[o]);
+        atomicMax(&a.flags[1], st_max);
+    }
+}
+
+template <int NT, bool HERM>
+__global__ void __launch_bounds__(NT * 64) expm_persistent_kernel(ExpmArgs a) {
+    expm_persistent<NT, HERM>(a, threadIdx.x);
 }
 
 template <int NT, bool PIVOTED, bool HERM = false>
