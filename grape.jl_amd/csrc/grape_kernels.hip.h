@@ -1187,33 +1187,30 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     gemm_dual13_rot<LD>(T, V, Xre, Xim, A2, A4, A6, wave, lane);
     STAMP(16);
     __syncthreads();                                                   // everybody is done reading X = A6
-    rot_exch_write(exch, T.re[1], T.im[1], wave, lane, 1.0);          // T through the exchange area,
-    rot_store_adjoint<LD>(Xre, Xim, V.re[1], V.im[1], wave, lane, 1.0);   // V through the (now free) X planes
+    rot_exch_write(exch, T.re[1], T.im[1], wave, lane, 1.0);          // T's mirrored tiles through the exchange area
     __syncthreads();
     rot_exch_read(exch, T, wave, lane);
-    rot_load_slot3<LD>(Xre, Xim, V, wave, lane);
     Strip<4> Uo;
     strip_zero(Uo);
-    gemm_rot<LD, 3>(Uo, Are, Aim, T, wave, lane);                      // U = A*T, skew-Hermitian
+    gemm_rot<LD, 3>(Uo, Are, Aim, T, wave, lane);                      // U = A*T, skew-Hermitian (slots 0..2)
     STAMP(17);
-    __syncthreads();                                                   // V's mirrored tiles have been read; A is dead
-    rot_store_adjoint<LD>(Xre, Xim, Uo.re[1], Uo.im[1], wave, lane, -1.0);
-    __syncthreads();
-    rot_load_slot3<LD>(Xre, Xim, Uo, wave, lane);
-    __syncthreads();                                                   // ... before the planes are overwritten below
-    // P = V + U -> X planes, Q = V - U -> A planes (natural positions), then reload as natural strips
+    __syncthreads();                                                   // A is dead, the X planes are free
+    // P = V + U -> X planes, Q = V - U -> A planes (natural positions).  V is Hermitian and U skew-Hermitian, so
+    // P = Q^dagger: the tile each wave did not compute, (w-1, w), is the conjugate transpose of the OTHER matrix's
+    // tile (w, w-1), which is slot 1 of wave w-1 -- neither V nor U needs its own mirror exchange.
     {
         Strip<4> Pr, Qr;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 3; ++t) {
             Pr.re[t] = V.re[t] + Uo.re[t]; Pr.im[t] = V.im[t] + Uo.im[t];
             Qr.re[t] = V.re[t] - Uo.re[t]; Qr.im[t] = V.im[t] - Uo.im[t];
         }
-        rot_store_slots<LD, 4>(Xre, Xim, Pr, wave, lane);
-        rot_store_slots<LD, 4>(Are, Aim, Qr, wave, lane);
+        rot_store_slots<LD, 3>(Xre, Xim, Pr, wave, lane);
+        rot_store_slots<LD, 3>(Are, Aim, Qr, wave, lane);
+        rot_store_adjoint<LD>(Xre, Xim, Qr.re[1], Qr.im[1], wave, lane, 1.0);   // P(w, w+1) = Q(w+1, w)^dagger
+        rot_store_adjoint<LD>(Are, Aim, Pr.re[1], Pr.im[1], wave, lane, 1.0);   // Q(w, w+1) = P(w+1, w)^dagger
     }
-    // a thread reloads exactly the elements it stored (same lane, other register order): no barrier needed,
-    // the LDS queue of a wave is in order
+    __syncthreads();
     strip_load_lds<4, LD>(Xre, Xim, Pn, wave, lane);
     strip_load_lds<4, LD>(Are, Aim, Qn, wave, lane);
 }
