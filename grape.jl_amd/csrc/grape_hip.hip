@@ -95,6 +95,8 @@ struct grape_handle {
     double2 *d_gpark = nullptr;  // [K][N_T][maxp][NP] terms of the forward series, consumed by deriv2_kernel
     int *d_morder = nullptr;     // [K][N_T]
     int maxp = 0;
+    int *d_batchflag = nullptr;  // [K * ceil(N_T / 16)] derivative batches left to deriv_sub_kernel (sub-stepped series)
+    double sub_theta = 0.0;      // threshold of deriv_substeps (0: off, gradient_method = :taylor mirrors the reference)
     int sq_plan = 2;             // blocked path: squaring launches issued per chunk (adapted by grape_check, see expm_large)
     double2 *d_chi_in = nullptr; // [K][N] host-supplied boundary states of grape_backward_chi (allocated on first use)
     // several GPUs behind one handle (grape_problem.ndev > 1): this handle owns no device memory, its trajectories
@@ -385,6 +387,27 @@ hipError_t launch_deriv2(int NP, const Deriv2Args &a, int nblocks, hipStream_t s
     }
 }
 
+template <int NP, int LMAX>
+hipError_t launch_ds(const DerivSubArgs &a, int nblocks, hipStream_t s) {
+    constexpr int NW = NP / 16 <= 8 ? NP / 16 : 8;
+    hipLaunchKernelGGL((deriv_sub_kernel<NP, LMAX>), dim3(nblocks), dim3(NW * 64), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_deriv_sub(int NP, const DerivSubArgs &a, int nblocks, hipStream_t s) {
+    const int L = a.m.L;
+#define DS_CASE(NP_)                                                         \
+    case NP_:                                                                \
+        if (L == 1) return launch_ds<NP_, 1>(a, nblocks, s);                 \
+        if (L == 2) return launch_ds<NP_, 2>(a, nblocks, s);                 \
+        if (L <= 4) return launch_ds<NP_, 4>(a, nblocks, s);                 \
+        return NP_ <= 64 ? launch_ds<NP_, 8>(a, nblocks, s) : hipErrorInvalidValue;
+    switch (NP) {
+        DS_CASE(48) DS_CASE(64) DS_CASE(128) DS_CASE(256)
+        default: return hipErrorInvalidValue;
+    }
+#undef DS_CASE
+}
+
 // phases 0,1 belong to the forward call, 2,3,4 to the backward call, 5 to grape_eval
 long phase_slot(grape_handle *h, int i) { return (i <= 1 ? h->n_fwd : (i <= 4 ? h->n_bwd : h->n_fwd)) % kRing; }
 void phase_begin(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[phase_slot(h, i)][i].e0, s); }
@@ -606,7 +629,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -885,12 +908,19 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             CCHK(hipMemcpy(h->d_n1, n1.data(), n1.size() * 8, hipMemcpyHostToDevice));
         }
     }
-    if (h->series) {
+    {   // 2-norm estimates of the operators (power iteration): sub-steps of the matrix-free propagator and of the
+        // derivative series
         std::vector<double> rb((size_t)K + (size_t)Kc * L);
         for (int k = 0; k < K; ++k) rb[k] = norm2_estimate(p->H0 + 2 * (size_t)k * nn, N);
         for (int kl = 0; kl < Kc * L; ++kl) rb[K + kl] = norm2_estimate(p->Hc + 2 * (size_t)kl * nn, N);
         CCHK(dmalloc(&h->d_rb, rb.size()));
         CCHK(hipMemcpy(h->d_rb, rb.data(), rb.size() * 8, hipMemcpyHostToDevice));
+        // the exact-derivative route sub-steps its series for ||H|| dt > theta; :taylor is the reference's plain recursion
+        const char *envd = getenv("GRAPE_DERIV_THETA");
+        h->sub_theta = p->gradient_method == GRAPE_GRAD_GRADGEN ? (envd ? atof(envd) : 4.0) : 0.0;
+        CCHK(dmalloc(&h->d_batchflag, (size_t)K * ((N_T + 15) / 16)));
+    }
+    if (h->series) {
         const char *env = getenv("GRAPE_SERIES_THETA");
         if (env && atof(env) > 0) h->series_theta = atof(env);
         // parked terms for the two-pass derivative kernel (N > 32, deriv2 on, series at least as tight as the
@@ -1158,12 +1188,23 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
     da.fw = h->d_fw; da.bw = h->d_bw; da.rho = unit ? h->d_ones : h->d_rho; da.tg = h->d_tg; da.flags = h->d_flags; da.stats = h->d_stats;
     da.K = h->K; da.L = h->L; da.N_T = h->N_T; da.hc_per_traj = h->p.hc_per_traj;
     da.max_order = h->taylor_max_order; da.tol = h->taylor_tol;
+    da.rb = h->d_rb; da.rb_k = h->K; da.sub_theta = h->sub_theta;
     // enough blocks to fill 256 CUs a few times over, but long runs per block to amortise the tile loads
     int cpb = 16;
     while (cpb > 1 && (long)h->K * ((h->N_T + cpb - 1) / cpb) < 2048) cpb >>= 1;
     da.cells_per_block = cpb;
     const int nblocks = h->K * ((h->N_T + cpb - 1) / cpb);
     phase_begin(h, 3, s);
+    if (h->NP >= 48 && h->sub_theta > 0.0) {   // which batches of 16 cells need a sub-stepped derivative series?
+        HIPCHK(h, hipMemsetAsync(h->d_flags + 3, 0, sizeof(int), s));
+        DerivFlagArgs fa{};
+        fa.rb = h->d_rb; fa.eps = h->d_eps; fa.shape = h->d_shape; fa.dts = h->d_dts;
+        fa.rb_k = h->K; fa.K = h->K; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj;
+        fa.batches_per_k = (h->N_T + 15) / 16; fa.nbatch_total = h->K * fa.batches_per_k;
+        fa.sub_theta = h->sub_theta; fa.batch_flag = h->d_batchflag; fa.flags = h->d_flags;
+        hipLaunchKernelGGL(deriv_flag_kernel, dim3((fa.nbatch_total + 255) / 256), dim3(256), 0, s, fa);
+        HIPCHK(h, hipGetLastError());
+    }
     if (h->NP >= 48 && h->deriv2) {
         Deriv2Args d2{};
         d2.H0p = h->d_H0p; d2.Hcp = h->d_Hcp; d2.H0q = h->d_H0q; d2.Hcq = h->d_Hcq;
@@ -1175,6 +1216,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         d2.batches_per_k = (h->N_T + 15) / 16;
         d2.nbatch_total = h->K * d2.batches_per_k;
         if (h->series) { d2.gpark = h->d_gpark; d2.morder = h->d_morder; d2.maxp = h->maxp; }
+        if (h->sub_theta > 0.0) d2.batch_flag = h->d_batchflag;
 #ifdef GRAPE_DIAG
         d2.ablate = getenv("GRAPE_DIAG_ABLATE_D2") ? atoi(getenv("GRAPE_DIAG_ABLATE_D2")) : 0;
 #endif
@@ -1188,6 +1230,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         dm.max_order = h->taylor_max_order; dm.tol = h->taylor_tol;
         dm.batches_per_k = (h->N_T + 15) / 16;
         dm.nbatch_total = h->K * dm.batches_per_k;
+        if (h->sub_theta > 0.0) dm.batch_flag = h->d_batchflag;
         e = launch_deriv_mfma(h->NP, dm, h->deriv_blocks, s);
     } else {
         switch (h->NP) {
@@ -1196,6 +1239,21 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         }
     }
     HIPCHK(h, e);
+    if (h->NP >= 48 && h->sub_theta > 0.0) {
+        // second pass over the batches the fast kernel flagged (cells whose series needs sub-steps); it ends at once
+        // when there are none
+        DerivSubArgs ds{};
+        DerivMfmaArgs &dm = ds.m;
+        dm.H0p = h->d_H0p; dm.Hcp = h->d_Hcp; dm.eps = h->d_eps; dm.shape = h->d_shape; dm.dts = h->d_dts;
+        dm.fw = h->d_fw; dm.bw = h->d_bw; dm.rho = unit ? h->d_ones : h->d_rho; dm.tg = h->d_tg; dm.vecs = h->d_vecs;
+        dm.flags = h->d_flags; dm.stats = h->d_stats;
+        dm.K = h->K; dm.L = h->L; dm.N_T = h->N_T; dm.hc_per_traj = h->p.hc_per_traj;
+        dm.max_order = h->taylor_max_order; dm.tol = h->taylor_tol;
+        dm.batches_per_k = (h->N_T + 15) / 16;
+        dm.nbatch_total = h->K * dm.batches_per_k;
+        ds.rb = h->d_rb; ds.rb_k = h->K; ds.sub_theta = h->sub_theta; ds.batch_flag = h->d_batchflag;
+        HIPCHK(h, launch_deriv_sub(h->NP, ds, h->deriv_blocks, s));
+    }
     phase_end(h, 3, s);
     // ---- phase 4: sum over trajectories ----
     phase_begin(h, 4, s);

@@ -1908,7 +1908,30 @@ struct DerivArgs {
     unsigned long long *stats;  // [8] += series order summed over cells
     int K, L, N_T, hc_per_traj, cells_per_block, max_order;
     double tol;
+    // sub-stepping of the derivative series (gradient_method = :gradgen only): 2-norm estimates of H0_k ([rb_k]) and of
+    // the control operators ([Kc][L]), threshold on ||H_kn||_2 dt per sub-step; sub_theta <= 0 switches it off
+    const double *rb;
+    int rb_k;
+    double sub_theta;
 };
+
+// Number of sub-steps of the derivative series of one cell.  The series of exp(-i G dt) on the extended vector is
+// summed unscaled; its rounding error grows like eps e^(||H|| dt), so for ||H_kn||_2 dt above theta the interval is cut
+// into m equal parts and the series is applied m times to the extended vector (exp(X) = exp(X/m)^m: the gradient
+// slots are simply not reset in between) -- the vector analogue of scaling and squaring, which is what keeps the
+// reference's gradient-generator route accurate for any norm.  The bound uses the operator norm estimates of
+// grape_create: ||H_kn|| <= ||H0_k|| + sum_l |eps_nl S_ln| ||H_l||.
+__device__ __forceinline__ int deriv_substeps(const double *rb, int rb_k, double theta, int k, int hc_per_traj, int L,
+                                              const double *eps, const double *shape, int N_T, int n, double dt) {
+    if (!rb || !(theta > 0.0)) return 1;
+    const double *rl = rb + rb_k + (size_t)(hc_per_traj ? k : 0) * L;
+    double b = rb[k];
+    for (int l = 0; l < L; ++l)
+        b += fabs(eps[(size_t)l * N_T + n] * (shape ? shape[(size_t)l * N_T + n] : 1.0)) * rl[l];
+    b *= fabs(dt);
+    const int m = (int)ceil(b / theta);
+    return m < 1 ? 1 : (m > 4096 ? 4096 : m);
+}
 
 // ---- wavefront-level reductions on DPP (no LDS traffic) ----
 template <int CTRL>
@@ -2060,6 +2083,7 @@ __global__ void __launch_bounds__(NTH) deriv_kernel(DerivArgs a) {
     static_assert(NCH <= 16 && NCH * CW == NP, "row chunks must be adjacent lanes of one DPP row");
     __shared__ double2 vec[2][NV][VLEN];   // ping-pong over series orders
     __shared__ double red[2][NW][LMAX];    // per wave: ||phi_l||^2 of its rows
+    __shared__ double redc[2][NW];         // per wave: ||pw||^2 of its rows (sub-stepped cells only)
     __shared__ double2 gsum[NW][LMAX];     // per wave: final <chi'_l | psi> of its rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2113,91 +2137,122 @@ __global__ void __launch_bounds__(NTH) deriv_kernel(DerivArgs a) {
                 hi[c] = fma(de, mui[l][c], hi[c]);
             }
         }
-        // row owner (q == 0) keeps Psi_k(t_{n-1})[i]; chi_k(t_n) becomes pw of order 0
-        double2 psi = make_double2(0., 0.);
-        __syncthreads();  // previous cell is done with vec[*] / gsum
+        // row owner (q == 0) keeps Psi_k(t_{n-1}) and its element of chi_k(t_n) and of the accumulated chi'_l
+        double2 psi = make_double2(0., 0.), chi_cur = make_double2(0., 0.);
         if (q == 0) {
             psi = a.fw[((size_t)k * (a.N_T + 1) + n) * NP + i];
-            vec[0][0][vi] = a.bw[((size_t)k * (a.N_T + 1) + n + 1) * NP + i];
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) vec[0][1 + l][vi] = make_double2(0., 0.);
+            chi_cur = a.bw[((size_t)k * (a.N_T + 1) + n + 1) * NP + i];
         }
-        __syncthreads();
         // series of exp(-i G dtb) on the extended vector, dtb = -dt: alpha_m = (i dt)^m / m!
         // row owners accumulate chi'_l[i] = sum_m alpha_m phi_m^l[i]  (the accumulation of taylor_grad_step!)
         double outr[LMAX], outi[LMAX];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) { outr[l] = 0.; outi[l] = 0.; }
-        double alr = 0., ali = dt;  // alpha_1 = i dt
-        int done_mask = 0, converged = 0, m_used = a.max_order, cur = 0;
-        for (int m = 1; m <= a.max_order; ++m) {
-            // ---- this thread's partial products over its CW columns ----
-            double pr = 0., pi = 0., gr[LMAX], gi[LMAX], ur[LMAX], ui[LMAX];
+        // sub-steps (see deriv_substeps): the extended vector (chi'_1..chi'_L, chi) of sub-step s starts from the result
+        // of sub-step s-1; with one sub-step this is exactly the single series of the reference
+        const int nsub = deriv_substeps(a.rb, a.rb_k, a.sub_theta, k, a.hc_per_traj, L, a.eps, a.shape, a.N_T, n, dt);
+        const double dts_ = dt / (double)nsub;
+        const int all_bits = nsub > 1 ? (all_done | (1 << LMAX)) : all_done;   // bit LMAX: the chi chain itself
+        int converged = 1, m_used = 0;
+        for (int sub = 0; sub < nsub; ++sub) {
+            __syncthreads();  // previous cell / sub-step is done with vec[*] / gsum
+            if (q == 0) {
+                vec[0][0][vi] = chi_cur;
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) { gr[l] = 0.; gi[l] = 0.; ur[l] = 0.; ui[l] = 0.; }
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                const double2 x0 = vec[cur][0][vq + c];
-                pr = fma(hr[c], x0.x, pr);   // Hd * pw
-                pr = fma(-hi[c], x0.y, pr);
-                pi = fma(hr[c], x0.y, pi);
-                pi = fma(hi[c], x0.x, pi);
-#pragma unroll
-                for (int l = 0; l < LMAX; ++l) {
-                    const double2 xl = vec[cur][1 + l][vq + c];
-                    ur[l] = fma(mur[l][c], x0.x, ur[l]);   // mu_l^d * pw
-                    ur[l] = fma(-mui[l][c], x0.y, ur[l]);
-                    ui[l] = fma(mur[l][c], x0.y, ui[l]);
-                    ui[l] = fma(mui[l][c], x0.x, ui[l]);
-                    gr[l] = fma(hr[c], xl.x, gr[l]);       // Hd * phi_l
-                    gr[l] = fma(-hi[c], xl.y, gr[l]);
-                    gi[l] = fma(hr[c], xl.y, gi[l]);
-                    gi[l] = fma(hi[c], xl.x, gi[l]);
-                }
-            }
-            // ---- sum the NCH chunks of each row (adjacent lanes, DPP) ----
-            pr = group_sum<NCH>(pr);
-            pi = group_sum<NCH>(pi);
-            const int nxt = cur ^ 1;
-            if (q == 0) vec[nxt][0][vi] = make_double2(pr, pi);
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
-                // phi_l(new) = S_l mu_l^d pw + Hd phi_l
-                const double fr = group_sum<NCH>(fma(sh[l], ur[l], gr[l]));
-                const double fi = group_sum<NCH>(fma(sh[l], ui[l], gi[l]));
-                double nn = 0.;
-                if (q == 0) {
-                    vec[nxt][1 + l][vi] = make_double2(fr, fi);
-                    if (!((done_mask >> l) & 1)) {
-                        outr[l] += alr * fr - ali * fi;   // += alpha_m * phi_m
-                        outi[l] += alr * fi + ali * fr;
-                    }
-                    nn = fr * fr + fi * fi;
-                }
-                // ||phi_l||^2 over this wave's rows (wavefront reduction); combined after the barrier
-                nn = wave_sum_dpp(nn);
-                if (lane == 0) red[nxt][wave][l] = nn;
+                for (int l = 0; l < LMAX; ++l) vec[0][1 + l][vi] = make_double2(outr[l], outi[l]);
             }
             __syncthreads();
-            const double al2 = alr * alr + ali * ali;
+            double ocr = 0., oci = 0.;    // sum_m alpha_m pw_m (row owner): chi after the sub-step
+            double alr = 0., ali = dts_;  // alpha_1 = i dt
+            int done_mask = 0, conv_sub = 0, m_sub = a.max_order, cur = 0;
+            for (int m = 1; m <= a.max_order; ++m) {
+                // ---- this thread's partial products over its CW columns ----
+                double pr = 0., pi = 0., gr[LMAX], gi[LMAX], ur[LMAX], ui[LMAX];
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
-                if (l < L) {
+                for (int l = 0; l < LMAX; ++l) { gr[l] = 0.; gi[l] = 0.; ur[l] = 0.; ui[l] = 0.; }
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    const double2 x0 = vec[cur][0][vq + c];
+                    pr = fma(hr[c], x0.x, pr);   // Hd * pw
+                    pr = fma(-hi[c], x0.y, pr);
+                    pi = fma(hr[c], x0.y, pi);
+                    pi = fma(hi[c], x0.x, pi);
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        const double2 xl = vec[cur][1 + l][vq + c];
+                        ur[l] = fma(mur[l][c], x0.x, ur[l]);   // mu_l^d * pw
+                        ur[l] = fma(-mui[l][c], x0.y, ur[l]);
+                        ui[l] = fma(mur[l][c], x0.y, ui[l]);
+                        ui[l] = fma(mui[l][c], x0.x, ui[l]);
+                        gr[l] = fma(hr[c], xl.x, gr[l]);       // Hd * phi_l
+                        gr[l] = fma(-hi[c], xl.y, gr[l]);
+                        gi[l] = fma(hr[c], xl.y, gi[l]);
+                        gi[l] = fma(hi[c], xl.x, gi[l]);
+                    }
+                }
+                // ---- sum the NCH chunks of each row (adjacent lanes, DPP) ----
+                pr = group_sum<NCH>(pr);
+                pi = group_sum<NCH>(pi);
+                const int nxt = cur ^ 1;
+                if (q == 0) vec[nxt][0][vi] = make_double2(pr, pi);
+                if (nsub > 1) {   // the chi chain is part of the result of a sub-step
+                    double nn = 0.;
+                    if (q == 0) {
+                        ocr += alr * pr - ali * pi;
+                        oci += alr * pi + ali * pr;
+                        nn = pr * pr + pi * pi;
+                    }
+                    nn = wave_sum_dpp(nn);
+                    if (lane == 0) redc[nxt][wave] = nn;
+                }
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    // phi_l(new) = S_l mu_l^d pw + Hd phi_l
+                    const double fr = group_sum<NCH>(fma(sh[l], ur[l], gr[l]));
+                    const double fi = group_sum<NCH>(fma(sh[l], ui[l], gi[l]));
+                    double nn = 0.;
+                    if (q == 0) {
+                        vec[nxt][1 + l][vi] = make_double2(fr, fi);
+                        if (!((done_mask >> l) & 1)) {
+                            outr[l] += alr * fr - ali * fi;   // += alpha_m * phi_m
+                            outi[l] += alr * fi + ali * fr;
+                        }
+                        nn = fr * fr + fi * fi;
+                    }
+                    // ||phi_l||^2 over this wave's rows (wavefront reduction); combined after the barrier
+                    nn = wave_sum_dpp(nn);
+                    if (lane == 0) red[nxt][wave][l] = nn;
+                }
+                __syncthreads();
+                const double al2 = alr * alr + ali * ali;
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l) {
+                    if (l < L) {
+                        double nn = 0.;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) nn += red[nxt][w][l];
+                        // reference stopping rule: |alpha_m| * ||phi_m|| < tolerance (optimize.jl:631-636)
+                        if (m >= 2 && al2 * nn < a.tol * a.tol) done_mask |= 1 << l;
+                    }
+                }
+                if (nsub > 1) {
                     double nn = 0.;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) nn += red[nxt][w][l];
-                    // reference stopping rule: |alpha_m| * ||phi_m|| < tolerance (optimize.jl:631-636)
-                    if (m >= 2 && al2 * nn < a.tol * a.tol) done_mask |= 1 << l;
+                    for (int w = 0; w < NW; ++w) nn += redc[nxt][w];
+                    if (m >= 2 && al2 * nn < a.tol * a.tol) done_mask |= 1 << LMAX;
+                }
+                cur = nxt;
+                if (done_mask == all_bits) { conv_sub = 1; m_sub = m; break; }
+                {   // alpha_{m+1} = alpha_m * (i dt) / (m+1)
+                    const double f = dts_ / (double)(m + 1);
+                    const double nr = -ali * f, ni = alr * f;
+                    alr = nr; ali = ni;
                 }
             }
-            cur = nxt;
-            if (done_mask == all_done) { converged = 1; m_used = m; break; }
-            {   // alpha_{m+1} = alpha_m * (i dt) / (m+1)
-                const double f = dt / (double)(m + 1);
-                const double nr = -ali * f, ni = alr * f;
-                alr = nr; ali = ni;
-            }
-        }
+            converged &= conv_sub;
+            m_used += m_sub;
+            chi_cur.x += ocr; chi_cur.y += oci;
+        }   // sub-steps
         // tau_grads[k][l][n] = rho_k * <chi'_l | psi> = rho_k sum_i conj(chi'_l[i]) psi[i]
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
@@ -2248,6 +2303,8 @@ struct DerivMfmaArgs {
     unsigned long long *stats;
     int K, L, N_T, hc_per_traj, max_order, nbatch_total, batches_per_k;
     double tol;
+    // batches that deriv_sub_kernel redoes (see Deriv2Args::batch_flag)
+    const int *batch_flag;
 };
 
 template <int NP, int LMAX, bool CACHE_A, bool VEC_LDS>
@@ -2463,10 +2520,275 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv_mfma_
             }
         }
         if (tid == 0) {
-            if (!converged) atomicOr(&a.flags[0], 4);
-            atomicAdd(&a.stats[8], (unsigned long long)m_used * (unsigned long long)min(16, a.N_T - n0));
+            const bool redone = a.batch_flag && a.batch_flag[batch];
+            if (!converged && !redone) atomicOr(&a.flags[0], 4);
+            if (!redone) atomicAdd(&a.stats[8], (unsigned long long)m_used * (unsigned long long)min(16, a.N_T - n0));
         }
         __syncthreads();   // red slots / scratch are reused by the next batch
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Kernel 5d: derivative overlaps of the batches whose cells need SUB-STEPS (deriv_substeps > 1; flagged by
+// deriv2_kernel / selected by `batch_flag`): the coupled recursion of deriv_mfma_kernel on the extended vectors,
+// applied m times with the step dt / m without resetting the gradient slots, so that
+//     (chi'_1..chi'_L, chi)  <-  exp(-i G dtb / m)^m (0, .., 0, chi)
+// stays accurate for any ||H|| dt (the role the scaling and squaring of the dense block exponential plays in the
+// reference's :gradgen route).  The results of a sub-step are needed as VECTORS (they start the next one), so the
+// accumulators are vector tiles in registers and the overlaps <chi'_l|Psi> are taken once at the end.  Operators stream
+// from L2 (fragment-packed), vectors ping-pong through the block-private global scratch: this is the slow, robust path.
+// ---------------------------------------------------------------------------------------
+// one thread per batch of 16 consecutive cells: does any of them need sub-steps?  (flags[3] counts the batches)
+struct DerivFlagArgs {
+    const double *rb, *eps, *shape, *dts;
+    int rb_k, K, L, N_T, hc_per_traj, batches_per_k, nbatch_total;
+    double sub_theta;
+    int *batch_flag, *flags;
+};
+__global__ void deriv_flag_kernel(DerivFlagArgs a) {
+    const int batch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (batch >= a.nbatch_total) return;
+    const int k = batch / a.batches_per_k, n0 = (batch - k * a.batches_per_k) * 16;
+    int ns = 1;
+    for (int n = n0; n < min(n0 + 16, a.N_T); ++n)
+        ns = max(ns, deriv_substeps(a.rb, a.rb_k, a.sub_theta, k, a.hc_per_traj, a.L, a.eps, a.shape, a.N_T, n, a.dts[n]));
+    a.batch_flag[batch] = ns > 1;
+    if (ns > 1) atomicAdd(&a.flags[3], 1);
+}
+
+struct DerivSubArgs {
+    DerivMfmaArgs m;          // operators, states, scratch, tolerances (deriv_mfma_kernel's)
+    const double *rb;         // 2-norm estimates, see deriv_substeps
+    int rb_k;
+    double sub_theta;
+    const int *batch_flag;    // nullptr: every batch; else only the batches with a non-zero flag
+};
+
+template <int NP, int LMAX>
+__global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv_sub_kernel(DerivSubArgs b) {
+    const DerivMfmaArgs &a = b.m;
+    constexpr int RT = NP / 16, KS = NP / 4;
+    constexpr int NW = RT <= 8 ? RT : 8, TPW = RT / NW, NV = 1 + LMAX;
+    static_assert(RT % NW == 0, "row tiles must divide evenly over the waves");
+    __shared__ double red[2][NW][NV][16];       // per wave and column: ||new vector||^2 of the wave's rows; index LMAX = the chi chain
+    __shared__ double redo[NW][LMAX][16][2];    // final overlaps
+    if (b.batch_flag && a.flags[3] == 0) return;   // no batch was flagged in this evaluation
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, rg = lane >> 4;
+    const int L = a.L;
+    const size_t vplane = (size_t)NP * 16;
+    double *vbase = a.vecs + (size_t)blockIdx.x * 2 * NV * 2 * vplane;
+    for (int batch = blockIdx.x; batch < a.nbatch_total; batch += gridDim.x) {
+        if (b.batch_flag && !b.batch_flag[batch]) continue;
+        const int k = batch / a.batches_per_k;
+        const int n0 = (batch - k * a.batches_per_k) * 16;
+        const int n = n0 + c;
+        const bool valid = n < a.N_T;
+        const int nc = valid ? n : a.N_T - 1;
+        const double *h0k = a.H0p + (size_t)k * RT * KS * 128;
+        const double *hck = a.Hcp + (size_t)(a.hc_per_traj ? k : 0) * L * RT * KS * 128;
+        const double dt = a.dts[nc];
+        double e[LMAX], sh[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            sh[l] = (l < L && a.shape) ? a.shape[(size_t)l * a.N_T + nc] : 1.0;
+            e[l] = l < L ? a.eps[(size_t)l * a.N_T + nc] * sh[l] : 0.;
+        }
+        // one sub-step count for the 16 cells of the batch (the columns advance in lockstep): the largest
+        int nsub = valid ? deriv_substeps(b.rb, b.rb_k, b.sub_theta, k, a.hc_per_traj, L, a.eps, a.shape, a.N_T, nc, dt) : 1;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) nsub = max(nsub, __shfl_xor(nsub, off, 64));
+        nsub = __builtin_amdgcn_readfirstlane(nsub);
+        const double dts_ = dt / (double)nsub;
+        const double rho = a.rho[k];
+        // this wave's tiles of Psi(t_n), of the running chi and of the accumulated chi'_l
+        double psr[TPW][4], psi_[TPW][4];
+        d4 chr[TPW], chi_[TPW], gfr[LMAX][TPW], gfi[LMAX][TPW];
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (wave + tt * NW) + 4 * r + rg;
+                const double2 p = a.fw[((size_t)k * (a.N_T + 1) + nc) * NP + row];
+                const double2 x = a.bw[((size_t)k * (a.N_T + 1) + nc + 1) * NP + row];
+                psr[tt][r] = p.x; psi_[tt][r] = p.y;
+                chr[tt][r] = valid ? x.x : 0.; chi_[tt][r] = valid ? x.y : 0.;
+            }
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) { gfr[l][tt] = (d4){0., 0., 0., 0.}; gfi[l][tt] = (d4){0., 0., 0., 0.}; }
+        }
+        const int all_done = ((1 << L) - 1) | (1 << LMAX);   // bit LMAX: the chi chain
+        int converged = 1;
+        unsigned long long orders = 0;
+        for (int sub = 0; sub < nsub; ++sub) {
+            __syncthreads();   // the scratch of the previous sub-step / batch is free
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = (size_t)(16 * (wave + tt * NW) + 4 * r + rg) * 16 + c;
+                    vbase[0 * vplane + o] = chr[tt][r];
+                    vbase[1 * vplane + o] = chi_[tt][r];
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        vbase[((1 + l) * 2 + 0) * vplane + o] = gfr[l][tt][r];
+                        vbase[((1 + l) * 2 + 1) * vplane + o] = gfi[l][tt][r];
+                    }
+                }
+            __syncthreads();
+            d4 ocr[TPW], oci[TPW];   // sum_m alpha_m pw_m
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) { ocr[tt] = (d4){0., 0., 0., 0.}; oci[tt] = (d4){0., 0., 0., 0.}; }
+            double alr = 0., ali = dts_;              // alpha_1 = i dt  (dtb = -dt)
+            int done_mask = valid ? 0 : all_done;
+            int cur = 0, conv_sub = 0, m_sub = a.max_order;
+            for (int m = 1; m <= a.max_order; ++m) {
+                const double *vc = vbase + (size_t)cur * NV * 2 * vplane;
+                double *vn = vbase + (size_t)(cur ^ 1) * NV * 2 * vplane;
+                const int slot = m & 1;
+                double snn[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) snn[v] = 0.;
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt) {
+                    const int rt = wave + tt * NW;
+                    const double *h0p = h0k + (size_t)rt * KS * 128;
+                    d4 pwr = {0., 0., 0., 0.}, pwi = {0., 0., 0., 0.};
+                    d4 mur[LMAX], mui[LMAX], phr[LMAX], phi[LMAX];
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        mur[l] = (d4){0., 0., 0., 0.}; mui[l] = (d4){0., 0., 0., 0.};
+                        phr[l] = (d4){0., 0., 0., 0.}; phi[l] = (d4){0., 0., 0., 0.};
+                    }
+#pragma unroll 2
+                    for (int ks = 0; ks < KS; ++ks) {
+                        double ar[NV], ai[NV];
+                        ar[0] = h0p[(size_t)ks * 128 + lane];
+                        ai[0] = h0p[(size_t)ks * 128 + 64 + lane];
+#pragma unroll
+                        for (int l = 0; l < LMAX; ++l) {
+                            ar[1 + l] = l < L ? hck[(((size_t)l * RT + rt) * KS + ks) * 128 + lane] : 0.;
+                            ai[1 + l] = l < L ? hck[(((size_t)l * RT + rt) * KS + ks) * 128 + 64 + lane] : 0.;
+                        }
+                        const size_t bo = (size_t)(4 * ks + rg) * 16 + c;
+                        const double bwr = vc[0 * vplane + bo], bwi = vc[1 * vplane + bo];
+                        pwr = MFMA64(ar[0], bwr, pwr);  pwi = MFMA64(ar[0], bwi, pwi);
+                        pwr = MFMA64(ai[0], -bwi, pwr); pwi = MFMA64(ai[0], bwr, pwi);
+#pragma unroll
+                        for (int l = 0; l < LMAX; ++l) {
+                            mur[l] = MFMA64(ar[1 + l], bwr, mur[l]);  mui[l] = MFMA64(ar[1 + l], bwi, mui[l]);
+                            mur[l] = MFMA64(ai[1 + l], -bwi, mur[l]); mui[l] = MFMA64(ai[1 + l], bwr, mui[l]);
+                        }
+                        if (m > 1 || sub > 0) {   // the gradient slots are empty only at the very start
+#pragma unroll
+                            for (int l = 0; l < LMAX; ++l) {
+                                const double br = vc[((1 + l) * 2 + 0) * vplane + bo], bi = vc[((1 + l) * 2 + 1) * vplane + bo];
+                                phr[l] = MFMA64(ar[0], br, phr[l]);  phi[l] = MFMA64(ar[0], bi, phi[l]);
+                                phr[l] = MFMA64(ai[0], -bi, phr[l]); phi[l] = MFMA64(ai[0], br, phi[l]);
+#pragma unroll
+                                for (int l2 = 0; l2 < LMAX; ++l2) {
+                                    const double sr = e[l2] * br, si = e[l2] * bi;   // column-scaled B operand
+                                    phr[l] = MFMA64(ar[1 + l2], sr, phr[l]);  phi[l] = MFMA64(ar[1 + l2], si, phi[l]);
+                                    phr[l] = MFMA64(ai[1 + l2], -si, phr[l]); phi[l] = MFMA64(ai[1 + l2], sr, phi[l]);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        pwr += e[l] * mur[l];
+                        pwi += e[l] * mui[l];
+                        phr[l] += sh[l] * mur[l];
+                        phi[l] += sh[l] * mui[l];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
+                        vn[0 * vplane + o] = pwr[r];
+                        vn[1 * vplane + o] = pwi[r];
+                        snn[LMAX] += pwr[r] * pwr[r] + pwi[r] * pwi[r];
+                    }
+                    ocr[tt] += alr * pwr - ali * pwi;   // += alpha_m pw_m
+                    oci[tt] += alr * pwi + ali * pwr;
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
+                            vn[((1 + l) * 2 + 0) * vplane + o] = phr[l][r];
+                            vn[((1 + l) * 2 + 1) * vplane + o] = phi[l][r];
+                            snn[l] += phr[l][r] * phr[l][r] + phi[l][r] * phi[l][r];
+                        }
+                        if (!((done_mask >> l) & 1)) {
+                            gfr[l][tt] += alr * phr[l] - ali * phi[l];   // += alpha_m phi_m
+                            gfi[l][tt] += alr * phi[l] + ali * phr[l];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {   // the 4 row groups of a column sit 16 lanes apart
+                    snn[v] += __shfl_xor(snn[v], 16, 64);
+                    snn[v] += __shfl_xor(snn[v], 32, 64);
+                    if (lane < 16) red[slot][wave][v][c] = snn[v];
+                }
+                __syncthreads();
+                const double al2 = alr * alr + ali * ali;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const bool used = v == LMAX || v < L;
+                    const int bit = v == LMAX ? LMAX : v;
+                    if (used && !((done_mask >> bit) & 1)) {
+                        double nn = 0.;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) nn += red[slot][w][v][c];
+                        if (m >= 2 && al2 * nn < a.tol * a.tol) done_mask |= 1 << bit;
+                    }
+                }
+                cur ^= 1;
+                if (__all(done_mask == all_done)) { conv_sub = 1; m_sub = m; break; }
+                {
+                    const double f = dts_ / (double)(m + 1);
+                    const double nr = -ali * f, ni = alr * f;
+                    alr = nr; ali = ni;
+                }
+            }
+            converged &= conv_sub;
+            orders += (unsigned long long)m_sub;
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) { chr[tt] += ocr[tt]; chi_[tt] += oci[tt]; }
+        }
+        // tau_grads = rho <chi'_l | Psi> = rho sum_rows conj(chi'_l) Psi
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            double orr = 0., oi = 0.;
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    orr += gfr[l][tt][r] * psr[tt][r] + gfi[l][tt][r] * psi_[tt][r];
+                    oi += gfr[l][tt][r] * psi_[tt][r] - gfi[l][tt][r] * psr[tt][r];
+                }
+            orr += __shfl_xor(orr, 16, 64); oi += __shfl_xor(oi, 16, 64);
+            orr += __shfl_xor(orr, 32, 64); oi += __shfl_xor(oi, 32, 64);
+            if (lane < 16) { redo[wave][l][c][0] = orr; redo[wave][l][c][1] = oi; }
+        }
+        __syncthreads();
+        if (tid < 16 && valid) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L) {
+                    double gr_ = 0., gi_ = 0.;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) { gr_ += redo[w][l][c][0]; gi_ += redo[w][l][c][1]; }
+                    a.tg[((size_t)k * L + l) * a.N_T + n] = make_double2(rho * gr_, rho * gi_);
+                }
+            }
+        }
+        if (tid == 0) {
+            if (!converged) atomicOr(&a.flags[0], 4);
+            atomicAdd(&a.stats[8], orders * (unsigned long long)min(16, a.N_T - n0));
+        }
     }
 }
 
@@ -2502,6 +2824,9 @@ struct Deriv2Args {
     const double2 *gpark;      // nullptr or [K][N_T][maxp][NP]
     const int *morder;         // [K][N_T] number of terms M of the cell (u_M below the tolerance), < 0: not usable
     int maxp;
+    // batches with a cell that needs sub-steps (deriv_flag_kernel) are redone by deriv_sub_kernel afterwards: whatever
+    // this kernel writes for them is overwritten, only its non-convergence flag has to stay down
+    const int *batch_flag;     // nullptr or [nbatch_total]
 #ifdef GRAPE_DIAG
     int ablate;                // diagnostic builds only: bit0 no parking traffic (results wrong)
 #endif
@@ -2763,8 +3088,9 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
             }
         }
         if (tid == 0) {
-            if (!converged) atomicOr(&a.flags[0], 4);
-            atomicAdd(&a.stats[8], (unsigned long long)M * (unsigned long long)min(16, a.N_T - n0));
+            const bool redone = a.batch_flag && a.batch_flag[batch];
+            if (!converged && !redone) atomicOr(&a.flags[0], 4);
+            if (!redone) atomicAdd(&a.stats[8], (unsigned long long)M * (unsigned long long)min(16, a.N_T - n0));
         }
         __syncthreads();   // LDS block, reduction slots and parking area are reused by the next batch
     }

@@ -533,3 +533,42 @@ def test_three_tile_instantiation_matches_padded_four_tile_path(g, ref, N, herm,
     Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:])
     assert abs(J3 - Jr) <= TOL_J and np.abs(tau3 - taur).max() <= TOL_TAU and np.abs(G3 - Gr).max() <= tol_G(Gr)
     assert np.abs(np.linalg.norm(bw3, axis=2) - 1.0).max() <= 1e-12 or not herm
+
+
+@pytest.mark.parametrize("N,L,K,N_T,dt,herm", [
+    (6, 2, 2, 5, 20.0, True), (20, 1, 2, 4, 25.0, False), (40, 2, 2, 3, 20.0, True), (64, 2, 3, 20, 18.0, True),
+    (64, 3, 2, 3, 60.0, True), (100, 2, 2, 3, 20.0, True)])
+def test_exact_gradient_route_is_accurate_for_large_norm_steps(g, ref, N, L, K, N_T, dt, herm):
+    """gradient_method = :gradgen at ||H|| dt ~ 20-70 per time step.  The reference's gradient-generator route goes
+    through the scaled-and-squared dense block exponential and is accurate for any norm; the HIP path sums the series
+    of that exponential on the extended vector and therefore cuts such a step into sub-steps (deriv_substeps: the
+    gradient slots are carried from one sub-step to the next).  Without them the unscaled series loses
+    eps * exp(||H|| dt) -- 1e-8 at 20, nothing at 40 -- or runs out of orders (GRAPE_ERR_TAYLOR).  Mixed problem: only
+    SOME time steps are long (non-uniform grid), so batches with and without sub-steps sit side by side."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=900 + N, dt=1.0, hermitian=herm)
+    tl = np.concatenate([[0.0], np.cumsum(np.where(np.arange(N_T) % 3 == 1, dt, 0.7))])   # every third step is long
+    args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        tg = h.tau_grads()
+        orders = h.work()["deriv_orders"]
+    Jr, Gr, taur, parts = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], want_parts=True)
+    assert abs(J - Jr) <= 1e-11 and np.abs(tau - taur).max() <= 1e-11     # 1e-16 * ||A||_1 * squarings on both sides
+    assert np.abs(G - Gr).max() <= tol_G(Gr) * 10                          # (the oracle's own error grows with the norm)
+    assert np.abs(tg - parts["tau_grads"]).max() <= 1e-9 * max(np.abs(parts["tau_grads"]).max(), 1e-3)
+    assert orders > 0
+
+
+def test_taylor_route_keeps_the_reference_behaviour_for_large_norm_steps(g):
+    """gradient_method = :taylor is the reference's plain recursion (optimize.jl:604-653): no sub-steps; a step whose
+    series does not converge within taylor_grad_max_order raises the reference's error."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(16, 1, 3, 1, seed=3, dt=60.0)
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], gradient_method=g.GRAD_TAYLOR) as h:
+        with pytest.raises(g.GrapeHipError) as ei:
+            h.eval(pr["pulsevals"])
+        assert ei.value.code == -5
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"]) as h:   # :gradgen works
+        J, G, _ = h.eval(pr["pulsevals"])
+        assert np.isfinite(G).all()
