@@ -314,7 +314,7 @@ def main():
                              "series_orders_per_cell": work["deriv_orders"] / work["cells"]},
             "J": J,
         }
-        if not args.no_matrix_free and N <= 64 and world == 1:
+        if not args.no_matrix_free and N <= 256 and world == 1:
             # secondary line, NOT `value`: the same evaluation with prop_method = GRAPE_PROP_SERIES (matrix-free
             # polynomial propagator, the role of the reference's Cheby/Newton methods), rank 0's shard only
             hm = g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"],

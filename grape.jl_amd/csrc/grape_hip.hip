@@ -10,6 +10,7 @@
 #include "grape_kernels.hip.h"
 #include "grape_large.hip.h"
 #include "grape_series.hip.h"
+#include "grape_cheby.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -98,6 +99,10 @@ struct grape_handle {
     int *d_batchflag = nullptr;  // [K * ceil(N_T / 16)] derivative batches left to deriv_sub_kernel (sub-stepped series)
     double sub_theta = 0.0;      // threshold of deriv_substeps (0: off, gradient_method = :taylor mirrors the reference)
     int sq_plan = 2;             // blocked path: squaring launches issued per chunk (adapted by grape_check, see expm_large)
+    // matrix-free propagator for 64 < N <= 256 (grape_cheby.hip.h): exchange slots, counters, launch plan
+    double2 *d_xch = nullptr;    // [2][K][4][NP]  (forward, backward), armed with the sentinel before every launch
+    int *d_xcc = nullptr;        // [2][K][16] XCC ids of the siblings (which XCD does each workgroup run on?)
+    int cheby_S = 0, cheby_round = 0, cheby_pair = 0;   // siblings per trajectory, trajectories per launch, both directions in one launch
     double2 *d_chi_in = nullptr; // [K][N] host-supplied boundary states of grape_backward_chi (allocated on first use)
     // several GPUs behind one handle (grape_problem.ndev > 1): this handle owns no device memory, its trajectories
     // are dealt to the child handles in contiguous blocks [shard_lo[g], shard_lo[g+1])
@@ -569,6 +574,51 @@ SeriesArgs series_args(grape_handle *h, const SweepArgs &sa, bool backward) {
     return ra;
 }
 
+// Cooperative polynomial sweeps for 64 < N <= 256 (grape_cheby.hip.h): the trajectories go through the kernel in rounds
+// of h->cheby_round; `sb` != nullptr adds the backward sweeps of the same trajectories to every launch.
+hipError_t launch_cheby(grape_handle *h, const SweepArgs *sf, const SweepArgs *sb, hipStream_t s) {
+    const int NP = h->NP, S = h->cheby_S, K = h->K;
+    const size_t lds = sizeof(double) * ((size_t)2 * 16 * (NP + 2) + 2 * (size_t)NP + CHEBY_MAXT + 2);
+    static bool attr_set[8] = {false};
+    if (!attr_set[h->device & 7]) {
+        hipError_t e = hipFuncSetAttribute((const void *)cheby_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[h->device & 7] = true;
+    }
+    hipLaunchKernelGGL(cheby_arm_kernel, dim3(256), dim3(256), 0, s, (unsigned long long *)h->d_xch, (size_t)2 * K * 4 * NP * 2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(h->d_xcc, 0xFF, (size_t)2 * K * 16 * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    auto fill = [&](ChebyArgs &c, const SweepArgs &sa, bool backward) {
+        c.s = sa;
+        c.H0 = backward ? h->d_H0t : h->d_H0f;
+        c.Hc = backward ? h->d_Hct : h->d_Hcf;
+        c.eps = h->d_eps; c.shape = h->d_shape; c.dts = h->d_dts; c.rb = h->d_rb; c.stats = h->d_stats;
+        c.xch = h->d_xch + (backward ? (size_t)K * 4 * NP : 0);
+        c.xcc = h->d_xcc + (backward ? (size_t)K * 16 : 0);
+        // XCD-local stores (sc0: they land in the XCD's L2, where the siblings' device-scope polls find them) are the
+        // default -- C5 shard sweeps 175 -> 141 ms; XCD-local LOADS (buffer_inv sc0 + sc0 load) never saw the data
+        // on gfx950 and are not used
+        c.xmode = getenv("GRAPE_CHEBY_XMODE") ? atoi(getenv("GRAPE_CHEBY_XMODE")) & 1 : 1;
+        c.tol = h->series_tol;
+        c.L = h->L; c.hc_per_traj = h->p.hc_per_traj; c.NP = NP; c.herm = h->herm ? 1 : 0;
+    };
+    for (int k0 = 0; k0 < K; k0 += h->cheby_round) {
+        const int kn = std::min(h->cheby_round, K - k0);
+        ChebyArgs cf{}, cb{};
+        if (sf) { fill(cf, *sf, false); cf.k0 = k0; cf.kn = kn; }
+        if (sb) { fill(cb, *sb, true); cb.k0 = k0; cb.kn = kn; }
+        const int nb = 8 * ((kn + 7) / 8) * S;
+        if (sf && sb) hipLaunchKernelGGL(cheby_coop_kernel, dim3(2 * nb), dim3(256), lds, s, cf, cb, S, nb);
+        else if (sf) { cb = cf; cb.kn = 0; hipLaunchKernelGGL(cheby_coop_kernel, dim3(nb), dim3(256), lds, s, cf, cb, S, nb); }
+        else { cf = cb; hipLaunchKernelGGL(cheby_coop_kernel, dim3(nb), dim3(256), lds, s, cf, cb, S, 0); }   // every block is a backward block
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 int status_from_flags(grape_handle *h, int flags) {
     // first: an evaluation whose propagators were never finished raises every other flag as a consequence
     if (flags & 32) {
@@ -629,7 +679,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -665,10 +715,6 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     if (p->functional < 0 || p->functional > 2) { g_create_error = "unknown functional"; return GRAPE_ERR_INVALID; }
     if (p->prop_method != GRAPE_PROP_EXP && p->prop_method != GRAPE_PROP_SERIES) {
         g_create_error = "unknown prop_method";
-        return GRAPE_ERR_INVALID;
-    }
-    if (p->prop_method == GRAPE_PROP_SERIES && p->N > 64) {
-        g_create_error = "prop_method = GRAPE_PROP_SERIES is built for N <= 64 (one workgroup holds the generator tile)";
         return GRAPE_ERR_INVALID;
     }
     for (int n = 0; n < p->N_T; ++n)
@@ -828,7 +874,10 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         CCHK(dmalloc(&h->d_Hcp, pk.size()));
         CCHK(hipMemcpy(h->d_Hcp, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
         const long nbatch = (long)K * ((N_T + 15) / 16);
-        h->deriv_blocks = (int)std::min<long>(nbatch, 1024);
+        // one workgroup per CU walks its batches for the fused sizes (measured at C3: 6.75 ms with 256 workgroups, 6.83
+        // with 1024, 6.93 with 4096; the parking area of the two-pass kernel shrinks with the grid)
+        h->deriv_blocks = (int)std::min<long>(nbatch, h->large ? 1024 : std::max(h->num_cus, 64));
+        if (const char *envb = getenv("GRAPE_DERIV_BLOCKS")) h->deriv_blocks = (int)std::min<long>(nbatch, std::max(1, atoi(envb)));
         {   // two-pass series kernel (deriv2_kernel): untransposed fragments and the u_a parking area
             const char *env = getenv("GRAPE_DERIV2");
             h->deriv2 = !(env && atoi(env) == 0);
@@ -845,7 +894,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         }
         CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + (h->large ? 4 : 8)) * 2 * NP * 16));
     }
-    if (h->large) {
+    if (h->large && !h->series) {
         const long ncell = (long)h->KC * N_T;
         const long cap = std::max<long>(1, (long)(6.0e9 / (9.0 * 2.0 * pp * 8.0)));
         h->chunk = (int)std::min<long>(ncell, std::min<long>(cap, 4096));
@@ -872,7 +921,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     {   // concurrent sweeps (see SweepArgs::unit_chi)
         const char *env = getenv("GRAPE_FUSED_SWEEPS");
         const bool have_gb = p->Dpen && p->lambda_b != 0.0;
-        h->fuse = !h->large && !have_gb && !(env && atoi(env) == 0);
+        h->fuse = (!h->large || h->series) && !have_gb && !(env && atoi(env) == 0);
         std::vector<double> itn(K), ones(K, 1.0);
         for (int k = 0; k < K; ++k) {
             double n2 = 0.0;
@@ -927,7 +976,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         // derivative series, and the area fits a modest share of HBM)
         const char *envp = getenv("GRAPE_SERIES_PARK");
         const size_t bytes = (size_t)K * N_T * 32 * NP * 16;
-        if (NP >= 48 && h->deriv2 && h->series_tol <= h->taylor_tol && bytes <= ((size_t)24 << 30) &&
+        if (NP >= 48 && !h->large && h->deriv2 && h->series_tol <= h->taylor_tol && bytes <= ((size_t)24 << 30) &&
             !(envp && atoi(envp) == 0)) {
             h->maxp = 32;
             CCHK(dmalloc(&h->d_gpark, (size_t)K * N_T * h->maxp * NP));
@@ -942,7 +991,22 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, 16));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
-    if (h->large) {
+    if (h->large && h->series) {
+        // cooperative polynomial sweeps (grape_cheby.hip.h): S = NP / 16 siblings per trajectory on one XCD, at most one
+        // workgroup per CU; the trajectories go through the kernel in rounds of `cheby_round`
+        const int per_xcd = std::max(1, h->num_cus / 8), S = h->NP / 16;
+        if (per_xcd < S) {
+            h->err = "prop_method = GRAPE_PROP_SERIES with N > 64 needs NP / 16 co-resident workgroups per XCD";
+            return fail(GRAPE_ERR_INVALID);
+        }
+        h->cheby_S = S;
+        h->cheby_pair = h->fuse && per_xcd >= 2 * S;
+        if (!h->cheby_pair) h->fuse = false;   // the two directions do not fit side by side: sequential sweeps
+        h->cheby_round = 8 * std::max(1, per_xcd / ((h->cheby_pair ? 2 : 1) * S));
+        CCHK(dmalloc(&h->d_xch, (size_t)2 * K * 4 * NP));
+        CCHK(dmalloc(&h->d_xcc, (size_t)2 * K * 16));
+    }
+    if (h->large && !h->series) {
         // cooperative sweeps when the trajectories alone cannot fill the chip: S siblings per trajectory,
         // all siblings of a trajectory on one XCD, at most one workgroup per CU (see sweep_coop_kernel).
         // A workgroup of NW waves owns R = NP / S = NW * RPW state rows, R in {4, 8, 16, 32, 64}.
@@ -1077,7 +1141,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         // backward sweep from the unit targets in the same launch: K more workgroups on the other CUs
         SweepArgs sb = sa;
         sb.store = h->d_bw; sb.tau = (double2 *)h->d_out; sb.f = nullptr; sb.unit_chi = 1; sb.inv_tnorm = h->d_inv_tnorm;
-        if (h->series) {
+        if (h->series && h->large) {
+            e = launch_cheby(h, &sa, &sb, s);
+        } else if (h->series) {
             const SeriesArgs rf = series_args(h, sa, false), rb = series_args(h, sb, true);
             const bool sc = 2 * h->K > h->num_cus;
             e = h->NP == 16 ? launch_series_pair<16>(rf, rb, sc, s) : h->NP == 32 ? launch_series_pair<32>(rf, rb, sc, s)
@@ -1086,6 +1152,8 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             e = h->NP == 16 ? launch_sweep_pair<16>(sa, sb, s) : h->NP == 32 ? launch_sweep_pair<32>(sa, sb, s)
                 : h->NP == 48 ? launch_sweep_pair<48>(sa, sb, s) : launch_sweep_pair<64>(sa, sb, s);
         }
+    } else if (h->series && h->large) {
+        e = launch_cheby(h, &sa, nullptr, s);
     } else if (h->series) {
         const SeriesArgs ra = series_args(h, sa, false);
         e = h->NP == 16 ? launch_series<16>(ra, false, s) : h->NP == 32 ? launch_series<32>(ra, false, s)
@@ -1161,6 +1229,8 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         hipLaunchKernelGGL(chi_coeff_kernel, dim3((h->K + 63) / 64), dim3(64), 0, s, ca);
         e = hipGetLastError();
         h->z_valid = true;
+    } else if (h->series && h->large) {
+        e = launch_cheby(h, nullptr, &sa, s);
     } else if (h->series) {
         const SeriesArgs ra = series_args(h, sa, true);
         e = h->NP == 16 ? launch_series<16>(ra, true, s) : h->NP == 32 ? launch_series<32>(ra, true, s)

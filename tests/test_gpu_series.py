@@ -137,11 +137,76 @@ def test_series_shaped_amplitudes_per_trajectory_controls_and_shards(g):
     assert np.abs(Gs - G).max() <= 1e-13
 
 
-def test_series_rejects_large_n(g):
+LARGE_SERIES = [  # N, L, N_T, K, dt, hermitian, functional
+    (65, 1, 5, 2, 1.0, True, 0),      # smallest blocked size: NP = 128, 8 siblings per trajectory
+    (100, 2, 6, 3, 1.0, True, 0),     # Chebyshev (Hermitian generators)
+    (128, 2, 4, 2, 2.5, True, 1),     # r dt ~ 6
+    (100, 2, 5, 2, 1.0, False, 2),    # non-Hermitian: Taylor recursion with an a-priori term count
+    (256, 4, 4, 2, 1.0, True, 0),     # C5-shaped cells (16 siblings)
+    (256, 1, 3, 9, 1.0, True, 1),     # more trajectories than one round of the launch plan
+    (200, 2, 3, 2, 30.0, True, 0),    # r dt ~ 70: many Chebyshev terms in one step (derivative series sub-stepped)
+]
+
+
+@pytest.mark.parametrize("case", LARGE_SERIES, ids=[f"N{c[0]}_L{c[1]}_dt{c[4]}_{'h' if c[5] else 'nh'}_f{c[6]}" for c in LARGE_SERIES])
+def test_polynomial_propagator_for_large_hilbert_spaces(g, ref, case):
+    """prop_method = GRAPE_PROP_SERIES for 64 < N <= 256 (the reference's `Cheby` for larger systems, README.md:55):
+    cooperative Chebyshev / Taylor sweeps of grape_cheby.hip.h, no propagator is materialised.  Parity with the oracle's
+    ExpProp route at the stated tolerance, with the blocked Pade path, and of every stored state."""
     from grape_jl_amd import synth
-    pr = synth.make_problem(65, 1, 2, 1, seed=1)
-    with pytest.raises(g.GrapeHipError):
-        g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], prop_method=g.PROP_SERIES)
+    N, L, N_T, K, dt, herm, functional = case
+    pr = synth.make_problem(N, L, N_T, K, seed=700 + N + K, dt=dt, hermitian=herm)
+    pr["weights"] = 0.5 + np.arange(K) / K
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    x = pr["pulsevals"]
+    with g.GrapeHip(*args, functional=functional, prop_method=g.PROP_SERIES) as h:
+        J, G, tau, psiT = h.eval(x, want_psiT=True)
+        fw, bw = h.storage(0), h.storage(1)
+        w = h.work()
+        assert w["expm_cells"] == 0 and w["series_terms"] > 0
+        with pytest.raises(g.GrapeHipError):
+            h.propagator(0, 0)          # matrix-free: nothing to return
+        Jf, Gf, _ = h.eval(x, gradient=False)
+        assert Gf is None and abs(Jf - J) <= 1e-15
+        J2, G2, _ = h.eval(x)
+        assert J2 == J and np.array_equal(G2, G)
+        assert h.set_fused_sweeps(False) is False
+        Js, Gs, _ = h.eval(x)           # sequential sweeps: the backward launch alone
+        assert abs(Js - J) <= 1e-14 and np.abs(Gs - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
+    Jr, Gr, taur, parts = ref.evaluate(*args[:3], x, *args[3:], functional=functional, want_parts=True)
+    lim = 10.0 if dt > 5 else 1.0       # (the oracle's own rounding grows with the norm of the step)
+    assert abs(J - Jr) <= TOL_J * lim and np.abs(tau - taur).max() <= TOL_TAU * lim
+    assert np.abs(psiT - parts["psiT"]).max() <= 1e-12 * lim
+    assert np.abs(G - Gr).max() <= tol_G(Gr) * lim
+    if herm:
+        assert np.abs(np.linalg.norm(fw, axis=2) - 1.0).max() <= 1e-12 * lim
+        assert np.abs(np.linalg.norm(bw, axis=2) - 1.0).max() <= 1e-12 * lim
+    with g.GrapeHip(*args, functional=functional) as he:   # blocked Pade path on the same inputs
+        Je, Ge, _ = he.eval(x)
+        assert np.abs(he.storage(0) - fw).max() <= 1e-12 * lim
+    assert abs(J - Je) <= 1e-12 * lim and np.abs(G - Ge).max() <= tol_G(Ge) * lim
+
+
+def test_polynomial_propagator_large_n_state_running_cost_and_custom_chi(g, ref):
+    from grape_jl_amd import synth
+    N, L, N_T, K = 100, 2, 5, 2
+    pr = synth.make_problem(N, L, N_T, K, seed=31)
+    rng = np.random.default_rng(2)
+    D = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    D = (D + D.conj().T) / 4
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args, prop_method=g.PROP_SERIES, D=D, lambda_b=0.3) as h:   # sequential sweeps (xi inhomogeneity)
+        J, G, tau = h.eval(pr["pulsevals"])
+    Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], D=D, lambda_b=0.3)
+    assert abs(J - Jr) <= TOL_J and np.abs(G - Gr).max() <= tol_G(Gr)
+    with g.GrapeHip(*args, prop_method=g.PROP_SERIES) as h:
+        h.forward(pr["pulsevals"])
+        chi = np.conj(h.final_states())[:, ::-1] * 0.5 + pr["target"]
+        Gc = h.backward_chi(chi)
+    _, _, _, parts = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], gradient=False, want_parts=True)
+    chi_r = np.conj(parts["psiT"])[:, ::-1] * 0.5 + pr["target"]
+    Gcr, *_ = ref.evaluate_chi(*args[:3], pr["pulsevals"], *args[3:-1], chi_r, weights=pr["weights"])
+    assert np.abs(Gc - Gcr).max() <= tol_G(Gcr)
 
 
 @pytest.mark.parametrize("prop", [0, 1], ids=["exp", "series"])

@@ -7,8 +7,6 @@ from grape_jl_amd import synth
 N, L, N_T, K = (int(v) for v in sys.argv[1:5])
 pr = synth.make_problem(N, L, N_T, K, seed=7)
 for name, pm in (("exp", g.PROP_EXP), ("series", g.PROP_SERIES)):
-    if pm == g.PROP_SERIES and N > 64:
-        continue
     h = g.GrapeHip(pr['H0'], pr['Hc'], pr['tlist'], pr['psi0'], pr['target'], pr['weights'], prop_method=pm)
     for it in range(3):
         t = time.time(); J, G, tau = h.eval(pr['pulsevals']); dt = time.time() - t
