@@ -333,8 +333,8 @@ __device__ __forceinline__ void cheby_coop_body(const ChebyArgs &a, const int k,
         }
     }
     if (tid == 0 && s == 0) {
-        atomicAdd(&a.stats[10], terms);
-        atomicAdd(&a.stats[11], steps);
+        stat_add(a.stats, 10, terms);
+        stat_add(a.stats, 11, steps);
     }
     if (!BACKWARD && s == 0) {   // tau_k = <target_k | Psi_k(T)>   (x holds Psi_k(T))
         __shared__ double2 part3[T];

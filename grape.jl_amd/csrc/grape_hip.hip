@@ -134,7 +134,8 @@ size_t expm_lds_bytes(int NT) {
 template <int NT>
 hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persistent_blocks = 0) {
     static bool attr_set[8] = {false};
-    const size_t lds = expm_lds_bytes(NT);
+    size_t lds = expm_lds_bytes(NT);
+    if (const char *envl = getenv("GRAPE_EXPM_LDS_PAD")) lds += (size_t)atoi(envl) * 1024;   // diagnostic: fewer cells per CU
     int dev = 0;
     hipGetDevice(&dev);
     if (!attr_set[dev & 7]) {
@@ -989,7 +990,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_tg, (size_t)K * L * N_T));
     CCHK(dmalloc(&h->d_out, (size_t)2 * K + 8));
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
-    CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, 16));
+    CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
     if (h->large && h->series) {
         // cooperative polynomial sweeps (grape_cheby.hip.h): S = NP / 16 siblings per trajectory on one XCD, at most one
@@ -1025,7 +1026,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         }
     }
     CCHK(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
-    CCHK(hipMemset(h->d_stats, 0, 16 * sizeof(unsigned long long)));
+    CCHK(hipMemset(h->d_stats, 0, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS * sizeof(unsigned long long)));
     CCHK(hipMemset(h->d_fw, 0, (size_t)K * (N_T + 1) * NP * 16));
     CCHK(hipMemset(h->d_bw, 0, (size_t)K * (N_T + 1) * NP * 16));
     CCHK(hipMemset(h->d_tg, 0, (size_t)K * L * N_T * 16));
@@ -1066,7 +1067,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     // allocation, a bad device ordinal) must not be reported by the launch checks of this evaluation
     (void)hipGetLastError();
     HIPCHK(h, hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
-    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, 16 * sizeof(unsigned long long), s));
+    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS * sizeof(unsigned long long), s));
     if (d_pulsevals != h->d_eps)
         HIPCHK(h, hipMemcpyAsync(h->d_eps, d_pulsevals, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToDevice, s));
     // ---- phase 0: expm of every cell ----
@@ -1698,8 +1699,10 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
-    unsigned long long st[16];
-    HIPCHK(h, hipMemcpy(st, h->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+    unsigned long long sh[GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS], st[GRAPE_STAT_SLOTS] = {0};
+    HIPCHK(h, hipMemcpy(sh, h->d_stats, sizeof(sh), hipMemcpyDeviceToHost));
+    for (int q = 0; q < GRAPE_STAT_SHARDS; ++q)
+        for (int i = 0; i < GRAPE_STAT_SLOTS; ++i) st[i] += sh[q * GRAPE_STAT_SLOTS + i];
     const double N3 = (double)h->N * h->N * h->N, N2 = (double)h->N * h->N;
     const double cells = (double)h->K * h->N_T, ecells = (double)h->KC * h->N_T;
     // F_exp = (g + s) * 8 N^3 + (32/3) N^3, g = GEMMs of the Pade order (13:6, 9:5, 7:4, 5:3, 3:2)

@@ -277,8 +277,8 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
     }
     if (tid == 0) {
         a.s_cell[blockIdx.x] = s;
-        atomicAdd(&a.stats[0], (unsigned long long)s);
-        atomicAdd(&a.stats[7], 1ull);   // the blocked path always evaluates the order-13 approximant
+        stat_add(a.stats, 0, (unsigned long long)s);
+        stat_add(a.stats, 7, 1ull);   // the blocked path always evaluates the order-13 approximant
         atomicMax(&a.flags[1], s);
     }
 }
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(1024) lg_pivoted_kernel(LgPivArgs a) {
         }
         if (tid == 0) {
             if (!ok) atomicOr(&a.flags[0], 1);   // exactly singular denominator
-            atomicAdd(&a.stats[9], 1ull);
+            stat_add(a.stats, 9, 1ull);
         }
     }
 }

@@ -355,8 +355,8 @@ __device__ __forceinline__ void series_sweep_body(const SeriesArgs &a, const int
     }
     if (tid == 0) {
         if (failed) atomicOr(&sa.flags[0], 16);
-        atomicAdd(&a.stats[10], terms);
-        atomicAdd(&a.stats[11], substeps);
+        stat_add(a.stats, 10, terms);
+        stat_add(a.stats, 11, substeps);
     }
 }
 
