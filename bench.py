@@ -248,7 +248,7 @@ def main():
             pmc_file = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))[-1]
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             for kname, d in pmc["kernels"].items():
-                if kname.startswith("void expm_pade_kernel") and d.get("MfmaUtil_percent", 0) > 0:   # the fast pass
+                if kname.startswith(("void expm_pade_kernel", "void expm_persistent_kernel")) and d.get("MfmaUtil_percent", 0) > 1:   # the fast pass
                     traffic = d.get("hbm_bytes_per_launch")
                     hw_util = d.get("MfmaUtil_percent")
         except Exception:
@@ -280,7 +280,7 @@ def main():
                        "one_eval": "one shard evaluation = functional + full gradient of 128 trajectories; "
                                    "value counts shard evaluations completed by all ranks per second",
                        "global_problem_evals_per_s": args.steps / elapsed},
-            "roofline": {"bound": "mfma", "kernel": ("expm_pade_kernel<%d,...>" % ((N + 15) // 16 if N <= 32 else 4) if N <= 64
+            "roofline": {"bound": "mfma", "kernel": (("expm_persistent_kernel<4,...>" if N > 48 else "expm_pade_kernel<%d,...>" % ((N + 15) // 16)) if N <= 64
                                                      else "lg_gemm_kernel chain (blocked Pade-13)") + " (v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
