@@ -374,6 +374,7 @@ __global__ void __launch_bounds__(256) cheby_coop_kernel(ChebyArgs af, ChebyArgs
     const int xcd = b & 7, slot = b >> 3;
     const int kl = (slot / S) * 8 + xcd, s = slot % S;
     if (kl >= a.kn) return;
+    if (a.s.drop_sibling && s == a.s.drop_sibling - 1) return;   // fault injection (tests): the siblings must time out, not hang
     if (bw) cheby_coop_body<true>(ab, ab.k0 + kl, s, S, hs, x, coef, plan);
     else cheby_coop_body<false>(af, af.k0 + kl, s, S, hs, x, coef, plan);
 }

@@ -1134,6 +1134,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     sa.store = h->d_fw; sa.tau = (double2 *)d_out; sa.f = nullptr; sa.rho = h->d_rho; sa.flags = h->d_flags;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
+    if (const char *envd = getenv("GRAPE_TEST_DROP_SIBLING")) sa.drop_sibling = atoi(envd);   // fault injection (tests)
     phase_begin(h, 1, s);
     const bool pair = h->fuse && h->fuse_on && h->want_bw;
     h->bw_done = h->bw_unit = pair;

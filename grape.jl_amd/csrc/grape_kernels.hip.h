@@ -1660,6 +1660,10 @@ struct SweepArgs {
     int unit_chi;
     // host-supplied boundary states chi_k(T) of grape_backward_chi ([K][N], not normalised): replace c_k target_k
     const double2 *chi_in;
+    // fault injection for the cooperative kernels (tests only, env GRAPE_TEST_DROP_SIBLING): sibling `drop_sibling - 1`
+    // of every trajectory exits at once, so that the others run into their spin limit -- the evaluation must fail
+    // with GRAPE_ERR_HIP and the grid must drain; 0 in production
+    int drop_sibling;
 };
 
 // c_k of chi_k(T) = c_k target_k for the three functionals (docs/src/tutorial.md:349-356, 402)

@@ -621,11 +621,13 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
     __shared__ double2 x[NP];
     __shared__ double2 part[T > NP ? T : NP];
     __shared__ double sc[2];
+    bool gone = false;   // (thread 0) a sibling did not arrive within the spin limit
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int k = (slot / S) * 8 + xcd, s = slot % S;
     if (k >= a.K) return;
+    if (a.drop_sibling && s == a.drop_sibling - 1) return;   // fault injection (tests): the siblings must time out, not hang
     const int r0 = s * R;   // first row (forward) / column (backward) of this workgroup's slice
     const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
     double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
@@ -695,7 +697,7 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
         const int nout = BACKWARD ? n : n + 1;       // storage row of the new state
         if (step > 0) {
             // wait until all S siblings have published step - 1, then fetch the full state
-            if (tid == 0) coop_wait(ck, (unsigned)(S * step), a.flags);
+            if (tid == 0 && !gone) gone = !coop_wait(ck, (unsigned)(S * step), a.flags);   // a time-out is final: no further waits
             __syncthreads();
             const int nin = BACKWARD ? n + 1 : n;
             if (tid < NP) x[tid] = coop_load(&st[(size_t)nin * NP + tid]);
@@ -746,7 +748,7 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
     }
 
     if (!BACKWARD && s == 0) {   // tau_k = <target_k | Psi_k(T)>
-        if (tid == 0) coop_wait(ck, (unsigned)(S * a.N_T), a.flags);
+        if (tid == 0 && !gone) coop_wait(ck, (unsigned)(S * a.N_T), a.flags);
         __syncthreads();
         double pr = 0., pi = 0.;
         if (tid < a.N) {

@@ -260,3 +260,26 @@ def test_blocked_path_squaring_plan_without_host_synchronisation(g, ref):
     with g.GrapeHip(*args, devices=[0, 0]) as hm:
         Jm, Gm, _ = hm.eval(x)
         assert abs(Jm - J) <= 1e-14 and np.abs(Gm - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
+
+
+@pytest.mark.parametrize("prop", [0, 1], ids=["coop_sweeps", "cheby_sweeps"])
+def test_cooperative_kernels_time_out_instead_of_hanging(g, prop, monkeypatch):
+    """The cooperative kernels (sweep_coop_kernel for ExpProp at N > 64, cheby_coop_kernel for the polynomial propagator)
+    let several workgroups share a trajectory and wait for each other.  Fault injection: one sibling of every trajectory
+    exits at once (GRAPE_TEST_DROP_SIBLING).  The others must run into their bounded spin, raise flag 8 and let the grid
+    drain: the call fails with GRAPE_ERR_HIP within seconds, and the same handle evaluates correctly afterwards."""
+    import time
+    from grape_jl_amd import synth
+    pr = synth.make_problem(100, 1, 4, 2, seed=12)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"])
+    with g.GrapeHip(*args, prop_method=prop) as h:
+        J0, G0, _ = h.eval(pr["pulsevals"])
+        monkeypatch.setenv("GRAPE_TEST_DROP_SIBLING", "2")
+        t0 = time.time()
+        with pytest.raises(g.GrapeHipError) as ei:
+            h.eval(pr["pulsevals"])
+        assert ei.value.code == -2 and "sibling" in str(ei.value)
+        assert time.time() - t0 < 60.0
+        monkeypatch.delenv("GRAPE_TEST_DROP_SIBLING")
+        J1, G1, _ = h.eval(pr["pulsevals"])
+        assert J1 == J0 and np.array_equal(G1, G0)
