@@ -517,3 +517,65 @@ def optimize(trajectories, tlist, backend=None, **kwargs):
     for l in range(wrk.L):
         res_.optimized_controls[l] = discretize(wrk.pulsevals[l * wrk.N_T:(l + 1) * wrk.N_T], res_.tlist)
     return res_
+
+
+# ---- iteration table ----------------------------------------------------------------------------
+_DELTA_HEADERS = {"ΔJ_T", "ΔJ_a", "ΔJ_b", "λ_a⋅ΔJ_a", "λ_b⋅ΔJ_b", "ΔJ", "ǁΔϵǁ", "max|Δϵ|", "ǁΔϵǁ/ǁϵǁ", "∫Δϵ²dt"}
+
+
+def make_grape_print_iters(print_iter_info=("iter.", "J_T", "ǁ∇Jǁ", "ǁΔϵǁ", "ΔJ", "FG(F)", "secs"), store_iter_info=(),
+                           out=None):
+    """``make_grape_print_iters`` (src/optimize.jl:310-537): the callback that prints one table row per iteration and
+    returns the tuple of ``store_iter_info`` fields for ``result.records``.  Columns, widths (11; ``iter.`` 6, ``FG(F)``
+    and ``secs`` 8) and number formats (``%.2e``, ``n/a`` for differences in iteration 0, ``FG(F)`` as ``fg(f)``) follow
+    the reference.  Supported fields: iter., J_T, J_a, J_b, λ_a⋅J_a, λ_b⋅J_b, J, ǁ∇J_Tǁ, ǁ∇(J_T+λ_b·J_b)ǁ, ǁ∇J_aǁ, λ_aǁ∇J_aǁ,
+    ǁ∇Jǁ, ǁΔϵǁ, ǁϵǁ, max|Δϵ|, max|ϵ|, ǁΔϵǁ/ǁϵǁ, ∫Δϵ²dt, ΔJ_T, ΔJ_a, ΔJ_b, λ_a⋅ΔJ_a, λ_b⋅ΔJ_b, ΔJ, FG(F), secs (the
+    line-search columns ǁsǁ, ∠°, α are properties of LBFGSB.jl's internals and are not available from scipy)."""
+    import sys
+    out = out or sys.stdout
+    fields = list(print_iter_info) + [f for f in store_iter_info if f not in print_iter_info]
+    unsupported = [f for f in fields if f in ("ǁsǁ", "∠°", "α")]
+    if unsupported:
+        raise ValueError(f"iteration-table fields {unsupported} need the optimizer's search direction (not available)")
+
+    def print_table(wrk, iteration, *args):
+        res, kw = wrk.result, wrk.kwargs
+        lam_a, lam_b = kw.get("lambda_a", 1.0), kw.get("lambda_b", 1.0)
+        eps, eps0 = wrk.pulsevals, wrk.pulsevals_guess
+        d = eps - eps0
+        dt = np.diff(wrk.tlist)
+        v = {"iter.": iteration, "J_T": res.J_T, "ΔJ_T": res.J_T - res.J_T_prev, "J_a": res.J_a,
+             "λ_a⋅J_a": float(wrk.J_parts[1]), "ΔJ_a": res.J_a - res.J_a_prev, "λ_a⋅ΔJ_a": lam_a * (res.J_a - res.J_a_prev),
+             "J_b": res.J_b, "λ_b⋅J_b": float(wrk.J_parts[2]), "ΔJ_b": res.J_b - res.J_b_prev,
+             "λ_b⋅ΔJ_b": lam_b * (res.J_b - res.J_b_prev), "J": res.J_T + lam_a * res.J_a + lam_b * res.J_b,
+             "ǁ∇J_Tǁ": float(np.linalg.norm(wrk.grad_J_Tb)), "ǁ∇(J_T+λ_b·J_b)ǁ": float(np.linalg.norm(wrk.grad_J_Tb)),
+             "ǁ∇J_aǁ": float(np.linalg.norm(wrk.grad_J_a)), "λ_aǁ∇J_aǁ": lam_a * float(np.linalg.norm(wrk.grad_J_a)),
+             "ǁ∇Jǁ": float(np.linalg.norm(wrk.gradient)),
+             "ΔJ": (res.J_T + lam_a * res.J_a + lam_b * res.J_b) - (res.J_T_prev + lam_a * res.J_a_prev + lam_b * res.J_b_prev),
+             "ǁΔϵǁ": float(np.linalg.norm(d)), "ǁϵǁ": float(np.linalg.norm(eps)), "max|Δϵ|": float(np.abs(d).max()),
+             "max|ϵ|": float(np.abs(eps).max()),
+             "ǁΔϵǁ/ǁϵǁ": float(np.linalg.norm(d) / max(np.linalg.norm(eps), 1e-300)),
+             "∫Δϵ²dt": float(sum(np.sum(d[l * wrk.N_T:(l + 1) * wrk.N_T] ** 2 * dt) for l in range(wrk.L))),
+             "FG(F)": tuple(wrk.fg_count), "secs": res.secs}
+        width = {"iter.": max(len(str(kw.get("iter_stop", 5000))), 6), "FG(F)": 8, "secs": 8, "ǁ∇(J_T+λ_b·J_b)ǁ": 17}
+        if print_iter_info:
+            if iteration == 0:
+                out.write("".join(h.rjust(width.get(h, 11)) for h in print_iter_info) + "\n")
+            row = []
+            for h in print_iter_info:
+                if h == "iter.":
+                    sv = str(v[h])
+                elif h == "FG(F)":
+                    sv = "%d(%d)" % v[h]
+                elif h == "secs":
+                    sv = "%.1f" % v[h]
+                elif h in _DELTA_HEADERS:
+                    sv = ("%.2e" % v[h]) if iteration > 0 else "n/a"
+                else:
+                    sv = "%.2e" % v[h]
+                row.append(sv.rjust(width.get(h, 11)))
+            out.write("".join(row) + "\n")
+            out.flush()
+        return tuple(v[f] for f in store_iter_info)
+
+    return print_table

@@ -119,3 +119,24 @@ def test_amplitude_wrapper_chain_rule_and_j_parts_split():
     assert abs(wrk.J_parts[0] - Jtot) <= 1e-14 and wrk.J_parts[2] == 0.0
     G.update_result(wrk, 0)
     assert wrk.result.J_b == 0.0 and abs(wrk.result.J_T - Jtot) <= 1e-14
+
+
+def test_iteration_table_mirrors_the_reference_format():
+    # make_grape_print_iters, /root/reference/src/optimize.jl:310-537: header row in iteration 0, "n/a" for differences
+    # there, %.2e numbers, FG(F) as fg(f), records of the stored fields
+    import io
+    trajs, tl, be = tls(lambda t: 0.2, nt=51)
+    buf = io.StringIO()
+    cb = G.make_grape_print_iters(store_iter_info=("iter.", "J_T", "ǁ∇Jǁ"), out=buf)
+    res = G.optimize(trajs, tl, backend=be, J_T=G.J_T_sm, iter_stop=3, callback=cb)
+    lines = buf.getvalue().splitlines()
+    assert lines[0].split() == ["iter.", "J_T", "ǁ∇Jǁ", "ǁΔϵǁ", "ΔJ", "FG(F)", "secs"]
+    assert len(lines) == 1 + len(res.records) == 1 + res.iter + 1
+    first = lines[1].split()
+    assert first[0] == "0" and first[3] == "n/a" and first[4] == "n/a" and first[5] == "1(0)"
+    assert all(len(ln) == 6 + 4 * 11 + 8 + 8 for ln in lines)
+    assert res.records[0][0] == 0 and abs(res.records[-1][1] - res.J_T) < 1e-15
+    import re
+    assert re.fullmatch(r"-?\d\.\d\de[+-]\d\d", lines[2].split()[1])
+    with pytest.raises(ValueError):
+        G.make_grape_print_iters(print_iter_info=("iter.", "∠°"))

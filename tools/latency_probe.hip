@@ -32,6 +32,17 @@ __global__ void probe(double *out, unsigned long long *t) {
             }
             if (MODE == 6) x = x * z;                                                 // dependent v_mul_f64
             if (MODE == 7) { float f = (float)x; f = f * 1.0001f + 0.5f; x = (double)f; }   // cvt + f32 fma + cvt
+            if (MODE == 8) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(x));   // 64-bit DPP move (dependent)
+            if (MODE == 9) {                                                          // two 32-bit DPP moves + fma (what invert16 does per element)
+                const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x153, 0xf, 0xf, true);
+                const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x153, 0xf, 0xf, true);
+                x = fma(__hiloint2double(hi, lo), z, y);
+            }
+            if (MODE == 10) {                                                         // 64-bit DPP move + fma
+                double b = x;
+                asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(b) : "v"(x));
+                x = fma(b, z, y);
+            }
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -48,10 +59,12 @@ int main() {
         hipLaunchKernelGGL(probe<2>, dim3(1), dim3(64), 0, 0, out, t); hipLaunchKernelGGL(probe<3>, dim3(1), dim3(64), 0, 0, out, t);
         hipLaunchKernelGGL(probe<4>, dim3(1), dim3(64), 0, 0, out, t); hipLaunchKernelGGL(probe<5>, dim3(1), dim3(64), 0, 0, out, t);
         hipLaunchKernelGGL(probe<6>, dim3(1), dim3(64), 0, 0, out, t); hipLaunchKernelGGL(probe<7>, dim3(1), dim3(64), 0, 0, out, t);
+        hipLaunchKernelGGL(probe<8>, dim3(1), dim3(64), 0, 0, out, t); hipLaunchKernelGGL(probe<9>, dim3(1), dim3(64), 0, 0, out, t);
+        hipLaunchKernelGGL(probe<10>, dim3(1), dim3(64), 0, 0, out, t);
     }
     hipDeviceSynchronize();
     unsigned long long ht[16]; hipMemcpy(ht, t, 128, hipMemcpyDeviceToHost);
-    const char *names[] = {"v_fma_f64 dependent", "v_rcp_f64 dependent", "readlane x2 + fma", "ds_bpermute x2 + mul", "v_fmac_f64_dpp (+s_nop 1)", "permlane32/16 swap bcast + mul", "v_mul_f64 dependent", "cvt f64->f32, fma f32, cvt back"};
-    for (int m = 0; m < 8; ++m) printf("%-34s %7.1f cycles per iteration\n", names[m], (double)ht[m] / (4.0 * REP));
+    const char *names[] = {"v_fma_f64 dependent", "v_rcp_f64 dependent", "readlane x2 + fma", "ds_bpermute x2 + mul", "v_fmac_f64_dpp (+s_nop 1)", "permlane32/16 swap bcast + mul", "v_mul_f64 dependent", "cvt f64->f32, fma f32, cvt back", "v_mov_b64_dpp dependent", "2x v_mov_b32_dpp + fma", "v_mov_b64_dpp + fma"};
+    for (int m = 0; m < 11; ++m) printf("%-34s %7.1f cycles per iteration\n", names[m], (double)ht[m] / (4.0 * REP));
     return 0;
 }
