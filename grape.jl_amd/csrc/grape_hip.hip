@@ -1115,10 +1115,12 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         const size_t nb = (size_t)h->KC * h->N_T;
         std::vector<unsigned long long> st(nb * 32);
         hipMemcpy(st.data(), ea.stamps, nb * 32 * 8, hipMemcpyDeviceToHost);
-        auto avg = [&](int i1, int i0) {
+        auto avg = [&](int i1, int i0) {   // over the workgroups that stamped (the persistent kernel has one per CU)
             double sum = 0;
-            for (size_t b = 0; b < nb; ++b) sum += (double)(st[b * 32 + i1] - st[b * 32 + i0]);
-            return sum / nb;
+            size_t cnt = 0;
+            for (size_t b = 0; b < nb; ++b)
+                if (st[b * 32 + i1] && st[b * 32 + i0]) { sum += (double)(st[b * 32 + i1] - st[b * 32 + i0]); ++cnt; }
+            return cnt ? sum / cnt : 0.0;
         };
         const char *pn[] = {"form A", "norm", "A2", "A4,A6 (+store A2)", "store A6 + combos", "dual", "U=A*T"};
         for (int j = 0; j < 7; ++j) fprintf(stderr, "  stamp %-24s %9.0f cycles\n", pn[j], avg(11 + j, j ? 10 + j : 0));

@@ -1564,6 +1564,7 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
         int s, order;
         double inv_b0sq;
         bool measure;
+        STAMP(0);
         if (!have_a) {
             const double bound = expm_norm_bound(a, cell);
             if constexpr (HERM && NT == 4) expm_form_a_herm64<256>(a, cell, smem, tid);
@@ -1581,7 +1582,9 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
             expm_norm_combine<NT>(smem, tid, LY::NTH / LY::NP);
             __syncthreads();
         }
+        STAMP(11);
         expm_poly<NT, HERM>(a, wave, lane, tid, smem, Pn, Qn, s, order, inv_b0sq);
+        STAMP(2);
         const int next = cell + per_x;
         // only cells without squarings leave the A region alone until the end of the solve: with s > 0 nothing
         // changes either (the squarings use the X region), so the prefetch is unconditional
@@ -1590,7 +1593,9 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
         block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true, hook);
         have_a = next < hi;
         if (lane == 0 && !(minrel > 1e-6)) { a.cellflag[cell] = 1; atomicAdd(&a.flags[2], 1); }
+        STAMP(3);
         expm_finish<NT>(a, cell, wave, lane, smem, Pn, s);
+        STAMP(4);
         // statistics are accumulated per workgroup and published once (three atomics per cell otherwise)
         st_s += s; st_max = max(st_max, s);
         st_ord[order == 13 ? 4 : (order - 3) / 2] += 1;

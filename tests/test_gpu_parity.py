@@ -572,3 +572,56 @@ def test_taylor_route_keeps_the_reference_behaviour_for_large_norm_steps(g):
     with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"]) as h:   # :gradgen works
         J, G, _ = h.eval(pr["pulsevals"])
         assert np.isfinite(G).all()
+
+
+def test_persistent_phase_a_matches_per_cell_launch_and_keeps_the_pivoted_fallback(g, ref, monkeypatch):
+    """N = 64 with enough cells for the persistent expm kernel (one workgroup per CU walking its cells, the next cell's A
+    formed under the first tile inversion): identical to the one-workgroup-per-cell launch (GRAPE_EXPM_PERSIST=0) bit
+    for bit, including cells that are flagged for the pivoted Pade solve, mixed Pade orders (non-uniform grid: some
+    steps are short enough for orders 7/9, one is long enough for a squaring) and a non-Hermitian generator set."""
+    from grape_jl_amd import synth
+    for herm in (True, False):
+        N, L, N_T, K = 64, 2, 560, 2                     # 1120 cells >= 4 x 256
+        pr = synth.make_problem(N, L, N_T, K, seed=50 + herm, hermitian=herm)
+        dts = np.ones(N_T)
+        dts[5::50] = 0.2                                  # lower Pade orders (norm certificate does not apply)
+        dts[7::100] = 3.0                                 # one squaring
+        tl = np.concatenate([[0.0], np.cumsum(dts)])
+        if herm:
+            # a two-level pi-pulse embedded in the 64-level system zeroes two diagonal entries of q(A) in the steps where
+            # control 0 has the value pi: those cells must go through the pivoted solve
+            pr["H0"][:, :2, :] = 0
+            pr["H0"][:, :, :2] = 0
+            pr["H0"][:, 0, 0], pr["H0"][:, 1, 1] = 1e-3, -1e-3
+            Hc0 = np.zeros((N, N), complex)
+            Hc0[0, 1] = Hc0[1, 0] = 1.0
+            Hc0[2:, 2:] = 0.05 * pr["Hc"][0, 2:, 2:]
+            pr["Hc"][0] = Hc0
+            pr["Hc"][1, :2, :] = 0
+            pr["Hc"][1, :, :2] = 0
+            pr["pulsevals"][[3, 300, 559]] = np.pi
+        args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
+        with g.GrapeHip(*args) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            w = h.work()
+            U = h.propagator(1, 7)
+        monkeypatch.setenv("GRAPE_EXPM_PERSIST", "0")
+        with g.GrapeHip(*args) as h0:
+            J0, G0, tau0 = h0.eval(pr["pulsevals"])
+            w0 = h0.work()
+            U0 = h0.propagator(1, 7)
+        monkeypatch.delenv("GRAPE_EXPM_PERSIST")
+        assert J == J0 and np.array_equal(G, G0) and np.array_equal(tau, tau0) and np.array_equal(U, U0)
+        assert w["squarings"] == w0["squarings"] > 0 and w["pivoted_cells"] == w0["pivoted_cells"]
+        assert w["flop_expm"] == w0["flop_expm"]
+        if herm:
+            assert w["pivoted_cells"] >= 2 * 3             # the three pi-pulse steps of both trajectories
+        # a sample of the first steps against the oracle (the full problem is too slow for the dense block exponential)
+        ns = 12
+        xs = pr["pulsevals"].reshape(L, N_T)[:, :ns].reshape(-1)
+        with g.GrapeHip(pr["H0"], pr["Hc"], tl[: ns + 1], pr["psi0"], pr["target"], pr["weights"]) as hs:
+            Js, Gs, taus = hs.eval(xs)
+        Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], tl[: ns + 1], xs, pr["psi0"], pr["target"], pr["weights"],
+                                    gradient_method=ref.TAYLOR)
+        assert abs(Js - Jr) <= TOL_J and np.abs(taus - taur).max() <= TOL_TAU and np.abs(Gs - Gr).max() <= tol_G(Gr)
+        assert np.abs(np.linalg.norm(U, axis=0) - 1.0).max() <= 1e-12 or not herm
