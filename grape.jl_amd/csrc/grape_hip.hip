@@ -144,8 +144,8 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess && NT == 4)
-            e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, false, NT == 4>,
+        if (e == hipSuccess && NT >= 3)
+            e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, false, NT >= 3>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set[dev & 7] = true;
@@ -167,8 +167,8 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
         if (herm) hipLaunchKernelGGL((expm_persistent_kernel<NT, NT == 4>), dim3(persistent_blocks), dim3(NT * 64), lds, s, a);
         else hipLaunchKernelGGL((expm_persistent_kernel<NT, false>), dim3(persistent_blocks), dim3(NT * 64), lds, s, a);
     } else
-    if (herm && NT == 4)   // Hermitian generators: three of four row tiles per strip from the MFMAs
-        hipLaunchKernelGGL((expm_pade_kernel<NT, false, NT == 4>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
+    if (herm && NT >= 3)   // Hermitian generators: NT - 1 of NT row tiles per strip from the MFMAs
+        hipLaunchKernelGGL((expm_pade_kernel<NT, false, NT >= 3>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
     else
         hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
     // pivoted pass over the flagged cells (all other workgroups exit at once)

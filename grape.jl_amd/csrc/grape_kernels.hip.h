@@ -733,13 +733,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // operand of k-step 16 ((w+s)&3) + 4r); only LDS addresses depend on the wave, through scalar offsets.
 // 12 instead of 16 MFMAs per k-step: the six products of the approximant cost 4.5.
 // ---------------------------------------------------------------------------------------
-template <int LD>
-__device__ __forceinline__ void rot_load_strip(const double *Xre, const double *Xim, Strip<4> &S, int wave, int lane) {
+template <int LD, int NT = 4>
+__device__ __forceinline__ void rot_load_strip(const double *Xre, const double *Xim, Strip<NT> &S, int wave, int lane) {
     const double *xr = Xre + (lane >> 4) * LD + 16 * wave + (lane & 15);
     const double *xi = Xim + (lane >> 4) * LD + 16 * wave + (lane & 15);
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-        const int tb = (wave + sl) & 3;
+    for (int sl = 0; sl < NT; ++sl) {
+        const int tb = (wave + sl) % NT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             S.re[sl][r] = xr[(16 * tb + 4 * r) * LD];
@@ -748,13 +748,13 @@ __device__ __forceinline__ void rot_load_strip(const double *Xre, const double *
     }
 }
 // slots 0..NS-1 to their natural plane positions
-template <int LD, int NS>
-__device__ __forceinline__ void rot_store_slots(double *Xre, double *Xim, const Strip<4> &S, int wave, int lane) {
+template <int LD, int NS, int NT = 4>
+__device__ __forceinline__ void rot_store_slots(double *Xre, double *Xim, const Strip<NT> &S, int wave, int lane) {
     double *xr = Xre + (lane >> 4) * LD + 16 * wave + (lane & 15);
     double *xi = Xim + (lane >> 4) * LD + 16 * wave + (lane & 15);
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
-        const int tb = (wave + sl) & 3;
+        const int tb = (wave + sl) % NT;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             xr[(16 * tb + 4 * r) * LD] = S.re[sl][r];
@@ -764,10 +764,10 @@ __device__ __forceinline__ void rot_store_slots(double *Xre, double *Xim, const 
 }
 // (signed) conjugate transpose of the slot-1 tile (row block w+1, column block w) into plane position
 // (row block w, column block w+1); sgn = +1 Hermitian, -1 skew-Hermitian
-template <int LD>
+template <int LD, int NT = 4>
 __device__ __forceinline__ void rot_store_adjoint(double *Xre, double *Xim, const d4 &tre, const d4 &tim, int wave,
                                                   int lane, double sgn) {
-    const int tb = (wave + 1) & 3, c = lane & 15, rg = lane >> 4;
+    const int tb = (wave + 1) % NT, c = lane & 15, rg = lane >> 4;
     double *xr = Xre + (16 * wave + c) * LD + 16 * tb + rg;
     double *xi = Xim + (16 * wave + c) * LD + 16 * tb + rg;
 #pragma unroll
@@ -776,34 +776,36 @@ __device__ __forceinline__ void rot_store_adjoint(double *Xre, double *Xim, cons
         xi[4 * r] = -sgn * tim[r];
     }
 }
-template <int LD>
-__device__ __forceinline__ void rot_load_slot3(const double *Xre, const double *Xim, Strip<4> &S, int wave, int lane) {
-    const int tb = (wave + 3) & 3;
+template <int LD, int NT = 4>
+__device__ __forceinline__ void rot_load_slot3(const double *Xre, const double *Xim, Strip<NT> &S, int wave, int lane) {
+    const int tb = (wave + NT - 1) % NT;
     const double *xr = Xre + ((lane >> 4) + 16 * tb) * LD + 16 * wave + (lane & 15);
     const double *xi = Xim + ((lane >> 4) + 16 * tb) * LD + 16 * wave + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        S.re[3][r] = xr[4 * r * LD];
-        S.im[3][r] = xi[4 * r * LD];
+        S.re[NT - 1][r] = xr[4 * r * LD];
+        S.im[NT - 1][r] = xi[4 * r * LD];
     }
 }
 // exchange through a small area (4 waves x 2 planes x 256 doubles) when no plane is free: the writer stores
 // its slot-1 tile in the reader's register layout, [lane'][r'] with lane' = 16 (c & 3) + 4r + rg, r' = c >> 2
+template <int NT = 4>
 __device__ __forceinline__ void rot_exch_write(double *area, const d4 &tre, const d4 &tim, int wave, int lane, double sgn) {
     const int c = lane & 15, rg = lane >> 4;
-    double *dst = area + ((wave + 1) & 3) * 512 + (16 * (c & 3) + rg) * 4 + (c >> 2);
+    double *dst = area + ((wave + 1) % NT) * 512 + (16 * (c & 3) + rg) * 4 + (c >> 2);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         dst[16 * r] = sgn * tre[r];          // lane' advances by 4 per r: (4r) * 4 doubles
         dst[256 + 16 * r] = -sgn * tim[r];
     }
 }
-__device__ __forceinline__ void rot_exch_read(const double *area, Strip<4> &S, int wave, int lane) {
+template <int NT = 4>
+__device__ __forceinline__ void rot_exch_read(const double *area, Strip<NT> &S, int wave, int lane) {
     const double *src = area + wave * 512 + lane * 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        S.re[3][r] = src[r];
-        S.im[3][r] = src[256 + r];
+        S.re[NT - 1][r] = src[r];
+        S.im[NT - 1][r] = src[256 + r];
     }
 }
 
@@ -813,14 +815,14 @@ __device__ __forceinline__ void rot_exch_read(const double *area, Strip<4> &S, i
 // per k-step; the operand sums are one VALU add each against 64-cycle MFMAs.  Software pipeline as in gemm_xb: the
 // real-plane operands of k-step ks+1 are requested once the P1 MFMAs have issued, the imaginary-plane operands
 // after the P2 MFMAs, so that every LDS read has at least NS MFMAs to land before the next operand sum needs it.
-template <int LD, int NS>
-__device__ __forceinline__ void gemm_rot(Strip<4> &acc, const double *__restrict__ Xre, const double *__restrict__ Xim,
-                                         const Strip<4> &B, int wave, int lane) {
+template <int LD, int NS, int NT = 4>
+__device__ __forceinline__ void gemm_rot(Strip<NT> &acc, const double *__restrict__ Xre, const double *__restrict__ Xim,
+                                         const Strip<NT> &B, int wave, int lane) {
     const double *__restrict__ xr = Xre + (lane & 15) * LD + (lane >> 4);
     const double *__restrict__ xi = Xim + (lane & 15) * LD + (lane >> 4);
     int rowoff[NS];
 #pragma unroll
-    for (int so = 0; so < NS; ++so) rowoff[so] = 16 * ((wave + so) & 3) * LD;
+    for (int so = 0; so < NS; ++so) rowoff[so] = 16 * ((wave + so) % NT) * LD;
     double are[NS], aim[NS];
     {
         const int k0 = 16 * wave;
@@ -831,11 +833,11 @@ __device__ __forceinline__ void gemm_rot(Strip<4> &acc, const double *__restrict
 #pragma unroll
     for (int so = 0; so < NS; ++so) { p1[so] = (d4){0., 0., 0., 0.}; p2[so] = (d4){0., 0., 0., 0.}; p3[so] = (d4){0., 0., 0., 0.}; }
 #pragma unroll
-    for (int sk = 0; sk < 4; ++sk) {
+    for (int sk = 0; sk < NT; ++sk) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int kn = (r < 3) ? 16 * ((wave + sk) & 3) + 4 * (r + 1) : 16 * ((wave + sk + 1) & 3);   // next k column
-            const bool more = !(sk == 3 && r == 3);
+            const int kn = (r < 3) ? 16 * ((wave + sk) % NT) + 4 * (r + 1) : 16 * ((wave + sk + 1) % NT);   // next k column
+            const bool more = !(sk == NT - 1 && r == 3);
             const double bre = B.re[sk][r], bim = B.im[sk][r];
             const double bs = bre + bim;
             double as[NS];
@@ -871,16 +873,16 @@ __device__ __forceinline__ void gemm_rot(Strip<4> &acc, const double *__restrict
 
 // rotated version of gemm_dual13: T[0..2] += X (b13 A6 + b11 A4 + b9 A2),  V[0..2] += X (b12 A6 + b10 A4 + b8 A2),
 // both by the 3M scheme (see gemm_rot): 18 instead of 24 MFMAs per k-step, the operand sums of X are shared.
-template <int LD>
-__device__ __forceinline__ void gemm_dual13_rot(Strip<4> &T, Strip<4> &V, const double *__restrict__ Xre,
-                                                const double *__restrict__ Xim, const Strip<4> &A2, const Strip<4> &A4,
-                                                const Strip<4> &A6, int wave, int lane) {
-    constexpr int NS = 3;
+template <int LD, int NT = 4>
+__device__ __forceinline__ void gemm_dual13_rot(Strip<NT> &T, Strip<NT> &V, const double *__restrict__ Xre,
+                                                const double *__restrict__ Xim, const Strip<NT> &A2, const Strip<NT> &A4,
+                                                const Strip<NT> &A6, int wave, int lane) {
+    constexpr int NS = NT - 1;
     const double *__restrict__ xr = Xre + (lane & 15) * LD + (lane >> 4);
     const double *__restrict__ xi = Xim + (lane & 15) * LD + (lane >> 4);
     int rowoff[NS];
 #pragma unroll
-    for (int so = 0; so < NS; ++so) rowoff[so] = 16 * ((wave + so) & 3) * LD;
+    for (int so = 0; so < NS; ++so) rowoff[so] = 16 * ((wave + so) % NT) * LD;
     d4 t1[NS], t2[NS], t3[NS], v1[NS], v2[NS], v3[NS];
 #pragma unroll
     for (int so = 0; so < NS; ++so) {
@@ -888,10 +890,10 @@ __device__ __forceinline__ void gemm_dual13_rot(Strip<4> &T, Strip<4> &V, const 
         v1[so] = (d4){0., 0., 0., 0.}; v2[so] = (d4){0., 0., 0., 0.}; v3[so] = (d4){0., 0., 0., 0.};
     }
 #pragma unroll
-    for (int sk = 0; sk < 4; ++sk) {
+    for (int sk = 0; sk < NT; ++sk) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int kc = 16 * ((wave + sk) & 3) + 4 * r;
+            const int kc = 16 * ((wave + sk) % NT) + 4 * r;
             const double wr = B13_13 * A6.re[sk][r] + B13_11 * A4.re[sk][r] + B13_9 * A2.re[sk][r];
             const double wi = B13_13 * A6.im[sk][r] + B13_11 * A4.im[sk][r] + B13_9 * A2.im[sk][r];
             const double zr = B13_12 * A6.re[sk][r] + B13_10 * A4.re[sk][r] + B13_8 * A2.re[sk][r];
@@ -1035,13 +1037,13 @@ __device__ __forceinline__ void expm_form_a(const ExpmArgs &a, const int cell, d
     }
 }
 
-// Hermitian generators, NP = 64: A = -i dt H is skew-Hermitian, so only the 10 tiles (16 x 16) on and above the block
-// diagonal are fetched (1280 instead of 2048 element pairs per plane and operator: the routine is bound by what a CU
-// can pull from L2 per cell) and every off-diagonal tile is written twice, a_ji = -conj(a_ij).
-template <int NTH = 256>   // threads that take part (t = 0..NTH-1): the whole workgroup, or the three waves that
-                           // wait for the first tile inversion of the previous cell (persistent kernel)
+// Hermitian generators: A = -i dt H is skew-Hermitian, so only the NT (NT + 1) / 2 tiles (16 x 16) on and above the block
+// diagonal are fetched (10 of 16 at NP = 64: the routine is bound by what a CU can pull from L2 per cell) and every
+// off-diagonal tile is written twice, a_ji = -conj(a_ij).
+template <int NTH = 256, int NT = 4>   // NTH threads take part (t = 0..NTH-1): the whole workgroup, or the waves that wait
+                                       // for the first tile inversion of the previous cell (persistent kernel)
 __device__ __forceinline__ void expm_form_a_herm64(const ExpmArgs &a, const int cell, double *smem, const int t) {
-    using LY = ExpmLds<4>;
+    using LY = ExpmLds<NT>;
     constexpr int NP = LY::NP, LD = LY::LD;
     double *Are = smem, *Aim = Are + NP * LD;
     const int kc = cell / a.N_T, n = cell - kc * a.N_T;
@@ -1055,15 +1057,20 @@ __device__ __forceinline__ void expm_form_a_herm64(const ExpmArgs &a, const int 
         e[l] = a.eps[(size_t)l * a.N_T + n];
         if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
     }
-    // 10 tiles x 128 element pairs = 1280 = 5 per thread (256 threads); tile q -> (ti, tj), ti <= tj, row by row
-    constexpr int NU = (1280 + NTH - 1) / NTH;
+    // NTILE tiles x 128 element pairs (1280 = 5 per thread at NP = 64 with 256 threads); tile q -> (ti, tj), ti <= tj,
+    // row by row
+    constexpr int NTILE = NT * (NT + 1) / 2, NPAIR = 128 * NTILE;
+    constexpr int NU = (NPAIR + NTH - 1) / NTH;
     int off[NU], ii[NU], jj[NU];
     bool diag[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int ep = min(t + u * NTH, 1279), q = ep >> 7, idx = ep & 127;   // (surplus threads repeat the last pair)
-        const int ti = q < 4 ? 0 : (q < 7 ? 1 : (q < 9 ? 2 : 3));
-        const int tj = q < 4 ? q : (q < 7 ? q - 3 : (q < 9 ? q - 5 : 3));
+        const int ep = min(t + u * NTH, NPAIR - 1), q = ep >> 7, idx = ep & 127;   // (surplus threads repeat the last pair)
+        int ti = 0, r = q;
+#pragma unroll
+        for (int it = 0; it < NT - 1; ++it)
+            if (r >= NT - ti) { r -= NT - ti; ++ti; }
+        const int tj = ti + r;
         ii[u] = 16 * ti + (idx >> 3);
         jj[u] = 16 * tj + 2 * (idx & 7);
         off[u] = (ii[u] * NP + jj[u]) >> 1;
@@ -1146,41 +1153,41 @@ __device__ __forceinline__ void expm_norm_combine(double *smem, const int tid, c
 
 // Order-13 numerator / denominator for a skew-Hermitian A (see the rotated-strip helpers): returns P = V+U and
 // Q = V-U as NATURAL strips.  regA holds A, regX is the staging plane pair, exch the small exchange area.
-template <int LD>
+template <int LD, int NT = 4>
 __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, double *exch, const int wave,
-                                                 const int lane, Strip<4> &Pn, Strip<4> &Qn) {
-    constexpr int NP = 64;
+                                                 const int lane, Strip<NT> &Pn, Strip<NT> &Qn) {
+    constexpr int NP = 16 * NT, NS = NT - 1;   // NS slots are computed, slot NT - 1 is the mirrored tile
     double *Are = regA, *Aim = regA + NP * LD, *Xre = regX, *Xim = regX + NP * LD;
-    Strip<4> A2, A4, A6;
+    Strip<NT> A2, A4, A6;
     {
-        Strip<4> As;
-        rot_load_strip<LD>(Are, Aim, As, wave, lane);
+        Strip<NT> As;
+        rot_load_strip<LD, NT>(Are, Aim, As, wave, lane);
         strip_zero(A2);
-        gemm_rot<LD, 3>(A2, Are, Aim, As, wave, lane);                 // A2 = A*A (slots 0..2)
+        gemm_rot<LD, NS, NT>(A2, Are, Aim, As, wave, lane);                 // A2 = A*A (slots 0..2)
     }
     STAMP(13);
-    rot_store_slots<LD, 3>(Xre, Xim, A2, wave, lane);                  // X = A2, with the mirrored tiles
-    rot_store_adjoint<LD>(Xre, Xim, A2.re[1], A2.im[1], wave, lane, 1.0);
+    rot_store_slots<LD, NS, NT>(Xre, Xim, A2, wave, lane);                  // X = A2, with the mirrored tiles
+    rot_store_adjoint<LD, NT>(Xre, Xim, A2.re[1], A2.im[1], wave, lane, 1.0);
     __syncthreads();
-    rot_load_slot3<LD>(Xre, Xim, A2, wave, lane);
+    rot_load_slot3<LD, NT>(Xre, Xim, A2, wave, lane);
     strip_zero(A4);
-    gemm_rot<LD, 3>(A4, Xre, Xim, A2, wave, lane);                     // A4 = A2*A2
-    rot_exch_write(exch, A4.re[1], A4.im[1], wave, lane, 1.0);
+    gemm_rot<LD, NS, NT>(A4, Xre, Xim, A2, wave, lane);                     // A4 = A2*A2
+    rot_exch_write<NT>(exch, A4.re[1], A4.im[1], wave, lane, 1.0);
     __syncthreads();
-    rot_exch_read(exch, A4, wave, lane);
+    rot_exch_read<NT>(exch, A4, wave, lane);
     strip_zero(A6);
-    gemm_rot<LD, 3>(A6, Xre, Xim, A4, wave, lane);                     // A6 = A2*A4
+    gemm_rot<LD, NS, NT>(A6, Xre, Xim, A4, wave, lane);                     // A6 = A2*A4
     STAMP(14);
     __syncthreads();                                                   // everybody is done reading X = A2
-    rot_store_slots<LD, 3>(Xre, Xim, A6, wave, lane);                  // X = A6
-    rot_store_adjoint<LD>(Xre, Xim, A6.re[1], A6.im[1], wave, lane, 1.0);
+    rot_store_slots<LD, NS, NT>(Xre, Xim, A6, wave, lane);                  // X = A6
+    rot_store_adjoint<LD, NT>(Xre, Xim, A6.re[1], A6.im[1], wave, lane, 1.0);
     __syncthreads();
-    rot_load_slot3<LD>(Xre, Xim, A6, wave, lane);
+    rot_load_slot3<LD, NT>(Xre, Xim, A6, wave, lane);
     // T = A6*(b13 A6 + b11 A4 + b9 A2) + b7 A6 + b5 A4 + b3 A2 + b1 I      (U = A*T)
     // V = A6*(b12 A6 + b10 A4 + b8 A2) + b6 A6 + b4 A4 + b2 A2 + b0 I
-    Strip<4> T, V;
+    Strip<NT> T, V;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NS; ++t) {
         T.re[t] = B13_7 * A6.re[t] + B13_5 * A4.re[t] + B13_3 * A2.re[t];
         T.im[t] = B13_7 * A6.im[t] + B13_5 * A4.im[t] + B13_3 * A2.im[t];
         V.re[t] = B13_6 * A6.re[t] + B13_4 * A4.re[t] + B13_2 * A2.re[t];
@@ -1193,35 +1200,35 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
             if (4 * r + rg == c) { T.re[0][r] += B13_1; V.re[0][r] += B13_0; }
     }
     STAMP(15);
-    gemm_dual13_rot<LD>(T, V, Xre, Xim, A2, A4, A6, wave, lane);
+    gemm_dual13_rot<LD, NT>(T, V, Xre, Xim, A2, A4, A6, wave, lane);
     STAMP(16);
     __syncthreads();                                                   // everybody is done reading X = A6
-    rot_exch_write(exch, T.re[1], T.im[1], wave, lane, 1.0);          // T's mirrored tiles through the exchange area
+    rot_exch_write<NT>(exch, T.re[1], T.im[1], wave, lane, 1.0);          // T's mirrored tiles through the exchange area
     __syncthreads();
-    rot_exch_read(exch, T, wave, lane);
-    Strip<4> Uo;
+    rot_exch_read<NT>(exch, T, wave, lane);
+    Strip<NT> Uo;
     strip_zero(Uo);
-    gemm_rot<LD, 3>(Uo, Are, Aim, T, wave, lane);                      // U = A*T, skew-Hermitian (slots 0..2)
+    gemm_rot<LD, NS, NT>(Uo, Are, Aim, T, wave, lane);                      // U = A*T, skew-Hermitian (slots 0..2)
     STAMP(17);
     __syncthreads();                                                   // A is dead, the X planes are free
     // P = V + U -> X planes, Q = V - U -> A planes (natural positions).  V is Hermitian and U skew-Hermitian, so
     // P = Q^dagger: the tile each wave did not compute, (w-1, w), is the conjugate transpose of the OTHER matrix's
     // tile (w, w-1), which is slot 1 of wave w-1 -- neither V nor U needs its own mirror exchange.
     {
-        Strip<4> Pr, Qr;
+        Strip<NT> Pr, Qr;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NS; ++t) {
             Pr.re[t] = V.re[t] + Uo.re[t]; Pr.im[t] = V.im[t] + Uo.im[t];
             Qr.re[t] = V.re[t] - Uo.re[t]; Qr.im[t] = V.im[t] - Uo.im[t];
         }
-        rot_store_slots<LD, 3>(Xre, Xim, Pr, wave, lane);
-        rot_store_slots<LD, 3>(Are, Aim, Qr, wave, lane);
-        rot_store_adjoint<LD>(Xre, Xim, Qr.re[1], Qr.im[1], wave, lane, 1.0);   // P(w, w+1) = Q(w+1, w)^dagger
-        rot_store_adjoint<LD>(Are, Aim, Pr.re[1], Pr.im[1], wave, lane, 1.0);   // Q(w, w+1) = P(w+1, w)^dagger
+        rot_store_slots<LD, NS, NT>(Xre, Xim, Pr, wave, lane);
+        rot_store_slots<LD, NS, NT>(Are, Aim, Qr, wave, lane);
+        rot_store_adjoint<LD, NT>(Xre, Xim, Qr.re[1], Qr.im[1], wave, lane, 1.0);   // P(w, w+1) = Q(w+1, w)^dagger
+        rot_store_adjoint<LD, NT>(Are, Aim, Pr.re[1], Pr.im[1], wave, lane, 1.0);   // Q(w, w+1) = P(w+1, w)^dagger
     }
     __syncthreads();
-    strip_load_lds<4, LD>(Xre, Xim, Pn, wave, lane);
-    strip_load_lds<4, LD>(Are, Aim, Qn, wave, lane);
+    strip_load_lds<NT, LD>(Xre, Xim, Pn, wave, lane);
+    strip_load_lds<NT, LD>(Are, Aim, Qn, wave, lane);
 }
 
 // Polynomial phase of one cell: Pade order / squaring count from ||A||_1 (in red[NTH]; A = -i dt H in LDS)
@@ -1269,8 +1276,8 @@ __device__ __forceinline__ void expm_poly(const ExpmArgs &a, const int wave, con
 #endif
         order = 13;
         inv_b0sq = 1.0 / (B13_0 * B13_0);
-        if constexpr (HERM && NT == 4) {
-            expm_poly13_herm<LD>(smem, smem + LY::REG, smem + 2 * LY::REG, wave, lane, Pn, Qn);
+        if constexpr (HERM && NT >= 3) {
+            expm_poly13_herm<LD, NT>(smem, smem + LY::REG, smem + 2 * LY::REG, wave, lane, Pn, Qn);
         } else {
         Strip<NT> A2, A4, A6;
         {
@@ -1482,7 +1489,7 @@ __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, c
         // order 13 without squaring and the norm of the cell is not needed (a cell whose true norm is below 2.1 then
         // gets order 13 instead of Julia's 9: same result to rounding); every other case measures the norm
         const double bound = expm_norm_bound(a, cell);
-        if constexpr (HERM && NT == 4) expm_form_a_herm64(a, cell, smem, tid);
+        if constexpr (HERM && NT >= 3) expm_form_a_herm64<64 * NT, NT>(a, cell, smem, tid);
         else expm_form_a<NT>(a, cell, smem, tid, LYY::NTH, 0, LYY::NP * LYY::NP / 2);
         if (bound > 2.1 && bound <= 5.4) {
             if (tid == 0) (smem + 2 * LYY::REG + LYY::DV)[LYY::NTH] = bound;
@@ -1530,7 +1537,7 @@ struct ExpmPrefetchHook {
         using LY = ExpmLds<NT>;
         if (next_cell < 0) return;
         const int t = tid - 64;   // waves 1..NT-1
-        if constexpr (HERM && NT == 4) expm_form_a_herm64<192>(a, next_cell, smem, t);
+        if constexpr (HERM && NT >= 3) expm_form_a_herm64<64 * (NT - 1), NT>(a, next_cell, smem, t);
         else expm_form_a<NT>(a, next_cell, smem, t, LY::NTH - 64, 0, LY::NP * LY::NP / 2);
         if (t == 0) {
             double *red = smem + 2 * LY::REG + LY::DV;
@@ -1567,7 +1574,7 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
         STAMP(0);
         if (!have_a) {
             const double bound = expm_norm_bound(a, cell);
-            if constexpr (HERM && NT == 4) expm_form_a_herm64<256>(a, cell, smem, tid);
+            if constexpr (HERM && NT >= 3) expm_form_a_herm64<64 * NT, NT>(a, cell, smem, tid);
             else expm_form_a<NT>(a, cell, smem, tid, LY::NTH, 0, LY::NP * LY::NP / 2);
             measure = !(bound > 2.1 && bound <= 5.4);
             if (!measure && tid == 0) red[LY::NTH] = bound;
