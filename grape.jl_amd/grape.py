@@ -463,7 +463,28 @@ def optimize(trajectories, tlist, backend=None, **kwargs):
     """``GRAPE.optimize(trajectories, tlist; kwargs...)`` -- src/optimize.jl:73-144."""
     from scipy.optimize import minimize
 
-    callback = kwargs.get("callback", lambda *a: None)
+    # callbacks: one callable or a tuple of them, called in order after every iteration; what they return (tuples) is
+    # concatenated into one record.  `print_iters` / `print_iter_info` / `store_iter_info` append the iteration table as
+    # the last callback, as QuantumControl.optimize does around GRAPE.optimize (set-up of `callback`, src/optimize.jl:92-103;
+    # test/test_iterations.jl:43-150).  (A callback that modifies wrk.pulsevals does not feed back into scipy's
+    # L-BFGS-B iterate -- LBFGSB.jl works on wrk.pulsevals itself, test_iterations.jl:128-148.)
+    cbs = kwargs.get("callback", ())
+    cbs = tuple(cbs) if isinstance(cbs, (tuple, list)) else (cbs,)
+    if kwargs.get("print_iters", False) or "print_iter_info" in kwargs or "store_iter_info" in kwargs:
+        info_print = kwargs.get("print_iter_info", ("iter.", "J_T", "ǁ∇Jǁ", "ǁΔϵǁ", "ΔJ", "FG(F)", "secs"))
+        if not kwargs.get("print_iters", True):
+            info_print = ()
+        cbs = cbs + (make_grape_print_iters(print_iter_info=info_print, store_iter_info=kwargs.get("store_iter_info", ()),
+                                            out=kwargs.get("print_iters_out")),)
+
+    def callback(wrk_, it):
+        rec = ()
+        for cb in cbs:
+            r = cb(wrk_, it)
+            if r is not None:
+                rec = rec + (tuple(r) if isinstance(r, (tuple, list)) else (r,))
+        return rec or None
+
     check_convergence = kwargs.get("check_convergence", lambda res: res)
     wrk = GrapeWrk(trajectories, tlist, backend=backend, **kwargs)
     G = np.zeros_like(wrk.pulsevals)

@@ -245,3 +245,30 @@ def test_nonlinear_amplitude_chain_rule_and_optimization():
     assert res.converged and res.J_T < 1e-3
     phys = A * np.tanh(np.asarray(res.optimized_controls[0]) / A)
     assert np.abs(phys).max() < A
+
+
+def test_pulse_optimization_does_not_mutate_the_guess_and_convergence_checks():
+    """/root/reference/test/test_pulse_optimization.jl:14-48 (the guess pulse array handed in as control is neither
+    replaced nor modified, optimized_controls live on tlist) and test_convergence_checks.jl:15-60 (a string from
+    check_convergence becomes the message; iter_stop ends with the reference's message) through the HIP backend."""
+    from grape_jl_amd import grape as G
+    trajs0, tlist = _dummy_problem(n_controls=1, N=10, nt=51)
+    gen = trajs0[0].generator
+    guess = G.discretize_on_midpoints(gen.controls[0], tlist)                   # pulses_as_controls = true
+    H = G.hamiltonian(gen.drift, (gen.ops[0], guess))
+    trajs = [G.Trajectory(trajs0[0].initial_state, H, target_state=trajs0[0].target_state)]
+    assert trajs[0].generator.controls[0] is guess and len(guess) == len(tlist) - 1
+    guess_copy = guess.copy()
+    res = G.optimize(trajs, tlist, J_T=G.J_T_re, iter_stop=2)
+    assert not res.message.startswith("Exception"), res.message
+    assert len(res.optimized_controls[0]) == len(tlist)
+    assert trajs[0].generator.controls[0] is guess and np.array_equal(guess, guess_copy)
+    opt_pulse = G.discretize_on_midpoints(res.optimized_controls[0], tlist)
+    assert np.linalg.norm(guess - opt_pulse) > 1e-3
+    res = G.optimize(trajs, tlist, J_T=G.J_T_ss, iter_stop=100,
+                     check_convergence=lambda r: "J_T < 0.5" if r.J_T < 0.5 else "",
+                     store_iter_info=("iter.", "J_T"), print_iters=False)
+    assert res.converged and res.message == "J_T < 0.5" and res.iter_start == 0 and res.iter_stop == 100
+    assert res.records[-1][0] == res.iter and abs(res.records[-1][1] - res.J_T) < 1e-15
+    res = G.optimize(trajs, tlist, J_T=G.J_T_ss, iter_stop=2, check_convergence=lambda r: "never" if r.J_T < -1 else "")
+    assert res.converged and res.iter == 2 and res.message == "Reached maximum number of iterations"

@@ -140,3 +140,31 @@ def test_iteration_table_mirrors_the_reference_format():
     assert re.fullmatch(r"-?\d\.\d\de[+-]\d\d", lines[2].split()[1])
     with pytest.raises(ValueError):
         G.make_grape_print_iters(print_iter_info=("iter.", "∠°"))
+
+
+def test_iter_start_stop_and_callback_chain():
+    # /root/reference/test/test_iterations.jl:18-41 (records of iterations [0, 11, 12] with iter_start = 10) and :43-125
+    # (a tuple of callbacks is called in order, their return values are concatenated with the stored table fields)
+    import io
+    trajs, tl, be = tls(lambda t: 0.2, nt=31)
+    buf = io.StringIO()
+    res = G.optimize(trajs, tl, backend=be, J_T=G.J_T_ss, iter_start=10, iter_stop=12, store_iter_info=("iter.", "J_T"),
+                     print_iters_out=buf)
+    assert res.converged and res.iter_start == 10 and res.iter_stop == 12
+    assert [r[0] for r in res.records] == [0, 11, 12]
+    assert buf.getvalue().splitlines()[0].split()[0] == "iter."
+    calls = []
+
+    def cb1(wrk, it, *a):
+        calls.append(("cb1", it))
+
+    def cb2(wrk, it, *a):
+        calls.append(("cb2", it))
+        return ("cb2", it)
+    res = G.optimize(trajs, tl, backend=be, J_T=G.J_T_ss, iter_stop=1, callback=(cb1, cb2))
+    assert res.converged and calls == [("cb1", 0), ("cb2", 0), ("cb1", 1), ("cb2", 1)]
+    assert res.records == [("cb2", 0), ("cb2", 1)]
+    res = G.optimize(trajs, tl, backend=be, J_T=G.J_T_ss, iter_stop=1, callback=(cb1, cb2), store_iter_info=("J_T",),
+                     print_iters=False)
+    assert len(res.records) == 2 and len(res.records[0]) == 3 and res.records[0][:2] == ("cb2", 0)
+    assert isinstance(res.records[0][2], float)
