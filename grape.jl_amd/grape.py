@@ -263,6 +263,19 @@ class GrapeWrk:
                                 arr[l::L] = opt[key]
                             else:
                                 arr[l * N_T:(l + 1) * N_T] = opt[key]
+        prev = self.kwargs.get("continue_from")
+        if prev is not None:
+            # src/workspace.jl:167-186: continue a previous optimization -- its result object is reused (counters and
+            # records kept), the pulses are re-discretised from its optimized controls
+            self.result = prev
+            prev.iter_stop = self.kwargs.get("iter_stop", 5000)
+            prev.converged = False
+            prev.message = "in progress"
+            self.pulsevals = np.concatenate([discretize_on_midpoints(c, prev.tlist) for c in prev.optimized_controls])
+            self.pulsevals_guess = self.pulsevals.copy()
+            prev.start_local_time = prev.end_local_time = time.time()
+            self.backend = backend if backend is not None else self._make_hip_backend()
+            return
         self.result = GrapeResult(tlist=self.tlist.copy(), iter_start=self.kwargs.get("iter_start", 0),
                                   iter_stop=self.kwargs.get("iter_stop", 5000))
         self.result.iter = self.result.iter_start

@@ -168,3 +168,19 @@ def test_iter_start_stop_and_callback_chain():
                      print_iters=False)
     assert len(res.records) == 2 and len(res.records[0]) == 3 and res.records[0][:2] == ("cb2", 0)
     assert isinstance(res.records[0][2], float)
+
+
+def test_continue_from_previous_result():
+    # src/workspace.jl:167-186 (test/test_tls_optimization.jl:417-480 continues across methods; here GRAPE -> GRAPE):
+    # the result object is reused, iterations keep counting, the first J_T of the continuation is the last of the first run
+    trajs, tl, be = tls(lambda t: 0.2, nt=51)
+    r1 = G.optimize(trajs, tl, backend=be, J_T=G.J_T_sm, iter_stop=2, store_iter_info=("iter.", "J_T"), print_iters=False)
+    J_mid, n_rec = r1.J_T, len(r1.records)
+    assert r1.iter == 2 and r1.message == "Reached maximum number of iterations"
+    r2 = G.optimize(trajs, tl, backend=be, J_T=G.J_T_sm, iter_stop=5, continue_from=r1, store_iter_info=("iter.", "J_T"),
+                    print_iters=False)
+    assert r2 is r1 and r2.iter == 5 and r2.iter_stop == 5 and r2.J_T < J_mid
+    # iteration 0 of the continuation re-evaluates the pulses re-discretised from the optimized controls (on tlist):
+    # intervals -> points -> midpoints is not the identity, so J_T is close to, not equal to, the last value
+    assert abs(r2.records[n_rec][1] - J_mid) < 0.05 * J_mid and r2.records[n_rec][0] == 0
+    assert [r[0] for r in r2.records[n_rec + 1:]] == [3, 4, 5]
