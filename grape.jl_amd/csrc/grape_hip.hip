@@ -1126,6 +1126,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         for (int j = 0; j < 7; ++j) fprintf(stderr, "  stamp %-24s %9.0f cycles\n", pn[j], avg(11 + j, j ? 10 + j : 0));
         fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "P,Q + first inversion", avg(5, 17));
         for (int j = 0; j < 4; ++j) fprintf(stderr, "  stamp solve step %d             %9.0f cycles\n", j, avg(6 + j, 5 + j));
+        for (int j = 0; j < 3; ++j)
+            fprintf(stderr, "  stamp   step %d, waves done after %6.0f %6.0f %6.0f %6.0f cycles\n", j, avg(18 + 4 * j, 5 + j),
+                    avg(19 + 4 * j, 5 + j), avg(20 + 4 * j, 5 + j), avg(21 + 4 * j, 5 + j));
         fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "squarings + store U", avg(4, 3));
         fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "TOTAL per cell", avg(4, 0));
     }

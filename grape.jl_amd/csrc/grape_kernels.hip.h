@@ -434,6 +434,12 @@ __device__ unsigned long long *g_diag_slot_base = nullptr;
 #else
 #define STAMP(i) do {} while (0)
 #endif
+// per-wave stamp (diagnostic builds): when a wave has finished its work of a solve step
+#ifdef GRAPE_DIAG
+#define WSTAMP(i) do { if ((threadIdx.x & 63) == 0 && g_diag_slot_base) g_diag_slot_base[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#endif
 #define GJSTAMP(i) STAMP(i)
 template <int NT>
 struct GjLds {
@@ -537,7 +543,7 @@ __device__ __forceinline__ void gj_update(Strip<NT> &S, int jb, const double *pa
             pre[c][tr] = par[16 * tr * PLD + 4 * c];
             pim[c][tr] = pai[16 * tr * PLD + 4 * c];
         }
-    // both products by the 3M scheme (see gemm_xb): 12 + 9 (NT - 1) instead of 16 + 12 (NT - 1) MFMAs
+    // both products by the 3M scheme (see gemm_xb): 12 + 12 (NT - 1) instead of 16 + 16 (NT - 1) MFMAs
     d4 yr = {0., 0., 0., 0.}, yi = {0., 0., 0., 0.};
     {
         d4 y1 = {0., 0., 0., 0.}, y2 = {0., 0., 0., 0.}, y3 = {0., 0., 0., 0.};
@@ -579,6 +585,86 @@ __device__ __forceinline__ void gj_update(Strip<NT> &S, int jb, const double *pa
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         if (t == jb) { S.re[t] = yr; S.im[t] = yi; }
+}
+
+// the Q- and the P-strip update of one block step in one pass: both strips multiply the same panel and the same
+// inverse, so the A operands (LDS loads, the 3M sums) are formed once, and the two sets of accumulation chains
+// interleave.  Every chain has the operation order of gj_update: the results are bit-identical.
+template <int NT>
+__device__ __forceinline__ void gj_update2(Strip<NT> &S, Strip<NT> &T, int jb, const double *pan, const double *dv, int lane) {
+    constexpr int NP = 16 * NT, PLD = 18;
+    const int ai = lane & 15, ak = lane >> 4;
+    const double *par = pan + ai * PLD + ak, *pai = pan + NP * PLD + ai * PLD + ak;
+    double dvr[4], dvi[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dvr[c] = dv[c * 64 + lane];
+        dvi[c] = dv[256 + c * 64 + lane];
+    }
+    double pre[4][NT], pim[4][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr) {
+            if (tr == jb) continue;
+            pre[c][tr] = par[16 * tr * PLD + 4 * c];
+            pim[c][tr] = pai[16 * tr * PLD + 4 * c];
+        }
+    d4 sr, si, tr_, ti_;
+    {
+        d4 y1 = {0., 0., 0., 0.}, y2 = {0., 0., 0., 0.}, y3 = {0., 0., 0., 0.};
+        d4 z1 = {0., 0., 0., 0.}, z2 = {0., 0., 0., 0.}, z3 = {0., 0., 0., 0.};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t != jb) continue;   // jb is a compile-time constant after unrolling
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double are = dvr[c], aim = dvi[c], as = dvr[c] + dvi[c];
+                y1 = MFMA64(are, S.re[t][c], y1);
+                z1 = MFMA64(are, T.re[t][c], z1);
+                y2 = MFMA64(aim, S.im[t][c], y2);
+                z2 = MFMA64(aim, T.im[t][c], z2);
+                y3 = MFMA64(as, S.re[t][c] + S.im[t][c], y3);
+                z3 = MFMA64(as, T.re[t][c] + T.im[t][c], z3);
+            }
+        }
+        sr = y1 - y2;
+        si = y3 - y1 - y2;
+        tr_ = z1 - z2;
+        ti_ = z3 - z1 - z2;
+    }
+    d4 q1[NT], q2[NT], q3[NT], r1[NT], r2[NT], r3[NT];
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr) {
+        q1[tr] = (d4){0., 0., 0., 0.}; q2[tr] = (d4){0., 0., 0., 0.}; q3[tr] = (d4){0., 0., 0., 0.};
+        r1[tr] = (d4){0., 0., 0., 0.}; r2[tr] = (d4){0., 0., 0., 0.}; r3[tr] = (d4){0., 0., 0., 0.};
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double bs = sr[c] + si[c], bt = tr_[c] + ti_[c];
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr) {
+            if (tr == jb) continue;
+            const double are = pre[c][tr], aim = pim[c][tr], as = are + aim;
+            q1[tr] = MFMA64(are, sr[c], q1[tr]);
+            r1[tr] = MFMA64(are, tr_[c], r1[tr]);
+            q2[tr] = MFMA64(aim, si[c], q2[tr]);
+            r2[tr] = MFMA64(aim, ti_[c], r2[tr]);
+            q3[tr] = MFMA64(as, bs, q3[tr]);
+            r3[tr] = MFMA64(as, bt, r3[tr]);
+        }
+    }
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr) {
+        if (tr == jb) continue;
+        S.re[tr] -= q1[tr] - q2[tr];
+        S.im[tr] -= q3[tr] - q1[tr] - q2[tr];
+        T.re[tr] -= r1[tr] - r2[tr];
+        T.im[tr] -= r3[tr] - r1[tr] - r2[tr];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t == jb) { S.re[t] = sr; S.im[t] = si; T.re[t] = tr_; T.im[t] = ti_; }
 }
 
 struct GjNoHook {
@@ -630,6 +716,162 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
         hook(jb);
         __syncthreads();
         STAMP(6 + jb);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// LOOK-AHEAD SCHEDULE of the block Gauss-Jordan solve (NT = 4, one barrier per block step, no flags).
+// What bounds the split schedule above is the chain  owner's strip update -> barrier -> tile inversion -> barrier
+// (12.7 K cycles per step, of which a wave issues MFMAs for 5-10 K).  The next diagonal tile,
+//     D'_{jb+1} = Q[jb+1][jb+1] - Panel_jb[jb+1] (Dinv_jb Q[jb][jb+1]),
+// only needs two tiles of strip jb+1 as they stand BEFORE step jb, the panel and the inverse of step jb: all of it is
+// published before the barrier that starts the step (the owner of strip jb+1 stores its two tiles one step ahead, 16 LDS
+// stores).  So the wave that inverts does the 24 MFMAs of that tile update itself -- in exactly the operation order of
+// gj_update, the tile is bit-identical to the one the owner computes -- inverts it and publishes the inverse while the
+// other waves issue the MFMAs of their two strip updates; nobody waits for anybody inside a step.  The inverting wave
+// is wave jb, whose Q strip is finished; its own P-strip update of the step is deferred to the next step, where that
+// wave has one update less than the others anyway (panels and inverses rotate through 3 slots, so the operands of step
+// jb are intact during step jb+1).  A step costs two strip updates (measured 4 x 9.8 K cycles instead of
+// 3 x 12.7 + 5.1 K; the inverting wave needs 9.1 K).  Every wave runs its own straight-line program (W is a template parameter): with run-time
+// branches on the wave index the register allocator moves strips between vector and accumulation registers at every
+// merge point.
+// ---------------------------------------------------------------------------------------
+// two row tiles (t0, t1) of this wave's strip -> look-ahead area [tile][plane][16][GJ_LAP]
+constexpr int GJ_LAP = 18;                  // row stride of a look-ahead tile (doubles)
+constexpr int GJ_LAPL = 16 * GJ_LAP;        // one plane of a tile
+constexpr int GJ_LA_SIZE = 4 * GJ_LAPL;     // two tiles, two planes
+template <int NT>
+__device__ __forceinline__ void gj_publish_tiles(const Strip<NT> &Q, int t0, int t1, double *la, int lane) {
+    const int ai = lane & 15, ak = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t != t0 && t != t1) continue;
+        double *dr = la + (t == t0 ? 0 : 2 * GJ_LAPL) + ak * GJ_LAP + ai, *di = dr + GJ_LAPL;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dr[4 * r * GJ_LAP] = Q.re[t][r];   // element [4r + ak][ai] of the tile
+            di[4 * r * GJ_LAP] = Q.im[t][r];
+        }
+    }
+}
+
+// the inverting wave: D' = tile1 - Panel[jn] (Dinv tile0) with the operation order of gj_update, then its inverse
+template <int NT>
+__device__ __forceinline__ void gj_lookahead_invert(int jn, const double *pan, const double *dv, double *la, double *dv_next,
+                                                    int lane, double &minrel, double inv_scale2) {
+    constexpr int NP = 16 * NT, PLD = 18;
+    const int ai = lane & 15, ak = lane >> 4;
+    const double *par = pan + ai * PLD + ak + 16 * jn * PLD, *pai = par + NP * PLD;
+    double dvr[4], dvi[4], pre[4], pim[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dvr[c] = dv[c * 64 + lane];
+        dvi[c] = dv[256 + c * 64 + lane];
+        pre[c] = par[4 * c];
+        pim[c] = pai[4 * c];
+    }
+    // tile0 as the B operand (k-step c: element [4c + ak][ai]); tile1 in the accumulator layout (register r: [4r + ak][ai])
+    const double *t0r = la + ak * GJ_LAP + ai, *t0i = t0r + GJ_LAPL, *t1r = t0r + 2 * GJ_LAPL, *t1i = t0r + 3 * GJ_LAPL;
+    d4 y1 = {0., 0., 0., 0.}, y2 = {0., 0., 0., 0.}, y3 = {0., 0., 0., 0.};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double bre = t0r[4 * c * GJ_LAP], bim = t0i[4 * c * GJ_LAP];
+        y1 = MFMA64(dvr[c], bre, y1);
+        y2 = MFMA64(dvi[c], bim, y2);
+        y3 = MFMA64(dvr[c] + dvi[c], bre + bim, y3);
+    }
+    const d4 yr = y1 - y2, yi = y3 - y1 - y2;
+    d4 q1 = {0., 0., 0., 0.}, q2 = {0., 0., 0., 0.}, q3 = {0., 0., 0., 0.};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double bre = yr[c], bim = yi[c], bs = yr[c] + yi[c];
+        q1 = MFMA64(pre[c], bre, q1);
+        q2 = MFMA64(pim[c], bim, q2);
+        q3 = MFMA64(pre[c] + pim[c], bs, q3);
+    }
+    d4 dre, dim;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dre[r] = t1r[4 * r * GJ_LAP]; dim[r] = t1i[4 * r * GJ_LAP]; }
+    dre -= q1 - q2;
+    dim -= q3 - q1 - q2;
+    // accumulator layout -> inversion layout through the (consumed) tile1 area: only this wave touches it
+    double *s_r = la + 2 * GJ_LAPL, *s_i = la + 3 * GJ_LAPL;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s_r[(4 * r + ak) * GJ_LAP + ai] = dre[r];
+        s_i[(4 * r + ak) * GJ_LAP + ai] = dim[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    double dr[4], di[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // D[i][4c + g], i = ai, g = ak
+        dr[c] = s_r[ai * GJ_LAP + 4 * c + ak];
+        di[c] = s_i[ai * GJ_LAP + 4 * c + ak];
+    }
+    const double mr = invert16(dr, di, lane, inv_scale2);
+    minrel = fmin(minrel, mr);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dv_next[c * 64 + lane] = dr[c];
+        dv_next[256 + c * 64 + lane] = di[c];
+    }
+}
+
+// a barrier the instruction scheduler may not move matrix instructions across: it otherwise sinks the tail of a
+// step's updates below the barrier, in front of the next step's tile inversion (measured: 44 K -> 39 K cycles per solve)
+#define GJ_SYNC() do { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <int NT, int W, class Hook>
+__device__ __forceinline__ void gj_lookahead_program(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
+                                                     double *la0, double *la1, int lane, double &minrel,
+                                                     double inv_scale2, const Hook &hook) {
+    static_assert(NT == 4, "the look-ahead schedule is written for four strips");
+    constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
+    GJ_SYNC();  // previous users of the staging region are done
+    if (W == 0) gj_publish_invert<NT>(Q, 0, panbase, dvbase, lane, minrel, inv_scale2, true);
+    else {
+        if (W == 1) gj_publish_tiles<NT>(Q, 0, 1, la0, lane);   // what wave 0 needs for D'_1 in step 0
+        hook.first_inversion_idle();
+    }
+    GJ_SYNC();
+    STAMP(5);
+#pragma unroll
+    for (int jb = 0; jb < NT; ++jb) {
+        const double *pan = panbase + (jb % 3) * PAN, *dv = dvbase + (jb % 3) * DV;
+        const double *pan_prev = panbase + ((jb + 2) % 3) * PAN, *dv_prev = dvbase + ((jb + 2) % 3) * DV;   // step jb-1
+        double *pan_next = panbase + ((jb + 1) % 3) * PAN, *dv_next = dvbase + ((jb + 1) % 3) * DV;
+        double *la_cur = (jb & 1) ? la1 : la0, *la_nxt = (jb & 1) ? la0 : la1;
+        if (jb >= 1 && W == jb - 1) {   // the P update this wave deferred while it inverted in the previous step
+            gj_update<NT>(P, jb - 1, pan_prev, dv_prev, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (jb + 1 < NT && W == jb) {
+            gj_lookahead_invert<NT>(jb + 1, pan, dv, la_cur, dv_next, lane, minrel, inv_scale2);
+        } else {
+            if (W > jb) {
+                gj_update2<NT>(Q, P, jb, pan, dv, lane);
+                if (W == jb + 1) gj_publish<NT>(Q, pan_next, lane);
+                if (W == jb + 2) gj_publish_tiles<NT>(Q, jb + 1, jb + 2, la_nxt, lane);
+            } else {
+                gj_update<NT>(P, jb, pan, dv, lane);
+            }
+        }
+        hook(jb);
+        if (jb < 3) { __builtin_amdgcn_sched_barrier(0); WSTAMP(18 + 4 * jb + W); }
+        GJ_SYNC();
+        STAMP(6 + jb);
+    }
+}
+
+template <int NT, class Hook = GjNoHook>
+__device__ __forceinline__ void block_gj_solve_lookahead(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
+                                                         double *la0, double *la1, int wave, int lane, double &minrel,
+                                                         double inv_scale2, const Hook &hook = Hook()) {
+    switch (wave) {   // wave-uniform (scalar) branch: each wave's path through the solve is straight-line code
+        case 0: gj_lookahead_program<NT, 0>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook); break;
+        case 1: gj_lookahead_program<NT, 1>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook); break;
+        case 2: gj_lookahead_program<NT, 2>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook); break;
+        default: gj_lookahead_program<NT, 3>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook); break;
     }
 }
 
@@ -955,7 +1197,10 @@ struct ExpmLds {
     // area of the Hermitian path here (2048).  The small kernels are latency-bound: less LDS = more cells per CU.
     static constexpr int DV = NT < 4 ? NSLOT * 512 : 2048;
     static constexpr int RED = NTH + 8 + NP;
-    static constexpr int TOTAL = 2 * REG + DV + RED;              // doubles
+    // look-ahead area of the NT = 4 solve: one buffer of two padded 16 x 16 tiles here, the second one in the tail of
+    // the X region behind the three panel slots (REG - SLOTS = 1536 doubles)
+    static constexpr int LA = NT == 4 ? 1152 : 0;
+    static constexpr int TOTAL = 2 * REG + DV + RED + LA;         // doubles
 };
 
 // A = -i dt (H0_k + sum_l a_l H_l) -> LDS (planar row-major), 16-byte coalesced loads: the element pairs
@@ -1597,6 +1842,12 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
         // changes either (the squarings use the X region), so the prefetch is unconditional
         const ExpmPrefetchHook<NT, HERM> hook{a, smem, next < hi ? next : -1, tid};
         double minrel = 1e300;
+#ifndef GRAPE_GJ_SPLIT
+        if constexpr (NT == 4)
+            block_gj_solve_lookahead<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, smem + 2 * LY::REG + LY::DV + LY::RED,
+                                         smem + LY::REG + LY::SLOTS, wave, lane, minrel, inv_b0sq, hook);
+        else
+#endif
         block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true, hook);
         have_a = next < hi;
         if (lane == 0 && !(minrel > 1e-6)) { a.cellflag[cell] = 1; atomicAdd(&a.flags[2], 1); }
