@@ -601,15 +601,6 @@ __device__ __forceinline__ void gj_update2(Strip<NT> &S, Strip<NT> &T, int jb, c
         dvr[c] = dv[c * 64 + lane];
         dvi[c] = dv[256 + c * 64 + lane];
     }
-    double pre[4][NT], pim[4][NT];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int tr = 0; tr < NT; ++tr) {
-            if (tr == jb) continue;
-            pre[c][tr] = par[16 * tr * PLD + 4 * c];
-            pim[c][tr] = pai[16 * tr * PLD + 4 * c];
-        }
     d4 sr, si, tr_, ti_;
     {
         d4 y1 = {0., 0., 0., 0.}, y2 = {0., 0., 0., 0.}, y3 = {0., 0., 0., 0.};
@@ -645,7 +636,7 @@ __device__ __forceinline__ void gj_update2(Strip<NT> &S, Strip<NT> &T, int jb, c
 #pragma unroll
         for (int tr = 0; tr < NT; ++tr) {
             if (tr == jb) continue;
-            const double are = pre[c][tr], aim = pim[c][tr], as = are + aim;
+            const double are = par[16 * tr * PLD + 4 * c], aim = pai[16 * tr * PLD + 4 * c], as = are + aim;
             q1[tr] = MFMA64(are, sr[c], q1[tr]);
             r1[tr] = MFMA64(are, tr_[c], r1[tr]);
             q2[tr] = MFMA64(aim, si[c], q2[tr]);
@@ -825,7 +816,7 @@ template <int NT, int W, class Hook>
 __device__ __forceinline__ void gj_lookahead_program(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
                                                      double *la0, double *la1, int lane, double &minrel,
                                                      double inv_scale2, const Hook &hook) {
-    static_assert(NT == 4, "the look-ahead schedule is written for four strips");
+    static_assert(NT >= 2 && W < NT, "one program per strip owner");
     constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
     GJ_SYNC();  // previous users of the staging region are done
     if (W == 0) gj_publish_invert<NT>(Q, 0, panbase, dvbase, lane, minrel, inv_scale2, true);
@@ -857,22 +848,30 @@ __device__ __forceinline__ void gj_lookahead_program(Strip<NT> &Q, Strip<NT> &P,
             }
         }
         hook(jb);
-        if (jb < 3) { __builtin_amdgcn_sched_barrier(0); WSTAMP(18 + 4 * jb + W); }
+        if (NT == 4 && jb < 3) { __builtin_amdgcn_sched_barrier(0); WSTAMP(18 + 4 * jb + W); }
         GJ_SYNC();
         STAMP(6 + jb);
     }
 }
 
+template <int NT, int W, class Hook>
+__device__ __forceinline__ void gj_lookahead_dispatch(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
+                                                      double *la0, double *la1, int wave, int lane, double &minrel,
+                                                      double inv_scale2, const Hook &hook) {
+    // wave-uniform (scalar) branches: each wave's path through the solve is straight-line code
+    if constexpr (W + 1 < NT) {
+        if (wave != W) {
+            gj_lookahead_dispatch<NT, W + 1>(Q, P, panbase, dvbase, la0, la1, wave, lane, minrel, inv_scale2, hook);
+            return;
+        }
+    }
+    gj_lookahead_program<NT, W>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook);
+}
 template <int NT, class Hook = GjNoHook>
 __device__ __forceinline__ void block_gj_solve_lookahead(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
                                                          double *la0, double *la1, int wave, int lane, double &minrel,
                                                          double inv_scale2, const Hook &hook = Hook()) {
-    switch (wave) {   // wave-uniform (scalar) branch: each wave's path through the solve is straight-line code
-        case 0: gj_lookahead_program<NT, 0>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook); break;
-        case 1: gj_lookahead_program<NT, 1>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook); break;
-        case 2: gj_lookahead_program<NT, 2>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook); break;
-        default: gj_lookahead_program<NT, 3>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook); break;
-    }
+    gj_lookahead_dispatch<NT, 0>(Q, P, panbase, dvbase, la0, la1, wave, lane, minrel, inv_scale2, hook);
 }
 
 // Robust fallback: Q X = P by Gaussian elimination with partial pivoting (LAPACK gesv semantics),
@@ -1197,9 +1196,13 @@ struct ExpmLds {
     // area of the Hermitian path here (2048).  The small kernels are latency-bound: less LDS = more cells per CU.
     static constexpr int DV = NT < 4 ? NSLOT * 512 : 2048;
     static constexpr int RED = NTH + 8 + NP;
-    // look-ahead area of the NT = 4 solve: one buffer of two padded 16 x 16 tiles here, the second one in the tail of
-    // the X region behind the three panel slots (REG - SLOTS = 1536 doubles)
+    // look-ahead areas of the solve (two buffers of two padded 16 x 16 tiles, 1152 doubles each).  The per-cell kernels
+    // put them into the A region, which is dead during the solve; the persistent kernel (NT = 4) forms the next cell's
+    // A there, so it has one buffer of its own and the other one in the tail of the X region behind the three panel
+    // slots (REG - SLOTS = 1536 doubles)
     static constexpr int LA = NT == 4 ? 1152 : 0;
+    static constexpr int LA0 = 2 * REG + DV + RED, LA1 = REG + SLOTS;   // offsets in the persistent kernel
+    static_assert(NT < 2 || REG >= 2304, "the A region holds both look-ahead buffers");
     static constexpr int TOTAL = 2 * REG + DV + RED + LA;         // doubles
 };
 
@@ -1756,7 +1759,13 @@ __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, c
     if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, !(a.ablate & 1));
     if (a.ablate & 3) minrel = 1.0;
 #else
-    block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true);
+    // (NT < 4 keeps the split schedule: with several cells per CU the latencies are hidden by the other workgroups,
+    // measured 16.5 ms either way for N = 48 and 5.3 -> 5.5 ms with the look-ahead for N = 32)
+    if constexpr (NT == 4)
+        block_gj_solve_lookahead<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, smem, smem + GJ_LA_SIZE, wave, lane,
+                                     minrel, inv_b0sq);
+    else
+        block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true);
 #endif
     // |pivot| < 1e-3 b0 (or NaN) in any of the diagonal tiles -> flag the cell for the pivoted pass
     if (lane == 0 && !(minrel > 1e-6)) { a.cellflag[cell] = 1; atomicAdd(&a.flags[2], 1); }   // flags[2]: flagged cells
@@ -1842,13 +1851,11 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
         // changes either (the squarings use the X region), so the prefetch is unconditional
         const ExpmPrefetchHook<NT, HERM> hook{a, smem, next < hi ? next : -1, tid};
         double minrel = 1e300;
-#ifndef GRAPE_GJ_SPLIT
-        if constexpr (NT == 4)
-            block_gj_solve_lookahead<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, smem + 2 * LY::REG + LY::DV + LY::RED,
-                                         smem + LY::REG + LY::SLOTS, wave, lane, minrel, inv_b0sq, hook);
+        if constexpr (NT == 4)   // (the only size the persistent variant is launched for)
+            block_gj_solve_lookahead<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, smem + LY::LA0, smem + LY::LA1, wave, lane,
+                                         minrel, inv_b0sq, hook);
         else
-#endif
-        block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true, hook);
+            block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true, hook);
         have_a = next < hi;
         if (lane == 0 && !(minrel > 1e-6)) { a.cellflag[cell] = 1; atomicAdd(&a.flags[2], 1); }
         STAMP(3);

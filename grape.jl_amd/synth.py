@@ -25,6 +25,9 @@ CONFIGS = {
     "C3": (64, 2, 1000, 128),   # headline
     "C4": (64, 2, 1000, 1024),  # 8 GPUs x 128 trajectories
     "C5": (256, 4, 2000, 64),
+    # not BASELINE configurations: the headline shape at the two other register-tile counts (timing tools only)
+    "X48": (48, 2, 1000, 128),
+    "X32": (32, 2, 1000, 128),
 }
 
 
