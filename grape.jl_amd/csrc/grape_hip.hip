@@ -1125,8 +1125,10 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         const char *pn[] = {"form A", "norm", "A2", "A4,A6 (+store A2)", "store A6 + combos", "dual", "U=A*T"};
         for (int j = 0; j < 7; ++j) fprintf(stderr, "  stamp %-24s %9.0f cycles\n", pn[j], avg(11 + j, j ? 10 + j : 0));
         fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "P,Q + first inversion", avg(5, 17));
+        fprintf(stderr, "  stamp   barrier %6.0f, P/Q stores %6.0f, barrier %6.0f, strip loads + barrier + I_0 %6.0f\n", avg(26, 17), avg(27, 26), avg(28, 27), avg(5, 28));
+        fprintf(stderr, "  stamp   strip loads + barrier %6.0f, then wave 0 (I_0) %6.0f, wave 1 (tiles + prefetch) %6.0f, wave 2 (prefetch) %6.0f\n", avg(22, 28), avg(29, 22), avg(30, 22), avg(31, 22));
         for (int j = 0; j < 4; ++j) fprintf(stderr, "  stamp solve step %d             %9.0f cycles\n", j, avg(6 + j, 5 + j));
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 1; ++j)
             fprintf(stderr, "  stamp   step %d, waves done after %6.0f %6.0f %6.0f %6.0f cycles\n", j, avg(18 + 4 * j, 5 + j),
                     avg(19 + 4 * j, 5 + j), avg(20 + 4 * j, 5 + j), avg(21 + 4 * j, 5 + j));
         fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "squarings + store U", avg(4, 3));

@@ -430,13 +430,16 @@ __device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int
 #ifdef GRAPE_DIAG
 __device__ unsigned long long *g_diag_slot_base = nullptr;
 #define g_diag_slot (g_diag_slot_base ? g_diag_slot_base + (size_t)blockIdx.x * 32 + 10 : nullptr)
-#define STAMP(i) do { if (threadIdx.x == 0 && g_diag_slot_base) g_diag_slot_base[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// stamps of the persistent kernel are taken in the SECOND cell of each workgroup (steady state: its A was prefetched
+// and it prefetches the next one); g_diag_off[block] != 0 switches the stamps off
+__device__ volatile int g_diag_off[1024];
+#define STAMP(i) do { if (threadIdx.x == 0 && g_diag_slot_base && !g_diag_off[blockIdx.x & 1023]) g_diag_slot_base[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
 // per-wave stamp (diagnostic builds): when a wave has finished its work of a solve step
 #ifdef GRAPE_DIAG
-#define WSTAMP(i) do { if ((threadIdx.x & 63) == 0 && g_diag_slot_base) g_diag_slot_base[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WSTAMP(i) do { if ((threadIdx.x & 63) == 0 && g_diag_slot_base && !g_diag_off[blockIdx.x & 1023]) g_diag_slot_base[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WSTAMP(i) do {} while (0)
 #endif
@@ -819,11 +822,13 @@ __device__ __forceinline__ void gj_lookahead_program(Strip<NT> &Q, Strip<NT> &P,
     static_assert(NT >= 2 && W < NT, "one program per strip owner");
     constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
     GJ_SYNC();  // previous users of the staging region are done
+    STAMP(22);
     if (W == 0) gj_publish_invert<NT>(Q, 0, panbase, dvbase, lane, minrel, inv_scale2, true);
     else {
         if (W == 1) gj_publish_tiles<NT>(Q, 0, 1, la0, lane);   // what wave 0 needs for D'_1 in step 0
         hook.first_inversion_idle();
     }
+    if (NT == 4 && W < 3) { __builtin_amdgcn_sched_barrier(0); WSTAMP(29 + W); }
     GJ_SYNC();
     STAMP(5);
 #pragma unroll
@@ -848,7 +853,7 @@ __device__ __forceinline__ void gj_lookahead_program(Strip<NT> &Q, Strip<NT> &P,
             }
         }
         hook(jb);
-        if (NT == 4 && jb < 3) { __builtin_amdgcn_sched_barrier(0); WSTAMP(18 + 4 * jb + W); }
+        if (NT == 4 && jb < 1) { __builtin_amdgcn_sched_barrier(0); WSTAMP(18 + 4 * jb + W); }
         GJ_SYNC();
         STAMP(6 + jb);
     }
@@ -1459,6 +1464,7 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     gemm_rot<LD, NS, NT>(Uo, Are, Aim, T, wave, lane);                      // U = A*T, skew-Hermitian (slots 0..2)
     STAMP(17);
     __syncthreads();                                                   // A is dead, the X planes are free
+    STAMP(26);
     // P = V + U -> X planes, Q = V - U -> A planes (natural positions).  V is Hermitian and U skew-Hermitian, so
     // P = Q^dagger: the tile each wave did not compute, (w-1, w), is the conjugate transpose of the OTHER matrix's
     // tile (w, w-1), which is slot 1 of wave w-1 -- neither V nor U needs its own mirror exchange.
@@ -1474,7 +1480,9 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
         rot_store_adjoint<LD, NT>(Xre, Xim, Qr.re[1], Qr.im[1], wave, lane, 1.0);   // P(w, w+1) = Q(w+1, w)^dagger
         rot_store_adjoint<LD, NT>(Are, Aim, Pr.re[1], Pr.im[1], wave, lane, 1.0);   // Q(w, w+1) = P(w+1, w)^dagger
     }
+    STAMP(27);
     __syncthreads();
+    STAMP(28);
     strip_load_lds<NT, LD>(Xre, Xim, Pn, wave, lane);
     strip_load_lds<NT, LD>(Are, Aim, Qn, wave, lane);
 }
@@ -1825,6 +1833,10 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
         int s, order;
         double inv_b0sq;
         bool measure;
+#ifdef GRAPE_DIAG
+        if (tid == 0) g_diag_off[blockIdx.x & 1023] = (cell != lo + ((int)blockIdx.x >> 3) + per_x);
+        __syncthreads();
+#endif
         STAMP(0);
         if (!have_a) {
             const double bound = expm_norm_bound(a, cell);
@@ -1866,6 +1878,9 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
         st_ord[order == 13 ? 4 : (order - 3) / 2] += 1;
         if (s > 0) __syncthreads();   // the last squaring read the X region, which the next cell writes after its first product
     }
+#ifdef GRAPE_DIAG
+    if (tid0 == 0) g_diag_off[blockIdx.x & 1023] = 0;
+#endif
     if (tid0 == 0) {
         stat_add(a.stats, 0, (unsigned long long)st_s);
 #pragma unroll
