@@ -1061,9 +1061,12 @@ __device__ __forceinline__ void rot_exch_read(const double *area, Strip<NT> &S, 
 // per k-step; the operand sums are one VALU add each against 64-cycle MFMAs.  Software pipeline as in gemm_xb: the
 // real-plane operands of k-step ks+1 are requested once the P1 MFMAs have issued, the imaginary-plane operands
 // after the P2 MFMAs, so that every LDS read has at least NS MFMAs to land before the next operand sum needs it.
+// `late_exch` != nullptr: the mirrored slot NT-1 of B is still on its way through the exchange area (its owner wrote it with
+// rot_exch_write just before this call); it is the LAST k-block of the rotated k order, so the barrier and the read wait
+// until the first NT-1 k-blocks have been issued -- the exchange costs no time of its own.
 template <int LD, int NS, int NT = 4>
 __device__ __forceinline__ void gemm_rot(Strip<NT> &acc, const double *__restrict__ Xre, const double *__restrict__ Xim,
-                                         const Strip<NT> &B, int wave, int lane) {
+                                         Strip<NT> &B, int wave, int lane, const double *late_exch = nullptr) {
     const double *__restrict__ xr = Xre + (lane & 15) * LD + (lane >> 4);
     const double *__restrict__ xi = Xim + (lane & 15) * LD + (lane >> 4);
     int rowoff[NS];
@@ -1080,6 +1083,10 @@ __device__ __forceinline__ void gemm_rot(Strip<NT> &acc, const double *__restric
     for (int so = 0; so < NS; ++so) { p1[so] = (d4){0., 0., 0., 0.}; p2[so] = (d4){0., 0., 0., 0.}; p3[so] = (d4){0., 0., 0., 0.}; }
 #pragma unroll
     for (int sk = 0; sk < NT; ++sk) {
+        if (sk == NT - 1 && late_exch) {
+            __syncthreads();
+            rot_exch_read<NT>(late_exch, B, wave, lane);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kn = (r < 3) ? 16 * ((wave + sk) % NT) + 4 * (r + 1) : 16 * ((wave + sk + 1) % NT);   // next k column
@@ -1426,10 +1433,8 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     strip_zero(A4);
     gemm_rot<LD, NS, NT>(A4, Xre, Xim, A2, wave, lane);                     // A4 = A2*A2
     rot_exch_write<NT>(exch, A4.re[1], A4.im[1], wave, lane, 1.0);
-    __syncthreads();
-    rot_exch_read<NT>(exch, A4, wave, lane);
     strip_zero(A6);
-    gemm_rot<LD, NS, NT>(A6, Xre, Xim, A4, wave, lane);                     // A6 = A2*A4
+    gemm_rot<LD, NS, NT>(A6, Xre, Xim, A4, wave, lane, exch);               // A6 = A2*A4 (mirrored tile of A4 arrives late)
     STAMP(14);
     __syncthreads();                                                   // everybody is done reading X = A2
     rot_store_slots<LD, NS, NT>(Xre, Xim, A6, wave, lane);                  // X = A6
@@ -1455,12 +1460,13 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     STAMP(15);
     gemm_dual13_rot<LD, NT>(T, V, Xre, Xim, A2, A4, A6, wave, lane);
     STAMP(16);
-    __syncthreads();                                                   // everybody is done reading X = A6
-    rot_exch_write<NT>(exch, T.re[1], T.im[1], wave, lane, 1.0);          // T's mirrored tiles through the exchange area
-    __syncthreads();
-    rot_exch_read<NT>(exch, T, wave, lane);
+    // T's mirrored tiles through the exchange area (its last readers, inside the A6 product, are two barriers back)
+    rot_exch_write<NT>(exch, T.re[1], T.im[1], wave, lane, 1.0);
     Strip<NT> Uo;
     strip_zero(Uo);
+    // (here the late arrival of the mirrored tile inside the product measured 1 % slower: 26.0 vs 25.8 ms)
+    __syncthreads();
+    rot_exch_read<NT>(exch, T, wave, lane);
     gemm_rot<LD, NS, NT>(Uo, Are, Aim, T, wave, lane);                      // U = A*T, skew-Hermitian (slots 0..2)
     STAMP(17);
     __syncthreads();                                                   // A is dead, the X planes are free
