@@ -815,11 +815,20 @@ __device__ __forceinline__ void gj_lookahead_invert(int jn, const double *pan, c
 // a barrier the instruction scheduler may not move matrix instructions across: it otherwise sinks the tail of a
 // step's updates below the barrier, in front of the next step's tile inversion (measured: 44 K -> 39 K cycles per solve)
 #define GJ_SYNC() do { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); } while (0)
-template <int NT, int W, class Hook>
-__device__ __forceinline__ void gj_lookahead_program(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
+template <int NT, int W, bool ROT, class Hook>
+__device__ __forceinline__ void gj_lookahead_program(Strip<NT> &Qio, Strip<NT> &Pio, double *panbase, double *dvbase,
                                                      double *la0, double *la1, int lane, double &minrel,
                                                      double inv_scale2, const Hook &hook) {
     static_assert(NT >= 2 && W < NT, "one program per strip owner");
+    // ROT: the strips arrive rotated (slot s = row tile (W + s) % NT); W is a compile-time constant here, so taking them
+    // into natural order is a renaming of registers.  P leaves in natural order.
+    Strip<NT> Q, P;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int src = ROT ? (t - W + NT) % NT : t;
+        Q.re[t] = Qio.re[src]; Q.im[t] = Qio.im[src];
+        P.re[t] = Pio.re[src]; P.im[t] = Pio.im[src];
+    }
     constexpr int PAN = GjLds<NT>::PAN, DV = GjLds<NT>::DV;
     GJ_SYNC();  // previous users of the staging region are done
     STAMP(22);
@@ -857,26 +866,28 @@ __device__ __forceinline__ void gj_lookahead_program(Strip<NT> &Q, Strip<NT> &P,
         GJ_SYNC();
         STAMP(6 + jb);
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { Pio.re[t] = P.re[t]; Pio.im[t] = P.im[t]; }
 }
 
-template <int NT, int W, class Hook>
+template <int NT, int W, bool ROT, class Hook>
 __device__ __forceinline__ void gj_lookahead_dispatch(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
                                                       double *la0, double *la1, int wave, int lane, double &minrel,
                                                       double inv_scale2, const Hook &hook) {
     // wave-uniform (scalar) branches: each wave's path through the solve is straight-line code
     if constexpr (W + 1 < NT) {
         if (wave != W) {
-            gj_lookahead_dispatch<NT, W + 1>(Q, P, panbase, dvbase, la0, la1, wave, lane, minrel, inv_scale2, hook);
+            gj_lookahead_dispatch<NT, W + 1, ROT>(Q, P, panbase, dvbase, la0, la1, wave, lane, minrel, inv_scale2, hook);
             return;
         }
     }
-    gj_lookahead_program<NT, W>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook);
+    gj_lookahead_program<NT, W, ROT>(Q, P, panbase, dvbase, la0, la1, lane, minrel, inv_scale2, hook);
 }
-template <int NT, class Hook = GjNoHook>
+template <int NT, bool ROT = false, class Hook = GjNoHook>
 __device__ __forceinline__ void block_gj_solve_lookahead(Strip<NT> &Q, Strip<NT> &P, double *panbase, double *dvbase,
                                                          double *la0, double *la1, int wave, int lane, double &minrel,
                                                          double inv_scale2, const Hook &hook = Hook()) {
-    gj_lookahead_dispatch<NT, 0>(Q, P, panbase, dvbase, la0, la1, wave, lane, minrel, inv_scale2, hook);
+    gj_lookahead_dispatch<NT, 0, ROT>(Q, P, panbase, dvbase, la0, la1, wave, lane, minrel, inv_scale2, hook);
 }
 
 // Robust fallback: Q X = P by Gaussian elimination with partial pivoting (LAPACK gesv semantics),
@@ -1413,7 +1424,11 @@ __device__ __forceinline__ void expm_norm_combine(double *smem, const int tid, c
 
 // Order-13 numerator / denominator for a skew-Hermitian A (see the rotated-strip helpers): returns P = V+U and
 // Q = V-U as NATURAL strips.  regA holds A, regX is the staging plane pair, exch the small exchange area.
-template <int LD, int NT = 4>
+// ROT_OUT (NT = 4, look-ahead solve): P and Q are handed over as ROTATED strips (slot s = row tile (w + s) % NT of column strip
+// w).  A rotated strip IS the wave's column strip, in a wave-dependent register order which the per-wave programs of the solve
+// undo by renaming; only the tile no wave computed for itself, (w-1, w), has to travel -- one exchange round of two tiles per
+// wave instead of two full matrices through the planes (64 stores, two barriers, 64 loads per wave).
+template <int LD, int NT = 4, bool ROT_OUT = false>
 __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, double *exch, const int wave,
                                                  const int lane, Strip<NT> &Pn, Strip<NT> &Qn) {
     constexpr int NP = 16 * NT, NS = NT - 1;   // NS slots are computed, slot NT - 1 is the mirrored tile
@@ -1469,6 +1484,24 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     rot_exch_read<NT>(exch, T, wave, lane);
     gemm_rot<LD, NS, NT>(Uo, Are, Aim, T, wave, lane);                      // U = A*T, skew-Hermitian (slots 0..2)
     STAMP(17);
+    if constexpr (ROT_OUT) {
+        // P = V + U, Q = V - U with P = Q^dagger: slot NT-1 of P, tile (w-1, w), is the conjugate transpose of Q's tile
+        // (w, w-1) = slot 1 of wave w-1, and vice versa.  The X region has been free since the barrier in front of this
+        // product (its last readers were in the T/V product); the A region is still being read by slower waves.
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            Pn.re[t] = V.re[t] + Uo.re[t]; Pn.im[t] = V.im[t] + Uo.im[t];
+            Qn.re[t] = V.re[t] - Uo.re[t]; Qn.im[t] = V.im[t] - Uo.im[t];
+        }
+        rot_exch_write<NT>(regX, Qn.re[1], Qn.im[1], wave, lane, 1.0);               // -> P(w, w+1) of wave w+1
+        rot_exch_write<NT>(regX + NT * 512, Pn.re[1], Pn.im[1], wave, lane, 1.0);    // -> Q(w, w+1) of wave w+1
+        STAMP(27);
+        __syncthreads();
+        STAMP(28);
+        rot_exch_read<NT>(regX, Pn, wave, lane);
+        rot_exch_read<NT>(regX + NT * 512, Qn, wave, lane);
+        return;
+    }
     __syncthreads();                                                   // A is dead, the X planes are free
     STAMP(26);
     // P = V + U -> X planes, Q = V - U -> A planes (natural positions).  V is Hermitian and U skew-Hermitian, so
@@ -1492,6 +1525,10 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     strip_load_lds<NT, LD>(Xre, Xim, Pn, wave, lane);
     strip_load_lds<NT, LD>(Are, Aim, Qn, wave, lane);
 }
+
+// Hermitian 64 x 64 cells hand P and Q to the look-ahead solve as rotated strips (expm_poly13_herm)
+template <int NT, bool HERM>
+struct ExpmRotOut { static constexpr bool value = HERM && NT == 4; };
 
 // Polynomial phase of one cell: Pade order / squaring count from ||A||_1 (in red[NTH]; A = -i dt H in LDS)
 // and the numerator P = V+U and denominator Q = V-U as register strips (strip index `wave` = column strip
@@ -1539,7 +1576,7 @@ __device__ __forceinline__ void expm_poly(const ExpmArgs &a, const int wave, con
         order = 13;
         inv_b0sq = 1.0 / (B13_0 * B13_0);
         if constexpr (HERM && NT >= 3) {
-            expm_poly13_herm<LD, NT>(smem, smem + LY::REG, smem + 2 * LY::REG, wave, lane, Pn, Qn);
+            expm_poly13_herm<LD, NT, ExpmRotOut<NT, HERM>::value>(smem, smem + LY::REG, smem + 2 * LY::REG, wave, lane, Pn, Qn);
         } else {
         Strip<NT> A2, A4, A6;
         {
@@ -1635,6 +1672,21 @@ __device__ __forceinline__ void expm_poly(const ExpmArgs &a, const int wave, con
             Pn.im[t] = V.im[t] + Uo.im[t];
             Qn.re[t] = V.re[t] - Uo.re[t];
             Qn.im[t] = V.im[t] - Uo.im[t];
+        }
+        if constexpr (ExpmRotOut<NT, HERM>::value) {
+            // (rare: ||A||_1 <= 2.1) the look-ahead solve expects rotated strips: the same column strip in another
+            // register order -- through this wave's own columns of the X planes
+            __syncthreads();   // everybody is done reading the X planes
+            strip_store_lds<NT, LD>(Xre, Xim, Pn, wave, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            rot_load_strip<LD, NT>(Xre, Xim, Pn, wave, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            strip_store_lds<NT, LD>(Xre, Xim, Qn, wave, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            rot_load_strip<LD, NT>(Xre, Xim, Qn, wave, lane);
         }
     }
 
@@ -1770,14 +1822,29 @@ __device__ __forceinline__ void expm_single(const ExpmArgs &a, const int cell, c
     STAMP(2);
     double minrel = 1e300;
 #ifdef GRAPE_DIAG
+    if constexpr (ExpmRotOut<NT, HERM>::value) {   // the ablations run the split schedule, which takes natural strips
+        constexpr int LD = LY::LD, NP = LY::NP;
+        double *Xre = smem + LY::REG, *Xim = Xre + NP * LD;
+        __syncthreads();
+        rot_store_slots<LD, NT, NT>(Xre, Xim, Pn, wave, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        strip_load_lds<NT, LD>(Xre, Xim, Pn, wave, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        rot_store_slots<LD, NT, NT>(Xre, Xim, Qn, wave, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        strip_load_lds<NT, LD>(Xre, Xim, Qn, wave, lane);
+    }
     if (!(a.ablate & 2)) block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, !(a.ablate & 1));
     if (a.ablate & 3) minrel = 1.0;
 #else
     // (NT < 4 keeps the split schedule: with several cells per CU the latencies are hidden by the other workgroups,
     // measured 16.5 ms either way for N = 48 and 5.3 -> 5.5 ms with the look-ahead for N = 32)
     if constexpr (NT == 4)
-        block_gj_solve_lookahead<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, smem, smem + GJ_LA_SIZE, wave, lane,
-                                     minrel, inv_b0sq);
+        block_gj_solve_lookahead<NT, ExpmRotOut<NT, HERM>::value>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, smem,
+                                                                  smem + GJ_LA_SIZE, wave, lane, minrel, inv_b0sq);
     else
         block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true);
 #endif
@@ -1870,8 +1937,8 @@ __device__ __forceinline__ void expm_persistent(const ExpmArgs &a, const int tid
         const ExpmPrefetchHook<NT, HERM> hook{a, smem, next < hi ? next : -1, tid};
         double minrel = 1e300;
         if constexpr (NT == 4)   // (the only size the persistent variant is launched for)
-            block_gj_solve_lookahead<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, smem + LY::LA0, smem + LY::LA1, wave, lane,
-                                         minrel, inv_b0sq, hook);
+            block_gj_solve_lookahead<NT, ExpmRotOut<NT, HERM>::value>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, smem + LY::LA0,
+                                                                      smem + LY::LA1, wave, lane, minrel, inv_b0sq, hook);
         else
             block_gj_solve<NT>(Qn, Pn, smem + LY::REG, smem + 2 * LY::REG, wave, lane, minrel, inv_b0sq, true, hook);
         have_a = next < hi;
