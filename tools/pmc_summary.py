@@ -7,13 +7,15 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = collections.defaultdict(dict)
 for name in ("fetch", "write", "mfma"):
-    files = glob.glob(f"gpurun_out/pmc_{tag}_{name}/**/*counter_collection.csv", recursive=True)
+    # gpurun merges every call's files into gpurun_out/: only the newest run of a pass is the current build
+    files = sorted(glob.glob(f"gpurun_out/pmc_{tag}_{name}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:
         shutil.copy(f, f"profiles/{tag}_pmc_{name}_counter_collection.csv")
