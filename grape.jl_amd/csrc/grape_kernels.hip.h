@@ -567,21 +567,22 @@ __device__ __forceinline__ void gj_update(Strip<NT> &S, int jb, const double *pa
     d4 q1[NT], q2[NT], q3[NT];
 #pragma unroll
     for (int tr = 0; tr < NT; ++tr) { q1[tr] = (d4){0., 0., 0., 0.}; q2[tr] = (d4){0., 0., 0., 0.}; q3[tr] = (d4){0., 0., 0., 0.}; }
+    // row tile by row tile (every accumulation chain still runs over the k-steps c = 0..3 in order): the sums of the
+    // three partial products of one tile are vector work that runs under the matrix instructions of the next tile --
+    // with the k-step outermost all chains end together and the whole tail (a third of the update's time) is exposed
+    double bs[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {  // k-step c: k = 4c + ak within the panel's 16 columns
-        const double bre = yr[c], bim = yi[c], bs = yr[c] + yi[c];
-#pragma unroll
-        for (int tr = 0; tr < NT; ++tr) {
-            if (tr == jb) continue;
-            const double are = pre[c][tr], aim = pim[c][tr];
-            q1[tr] = MFMA64(are, bre, q1[tr]);
-            q2[tr] = MFMA64(aim, bim, q2[tr]);
-            q3[tr] = MFMA64(are + aim, bs, q3[tr]);
-        }
-    }
+    for (int c = 0; c < 4; ++c) bs[c] = yr[c] + yi[c];
 #pragma unroll
     for (int tr = 0; tr < NT; ++tr) {
         if (tr == jb) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // k-step c: k = 4c + ak within the panel's 16 columns
+            const double are = pre[c][tr], aim = pim[c][tr];
+            q1[tr] = MFMA64(are, yr[c], q1[tr]);
+            q2[tr] = MFMA64(aim, yi[c], q2[tr]);
+            q3[tr] = MFMA64(are + aim, bs[c], q3[tr]);
+        }
         S.re[tr] -= q1[tr] - q2[tr];
         S.im[tr] -= q3[tr] - q1[tr] - q2[tr];
     }
@@ -633,24 +634,22 @@ __device__ __forceinline__ void gj_update2(Strip<NT> &S, Strip<NT> &T, int jb, c
         q1[tr] = (d4){0., 0., 0., 0.}; q2[tr] = (d4){0., 0., 0., 0.}; q3[tr] = (d4){0., 0., 0., 0.};
         r1[tr] = (d4){0., 0., 0., 0.}; r2[tr] = (d4){0., 0., 0., 0.}; r3[tr] = (d4){0., 0., 0., 0.};
     }
+    double bs[4], bt[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const double bs = sr[c] + si[c], bt = tr_[c] + ti_[c];
+    for (int c = 0; c < 4; ++c) { bs[c] = sr[c] + si[c]; bt[c] = tr_[c] + ti_[c]; }
 #pragma unroll
-        for (int tr = 0; tr < NT; ++tr) {
-            if (tr == jb) continue;
+    for (int tr = 0; tr < NT; ++tr) {   // row tile by row tile, see gj_update
+        if (tr == jb) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
             const double are = par[16 * tr * PLD + 4 * c], aim = pai[16 * tr * PLD + 4 * c], as = are + aim;
             q1[tr] = MFMA64(are, sr[c], q1[tr]);
             r1[tr] = MFMA64(are, tr_[c], r1[tr]);
             q2[tr] = MFMA64(aim, si[c], q2[tr]);
             r2[tr] = MFMA64(aim, ti_[c], r2[tr]);
-            q3[tr] = MFMA64(as, bs, q3[tr]);
-            r3[tr] = MFMA64(as, bt, r3[tr]);
+            q3[tr] = MFMA64(as, bs[c], q3[tr]);
+            r3[tr] = MFMA64(as, bt[c], r3[tr]);
         }
-    }
-#pragma unroll
-    for (int tr = 0; tr < NT; ++tr) {
-        if (tr == jb) continue;
         S.re[tr] -= q1[tr] - q2[tr];
         S.im[tr] -= q3[tr] - q1[tr] - q2[tr];
         T.re[tr] -= r1[tr] - r2[tr];
