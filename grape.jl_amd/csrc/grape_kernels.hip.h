@@ -422,11 +422,9 @@ __device__ __forceinline__ double invert16(double (&ar)[4], double (&ai)[4], int
 //     Y      = Dinv * S[jb]             (16x16x16)
 //     S[tr] -= Panel[tr] * Y  (tr != jb),   S[jb] = Y
 // After NT steps Q == I and P == X.
-// LOOK-AHEAD: the register inversion is serial (one wave, 16 dependent pivot steps), so in step jb
-// wave jb+1 updates only its Q strip, immediately publishes the next panel and inverts the next
-// diagonal tile while the other waves are still issuing their MFMA updates; its own P-strip update of
-// step jb is deferred to step jb+1 (where it has no Q strip left to update).  Panels and inverses
-// live in 3 rotating LDS slots so that the deferred update still finds the operands of step jb.
+// The register inversion of a diagonal tile is serial (one wave, 16 dependent pivot steps, ~6.5 K cycles): the two
+// schedules below (block_gj_solve: split steps, NT <= 3; block_gj_solve_lookahead: NT = 4) differ in how they keep the
+// other waves busy meanwhile.  Panels and inverses live in 3 rotating LDS slots.
 #ifdef GRAPE_DIAG
 __device__ unsigned long long *g_diag_slot_base = nullptr;
 #define g_diag_slot (g_diag_slot_base ? g_diag_slot_base + (size_t)blockIdx.x * 32 + 10 : nullptr)
@@ -725,9 +723,9 @@ __device__ __forceinline__ void block_gj_solve(Strip<NT> &Q, Strip<NT> &P, doubl
 // is wave jb, whose Q strip is finished; its own P-strip update of the step is deferred to the next step, where that
 // wave has one update less than the others anyway (panels and inverses rotate through 3 slots, so the operands of step
 // jb are intact during step jb+1).  A step costs two strip updates (measured 4 x 9.8 K cycles instead of
-// 3 x 12.7 + 5.1 K; the inverting wave needs 9.1 K).  Every wave runs its own straight-line program (W is a template parameter): with run-time
-// branches on the wave index the register allocator moves strips between vector and accumulation registers at every
-// merge point.
+// 3 x 12.7 + 5.1 K; the inverting wave needs 9.1 K).  Every wave runs its own straight-line program (W is a template
+// parameter): with run-time branches on the wave index the register allocator moves strips between vector and
+// accumulation registers at every merge point.
 // ---------------------------------------------------------------------------------------
 // two row tiles (t0, t1) of this wave's strip -> look-ahead area [tile][plane][16][GJ_LAP]
 constexpr int GJ_LAP = 18;                  // row stride of a look-ahead tile (doubles)
