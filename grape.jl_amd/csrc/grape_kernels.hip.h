@@ -2130,10 +2130,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
     __syncthreads();
 
     int cur = 0;
-    // software prefetch, two steps deep: the U tiles of steps n+1 and n+2 are in flight while step n is reduced
-    // (the recurrence only couples the steps through the state, never through U); 128 KB per workgroup in
-    // flight is what it takes to keep the HBM stream busy with one workgroup per trajectory
-    double2 unext[RW], unext2[RW];
+    // software prefetch: the U tiles of the next steps are in flight while step n is reduced (the recurrence only
+    // couples the steps through the state, never through U)
     auto load_tile = [&](double2 (&dst)[RW], int step) __attribute__((always_inline)) {
         const int nn = BACKWARD ? a.N_T - 1 - step : step;
         const double2 *Un = Uk + (size_t)nn * NP * NP;
@@ -2141,22 +2139,21 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
         for (int r = 0; r < RW; ++r)
             dst[r] = lane < NP ? Un[(size_t)(wave * RW + r) * NP + lane] : make_double2(0., 0.);
     };
-    // (two deep only backward: the forward reduce-scatter needs the registers, measured 2.09 -> 2.24 ms with it)
-    constexpr bool DEEP = BACKWARD;
-    load_tile(unext, 0);
-    if (DEEP && a.N_T > 1) load_tile(unext2, 1);
-    for (int step = 0; step < a.N_T; ++step) {
+    // The tiles of the next D steps are in flight in a ring of registers with STATIC indices (the time loop is unrolled D
+    // times).  A ring that is shifted with register moves makes every step wait for the newest load (s_waitcnt vmcnt(0)):
+    // the sweeps then run at one memory latency per step whatever the depth.
+    constexpr int D = NP == 64 ? 2 : 3;   // (measured at the C3 shape: N = 64 2.98 / 3.07 ms with 2 / 3, N = 48 2.30 / 2.14, N = 32 1.33 / 1.24)
+    double2 un[D][RW];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < a.N_T) load_tile(un[d], d);
+    for (int step0 = 0; step0 < a.N_T; step0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int step = step0 + d;
+        if (step >= a.N_T) break;
         const int n = BACKWARD ? a.N_T - 1 - step : step;
-        double2 ucur[RW];
-        if constexpr (DEEP) {
-#pragma unroll
-            for (int r = 0; r < RW; ++r) { ucur[r] = unext[r]; unext[r] = unext2[r]; }
-            if (step + 2 < a.N_T) load_tile(unext2, step + 2);
-        } else {
-#pragma unroll
-            for (int r = 0; r < RW; ++r) ucur[r] = unext[r];
-            if (step + 1 < a.N_T) load_tile(unext, step + 1);
-        }
+        double2 (&ucur)[RW] = un[d];
         if (!BACKWARD) {
             // y_i = sum_j U[i][j] x_j : lane j holds the products of this wave's RW rows; the sums over
             // lanes are a wavefront reduce-scatter (RW values -> 1 value per lane, then a 64/RW-lane sum)
@@ -2168,6 +2165,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
                 pr[r] = u.x * xv.x - u.y * xv.y;
                 pi[r] = u.x * xv.y + u.y * xv.x;
             }
+            if (step + D < a.N_T) load_tile(un[d], step + D);   // (the tile of this step is consumed)
             int row = 0;
             rs_step<RW / 2, 32>(pr, pi, lane, row);
             if constexpr (RW >= 4) rs_step<RW / 4, 16>(pr, pi, lane, row);
@@ -2193,6 +2191,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
                 ar += u.x * xi.x + u.y * xi.y;
                 ai += u.x * xi.y - u.y * xi.x;
             }
+            if (step + D < a.N_T) load_tile(un[d], step + D);   // (the tile of this step is consumed)
             if (lane < NP) part[wave][lane] = make_double2(ar, ai);
             __syncthreads();
             if (tid < NP) {
@@ -2210,6 +2209,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
         }
         __syncthreads();
         cur ^= 1;
+      }
     }
     if (!BACKWARD) {
         // tau_k = <target_k | Psi_k(T)>  (optimize.jl:753)
@@ -2379,38 +2379,48 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs &a, const int k, do
 #pragma unroll
         for (int m = 0; m < 4; ++m) dst[m] = BACKWARD ? Un[(4 * c + m) * NP + r] : Un[r * NP + 4 * c + m];
     };
-    double2 u0[4], u1[4], u2[4];
-    load_tile(u1, 0);
-    if (a.N_T > 1) load_tile(u2, 1);
+    // The tiles of the next DEPTH steps are in flight, in a ring of registers with STATIC indices (the time loop is
+    // unrolled DEPTH times): shifting the ring with register moves makes every step wait for the newest load
+    // (s_waitcnt vmcnt(0)), and the loop then runs at one memory latency per step whatever the depth.
+    constexpr int DEPTH = 8;
+    double2 un[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < a.N_T) load_tile(un[d], d);
     double2 y = make_double2(0., 0.);
-    for (int step = 0; step < a.N_T; ++step) {
-        const int n = BACKWARD ? a.N_T - 1 - step : step;
+    for (int step0 = 0; step0 < a.N_T; step0 += DEPTH) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { u0[m] = u1[m]; u1[m] = u2[m]; }
-        if (step + 2 < a.N_T) load_tile(u2, step + 2);
-        double pr = 0., pi = 0.;
+        for (int d = 0; d < DEPTH; ++d) {
+            const int step = step0 + d;
+            if (step < a.N_T) {
+                const int n = BACKWARD ? a.N_T - 1 - step : step;
+                double pr = 0., pi = 0.;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const double2 x = xs[4 * c + m];
-            if (!BACKWARD) {   // U x
-                pr = fma(u0[m].x, x.x, pr); pr = fma(-u0[m].y, x.y, pr);
-                pi = fma(u0[m].x, x.y, pi); pi = fma(u0[m].y, x.x, pi);
-            } else {           // conj(U) x
-                pr = fma(u0[m].x, x.x, pr); pr = fma(u0[m].y, x.y, pr);
-                pi = fma(u0[m].x, x.y, pi); pi = fma(-u0[m].y, x.x, pi);
+                for (int m = 0; m < 4; ++m) {
+                    const double2 x = xs[4 * c + m];
+                    const double2 u = un[d][m];
+                    if (!BACKWARD) {   // U x
+                        pr = fma(u.x, x.x, pr); pr = fma(-u.y, x.y, pr);
+                        pi = fma(u.x, x.y, pi); pi = fma(u.y, x.x, pi);
+                    } else {           // conj(U) x
+                        pr = fma(u.x, x.x, pr); pr = fma(u.y, x.y, pr);
+                        pi = fma(u.x, x.y, pi); pi = fma(-u.y, x.x, pi);
+                    }
+                }
+                if (step + DEPTH < a.N_T) load_tile(un[d], step + DEPTH);
+                pr = group_sum<4>(pr);
+                pi = group_sum<4>(pi);
+                if (BACKWARD && a.xi && n > 0) {   // chi(t_n) += lambda_b Dt_n / rho_k xi_k(t_n)   (optimize.jl:897-908)
+                    const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + n) * NP + r];
+                    const double cc = a.lambda_b * a.wq[n] / rho;
+                    pr += cc * x_.x; pi += cc * x_.y;
+                }
+                y = make_double2(pr, pi);
+                if (c == 0) {
+                    xs[r] = y;     // in order behind this wave's reads of the previous state
+                    st[(size_t)(BACKWARD ? n : n + 1) * NP + r] = y;
+                }
             }
-        }
-        pr = group_sum<4>(pr);
-        pi = group_sum<4>(pi);
-        if (BACKWARD && a.xi && n > 0) {   // chi(t_n) += lambda_b Dt_n / rho_k xi_k(t_n)   (optimize.jl:897-908)
-            const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + n) * NP + r];
-            const double cc = a.lambda_b * a.wq[n] / rho;
-            pr += cc * x_.x; pi += cc * x_.y;
-        }
-        y = make_double2(pr, pi);
-        if (c == 0) {
-            xs[r] = y;     // in order behind this wave's reads of the previous state
-            st[(size_t)(BACKWARD ? n : n + 1) * NP + r] = y;
         }
     }
     if (!BACKWARD) {
