@@ -1043,14 +1043,24 @@ __device__ __forceinline__ void rot_load_slot3(const double *Xre, const double *
 }
 // exchange through a small area (4 waves x 2 planes x 256 doubles) when no plane is free: the writer stores
 // its slot-1 tile in the reader's register layout, [lane'][r'] with lane' = 16 (c & 3) + 4r + rg, r' = c >> 2
-template <int NT = 4>
+template <int NT = 4, int DIST = 1>   // DIST: the reader is wave + DIST (1: slot-1 tile -> mirrored slot, 2: see gemm_rot HALF_LAST)
 __device__ __forceinline__ void rot_exch_write(double *area, const d4 &tre, const d4 &tim, int wave, int lane, double sgn) {
     const int c = lane & 15, rg = lane >> 4;
-    double *dst = area + ((wave + 1) % NT) * 512 + (16 * (c & 3) + rg) * 4 + (c >> 2);
+    double *dst = area + ((wave + DIST) % NT) * 512 + (16 * (c & 3) + rg) * 4 + (c >> 2);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         dst[16 * r] = sgn * tre[r];          // lane' advances by 4 per r: (4r) * 4 doubles
         dst[256 + 16 * r] = -sgn * tim[r];
+    }
+}
+// the tile addressed to this wave, added to slot SLOT
+template <int NT, int SLOT>
+__device__ __forceinline__ void rot_exch_add(const double *area, Strip<NT> &S, int wave, int lane) {
+    const double *src = area + wave * 512 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        S.re[SLOT][r] += src[r];
+        S.im[SLOT][r] += src[256 + r];
     }
 }
 template <int NT = 4>
@@ -1072,7 +1082,12 @@ __device__ __forceinline__ void rot_exch_read(const double *area, Strip<NT> &S, 
 // `late_exch` != nullptr: the mirrored slot NT-1 of B is still on its way through the exchange area (its owner wrote it with
 // rot_exch_write just before this call); it is the LAST k-block of the rotated k order, so the barrier and the read wait
 // until the first NT-1 k-blocks have been issued -- the exchange costs no time of its own.
-template <int LD, int NS, int NT = 4>
+// HALF_LAST (NT = 4, squares of a Hermitian matrix, X == B): the last computed slot, tile (w+2, w), is also computed -- as its
+// conjugate transpose (w, w+2) -- by wave w+2.  In a square X X the two are adjoint TERM BY TERM,
+// (X(i,k) X(k,j))^dagger = X(j,k) X(k,i), so each of the two waves only sums the first two k-blocks of its rotated k order
+// (w, w+1 here; w+2, w+3 there) and the caller adds the partner's partial sum, exchanged like the mirrored tiles:
+// 120 instead of 144 matrix instructions.
+template <int LD, int NS, int NT = 4, bool HALF_LAST = false>
 __device__ __forceinline__ void gemm_rot(Strip<NT> &acc, const double *__restrict__ Xre, const double *__restrict__ Xim,
                                          Strip<NT> &B, int wave, int lane, const double *late_exch = nullptr) {
     const double *__restrict__ xr = Xre + (lane & 15) * LD + (lane >> 4);
@@ -1101,27 +1116,34 @@ __device__ __forceinline__ void gemm_rot(Strip<NT> &acc, const double *__restric
             const bool more = !(sk == NT - 1 && r == 3);
             const double bre = B.re[sk][r], bim = B.im[sk][r];
             const double bs = bre + bim;
+            const int ns = (HALF_LAST && 2 * sk >= NT) ? NS - 1 : NS;                                    // slots of this k-step
+            const int nsn = (HALF_LAST && (2 * sk >= NT || (2 * (sk + 1) >= NT && r == 3))) ? NS - 1 : NS;   // ... of the next one
             double as[NS];
 #pragma unroll
             for (int so = 0; so < NS; ++so) as[so] = are[so] + aim[so];
 #pragma unroll
-            for (int so = 0; so < NS; ++so) p1[so] = MFMA64(are[so], bre, p1[so]);
+            for (int so = 0; so < NS; ++so)
+                if (so < ns) p1[so] = MFMA64(are[so], bre, p1[so]);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
 #pragma unroll
-                for (int so = 0; so < NS; ++so) are[so] = xr[rowoff[so] + kn];
+                for (int so = 0; so < NS; ++so)
+                    if (so < nsn) are[so] = xr[rowoff[so] + kn];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int so = 0; so < NS; ++so) p2[so] = MFMA64(aim[so], bim, p2[so]);
+            for (int so = 0; so < NS; ++so)
+                if (so < ns) p2[so] = MFMA64(aim[so], bim, p2[so]);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
 #pragma unroll
-                for (int so = 0; so < NS; ++so) aim[so] = xi[rowoff[so] + kn];
+                for (int so = 0; so < NS; ++so)
+                    if (so < nsn) aim[so] = xi[rowoff[so] + kn];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int so = 0; so < NS; ++so) p3[so] = MFMA64(as[so], bs, p3[so]);
+            for (int so = 0; so < NS; ++so)
+                if (so < ns) p3[so] = MFMA64(as[so], bs, p3[so]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1435,7 +1457,12 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
         Strip<NT> As;
         rot_load_strip<LD, NT>(Are, Aim, As, wave, lane);
         strip_zero(A2);
-        gemm_rot<LD, NS, NT>(A2, Are, Aim, As, wave, lane);                 // A2 = A*A (slots 0..2)
+        gemm_rot<LD, NS, NT, NT == 4>(A2, Are, Aim, As, wave, lane);        // A2 = A*A (slots 0..2; NT = 4: slot 2 half)
+    }
+    if constexpr (NT == 4) {   // slot 2 += (partial sum of wave w+2)^dagger
+        rot_exch_write<NT, 2>(exch, A2.re[2], A2.im[2], wave, lane, 1.0);
+        __syncthreads();
+        rot_exch_add<NT, 2>(exch, A2, wave, lane);
     }
     STAMP(13);
     rot_store_slots<LD, NS, NT>(Xre, Xim, A2, wave, lane);                  // X = A2, with the mirrored tiles
@@ -1443,7 +1470,13 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     __syncthreads();
     rot_load_slot3<LD, NT>(Xre, Xim, A2, wave, lane);
     strip_zero(A4);
-    gemm_rot<LD, NS, NT>(A4, Xre, Xim, A2, wave, lane);                     // A4 = A2*A2
+    gemm_rot<LD, NS, NT, NT == 4>(A4, Xre, Xim, A2, wave, lane);            // A4 = A2*A2 (NT = 4: slot 2 half)
+    if constexpr (NT == 4) {   // slot 2 += (partial sum of wave w+2)^dagger; the second barrier frees the area again
+        rot_exch_write<NT, 2>(exch, A4.re[2], A4.im[2], wave, lane, 1.0);
+        __syncthreads();
+        rot_exch_add<NT, 2>(exch, A4, wave, lane);
+        __syncthreads();
+    }
     rot_exch_write<NT>(exch, A4.re[1], A4.im[1], wave, lane, 1.0);
     strip_zero(A6);
     gemm_rot<LD, NS, NT>(A6, Xre, Xim, A4, wave, lane, exch);               // A6 = A2*A4 (mirrored tile of A4 arrives late)
