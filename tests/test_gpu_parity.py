@@ -625,3 +625,36 @@ def test_persistent_phase_a_matches_per_cell_launch_and_keeps_the_pivoted_fallba
                                     gradient_method=ref.TAYLOR)
         assert abs(Js - Jr) <= TOL_J and np.abs(taus - taur).max() <= TOL_TAU and np.abs(Gs - Gr).max() <= tol_G(Gr)
         assert np.abs(np.linalg.norm(U, axis=0) - 1.0).max() <= 1e-12 or not herm
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_exponential_paths_differential_on_random_grids(g, ref, case, monkeypatch):
+    """The N = 64 exponential in all its forms on random problems with non-uniform time grids whose step sizes reach every
+    Pade order and up to three squarings: persistent kernel == one-workgroup-per-cell kernel bit for bit (both run the
+    look-ahead solve on rotated strips, split squares, late-arriving mirrored tiles), Hermitian fast path == general path
+    (GRAPE_NO_HERM=1) to rounding, and the evaluation against the C restatement (tools/diff_paths.py is the long form)."""
+    from grape_jl_amd import synth
+    rng = np.random.default_rng(977 + case)
+    N = (64, 64, 60, 49, 64, 64)[case]
+    K = 9 if case % 2 else 5          # 9 x 120 cells: persistent kernel; 5 x 120: per-cell kernel by size
+    N_T, L = 120, 2
+    pr = synth.make_problem(N, L, N_T, K, seed=int(rng.integers(1 << 30)))
+    scale = (0.02, 0.2, 1.0, 6.0, 2.5, 0.6)[case]
+    tl = np.concatenate([[0.0], np.cumsum(scale * (0.5 + rng.random(N_T)))])
+    args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
+    res = {}
+    for name, env in (("persist", {}), ("percell", {"GRAPE_EXPM_PERSIST": "0"}), ("general", {"GRAPE_NO_HERM": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with g.GrapeHip(*args) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            res[name] = (J, G.copy(), np.stack([h.propagator(0, n) for n in (0, N_T // 2, N_T - 1)]))
+        for k in env:
+            monkeypatch.delenv(k)
+    assert res["persist"][0] == res["percell"][0] and np.array_equal(res["persist"][1], res["percell"][1])
+    assert np.array_equal(res["persist"][2], res["percell"][2])
+    assert abs(res["persist"][0] - res["general"][0]) <= TOL_J
+    assert np.abs(res["persist"][1] - res["general"][1]).max() <= tol_G(res["general"][1])
+    assert np.abs(res["persist"][2] - res["general"][2]).max() <= 1e-12
+    Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], gradient_method=ref.TAYLOR)
+    assert abs(res["persist"][0] - Jr) <= TOL_J and np.abs(res["persist"][1] - Gr).max() <= tol_G(Gr)
