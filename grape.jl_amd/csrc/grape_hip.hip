@@ -1337,7 +1337,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
     // ---- phase 4: sum over trajectories ----
     phase_begin(h, 4, s);
     const int LN = h->L * h->N_T;
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((LN + 255) / 256), dim3(256), 0, s, h->d_tg, h->K, LN, d_G,
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((LN + 15) / 16), dim3(256), 0, s, h->d_tg, h->K, LN, d_G,
                        unit ? (const double2 *)h->d_z : (const double2 *)nullptr);
     HIPCHK(h, hipGetLastError());
     phase_end(h, 4, s);

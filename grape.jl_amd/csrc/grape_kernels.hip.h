@@ -3566,20 +3566,32 @@ __global__ void __launch_bounds__(256) jb_reduce_kernel(const double *gb, const 
 // ---------------------------------------------------------------------------------------
 // Kernel 6: G[l*N_T + n] = -2 Re sum_k tau_grads[k][l][n]   (_grad_J_T_via_chi!, optimize.jl:574-584)
 // ---------------------------------------------------------------------------------------
-__global__ void grad_reduce_kernel(double2 *tg, int K, int LN, double *G, const double2 *z) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= LN) return;
+__global__ void __launch_bounds__(256) grad_reduce_kernel(double2 *tg, int K, int LN, double *G, const double2 *z) {
+    // 16 gradient entries per workgroup, 16 threads per entry over the trajectories (a thread per entry walking all K rows
+    // is a chain of K dependent load latencies on a handful of CUs: 46 us at C3); partial sums meet in LDS in a fixed order
+    __shared__ double part[16][17];
+    const int j = threadIdx.x & 15, kg = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + j;
     double s = 0.;
-    if (z) {
-        // concurrent sweeps: the derivative kernels saw the unit backward states; tau_grads = z_k <chi~'_l|Psi>
-        for (int k = 0; k < K; ++k) {
-            const double2 t = tg[(size_t)k * LN + idx], zk = z[k];
-            const double2 v = make_double2(zk.x * t.x - zk.y * t.y, zk.x * t.y + zk.y * t.x);
-            tg[(size_t)k * LN + idx] = v;
-            s += v.x;
+    if (idx < LN) {
+        if (z) {
+            // concurrent sweeps: the derivative kernels saw the unit backward states; tau_grads = z_k <chi~'_l|Psi>
+            for (int k = kg; k < K; k += 16) {
+                const double2 t = tg[(size_t)k * LN + idx], zk = z[k];
+                const double2 v = make_double2(zk.x * t.x - zk.y * t.y, zk.x * t.y + zk.y * t.x);
+                tg[(size_t)k * LN + idx] = v;
+                s += v.x;
+            }
+        } else {
+            for (int k = kg; k < K; k += 16) s += tg[(size_t)k * LN + idx].x;
         }
-    } else {
-        for (int k = 0; k < K; ++k) s += tg[(size_t)k * LN + idx].x;
     }
-    G[idx] = -2.0 * s;
+    part[kg][j] = s;
+    __syncthreads();
+    if (kg == 0 && idx < LN) {
+        double t = 0.;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][j];
+        G[idx] = -2.0 * t;
+    }
 }
