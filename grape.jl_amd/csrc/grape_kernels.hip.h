@@ -1484,10 +1484,9 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
     __syncthreads();                                                   // everybody is done reading X = A2
     rot_store_slots<LD, NS, NT>(Xre, Xim, A6, wave, lane);                  // X = A6
     rot_store_adjoint<LD, NT>(Xre, Xim, A6.re[1], A6.im[1], wave, lane, 1.0);
-    __syncthreads();
-    rot_load_slot3<LD, NT>(Xre, Xim, A6, wave, lane);
     // T = A6*(b13 A6 + b11 A4 + b9 A2) + b7 A6 + b5 A4 + b3 A2 + b1 I      (U = A*T)
     // V = A6*(b12 A6 + b10 A4 + b8 A2) + b6 A6 + b4 A4 + b2 A2 + b0 I
+    // (the start values only need the computed slots: formed while the stores drain, in front of the barrier)
     Strip<NT> T, V;
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
@@ -1502,6 +1501,8 @@ __device__ __forceinline__ void expm_poly13_herm(double *regA, double *regX, dou
         for (int r = 0; r < 4; ++r)
             if (4 * r + rg == c) { T.re[0][r] += B13_1; V.re[0][r] += B13_0; }
     }
+    __syncthreads();
+    rot_load_slot3<LD, NT>(Xre, Xim, A6, wave, lane);
     STAMP(15);
     gemm_dual13_rot<LD, NT>(T, V, Xre, Xim, A2, A4, A6, wave, lane);
     STAMP(16);
