@@ -11,6 +11,7 @@
 #include "grape_large.hip.h"
 #include "grape_series.hip.h"
 #include "grape_cheby.hip.h"
+#include "grape_t18.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -60,6 +61,7 @@ struct grape_handle {
     // propagators U_cn; KC == K (d_cls == nullptr) for ensembles of distinct generators
     int KC = 0;
     bool herm = false;           // all generators Hermitian: A = -i dt H is skew-Hermitian (expm uses the symmetry)
+    bool t18 = false;            // Hermitian generators: inverse-free polynomial exponential (grape_t18.hip.h)
     std::vector<int> cls;        // [K] class of trajectory k
     int *d_cls = nullptr, *d_rep = nullptr;
     unsigned *d_coop = nullptr;  // [2][K] step counters of the cooperative sweeps (forward, backward)
@@ -173,6 +175,22 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
         hipLaunchKernelGGL((expm_pade_kernel<NT, false>), dim3(a.K * a.N_T), dim3(NT * 64), lds, s, a);
     // pivoted pass over the flagged cells (all other workgroups exit at once)
     hipLaunchKernelGGL((expm_pade_kernel<NT, true>), dim3(std::min(a.K * a.N_T, 1024)), dim3(NT * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+// Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h), persistent grid
+template <int NT>
+hipError_t launch_expm_t18(const ExpmArgs &a, hipStream_t s, int blocks) {
+    static size_t lds_set[64] = {0};
+    const size_t lds = expm_lds_bytes(NT);
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (lds_set[dev & 63] < lds) {
+        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set[dev & 63] = lds;
+    }
+    hipLaunchKernelGGL((expm_t18_kernel<NT>), dim3(blocks), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -628,6 +646,7 @@ int status_from_flags(grape_handle *h, int flags) {
         return GRAPE_ERR_AGAIN;
     }
     if (flags & 1) { h->err = "Pade denominator numerically singular in at least one cell"; return GRAPE_ERR_SINGULAR; }
+    if (flags & 64) { h->err = "exponential: a generator H_kn dt is not finite (NaN or overflow)"; return GRAPE_ERR_SINGULAR; }
     if (flags & 2) {
         h->err = "The chi state of at least one trajectory has norm < chi_min_norm (optimize.jl:1021-1025)";
         return GRAPE_ERR_CHI_NORM;
@@ -799,6 +818,9 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             for (int q = 0; q < nhc && herm; ++q) is_herm(p->Hc + (size_t)q * 2 * p->N * p->N);
             const char *envh = getenv("GRAPE_NO_HERM");
             h->herm = herm && !(envh && atoi(envh));
+            // GRAPE_EXPM_T18=0: Hermitian generators through the order-13 Pade kernel as well (parity reference, A/B timing)
+            const char *envt = getenv("GRAPE_EXPM_T18");
+            h->t18 = h->herm && !(envt && !atoi(envt));
         }
         if (h->KC < p->K) {
             if (hipSetDevice(h->device) != hipSuccess || hipMalloc((void **)&h->d_cls, p->K * sizeof(int)) != hipSuccess ||
@@ -1092,6 +1114,11 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         if (h->large) {
             e = expm_large(h, s);
         } else {
+            const long ncell = (long)ea.K * ea.N_T;
+            const int t18_blocks = 8 * (int)std::max<long>(1, std::min<long>(h->num_cus / 8, (ncell + 7) / 8));
+            if (h->t18 && h->NT >= 3) {
+                e = h->NT == 3 ? launch_expm_t18<3>(ea, s, t18_blocks) : launch_expm_t18<4>(ea, s, t18_blocks);
+            } else
             switch (h->NT) {
                 case 1: e = launch_expm<1>(ea, h->herm, s); break;
                 case 2: e = launch_expm<2>(ea, h->herm, s); break;
@@ -1695,10 +1722,10 @@ int grape_reset_timings(grape_handle *h) {
 int grape_get_work(grape_handle *h, double *out, int n) {
     if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
     if (!h->shards.empty()) {   // every entry is a count: the shards add up
-        const int m = n < 9 ? n : 9;
+        const int m = n < 12 ? n : 12;
         std::fill(out, out + m, 0.0);
         for (grape_handle *c : h->shards) {
-            double cw[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+            double cw[12] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
             const int rc = grape_get_work(c, cw, m);
             if (rc < 0) return multi_fail(h, c, rc);
             for (int i = 0; i < m; ++i) out[i] += cw[i];
@@ -1725,6 +1752,11 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     if (n > 6) out[6] = h->series ? 0.0 : ecells;   // propagators actually exponentiated (generator classes x time steps)
     if (n > 7) out[7] = (double)st[10];  // matrix-free propagator: series terms summed over both sweeps
     if (n > 8) out[8] = (double)st[11];  // ... and (sub-)steps
+    // inverse-free exponential (grape_t18.hip.h): EXECUTED matrix-instruction flop (2048 per v_mfma_f64_16x16x4), its
+    // own squarings and cells
+    if (n > 9) out[9] = (double)st[12] * 2048.0;
+    if (n > 10) out[10] = (double)st[13];
+    if (n > 11) out[11] = (double)st[14];
     return 4;
 }
 
