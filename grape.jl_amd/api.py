@@ -56,22 +56,32 @@ def library_path() -> str:
     return os.path.join(_CSRC, _LIBNAME)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    out = library_path()
-    srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_kernels.hip.h", "grape_large.hip.h",
-                                             "grape_series.hip.h", "grape_cheby.hip.h")]
+    out = out or library_path()
+    srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_t18.hip", "grape_kernels.hip.h", "grape_large.hip.h",
+                                             "grape_series.hip.h", "grape_cheby.hip.h", "grape_t18.hip.h")]
     hdr = os.path.join(_HERE, "..", "include", "grape_hip.h")
     if (not force and os.path.exists(out)
             and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs + [hdr])):
         return out
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           srcs[0], "-o", out]
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    # two translation units (built side by side): the inverse-free exponential kernel takes a code-generation switch the
+    # rest of the library cannot be compiled with (see grape_t18.hip)
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + list(extra_flags)
+    objs = [os.path.join(_CSRC, "grape_hip.o"), os.path.join(_CSRC, "grape_t18.o")]
+    cmds = [base + ["-c", srcs[0], "-o", objs[0]],
+            base + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-c", srcs[1], "-o", objs[1]]]
+    procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for c in cmds]
+    outs = [p.communicate()[0] for p in procs]
+    if verbose or any(p.returncode for p in procs):
+        print("\n".join(outs))
+    if any(p.returncode for p in procs):
+        raise RuntimeError("hipcc failed building " + out)
+    res = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out], capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout, res.stderr)
     if res.returncode:
-        raise RuntimeError("hipcc failed building " + out)
+        raise RuntimeError("hipcc failed linking " + out)
     return out
 
 

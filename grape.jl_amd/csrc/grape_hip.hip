@@ -11,7 +11,6 @@
 #include "grape_large.hip.h"
 #include "grape_series.hip.h"
 #include "grape_cheby.hip.h"
-#include "grape_t18.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -178,21 +177,12 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
     return hipGetLastError();
 }
 
-// Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h), persistent grid
-template <int NT>
-hipError_t launch_expm_t18(const ExpmArgs &a, hipStream_t s, int blocks) {
-    static size_t lds_set[64] = {0};
-    const size_t lds = expm_lds_bytes(NT);
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (lds_set[dev & 63] < lds) {
-        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_set[dev & 63] = lds;
-    }
-    hipLaunchKernelGGL((expm_t18_kernel<NT>), dim3(blocks), dim3(NT * 64), lds, s, a);
-    return hipGetLastError();
-}
+// Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
+// unit grape_t18.hip), persistent grid
+extern "C" int grape_t18_launch(int NT, const void *args, size_t args_size, void *stream, int blocks);
+#ifdef GRAPE_DIAG
+extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream);
+#endif
 
 template <int CPL>
 hipError_t launch_coop(const SweepArgs &a, bool backward, int S, int rpw, int nw, unsigned *cnt, hipStream_t s) {
@@ -1107,6 +1097,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     }
     ea.stamps = d_stamps;
     hipMemcpyToSymbolAsync(HIP_SYMBOL(g_diag_slot_base), &d_stamps, sizeof(d_stamps), 0, hipMemcpyHostToDevice, s);
+    grape_t18_set_stamps(d_stamps, (void *)s);
 #endif
     hipError_t e = hipSuccess;
     if (!h->series) {
@@ -1117,7 +1108,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             const long ncell = (long)ea.K * ea.N_T;
             const int t18_blocks = 8 * (int)std::max<long>(1, std::min<long>(h->num_cus / 8, (ncell + 7) / 8));
             if (h->t18 && h->NT >= 3) {
-                e = h->NT == 3 ? launch_expm_t18<3>(ea, s, t18_blocks) : launch_expm_t18<4>(ea, s, t18_blocks);
+                e = (hipError_t)grape_t18_launch(h->NT, &ea, sizeof(ea), (void *)s, t18_blocks);
             } else
             switch (h->NT) {
                 case 1: e = launch_expm<1>(ea, h->herm, s); break;
@@ -1149,6 +1140,13 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                 if (st[b * 32 + i1] && st[b * 32 + i0]) { sum += (double)(st[b * 32 + i1] - st[b * 32 + i0]); ++cnt; }
             return cnt ? sum / cnt : 0.0;
         };
+        if (h->t18 && h->NT >= 3) {
+            const char *tn[] = {"form A (+norm)", "A2 = A A + half exchange", "A3 = A A2", "store A3, norm A2, barrier", "A6 = A3 A3",
+                                "A6 exchanges + norms", "scaling, B1 -> X, barrier", "A9 = B1 B5", "+B4, B3+A9 -> X, B2", "p = B2 + (B3+A9) A9",
+                                "squarings", "store U", "end barrier"};
+            for (int j = 0; j < 13; ++j) fprintf(stderr, "  stamp %-28s %9.0f cycles\n", tn[j], avg(j + 1, j));
+            fprintf(stderr, "  stamp %-28s %9.0f cycles\n", "TOTAL per cell", avg(13, 0));
+        } else {
         const char *pn[] = {"form A", "norm", "A2", "A4,A6 (+store A2)", "store A6 + combos", "dual", "U=A*T"};
         for (int j = 0; j < 7; ++j) fprintf(stderr, "  stamp %-24s %9.0f cycles\n", pn[j], avg(11 + j, j ? 10 + j : 0));
         fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "P,Q + first inversion", avg(5, 17));
@@ -1160,6 +1158,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                     avg(19 + 4 * j, 5 + j), avg(20 + 4 * j, 5 + j), avg(21 + 4 * j, 5 + j));
         fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "squarings + store U", avg(4, 3));
         fprintf(stderr, "  stamp %-24s %9.0f cycles\n", "TOTAL per cell", avg(4, 0));
+        }
     }
 #endif
     // ---- phase 1: forward sweep + tau ----

@@ -1,0 +1,43 @@
+// grape_t18.hip -- translation unit of the inverse-free exponential kernel (grape_t18.hip.h).
+//
+// Its own translation unit because it is compiled with -mllvm -amdgpu-mfma-vgpr-form: the partial products of the 3M
+// scheme then live in the vector half of the register file, where the vector ALU combines them without
+// v_accvgpr_read copies (8.4 cycles each, profiles/r03_mfma_f64_filler_probe.txt).  The switch crashes this compiler
+// (ROCm 7.2, AMDGPURewriteAGPRCopyMFMA) on deriv_mfma_kernel, so the rest of the library is built without it.
+// The device helpers of grape_kernels.hip.h are included into an anonymous namespace: this unit gets private copies of
+// the constant tables and instantiates nothing but expm_t18_kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+namespace {
+#include "grape_t18.hip.h"
+
+template <int NT>
+hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
+    static size_t lds_set[64] = {0};
+    const size_t lds = sizeof(double) * (size_t)T18Lds<NT>::TOTAL;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (lds_set[dev & 63] < lds) {
+        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set[dev & 63] = lds;
+    }
+    hipLaunchKernelGGL((expm_t18_kernel<NT>), dim3(blocks), dim3(NT * 64), lds, s, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+// args: the ExpmArgs of grape_kernels.hip.h (same header on both sides), passed as bytes because the type of this unit
+// lives in an anonymous namespace
+extern "C" int grape_t18_launch(int NT, const void *args, size_t args_size, void *stream, int blocks) {
+    if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
+    ExpmArgs a;
+    memcpy(&a, args, sizeof(a));
+    return (int)(NT == 3 ? launch<3>(a, (hipStream_t)stream, blocks) : launch<4>(a, (hipStream_t)stream, blocks));
+}
+#ifdef GRAPE_DIAG
+extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream) {
+    hipMemcpyToSymbolAsync(HIP_SYMBOL(g_diag_slot_base), &d_stamps, sizeof(d_stamps), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
+}
+#endif

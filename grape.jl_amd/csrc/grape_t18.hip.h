@@ -20,8 +20,29 @@
 // rho(H dt)^6 <= ||A6||_1 (Hermitian matrices: ||M||_2 <= ||M||_1; |re| + |im| stands in for the modulus, which can only
 // enlarge the bound).  beta = min(sqrt ||A2||_1, ||A6||_1^(1/6)); beta > 2: A is scaled by 2^-s (the powers by 2^-ks,
 // exact) and the result squared s times.  At the headline configuration ||A||_1 = 4.2 but beta = 1.17: no squaring.
+//
+// Cost model behind the layout (tools/mfma_filler_probe.hip, profiles/r03_mfma_f64_filler_probe.txt; one wave per SIMD):
+// a v_mfma_f64_16x16x4 occupies the vector ALU for its 64 cycles -- NOTHING the wave issues to the VALU runs underneath
+// it (PMC SQ_VALU_MFMA_COEXEC_CYCLES = 0): the first vector instruction between two matrix instructions costs 24
+// cycles, every further one 4.6-4.9, a v_accvgpr_read/write 8.4; only LDS reads (up to ~8 per gap) and scalar
+// instructions are free.  Hence
+//   * the k loops contain matrix instructions and LDS reads ONLY: the operand sums of the 3M scheme come from a third
+//     LDS plane (re + im, written once by whoever writes the left operand) and a third strip component (formed once per
+//     right operand) instead of 5 additions per k-step;
+//   * the linear combinations are formed in ONE pass over the powers, right after the third product (each power is
+//     read by the VALU once instead of four or five times -- with 450 live registers most of them live in accumulation
+//     registers and every VALU pass over them is a stream of v_accvgpr_read); B4 and B2 enter their products as start
+//     values of the accumulators.
 #pragma once
 #include "grape_kernels.hip.h"
+
+// diagnostic builds only (tools/t18_ablate.sh): -DT18_STOP=n leaves the cell after phase n (results are wrong; the
+// differences of the launch times are the cost of the phases -- in-kernel stamps perturb this kernel by a third)
+#ifdef T18_STOP
+#define T18_STOP_AT(n, Uout, Src) do { if (T18_STOP == (n)) { _Pragma("unroll") for (int t_ = 0; t_ < NT; ++t_) { (Uout).re[t_] = (Src).re[t_ % (sizeof((Src).re) / sizeof((Src).re[0]))]; (Uout).im[t_] = (Src).im[t_ % (sizeof((Src).im) / sizeof((Src).im[0]))]; } s_out = 0; bad = false; return; } } while (0)
+#else
+#define T18_STOP_AT(n, Uout, Src) do {} while (0)
+#endif
 
 #define T18_THETA 2.0
 // a1, a2, a3, b1, b2, b3, b6, c0, c1, c2, c3, c6, d0, d1, d2, d3, d6, e2, e3, e6  (tools/t18_coeffs.py 2.0)
@@ -46,15 +67,41 @@
 #define T18_E3 -0.013910627366173824328
 #define T18_E6 -0.000014649629174709440602
 
+// LDS carve: ONE left-operand region of three planes (re, im, re + im; leading dimension NP + 2), two exchange areas
+// (partial sums of the doubly computed tile, mirrored tiles) and the reduction scratch
+template <int NT>
+struct T18Lds {
+    static constexpr int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
+    static constexpr int PL = NP * LD;          // doubles per plane
+    static constexpr int E1 = 3 * PL, E2 = E1 + NT * 512, RED = E2 + NT * 512;
+    static constexpr int TOTAL = RED + NTH + 8 + NP;   // doubles
+};
+
+// a right operand: rotated column strip (slot s of wave w = row tile (w + s) % NT) with the sums re + im of the 3M scheme
+template <int NT>
+struct Strip3M {
+    d4 re[NT], im[NT], sm[NT];
+};
+// the three partial products of the 3M scheme: re = p1 - p2, im = p3 - p1 - p2
+template <int NS>
+struct Acc3 {
+    d4 p1[NS], p2[NS], p3[NS];
+};
+template <int NS>
+__device__ __forceinline__ void acc3_zero(Acc3<NS> &q) {
+#pragma unroll
+    for (int t = 0; t < NS; ++t) { q.p1[t] = (d4){0., 0., 0., 0.}; q.p2[t] = (d4){0., 0., 0., 0.}; q.p3[t] = (d4){0., 0., 0., 0.}; }
+}
+
 // max_j sum_i (|re| + |im|) over the wave's 16 columns of a complete rotated strip (all NT slots): an upper bound of the
 // largest column sum of moduli of this column strip; uniform over the wave
-template <int NT>
-__device__ __forceinline__ double t18_colsum_max(const Strip<NT> &S) {
+template <int NT, class S>
+__device__ __forceinline__ double t18_colsum_max(const S &s) {
     double c = 0.;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c += fabs(S.re[t][r]) + fabs(S.im[t][r]);
+        for (int r = 0; r < 4; ++r) c += fabs(s.re[t][r]) + fabs(s.im[t][r]);
     c += __shfl_xor(c, 16, 64);   // the four lane rows hold the same column
     c += __shfl_xor(c, 32, 64);
     c = fmax(c, dpp_f64<DPP_QUAD_XOR1>(c));
@@ -65,48 +112,48 @@ __device__ __forceinline__ double t18_colsum_max(const Strip<NT> &S) {
 }
 
 struct T18NoHook {
-    __device__ __forceinline__ void operator()(int) const {}
+    __device__ __forceinline__ void operator()(int, int) const {}
 };
 
-// acc[0..NS-1] += X * B for rotated strips, X in LDS planes (natural layout), 3M scheme and software pipeline exactly as
-// gemm_rot; the right operand comes from a functor bop(sk, r, bre, bim) (slot sk, register r: k-step 16 ((w + sk) % NT) + 4 r)
-// so that a linear combination of strips is formed on the fly, and hook(sk) runs in front of k-block sk (late arrival
-// of a mirrored tile, staged prefetch of the next cell).
-template <int LD, int NS, int NT, bool HALF_LAST, class BOp, class Hook>
-__device__ __forceinline__ void t18_gemm(Strip<NT> &acc, const double *__restrict__ Xre, const double *__restrict__ Xim,
-                                         int wave, int lane, BOp bop, Hook hook) {
-    const double *__restrict__ xr = Xre + (lane & 15) * LD + (lane >> 4);
-    const double *__restrict__ xi = Xim + (lane & 15) * LD + (lane >> 4);
+// q[0..NS-1] += X * B for rotated strips: X in the three LDS planes R (natural layout), B a Strip3M.  The k loop issues
+// matrix instructions and LDS reads only (see the cost model above): the operands of k-step ks+1 are requested one
+// plane at a time behind the matrix instructions that consumed that plane's registers.  hook(sk, r) runs in front of
+// k-step r of k-block sk (late arrival of a mirrored tile, stores of the previous cell's result, requests for the next cell's
+// operator tiles).  Measured (tools/ab_lib.py, C3): the 16 result stores of a lane as four per k-block 17.33 ms, as one per
+// k-step 17.51 ms (every store brings its address arithmetic, i.e. a matrix -> vector -> matrix transition of 24 cycles,
+// into the k-step), all 16 behind the last product 17.60 ms.
+// HALF_LAST (NT = 4, squares of a (skew-)Hermitian matrix, X == B): the last computed slot, tile (w+2, w), is also computed
+// -- as its conjugate transpose -- by wave w+2; the two are adjoint term by term, so each wave sums only the first two
+// k-blocks of its rotated k order and the caller adds the partner's partial sum (gemm_rot in grape_kernels.hip.h).
+template <int LD, int NS, int NT, bool HALF_LAST, class Hook>
+__device__ __forceinline__ void t18_gemm(Acc3<NS> &q, const double *__restrict__ R, const Strip3M<NT> &B, int wave, int lane,
+                                         Hook hook) {
+    constexpr int PL = 16 * NT * LD;
+    const double *__restrict__ xr = R + (lane & 15) * LD + (lane >> 4);
     int rowoff[NS];
 #pragma unroll
     for (int so = 0; so < NS; ++so) rowoff[so] = 16 * ((wave + so) % NT) * LD;
-    double are[NS], aim[NS];
+    double are[NS], aim[NS], asu[NS];
     {
         const int k0 = 16 * wave;
 #pragma unroll
-        for (int so = 0; so < NS; ++so) { are[so] = xr[rowoff[so] + k0]; aim[so] = xi[rowoff[so] + k0]; }
+        for (int so = 0; so < NS; ++so) {
+            are[so] = xr[rowoff[so] + k0]; aim[so] = xr[PL + rowoff[so] + k0]; asu[so] = xr[2 * PL + rowoff[so] + k0];
+        }
     }
-    d4 p1[NS], p2[NS], p3[NS];
-#pragma unroll
-    for (int so = 0; so < NS; ++so) { p1[so] = (d4){0., 0., 0., 0.}; p2[so] = (d4){0., 0., 0., 0.}; p3[so] = (d4){0., 0., 0., 0.}; }
 #pragma unroll
     for (int sk = 0; sk < NT; ++sk) {
-        hook(sk);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            hook(sk, r);
             const int kn = (r < 3) ? 16 * ((wave + sk) % NT) + 4 * (r + 1) : 16 * ((wave + sk + 1) % NT);   // next k column
             const bool more = !(sk == NT - 1 && r == 3);
-            double bre, bim;
-            bop(sk, r, bre, bim);
-            const double bs = bre + bim;
             const int ns = (HALF_LAST && 2 * sk >= NT) ? NS - 1 : NS;                                    // slots of this k-step
             const int nsn = (HALF_LAST && (2 * sk >= NT || (2 * (sk + 1) >= NT && r == 3))) ? NS - 1 : NS;   // ... of the next one
-            double as[NS];
-#pragma unroll
-            for (int so = 0; so < NS; ++so) as[so] = are[so] + aim[so];
+            const double bre = B.re[sk][r], bim = B.im[sk][r], bsm = B.sm[sk][r];
 #pragma unroll
             for (int so = 0; so < NS; ++so)
-                if (so < ns) p1[so] = MFMA64(are[so], bre, p1[so]);
+                if (so < ns) q.p1[so] = MFMA64(are[so], bre, q.p1[so]);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
 #pragma unroll
@@ -116,25 +163,215 @@ __device__ __forceinline__ void t18_gemm(Strip<NT> &acc, const double *__restric
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int so = 0; so < NS; ++so)
-                if (so < ns) p2[so] = MFMA64(aim[so], bim, p2[so]);
+                if (so < ns) q.p2[so] = MFMA64(aim[so], bim, q.p2[so]);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
 #pragma unroll
                 for (int so = 0; so < NS; ++so)
-                    if (so < nsn) aim[so] = xi[rowoff[so] + kn];
+                    if (so < nsn) aim[so] = xr[PL + rowoff[so] + kn];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int so = 0; so < NS; ++so)
-                if (so < ns) p3[so] = MFMA64(as[so], bs, p3[so]);
+                if (so < ns) q.p3[so] = MFMA64(asu[so], bsm, q.p3[so]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+#pragma unroll
+                for (int so = 0; so < NS; ++so)
+                    if (so < nsn) asu[so] = xr[2 * PL + rowoff[so] + kn];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+// slots 0..NS-1 of a rotated strip to their natural positions in the three planes
+template <int LD, int NS, int NT, class S>
+__device__ __forceinline__ void t18_store_slots(double *R, const S &s, int wave, int lane) {
+    constexpr int PL = 16 * NT * LD;
+    double *x = R + (lane >> 4) * LD + 16 * wave + (lane & 15);
 #pragma unroll
-    for (int so = 0; so < NS; ++so) {
-        acc.re[so] += p1[so] - p2[so];
-        acc.im[so] += p3[so] - p1[so] - p2[so];
+    for (int sl = 0; sl < NS; ++sl) {
+        const int tb = (wave + sl) % NT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (16 * tb + 4 * r) * LD;
+            x[o] = s.re[sl][r];
+            x[PL + o] = s.im[sl][r];
+            x[2 * PL + o] = s.re[sl][r] + s.im[sl][r];
+        }
     }
+}
+// (signed) conjugate transpose of the slot-1 tile (row block w+1, column block w) into position (w, w+1), three planes
+template <int LD, int NT>
+__device__ __forceinline__ void t18_store_adjoint(double *R, const d4 &tre, const d4 &tim, int wave, int lane, double sgn) {
+    constexpr int PL = 16 * NT * LD;
+    const int tb = (wave + 1) % NT, c = lane & 15, rg = lane >> 4;
+    double *x = R + (16 * wave + c) * LD + 16 * tb + rg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double vr = sgn * tre[r], vi = -sgn * tim[r];
+        x[4 * r] = vr;
+        x[PL + 4 * r] = vi;
+        x[2 * PL + 4 * r] = vr + vi;
+    }
+}
+template <int LD, int NT>
+__device__ __forceinline__ void t18_load_strip(const double *R, Strip3M<NT> &s, int wave, int lane) {
+    constexpr int PL = 16 * NT * LD;
+    const double *x = R + (lane >> 4) * LD + 16 * wave + (lane & 15);
+#pragma unroll
+    for (int sl = 0; sl < NT; ++sl) {
+        const int tb = (wave + sl) % NT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (16 * tb + 4 * r) * LD;
+            s.re[sl][r] = x[o]; s.im[sl][r] = x[PL + o]; s.sm[sl][r] = x[2 * PL + o];
+        }
+    }
+}
+// mirrored slot NT-1 of a (skew-)Hermitian matrix whose planes are complete
+template <int LD, int NT>
+__device__ __forceinline__ void t18_load_slot_last(const double *R, Strip3M<NT> &s, int wave, int lane) {
+    constexpr int PL = 16 * NT * LD;
+    const int tb = (wave + NT - 1) % NT;
+    const double *x = R + ((lane >> 4) + 16 * tb) * LD + 16 * wave + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s.re[NT - 1][r] = x[4 * r * LD]; s.im[NT - 1][r] = x[PL + 4 * r * LD]; s.sm[NT - 1][r] = x[2 * PL + 4 * r * LD];
+    }
+}
+// exchange areas (NT waves x 2 planes x 256 doubles): see rot_exch_write / rot_exch_add / rot_exch_read
+template <int NT, int SLOT>
+__device__ __forceinline__ void t18_exch_add(const double *area, Strip3M<NT> &s, int wave, int lane) {
+    const double *src = area + wave * 512 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s.re[SLOT][r] += src[r]; s.im[SLOT][r] += src[256 + r]; }
+}
+template <int NT>
+__device__ __forceinline__ void t18_exch_read_last(const double *area, Strip3M<NT> &s, int wave, int lane) {
+    const double *src = area + wave * 512 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s.re[NT - 1][r] = src[r]; s.im[NT - 1][r] = src[256 + r]; }
+    s.sm[NT - 1] = s.re[NT - 1] + s.im[NT - 1];
+}
+// slots 0..NS-1 of S from the partial products
+template <int NS, int NT>
+__device__ __forceinline__ void t18_combine(const Acc3<NS> &q, Strip3M<NT> &s) {
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        s.re[t] = q.p1[t] - q.p2[t];
+        s.im[t] = q.p3[t] - q.p1[t] - q.p2[t];
+    }
+}
+
+// Formation of a cell's A = -i dt H in the three planes (upper block triangle fetched, both triangles written; see
+// expm_form_a_herm64): issue() requests the operator tiles, commit() combines them with the pulse values.
+template <int NTH, int NT>
+struct T18FormA {
+    static constexpr int NP = 16 * NT, LD = NP + 2, HALF = NP * NP / 2, PL = NP * LD;
+    static constexpr int NTILE = NT * (NT + 1) / 2, NPAIR = 128 * NTILE, NU = (NPAIR + NTH - 1) / NTH;
+    const ExpmArgs &a;
+    double *R;
+    int cell, t;
+    double2 hr[NU], hi[NU], c0r[NU], c0i[NU], c1r[NU], c1i[NU];
+    __device__ __forceinline__ T18FormA(const ExpmArgs &a_, double *R_, int cell_, int t_) : a(a_), R(R_), cell(cell_), t(t_) {}
+    __device__ __forceinline__ void locate(int u, int &i, int &j, bool &diag) const {
+        const int ep = min(t + u * NTH, NPAIR - 1), q = ep >> 7, idx = ep & 127;   // (surplus threads repeat the last pair)
+        int ti = 0, r = q;
+#pragma unroll
+        for (int it = 0; it < NT - 1; ++it)
+            if (r >= NT - ti) { r -= NT - ti; ++ti; }
+        const int tj = ti + r;
+        i = 16 * ti + (idx >> 3);
+        j = 16 * tj + 2 * (idx & 7);
+        diag = ti == tj;
+    }
+    __device__ __forceinline__ void issue() {
+        const int kc = cell / a.N_T;
+        const int k = a.rep ? a.rep[kc] : kc;
+        const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
+        const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
+        const size_t o1 = a.L > 1 ? (size_t)2 * HALF : 0;   // (one control: the same tile again, unused)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            int i, j; bool dg;
+            locate(u, i, j, dg);
+            const int off = (i * NP + j) >> 1;
+            hr[u] = h0[off]; hi[u] = h0[HALF + off];
+            c0r[u] = hc[off]; c0i[u] = hc[HALF + off];
+            c1r[u] = hc[o1 + off]; c1i[u] = hc[o1 + HALF + off];
+        }
+    }
+    __device__ __forceinline__ void commit() {
+        const int kc = cell / a.N_T, n = cell - kc * a.N_T;
+        const int k = a.rep ? a.rep[kc] : kc;
+        const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
+        const double dt = a.dts[n];
+        double e[8];
+        for (int l = 0; l < a.L; ++l) {
+            e[l] = a.eps[(size_t)l * a.N_T + n];
+            if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            int i, j; bool dg;
+            locate(u, i, j, dg);
+            double2 xr = hr[u], xi = hi[u];
+            xr.x = fma(e[0], c0r[u].x, xr.x); xr.y = fma(e[0], c0r[u].y, xr.y);
+            xi.x = fma(e[0], c0i[u].x, xi.x); xi.y = fma(e[0], c0i[u].y, xi.y);
+            if (a.L > 1) {
+                xr.x = fma(e[1], c1r[u].x, xr.x); xr.y = fma(e[1], c1r[u].y, xr.y);
+                xi.x = fma(e[1], c1i[u].x, xi.x); xi.y = fma(e[1], c1i[u].y, xi.y);
+            }
+            const int off = (i * NP + j) >> 1;
+            for (int l = 2; l < a.L; ++l) {   // (more than two controls: fetched here)
+                const double2 cr = hc[(size_t)l * 2 * HALF + off], ci = hc[(size_t)l * 2 * HALF + HALF + off];
+                xr.x = fma(e[l], cr.x, xr.x); xr.y = fma(e[l], cr.y, xr.y);
+                xi.x = fma(e[l], ci.x, xi.x); xi.y = fma(e[l], ci.y, xi.y);
+            }
+            const double ar0 = dt * xi.x, ar1 = dt * xi.y, ai0 = -dt * xr.x, ai1 = -dt * xr.y;
+            double *p = R + i * LD + j;
+            p[0] = ar0; p[1] = ar1;
+            p[PL] = ai0; p[PL + 1] = ai1;
+            p[2 * PL] = ar0 + ai0; p[2 * PL + 1] = ar1 + ai1;
+            if (!dg) {   // mirrored tile: a_ji = -conj(a_ij)
+                double *m = R + j * LD + i;
+                m[0] = -ar0; m[LD] = -ar1;
+                m[PL] = ai0; m[PL + LD] = ai1;
+                m[2 * PL] = ai0 - ar0; m[2 * PL + LD] = ai1 - ar1;
+            }
+        }
+    }
+};
+
+// ||A||_1 of the A in the planes (credited statistics only, cells whose operator-norm bound does not certify the order):
+// all threads; returns the norm to everybody
+template <int NT>
+__device__ __forceinline__ double t18_norm1(double *smem, const int tid) {
+    using LY = T18Lds<NT>;
+    constexpr int NP = LY::NP, LD = LY::LD, NTH = LY::NTH, PARTS = NTH / NP;
+    double *red = smem + LY::RED;
+    const int j = tid % NP, part = tid / NP;
+    double sum = 0.;
+    for (int i = part; i < NP; i += PARTS) {
+        const double xr = smem[i * LD + j], xi = smem[LY::PL + i * LD + j];
+        sum += fast_sqrt(xr * xr + xi * xi);
+    }
+    red[tid] = sum;
+    __syncthreads();
+    if (tid < 64) {
+        double c = 0.;
+        if (tid < NP)
+            for (int p = 0; p < PARTS; ++p) c += red[p * NP + tid];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c = fmax(c, __shfl_xor(c, off, 64));
+        if (tid == 0) red[NTH] = c;
+    }
+    __syncthreads();
+    const double nA = red[NTH];
+    __syncthreads();   // red is written again inside the cell
+    return nA;
 }
 
 // matrix instructions per wave of one cell without squarings / of one squaring (executed-work counter)
@@ -147,57 +384,78 @@ struct T18Count {
     static constexpr int CELL = 2 * SQH + HP + 2 * GP;
 };
 
-// One cell: A = -i dt H (skew-Hermitian) is in the A region of the LDS; returns U = exp(A) as a ROTATED column strip
-// (slot s of wave w = row tile (w + s) % NT, all NT slots) and the number of squarings that were applied.
-template <int NT, class Hook = T18NoHook>
-__device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, const int lane, Strip<NT> &T, int &s_out,
-                                              bool &bad, Hook hook = Hook()) {
-    using LY = ExpmLds<NT>;
-    constexpr int NP = LY::NP, LD = LY::LD, NS = NT - 1;
-    double *Are = smem, *Aim = Are + NP * LD, *Xre = smem + LY::REG, *Xim = Xre + NP * LD;
-    double *exch = smem + 2 * LY::REG, *red = exch + LY::DV;
-    Strip<NT> As, A2, A3, A6;
-    rot_load_strip<LD, NT>(Are, Aim, As, wave, lane);
+// One cell: A = -i dt H (skew-Hermitian) is in the planes; returns U = exp(A) as a ROTATED column strip (slot s of wave w
+// = row tile (w + s) % NT, all NT slots) and the number of squarings that were applied.  On return other waves may
+// still be reading the planes.
+template <int NT, class HookFirst, class HookLast>
+__device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, const int lane, Strip3M<NT> &U, int &s_out,
+                                              bool &bad, HookFirst hook_first, HookLast hook_last) {
+    using LY = T18Lds<NT>;
+    constexpr int LD = LY::LD, NS = NT - 1;
+    double *R = smem, *e1 = smem + LY::E1, *e2 = smem + LY::E2, *red = smem + LY::RED;
+    const T18NoHook nohook;
+    Strip3M<NT> As, A2, A3, A6;
+    t18_load_strip<LD, NT>(R, As, wave, lane);
+    T18_STOP_AT(1, U, As);
     // ---- A2 = A A (Hermitian) ----
-    strip_zero(A2);
-    t18_gemm<LD, NS, NT, NT == 4>(A2, Are, Aim, wave, lane,
-        [&](int sk, int r, double &br, double &bi) { br = As.re[sk][r]; bi = As.im[sk][r]; }, T18NoHook());
-    if constexpr (NT == 4) {   // slot 2 += (partial sum of wave w+2)^dagger, through the idle X region
-        rot_exch_write<NT, 2>(Xre, A2.re[2], A2.im[2], wave, lane, 1.0);
-        __syncthreads();
-        rot_exch_add<NT, 2>(Xre, A2, wave, lane);
+    {
+        Acc3<NS> q;
+        acc3_zero(q);
+        t18_gemm<LD, NS, NT, NT == 4>(q, R, As, wave, lane, hook_first);
+        t18_combine<NS, NT>(q, A2);
     }
-    // the mirrored tile of A2 travels while the first NT - 1 k-blocks of the next product run
-    rot_exch_write<NT>(exch, A2.re[1], A2.im[1], wave, lane, 1.0);
-    // ---- A3 = A A2 (skew-Hermitian) ----
-    strip_zero(A3);
-    t18_gemm<LD, NS, NT, false>(A3, Are, Aim, wave, lane,
-        [&](int sk, int r, double &br, double &bi) { br = A2.re[sk][r]; bi = A2.im[sk][r]; },
-        [&](int sk) { if (sk == NT - 1) { __syncthreads(); rot_exch_read<NT>(exch, A2, wave, lane); } });
-    // (every wave is past the barrier inside the product: the exchange tiles in the X region have been consumed)
-    rot_store_slots<LD, NS, NT>(Xre, Xim, A3, wave, lane);                    // X = A3, with the mirrored tiles
-    rot_store_adjoint<LD, NT>(Xre, Xim, A3.re[1], A3.im[1], wave, lane, -1.0);
+    if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A2.re[2], A2.im[2], wave, lane, 1.0);   // partial sum of tile (w+2, w) -> wave w+2
+    rot_exch_write<NT>(e2, A2.re[1], A2.im[1], wave, lane, 1.0);                             // mirrored tile -> wave w+1
+#pragma unroll
+    for (int t = 0; t < 2; ++t) A2.sm[t] = A2.re[t] + A2.im[t];
+    T18_STOP_AT(2, U, A2);
+    STAMP(2);
+    // ---- A3 = A A2 (skew-Hermitian); the exchanged tiles of A2 arrive while the first k-blocks run ----
+    {
+        Acc3<NS> q;
+        acc3_zero(q);
+        t18_gemm<LD, NS, NT, false>(q, R, A2, wave, lane, [&](int sk, int r) {
+            if (sk == 2 && r == 0) {
+                __syncthreads();
+                if constexpr (NT == 4) { t18_exch_add<NT, 2>(e1, A2, wave, lane); A2.sm[2] = A2.re[2] + A2.im[2]; }
+                t18_exch_read_last<NT>(e2, A2, wave, lane);
+            }
+        });
+        t18_combine<NS, NT>(q, A3);
+    }
+    T18_STOP_AT(3, U, A3);
+    STAMP(3);
     const double n2w = t18_colsum_max<NT>(A2);
-    __syncthreads();                                                          // A is dead from here on
-    rot_load_slot3<LD, NT>(Xre, Xim, A3, wave, lane);
-    // ---- A6 = A3 A3 (Hermitian) ----
-    strip_zero(A6);
-    t18_gemm<LD, NS, NT, NT == 4>(A6, Xre, Xim, wave, lane,
-        [&](int sk, int r, double &br, double &bi) { br = A3.re[sk][r]; bi = A3.im[sk][r]; }, hook);
-    if constexpr (NT == 4) {
-        rot_exch_write<NT, 2>(exch, A6.re[2], A6.im[2], wave, lane, 1.0);
-        __syncthreads();
-        rot_exch_add<NT, 2>(exch, A6, wave, lane);
-        __syncthreads();
-    }
-    rot_exch_write<NT>(exch, A6.re[1], A6.im[1], wave, lane, 1.0);
     if (lane == 0) red[wave] = n2w;
-    __syncthreads();                                                          // (also: everybody is done reading X = A3)
-    rot_exch_read<NT>(exch, A6, wave, lane);
+    __syncthreads();                                                          // everybody is done reading A
+    t18_store_slots<LD, NS, NT>(R, A3, wave, lane);                           // planes = A3, with the mirrored tiles
+    t18_store_adjoint<LD, NT>(R, A3.re[1], A3.im[1], wave, lane, -1.0);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) A3.sm[t] = A3.re[t] + A3.im[t];
+    __syncthreads();
+    t18_load_slot_last<LD, NT>(R, A3, wave, lane);
+    T18_STOP_AT(4, U, A3);
+    STAMP(4);
+    // ---- A6 = A3 A3 (Hermitian) ----
+    {
+        Acc3<NS> q;
+        acc3_zero(q);
+        t18_gemm<LD, NS, NT, NT == 4>(q, R, A3, wave, lane, nohook);
+        t18_combine<NS, NT>(q, A6);
+    }
+    T18_STOP_AT(5, U, A6);
+    STAMP(5);
+    if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A6.re[2], A6.im[2], wave, lane, 1.0);
+    rot_exch_write<NT>(e2, A6.re[1], A6.im[1], wave, lane, 1.0);
+    __syncthreads();                                                          // (also: everybody is done reading the planes)
+    if constexpr (NT == 4) t18_exch_add<NT, 2>(e1, A6, wave, lane);
+    t18_exch_read_last<NT>(e2, A6, wave, lane);
     const double n6w = t18_colsum_max<NT>(A6);
     if (lane == 0) red[NT + wave] = n6w;
-    // B1 needs the scaling, the scaling needs the norm of A6 of every wave: one more barrier
+    // the scaling needs the norm of A6 of every wave: one more barrier
     __syncthreads();
+    T18_STOP_AT(6, U, A6);
+    STAMP(6);
     double n2 = red[0], n6 = red[NT];
 #pragma unroll
     for (int w = 1; w < NT; ++w) { n2 = fmax(n2, red[w]); n6 = fmax(n6, red[NT + w]); }
@@ -219,73 +477,76 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
         }
     }
     s_out = s;
-    // ---- B1 -> X region ----
-    {
-        Strip<NT> B;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            B.re[t] = T18_A1 * As.re[t] + T18_A2 * A2.re[t] + T18_A3 * A3.re[t];
-            B.im[t] = T18_A1 * As.im[t] + T18_A2 * A2.im[t] + T18_A3 * A3.im[t];
-        }
-        rot_store_slots<LD, NT, NT>(Xre, Xim, B, wave, lane);
-    }
-    // ---- A9 = B1 B5 + B4 ----  (B4 is added behind the product: as a start value it would occupy 64 more registers
-    // while the four strips, the three partial-product sets and the operands are live)
-    Strip<NT> A9;
-    strip_zero(A9);
+    // ---- ONE pass over the powers: B1 -> planes, B5 (right operand), B4 (start value of A9), B3 and B2 (kept) ----
+    Strip3M<NT> B5;
+    Acc3<NT> q;
+    Strip<NT> B3, B2;
     const int cdiag = lane & 15, rgd = lane >> 4;   // the diagonal tile is slot 0: row 4r + rg == column c
-    __syncthreads();
-    t18_gemm<LD, NT, NT, false>(A9, Xre, Xim, wave, lane,
-        [&](int sk, int r, double &br, double &bi) {
-            br = T18_E2 * A2.re[sk][r] + T18_E3 * A3.re[sk][r] + T18_E6 * A6.re[sk][r];
-            bi = T18_E2 * A2.im[sk][r] + T18_E3 * A3.im[sk][r] + T18_E6 * A6.im[sk][r];
-        }, hook);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        A9.re[t] += T18_D1 * As.re[t] + T18_D2 * A2.re[t] + T18_D3 * A3.re[t] + T18_D6 * A6.re[t];
-        A9.im[t] += T18_D1 * As.im[t] + T18_D2 * A2.im[t] + T18_D3 * A3.im[t] + T18_D6 * A6.im[t];
-    }
+        Strip3M<NT> &B1 = U;   // (U is free until the last product: its slots carry B1 to the planes)
+        B1.re[t] = T18_A1 * As.re[t] + T18_A2 * A2.re[t] + T18_A3 * A3.re[t];
+        B1.im[t] = T18_A1 * As.im[t] + T18_A2 * A2.im[t] + T18_A3 * A3.im[t];
+        B5.re[t] = T18_E2 * A2.re[t] + T18_E3 * A3.re[t] + T18_E6 * A6.re[t];
+        B5.im[t] = T18_E2 * A2.im[t] + T18_E3 * A3.im[t] + T18_E6 * A6.im[t];
+        B5.sm[t] = B5.re[t] + B5.im[t];
+        d4 b4r = T18_D1 * As.re[t] + T18_D2 * A2.re[t] + T18_D3 * A3.re[t] + T18_D6 * A6.re[t];
+        const d4 b4i = T18_D1 * As.im[t] + T18_D2 * A2.im[t] + T18_D3 * A3.im[t] + T18_D6 * A6.im[t];
+        B3.re[t] = T18_C1 * As.re[t] + T18_C2 * A2.re[t] + T18_C3 * A3.re[t] + T18_C6 * A6.re[t];
+        B3.im[t] = T18_C1 * As.im[t] + T18_C2 * A2.im[t] + T18_C3 * A3.im[t] + T18_C6 * A6.im[t];
+        B2.re[t] = T18_B1 * As.re[t] + T18_B2 * A2.re[t] + T18_B3 * A3.re[t] + T18_B6 * A6.re[t];
+        B2.im[t] = T18_B1 * As.im[t] + T18_B2 * A2.im[t] + T18_B3 * A3.im[t] + T18_B6 * A6.im[t];
+        if (t == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (4 * r + rgd == cdiag) A9.re[0][r] += T18_D0;
-    // ---- p = B2 + (B3 + A9) A9 ----
-    __syncthreads();                                                          // everybody is done reading X = B1
-    {
-        Strip<NT> Lm;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            Lm.re[t] = A9.re[t] + T18_C1 * As.re[t] + T18_C2 * A2.re[t] + T18_C3 * A3.re[t] + T18_C6 * A6.re[t];
-            Lm.im[t] = A9.im[t] + T18_C1 * As.im[t] + T18_C2 * A2.im[t] + T18_C3 * A3.im[t] + T18_C6 * A6.im[t];
+            for (int r = 0; r < 4; ++r)
+                if (4 * r + rgd == cdiag) { b4r[r] += T18_D0; B3.re[0][r] += T18_C0; }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * r + rgd == cdiag) Lm.re[0][r] += T18_C0;
-        rot_store_slots<LD, NT, NT>(Xre, Xim, Lm, wave, lane);
+        // A9 = B1 B5 + B4 through the start values: re = p1 - p2, im = p3 - p1 - p2
+        q.p1[t] = b4r; q.p2[t] = (d4){0., 0., 0., 0.}; q.p3[t] = b4r + b4i;
     }
+    t18_store_slots<LD, NT, NT>(R, U, wave, lane);                            // planes = B1 (free since the last barrier)
+    __syncthreads();
+    T18_STOP_AT(7, U, B5);
+    STAMP(7);
+    // ---- A9 = B1 B5 + B4 ----
+    t18_gemm<LD, NT, NT, false>(q, R, B5, wave, lane, nohook);
+    Strip3M<NT> A9;
+    t18_combine<NT, NT>(q, A9);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) A9.sm[t] = A9.re[t] + A9.im[t];
+    T18_STOP_AT(8, U, A9);
+    STAMP(8);
+    // ---- p = B2 + (B3 + A9) A9 ----
+    __syncthreads();                                                          // everybody is done reading B1
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        T.re[t] = T18_B1 * As.re[t] + T18_B2 * A2.re[t] + T18_B3 * A3.re[t] + T18_B6 * A6.re[t];
-        T.im[t] = T18_B1 * As.im[t] + T18_B2 * A2.im[t] + T18_B3 * A3.im[t] + T18_B6 * A6.im[t];
+        U.re[t] = A9.re[t] + B3.re[t];
+        U.im[t] = A9.im[t] + B3.im[t];
+        q.p1[t] = B2.re[t]; q.p2[t] = (d4){0., 0., 0., 0.}; q.p3[t] = B2.re[t] + B2.im[t];
     }
+    t18_store_slots<LD, NT, NT>(R, U, wave, lane);                            // planes = B3 + A9
     __syncthreads();
-    t18_gemm<LD, NT, NT, false>(T, Xre, Xim, wave, lane,
-        [&](int sk, int r, double &br, double &bi) { br = A9.re[sk][r]; bi = A9.im[sk][r]; }, hook);
+    T18_STOP_AT(9, U, A9);
+    STAMP(9);
+    t18_gemm<LD, NT, NT, false>(q, R, A9, wave, lane, hook_last);
+    t18_combine<NT, NT>(q, U);
+    STAMP(10);
     // ---- squarings ----
     for (int it = 0; it < s; ++it) {
         __syncthreads();
-        rot_store_slots<LD, NT, NT>(Xre, Xim, T, wave, lane);
+        t18_store_slots<LD, NT, NT>(R, U, wave, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) U.sm[t] = U.re[t] + U.im[t];
         __syncthreads();
-        Strip<NT> Sq;
-        strip_zero(Sq);
-        t18_gemm<LD, NT, NT, false>(Sq, Xre, Xim, wave, lane,
-            [&](int sk, int r, double &br, double &bi) { br = T.re[sk][r]; bi = T.im[sk][r]; }, T18NoHook());
-        T = Sq;
+        acc3_zero(q);
+        t18_gemm<LD, NT, NT, false>(q, R, U, wave, lane, nohook);
+        t18_combine<NT, NT>(q, U);
     }
 }
 
 // store of a rotated strip as U_kn (row-major interleaved complex)
 template <int NT>
-__device__ __forceinline__ void t18_store_u(const ExpmArgs &a, const int cell, const int wave, const int lane, const Strip<NT> &T) {
+__device__ __forceinline__ void t18_store_u(const ExpmArgs &a, const int cell, const int wave, const int lane, const Strip3M<NT> &T) {
     constexpr int NP = 16 * NT;
     double2 *Uc = a.U + (size_t)cell * NP * NP;
     const int col = 16 * wave + (lane & 15), rg = lane >> 4;
@@ -297,15 +558,25 @@ __device__ __forceinline__ void t18_store_u(const ExpmArgs &a, const int cell, c
     }
 }
 
+// one slot (row tile) of the above: four 16-byte stores per lane in front of a k-block of the NEXT cell's first product
+template <int NT>
+__device__ __forceinline__ void t18_store_u_slot(const ExpmArgs &a, const int cell, const int wave, const int lane, const Strip<NT> &T,
+                                                 const int sl) {
+    constexpr int NP = 16 * NT;
+    double2 *Uc = a.U + (size_t)cell * NP * NP;
+    const int col = 16 * wave + (lane & 15), rg = lane >> 4, tb = (wave + sl) % NT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Uc[(16 * tb + 4 * r + rg) * NP + col] = make_double2(T.re[sl][r], T.im[sl][r]);
+}
+
 // Persistent launch: one workgroup per CU walks a round-robin share of the cells of its XCD (neighbouring cells of the
 // same trajectories run concurrently on one XCD: H0_k stays in that XCD's L2).  The credited statistics (Pade order and
 // squarings Julia's exp! would use) come from the 1-norm bound of the operators or, outside its certifying
 // window, from the measured norm, exactly as in expm_persistent; the executed work is counted separately.
 template <int NT>
 __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
-    using LY = ExpmLds<NT>;
+    using LY = T18Lds<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *red = smem + 2 * LY::REG + LY::DV;
     const int tid0 = threadIdx.x, lane0 = tid0 & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int ncell = a.K * a.N_T;
@@ -313,22 +584,31 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
     const int lo = (int)((long)x * ncell / 8), hi = (int)((long)(x + 1) * ncell / 8);
     int st_s = 0, st_max = 0, st_ord[5] = {0, 0, 0, 0, 0}, st_sq = 0, st_cells = 0;
     bool any_bad = false;
-    for (int cell = lo + ((int)blockIdx.x >> 3); cell < hi; cell += per_x) {
+    // Software pipeline over the cells of this workgroup: the result of cell c is stored between the matrix instructions
+    // of the first product of cell c+1, the operator tiles of cell c+1 are requested in front of the last product of
+    // cell c (lowest register pressure of the cell) and combined into the planes behind it.
+    Strip<NT> Uprev;
+    strip_zero(Uprev);
+    int prev = -1;
+    const int first = lo + ((int)blockIdx.x >> 3);
+    if (first < hi) {
+        T18FormA<64 * NT, NT> fa(a, smem, first, tid0);
+        fa.issue();
+        fa.commit();
+    }
+    __syncthreads();
+    for (int cell = first; cell < hi; cell += per_x) {
         int lane = lane0, tid = tid0;
         asm volatile("" : "+v"(lane), "+v"(tid));   // per-lane addresses are recomputed per cell (see expm_persistent)
-        const double bound = expm_norm_bound(a, cell);
-        expm_form_a_herm64<64 * NT, NT>(a, cell, smem, tid);
+#ifdef GRAPE_DIAG
+        if (tid == 0) g_diag_off[blockIdx.x & 1023] = (cell != first + per_x);
         __syncthreads();
+#endif
+        STAMP(0);
         // credited work: what Julia's exp! would do for this cell (order and squarings from ||A||_1)
+        const double bound = expm_norm_bound(a, cell);
         double nA = bound;
-        if (!(bound > 2.1 && bound <= 5.4)) {
-            expm_norm_partial<NT>(smem, tid, LY::NTH / LY::NP);
-            __syncthreads();
-            expm_norm_combine<NT>(smem, tid, LY::NTH / LY::NP);
-            __syncthreads();
-            nA = red[LY::NTH];
-            __syncthreads();   // red is written again inside the cell
-        }
+        if (!(bound > 2.1 && bound <= 5.4)) nA = t18_norm1<NT>(smem, tid);
         int sj = 0;
         if (nA > 5.4) {
             const double r = nA / 5.4;
@@ -336,16 +616,36 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
             sj = (r == ldexp(1.0, e)) ? e : e + 1;
         }
         const int oj = nA > 2.1 ? 4 : nA > 0.95 ? 3 : nA > 0.25 ? 2 : nA > 0.015 ? 1 : 0;
-        Strip<NT> T;
+        Strip3M<NT> U;
         int s;
         bool bad;
-        expm_t18_cell<NT>(smem, wave, lane, T, s, bad);
-        t18_store_u<NT>(a, cell, wave, lane, T);
+        STAMP(1);
+        const int next = cell + per_x;
+        const bool have_next = next < hi;
+        T18FormA<64 * NT, NT> fa(a, smem, have_next ? next : cell, tid);   // (no next cell: the same tiles again, not committed)
+        expm_t18_cell<NT>(smem, wave, lane, U, s, bad,
+            [&](int sk, int r) { if (r == 0 && prev >= 0) t18_store_u_slot<NT>(a, prev, wave, lane, Uprev, sk); },
+            [&](int sk, int r) { if (sk == 1 && r == 0) fa.issue(); });   // (fenced by scheduling barriers on both sides)
+        STAMP(11);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { Uprev.re[t] = U.re[t]; Uprev.im[t] = U.im[t]; }
+        prev = cell;
         any_bad |= bad;
         st_s += sj; st_max = max(st_max, sj); st_ord[oj] += 1;
         st_sq += s; st_cells += 1;
-        __syncthreads();   // the next cell writes the A region (read by slow waves as exchange area / product operand)
+        __syncthreads();   // everybody is done reading the planes
+        STAMP(12);
+        if (have_next) fa.commit();
+        __syncthreads();
+        STAMP(13);
     }
+    if (prev >= 0) {
+#pragma unroll
+        for (int sl = 0; sl < NT; ++sl) t18_store_u_slot<NT>(a, prev, wave, lane0, Uprev, sl);
+    }
+#ifdef GRAPE_DIAG
+    if (tid0 == 0) g_diag_off[blockIdx.x & 1023] = 0;
+#endif
     if (tid0 == 0) {
         stat_add(a.stats, 0, (unsigned long long)st_s);
 #pragma unroll

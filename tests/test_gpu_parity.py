@@ -601,6 +601,9 @@ def test_persistent_phase_a_matches_per_cell_launch_and_keeps_the_pivoted_fallba
             pr["Hc"][1, :, :2] = 0
             pr["pulsevals"][[3, 300, 559]] = np.pi
         args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
+        # Hermitian generators take the inverse-free polynomial kernel by default: the Pade kernels are selected with
+        # GRAPE_EXPM_T18=0 (read at grape_create), and the default path is compared with them below
+        monkeypatch.setenv("GRAPE_EXPM_T18", "0")
         with g.GrapeHip(*args) as h:
             J, G, tau = h.eval(pr["pulsevals"])
             w = h.work()
@@ -611,7 +614,25 @@ def test_persistent_phase_a_matches_per_cell_launch_and_keeps_the_pivoted_fallba
             w0 = h0.work()
             U0 = h0.propagator(1, 7)
         monkeypatch.delenv("GRAPE_EXPM_PERSIST")
+        monkeypatch.delenv("GRAPE_EXPM_T18")
         assert J == J0 and np.array_equal(G, G0) and np.array_equal(tau, tau0) and np.array_equal(U, U0)
+        if herm:
+            # the polynomial kernel on the same problem -- pi-pulse cells (no denominator: nothing to pivot), short steps,
+            # the step that needs a squaring in the Pade route: same credited work, results equal to rounding
+            with g.GrapeHip(*args) as ht:
+                Jt, Gt, taut = ht.eval(pr["pulsevals"])
+                wt = ht.work()
+                Ut = np.stack([ht.propagator(1, n) for n in (3, 5, 7, 300)])
+            assert wt["t18_cells"] == K * N_T and wt["pivoted_cells"] == 0
+            assert wt["flop_expm"] == w["flop_expm"] and wt["squarings"] == w["squarings"]
+            assert abs(Jt - J) <= TOL_J and np.abs(taut - tau).max() <= TOL_TAU and np.abs(Gt - G).max() <= tol_G(G)
+            monkeypatch.setenv("GRAPE_EXPM_T18", "0")
+            with g.GrapeHip(*args) as hp:
+                hp.eval(pr["pulsevals"])
+                Up = np.stack([hp.propagator(1, n) for n in (3, 5, 7, 300)])
+            monkeypatch.delenv("GRAPE_EXPM_T18")
+            assert np.abs(Ut - Up).max() <= 2e-14
+            assert np.abs(np.einsum("nij,nik->njk", Ut.conj(), Ut) - np.eye(N)).max() <= 1e-13
         assert w["squarings"] == w0["squarings"] > 0 and w["pivoted_cells"] == w0["pivoted_cells"]
         assert w["flop_expm"] == w0["flop_expm"]
         if herm:
@@ -643,7 +664,8 @@ def test_exponential_paths_differential_on_random_grids(g, ref, case, monkeypatc
     tl = np.concatenate([[0.0], np.cumsum(scale * (0.5 + rng.random(N_T)))])
     args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
     res = {}
-    for name, env in (("persist", {}), ("percell", {"GRAPE_EXPM_PERSIST": "0"}), ("general", {"GRAPE_NO_HERM": "1"})):
+    for name, env in (("t18", {}), ("persist", {"GRAPE_EXPM_T18": "0"}),
+                      ("percell", {"GRAPE_EXPM_T18": "0", "GRAPE_EXPM_PERSIST": "0"}), ("general", {"GRAPE_NO_HERM": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with g.GrapeHip(*args) as h:
@@ -653,8 +675,13 @@ def test_exponential_paths_differential_on_random_grids(g, ref, case, monkeypatc
             monkeypatch.delenv(k)
     assert res["persist"][0] == res["percell"][0] and np.array_equal(res["persist"][1], res["percell"][1])
     assert np.array_equal(res["persist"][2], res["percell"][2])
+    # the inverse-free polynomial kernel (default for Hermitian generators, N > 32) against the Pade kernel
+    assert abs(res["t18"][0] - res["persist"][0]) <= TOL_J
+    assert np.abs(res["t18"][1] - res["persist"][1]).max() <= tol_G(res["persist"][1])
+    assert np.abs(res["t18"][2] - res["persist"][2]).max() <= 1e-12
     assert abs(res["persist"][0] - res["general"][0]) <= TOL_J
     assert np.abs(res["persist"][1] - res["general"][1]).max() <= tol_G(res["general"][1])
     assert np.abs(res["persist"][2] - res["general"][2]).max() <= 1e-12
     Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], gradient_method=ref.TAYLOR)
     assert abs(res["persist"][0] - Jr) <= TOL_J and np.abs(res["persist"][1] - Gr).max() <= tol_G(Gr)
+    assert abs(res["t18"][0] - Jr) <= TOL_J and np.abs(res["t18"][1] - Gr).max() <= tol_G(Gr)
