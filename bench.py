@@ -192,12 +192,11 @@ def main():
             ev.eval_device(stream)
             G_host.copy_(G, non_blocking=True)
             sums_host.copy_(out[2 * K_local:2 * K_local + 8], non_blocking=True)
-            try:
-                h.check(stream)    # synchronises the stream and raises on a device-side error flag
+            again = ev.check_collective(stream)   # GRAPE_ERR_AGAIN (N > 64) is decided by ALL ranks together
+            if not again:
                 break
-            except g.GrapeHipError as exc:   # GRAPE_ERR_AGAIN (N > 64): the launch plan was adapted, repeat once
-                if exc.code != -7 or attempt:
-                    raise
+            if attempt:
+                raise g.GrapeHipError(-7, "the squaring plan was still too short after one repetition")
         return None
 
     for i in range(args.warmup):
@@ -243,18 +242,42 @@ def main():
     if rank == 0:
         # HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes of tools/pmc.sh
         # (separate run: counters cannot be collected inside the timed bench), see profiles/.
-        traffic, hw_util, pmc_file = None, None, None
+        traffic, hw_util, pmc_file, pmc_mops = None, None, None, None
         try:
-            pmc_file = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))[-1]
-            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            for kname, d in pmc["kernels"].items():
-                if kname.startswith(("void expm_pade_kernel", "void expm_persistent_kernel")) and d.get("MfmaUtil_percent", 0) > 1:   # the fast pass
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"_pmc_summary_{args.config}.json"))
+            pmc_file = cands[-1] if cands else None
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file))) if pmc_file else {"kernels": {}}
+            for kname, d in pmc["kernels"].items():   # the dominant kernel of phase A of THIS configuration
+                if any(t in kname for t in ("expm_t18_kernel", "expm_pade_kernel", "expm_persistent_kernel", "lg_gemm_kernel")) \
+                        and d.get("MfmaUtil_percent", 0) > 1:
                     traffic = d.get("hbm_bytes_per_launch")
                     hw_util = d.get("MfmaUtil_percent")
+                    pmc_mops = d.get("SQ_INSTS_VALU_MFMA_MOPS_F64")
         except Exception:
             pass
         expm_ms = tm["expm"]
-        achieved = work["flop_expm"] / (expm_ms * 1e-3) * 1e-12
+        algorithmic = work["flop_expm"] / (expm_ms * 1e-3) * 1e-12
+        # EXECUTED matrix-instruction flop per launch: counted by the kernel itself on the inverse-free path (2048 flop per
+        # v_mfma_f64_16x16x4 issued; the PMC counter SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 in profiles/ must agree), otherwise
+        # from the committed PMC summary of this configuration; frac = executed / time / peak is <= 1 by construction
+        executed_flop, executed_src = None, None
+        if work.get("t18_mfma_flop", 0.0) > 0.0:
+            executed_flop, executed_src = work["t18_mfma_flop"], "kernel counter (grape_get_work[9]), this run"
+        elif pmc_mops and N <= 64:
+            executed_flop, executed_src = pmc_mops * 512.0, f"profiles/{pmc_file} (PMC SQ_INSTS_VALU_MFMA_MOPS_F64 x 512; NOT measured in this run)"
+        achieved = executed_flop / (expm_ms * 1e-3) * 1e-12 if executed_flop else None
+        if N <= 16:
+            sweep_kernel = "sweep16_pair_kernel (one wave per trajectory and direction)"
+        elif N <= 64:
+            sweep_kernel = "sweep_pair_kernel (forward and backward sweep in one launch)"
+        else:
+            sweep_kernel = "sweep_coop_kernel (several workgroups per trajectory, forward then backward)"
+        if N > 64:
+            expm_kernel = "lg_gemm_kernel chain (blocked path)"
+        elif work.get("t18_cells", 0.0) > 0.0:
+            expm_kernel = "expm_t18_kernel<%d> (inverse-free degree-18 polynomial, five products)" % ((N + 15) // 16)
+        else:
+            expm_kernel = ("expm_persistent_kernel<4,...>" if N > 48 else "expm_pade_kernel<%d,...>" % ((N + 15) // 16)) + " (order-13 Pade)"
         res = {
             "metric": "GRAPE gradient evals/sec (N=64, 1000 steps, 128 traj)" if args.config == "C3"
                       else f"GRAPE gradient evals/sec ({args.config})",
@@ -277,29 +300,32 @@ def main():
                                    f"{K_local} trajectories per GPU ({K_total} total), J_T_sm, ExpProp",
                        "gradient_method": "gradgen (exact derivative via the series of the gradient-generator "
                                           "propagator on the extended state)",
-                       "one_eval": "one shard evaluation = functional + full gradient of 128 trajectories; "
+                       "one_eval": f"one shard evaluation = functional + full gradient of {K_local} trajectories; "
                                    "value counts shard evaluations completed by all ranks per second",
                        "global_problem_evals_per_s": args.steps / elapsed},
-            "roofline": {"bound": "mfma", "kernel": (("expm_persistent_kernel<4,...>" if N > 48 else "expm_pade_kernel<%d,...>" % ((N + 15) // 16)) if N <= 64
-                                                     else "lg_gemm_kernel chain (blocked Pade-13)") + " (v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": expm_kernel + " (v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS if achieved else None,
+                         "executed_flop_per_launch": executed_flop, "executed_flop_source": executed_src,
+                         "algorithmic_achieved": algorithmic, "algorithmic_frac": algorithmic / PEAK_FP64_MFMA_TFLOPS,
+                         "flop_per_launch": work["flop_expm"], "avg_launch_ms": expm_ms,
+                         "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE); algorithmic bytes per launch = "
-                                         "K*N_T*N^2*16 (U store) = 8.39e9",
+                                         f"K*N_T*N^2*16 (U store) = {16.0 * work['expm_cells'] * N * N:.3e}",
                          "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc passes of tools/pmc.sh; NOT "
                                            "measured in this run)" if pmc_file else None,
-                         "flop_per_launch": work["flop_expm"], "avg_launch_ms": expm_ms,
                          "hw_mfma_busy_percent": hw_util,
                          "hw_mfma_busy_source": f"profiles/{pmc_file} (PMC SQ_VALU_MFMA_BUSY_CYCLES, NOT measured in this run)"
                                                 if pmc_file else None,
-                         "note": "achieved / frac = ALGORITHMIC flops (SURVEY 8d model: 8N^3 per complex GEMM, full "
-                                 "matrices) per second over the measured launch time.  The kernel executes fewer: complex "
-                                 "products are 3 real MFMA products instead of 4 (3M scheme) and, for Hermitian "
-                                 "generators, a quarter of the tiles follow by symmetry.  The hardware matrix pipe is "
-                                 "therefore busy for hw_mfma_busy_percent of the time (PMC, profiles/), not for frac",
-                         "flop_model": "SURVEY 8d F_exp = (6+s)*8N^3 + (32/3)N^3 per Pade-13 cell"},
+                         "note": "frac = matrix-instruction flop the kernel EXECUTES per second / peak (a hardware fraction, "
+                                 "<= 1).  algorithmic_frac = the credited work of SURVEY 8d (what Julia's exp! would do for "
+                                 "the same cells: order-13 Pade with 8N^3 per complex GEMM) per second / peak; it exceeds frac "
+                                 "because this build executes less than it is credited for: complex products are 3 real MFMA "
+                                 "products (3M), Hermitian symmetry supplies a quarter of the tiles of three products, and "
+                                 "Hermitian generators take a five-product polynomial without the Pade solve",
+                         "flop_model": "SURVEY 8d F_exp = (g+s)*8N^3 + (32/3)N^3 per cell, g = 6 for Pade order 13"},
             "phases_ms": {k: round(v, 4) for k, v in tm.items() if v >= 0},
-            "phase_b": {"kernel": "sweep_pair_kernel (forward and backward sweep in one launch)",
+            "phase_b": {"kernel": sweep_kernel,
                         "algorithmic_bytes": 2.0 * K_local * N_T * (N * N * 16 + 3 * N * 16),
                         "GB_per_s": 2.0 * K_local * N_T * (N * N * 16 + 3 * N * 16) / (tm["forward"] * 1e-3) * 1e-9
                         if tm.get("forward", -1) > 0 else None, "bound": "hbm"},

@@ -88,6 +88,29 @@ class ShardedEvaluator:
         if self.dist is not None:
             self.dist.all_reduce(self._G)
 
+    def check_collective(self, stream_ptr):
+        """``grape_check`` on every rank, with the one recoverable status decided TOGETHER: GRAPE_ERR_AGAIN (blocked
+        exponential, N > 64: the asynchronous squaring plan was too short and has been adapted) makes a rank repeat the
+        evaluation, and an evaluation contains collectives -- a rank repeating alone would pair its all-reduces with the
+        other ranks' next step.  Returns True when ALL ranks have to repeat the evaluation (any rank saw AGAIN); every
+        other error is raised.  One extra all-reduce of one integer, only for handles on the blocked path."""
+        from .api import GrapeHipError
+        state, err = 0, None   # 0 fine, 1 repeat, 2 failed (a rank that fails must not leave the others in the collective)
+        try:
+            self.h.check(stream_ptr)
+        except GrapeHipError as exc:
+            state, err = (1, None) if exc.code == -7 else (2, exc)
+        if self.dist is not None and getattr(self.h, "N", 0) > 64:
+            import torch
+            flag = torch.tensor([state], dtype=torch.int32, device=self.device if self.device is not None else "cpu")
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            state = int(flag.item())
+        if err is not None:
+            raise err
+        if state == 2:
+            raise GrapeHipError(-3, "another rank's shard failed in this evaluation")
+        return state == 1
+
     def J_device(self):
         K = self._K
         return functional_value(self.functional, self._out[2 * K:2 * K + 8].tolist(), self.K_total,

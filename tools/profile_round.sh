@@ -3,8 +3,9 @@
 #   gpurun_out/<tag>_bench_{C3,C2,C5}.json, gpurun_out/<tag>_{C3,C5}_kernel_stats.csv
 # (the summaries that are to be judged are copied to profiles/ and committed by hand)
 cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
-tag=${1:-r02}
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+mkdir -p gpurun_out
+tag=${1:-r03}
 python3 bench.py > gpurun_out/${tag}_bench_C3.json 2> gpurun_out/${tag}_bench_C3.err &&
 python3 bench.py --config C2 --steps 50 --warmup 5 > gpurun_out/${tag}_bench_C2.json 2> gpurun_out/${tag}_bench_C2.err &&
 python3 bench.py --config C5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_C5.json 2> gpurun_out/${tag}_bench_C5.err &&
