@@ -8,6 +8,7 @@
 // No CPU fallback exists: every entry point fails loudly when HIP does.
 #include "../../include/grape_hip.h"
 #include "grape_kernels.hip.h"
+#include "grape_t18_coeffs.h"
 #include "grape_large.hip.h"
 #include "grape_series.hip.h"
 #include "grape_cheby.hip.h"
@@ -18,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -61,6 +63,12 @@ struct grape_handle {
     int KC = 0;
     bool herm = false;           // all generators Hermitian: A = -i dt H is skew-Hermitian (expm uses the symmetry)
     bool t18 = false;            // Hermitian generators: inverse-free polynomial exponential (grape_t18.hip.h)
+    // diagnostic switches, read ONCE in grape_create (never in the evaluation path: getenv is not thread-safe against setenv)
+    bool expm_persist = true;    // GRAPE_EXPM_PERSIST=0: one workgroup per cell instead of the persistent Pade kernel
+    int expm_lds_pad_kb = 0;     // GRAPE_EXPM_LDS_PAD: extra dynamic LDS of the Pade kernels (fewer cells per CU)
+    int cheby_xmode = 1;         // GRAPE_CHEBY_XMODE
+    bool test_hooks = false;     // GRAPE_TEST_HOOKS=1 at grape_create: the fault injection of the test suite (GRAPE_TEST_DROP_SIBLING)
+                                 // is looked up per evaluation; without it the evaluation path never calls getenv
     std::vector<int> cls;        // [K] class of trajectory k
     int *d_cls = nullptr, *d_rep = nullptr;
     unsigned *d_coop = nullptr;  // [2][K] step counters of the cooperative sweeps (forward, backward)
@@ -127,44 +135,44 @@ namespace {
 template <typename T>
 hipError_t dmalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is raised per kernel and device whenever a launch needs more than has been
+// set so far (the size depends on NP and on diagnostic padding: a cache keyed by the device alone would let a second,
+// larger handle launch with the first one's limit)
+struct LdsLimit {
+    size_t set[64] = {0};
+    hipError_t ensure(const void *fn, int dev, size_t bytes) {
+        size_t &cur = set[((unsigned)dev) % 64u];
+        if (bytes <= cur) return hipSuccess;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) cur = bytes;
+        return e;
+    }
+};
+
 size_t expm_lds_bytes(int NT) {
     const int total = NT == 1 ? ExpmLds<1>::TOTAL : NT == 2 ? ExpmLds<2>::TOTAL : NT == 3 ? ExpmLds<3>::TOTAL : ExpmLds<4>::TOTAL;
     return sizeof(double) * (size_t)total;
 }
 
 template <int NT>
-hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persistent_blocks = 0) {
-    static bool attr_set[8] = {false};
-    size_t lds = expm_lds_bytes(NT);
-    if (const char *envl = getenv("GRAPE_EXPM_LDS_PAD")) lds += (size_t)atoi(envl) * 1024;   // diagnostic: fewer cells per CU
+hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persistent_blocks = 0, int lds_pad_kb = 0) {
+    static LdsLimit lim_fast, lim_piv, lim_herm, lim_pers, lim_persh;
+    const size_t lds = expm_lds_bytes(NT) + (size_t)lds_pad_kb * 1024;   // (padding: diagnostic, fewer cells per CU)
     int dev = 0;
     hipGetDevice(&dev);
-    if (!attr_set[dev & 7]) {
-        hipError_t e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess && NT >= 3)
-            e = hipFuncSetAttribute((const void *)expm_pade_kernel<NT, false, NT >= 3>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = lim_fast.ensure((const void *)expm_pade_kernel<NT, false>, dev, lds);
+        if (e == hipSuccess) e = lim_piv.ensure((const void *)expm_pade_kernel<NT, true>, dev, lds);
+        if (e == hipSuccess && NT >= 3) e = lim_herm.ensure((const void *)expm_pade_kernel<NT, false, NT >= 3>, dev, lds);
         if (e != hipSuccess) return e;
-        attr_set[dev & 7] = true;
     }
     hipError_t e = hipMemsetAsync(a.cellflag, 0, (size_t)a.K * a.N_T * sizeof(int), s);
     if (e != hipSuccess) return e;
     // fast pass: unpivoted block Gauss-Jordan, flags the cells it cannot solve safely; one workgroup per cell
     if (NT == 4 && persistent_blocks > 0) {   // one workgroup per CU walks its cells (see expm_persistent)
-        static bool attr_p[8] = {false};
-        if (!attr_p[dev & 7]) {
-            hipError_t ep = hipFuncSetAttribute((const void *)expm_persistent_kernel<NT, false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (ep == hipSuccess)
-                ep = hipFuncSetAttribute((const void *)expm_persistent_kernel<NT, NT == 4>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (ep != hipSuccess) return ep;
-            attr_p[dev & 7] = true;
-        }
+        hipError_t ep = lim_pers.ensure((const void *)expm_persistent_kernel<NT, false>, dev, lds);
+        if (ep == hipSuccess) ep = lim_persh.ensure((const void *)expm_persistent_kernel<NT, NT == 4>, dev, lds);
+        if (ep != hipSuccess) return ep;
         if (herm) hipLaunchKernelGGL((expm_persistent_kernel<NT, NT == 4>), dim3(persistent_blocks), dim3(NT * 64), lds, s, a);
         else hipLaunchKernelGGL((expm_persistent_kernel<NT, false>), dim3(persistent_blocks), dim3(NT * 64), lds, s, a);
     } else
@@ -291,6 +299,47 @@ double norm2_estimate(const double *M, int N) {
     return 1.1 * std::sqrt(sigma2);
 }
 
+// RIGOROUS upper bound of the 2-norm of a Hermitian N x N matrix (column-major interleaved complex):
+// ||M||_2 = rho(M) and rho(M)^p = rho(M^p) <= ||M^p||_1, so min(||M||_1, ||M^2||_1^(1/2), ||M^4||_1^(1/4)) bounds it;
+// for a matrix with semicircle spectrum the last figure is 1.2-1.4 rho at N = 64...256 where ||M||_1 is 4-8 rho.
+// The Chebyshev propagator needs a GUARANTEED spectral interval (an eigenvalue outside it makes the three-term recursion
+// grow exponentially, silently); the power iteration above approaches the norm from below and guarantees nothing.
+// Two N^3 products per operator, once per grape_create.
+double herm_norm2_bound(const double *M, int N) {
+    const size_t nn = (size_t)N * N;
+    auto norm1 = [&](const std::vector<double> &a) {
+        double best = 0.0;
+        for (int j = 0; j < N; ++j) {
+            double cs = 0.0;
+            for (int i = 0; i < N; ++i) cs += std::hypot(a[2 * ((size_t)j * N + i)], a[2 * ((size_t)j * N + i) + 1]);
+            best = std::max(best, cs);
+        }
+        return best;
+    };
+    auto square = [&](const std::vector<double> &a, std::vector<double> &c) {   // c = a a (column j of c = a times column j of a)
+        std::fill(c.begin(), c.end(), 0.0);
+        for (int j = 0; j < N; ++j)
+            for (int k = 0; k < N; ++k) {
+                const double br = a[2 * ((size_t)j * N + k)], bi = a[2 * ((size_t)j * N + k) + 1];
+                const double *ak = &a[2 * (size_t)k * N];
+                double *cj = &c[2 * (size_t)j * N];
+                for (int i = 0; i < N; ++i) {
+                    cj[2 * i] += ak[2 * i] * br - ak[2 * i + 1] * bi;
+                    cj[2 * i + 1] += ak[2 * i] * bi + ak[2 * i + 1] * br;
+                }
+            }
+    };
+    std::vector<double> m1(M, M + 2 * nn), m2(2 * nn), m4(2 * nn);
+    const double b1 = norm1(m1);
+    if (!(b1 > 0.0) || !std::isfinite(b1)) return b1;
+    square(m1, m2);
+    square(m2, m4);
+    const double b2 = std::sqrt(norm1(m2)), b4 = std::sqrt(std::sqrt(norm1(m4)));
+    double b = std::min(b1, std::min(b2, b4));
+    if (!std::isfinite(b)) b = b1;
+    return b * (1.0 + 1e-10 * N);   // rounding of the computed powers
+}
+
 #ifndef DERIV32_NTH
 #define DERIV32_NTH 128
 #endif
@@ -319,15 +368,11 @@ hipError_t launch_dm(const DerivMfmaArgs &a, int nblocks, hipStream_t s) {
     constexpr int NW = NP / 16 <= 8 ? NP / 16 : 8;
     const size_t lds = VLDS ? sizeof(double) * 2 * (1 + LMAX) * 2 * NP * 16 : 0;
     if (VLDS) {
-        static bool attr_set[8] = {false};
+        static LdsLimit lim;
         int dev = 0;
         hipGetDevice(&dev);
-        if (!attr_set[dev & 7]) {
-            hipError_t e = hipFuncSetAttribute((const void *)deriv_mfma_kernel<NP, LMAX, CACHE, VLDS>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set[dev & 7] = true;
-        }
+        hipError_t e = lim.ensure((const void *)deriv_mfma_kernel<NP, LMAX, CACHE, VLDS>, dev, lds);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((deriv_mfma_kernel<NP, LMAX, CACHE, VLDS>), dim3(nblocks), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
@@ -363,14 +408,12 @@ template <int NP, int LMAX, bool CACHE>
 hipError_t launch_d2(const Deriv2Args &a, int nblocks, hipStream_t s) {
     constexpr int NW = NP / 16 <= 8 ? NP / 16 : 8;
     const size_t lds = sizeof(double) * 2 * 2 * NP * 16;
-    static bool attr_set[8] = {false};
+    static LdsLimit lim;
     int dev = 0;
     hipGetDevice(&dev);
-    if (lds > 48 * 1024 && !attr_set[dev & 7]) {
-        hipError_t e = hipFuncSetAttribute((const void *)deriv2_kernel<NP, LMAX, CACHE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) {
+        hipError_t e = lim.ensure((const void *)deriv2_kernel<NP, LMAX, CACHE>, dev, lds);
         if (e != hipSuccess) return e;
-        attr_set[dev & 7] = true;
     }
     hipLaunchKernelGGL((deriv2_kernel<NP, LMAX, CACHE>), dim3(nblocks), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
@@ -455,6 +498,28 @@ hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, 
     return hipGetLastError();
 }
 
+// the polynomial route's products: up to four epilogue terms with powers of the per-cell scaling, optional second output
+hipError_t lg_gemm_poly(hipStream_t s, int nc, int NB, LgView X, LgView Y, LgView C, int herm, int nadd, const LgView *add,
+                        const double *coef, const int *add_pow, double cI, const int *scale_s,
+                        const LgView *C2 = nullptr, const double *coef2 = nullptr, double cI2 = 0.0,
+                        double2 *Uout = nullptr, int u_np = 0, const int *smax_ptr = nullptr) {
+    LgGemmArgs a{};
+    a.X = X; a.Y = Y; a.C = C; a.kblocks = NB; a.alpha = 1.0; a.beta = 0.0; a.cI = cI;
+    a.nadd = nadd;
+    for (int i = 0; i < nadd; ++i) {
+        a.Add[i] = add[i]; a.coef[i] = coef[i]; a.add_pow[i] = add_pow[i];
+        a.coef2[i] = coef2 ? coef2[i] : 0.0;
+    }
+    if (C2) { a.C2 = *C2; a.cI2 = cI2; }
+    a.herm = herm; a.scale_s = scale_s; a.scale_pow = 0; a.skip_bi = -1;
+    if (Uout) { a.Uout = Uout; a.u_np = u_np; a.smax_ptr = smax_ptr; a.u_if_smax0 = 1; }
+    a.nbi = NB; a.nbj = NB; a.ncell = nc;
+    const int groups = (nc + 7) / 8;
+    const int per_cell = a.herm ? NB * (NB + 1) / 2 : NB * NB;
+    hipLaunchKernelGGL(lg_gemm_kernel, dim3(groups * 8 * per_cell), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t lg_lincomb(hipStream_t s, double *out, size_t n, int nin, const double *const *in, const double *coef) {
     LgLincombArgs a{};
     a.out = out; a.n = n; a.nin = nin;
@@ -474,16 +539,98 @@ hipError_t lg_lincomb2(hipStream_t s, double *out0, double *out1, size_t n, int 
 
 #define LGCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
+// Blocked path, polynomial route (default; GRAPE_EXPM_T18=0 selects the order-13 Pade route below): five products and no
+// solve.  Hermitian generators: Chebyshev coefficient set, three of the five products compute the upper block triangle
+// only, scaling from the spectral bound (at C5 no squaring at all where ||A||_1 = 8.3 costs the Pade route one).
+// General matrices: Taylor coefficient set, scaling from alpha = min(||A||_1, max(d2, d3)).
+hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
+    const int NP = h->NP, NB = NP / 64;
+    const size_t pp = (size_t)NP * NP;
+    const long ncell = (long)h->KC * h->N_T;
+    // nine chunk buffers: the four powers, then the five combinations; the powers are dead once those are formed and
+    // their buffers take A9, B3 + A9 and the result
+    double *A = h->d_lg[0], *A2 = h->d_lg[1], *A3 = h->d_lg[2], *A6 = h->d_lg[3], *B1 = h->d_lg[4], *B5 = h->d_lg[5],
+           *B4 = h->d_lg[6], *B3 = h->d_lg[7], *B2 = h->d_lg[8];
+    double *A9 = A, *Lm = A2, *T = A3;
+    const bool hm = h->herm;
+    // executed matrix instructions per cell (all waves of all workgroups; a 64-block product of one output block is 4 waves
+    // x 192 instructions): full products NB^3 blocks, triangular ones NB^2 (NB + 1) / 2
+    const unsigned long long blk = 4ull * 192ull;
+    const unsigned long long gen = blk * NB * NB * NB, tri = blk * NB * NB * (NB + 1) / 2;
+    for (long c0_ = 0; c0_ < ncell; c0_ += h->chunk) {
+        const int nc = (int)std::min<long>(h->chunk, ncell - c0_);
+        const size_t nel = (size_t)nc * 2 * pp;
+        LgFormArgs fa{};
+        fa.H0f = h->d_H0f; fa.Hcf = h->d_Hcf; fa.eps = h->d_eps; fa.shape = h->d_shape; fa.dts = h->d_dts;
+        fa.A = A; fa.s_cell = h->d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
+        fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0_; fa.rep = h->d_rep;
+        fa.norm1 = h->d_dinv;   // (the inverse slots of the Pade route are idle here: ||A||_1 per cell)
+        hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(256), 0, s, fa);
+        LGCHK(hipGetLastError());
+        const LgView vA = lg_full(A, NP), vA2 = lg_full(A2, NP), vA3 = lg_full(A3, NP), vA6 = lg_full(A6, NP),
+                     vB1 = lg_full(B1, NP), vB5 = lg_full(B5, NP), vA9 = lg_full(A9, NP), vL = lg_full(Lm, NP), vT = lg_full(T, NP);
+        LGCHK(lg_gemm(s, nc, NB, NB, vA, vA, vA2, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? 1 : 0));     // A2 = A A
+        LGCHK(lg_gemm(s, nc, NB, NB, vA2, vA, vA3, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? -1 : 0));   // A3 = A2 A
+        LGCHK(lg_gemm(s, nc, NB, NB, vA3, vA3, vA6, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? 1 : 0));   // A6 = A3 A3
+        LgT18ScaleArgs sa{};
+        sa.P = A2; sa.Q = hm ? A6 : A3; sa.qpow = hm ? 6 : 3; sa.norm1 = hm ? nullptr : h->d_dinv;
+        sa.s_cell = h->d_scell; sa.flags = h->d_flags; sa.stats = h->d_stats; sa.NP = NP;
+        sa.theta = hm ? T18_THETA : T18T_THETA;
+        sa.mfma_per_cell = (hm ? 3 * tri : 3 * gen) + 2 * gen; sa.mfma_per_sq = gen;
+        hipLaunchKernelGGL(lg_t18_scale_kernel, dim3(nc), dim3(256), 0, s, sa);
+        LGCHK(hipGetLastError());
+        LgT18OperandsArgs oa{};
+        oa.A = A; oa.A2 = A2; oa.A3 = A3; oa.A6 = A6; oa.B1 = B1; oa.B5 = B5; oa.B4 = B4; oa.B3 = B3; oa.B2 = B2;
+        oa.s_cell = h->d_scell; oa.NP = NP; oa.per_cell = 2 * pp; oa.n = nel;
+        if (hm) {
+            const double a_[3] = {T18_A1, T18_A2, T18_A3}, e_[3] = {T18_E2, T18_E3, T18_E6}, b_[4] = {T18_B1, T18_B2, T18_B3, T18_B6};
+            const double c_[5] = {T18_C0, T18_C1, T18_C2, T18_C3, T18_C6}, d_[5] = {T18_D0, T18_D1, T18_D2, T18_D3, T18_D6};
+            memcpy(oa.a, a_, sizeof(a_)); memcpy(oa.e, e_, sizeof(e_)); memcpy(oa.b, b_, sizeof(b_));
+            memcpy(oa.c, c_, sizeof(c_)); memcpy(oa.d, d_, sizeof(d_));
+        } else {
+            const double a_[3] = {T18T_A1, T18T_A2, T18T_A3}, e_[3] = {T18T_E2, T18T_E3, T18T_E6}, b_[4] = {T18T_B1, T18T_B2, T18T_B3, T18T_B6};
+            const double c_[5] = {T18T_C0, T18T_C1, T18T_C2, T18T_C3, T18T_C6}, d_[5] = {T18T_D0, T18T_D1, T18T_D2, T18T_D3, T18T_D6};
+            memcpy(oa.a, a_, sizeof(a_)); memcpy(oa.e, e_, sizeof(e_)); memcpy(oa.b, b_, sizeof(b_));
+            memcpy(oa.c, c_, sizeof(c_)); memcpy(oa.d, d_, sizeof(d_));
+        }
+        hipLaunchKernelGGL(lg_t18_operands_kernel, dim3(2048), dim3(256), 0, s, oa);
+        LGCHK(hipGetLastError());
+        const LgView vB4 = lg_full(B4, NP), vB3 = lg_full(B3, NP), vB2 = lg_full(B2, NP);
+        const int *smax_ptr = h->d_flags + 1;
+        {   // A9 = B1 B5 + B4 and, from the same launch, B3 + A9 (the left operand of the last product)
+            const LgView add[2] = {vB4, vB3};
+            const double c1[2] = {1.0, 0.0}, c2[2] = {0.0, 1.0};
+            const int pw0[2] = {0, 0};
+            LGCHK(lg_gemm_poly(s, nc, NB, vB1, vB5, vA9, 0, 2, add, c1, pw0, 0.0, nullptr, &vL, c2, 0.0));
+        }
+        {   // p = B2 + (B3 + A9) A9: straight into U_kn unless a cell of this evaluation needs a squaring
+            const LgView add[1] = {vB2};
+            const double c1[1] = {1.0};
+            const int pw0[1] = {0};
+            LGCHK(lg_gemm_poly(s, nc, NB, vL, vA9, vT, 0, 1, add, c1, pw0, 0.0, nullptr, nullptr, nullptr, 0.0,
+                               h->d_U + (size_t)c0_ * pp, NP, smax_ptr));
+        }
+        // squarings by the launch plan (see expm_large): every launch exits at once when it is not needed, the last
+        // needed one writes U_kn for all cells of the chunk (cells that are done are copied through)
+        double *X = T, *Y = B1;
+        for (int it = 0; it < h->sq_plan; ++it) {
+            LGCHK(lg_gemm(s, nc, NB, NB, lg_full(X, NP), lg_full(X, NP), lg_full(Y, NP), NB, 1.0, 0.0, 0, nullptr, nullptr,
+                          0.0, h->d_scell, it, 0, nullptr, 0, h->d_U + (size_t)c0_ * pp, NP, -1, smax_ptr));
+            std::swap(X, Y);
+        }
+    }
+    hipLaunchKernelGGL(lg_plan_check_kernel, dim3(1), dim3(1), 0, s, h->d_flags, h->sq_plan);
+    LGCHK(hipGetLastError());
+    return hipSuccess;
+}
+
 hipError_t expm_large(grape_handle *h, hipStream_t s) {
     const int NP = h->NP, NB = NP / 64;
     const size_t pp = (size_t)NP * NP;
     const long ncell = (long)h->KC * h->N_T;
-    static bool attr_set[8] = {false};
+    static LdsLimit lim_inv;
     const size_t inv_lds = sizeof(double) * (3 * 2 * 64 * 18 + 1536);
-    if (!attr_set[h->device & 7]) {
-        LGCHK(hipFuncSetAttribute((const void *)lg_inv64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
-        attr_set[h->device & 7] = true;
-    }
+    LGCHK(lim_inv.ensure((const void *)lg_inv64_kernel, h->device, inv_lds));
     double *A = h->d_lg[0], *A2 = h->d_lg[1], *A4 = h->d_lg[2], *A6 = h->d_lg[3], *W = h->d_lg[4], *Z = h->d_lg[5],
            *T = h->d_lg[6], *V = h->d_lg[7], *Uo = h->d_lg[8];
     for (long c0 = 0; c0 < ncell; c0 += h->chunk) {
@@ -588,11 +735,10 @@ SeriesArgs series_args(grape_handle *h, const SweepArgs &sa, bool backward) {
 hipError_t launch_cheby(grape_handle *h, const SweepArgs *sf, const SweepArgs *sb, hipStream_t s) {
     const int NP = h->NP, S = h->cheby_S, K = h->K;
     const size_t lds = sizeof(double) * ((size_t)2 * 16 * (NP + 2) + 2 * (size_t)NP + CHEBY_MAXT + 2);
-    static bool attr_set[8] = {false};
-    if (!attr_set[h->device & 7]) {
-        hipError_t e = hipFuncSetAttribute((const void *)cheby_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsLimit lim;
+    {
+        hipError_t e = lim.ensure((const void *)cheby_coop_kernel, h->device, lds);
         if (e != hipSuccess) return e;
-        attr_set[h->device & 7] = true;
     }
     hipLaunchKernelGGL(cheby_arm_kernel, dim3(256), dim3(256), 0, s, (unsigned long long *)h->d_xch, (size_t)2 * K * 4 * NP * 2);
     hipError_t e = hipGetLastError();
@@ -609,7 +755,7 @@ hipError_t launch_cheby(grape_handle *h, const SweepArgs *sf, const SweepArgs *s
         // XCD-local stores (sc0: they land in the XCD's L2, where the siblings' device-scope polls find them) are the
         // default -- C5 shard sweeps 175 -> 141 ms; XCD-local LOADS (buffer_inv sc0 + sc0 load) never saw the data
         // on gfx950 and are not used
-        c.xmode = getenv("GRAPE_CHEBY_XMODE") ? atoi(getenv("GRAPE_CHEBY_XMODE")) & 1 : 1;
+        c.xmode = h->cheby_xmode;
         c.tol = h->series_tol;
         c.L = h->L; c.hc_per_traj = h->p.hc_per_traj; c.NP = NP; c.herm = h->herm ? 1 : 0;
     };
@@ -810,7 +956,16 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             h->herm = herm && !(envh && atoi(envh));
             // GRAPE_EXPM_T18=0: Hermitian generators through the order-13 Pade kernel as well (parity reference, A/B timing)
             const char *envt = getenv("GRAPE_EXPM_T18");
-            h->t18 = h->herm && !(envt && !atoi(envt));
+            // (N <= 64: Hermitian generators only; blocked path: every generator, with the Taylor coefficient set otherwise)
+            h->t18 = (h->herm || h->large) && !(envt && !atoi(envt));
+        }
+        {
+            const char *envp = getenv("GRAPE_EXPM_PERSIST"), *envl = getenv("GRAPE_EXPM_LDS_PAD"), *envx = getenv("GRAPE_CHEBY_XMODE");
+            const char *envk = getenv("GRAPE_TEST_HOOKS");
+            h->expm_persist = envp ? atoi(envp) != 0 : true;
+            h->expm_lds_pad_kb = envl ? std::max(0, atoi(envl)) : 0;
+            h->cheby_xmode = envx ? atoi(envx) & 1 : 1;
+            h->test_hooks = envk && atoi(envk) == 1;
         }
         if (h->KC < p->K) {
             if (hipSetDevice(h->device) != hipSuccess || hipMalloc((void **)&h->d_cls, p->K * sizeof(int)) != hipSuccess ||
@@ -973,8 +1128,20 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     {   // 2-norm estimates of the operators (power iteration): sub-steps of the matrix-free propagator and of the
         // derivative series
         std::vector<double> rb((size_t)K + (size_t)Kc * L);
-        for (int k = 0; k < K; ++k) rb[k] = norm2_estimate(p->H0 + 2 * (size_t)k * nn, N);
-        for (int kl = 0; kl < Kc * L; ++kl) rb[K + kl] = norm2_estimate(p->Hc + 2 * (size_t)kl * nn, N);
+        // Hermitian generators on the Chebyshev propagator (matrix-free, N > 64): guaranteed bounds instead of estimates
+        const bool rigorous = h->herm && p->prop_method == GRAPE_PROP_SERIES && h->large;
+        auto bound_of = [&](const double *m) { return rigorous ? herm_norm2_bound(m, N) : norm2_estimate(m, N); };
+        const int nops = K + Kc * L;
+        auto op_ptr = [&](int q) { return q < K ? p->H0 + 2 * (size_t)q * nn : p->Hc + 2 * (size_t)(q - K) * nn; };
+        if (rigorous && nops > 1) {   // two N^3 products per operator: over the host cores
+            const int nth = (int)std::max(1u, std::min<unsigned>(std::min<unsigned>(std::thread::hardware_concurrency(), 32u), (unsigned)nops));
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nth; ++t)
+                pool.emplace_back([&, t]() { for (int q = t; q < nops; q += nth) rb[q] = bound_of(op_ptr(q)); });
+            for (auto &th : pool) th.join();
+        } else {
+            for (int q = 0; q < nops; ++q) rb[q] = bound_of(op_ptr(q));
+        }
         CCHK(dmalloc(&h->d_rb, rb.size()));
         CCHK(hipMemcpy(h->d_rb, rb.data(), rb.size() * 8, hipMemcpyHostToDevice));
         // the exact-derivative route sub-steps its series for ||H|| dt > theta; :taylor is the reference's plain recursion
@@ -1103,7 +1270,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     if (!h->series) {
         phase_begin(h, 0, s);
         if (h->large) {
-            e = expm_large(h, s);
+            e = h->t18 ? expm_large_t18(h, s) : expm_large(h, s);
         } else {
             const long ncell = (long)ea.K * ea.N_T;
             const int t18_blocks = 8 * (int)std::max<long>(1, std::min<long>(h->num_cus / 8, (ncell + 7) / 8));
@@ -1111,15 +1278,14 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                 e = (hipError_t)grape_t18_launch(h->NT, &ea, sizeof(ea), (void *)s, t18_blocks);
             } else
             switch (h->NT) {
-                case 1: e = launch_expm<1>(ea, h->herm, s); break;
-                case 2: e = launch_expm<2>(ea, h->herm, s); break;
-                case 3: e = launch_expm<3>(ea, h->herm, s); break;
+                case 1: e = launch_expm<1>(ea, h->herm, s, 0, h->expm_lds_pad_kb); break;
+                case 2: e = launch_expm<2>(ea, h->herm, s, 0, h->expm_lds_pad_kb); break;
+                case 3: e = launch_expm<3>(ea, h->herm, s, 0, h->expm_lds_pad_kb); break;
                 default: {
                     // persistent variant (one workgroup per CU) when every CU gets at least a few cells
-                    const char *envp = getenv("GRAPE_EXPM_PERSIST");
                     const int nb = 8 * (h->num_cus / 8);
-                    const bool persist = (envp ? atoi(envp) != 0 : true) && nb >= 8 && (long)ea.K * ea.N_T >= 4L * nb;
-                    e = launch_expm<4>(ea, h->herm, s, persist ? nb : 0);
+                    const bool persist = h->expm_persist && nb >= 8 && (long)ea.K * ea.N_T >= 4L * nb;
+                    e = launch_expm<4>(ea, h->herm, s, persist ? nb : 0, h->expm_lds_pad_kb);
                     break;
                 }
             }
@@ -1167,7 +1333,10 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     sa.store = h->d_fw; sa.tau = (double2 *)d_out; sa.f = nullptr; sa.rho = h->d_rho; sa.flags = h->d_flags;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
-    if (const char *envd = getenv("GRAPE_TEST_DROP_SIBLING")) sa.drop_sibling = atoi(envd);   // fault injection (tests)
+    if (h->test_hooks) {   // fault injection (test suite only, see grape_handle::test_hooks)
+        const char *envd = getenv("GRAPE_TEST_DROP_SIBLING");
+        sa.drop_sibling = envd ? atoi(envd) : 0;
+    }
     phase_begin(h, 1, s);
     const bool pair = h->fuse && h->fuse_on && h->want_bw;
     h->bw_done = h->bw_unit = pair;

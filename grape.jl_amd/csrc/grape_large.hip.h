@@ -21,9 +21,15 @@ struct LgView {          // a block view into a batch of planar matrices
 
 struct LgGemmArgs {
     LgView X, Y, C;      // C[bi][bj] = alpha * sum_kb X[bi][kb] Y[kb][bj] + beta * C[bi][bj] + sum_i coef[i] Add_i + cI * I
-    LgView Add[3];
-    double coef[3];
+    LgView Add[4];
+    double coef[4];
     double alpha, beta, cI;
+    // second output of the same launch (C2.p != nullptr): C2 = C + sum_i coef2[i] Add_i + cI2 * I -- the polynomial route
+    // gets A9 = B1 B5 + B4 and B3 + A9 from one product (B3 and B4 combine the same four blocks)
+    LgView C2;
+    double coef2[4], cI2;
+    int add_pow[4];      // with scale_s: coef[i] and coef2[i] are multiplied by 2^(-add_pow[i] * scale_s[cell]) (Add_i = A^add_pow[i]
+                         // of the UNSCALED A: the scaling A / 2^s of scaling and squaring, exact in binary)
     int nadd, kblocks;
     int nbi, nbj, ncell; // output blocks per cell and cells in this launch
     const int *s_cell;   // optional: squarings per cell; cells with s_cell[cell] <= sq_iter copy X instead
@@ -36,6 +42,8 @@ struct LgGemmArgs {
     int u_np;
     int skip_bi;         // block row that is left alone (-1: none): the trailing update of a Gauss-Jordan step covers all
                          // block rows but the pivot row in ONE launch
+    int u_if_smax0;      // last product of the polynomial route: the result goes to Uout when *smax_ptr == 0 (no cell of the
+                         // evaluation so far needs a squaring), to C otherwise
     const int *smax_ptr; // squarings only: the launch belongs to iteration sq_iter of a plan of fixed length; it exits at
                          // once when sq_iter >= *smax_ptr (the largest squaring count so far, known only on the device)
                          // and writes U when it is the last one -- no host read-back of the count between launches
@@ -68,7 +76,9 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
     }
     if (bi == a.skip_bi) return;
     double2 *Uout = a.Uout;
-    if (a.smax_ptr) {
+    if (a.u_if_smax0) {
+        if (*a.smax_ptr != 0) Uout = nullptr;
+    } else if (a.smax_ptr) {
         const int sm = *a.smax_ptr;
         if (a.sq_iter >= sm) return;
         if (a.sq_iter != sm - 1) Uout = nullptr;
@@ -90,6 +100,13 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
         return;
     }
     const double alpha = a.scale_s ? ldexp(a.alpha, -a.scale_pow * a.scale_s[cell]) : a.alpha;
+    double cf[4], cf2[4];
+    for (int q = 0; q < a.nadd; ++q) {
+        const double f = (a.scale_s && a.add_pow[q]) ? ldexp(1.0, -a.add_pow[q] * a.scale_s[cell]) : 1.0;
+        cf[q] = a.coef[q] * f;
+        cf2[q] = a.coef2[q] * f;
+    }
+    double *c2o = a.C2.p ? lg_ptr(a.C2, cell, bi, bj) : nullptr;
     Strip3<4> acc3;   // 3M partial products, combined once after the K loop
     strip3_zero(acc3);
     for (int kb = 0; kb < a.kblocks; ++kb) {
@@ -127,13 +144,22 @@ __global__ void __launch_bounds__(256, 2) lg_gemm_kernel(LgGemmArgs a) {  // 2 w
             const size_t o = (size_t)row * a.C.ld + col;
             double vr = alpha * acc.re[t][r], vi = alpha * acc.im[t][r];
             if (a.beta != 0.0) { vr += a.beta * c[o]; vi += a.beta * c[a.C.plane + o]; }
+            double wr = 0., wi = 0.;
             for (int q = 0; q < a.nadd; ++q) {
                 const double *ad = lg_ptr(a.Add[q], cell, bi, bj);
                 const size_t oa = (size_t)row * a.Add[q].ld + col;
-                vr += a.coef[q] * ad[oa];
-                vi += a.coef[q] * ad[a.Add[q].plane + oa];
+                const double xr = ad[oa], xi = ad[a.Add[q].plane + oa];
+                vr += cf[q] * xr;
+                vi += cf[q] * xi;
+                wr += cf2[q] * xr;
+                wi += cf2[q] * xi;
             }
             if (a.cI != 0.0 && grow0 + row == gcol) vr += a.cI;
+            if (c2o) {
+                const size_t o2 = (size_t)row * a.C2.ld + col;
+                c2o[o2] = vr + wr + ((grow0 + row == gcol) ? a.cI2 : 0.0);
+                c2o[a.C2.plane + o2] = vi + wi;
+            }
             if (Uout) {
                 Uout[(size_t)cell * a.u_np * a.u_np + (size_t)(bi * 64 + row) * a.u_np + bj * 64 + col] = make_double2(vr, vi);
             } else {
@@ -216,6 +242,8 @@ struct LgFormArgs {
     int *flags;
     int NP, L, N_T, hc_per_traj, cell0;
     const int *rep;       // nullptr or representative trajectory per generator class
+    double *norm1;        // polynomial route (lg_t18_scale_kernel decides the scaling): ||A||_1 per cell goes here, the
+                          // Pade squaring count is only CREDITED (statistics), s_cell and flags[1] are left alone
 };
 __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
     __shared__ double colsum[256];
@@ -276,13 +304,103 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
         s = (r == ldexp(1.0, ex)) ? ex : ex + 1;
     }
     if (tid == 0) {
-        a.s_cell[blockIdx.x] = s;
         stat_add(a.stats, 0, (unsigned long long)s);
-        stat_add(a.stats, 7, 1ull);   // the blocked path always evaluates the order-13 approximant
-        atomicMax(&a.flags[1], s);
+        stat_add(a.stats, 7, 1ull);   // the blocked path always evaluates (or is credited with) the order-13 approximant
+        if (a.norm1) {
+            a.norm1[blockIdx.x] = nA;
+        } else {
+            a.s_cell[blockIdx.x] = s;
+            atomicMax(&a.flags[1], s);
+        }
     }
 }
 
+// ---- polynomial route of the blocked path (five products, no solve; scheme and coefficients: grape_t18_coeffs.h) ----
+// Scaling of one cell from the powers: Hermitian generators beta = min(||A2||_1^(1/2), ||A6||_1^(1/6)) against theta = 2
+// (spectral bound, see grape_t18.hip.h); general matrices alpha = min(||A||_1, max(||A2||_1^(1/2), ||A3||_1^(1/3))) against
+// theta = 1.09.  P and Q are the two powers whose column sums are needed (A2 and A6, or A2 and A3); |re| + |im| stands in
+// for the modulus (an upper bound of the norm is all the theory needs).  One 256-thread workgroup per cell, thread j
+// owns column j.
+struct LgT18ScaleArgs {
+    const double *P, *Q;   // [ncell][2][NP*NP]
+    const double *norm1;   // ||A||_1 per cell (general matrices), nullptr for Hermitian generators
+    int *s_cell;
+    int *flags;
+    unsigned long long *stats;
+    int NP, qpow;          // Q = A^qpow (6 or 3)
+    double theta;
+    unsigned long long mfma_per_cell, mfma_per_sq;   // executed matrix instructions (all waves): statistics
+};
+__global__ void __launch_bounds__(256) lg_t18_scale_kernel(LgT18ScaleArgs a) {
+    __shared__ double cs[2][256];
+    const int tid = threadIdx.x, NP = a.NP;
+    const size_t pp = (size_t)NP * NP;
+    const double *P = a.P + (size_t)blockIdx.x * 2 * pp, *Q = a.Q + (size_t)blockIdx.x * 2 * pp;
+    double sp = 0., sq = 0.;
+    if (tid < NP) {
+#pragma unroll 8
+        for (int i = 0; i < NP; ++i) {
+            const size_t o = (size_t)i * NP + tid;
+            sp += fabs(P[o]) + fabs(P[pp + o]);
+            sq += fabs(Q[o]) + fabs(Q[pp + o]);
+        }
+    }
+    cs[0][tid] = sp; cs[1][tid] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        double np_ = 0., nq = 0.;
+        for (int j = 0; j < NP; ++j) { np_ = fmax(np_, cs[0][j]); nq = fmax(nq, cs[1][j]); }
+        np_ *= 1.0 + 1e-9; nq *= 1.0 + 1e-9;   // rounding of the computed powers
+        int s = 0;
+        bool bad = false;
+        if (!a.norm1) {   // beta <= theta 2^s  <=>  ||A2|| <= (theta 2^s)^2  or  ||A6|| <= (theta 2^s)^6
+            double t2 = a.theta * a.theta, t6 = t2 * t2 * t2;
+            while (!(np_ <= t2 || nq <= t6) && s < 64) { ++s; t2 *= 4.0; t6 *= 64.0; }
+            bad = s >= 64;
+        } else {          // alpha <= theta 2^s  <=>  ||A|| <= theta 2^s  or  (||A2|| <= (theta 2^s)^2 and ||A3|| <= (theta 2^s)^3)
+            const double n1 = a.norm1[blockIdx.x];
+            double t1 = a.theta, t2 = t1 * t1, t3 = t2 * t1;
+            while (!(n1 <= t1 || (np_ <= t2 && nq <= t3)) && s < 64) { ++s; t1 *= 2.0; t2 *= 4.0; t3 *= 8.0; }
+            bad = s >= 64;
+        }
+        if (bad) { s = 0; atomicOr(&a.flags[0], 64); }   // NaN / overflow in the generator
+        a.s_cell[blockIdx.x] = s;
+        atomicMax(&a.flags[1], s);
+        stat_add(a.stats, 12, a.mfma_per_cell + (unsigned long long)s * a.mfma_per_sq);
+        stat_add(a.stats, 13, (unsigned long long)s);
+        stat_add(a.stats, 14, 1ull);
+    }
+}
+
+// The five linear combinations of the scaled powers (A / 2^s)^k = A^k 2^(-k s) in ONE streaming pass (4 reads, 5 writes per
+// element at the HBM rate): B1, B5 (operands of the fourth product), B4, B3, B2 (added in the epilogues of the fourth and
+// fifth product: one or two extra blocks per output block -- with the four powers combined in the epilogue itself the
+// two general products took 2.1 ms per chunk instead of 1.1, their block loads being issued one element at a time).
+// B4 and B3 include their multiples of the identity.
+struct LgT18OperandsArgs {
+    const double *A, *A2, *A3, *A6;
+    double *B1, *B5, *B4, *B3, *B2;
+    const int *s_cell;
+    double a[3], e[3], b[4], c[5], d[5];   // b: A, A2, A3, A6;  c, d: I, A, A2, A3, A6
+    int NP;
+    size_t per_cell;   // 2 * NP * NP
+    size_t n;          // per_cell * cells
+};
+__global__ void lg_t18_operands_kernel(LgT18OperandsArgs a) {
+    const size_t pp = a.per_cell / 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t cell = i / a.per_cell, o = i - cell * a.per_cell;
+        const int s = a.s_cell[cell];
+        const double f1 = ldexp(1.0, -s), f2 = f1 * f1, f3 = f2 * f1, f6 = f3 * f3;
+        const double x1 = f1 * a.A[i], x2 = f2 * a.A2[i], x3 = f3 * a.A3[i], x6 = f6 * a.A6[i];
+        const bool diag = o < pp && (o / a.NP) == (o % a.NP);   // real plane, row == column
+        a.B1[i] = a.a[0] * x1 + a.a[1] * x2 + a.a[2] * x3;
+        a.B5[i] = a.e[0] * x2 + a.e[1] * x3 + a.e[2] * x6;
+        a.B4[i] = a.d[1] * x1 + a.d[2] * x2 + a.d[3] * x3 + a.d[4] * x6 + (diag ? a.d[0] : 0.0);
+        a.B3[i] = a.c[1] * x1 + a.c[2] * x2 + a.c[3] * x3 + a.c[4] * x6 + (diag ? a.c[0] : 0.0);
+        a.B2[i] = a.b[0] * x1 + a.b[1] * x2 + a.b[2] * x3 + a.b[3] * x6;
+    }
+}
 // Dinv = inverse of the 64x64 block (jb, jb) of Q, one workgroup per cell (fused-kernel solver, P = I)
 struct LgInvArgs {
     LgView Q;         // view positioned at block (jb, jb)

@@ -44,28 +44,7 @@
 #define T18_STOP_AT(n, Uout, Src) do {} while (0)
 #endif
 
-#define T18_THETA 2.0
-// a1, a2, a3, b1, b2, b3, b6, c0, c1, c2, c3, c6, d0, d1, d2, d3, d6, e2, e3, e6  (tools/t18_coeffs.py 2.0)
-#define T18_A1 -0.10036558103014462001
-#define T18_A2 -0.007456351650625886579
-#define T18_A3 -0.00083091953191006175088
-#define T18_B1 0.24166417193309948294
-#define T18_B2 1.1119704726210786376
-#define T18_B3 0.29736195952844853785
-#define T18_B6 -0.000564510422238531483
-#define T18_C0 -4.2636626654470864734
-#define T18_C1 1.7157463766850012865
-#define T18_C2 0.073686948027488562391
-#define T18_C3 -0.0033650385206633560936
-#define T18_C6 0.000033927981037541774044
-#define T18_D0 -0.22288835997489735785
-#define T18_D1 -0.24222749901747747758
-#define T18_D2 0.050668391204088569683
-#define T18_D3 0.023404567895744140748
-#define T18_D6 -0.000010355013205937047443
-#define T18_E2 -0.13912895765004587534
-#define T18_E3 -0.013910627366173824328
-#define T18_E6 -0.000014649629174709440602
+#include "grape_t18_coeffs.h"
 
 // LDS carve: ONE left-operand region of three planes (re, im, re + im; leading dimension NP + 2), two exchange areas
 // (partial sums of the doubly computed tile, mirrored tiles) and the reduction scratch

@@ -232,15 +232,18 @@ def test_blocked_path_squaring_plan_without_host_synchronisation(g, ref):
     import torch
     from grape_jl_amd import synth
     from grape_jl_amd.sharded import ShardedEvaluator
-    pr = synth.make_problem(100, 1, 3, 2, seed=5, dt=5.0)    # ||A||_1 ~ 26: s = 3 > the initial plan of 2 launches
+    # ||A||_1 ~ 62 (Julia's exp! would square 4 times), spectral bound ~ 15: the polynomial route squares 3 times, more
+    # than the initial plan of 2 launches
+    pr = synth.make_problem(100, 1, 3, 2, seed=5, dt=12.0)
     args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
     x = pr["pulsevals"]
     Jr, Gr, taur = ref.evaluate(*args[:3], x, *args[3:])
     with g.GrapeHip(*args) as h:
         J, G, tau = h.eval(x)                     # plan too short -> adapted -> repeated inside grape_forward
         w = h.work()
-        assert w["squarings"] / w["cells"] >= 3
-        assert abs(J - Jr) <= 1e-12 and np.abs(tau - taur).max() <= 1e-12 and np.abs(G - Gr).max() <= tol_G(Gr)
+        assert w["squarings"] / w["cells"] >= 3 and w["t18_squarings"] / w["t18_cells"] >= 3
+        # (the oracle's own rounding grows with the norm of the step)
+        assert abs(J - Jr) <= 1e-11 and np.abs(tau - taur).max() <= 1e-11 and np.abs(G - Gr).max() <= 10 * tol_G(Gr)
         J2, G2, _ = h.eval(x)                     # the adapted plan fits: same numbers
         assert J2 == J and np.array_equal(G2, G)
     with g.GrapeHip(*args) as h:                  # fresh handle, device-pointer API
@@ -272,6 +275,7 @@ def test_cooperative_kernels_time_out_instead_of_hanging(g, prop, monkeypatch):
     from grape_jl_amd import synth
     pr = synth.make_problem(100, 1, 4, 2, seed=12)
     args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"])
+    monkeypatch.setenv("GRAPE_TEST_HOOKS", "1")   # (read at grape_create: only then is the fault switch looked up per evaluation)
     with g.GrapeHip(*args, prop_method=prop) as h:
         J0, G0, _ = h.eval(pr["pulsevals"])
         monkeypatch.setenv("GRAPE_TEST_DROP_SIBLING", "2")

@@ -238,3 +238,45 @@ def test_concurrent_sweeps_equal_sequential_sweeps(g, ref, prop, functional):
         assert np.abs(tg - parts["tau_grads"]).max() <= 1e-10 * max(np.abs(parts["tau_grads"]).max(), 1e-3)
     assert np.abs(out[0][4] - out[1][4]).max() <= 1e-13      # chi_k(t_n): phase restored by the storage getter
     assert np.abs(out[0][3] - out[1][3]).max() <= 1e-13 * max(1.0, np.abs(out[1][3]).max())
+
+
+def test_chebyshev_spectral_interval_is_guaranteed(g, ref):
+    """The Chebyshev propagator (Hermitian generators, 64 < N <= 256) needs a GUARANTEED spectral interval: an eigenvalue
+    outside it makes the three-term recursion grow exponentially and nothing would flag it.  A power iteration approaches
+    the norm from below: here the largest eigenvalue (1.3 times the second one) belongs to an eigenvector that is exactly
+    orthogonal to the iteration's deterministic start vector, so the estimate converges to the SECOND eigenvalue and its
+    10 % inflation does not reach the first.  grape_create bounds the norm of Hermitian operators rigorously
+    (min of ||M||_1, ||M^2||_1^(1/2), ||M^4||_1^(1/4)): the evaluation agrees with the oracle."""
+    N, L, N_T, K = 80, 1, 4, 1
+    rng = np.random.default_rng(5)
+    # the start vector of norm2_estimate (grape_hip.hip): 64-bit LCG, bits 11..30
+    st, v = 0x9E3779B97F4A7C15, np.empty(2 * N)
+    for j in range(2 * N):
+        st = (st * 6364136223846793005 + 1442695040888963407) & ((1 << 64) - 1)
+        v[j] = ((st >> 11) & 0xFFFFF) / 1048576.0 - 0.5
+    v0 = v[0::2] + 1j * v[1::2]
+    u = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    u -= v0 * (np.vdot(v0, u) / np.vdot(v0, v0))          # top eigenvector orthogonal to the start vector
+    u /= np.linalg.norm(u)
+    X = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    Gm = (X + X.conj().T)
+    P = np.eye(N) - np.outer(u, u.conj())
+    Gm = P @ Gm @ P
+    Gm = (Gm + Gm.conj().T) / 2
+    Gm /= np.abs(np.linalg.eigvalsh(Gm)).max()
+    H0 = (1.3 * np.outer(u, u.conj()) + Gm)[None]          # eigenvalues: 1.3 (eigenvector u), the rest in [-1, 1]
+    H0 = (H0 + H0.conj().transpose(0, 2, 1)) / 2
+    Hc = np.zeros((L, N, N), complex)
+    Hc[0, 0, 1] = Hc[0, 1, 0] = 0.01
+    tl = 8.0 * np.arange(N_T + 1)                           # long steps: many Chebyshev terms
+    psi0 = (u + 0.3 * rng.standard_normal(N))[None]
+    psi0 /= np.linalg.norm(psi0)
+    target = (rng.standard_normal(N) + 1j * rng.standard_normal(N))[None]
+    target /= np.linalg.norm(target)
+    x = np.full(L * N_T, 0.1)
+    with g.GrapeHip(H0, Hc, tl, psi0, target, prop_method=g.PROP_SERIES) as h:
+        J, G, tau = h.eval(x)
+        fw = h.storage(0)
+    Jr, Gr, taur = ref.evaluate(H0, Hc, tl, x, psi0, target, np.ones(K))
+    assert np.abs(np.linalg.norm(fw, axis=2) - 1.0).max() <= 1e-11
+    assert abs(J - Jr) <= 1e-11 and np.abs(tau - taur).max() <= 1e-11 and np.abs(G - Gr).max() <= 10 * tol_G(Gr)
