@@ -187,7 +187,7 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 
 // Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
 // unit grape_t18.hip), persistent grid
-extern "C" int grape_t18_launch(int NT, const void *args, size_t args_size, void *stream, int blocks);
+extern "C" int grape_t18_launch(int NT, int herm, const void *args, size_t args_size, void *stream, int blocks);
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream);
 #endif
@@ -956,8 +956,9 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             h->herm = herm && !(envh && atoi(envh));
             // GRAPE_EXPM_T18=0: Hermitian generators through the order-13 Pade kernel as well (parity reference, A/B timing)
             const char *envt = getenv("GRAPE_EXPM_T18");
-            // (N <= 64: Hermitian generators only; blocked path: every generator, with the Taylor coefficient set otherwise)
-            h->t18 = (h->herm || h->large) && !(envt && !atoi(envt));
+            // (every generator for N > 32: Chebyshev coefficient set and spectral scaling for Hermitian generators, Taylor set
+            // and norm-based scaling otherwise; N <= 32 keeps the Pade kernels: two or more cells per CU, latency-bound)
+            h->t18 = !(envt && !atoi(envt));
         }
         {
             const char *envp = getenv("GRAPE_EXPM_PERSIST"), *envl = getenv("GRAPE_EXPM_LDS_PAD"), *envx = getenv("GRAPE_CHEBY_XMODE");
@@ -1275,7 +1276,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             const long ncell = (long)ea.K * ea.N_T;
             const int t18_blocks = 8 * (int)std::max<long>(1, std::min<long>(h->num_cus / 8, (ncell + 7) / 8));
             if (h->t18 && h->NT >= 3) {
-                e = (hipError_t)grape_t18_launch(h->NT, &ea, sizeof(ea), (void *)s, t18_blocks);
+                e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, &ea, sizeof(ea), (void *)s, t18_blocks);
             } else
             switch (h->NT) {
                 case 1: e = launch_expm<1>(ea, h->herm, s, 0, h->expm_lds_pad_kb); break;

@@ -12,29 +12,31 @@
 namespace {
 #include "grape_t18.hip.h"
 
-template <int NT>
+template <int NT, bool HERM>
 hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
     static size_t lds_set[64] = {0};
     const size_t lds = sizeof(double) * (size_t)T18Lds<NT>::TOTAL;
     int dev = 0;
     hipGetDevice(&dev);
     if (lds_set[dev & 63] < lds) {
-        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT, HERM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_set[dev & 63] = lds;
     }
-    hipLaunchKernelGGL((expm_t18_kernel<NT>), dim3(blocks), dim3(NT * 64), lds, s, a);
+    hipLaunchKernelGGL((expm_t18_kernel<NT, HERM>), dim3(blocks), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
 
 // args: the ExpmArgs of grape_kernels.hip.h (same header on both sides), passed as bytes because the type of this unit
 // lives in an anonymous namespace
-extern "C" int grape_t18_launch(int NT, const void *args, size_t args_size, void *stream, int blocks) {
+extern "C" int grape_t18_launch(int NT, int herm, const void *args, size_t args_size, void *stream, int blocks) {
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
-    return (int)(NT == 3 ? launch<3>(a, (hipStream_t)stream, blocks) : launch<4>(a, (hipStream_t)stream, blocks));
+    hipStream_t s = (hipStream_t)stream;
+    if (herm) return (int)(NT == 3 ? launch<3, true>(a, s, blocks) : launch<4, true>(a, s, blocks));
+    return (int)(NT == 3 ? launch<3, false>(a, s, blocks) : launch<4, false>(a, s, blocks));
 }
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream) {

@@ -46,6 +46,19 @@
 
 #include "grape_t18_coeffs.h"
 
+// coefficient sets: Chebyshev truncation on i[-2, 2] (Hermitian generators) / Taylor polynomial (general matrices)
+template <bool HERM> struct T18Coef;
+template <> struct T18Coef<true> {
+    static constexpr double A1 = T18_A1, A2 = T18_A2, A3 = T18_A3, B1 = T18_B1, B2 = T18_B2, B3 = T18_B3, B6 = T18_B6,
+        C0 = T18_C0, C1 = T18_C1, C2 = T18_C2, C3 = T18_C3, C6 = T18_C6, D0 = T18_D0, D1 = T18_D1, D2 = T18_D2, D3 = T18_D3,
+        D6 = T18_D6, E2 = T18_E2, E3 = T18_E3, E6 = T18_E6, THETA = T18_THETA;
+};
+template <> struct T18Coef<false> {
+    static constexpr double A1 = T18T_A1, A2 = T18T_A2, A3 = T18T_A3, B1 = T18T_B1, B2 = T18T_B2, B3 = T18T_B3, B6 = T18T_B6,
+        C0 = T18T_C0, C1 = T18T_C1, C2 = T18T_C2, C3 = T18T_C3, C6 = T18T_C6, D0 = T18T_D0, D1 = T18T_D1, D2 = T18T_D2, D3 = T18T_D3,
+        D6 = T18T_D6, E2 = T18T_E2, E3 = T18T_E3, E6 = T18T_E6, THETA = T18T_THETA;
+};
+
 // LDS carve: ONE left-operand region of three planes (re, im, re + im; leading dimension NP + 2), two exchange areas
 // (partial sums of the doubly computed tile, mirrored tiles) and the reduction scratch
 template <int NT>
@@ -324,6 +337,56 @@ struct T18FormA {
     }
 };
 
+// General (non-Hermitian) generators: every element is fetched; two batches of NP*NP/4 element pairs over NTH threads
+template <int NTH, int NT>
+__device__ __forceinline__ void t18_form_a_general(const ExpmArgs &a, double *R, const int cell, const int t) {
+    constexpr int NP = 16 * NT, LD = NP + 2, HALF = NP * NP / 2, PL = NP * LD;
+    constexpr int NU = (HALF / 2 + NTH - 1) / NTH;   // pairs per thread and batch
+    const int kc = cell / a.N_T, n = cell - kc * a.N_T;
+    const int k = a.rep ? a.rep[kc] : kc;
+    const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
+    const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
+    const size_t o1 = a.L > 1 ? (size_t)2 * HALF : 0;
+    const double dt = a.dts[n];
+    double e[8];
+    for (int l = 0; l < a.L; ++l) {
+        e[l] = a.eps[(size_t)l * a.N_T + n];
+        if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
+    }
+    for (int b = 0; b < 2; ++b) {
+        double2 hr[NU], hi[NU], c0r[NU], c0i[NU], c1r[NU], c1i[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int off = min(b * (HALF / 2) + t + u * NTH, HALF - 1);
+            hr[u] = h0[off]; hi[u] = h0[HALF + off];
+            c0r[u] = hc[off]; c0i[u] = hc[HALF + off];
+            c1r[u] = hc[o1 + off]; c1i[u] = hc[o1 + HALF + off];
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int off = min(b * (HALF / 2) + t + u * NTH, HALF - 1);
+            double2 xr = hr[u], xi = hi[u];
+            xr.x = fma(e[0], c0r[u].x, xr.x); xr.y = fma(e[0], c0r[u].y, xr.y);
+            xi.x = fma(e[0], c0i[u].x, xi.x); xi.y = fma(e[0], c0i[u].y, xi.y);
+            if (a.L > 1) {
+                xr.x = fma(e[1], c1r[u].x, xr.x); xr.y = fma(e[1], c1r[u].y, xr.y);
+                xi.x = fma(e[1], c1i[u].x, xi.x); xi.y = fma(e[1], c1i[u].y, xi.y);
+            }
+            for (int l = 2; l < a.L; ++l) {
+                const double2 cr = hc[(size_t)l * 2 * HALF + off], ci = hc[(size_t)l * 2 * HALF + HALF + off];
+                xr.x = fma(e[l], cr.x, xr.x); xr.y = fma(e[l], cr.y, xr.y);
+                xi.x = fma(e[l], ci.x, xi.x); xi.y = fma(e[l], ci.y, xi.y);
+            }
+            const int i = (2 * off) / NP, j = 2 * off - i * NP;
+            const double ar0 = dt * xi.x, ar1 = dt * xi.y, ai0 = -dt * xr.x, ai1 = -dt * xr.y;
+            double *p = R + i * LD + j;
+            p[0] = ar0; p[1] = ar1;
+            p[PL] = ai0; p[PL + 1] = ai1;
+            p[2 * PL] = ar0 + ai0; p[2 * PL + 1] = ar1 + ai1;
+        }
+    }
+}
+
 // ||A||_1 of the A in the planes (credited statistics only, cells whose operator-norm bound does not certify the order):
 // all threads; returns the norm to everybody
 template <int NT>
@@ -360,44 +423,56 @@ struct T18Count {
     static constexpr int SQH = NT == 4 ? 3 * 4 * (NT * NS - NT / 2) : 3 * 4 * NT * NS;   // Hermitian square (half of the doubly computed tile)
     static constexpr int HP = 3 * 4 * NT * NS;                                           // Hermitian-result product
     static constexpr int GP = 3 * 4 * NT * NT;                                           // general product
-    static constexpr int CELL = 2 * SQH + HP + 2 * GP;
+    static constexpr int CELL = 2 * SQH + HP + 2 * GP;   // Hermitian generators
+    static constexpr int CELL_GENERAL = 5 * GP;
 };
 
 // One cell: A = -i dt H (skew-Hermitian) is in the planes; returns U = exp(A) as a ROTATED column strip (slot s of wave w
 // = row tile (w + s) % NT, all NT slots) and the number of squarings that were applied.  On return other waves may
 // still be reading the planes.
-template <int NT, class HookFirst, class HookLast>
+template <int NT, bool HERM, class HookFirst, class HookLast>
 __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, const int lane, Strip3M<NT> &U, int &s_out,
                                               bool &bad, HookFirst hook_first, HookLast hook_last) {
     using LY = T18Lds<NT>;
-    constexpr int LD = LY::LD, NS = NT - 1;
+    using CF = T18Coef<HERM>;
+    // Hermitian generators: NT - 1 of NT row tiles of the three powers come from the matrix instructions, the last one is
+    // the mirrored tile; general matrices: all NT
+    constexpr int LD = LY::LD, NS = HERM ? NT - 1 : NT;
+    constexpr bool HALF = HERM && NT == 4;
     double *R = smem, *e1 = smem + LY::E1, *e2 = smem + LY::E2, *red = smem + LY::RED;
     const T18NoHook nohook;
     Strip3M<NT> As, A2, A3, A6;
     t18_load_strip<LD, NT>(R, As, wave, lane);
     T18_STOP_AT(1, U, As);
-    // ---- A2 = A A (Hermitian) ----
+    // ---- A2 = A A ----
     {
         Acc3<NS> q;
         acc3_zero(q);
-        t18_gemm<LD, NS, NT, NT == 4>(q, R, As, wave, lane, hook_first);
+        t18_gemm<LD, NS, NT, HALF>(q, R, As, wave, lane, hook_first);
         t18_combine<NS, NT>(q, A2);
     }
-    if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A2.re[2], A2.im[2], wave, lane, 1.0);   // partial sum of tile (w+2, w) -> wave w+2
-    rot_exch_write<NT>(e2, A2.re[1], A2.im[1], wave, lane, 1.0);                             // mirrored tile -> wave w+1
+    if constexpr (HERM) {
+        if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A2.re[2], A2.im[2], wave, lane, 1.0);   // partial sum of tile (w+2, w) -> wave w+2
+        rot_exch_write<NT>(e2, A2.re[1], A2.im[1], wave, lane, 1.0);                             // mirrored tile -> wave w+1
 #pragma unroll
-    for (int t = 0; t < 2; ++t) A2.sm[t] = A2.re[t] + A2.im[t];
+        for (int t = 0; t < 2; ++t) A2.sm[t] = A2.re[t] + A2.im[t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) A2.sm[t] = A2.re[t] + A2.im[t];
+    }
     T18_STOP_AT(2, U, A2);
     STAMP(2);
-    // ---- A3 = A A2 (skew-Hermitian); the exchanged tiles of A2 arrive while the first k-blocks run ----
+    // ---- A3 = A A2 (Hermitian generators: the exchanged tiles of A2 arrive while the first k-blocks run) ----
     {
         Acc3<NS> q;
         acc3_zero(q);
         t18_gemm<LD, NS, NT, false>(q, R, A2, wave, lane, [&](int sk, int r) {
-            if (sk == 2 && r == 0) {
-                __syncthreads();
-                if constexpr (NT == 4) { t18_exch_add<NT, 2>(e1, A2, wave, lane); A2.sm[2] = A2.re[2] + A2.im[2]; }
-                t18_exch_read_last<NT>(e2, A2, wave, lane);
+            if constexpr (HERM) {
+                if (sk == 2 && r == 0) {
+                    __syncthreads();
+                    if constexpr (NT == 4) { t18_exch_add<NT, 2>(e1, A2, wave, lane); A2.sm[2] = A2.re[2] + A2.im[2]; }
+                    t18_exch_read_last<NT>(e2, A2, wave, lane);
+                }
             }
         });
         t18_combine<NS, NT>(q, A3);
@@ -406,43 +481,57 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
     STAMP(3);
     const double n2w = t18_colsum_max<NT>(A2);
     if (lane == 0) red[wave] = n2w;
+    if constexpr (!HERM) {   // general matrices: ||A||_1 and ||A3||_1 as well
+        const double n1w = t18_colsum_max<NT>(As), n3w = t18_colsum_max<NT>(A3);
+        if (lane == 0) { red[NT + wave] = n3w; red[2 * NT + wave] = n1w; }
+    }
     __syncthreads();                                                          // everybody is done reading A
-    t18_store_slots<LD, NS, NT>(R, A3, wave, lane);                           // planes = A3, with the mirrored tiles
-    t18_store_adjoint<LD, NT>(R, A3.re[1], A3.im[1], wave, lane, -1.0);
+    t18_store_slots<LD, NS, NT>(R, A3, wave, lane);                           // planes = A3 (Hermitian: with the mirrored tiles)
+    if constexpr (HERM) t18_store_adjoint<LD, NT>(R, A3.re[1], A3.im[1], wave, lane, -1.0);
 #pragma unroll
     for (int t = 0; t < NS; ++t) A3.sm[t] = A3.re[t] + A3.im[t];
     __syncthreads();
-    t18_load_slot_last<LD, NT>(R, A3, wave, lane);
+    if constexpr (HERM) t18_load_slot_last<LD, NT>(R, A3, wave, lane);
     T18_STOP_AT(4, U, A3);
     STAMP(4);
-    // ---- A6 = A3 A3 (Hermitian) ----
+    // ---- A6 = A3 A3 ----
     {
         Acc3<NS> q;
         acc3_zero(q);
-        t18_gemm<LD, NS, NT, NT == 4>(q, R, A3, wave, lane, nohook);
+        t18_gemm<LD, NS, NT, HALF>(q, R, A3, wave, lane, nohook);
         t18_combine<NS, NT>(q, A6);
     }
     T18_STOP_AT(5, U, A6);
     STAMP(5);
-    if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A6.re[2], A6.im[2], wave, lane, 1.0);
-    rot_exch_write<NT>(e2, A6.re[1], A6.im[1], wave, lane, 1.0);
-    __syncthreads();                                                          // (also: everybody is done reading the planes)
-    if constexpr (NT == 4) t18_exch_add<NT, 2>(e1, A6, wave, lane);
-    t18_exch_read_last<NT>(e2, A6, wave, lane);
-    const double n6w = t18_colsum_max<NT>(A6);
-    if (lane == 0) red[NT + wave] = n6w;
-    // the scaling needs the norm of A6 of every wave: one more barrier
+    if constexpr (HERM) {
+        if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A6.re[2], A6.im[2], wave, lane, 1.0);
+        rot_exch_write<NT>(e2, A6.re[1], A6.im[1], wave, lane, 1.0);
+        __syncthreads();                                                      // (also: everybody is done reading the planes)
+        if constexpr (NT == 4) t18_exch_add<NT, 2>(e1, A6, wave, lane);
+        t18_exch_read_last<NT>(e2, A6, wave, lane);
+        const double n6w = t18_colsum_max<NT>(A6);
+        if (lane == 0) red[NT + wave] = n6w;
+    }
+    // the scaling needs the norms of every wave (and everybody has to be done reading the planes): one barrier
     __syncthreads();
     T18_STOP_AT(6, U, A6);
     STAMP(6);
-    double n2 = red[0], n6 = red[NT];
-#pragma unroll
-    for (int w = 1; w < NT; ++w) { n2 = fmax(n2, red[w]); n6 = fmax(n6, red[NT + w]); }
-    n2 *= 1.0 + 1e-9; n6 *= 1.0 + 1e-9;   // (rounding of the computed powers)
     int s = 0;
     {
-        double t2 = T18_THETA * T18_THETA, t6 = t2 * t2 * t2;
-        while (!(n2 <= t2 || n6 <= t6) && s < 64) { ++s; t2 *= 4.0; t6 *= 64.0; }
+        double n2 = red[0], nq = red[NT], n1 = HERM ? 0.0 : red[2 * NT];
+#pragma unroll
+        for (int w = 1; w < NT; ++w) {
+            n2 = fmax(n2, red[w]); nq = fmax(nq, red[NT + w]);
+            if constexpr (!HERM) n1 = fmax(n1, red[2 * NT + w]);
+        }
+        n2 *= 1.0 + 1e-9; nq *= 1.0 + 1e-9;   // (rounding of the computed powers)
+        if constexpr (HERM) {   // beta = min(sqrt ||A2||, ||A6||^(1/6)) <= theta 2^s
+            double t2 = CF::THETA * CF::THETA, t6 = t2 * t2 * t2;
+            while (!(n2 <= t2 || nq <= t6) && s < 64) { ++s; t2 *= 4.0; t6 *= 64.0; }
+        } else {                // alpha = min(||A||, max(||A2||^(1/2), ||A3||^(1/3))) <= theta 2^s
+            double t1 = CF::THETA, t2 = t1 * t1, t3 = t2 * t1;
+            while (!(n1 <= t1 || (n2 <= t2 && nq <= t3)) && s < 64) { ++s; t1 *= 2.0; t2 *= 4.0; t3 *= 8.0; }
+        }
     }
     bad = s >= 64;   // NaN / overflow in the generator
     if (bad) s = 0;
@@ -464,21 +553,21 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         Strip3M<NT> &B1 = U;   // (U is free until the last product: its slots carry B1 to the planes)
-        B1.re[t] = T18_A1 * As.re[t] + T18_A2 * A2.re[t] + T18_A3 * A3.re[t];
-        B1.im[t] = T18_A1 * As.im[t] + T18_A2 * A2.im[t] + T18_A3 * A3.im[t];
-        B5.re[t] = T18_E2 * A2.re[t] + T18_E3 * A3.re[t] + T18_E6 * A6.re[t];
-        B5.im[t] = T18_E2 * A2.im[t] + T18_E3 * A3.im[t] + T18_E6 * A6.im[t];
+        B1.re[t] = CF::A1 * As.re[t] + CF::A2 * A2.re[t] + CF::A3 * A3.re[t];
+        B1.im[t] = CF::A1 * As.im[t] + CF::A2 * A2.im[t] + CF::A3 * A3.im[t];
+        B5.re[t] = CF::E2 * A2.re[t] + CF::E3 * A3.re[t] + CF::E6 * A6.re[t];
+        B5.im[t] = CF::E2 * A2.im[t] + CF::E3 * A3.im[t] + CF::E6 * A6.im[t];
         B5.sm[t] = B5.re[t] + B5.im[t];
-        d4 b4r = T18_D1 * As.re[t] + T18_D2 * A2.re[t] + T18_D3 * A3.re[t] + T18_D6 * A6.re[t];
-        const d4 b4i = T18_D1 * As.im[t] + T18_D2 * A2.im[t] + T18_D3 * A3.im[t] + T18_D6 * A6.im[t];
-        B3.re[t] = T18_C1 * As.re[t] + T18_C2 * A2.re[t] + T18_C3 * A3.re[t] + T18_C6 * A6.re[t];
-        B3.im[t] = T18_C1 * As.im[t] + T18_C2 * A2.im[t] + T18_C3 * A3.im[t] + T18_C6 * A6.im[t];
-        B2.re[t] = T18_B1 * As.re[t] + T18_B2 * A2.re[t] + T18_B3 * A3.re[t] + T18_B6 * A6.re[t];
-        B2.im[t] = T18_B1 * As.im[t] + T18_B2 * A2.im[t] + T18_B3 * A3.im[t] + T18_B6 * A6.im[t];
+        d4 b4r = CF::D1 * As.re[t] + CF::D2 * A2.re[t] + CF::D3 * A3.re[t] + CF::D6 * A6.re[t];
+        const d4 b4i = CF::D1 * As.im[t] + CF::D2 * A2.im[t] + CF::D3 * A3.im[t] + CF::D6 * A6.im[t];
+        B3.re[t] = CF::C1 * As.re[t] + CF::C2 * A2.re[t] + CF::C3 * A3.re[t] + CF::C6 * A6.re[t];
+        B3.im[t] = CF::C1 * As.im[t] + CF::C2 * A2.im[t] + CF::C3 * A3.im[t] + CF::C6 * A6.im[t];
+        B2.re[t] = CF::B1 * As.re[t] + CF::B2 * A2.re[t] + CF::B3 * A3.re[t] + CF::B6 * A6.re[t];
+        B2.im[t] = CF::B1 * As.im[t] + CF::B2 * A2.im[t] + CF::B3 * A3.im[t] + CF::B6 * A6.im[t];
         if (t == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (4 * r + rgd == cdiag) { b4r[r] += T18_D0; B3.re[0][r] += T18_C0; }
+                if (4 * r + rgd == cdiag) { b4r[r] += CF::D0; B3.re[0][r] += CF::C0; }
         }
         // A9 = B1 B5 + B4 through the start values: re = p1 - p2, im = p3 - p1 - p2
         q.p1[t] = b4r; q.p2[t] = (d4){0., 0., 0., 0.}; q.p3[t] = b4r + b4i;
@@ -552,7 +641,7 @@ __device__ __forceinline__ void t18_store_u_slot(const ExpmArgs &a, const int ce
 // same trajectories run concurrently on one XCD: H0_k stays in that XCD's L2).  The credited statistics (Pade order and
 // squarings Julia's exp! would use) come from the 1-norm bound of the operators or, outside its certifying
 // window, from the measured norm, exactly as in expm_persistent; the executed work is counted separately.
-template <int NT>
+template <int NT, bool HERM>
 __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
     using LY = T18Lds<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -571,9 +660,13 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
     int prev = -1;
     const int first = lo + ((int)blockIdx.x >> 3);
     if (first < hi) {
-        T18FormA<64 * NT, NT> fa(a, smem, first, tid0);
-        fa.issue();
-        fa.commit();
+        if constexpr (HERM) {
+            T18FormA<64 * NT, NT> fa(a, smem, first, tid0);
+            fa.issue();
+            fa.commit();
+        } else {
+            t18_form_a_general<64 * NT, NT>(a, smem, first, tid0);
+        }
     }
     __syncthreads();
     for (int cell = first; cell < hi; cell += per_x) {
@@ -601,20 +694,27 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
         STAMP(1);
         const int next = cell + per_x;
         const bool have_next = next < hi;
-        T18FormA<64 * NT, NT> fa(a, smem, have_next ? next : cell, tid);   // (no next cell: the same tiles again, not committed)
-        expm_t18_cell<NT>(smem, wave, lane, U, s, bad,
-            [&](int sk, int r) { if (r == 0 && prev >= 0) t18_store_u_slot<NT>(a, prev, wave, lane, Uprev, sk); },
-            [&](int sk, int r) { if (sk == 1 && r == 0) fa.issue(); });   // (fenced by scheduling barriers on both sides)
-        STAMP(11);
+        if constexpr (HERM) {
+            T18FormA<64 * NT, NT> fa(a, smem, have_next ? next : cell, tid);   // (no next cell: the same tiles again, not committed)
+            expm_t18_cell<NT, true>(smem, wave, lane, U, s, bad,
+                [&](int sk, int r) { if (r == 0 && prev >= 0) t18_store_u_slot<NT>(a, prev, wave, lane, Uprev, sk); },
+                [&](int sk, int r) { if (sk == 1 && r == 0) fa.issue(); });   // (fenced by scheduling barriers on both sides)
+            STAMP(11);
+            __syncthreads();   // everybody is done reading the planes
+            STAMP(12);
+            if (have_next) fa.commit();
+        } else {
+            expm_t18_cell<NT, false>(smem, wave, lane, U, s, bad,
+                [&](int sk, int r) { if (r == 0 && prev >= 0) t18_store_u_slot<NT>(a, prev, wave, lane, Uprev, sk); }, T18NoHook());
+            __syncthreads();
+            if (have_next) t18_form_a_general<64 * NT, NT>(a, smem, next, tid);   // (all elements: not fetched ahead)
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Uprev.re[t] = U.re[t]; Uprev.im[t] = U.im[t]; }
         prev = cell;
         any_bad |= bad;
         st_s += sj; st_max = max(st_max, sj); st_ord[oj] += 1;
         st_sq += s; st_cells += 1;
-        __syncthreads();   // everybody is done reading the planes
-        STAMP(12);
-        if (have_next) fa.commit();
         __syncthreads();
         STAMP(13);
     }
@@ -632,7 +732,8 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
             if (st_ord[o]) stat_add(a.stats, 3 + o, (unsigned long long)st_ord[o]);
         if (st_max > 0) atomicMax(&a.flags[1], st_max);
         // executed matrix instructions (all waves), squarings and cells of this path
-        stat_add(a.stats, 12, (unsigned long long)NT * ((unsigned long long)st_cells * T18Count<NT>::CELL + (unsigned long long)st_sq * T18Count<NT>::GP));
+        stat_add(a.stats, 12, (unsigned long long)NT * ((unsigned long long)st_cells * (HERM ? T18Count<NT>::CELL : T18Count<NT>::CELL_GENERAL)
+                                                         + (unsigned long long)st_sq * T18Count<NT>::GP));
         stat_add(a.stats, 13, (unsigned long long)st_sq);
         stat_add(a.stats, 14, (unsigned long long)st_cells);
         if (any_bad) atomicOr(&a.flags[0], 64);

@@ -413,11 +413,10 @@ def test_trajectories_with_identical_generators_share_propagators(g, ref, N, mon
 
 @pytest.mark.parametrize("N", [40, 64, 130])
 def test_hermitian_fast_path_matches_general_path(g, N, monkeypatch):
-    """Hermitian generators let phase A skip the mirrored tiles / blocks of the powers (N <= 64: inverse-free polynomial
-    kernel against the general order-13 Pade kernel; N > 64: Chebyshev coefficient set with the spectral scaling against
-    the Taylor set with the norm-based scaling of general matrices); the general path (GRAPE_NO_HERM=1) must give the
-    same propagators and gradient to rounding -- two different approximants, each at the 2e-14 * max(1, dt) of
-    test_expm_kernel_vs_scipy."""
+    """Hermitian generators let phase A skip the mirrored tiles / blocks of the powers and use the Chebyshev coefficient
+    set with the spectral scaling, where general matrices (GRAPE_NO_HERM=1) take the Taylor set with the norm-based
+    scaling: the two must give the same propagators and gradient to rounding -- two different approximants, each at
+    the 2e-14 * max(1, dt) of test_expm_kernel_vs_scipy."""
     from grape_jl_amd import synth
     pr = synth.make_problem(N, 2, 6, 3, seed=4242 + N, dt=1.7)
     args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
@@ -428,7 +427,7 @@ def test_hermitian_fast_path_matches_general_path(g, N, monkeypatch):
     with g.GrapeHip(*args) as h:
         J1, G1, tau1 = h.eval(pr["pulsevals"])
         U1 = h.propagator(1, 3)
-    assert np.abs(U - U1).max() <= (5e-15 if N <= 64 else 2e-14 * 1.7)
+    assert np.abs(U - U1).max() <= 2e-14 * 1.7
     assert np.abs(U.conj().T @ U - np.eye(N)).max() <= 1e-13
     assert abs(J - J1) <= 1e-14 and np.abs(tau - tau1).max() <= 1e-13
     assert np.abs(G - G1).max() <= 1e-13 * max(1.0, np.abs(G1).max())

@@ -1,14 +1,19 @@
 """A/B of the two exponentials for Hermitian generators inside ONE process: the inverse-free degree-18 polynomial kernel
 (default) against the order-13 Pade kernel (GRAPE_EXPM_T18=0, read at grape_create).
-python tools/ab_t18.py [config] [reps]  -- phase timings, differences of J, G, tau and of a sample of propagators."""
+python tools/ab_t18.py [config] [reps] [K|-] [nh]  -- phase timings, differences of J, G, tau and of a sample of propagators."""
 import os, sys, numpy as np
 sys.path.insert(0, '.')
 import grape_jl_amd as g
 from grape_jl_amd import synth
 cid = sys.argv[1] if len(sys.argv) > 1 else "C3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-K = int(sys.argv[3]) if len(sys.argv) > 3 else None
-pr = synth.make_config(cid, K=K)
+K = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+nonherm = len(sys.argv) > 4 and sys.argv[4] == "nh"   # the same shape with non-Hermitian generators (Liouvillian-like)
+if nonherm:
+    N_, L_, NT_, K0_ = synth.CONFIGS[cid]
+    pr = synth.make_problem(N_, L_, NT_, K or K0_, seed=synth.BASE_SEED ^ int(cid[1:]), hermitian=False)
+else:
+    pr = synth.make_config(cid, K=K)
 hs = []
 for v in (0, 1):
     os.environ["GRAPE_EXPM_T18"] = str(v)
