@@ -20,7 +20,7 @@ _LIBNAME = "libgrape_hip.so"
 J_T_SM, J_T_SS, J_T_RE = 0, 1, 2
 GRAD_GRADGEN, GRAD_TAYLOR = 0, 1
 PROP_EXP, PROP_SERIES = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAPE_ERR_CHI_NORM",
           -4: "GRAPE_ERR_SINGULAR", -5: "GRAPE_ERR_TAYLOR", -6: "GRAPE_ERR_NO_CONTROLS", -7: "GRAPE_ERR_AGAIN"}
@@ -29,7 +29,7 @@ STATUS = {0: "GRAPE_OK", -1: "GRAPE_ERR_INVALID", -2: "GRAPE_ERR_HIP", -3: "GRAP
 EXPORTS = ["grape_create", "grape_destroy", "grape_eval", "grape_forward", "grape_backward",
            "grape_forward_device", "grape_backward_device", "grape_check", "grape_get_propagator",
            "grape_get_tau_grads", "grape_get_storage", "grape_get_timings", "grape_reset_timings", "grape_get_work",
-           "grape_last_error", "grape_abi_version", "grape_set_fused_sweeps", "grape_get_sums",
+           "grape_last_error", "grape_abi_version", "grape_set_fused_sweeps", "grape_get_sums", "grape_backward_xi",
            "grape_get_final_states", "grape_backward_chi"]
 
 
@@ -123,6 +123,7 @@ def load_library():
     lib.grape_get_sums.argtypes = [vp, vp]
     lib.grape_get_final_states.argtypes = [vp, vp]
     lib.grape_backward_chi.argtypes = [vp, vp, vp]
+    lib.grape_backward_xi.argtypes = [vp, vp, vp, vp, C.c_double, vp]
     lib.grape_last_error.argtypes = [vp]
     lib.grape_last_error.restype = C.c_char_p
     lib.grape_abi_version.restype = ip
@@ -282,6 +283,26 @@ class GrapeHip:
         chi = _c128(chi, (self.K, self.N))
         G = np.empty(self.L * self.N_T)
         self._chk(self._lib.grape_backward_chi(self._h, chi.ctypes.data, G.ctypes.data))
+        return G
+
+    def backward_xi(self, xi, lambda_b, f_total=None, chi=None):
+        """Backward half with a caller-supplied inhomogeneity xi_k(t_n) = -d g_b / d<Psi_k(t_n)| of an ARBITRARY state
+        running cost g_b ([K, N_T+1, N], evaluated by the caller on ``storage(0)``; optimize.jl:856-866, 897-908).
+        ``chi``: boundary states of a user-defined J_T ([K, N]) or None for the handle's functional with ``f_total``
+        (default: this handle's own sum_k w_k tau_k).  Returns the gradient of J_T + lambda_b J_b."""
+        xi = _c128(xi, (self.K, self.N_T + 1, self.N))
+        G = np.empty(self.L * self.N_T)
+        cptr, fptr = None, None
+        if chi is not None:
+            chi = _c128(chi, (self.K, self.N))
+            cptr = chi.ctypes.data
+        else:
+            if f_total is None:
+                sm = self.sums()
+                f_total = complex(sm[0], sm[1])
+            f = np.array([complex(f_total).real, complex(f_total).imag], dtype=np.float64)
+            fptr = f.ctypes.data
+        self._chk(self._lib.grape_backward_xi(self._h, fptr, cptr, xi.ctypes.data, float(lambda_b), G.ctypes.data))
         return G
 
     # -- device-pointer API (torch tensors on the handle's device) -----------------------------

@@ -78,6 +78,9 @@ struct grape_handle {
     double2 *d_Dt = nullptr, *d_xi = nullptr;
     double *d_wq = nullptr, *d_gb = nullptr;
     bool have_gb = false;
+    // caller-supplied inhomogeneity xi_k(t_n) of an arbitrary state running cost (grape_backward_xi): uploaded into d_xi
+    const double2 *xi_user = nullptr;   // non-null only while that call's backward phase is being enqueued
+    double lambda_user = 0.0;
     unsigned long long *d_stats = nullptr;
     double *h_pin = nullptr;  // pinned staging
     size_t h_pin_doubles = 0;
@@ -1419,14 +1422,16 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
     SweepArgs sa{};
     sa.U = h->d_U; sa.cls = h->d_cls; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
     sa.store = h->d_bw; sa.tau = (double2 *)h->d_out; sa.f = d_f; sa.rho = h->d_rho; sa.flags = h->d_flags;
-    sa.xi = h->have_gb ? h->d_xi : nullptr; sa.wq = h->d_wq; sa.lambda_b = h->p.lambda_b;
+    sa.xi = h->xi_user ? h->xi_user : (h->have_gb ? h->d_xi : nullptr); sa.wq = h->d_wq;
+    sa.lambda_b = h->xi_user ? h->lambda_user : h->p.lambda_b;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
     sa.chi_in = d_chi;
     phase_begin(h, 2, s);
-    const bool unit = h->bw_done && !d_chi;
+    // (a caller-supplied chi or xi breaks the linearity the concurrent sweeps rely on: the backward sweep runs here)
+    const bool unit = h->bw_done && !d_chi && !h->xi_user;
     h->bw_done = false;
-    if (d_chi) h->bw_unit = false;   // d_bw is about to hold the true (normalised) backward states
+    if (d_chi || h->xi_user) h->bw_unit = false;   // d_bw is about to hold the true (normalised) backward states
     if (unit) {
         // the backward states are already there (unit targets): only rho_k and the factors z_k are left
         ChiCoeffArgs ca{};
@@ -1598,8 +1603,25 @@ int forward_finish(grape_handle *h, double *tau) {
 }
 const double *forward_sums(const grape_handle *h) { return h->h_pin + (size_t)h->L * h->N_T + 2 * (size_t)h->K; }
 
-int backward_enqueue(grape_handle *h, const double f_total[2], const double *chi) {
+int backward_enqueue(grape_handle *h, const double f_total[2], const double *chi, const double *xi = nullptr,
+                     double lambda_b = 0.0) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (xi) {   // [K][N_T+1][N] complex -> d_xi [K][N_T+1][NP] (zero padded); trapezoid weights of optimize.jl:727-750
+        const size_t rows = (size_t)h->K * (h->N_T + 1);
+        if (!h->d_xi) HIPCHK(h, dmalloc(&h->d_xi, rows * h->NP));
+        if (!h->d_wq) {
+            const int N_T = h->N_T;
+            std::vector<double> tl(N_T + 1), wq(N_T + 1);
+            HIPCHK(h, hipMemcpy(wq.data(), h->d_dts, (size_t)N_T * 8, hipMemcpyDeviceToHost));   // dt_n
+            for (int m = 0; m <= N_T; ++m)
+                tl[m] = m == 0 ? 0.5 * wq[0] : (m < N_T ? 0.5 * (wq[m - 1] + wq[m]) : 0.5 * wq[N_T - 1]);
+            HIPCHK(h, dmalloc(&h->d_wq, (size_t)N_T + 1));
+            HIPCHK(h, hipMemcpy(h->d_wq, tl.data(), tl.size() * 8, hipMemcpyHostToDevice));
+        }
+        if (h->NP != h->N) HIPCHK(h, hipMemsetAsync(h->d_xi, 0, rows * h->NP * 16, h->stream));
+        HIPCHK(h, hipMemcpy2DAsync(h->d_xi, (size_t)h->NP * 16, xi, (size_t)h->N * 16, (size_t)h->N * 16, rows,
+                                   hipMemcpyHostToDevice, h->stream));
+    }
     const double2 *d_chi = nullptr;
     if (chi) {
         if (!h->d_chi_in) HIPCHK(h, dmalloc(&h->d_chi_in, (size_t)h->K * h->N));
@@ -1608,7 +1630,10 @@ int backward_enqueue(grape_handle *h, const double f_total[2], const double *chi
     }
     const double f0[2] = {0.0, 0.0};
     HIPCHK(h, hipMemcpyAsync(h->d_f, f_total ? f_total : f0, 16, hipMemcpyHostToDevice, h->stream));
+    h->xi_user = xi ? h->d_xi : nullptr;
+    h->lambda_user = lambda_b;
     const int rc = backward_device_impl(h, h->d_f, h->d_G, h->stream, d_chi);
+    h->xi_user = nullptr;
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_G, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToHost, h->stream));
     return GRAPE_OK;
@@ -1648,10 +1673,12 @@ int multi_forward(grape_handle *h, const double *pulsevals, double *tau) {
     return GRAPE_OK;
 }
 
-int multi_backward(grape_handle *h, const double f_total[2], const double *chi, double *G) {
+int multi_backward(grape_handle *h, const double f_total[2], const double *chi, double *G, const double *xi = nullptr,
+                   double lambda_b = 0.0) {
     for (size_t g = 0; g < h->shards.size(); ++g) {
         grape_handle *c = h->shards[g];
-        const int rc = backward_enqueue(c, f_total, chi ? chi + 2 * (size_t)h->shard_lo[g] * h->N : nullptr);
+        const int rc = backward_enqueue(c, f_total, chi ? chi + 2 * (size_t)h->shard_lo[g] * h->N : nullptr,
+                                        xi ? xi + 2 * (size_t)h->shard_lo[g] * (h->N_T + 1) * h->N : nullptr, lambda_b);
         if (rc) return multi_fail(h, c, rc);
     }
     for (size_t g = 0; g < h->shards.size(); ++g) {   // sum over k of optimize.jl:579 across the shards, in shard order
@@ -1702,6 +1729,16 @@ int grape_backward_chi(grape_handle *h, const double *chi, double *G) {
     return backward_finish(h, G, false);
 }
 
+int grape_backward_xi(grape_handle *h, const double f_total[2], const double *chi, const double *xi, double lambda_b,
+                      double *G) {
+    if (!h || !xi || !G || (!chi && !f_total)) return GRAPE_ERR_INVALID;
+    if (!h->have_forward) { h->err = "grape_backward_xi called before grape_forward"; return GRAPE_ERR_INVALID; }
+    if (!h->shards.empty()) return multi_backward(h, chi ? nullptr : f_total, chi, G, xi, lambda_b);
+    int rc = backward_enqueue(h, chi ? nullptr : f_total, chi, xi, lambda_b);
+    if (rc) return rc;
+    return backward_finish(h, G, false);
+}
+
 int grape_get_sums(grape_handle *h, double sums[8]) {
     if (!h || !sums) return GRAPE_ERR_INVALID;
     if (!h->have_forward) { h->err = "grape_get_sums called before grape_forward"; return GRAPE_ERR_INVALID; }
@@ -1716,7 +1753,7 @@ int grape_get_sums(grape_handle *h, double sums[8]) {
         return GRAPE_OK;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // (the handle's stream only: other handles of the process keep running)
     HIPCHK(h, hipMemcpy(sums, h->d_out + 2 * (size_t)h->K, 8 * sizeof(double), hipMemcpyDeviceToHost));
     return GRAPE_OK;
 }
@@ -1732,7 +1769,7 @@ int grape_get_final_states(grape_handle *h, double *psiT) {
         return GRAPE_OK;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy2D(psiT, (size_t)h->N * 16, h->d_fw + (size_t)h->N_T * h->NP,
                           (size_t)(h->N_T + 1) * h->NP * 16, (size_t)h->N * 16, h->K, hipMemcpyDeviceToHost));
     return GRAPE_OK;

@@ -338,7 +338,20 @@ class GrapeWrk:
             funcs.append(fd[0][0] if fd else None)
             dfuncs.append(fd[0][1] if fd else None)
         wrap = (lambda b: _AmplitudeBackend(b, funcs, dfuncs, self.N_T)) if any(f is not None for f in funcs) else (lambda b: b)
-        if custom:
+        # keyword arguments g_b / xi of the reference (src/docstring.jl): an arbitrary state running cost.  (state_penalty=D
+        # selects the device-side fast path of the family g_b = <Psi|D|Psi>.)
+        g_b, xi_fn = self.kwargs.get("g_b"), self.kwargs.get("xi")
+        if g_b is not None and self.kwargs.get("lambda_b", 1.0) != 0.0:
+            if not callable(xi_fn):
+                # (the reference builds xi by automatic differentiation when it is missing, src/workspace.jl:313-316)
+                raise ValueError("a state running cost g_b needs the matching `xi(state, trajectory, tlist, n)`")
+            if self.kwargs.get("state_penalty") is not None:
+                raise ValueError("give either state_penalty (g_b = <Psi|D|Psi>) or the callbacks g_b / xi, not both")
+            inner_wrap_rc = wrap
+            tl, lam = self.tlist, self.kwargs.get("lambda_b", 1.0)
+            wrap = lambda b: inner_wrap_rc(_CustomRunningCostBackend(  # noqa: E731
+                b, g_b, xi_fn, lam, trajs, tl, J_T if custom else None, self.kwargs["chi"] if custom else None))
+        elif custom:
             inner_wrap = wrap
             wrap = lambda b: inner_wrap(_CustomChiBackend(b, J_T, self.kwargs["chi"], trajs))  # noqa: E731
         targets = [t.target_state if t.target_state is not None else np.zeros_like(t.initial_state) for t in trajs]
@@ -365,6 +378,9 @@ class _CustomChiBackend:
 
     def __init__(self, inner, J_T, chi, trajectories):
         self.inner, self.J_T, self.chi, self.trajectories = inner, J_T, chi, trajectories
+        # the forward call must not run the (unit-target) backward sweep in the same launch: the caller's chi arrives
+        # afterwards and the backward sweep runs then, once
+        self.inner.set_fused_sweeps(False)
 
     def eval(self, x, gradient=True, want_psiT=False):
         tau = self.inner.forward(x)
@@ -381,12 +397,58 @@ class _CustomChiBackend:
         return getattr(self.inner, name)
 
 
+class _CustomRunningCostBackend:
+    """An arbitrary state running cost on the HIP path (the ``g_b`` / ``xi`` keyword arguments of the reference,
+    src/docstring.jl; used at src/optimize.jl:727-750, 856-866, 897-908): the forward sweep runs on the device, ``g_b`` and
+    ``xi`` are evaluated on the host on the stored forward states (``grape_get_storage``), and the backward sweep takes
+    the ``xi`` array (``grape_backward_xi``).  ``chi`` (optional): the user's chi of a user-defined J_T."""
+
+    def __init__(self, inner, g_b, xi, lambda_b, trajectories, tlist, J_T=None, chi=None):
+        self.inner, self.g_b, self.xi, self.lambda_b = inner, g_b, xi, float(lambda_b)
+        self.trajectories, self.tlist, self.J_T, self.chi = trajectories, np.asarray(tlist, dtype=np.float64), J_T, chi
+        self.inner.set_fused_sweeps(False)
+
+    def eval(self, x, gradient=True, want_psiT=False):
+        tau = self.inner.forward(x)
+        fw = self.inner.storage(0)                      # Psi_k(t_n), [K, N_T+1, N]
+        K, NT1, _ = fw.shape
+        tl = self.tlist
+        J_b = 0.0
+        for k in range(K):                              # trapezoid rule of optimize.jl:727-750
+            traj = self.trajectories[k]
+            J_b += float(self.g_b(fw[k, 0], traj, tl, 1)) * (tl[1] - tl[0]) / 2.0
+            for n in range(1, NT1):
+                dt = 0.5 * (tl[n + 1] - tl[n - 1]) if n < NT1 - 1 else (tl[-1] - tl[-2]) / 2.0
+                J_b += float(self.g_b(fw[k, n], traj, tl, n + 1)) * dt
+        psiT = fw[:, -1, :]
+        if self.J_T is not None:
+            J = float(self.J_T(list(psiT), self.trajectories, tau=list(tau)))
+        else:
+            from .sharded import functional_value
+            J = functional_value(self.inner.functional, self.inner.sums(), self.inner.K_total, 0.0)
+        J += self.lambda_b * J_b
+        G = None
+        if gradient:
+            xi = np.zeros_like(fw)
+            for k in range(K):
+                for n in range(1, NT1):
+                    xi[k, n] = np.asarray(self.xi(fw[k, n], self.trajectories[k], tl, n + 1), dtype=np.complex128)
+            chi = None
+            if self.chi is not None:
+                chi = np.stack([np.asarray(c, dtype=np.complex128) for c in self.chi(list(psiT), self.trajectories, tau=list(tau))])
+            G = self.inner.backward_xi(xi, self.lambda_b, chi=chi)
+        return (J, G, tau, psiT) if want_psiT else (J, G, tau)
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+
 def _split_functional(wrk, J, tau):
     """J_parts[1] = J_T from the overlaps, J_parts[3] = lambda_b * sum_k J_b,k (src/optimize.jl:757-766): the backend
     returns their sum; J_T is evaluated again on the host from the final states / tau."""
     J_T = wrk.kwargs["J_T"](getattr(wrk, "_states", None), wrk.trajectories, tau=list(tau))
     wrk.J_parts[0] = float(J_T)
-    on = wrk.kwargs.get("state_penalty") is not None and wrk.kwargs.get("lambda_b", 1.0) != 0.0
+    on = (wrk.kwargs.get("state_penalty") is not None or wrk.kwargs.get("g_b") is not None) and wrk.kwargs.get("lambda_b", 1.0) != 0.0
     wrk.J_parts[2] = float(J - J_T) if on else 0.0
 
 

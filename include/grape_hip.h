@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_HIP_ABI_VERSION 4
+#define GRAPE_HIP_ABI_VERSION 5
 
 typedef struct grape_handle grape_handle;
 
@@ -165,6 +165,20 @@ int grape_get_final_states(grape_handle *h, double *psiT);
  * Returns the (partial, if sharded) gradient in G [L*N_T].
  */
 int grape_backward_chi(grape_handle *h, const double *chi, double *G);
+
+/* ABI v5.  An ARBITRARY state running cost g_b (optimize.jl:727-750, 856-866, 897-908: the reference calls the user's
+ * g_b(state, trajectory, tlist, n) and xi(state, trajectory, tlist, n) = -d g_b / d<Psi| inside its loops; callbacks cannot
+ * cross a C ABI, so the data does): after grape_forward the caller reads the stored forward states
+ * (grape_get_storage(0): Psi_k(t_n), [K][N_T+1][N]), evaluates g_b and xi on them, and hands back
+ *   xi       : [K][N_T+1][N] complex, xi_k(t_n) (entry n = 0 is not used, as in the reference),
+ *   lambda_b : the weight of J_b in J.
+ * The library adds lambda_b dt/2 xi_k(T) to chi_k(T) (optimize.jl:856-866) and lambda_b Dt_n / rho_k xi_k(t_n) behind
+ * every backward step (:897-908, trapezoid weights of :727-750) and returns the gradient of J_T + lambda_b J_b.  chi:
+ * [K][N] boundary states of a user-defined J_T as in grape_backward_chi, or NULL for the handle's built-in functional
+ * (then f_total = all-reduced sum_k w_k tau_k as in grape_backward).  J_b itself is the caller's trapezoid sum of g_b.
+ * (The built-in family g_b = <Psi|D|Psi> of grape_problem.Dpen stays the device-side fast path.) */
+int grape_backward_xi(grape_handle *h, const double f_total[2], const double *chi, const double *xi, double lambda_b,
+                      double *G);
 
 /* Device-resident variants used by the bench / RCCL path: same semantics, every pointer is a
  * device pointer on the handle's device; work is enqueued on `stream` (a hipStream_t passed as

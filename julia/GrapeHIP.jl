@@ -15,7 +15,7 @@ using QuantumControl.QuantumPropagators.Amplitudes: ShapedAmplitude
 using QuantumControl.Functionals: J_T_sm, J_T_ss, J_T_re
 
 const libgrape = get(ENV, "GRAPE_HIP_LIB", "libgrape_hip.so")
-const ABI_VERSION = 4
+const ABI_VERSION = 5
 
 # mirror of `grape_problem` (include/grape_hip.h); field order and types must match the C struct
 # (tests/test_abi.py compares the field lists)
@@ -170,6 +170,11 @@ function Handle(wrk; device = 0, devices = nothing, prop_method = 0, D = nothing
     rc == 0 || error(last_error(C_NULL))
     h = Handle(out[], keep, K, N, functional)
     finalizer(x -> ccall((:grape_destroy, libgrape), Cvoid, (Ptr{Cvoid},), x.ptr), h)
+    # caller-supplied chi (functional == -1) or xi (a g_b that is not given as the operator D): the backward sweep runs
+    # when that data arrives -- the forward call must not run a (unit-target) backward sweep in the same launch
+    if functional < 0 || (!isnothing(get(kw, :g_b, nothing)) && isnothing(D))
+        ccall((:grape_set_fused_sweeps, libgrape), Cint, (Ptr{Cvoid}, Cint), h.ptr, 0)
+    end
     return h
 end
 
@@ -192,7 +197,28 @@ function make_fg!(h::Handle, wrk)
     J_a, grad_J_a = get(kw, :J_a, nothing), get(kw, :grad_J_a, nothing)
     λₐ, λ_b = get(kw, :lambda_a, 1.0), get(kw, :lambda_b, 1.0)
     has_gb = !isnothing(get(kw, :g_b, nothing))
+    # g_b / xi as callbacks (src/optimize.jl:727-750, 856-866, 897-908) when no operator D was handed to create_handle:
+    # evaluated here on the stored forward states, the array xi_k(t_n) goes to grape_backward_xi (ABI v5)
+    g_b, xi = get(kw, :g_b, nothing), get(kw, :xi, nothing)
+    xi_route = has_gb && isnothing(h.keep[8])                              # (keep[8]: the operator D handed to Handle(...))
+    N_T = length(tlist) - 1
+    fw = xi_route ? Array{ComplexF64}(undef, N, N_T + 1, K) : nothing      # Ψ_k(t_n): [K][N_T+1][N] on the C side
+    xi_arr = xi_route ? zeros(ComplexF64, N, N_T + 1, K) : nothing
     states() = [view(psiT, :, k) for k = 1:K]
+    function J_b_and_xi!(want_xi)
+        check(h, ccall((:grape_get_storage, libgrape), Cint, (Ptr{Cvoid}, Cint, Ptr{ComplexF64}), h.ptr, 0, fw))
+        J_b = 0.0
+        for k = 1:K
+            traj = wrk.trajectories[k]
+            J_b += g_b(view(fw, :, 1, k), traj, tlist, 1) * (tlist[2] - tlist[1]) / 2          # :728-730
+            for n = 2:(N_T + 1)                                                                 # :739-749
+                dt = n <= N_T ? (tlist[n + 1] - tlist[n - 1]) / 2 : (tlist[end] - tlist[end - 1]) / 2
+                J_b += g_b(view(fw, :, n, k), traj, tlist, n) * dt
+                want_xi && (xi_arr[:, n, k] .= xi(view(fw, :, n, k), traj, tlist, n))
+            end
+        end
+        return J_b
+    end
 
     return function fg!(F, G, pulsevals)
         (pulsevals !== wrk.pulsevals) && (wrk.pulsevals .= pulsevals)      # src/optimize.jl:706-713
@@ -202,7 +228,22 @@ function make_fg!(h::Handle, wrk)
             wrk.result.fg_calls += 1; wrk.fg_count[1] += 1                 # :838-839
         end
         x, tau = wrk.pulsevals, wrk.result.tau_vals
-        if h.functional >= 0
+        if h.functional >= 0 && xi_route
+            # built-in J_T with a g_b given as callbacks: split-phase calls, xi on the host
+            check(h, GC.@preserve x tau ccall((:grape_forward, libgrape), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}), h.ptr, pointer(x), pointer(tau)))
+            check(h, ccall((:grape_get_final_states, libgrape), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), h.ptr, psiT))
+            check(h, ccall((:grape_get_sums, libgrape), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, sums))
+            Ψ = states()
+            wrk.J_parts[1] = wrk.J_T_takes_tau ? J_T(Ψ, wrk.trajectories; tau = tau) : J_T(Ψ, wrk.trajectories)
+            wrk.J_parts[3] = λ_b * J_b_and_xi!(!isnothing(G))
+            if !isnothing(G)
+                f_total = Float64[sums[1], sums[2]]                        # Σ_k w_k τ_k of this (unsharded) handle
+                check(h, GC.@preserve f_total xi_arr wrk ccall((:grape_backward_xi, libgrape), Cint,
+                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Cdouble, Ptr{Float64}),
+                    h.ptr, pointer(f_total), C_NULL, pointer(xi_arr), λ_b, pointer(wrk.grad_J_Tb)))
+            end
+        elseif h.functional >= 0
             # built-in functional: one call, χ is formed on the device
             J = Ref{Float64}(0.0)
             Gp = isnothing(G) ? Ptr{Float64}(C_NULL) : pointer(wrk.grad_J_Tb)
@@ -229,13 +270,20 @@ function make_fg!(h::Handle, wrk)
                 check(h, ccall((:grape_get_sums, libgrape), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, sums))
                 wrk.J_parts[3] = λ_b * sums[5]
             end
+            xi_route && (wrk.J_parts[3] = λ_b * J_b_and_xi!(!isnothing(G)))
             if !isnothing(G)
                 χ = wrk.chi_takes_tau ? chi(Ψ, wrk.trajectories; tau = tau) : chi(Ψ, wrk.trajectories)
                 for k = 1:K
                     chiT[:, k] .= χ[k]
                 end
-                check(h, GC.@preserve chiT wrk ccall((:grape_backward_chi, libgrape), Cint,
-                    (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}), h.ptr, pointer(chiT), pointer(wrk.grad_J_Tb)))
+                if xi_route
+                    check(h, GC.@preserve chiT xi_arr wrk ccall((:grape_backward_xi, libgrape), Cint,
+                        (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Cdouble, Ptr{Float64}),
+                        h.ptr, C_NULL, pointer(chiT), pointer(xi_arr), λ_b, pointer(wrk.grad_J_Tb)))
+                else
+                    check(h, GC.@preserve chiT wrk ccall((:grape_backward_chi, libgrape), Cint,
+                        (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}), h.ptr, pointer(chiT), pointer(wrk.grad_J_Tb)))
+                end
             end
         end
         if !isnothing(J_a)

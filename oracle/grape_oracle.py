@@ -120,28 +120,32 @@ def g_b_expectation(D, psi):
     return float(np.real(np.vdot(psi, D @ psi)))
 
 
-def J_b_trajectory(D, storage_k, tlist):
-    """Trapezoid rule of optimize.jl:727-750 for one trajectory."""
+def J_b_trajectory(D, storage_k, tlist, g_b=None, k=0):
+    """Trapezoid rule of optimize.jl:727-750 for one trajectory.  ``g_b(psi, k, n)``: an arbitrary state running cost
+    (the reference calls ``g_b(state, trajectory, tlist, n)``, optimize.jl:729, 745) instead of the <Psi|D|Psi> family."""
     N_T = len(tlist) - 1
-    Jb = g_b_expectation(D, storage_k[0]) * (tlist[1] - tlist[0]) / 2.0          # :728-730
+    g = (lambda psi, n: g_b(psi, k, n)) if g_b is not None else (lambda psi, n: g_b_expectation(D, psi))
+    Jb = g(storage_k[0], 0) * (tlist[1] - tlist[0]) / 2.0                        # :728-730
     for n_tl in range(1, N_T + 1):                                               # :739-749
         if n_tl < N_T:
             dt = 0.5 * (tlist[n_tl + 1] - tlist[n_tl - 1])
         else:
             dt = (tlist[-1] - tlist[-2]) / 2.0
-        Jb += g_b_expectation(D, storage_k[n_tl]) * dt
+        Jb += g(storage_k[n_tl], n_tl) * dt
     return Jb
 
 
 def evaluate_functional(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
-                        functional=FUNCTIONAL_SM, shape=None, D=None, lambda_b=1.0):
-    """optimize.jl:696-768.  Returns (J, tau, storage); J = J_T + lambda_b J_b when D is given."""
+                        functional=FUNCTIONAL_SM, shape=None, D=None, lambda_b=1.0, g_b=None):
+    """optimize.jl:696-768.  Returns (J, tau, storage); J = J_T + lambda_b J_b when D (or a callback g_b) is given."""
     K = psi0.shape[0]
     weights = np.ones(K) if weights is None else weights
     storage = forward(H0, Hc, tlist, pulsevals, psi0, shape)
     tau = np.array([np.vdot(target[k], storage[k, -1]) for k in range(K)])  # :753
     J_T, _ = J_T_and_chi(functional, tau, target, weights)
-    if D is not None:  # :764-766
+    if g_b is not None:
+        J_T += lambda_b * sum(J_b_trajectory(None, storage[k], tlist, g_b, k) for k in range(K))
+    elif D is not None:  # :764-766
         J_T += lambda_b * sum(J_b_trajectory(_dop_of(np.asarray(D), k), storage[k], tlist) for k in range(K))
     return J_T, tau, storage
 
@@ -149,8 +153,10 @@ def evaluate_functional(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
 def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
                       functional=FUNCTIONAL_SM, gradient_method="gradgen", shape=None,
                       taylor_max_order=100, taylor_tol=1e-16, return_parts=False,
-                      K_total=None, f_total=None, D=None, lambda_b=1.0):
-    """optimize.jl:824-1014 (without running costs).  Returns (J, G, tau[, parts])."""
+                      K_total=None, f_total=None, D=None, lambda_b=1.0, g_b=None, xi=None):
+    """optimize.jl:824-1014.  Returns (J, G, tau[, parts]).  State running cost: the operator D of the <Psi|D|Psi> family,
+    or the callbacks ``g_b(psi, k, n)`` and ``xi(psi, k, n)`` = -d g_b / d<Psi| (optimize.jl:856-866, 897-908 call
+    ``xi(state, trajectory, tlist, n)``)."""
     K, N = psi0.shape
     L = _hc_of(Hc, 0).shape[0]
     N_T = len(tlist) - 1
@@ -158,12 +164,18 @@ def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
     eps = np.asarray(pulsevals, dtype=np.float64).reshape(L, N_T)
 
     J_T, tau, storage = evaluate_functional(H0, Hc, tlist, pulsevals, psi0, target, weights,
-                                            functional, shape, D, lambda_b)
+                                            functional, shape, D, lambda_b, g_b)
     _, chi = J_T_and_chi(functional, tau, target, weights, K_total, f_total)  # :848-855
-    if D is not None and lambda_b != 0.0:  # :856-866  chi_k += lambda_b dt/2 xi_k(T), xi = -D Psi
+    if xi is not None:
+        xi_of = xi
+    elif D is not None:
+        xi_of = lambda psi, k, n: -(_dop_of(np.asarray(D), k) @ psi)  # noqa: E731
+    else:
+        xi_of = None
+    if xi_of is not None and lambda_b != 0.0:  # :856-866  chi_k += lambda_b dt/2 xi_k(T)
         dtl = tlist[-1] - tlist[-2]
         for k in range(K):
-            chi[k] = chi[k] + (lambda_b * dtl / 2.0) * (-(_dop_of(np.asarray(D), k) @ storage[k, -1]))
+            chi[k] = chi[k] + (lambda_b * dtl / 2.0) * xi_of(storage[k, -1], k, N_T)
     rho = np.array([np.linalg.norm(chi[k]) for k in range(K)])  # :867
     for k in range(K):
         if rho[k] < CHI_MIN_NORM:  # :1021-1025
@@ -206,9 +218,9 @@ def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
                 chik = expm(-1j * Hdag * (-dt)) @ chik  # :972
             else:
                 raise ValueError(f"Invalid gradient_method={gradient_method!r}")
-            if D is not None and lambda_b != 0.0 and n > 0:  # :897-908 (reference n > 1, 1-based)
+            if xi_of is not None and lambda_b != 0.0 and n > 0:  # :897-908 (reference n > 1, 1-based)
                 dtn = 0.5 * (tlist[n + 1] - tlist[n - 1])
-                chik = chik + (lambda_b * dtn / rho[k]) * (-(_dop_of(np.asarray(D), k) @ psi))
+                chik = chik + (lambda_b * dtn / rho[k]) * xi_of(psi, k, n)
             chi_store[k, n] = chik
 
     G_out = np.zeros(L * N_T)

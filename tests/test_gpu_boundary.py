@@ -287,3 +287,85 @@ def test_cooperative_kernels_time_out_instead_of_hanging(g, prop, monkeypatch):
         monkeypatch.delenv("GRAPE_TEST_DROP_SIBLING")
         J1, G1, _ = h.eval(pr["pulsevals"])
         assert J1 == J0 and np.array_equal(G1, G0)
+
+
+def test_arbitrary_state_running_cost_through_xi(g):
+    """ABI v5, grape_backward_xi: an ARBITRARY g_b (optimize.jl:727-750, 856-866, 897-908).  The reference calls the user's
+    g_b / xi inside its loops; here the forward sweep runs on the device, the caller evaluates xi_k(t_n) on the stored
+    states and the backward sweep takes the array.  g_b = <Psi|D|Psi>^2 (not of the built-in quadratic family), with the
+    built-in J_T_sm and with a user-supplied chi, against the numpy oracle with the same callbacks and against central
+    finite differences of the total functional; the concurrent sweeps are switched off and ONE backward sweep runs."""
+    import grape_oracle as go
+    from grape_jl_amd import synth
+    N, L, N_T, K = 12, 2, 7, 3
+    pr = synth.make_problem(N, L, N_T, K, seed=91)
+    rng = np.random.default_rng(3)
+    D = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    D = (D + D.conj().T) / 4
+    lam = 0.7
+    g_b = lambda psi, k, n: float(np.real(np.vdot(psi, D @ psi))) ** 2                     # noqa: E731
+    xi = lambda psi, k, n: -2.0 * float(np.real(np.vdot(psi, D @ psi))) * (D @ psi)        # noqa: E731  -d g_b / d<Psi|
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    x = pr["pulsevals"]
+    tl = pr["tlist"]
+
+    def total(h, xx):
+        h.forward(xx)
+        fw = h.storage(0)
+        Jb = 0.0
+        for k in range(K):
+            Jb += g_b(fw[k, 0], k, 0) * (tl[1] - tl[0]) / 2
+            for n in range(1, N_T + 1):
+                dt = 0.5 * (tl[n + 1] - tl[n - 1]) if n < N_T else (tl[-1] - tl[-2]) / 2
+                Jb += g_b(fw[k, n], k, n) * dt
+        sm = h.sums()
+        return 1.0 - (sm[0] ** 2 + sm[1] ** 2) / K ** 2 + lam * Jb, fw
+
+    with g.GrapeHip(*args) as h:
+        assert h.set_fused_sweeps(False) is False
+        J, fw = total(h, x)
+        h.reset_timings()
+        xi_arr = np.zeros_like(fw)
+        for k in range(K):
+            for n in range(1, N_T + 1):
+                xi_arr[k, n] = xi(fw[k, n], k, n)
+        G = h.backward_xi(xi_arr, lam)
+        Jr, Gr, _ = go.evaluate_gradient(*args[:3], x, *args[3:], lambda_b=lam, g_b=g_b, xi=xi)
+        assert abs(J - Jr) <= 1e-12 and np.abs(G - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)
+        for i in (0, 5, L * N_T - 1):                       # finite differences of the GPU functional itself
+            e = np.zeros_like(x); e[i] = 1e-6
+            fd = (total(h, x + e)[0] - total(h, x - e)[0]) / 2e-6
+            assert abs(fd - G[i]) <= 2e-8 * max(1.0, abs(G[i]))
+        # with a caller-supplied chi as well (chi of J_T_sm written out by hand)
+        tau = h.forward(x)
+        chi = (np.sum(pr["weights"] * tau) / K ** 2) * pr["weights"][:, None] * pr["target"]
+        G2 = h.backward_xi(xi_arr, lam, chi=chi)
+        assert np.abs(G2 - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
+
+
+def test_custom_chi_route_runs_one_backward_sweep(g):
+    """The mirror's custom-chi backend (and julia/GrapeHIP.jl make_fg! for functional_code == -1) switches the concurrent
+    sweeps off: the forward call of the custom route must not pay for a unit-target backward sweep that grape_backward_chi
+    then repeats.  HIP-event timings: the forward phase of the custom route costs what a forward-only evaluation costs."""
+    import grape_jl_amd.grape as gm
+    from grape_jl_amd import synth
+    N, L, N_T, K = 64, 1, 400, 64
+    pr = synth.make_problem(N, L, N_T, K, seed=17)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    chi_fn = lambda psis, trajs, tau=None: [  # noqa: E731  (chi of J_T_sm)
+        (np.sum(np.asarray(tau)) / K ** 2) * pr["target"][k] for k in range(K)]
+    J_fn = lambda psis, trajs, tau=None: 1.0 - abs(np.sum(np.asarray(tau))) ** 2 / K ** 2   # noqa: E731
+    with g.GrapeHip(*args) as inner:
+        be = gm._CustomChiBackend(inner, J_fn, chi_fn, [None] * K)
+        be.eval(pr["pulsevals"])
+        inner.reset_timings()
+        J, G, tau = be.eval(pr["pulsevals"])
+        t_custom = inner.timings()
+        inner.reset_timings()
+        inner.eval(pr["pulsevals"], gradient=False)
+        t_fwd = inner.timings()
+    with g.GrapeHip(*args) as h:
+        Jb, Gb, _ = h.eval(pr["pulsevals"])
+    assert abs(J - Jb) <= 1e-12 and np.abs(G - Gb).max() <= 1e-10 * max(np.abs(Gb).max(), 1e-3)
+    # forward sweep alone in both cases (a fused launch of both directions takes visibly longer: 2K workgroups share HBM)
+    assert t_custom["forward"] <= 1.25 * t_fwd["forward"] + 0.05
