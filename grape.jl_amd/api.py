@@ -336,9 +336,12 @@ class GrapeHip:
         return out
 
     def timings(self):
-        ms = np.zeros(6)
-        self._lib.grape_get_timings(self._h, ms.ctypes.data, 6)
-        return dict(zip(["expm", "forward", "backward", "deriv", "reduce", "total"], ms.tolist()))
+        ms = np.full(7, -1.0)
+        self._lib.grape_get_timings(self._h, ms.ctypes.data, 7)
+        out = dict(zip(["expm", "forward", "backward", "deriv", "reduce", "total"], ms[:6].tolist()))
+        if ms[6] >= 0.0:   # several devices behind this handle: host wall time of the enqueue halves per evaluation
+            out["host_enqueue"] = float(ms[6])
+        return out
 
     def reset_timings(self):
         self._chk(self._lib.grape_reset_timings(self._h))

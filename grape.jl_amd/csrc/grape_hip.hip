@@ -14,6 +14,7 @@
 #include "grape_cheby.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -122,6 +123,10 @@ struct grape_handle {
     std::vector<int> shard_lo;
     std::vector<int> shard_dev;
     std::vector<double> h_multi;   // host scratch of the composite: pulses, per-shard gradients
+    bool multi_threads = true;     // composite: the enqueue half of every shard from its own host thread (GRAPE_MULTI_THREADS=0:
+                                   // one after the other from the calling thread)
+    double host_enqueue_ms = 0.0;  // composite: wall time of the enqueue halves since the last grape_reset_timings
+    long host_enqueue_calls = 0;
 };
 
 namespace {
@@ -1650,12 +1655,43 @@ int backward_finish(grape_handle *h, double *G, bool accumulate) {
 // ---- several devices behind one handle: every call walks the shards twice (enqueue, then wait) ----
 int multi_fail(grape_handle *h, grape_handle *c, int rc) { h->err = c->err; return rc; }
 
+// The enqueue half of a call for every shard (copies and launches on the shard's stream, nothing waits): one host thread
+// per shard, so that a shard's several hundred launches (blocked path: ~260 per evaluation) do not delay the start of the
+// next device by their host time; the waiting half and both reductions stay on the calling thread, in shard order
+// (bitwise repeatable).  Returns the first failing shard's status.
+template <class F>
+int multi_enqueue(grape_handle *h, F fn) {
+    const size_t G = h->shards.size();
+    std::vector<int> rcs(G, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (h->multi_threads && G > 1) {
+        std::vector<std::thread> pool;
+        pool.reserve(G);
+        for (size_t g = 0; g < G; ++g) pool.emplace_back([&, g]() { rcs[g] = fn(h->shards[g], g); });
+        for (auto &t : pool) t.join();
+    } else {
+        for (size_t g = 0; g < G; ++g) {
+            rcs[g] = fn(h->shards[g], g);
+            if (rcs[g]) break;
+        }
+    }
+    h->host_enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->host_enqueue_calls += 1;
+    for (size_t g = 0; g < G; ++g)
+        if (rcs[g]) return multi_fail(h, h->shards[g], rcs[g]);
+    return GRAPE_OK;
+}
+
 int multi_forward(grape_handle *h, const double *pulsevals, double *tau) {
-    for (grape_handle *c : h->shards) {
-        c->want_bw = h->want_bw;
-        const int rc = forward_enqueue(c, pulsevals);
-        c->want_bw = true;
-        if (rc) return multi_fail(h, c, rc);
+    {
+        const bool want_bw = h->want_bw;
+        const int rc = multi_enqueue(h, [&](grape_handle *c, size_t) {
+            c->want_bw = want_bw;
+            const int r = forward_enqueue(c, pulsevals);
+            c->want_bw = true;
+            return r;
+        });
+        if (rc) return rc;
     }
     double *sums = h->h_multi.data();   // [8]: shard sums added in shard order (fixed: reproducible)
     std::fill(sums, sums + 8, 0.0);
@@ -1675,11 +1711,12 @@ int multi_forward(grape_handle *h, const double *pulsevals, double *tau) {
 
 int multi_backward(grape_handle *h, const double f_total[2], const double *chi, double *G, const double *xi = nullptr,
                    double lambda_b = 0.0) {
-    for (size_t g = 0; g < h->shards.size(); ++g) {
-        grape_handle *c = h->shards[g];
-        const int rc = backward_enqueue(c, f_total, chi ? chi + 2 * (size_t)h->shard_lo[g] * h->N : nullptr,
-                                        xi ? xi + 2 * (size_t)h->shard_lo[g] * (h->N_T + 1) * h->N : nullptr, lambda_b);
-        if (rc) return multi_fail(h, c, rc);
+    {
+        const int rc = multi_enqueue(h, [&](grape_handle *c, size_t g) {
+            return backward_enqueue(c, f_total, chi ? chi + 2 * (size_t)h->shard_lo[g] * h->N : nullptr,
+                                    xi ? xi + 2 * (size_t)h->shard_lo[g] * (h->N_T + 1) * h->N : nullptr, lambda_b);
+        });
+        if (rc) return rc;
     }
     for (size_t g = 0; g < h->shards.size(); ++g) {   // sum over k of optimize.jl:579 across the shards, in shard order
         grape_handle *c = h->shards[g];
@@ -1890,6 +1927,9 @@ int grape_get_timings(grape_handle *h, double *ms, int n) {
             if (cnt < 0) return multi_fail(h, h->shards[g], cnt);
             for (int i = 0; i < cnt; ++i) ms[i] = g == 0 ? cm[i] : std::max(ms[i], cm[i]);
         }
+        // [6]: host wall time of the enqueue halves (forward + backward) per evaluation -- what the calling thread spends
+        // before the first device can be waited for
+        if (n > kPhases) { ms[kPhases] = h->host_enqueue_calls ? 2.0 * h->host_enqueue_ms / h->host_enqueue_calls : -1.0; cnt = kPhases + 1; }
         return cnt;
     }
     HIPCHK(h, hipSetDevice(h->device));
@@ -1915,6 +1955,8 @@ int grape_reset_timings(grape_handle *h) {
             const int rc = grape_reset_timings(c);
             if (rc) return multi_fail(h, c, rc);
         }
+        h->host_enqueue_ms = 0.0;
+        h->host_enqueue_calls = 0;
         return GRAPE_OK;
     }
     HIPCHK(h, hipSetDevice(h->device));
@@ -1979,6 +2021,10 @@ int multi_create(grape_handle **out, const grape_problem *p) {
     h->K_total = p->K_total > 0 ? p->K_total : p->K;
     h->device = p->devices ? p->devices[0] : p->device;
     h->h_multi.assign(8, 0.0);
+    {
+        const char *envm = getenv("GRAPE_MULTI_THREADS");
+        h->multi_threads = !(envm && atoi(envm) == 0);
+    }
     const size_t nn2 = (size_t)2 * p->N * p->N;
     const int base = p->K / G, rem = p->K % G;
     for (int g = 0; g < G; ++g) {

@@ -216,7 +216,9 @@ int grape_get_storage(grape_handle *h, int which /*0 fw, 1 bw*/, double *out /* 
 /* Per-phase device time in milliseconds, measured with HIP events recorded on the stream the
  * kernels were launched on, AVERAGED over the evaluations since the last grape_reset_timings
  * (at most the 64 most recent): [0] expm kernel, [1] forward sweep, [2] backward sweep,
- * [3] cell derivatives, [4] reduction, [5] whole grape_eval.  Synchronises the device.
+ * [3] cell derivatives, [4] reduction, [5] whole grape_eval; handles with several devices (ndev > 1) also [6] the host
+ * wall time of the enqueue halves per evaluation (every shard is enqueued from its own host thread).  Synchronises
+ * the device.
  * Returns the number of entries written. */
 int grape_get_timings(grape_handle *h, double *ms, int n);
 int grape_reset_timings(grape_handle *h);
