@@ -103,6 +103,7 @@ struct grape_handle {
     double2 *d_z = nullptr;
     int num_cus = 256;
     bool series = false;
+    bool u_fallback = false;     // prop_method = ExpProp was asked for, but the propagators do not fit the device: matrix-free
     double *d_rb = nullptr;      // [K + Kc*L] 2-norm estimates of H0_k and of the control operators
     double series_tol = 1e-17, series_theta = 3.0;
     double *d_n1 = nullptr;      // 1-norms of H0_k and of the control operators (order-13 certificate of the expm kernel)
@@ -990,6 +991,27 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     for (auto &ring : h->ph)
         for (auto &ph : ring) { CCHK(hipEventCreate(&ph.e0)); CCHK(hipEventCreate(&ph.e1)); ph.used = false; }
 
+    if (!h->series) {
+        // The reference's memory grows as K N (N_T + 1) (stored states, src/workspace.jl:215); the materialised propagators
+        // of this path take KC N_T NP^2 16 bytes on top (8.4 GB at C3, 134 GB at C5).  When they do not fit the device,
+        // the evaluation does NOT fail in hipMalloc: the handle switches to the matrix-free propagator (power series /
+        // Chebyshev sweeps summed to rounding: the same exp(-i H dt) Psi to 1e-15, no U; without the parked terms if
+        // those do not fit either) and says so in grape_get_work[12].  GRAPE_U_BUDGET_GB overrides the free-memory figure.
+        size_t free_b = 0, total_b = 0;
+        const char *envb = getenv("GRAPE_U_BUDGET_GB");
+        if (envb) free_b = (size_t)(atof(envb) * 1073741824.0);
+        else if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)-1;
+        const double u_bytes = (double)h->KC * h->N_T * (double)h->NP * h->NP * 16.0;
+        // everything else the ExpProp path allocates is at most a few GB: stored states, operator copies, chunk scratch
+        const double other = 2.0 * h->K * (h->N_T + 1.0) * h->NP * 16.0 + 6.0 * h->K * (double)h->NP * h->NP * 16.0 + (h->large ? 7e9 : 1e8);
+        if (u_bytes + other > 0.92 * (double)free_b) {
+            h->series = true;
+            h->u_fallback = true;
+            if (h->NP == 48) { h->NT = 4; h->NP = 64; }   // (the matrix-free kernels are built for 16 / 32 / 64)
+            if (p->gradient_method == GRAPE_GRAD_GRADGEN) h->series_tol = std::min(h->series_tol, 1e-17);
+        }
+    }
+
     const int N = h->N, NP = h->NP, L = h->L, K = h->K, N_T = h->N_T;
     const size_t pp = (size_t)NP * NP, nn = (size_t)N * N;
     const int Kc = p->hc_per_traj ? K : 1;
@@ -1138,7 +1160,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         // derivative series
         std::vector<double> rb((size_t)K + (size_t)Kc * L);
         // Hermitian generators on the Chebyshev propagator (matrix-free, N > 64): guaranteed bounds instead of estimates
-        const bool rigorous = h->herm && p->prop_method == GRAPE_PROP_SERIES && h->large;
+        const bool rigorous = h->herm && h->series && h->large;
         auto bound_of = [&](const double *m) { return rigorous ? herm_norm2_bound(m, N) : norm2_estimate(m, N); };
         const int nops = K + Kc * L;
         auto op_ptr = [&](int q) { return q < K ? p->H0 + 2 * (size_t)q * nn : p->Hc + 2 * (size_t)(q - K) * nn; };
@@ -1165,8 +1187,11 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         // derivative series, and the area fits a modest share of HBM)
         const char *envp = getenv("GRAPE_SERIES_PARK");
         const size_t bytes = (size_t)K * N_T * 32 * NP * 16;
+        size_t free_p = 0, total_p = 0;
+        if (const char *envb = getenv("GRAPE_U_BUDGET_GB")) free_p = (size_t)(atof(envb) * 1073741824.0);
+        else if (hipMemGetInfo(&free_p, &total_p) != hipSuccess) free_p = (size_t)-1;
         if (NP >= 48 && !h->large && h->deriv2 && h->series_tol <= h->taylor_tol && bytes <= ((size_t)24 << 30) &&
-            !(envp && atoi(envp) == 0)) {
+            (double)bytes <= 0.5 * (double)free_p && !(envp && atoi(envp) == 0)) {
             h->maxp = 32;
             CCHK(dmalloc(&h->d_gpark, (size_t)K * N_T * h->maxp * NP));
             CCHK(dmalloc(&h->d_morder, (size_t)K * N_T));
@@ -1903,7 +1928,11 @@ int grape_get_propagator(grape_handle *h, int k, int n, double *out) {
         const int rc = grape_get_propagator(h->shards[g], k - h->shard_lo[g], n, out);
         return rc ? multi_fail(h, h->shards[g], rc) : GRAPE_OK;
     }
-    if (h->series) { h->err = "prop_method = GRAPE_PROP_SERIES is matrix-free: no propagator is materialised"; return GRAPE_ERR_INVALID; }
+    if (h->series) {
+        h->err = h->u_fallback ? "the propagators did not fit the device: this handle evaluates matrix-free (grape_get_work[12]), no propagator is materialised"
+                               : "prop_method = GRAPE_PROP_SERIES is matrix-free: no propagator is materialised";
+        return GRAPE_ERR_INVALID;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     const size_t pp = (size_t)h->NP * h->NP;
@@ -1970,10 +1999,10 @@ int grape_reset_timings(grape_handle *h) {
 int grape_get_work(grape_handle *h, double *out, int n) {
     if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
     if (!h->shards.empty()) {   // every entry is a count: the shards add up
-        const int m = n < 12 ? n : 12;
+        const int m = n < 13 ? n : 13;
         std::fill(out, out + m, 0.0);
         for (grape_handle *c : h->shards) {
-            double cw[12] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+            double cw[13] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
             const int rc = grape_get_work(c, cw, m);
             if (rc < 0) return multi_fail(h, c, rc);
             for (int i = 0; i < m; ++i) out[i] += cw[i];
@@ -2005,6 +2034,9 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     if (n > 9) out[9] = (double)st[12] * 2048.0;
     if (n > 10) out[10] = (double)st[13];
     if (n > 11) out[11] = (double)st[14];
+    // mode of the ExpProp request: 0 the propagators are materialised, 1 they did not fit the device and the evaluation
+    // runs matrix-free (see grape_create)
+    if (n > 12) out[12] = h->u_fallback ? 1.0 : 0.0;
     return 4;
 }
 

@@ -226,7 +226,10 @@ int grape_reset_timings(grape_handle *h);
  * [2] flop of the expm kernel (SURVEY 8d F_exp), [3] flop of the derivative kernel, [4] derivative series orders,
  * [5] cells solved by the pivoted fallback, [6] propagators exponentiated, [7] terms and [8] (sub-)steps of the
  * matrix-free propagator, [9] flop of the matrix instructions EXECUTED by the inverse-free exponential of Hermitian
- * generators (grape_t18.hip.h), [10] its squarings, [11] its cells (entries beyond n are not written). */
+ * generators (grape_t18.hip.h), [10] its squarings, [11] its cells, [12] 1 when prop_method = GRAPE_PROP_EXP was asked for
+ * but the propagators (KC N_T NP^2 16 bytes) do not fit the device and the handle evaluates matrix-free instead of
+ * failing in hipMalloc (same results to rounding; shards of a composite handle: the number of shards in that mode)
+ * (entries beyond n are not written). */
 int grape_get_work(grape_handle *h, double *out, int n);
 
 const char *grape_last_error(grape_handle *h); /* h may be NULL: error of the last failed create */

@@ -130,3 +130,48 @@ def test_baseline_config_c5_full_problem_and_gpu_shard(g):
     assert abs(functional_value(0, sums, K) - J) <= 1e-14
     assert np.abs(Gsum - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
     print(f"C5 full (K = 64) on one GPU: {tm_full}\nC5 shard (K = 8): {tm_shard}")
+
+
+def test_propagators_that_do_not_fit_the_device_fall_back_to_the_matrix_free_path(g, monkeypatch):
+    """The reference's memory grows as K N (N_T + 1) (src/workspace.jl:215); the materialised propagators of the ExpProp
+    path take KC N_T NP^2 16 bytes on top.  When they do not fit, grape_create switches the handle to the matrix-free
+    propagator instead of failing in hipMalloc and reports it (grape_get_work[12]).
+    (a) forced on a small problem (GRAPE_U_BUDGET_GB): same J, tau, G as the ExpProp evaluation to rounding;
+    (b) N = 64, 1000 steps, K = 5120: 336 GB of propagators on a 288-GiB device (K = 4096, 268 GB, still fits and runs
+        as ExpProp) -- properties of the evaluation."""
+    from grape_jl_amd import synth
+    for N in (40, 64):
+        pr = synth.make_problem(N, 2, 30, 5, seed=77 + N)
+        args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+        with g.GrapeHip(*args) as h:
+            J0, G0, tau0 = h.eval(pr["pulsevals"])
+            assert h.work()["matrix_free_fallback"] == 0
+        monkeypatch.setenv("GRAPE_U_BUDGET_GB", "0.0001")
+        with g.GrapeHip(*args) as h:
+            J1, G1, tau1 = h.eval(pr["pulsevals"])
+            w = h.work()
+            assert w["matrix_free_fallback"] == 1 and w["expm_cells"] == 0 and w["series_terms"] > 0
+            with pytest.raises(g.GrapeHipError):
+                h.propagator(0, 0)
+        monkeypatch.delenv("GRAPE_U_BUDGET_GB")
+        assert abs(J1 - J0) <= 1e-12 and np.abs(tau1 - tau0).max() <= 1e-12
+        assert np.abs(G1 - G0).max() <= 1e-10 * max(np.abs(G0).max(), 1e-3)
+    # (b) K = 5120 at the headline shape
+    N, L, N_T, K = 64, 2, 1000, 5120
+    pr = synth.make_problem(N, L, N_T, K, seed=4096)
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+        x = pr["pulsevals"]
+        J, G, tau = h.eval(x)
+        w = h.work()
+        assert w["matrix_free_fallback"] == 1 and w["cells"] == K * N_T
+        assert abs(J - (1.0 - abs(tau.sum()) ** 2 / K ** 2)) <= 1e-12
+        assert np.isfinite(G).all() and np.abs(G).max() > 0
+        fw = h.storage(0)[:64]
+        assert np.abs(np.linalg.norm(fw, axis=2) - 1.0).max() <= 1e-11
+        rng = np.random.default_rng(0)
+        d = rng.standard_normal(L * N_T)
+        d /= np.linalg.norm(d)
+        eps = 1e-5
+        Jp, _, _ = h.eval(x + eps * d, gradient=False)
+        Jm, _, _ = h.eval(x - eps * d, gradient=False)
+        assert abs((Jp - Jm) / (2 * eps) - G @ d) <= 1e-7 * max(1.0, abs(G @ d)) + 1e-9
