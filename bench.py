@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matrix-free", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--nonhermitian", action="store_true",
+                    help="the same shape with non-Hermitian generators (Liouvillian-like; secondary lines in profiles/)")
     args = ap.parse_args()
 
     import torch
@@ -161,7 +163,7 @@ def main():
     per_gpu_default = {"C4": 128, "C5": 8}   # BASELINE.json: C4 = 1024 and C5 = 64 trajectories over 8 GPUs
     K_local = args.traj_per_gpu or per_gpu_default.get(args.config, K0)
     K_total = K_local * world
-    pr = synth.make_config(args.config, K=K_local, k_offset=rank * K_local)
+    pr = synth.make_config(args.config, K=K_local, k_offset=rank * K_local, hermitian=not args.nonhermitian)
     h = g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"],
                    functional=g.J_T_SM, gradient_method=g.GRAD_GRADGEN, K_total=K_total, device=dev.index)
     ev = ShardedEvaluator(h, K_total, g.J_T_SM, dist=dist, device=dev)
@@ -297,7 +299,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: N={N}, L={L} controls, N_T={N_T} time steps, "
-                                   f"{K_local} trajectories per GPU ({K_total} total), J_T_sm, ExpProp",
+                                   f"{K_local} trajectories per GPU ({K_total} total), J_T_sm, ExpProp"
+                                   + (", NON-HERMITIAN generators" if args.nonhermitian else ""),
                        "gradient_method": "gradgen (exact derivative via the series of the gradient-generator "
                                           "propagator on the extended state)",
                        "one_eval": f"one shard evaluation = functional + full gradient of {K_local} trajectories; "

@@ -43,6 +43,8 @@ struct grape_handle {
     double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;
     double *d_H0q = nullptr, *d_Hcq = nullptr, *d_park2 = nullptr;   // two-pass series kernel: untransposed fragments, parking area
     int deriv2 = 0, deriv2_maxm = 0;
+    bool deriv_stream = false;   // GRAPE_DERIV_STREAM=1: matrix-at-a-time products in deriv2_kernel for 3-4 controls as well
+    bool deriv_stream_never = false;   // GRAPE_DERIV_STREAM=0: the all-at-once form for more than four controls too (A/B timing)
     int deriv_blocks = 0;
     // blocked path (64 < N <= 256): per-chunk scratch matrices, planar [cell][2][NP*NP]
     bool large = false;
@@ -413,7 +415,7 @@ hipError_t launch_deriv_mfma(int NP, const DerivMfmaArgs &a, int nblocks, hipStr
     }
 }
 
-template <int NP, int LMAX, bool CACHE>
+template <int NP, int LMAX, bool CACHE, bool STREAM = false>
 hipError_t launch_d2(const Deriv2Args &a, int nblocks, hipStream_t s) {
     constexpr int NW = NP / 16 <= 8 ? NP / 16 : 8;
     const size_t lds = sizeof(double) * 2 * 2 * NP * 16;
@@ -421,33 +423,35 @@ hipError_t launch_d2(const Deriv2Args &a, int nblocks, hipStream_t s) {
     int dev = 0;
     hipGetDevice(&dev);
     if (lds > 48 * 1024) {
-        hipError_t e = lim.ensure((const void *)deriv2_kernel<NP, LMAX, CACHE>, dev, lds);
+        hipError_t e = lim.ensure((const void *)deriv2_kernel<NP, LMAX, CACHE, STREAM>, dev, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((deriv2_kernel<NP, LMAX, CACHE>), dim3(nblocks), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((deriv2_kernel<NP, LMAX, CACHE, STREAM>), dim3(nblocks), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_deriv2(int NP, const Deriv2Args &a, int nblocks, hipStream_t s) {
+// stream_l: the 1 + L products of an order one matrix at a time (deriv2_kernel STREAM_L): always for more than four controls
+// (the all-at-once form spills there), for three and four controls when asked for (GRAPE_DERIV_STREAM=1)
+hipError_t launch_deriv2(int NP, const Deriv2Args &a, int nblocks, hipStream_t s, bool stream_l = false, bool never = false) {
     switch (NP) {
         case 48:
             if (a.L == 1) return launch_d2<48, 1, true>(a, nblocks, s);
             if (a.L == 2) return launch_d2<48, 2, true>(a, nblocks, s);
-            if (a.L <= 4) return launch_d2<48, 4, false>(a, nblocks, s);
-            return launch_d2<48, 8, false>(a, nblocks, s);
+            if (a.L <= 4) return stream_l ? launch_d2<48, 4, false, true>(a, nblocks, s) : launch_d2<48, 4, false>(a, nblocks, s);
+            return never ? launch_d2<48, 8, false>(a, nblocks, s) : launch_d2<48, 8, false, true>(a, nblocks, s);
         case 64:
             if (a.L == 1) return launch_d2<64, 1, true>(a, nblocks, s);
             if (a.L == 2) return launch_d2<64, 2, true>(a, nblocks, s);
-            if (a.L <= 4) return launch_d2<64, 4, false>(a, nblocks, s);
-            return launch_d2<64, 8, false>(a, nblocks, s);
+            if (a.L <= 4) return stream_l ? launch_d2<64, 4, false, true>(a, nblocks, s) : launch_d2<64, 4, false>(a, nblocks, s);
+            return never ? launch_d2<64, 8, false>(a, nblocks, s) : launch_d2<64, 8, false, true>(a, nblocks, s);
         case 128:
             if (a.L == 1) return launch_d2<128, 1, false>(a, nblocks, s);
             if (a.L == 2) return launch_d2<128, 2, false>(a, nblocks, s);
-            return launch_d2<128, 4, false>(a, nblocks, s);
+            return stream_l ? launch_d2<128, 4, false, true>(a, nblocks, s) : launch_d2<128, 4, false>(a, nblocks, s);
         case 256:
             if (a.L == 1) return launch_d2<256, 1, false>(a, nblocks, s);
             if (a.L == 2) return launch_d2<256, 2, false>(a, nblocks, s);
-            return launch_d2<256, 4, false>(a, nblocks, s);
+            return stream_l ? launch_d2<256, 4, false, true>(a, nblocks, s) : launch_d2<256, 4, false>(a, nblocks, s);
         default:
             return hipErrorInvalidValue;
     }
@@ -976,6 +980,9 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             h->expm_lds_pad_kb = envl ? std::max(0, atoi(envl)) : 0;
             h->cheby_xmode = envx ? atoi(envx) & 1 : 1;
             h->test_hooks = envk && atoi(envk) == 1;
+            const char *envs = getenv("GRAPE_DERIV_STREAM");
+            h->deriv_stream = envs && atoi(envs) == 1;
+            h->deriv_stream_never = envs && atoi(envs) == 0;
         }
         if (h->KC < p->K) {
             if (hipSetDevice(h->device) != hipSuccess || hipMalloc((void **)&h->d_cls, p->K * sizeof(int)) != hipSuccess ||
@@ -1530,7 +1537,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
 #ifdef GRAPE_DIAG
         d2.ablate = getenv("GRAPE_DIAG_ABLATE_D2") ? atoi(getenv("GRAPE_DIAG_ABLATE_D2")) : 0;
 #endif
-        e = launch_deriv2(h->NP, d2, h->deriv_blocks, s);
+        e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);
     } else if (h->NP >= 48) {
         DerivMfmaArgs dm{};
         dm.H0p = h->d_H0p; dm.Hcp = h->d_Hcp; dm.eps = h->d_eps; dm.shape = h->d_shape; dm.dts = h->d_dts;

@@ -3248,13 +3248,18 @@ struct Deriv2Args {
 #endif
 };
 
-template <int NP, int LMAX, bool CACHE_A>
+// STREAM_L (more than four controls): the 1 + L products of an order are formed ONE MATRIX AT A TIME and folded into the
+// running sum at once (H w = H0 w + sum_l e_l mu_l w; pass 2 also takes the overlap of mu_l^dagger w with u_a), so that the
+// partial products of a single matrix are live instead of those of all 1 + L: with all of them live the kernel needs
+// 24 (1 + L) accumulator registers and spills from L = 5 on (644 bytes of scratch per lane at L = 6).
+template <int NP, int LMAX, bool CACHE_A, bool STREAM_L = false>
 __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kernel(Deriv2Args a) {
     extern __shared__ __attribute__((aligned(16))) double dsm2[];   // [2][2][NP*16] ping-pong vector block
     constexpr int RT = NP / 16, KS = NP / 4;
     constexpr int NW = RT <= 8 ? RT : 8, TPW = RT / NW, NV = 1 + LMAX;
     static_assert(RT % NW == 0, "row tiles must divide evenly over the waves");
     static_assert(!CACHE_A || TPW == 1, "operand caching only for one tile per wave");
+    static_assert(!(CACHE_A && STREAM_L), "the streamed form reads its operator fragments from L2");
     __shared__ double redn[2][NW][16];
     __shared__ double redo[NW][LMAX][16][2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -3345,6 +3350,25 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
             }
         };
 
+        // product of ONE fixed matrix (fragments at `frag`: [RT][KS][2][64]) with the vector block `vc` for row tile rt
+        auto product1 = [&](const double *frag, const double *vc, const int rt, d4 &qr, d4 &qi) __attribute__((always_inline)) {
+            d4 p1 = (d4){0., 0., 0., 0.}, p2 = p1, p3 = p1;
+            const double *vb = vc + (size_t)rg * 16 + c;
+            double bwr = vb[0], bwi = vb[vplane];
+#pragma unroll 4
+            for (int ks = 0; ks < KS; ++ks) {
+                const double ar = frag[((size_t)rt * KS + ks) * 128 + lane], ai = frag[((size_t)rt * KS + ks) * 128 + 64 + lane];
+                const double br = bwr, bi = bwi, bs = bwr + bwi;
+                if (ks + 1 < KS) {
+                    bwr = vb[(size_t)(4 * (ks + 1)) * 16];
+                    bwi = vb[vplane + (size_t)(4 * (ks + 1)) * 16];
+                }
+                p1 = MFMA64(ar, br, p1); p2 = MFMA64(ai, bi, p2); p3 = MFMA64(ar + ai, bs, p3);
+            }
+            qr = p1 - p2;
+            qi = p3 - p1 - p2;
+        };
+
         // ---- terms already parked by the forward sweep? (same 16 cells in every wave: uniform decision) ----
         int Mc = 0;
         bool use_g = false;
@@ -3384,10 +3408,19 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt) {
                 const int rt = wave + tt * NW;
-                d4 pr[NV], pi[NV];
-                products(h0q, hcq, vc, rt, pr, pi);
+                d4 pr[STREAM_L ? 1 : NV], pi[STREAM_L ? 1 : NV];
+                if constexpr (STREAM_L) {
+                    product1(h0q, vc, rt, pr[0], pi[0]);
+                    for (int l = 0; l < L; ++l) {
+                        d4 qr, qi;
+                        product1(hcq + (size_t)l * RT * KS * 128, vc, rt, qr, qi);
+                        pr[0] += e[l] * qr; pi[0] += e[l] * qi;
+                    }
+                } else {
+                    products(h0q, hcq, vc, rt, pr, pi);
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) { pr[0] += e[l] * pr[1 + l]; pi[0] += e[l] * pi[1 + l]; }
+                    for (int l = 0; l < LMAX; ++l) { pr[0] += e[l] * pr[1 + l]; pi[0] += e[l] * pi[1 + l]; }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
@@ -3457,7 +3490,25 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                         { ur[r] = park[o]; ui[r] = park[vplane + o]; }
                     }
                 }
-                d4 pr[NV], pi[NV];
+                d4 pr[STREAM_L ? 1 : NV], pi[STREAM_L ? 1 : NV];
+                if constexpr (STREAM_L) {
+                    product1(h0p, vc, rt, pr[0], pi[0]);
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) {
+                        if (l < L) {
+                            d4 qr, qi;
+                            product1(hcp + (size_t)l * RT * KS * 128, vc, rt, qr, qi);
+                            double sr = 0., si = 0.;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {   // conj(mu_l^dagger w) * u
+                                sr += qr[r] * ur[r] + qi[r] * ui[r];
+                                si += qr[r] * ui[r] - qi[r] * ur[r];
+                            }
+                            dr[l] += inv * sr; di[l] += inv * si;
+                            pr[0] += e[l] * qr; pi[0] += e[l] * qi;
+                        }
+                    }
+                } else {
                 products(h0p, hcp, vc, rt, pr, pi);
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) {
@@ -3469,6 +3520,7 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                     }
                     dr[l] += inv * sr; di[l] += inv * si;
                     pr[0] += e[l] * pr[1 + l]; pi[0] += e[l] * pi[1 + l];
+                }
                 }
                 if (aa > 0) {
 #pragma unroll

@@ -28,6 +28,7 @@ CONFIGS = {
     # not BASELINE configurations: the headline shape at the two other register-tile counts (timing tools only)
     "X48": (48, 2, 1000, 128),
     "X32": (32, 2, 1000, 128),
+    "C3L6": (64, 6, 1000, 128),   # six controls (the control count of /root/reference/test/test_lbfgsb_saddle_point.jl:89-124)
 }
 
 
@@ -101,11 +102,12 @@ def make_problem(N: int, L: int, N_T: int, K: int, seed: int = BASE_SEED, dt: fl
                 pulsevals=pulsevals, weights=np.ones(K))
 
 
-def make_config(cid: str, K: int | None = None, k_offset: int = 0):
+def make_config(cid: str, K: int | None = None, k_offset: int = 0, hermitian: bool = True):
     N, L, N_T, K0 = CONFIGS[cid]
     if cid == "C1":
         return readme_tls()
-    return make_problem(N, L, N_T, K0 if K is None else K, seed=BASE_SEED ^ int(cid[1:]), k_offset=k_offset)
+    tag = int("".join(ch for ch in cid if ch.isdigit()))   # C3 -> 3, X48 -> 48, C3L6 -> 36
+    return make_problem(N, L, N_T, K0 if K is None else K, seed=BASE_SEED ^ tag, k_offset=k_offset, hermitian=hermitian)
 
 
 def readme_tls(eps0: float = 0.2, T: float = 5.0, nt: int = 501):
