@@ -268,7 +268,33 @@ struct T18FormA {
     int cell, t;
     double2 hr[NU], hi[NU], c0r[NU], c0i[NU], c1r[NU], c1i[NU];
     __device__ __forceinline__ T18FormA(const ExpmArgs &a_, double *R_, int cell_, int t_) : a(a_), R(R_), cell(cell_), t(t_) {}
+    // tile q of the upper block triangle, row by row: (ti, tj), ti <= tj
+    static constexpr int tile_i(int q) {
+        int ti = 0, r = q;
+        for (int it = 0; it < NT - 1; ++it)
+            if (r >= NT - ti) { r -= NT - ti; ++ti; }
+        return ti;
+    }
+    static constexpr int tile_j(int q) {
+        int ti = 0, r = q;
+        for (int it = 0; it < NT - 1; ++it)
+            if (r >= NT - ti) { r -= NT - ti; ++ti; }
+        return ti + r;
+    }
     __device__ __forceinline__ void locate(int u, int &i, int &j, bool &diag) const {
+        if constexpr (NTH == 256) {
+            // element pair t + 256 u: tile 2u + (t >> 7), position t & 127 inside it -- the tile indices are compile-time
+            // constants up to one select (the general form below costs ~120 vector instructions per cell for index
+            // arithmetic, and nothing issued to the vector ALU is free in this kernel)
+            const bool hi = (t >> 7) != 0;
+            const int idx = t & 127;
+            const int q0 = 2 * u < NTILE ? 2 * u : NTILE - 1, q1 = 2 * u + 1 < NTILE ? 2 * u + 1 : NTILE - 1;
+            const int ti = hi ? tile_i(q1) : tile_i(q0), tj = hi ? tile_j(q1) : tile_j(q0);
+            i = 16 * ti + (idx >> 3);
+            j = 16 * tj + 2 * (idx & 7);
+            diag = ti == tj;
+            return;
+        }
         const int ep = min(t + u * NTH, NPAIR - 1), q = ep >> 7, idx = ep & 127;   // (surplus threads repeat the last pair)
         int ti = 0, r = q;
 #pragma unroll
@@ -337,11 +363,13 @@ struct T18FormA {
     }
 };
 
-// General (non-Hermitian) generators: every element is fetched; two batches of NP*NP/4 element pairs over NTH threads
+// General (non-Hermitian) generators: every element is fetched; NBATCH batches of element pairs over NTH threads (each
+// batch keeps 6 x 16 bytes per pair and thread in flight: four batches stay inside the register budget of this kernel)
 template <int NTH, int NT>
 __device__ __forceinline__ void t18_form_a_general(const ExpmArgs &a, double *R, const int cell, const int t) {
     constexpr int NP = 16 * NT, LD = NP + 2, HALF = NP * NP / 2, PL = NP * LD;
-    constexpr int NU = (HALF / 2 + NTH - 1) / NTH;   // pairs per thread and batch
+    constexpr int NBATCH = 4;
+    constexpr int NU = (HALF / NBATCH + NTH - 1) / NTH;   // pairs per thread and batch
     const int kc = cell / a.N_T, n = cell - kc * a.N_T;
     const int k = a.rep ? a.rep[kc] : kc;
     const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
@@ -353,18 +381,18 @@ __device__ __forceinline__ void t18_form_a_general(const ExpmArgs &a, double *R,
         e[l] = a.eps[(size_t)l * a.N_T + n];
         if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
     }
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NBATCH; ++b) {
         double2 hr[NU], hi[NU], c0r[NU], c0i[NU], c1r[NU], c1i[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int off = min(b * (HALF / 2) + t + u * NTH, HALF - 1);
+            const int off = min(b * (HALF / NBATCH) + t + u * NTH, HALF - 1);
             hr[u] = h0[off]; hi[u] = h0[HALF + off];
             c0r[u] = hc[off]; c0i[u] = hc[HALF + off];
             c1r[u] = hc[o1 + off]; c1i[u] = hc[o1 + HALF + off];
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int off = min(b * (HALF / 2) + t + u * NTH, HALF - 1);
+            const int off = min(b * (HALF / NBATCH) + t + u * NTH, HALF - 1);
             double2 xr = hr[u], xi = hi[u];
             xr.x = fma(e[0], c0r[u].x, xr.x); xr.y = fma(e[0], c0r[u].y, xr.y);
             xi.x = fma(e[0], c0i[u].x, xi.x); xi.y = fma(e[0], c0i[u].y, xi.y);
@@ -704,14 +732,23 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
             STAMP(12);
             if (have_next) fa.commit();
         } else {
-            expm_t18_cell<NT, false>(smem, wave, lane, U, s, bad,
-                [&](int sk, int r) { if (r == 0 && prev >= 0) t18_store_u_slot<NT>(a, prev, wave, lane, Uprev, sk); }, T18NoHook());
+            // (general matrices: the result is stored at once -- carried into the next cell's first product it costs 64
+            // registers there, and this variant runs at the register limit: 84 bytes of scratch per lane with it)
+            expm_t18_cell<NT, false>(smem, wave, lane, U, s, bad, T18NoHook(), T18NoHook());
+#pragma unroll
+            for (int sl = 0; sl < NT; ++sl) {
+                Strip<NT> Us;
+                Us.re[sl] = U.re[sl]; Us.im[sl] = U.im[sl];
+                t18_store_u_slot<NT>(a, cell, wave, lane, Us, sl);
+            }
             __syncthreads();
             if (have_next) t18_form_a_general<64 * NT, NT>(a, smem, next, tid);   // (all elements: not fetched ahead)
         }
+        if constexpr (HERM) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { Uprev.re[t] = U.re[t]; Uprev.im[t] = U.im[t]; }
-        prev = cell;
+            for (int t = 0; t < NT; ++t) { Uprev.re[t] = U.re[t]; Uprev.im[t] = U.im[t]; }
+            prev = cell;
+        }
         any_bad |= bad;
         st_s += sj; st_max = max(st_max, sj); st_ord[oj] += 1;
         st_sq += s; st_cells += 1;
