@@ -121,17 +121,24 @@ template <int LD, int NS, int NT, bool HALF_LAST, class Hook>
 __device__ __forceinline__ void t18_gemm(Acc3<NS> &q, const double *__restrict__ R, const Strip3M<NT> &B, int wave, int lane,
                                          Hook hook) {
     constexpr int PL = 16 * NT * LD;
-    const double *__restrict__ xr = R + (lane & 15) * LD + (lane >> 4);
-    int rowoff[NS];
+    // one base address per slot for the planes re / im (the im plane is an immediate offset of 8 PL <= 33792 bytes away)
+    // and ONE MORE per slot for the third plane: 16 PL bytes exceed the 16-bit offset field of ds_read, and with a single
+    // base the compiler kept a table of per-k-step addresses in accumulation registers -- three v_accvgpr_read per
+    // k-step, i.e. vector instructions between the matrix instructions of every k-step (8 % of a product)
+    const double *__restrict__ xp[NS], *__restrict__ xq[NS];
 #pragma unroll
-    for (int so = 0; so < NS; ++so) rowoff[so] = 16 * ((wave + so) % NT) * LD;
+    for (int so = 0; so < NS; ++so) {
+        xp[so] = R + (lane & 15) * LD + (lane >> 4) + 16 * ((wave + so) % NT) * LD;
+        xq[so] = xp[so] + 2 * PL;
+        // (NT = 4: keep it a register of its own -- folded back into xp[so] + constant it is the table again; NT = 3: all
+        // three planes are within the offset field of one base)
+        if constexpr (8 * (3 * PL) > 65535) asm volatile("" : "+v"(xq[so]));
+    }
     double are[NS], aim[NS], asu[NS];
     {
         const int k0 = 16 * wave;
 #pragma unroll
-        for (int so = 0; so < NS; ++so) {
-            are[so] = xr[rowoff[so] + k0]; aim[so] = xr[PL + rowoff[so] + k0]; asu[so] = xr[2 * PL + rowoff[so] + k0];
-        }
+        for (int so = 0; so < NS; ++so) { are[so] = xp[so][k0]; aim[so] = xp[so][PL + k0]; asu[so] = xq[so][k0]; }
     }
 #pragma unroll
     for (int sk = 0; sk < NT; ++sk) {
@@ -150,7 +157,7 @@ __device__ __forceinline__ void t18_gemm(Acc3<NS> &q, const double *__restrict__
             if (more) {
 #pragma unroll
                 for (int so = 0; so < NS; ++so)
-                    if (so < nsn) are[so] = xr[rowoff[so] + kn];
+                    if (so < nsn) are[so] = xp[so][kn];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -160,7 +167,7 @@ __device__ __forceinline__ void t18_gemm(Acc3<NS> &q, const double *__restrict__
             if (more) {
 #pragma unroll
                 for (int so = 0; so < NS; ++so)
-                    if (so < nsn) aim[so] = xr[PL + rowoff[so] + kn];
+                    if (so < nsn) aim[so] = xp[so][PL + kn];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -170,7 +177,7 @@ __device__ __forceinline__ void t18_gemm(Acc3<NS> &q, const double *__restrict__
             if (more) {
 #pragma unroll
                 for (int so = 0; so < NS; ++so)
-                    if (so < nsn) asu[so] = xr[2 * PL + rowoff[so] + kn];
+                    if (so < nsn) asu[so] = xq[so][kn];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -659,10 +666,13 @@ template <int NT>
 __device__ __forceinline__ void t18_store_u_slot(const ExpmArgs &a, const int cell, const int wave, const int lane, const Strip<NT> &T,
                                                  const int sl) {
     constexpr int NP = 16 * NT;
-    double2 *Uc = a.U + (size_t)cell * NP * NP;
-    const int col = 16 * wave + (lane & 15), rg = lane >> 4, tb = (wave + sl) % NT;
+    // wave-uniform part of the address (cell, row tile, register) in scalar registers, one per-lane offset for all stores:
+    // address arithmetic on the vector ALU would sit between the matrix instructions of the product these stores ride in
+    const int tb = (wave + sl) % NT;
+    double2 *Ut = a.U + ((size_t)cell * NP + 16 * tb) * NP;
+    const unsigned loff = (unsigned)((lane >> 4) * NP + 16 * wave + (lane & 15));   // (unsigned: scalar base + 32-bit lane offset)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Uc[(16 * tb + 4 * r + rg) * NP + col] = make_double2(T.re[sl][r], T.im[sl][r]);
+    for (int r = 0; r < 4; ++r) (Ut + (size_t)(4 * r) * NP)[loff] = make_double2(T.re[sl][r], T.im[sl][r]);
 }
 
 // Persistent launch: one workgroup per CU walks a round-robin share of the cells of its XCD (neighbouring cells of the
