@@ -16,4 +16,8 @@ for c in C3 C5; do
   f=$(find gpurun_out/${tag}_prof_$c -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/${tag}_${c}_kernel_stats.csv
 done
+
+# secondary lines: six controls and non-Hermitian generators at the headline shape
+python3 bench.py --config C3L6 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_L6.json 2> gpurun_out/${tag}_bench_C3_L6.err
+python3 bench.py --config C3 --nonhermitian --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_nonherm.json 2> gpurun_out/${tag}_bench_C3_nonherm.err
 exit $rc
