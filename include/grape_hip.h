@@ -74,10 +74,15 @@ typedef enum {
 
 /* prop_method keyword of the reference (workspace.jl:222-232 -> QuantumPropagators.init_prop) */
 typedef enum {
-    GRAPE_PROP_EXP = 0,    /* ExpProp: U_n = exp(-i H_n dt_n) materialised (Pade scaling and squaring on MFMA) */
+    GRAPE_PROP_EXP = 0,    /* ExpProp: U_n = exp(-i H_n dt_n) materialised on MFMA: N > 32 by an inverse-free degree-18
+                              polynomial in five products with scaling and squaring (Chebyshev coefficients and a spectral
+                              bound for Hermitian generators, Taylor coefficients otherwise), N <= 32 and GRAPE_EXPM_T18=0
+                              by the order-13 Pade approximant as in Julia's exp!.  Propagators that do not fit the device
+                              make the handle evaluate matrix-free (grape_get_work[12]).                           */
     GRAPE_PROP_SERIES = 1  /* matrix-free polynomial propagator on the state vector (the role of the reference's
-                              Cheby / Newton methods, README.md:55): power series of exp(-i H_n dt_n) Psi summed to
-                              prop_tolerance, O(N^2) per term, no U; N <= 64                                      */
+                              Cheby / Newton methods, README.md:55), no U: N <= 64 power series of exp(-i H_n dt_n) Psi
+                              summed to prop_tolerance, O(N^2) per term; 64 < N <= 256 cooperative Chebyshev sweeps
+                              (Hermitian generators, guaranteed spectral interval) or Taylor sub-steps              */
 } grape_prop_method;
 
 typedef struct {
