@@ -87,3 +87,79 @@ def test_shard_range_and_functional_value():
     assert abs(functional_value(1, [0, 0, 2.0, 0], 4) - 0.5) < 1e-15
     assert abs(functional_value(2, [0, 0, 0, 1.0], 4) - 0.75) < 1e-15
     _ = torch
+
+
+class _AgainShard:
+    """Stand-in whose check() reports GRAPE_ERR_AGAIN (blocked path: the squaring plan was too short) on chosen ranks for
+    the first evaluation only, as GrapeHip.check does."""
+    N = 100   # blocked path: the collective decision applies
+
+    def __init__(self, again_first):
+        self.calls, self.again_first = 0, again_first
+
+    def check(self, stream):
+        from grape_jl_amd.api import GrapeHipError
+        self.calls += 1
+        if self.calls == 1 and self.again_first:
+            raise GrapeHipError(-7, "plan too short")
+
+
+def _again_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # only rank 1 sees AGAIN: BOTH ranks must be told to repeat (an evaluation contains collectives; a rank repeating alone
+    # would pair its all-reduces with the other rank's next step), and nobody repeats the second time
+    ev = ShardedEvaluator(_AgainShard(again_first=(rank == 1)), 4, 0, dist=dist, device=None)
+    first = ev.check_collective(0)
+    second = ev.check_collective(0)
+    q.put((rank, first, second))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_again_is_decided_by_all_ranks_together():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_again_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get() for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == [(0, True, False), (1, True, False)]
+
+
+def test_in_handle_reduction_order_is_the_shard_order():
+    """Several devices behind ONE handle (grape_problem.ndev): the library adds the shard sums and the partial gradients in
+    shard order on the calling thread, whatever order the per-shard host threads finish their enqueue halves in -- the
+    result equals the left-to-right sum over contiguous trajectory blocks bit for bit, and differs from other orders only
+    in the last bits.  Restated here with the oracle shards: (a) blocks of shard_range reproduce the unsharded result,
+    (b) the fixed order is what makes repeated evaluations identical."""
+    pr = synth.make_problem(6, 2, 5, 7, seed=9)
+    pr["weights"] = np.linspace(0.5, 2.0, 7)
+    G_parts, sums = [], np.zeros(8)
+    shards = []
+    for g in range(3):
+        lo, hi = shard_range(7, 3, g)
+        sh = OracleShard(pr, lo, hi, 7, 0)
+        sh.forward(pr["pulsevals"])
+        shards.append(sh)
+        sums += sh.sums()                       # shard order, as multi_forward does
+    for sh in shards:
+        G_parts.append(sh.backward(complex(sums[0], sums[1])))
+    G = G_parts[0].copy()
+    for part in G_parts[1:]:
+        G += part                               # shard order, as multi_backward does
+    Jr, Gr, _ = go.evaluate_gradient(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                                     pr["weights"], functional=0)
+    assert abs(functional_value(0, sums, 7) - Jr) < 1e-14 and np.abs(G - Gr).max() < 1e-14
+    G2 = G_parts[0].copy()
+    for part in G_parts[1:]:
+        G2 += part
+    assert np.array_equal(G, G2)
+    assert np.abs((G_parts[2] + G_parts[1]) + G_parts[0] - G).max() < 1e-15   # another order: equal to rounding only

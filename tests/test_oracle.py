@@ -192,3 +192,32 @@ def test_state_running_cost_oracles_agree_and_match_finite_differences(ref):
     J0 = go.evaluate_functional(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], 0)[0]
     J1 = go.evaluate_functional(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], 0, D=D, lambda_b=0.5)[0]
     assert abs(J1 - J0 - 0.5 * Jb) < 1e-13
+
+
+def test_state_running_cost_callbacks_reproduce_the_operator_family():
+    """The numpy oracle takes an arbitrary state running cost as callbacks g_b(psi, k, n) / xi(psi, k, n) (its restatement
+    of /root/reference/src/optimize.jl:727-750, 856-866, 897-908, used as the checker of grape_backward_xi): with
+    g_b = <Psi|D|Psi>, xi = -D Psi they reproduce the operator route, and a quartic g_b agrees with central finite
+    differences of the total functional."""
+    import grape_oracle as go
+    from grape_jl_amd import synth
+    pr = synth.make_problem(5, 2, 6, 2, seed=12)
+    rng = np.random.default_rng(1)
+    D = rng.standard_normal((5, 5)) + 1j * rng.standard_normal((5, 5))
+    D = (D + D.conj().T) / 4
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"])
+    J0, G0, _ = go.evaluate_gradient(*args, D=D, lambda_b=0.6)
+    J1, G1, _ = go.evaluate_gradient(*args, lambda_b=0.6, g_b=lambda p, k, n: float(np.real(np.vdot(p, D @ p))),
+                                     xi=lambda p, k, n: -(D @ p))
+    assert abs(J0 - J1) < 1e-14 and np.abs(G0 - G1).max() < 1e-14
+    g4 = lambda p, k, n: float(np.real(np.vdot(p, D @ p))) ** 2                      # noqa: E731
+    x4 = lambda p, k, n: -2.0 * float(np.real(np.vdot(p, D @ p))) * (D @ p)         # noqa: E731
+    J, G, _ = go.evaluate_gradient(*args, lambda_b=0.6, g_b=g4, xi=x4)
+    x = pr["pulsevals"]
+    for i in (0, 7):
+        e = np.zeros_like(x); e[i] = 1e-6
+        Jp = go.evaluate_functional(pr["H0"], pr["Hc"], pr["tlist"], x + e, pr["psi0"], pr["target"], pr["weights"],
+                                    lambda_b=0.6, g_b=g4)[0]
+        Jm = go.evaluate_functional(pr["H0"], pr["Hc"], pr["tlist"], x - e, pr["psi0"], pr["target"], pr["weights"],
+                                    lambda_b=0.6, g_b=g4)[0]
+        assert abs((Jp - Jm) / 2e-6 - G[i]) < 1e-8
