@@ -65,7 +65,8 @@ struct grape_handle {
     // propagators U_cn; KC == K (d_cls == nullptr) for ensembles of distinct generators
     int KC = 0;
     bool herm = false;           // all generators Hermitian: A = -i dt H is skew-Hermitian (expm uses the symmetry)
-    bool t18 = false;            // Hermitian generators: inverse-free polynomial exponential (grape_t18.hip.h)
+    bool t18 = false;            // inverse-free polynomial exponential (grape_t18.hip.h)
+    bool t18_small = true;       // ... also for N <= 32 (GRAPE_EXPM_T18_SMALL=0: the Pade kernels there)
     // diagnostic switches, read ONCE in grape_create (never in the evaluation path: getenv is not thread-safe against setenv)
     bool expm_persist = true;    // GRAPE_EXPM_PERSIST=0: one workgroup per cell instead of the persistent Pade kernel
     int expm_lds_pad_kb = 0;     // GRAPE_EXPM_LDS_PAD: extra dynamic LDS of the Pade kernels (fewer cells per CU)
@@ -972,6 +973,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             // (every generator for N > 32: Chebyshev coefficient set and spectral scaling for Hermitian generators, Taylor set
             // and norm-based scaling otherwise; N <= 32 keeps the Pade kernels: two or more cells per CU, latency-bound)
             h->t18 = !(envt && !atoi(envt));
+            const char *envs2 = getenv("GRAPE_EXPM_T18_SMALL");
+            h->t18_small = !(envs2 && !atoi(envs2));
         }
         {
             const char *envp = getenv("GRAPE_EXPM_PERSIST"), *envl = getenv("GRAPE_EXPM_LDS_PAD"), *envx = getenv("GRAPE_CHEBY_XMODE");
@@ -1314,8 +1317,11 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             e = h->t18 ? expm_large_t18(h, s) : expm_large(h, s);
         } else {
             const long ncell = (long)ea.K * ea.N_T;
-            const int t18_blocks = 8 * (int)std::max<long>(1, std::min<long>(h->num_cus / 8, (ncell + 7) / 8));
-            if (h->t18 && h->NT >= 3) {
+            // workgroups per CU of the polynomial kernel: one at three and four tiles per side (512 registers, 137 / 84 KB of
+            // LDS), several of the small ones (NT = 1: 139 registers and 16 KB, NT = 2: 256 registers) -- those are latency-bound
+            const int per_cu = h->NT == 1 ? 10 : h->NT == 2 ? 4 : 1;
+            const int t18_blocks = 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * per_cu, (ncell + 7) / 8));
+            if (h->t18 && (h->NT >= 3 || h->t18_small)) {
                 e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, &ea, sizeof(ea), (void *)s, t18_blocks);
             } else
             switch (h->NT) {

@@ -12,18 +12,18 @@
 namespace {
 #include "grape_t18.hip.h"
 
-template <int NT, bool HERM>
+template <int NT, bool SYM, bool CHEB>
 hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
     static size_t lds_set[64] = {0};
     const size_t lds = sizeof(double) * (size_t)T18Lds<NT>::TOTAL;
     int dev = 0;
     hipGetDevice(&dev);
     if (lds_set[dev & 63] < lds) {
-        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT, HERM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT, SYM, CHEB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_set[dev & 63] = lds;
     }
-    hipLaunchKernelGGL((expm_t18_kernel<NT, HERM>), dim3(blocks), dim3(NT * 64), lds, s, a);
+    hipLaunchKernelGGL((expm_t18_kernel<NT, SYM, CHEB>), dim3(blocks), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -35,8 +35,14 @@ extern "C" int grape_t18_launch(int NT, int herm, const void *args, size_t args_
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
     hipStream_t s = (hipStream_t)stream;
-    if (herm) return (int)(NT == 3 ? launch<3, true>(a, s, blocks) : launch<4, true>(a, s, blocks));
-    return (int)(NT == 3 ? launch<3, false>(a, s, blocks) : launch<4, false>(a, s, blocks));
+    // Hermitian generators: Chebyshev coefficient set and spectral scaling for every size, the tile symmetry from three
+    // tiles per side on; general matrices: Taylor set
+    switch (NT) {
+        case 1: return (int)(herm ? launch<1, false, true>(a, s, blocks) : launch<1, false, false>(a, s, blocks));
+        case 2: return (int)(herm ? launch<2, false, true>(a, s, blocks) : launch<2, false, false>(a, s, blocks));
+        case 3: return (int)(herm ? launch<3, true, true>(a, s, blocks) : launch<3, false, false>(a, s, blocks));
+        default: return (int)(herm ? launch<4, true, true>(a, s, blocks) : launch<4, false, false>(a, s, blocks));
+    }
 }
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream) {

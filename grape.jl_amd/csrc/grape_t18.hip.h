@@ -454,7 +454,7 @@ __device__ __forceinline__ double t18_norm1(double *smem, const int tid) {
 // matrix instructions per wave of one cell without squarings / of one squaring (executed-work counter)
 template <int NT>
 struct T18Count {
-    static constexpr int NS = NT - 1;
+    static constexpr int NS = NT > 1 ? NT - 1 : 1;
     static constexpr int SQH = NT == 4 ? 3 * 4 * (NT * NS - NT / 2) : 3 * 4 * NT * NS;   // Hermitian square (half of the doubly computed tile)
     static constexpr int HP = 3 * 4 * NT * NS;                                           // Hermitian-result product
     static constexpr int GP = 3 * 4 * NT * NT;                                           // general product
@@ -465,15 +465,19 @@ struct T18Count {
 // One cell: A = -i dt H (skew-Hermitian) is in the planes; returns U = exp(A) as a ROTATED column strip (slot s of wave w
 // = row tile (w + s) % NT, all NT slots) and the number of squarings that were applied.  On return other waves may
 // still be reading the planes.
-template <int NT, bool HERM, class HookFirst, class HookLast>
+// SYM: the tile symmetry of Hermitian generators is used (NT >= 3: NT - 1 of NT row tiles of the three powers from the matrix
+// instructions); CHEB: Hermitian generators (Chebyshev coefficient set, spectral scaling) -- without SYM for NT <= 2, where no
+// wave computes an off-diagonal tile it could mirror.
+template <int NT, bool SYM, bool CHEB, class HookFirst, class HookLast>
 __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, const int lane, Strip3M<NT> &U, int &s_out,
                                               bool &bad, HookFirst hook_first, HookLast hook_last) {
     using LY = T18Lds<NT>;
-    using CF = T18Coef<HERM>;
+    using CF = T18Coef<CHEB>;
     // Hermitian generators: NT - 1 of NT row tiles of the three powers come from the matrix instructions, the last one is
     // the mirrored tile; general matrices: all NT
-    constexpr int LD = LY::LD, NS = HERM ? NT - 1 : NT;
-    constexpr bool HALF = HERM && NT == 4;
+    constexpr int LD = LY::LD, NS = SYM ? NT - 1 : NT;
+    constexpr bool HALF = SYM && NT == 4;
+    static_assert(!SYM || (CHEB && NT >= 3), "tile symmetry needs Hermitian generators and at least three tiles per side");
     double *R = smem, *e1 = smem + LY::E1, *e2 = smem + LY::E2, *red = smem + LY::RED;
     const T18NoHook nohook;
     Strip3M<NT> As, A2, A3, A6;
@@ -486,7 +490,7 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
         t18_gemm<LD, NS, NT, HALF>(q, R, As, wave, lane, hook_first);
         t18_combine<NS, NT>(q, A2);
     }
-    if constexpr (HERM) {
+    if constexpr (SYM) {
         if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A2.re[2], A2.im[2], wave, lane, 1.0);   // partial sum of tile (w+2, w) -> wave w+2
         rot_exch_write<NT>(e2, A2.re[1], A2.im[1], wave, lane, 1.0);                             // mirrored tile -> wave w+1
 #pragma unroll
@@ -502,7 +506,7 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
         Acc3<NS> q;
         acc3_zero(q);
         t18_gemm<LD, NS, NT, false>(q, R, A2, wave, lane, [&](int sk, int r) {
-            if constexpr (HERM) {
+            if constexpr (SYM) {
                 if (sk == 2 && r == 0) {
                     __syncthreads();
                     if constexpr (NT == 4) { t18_exch_add<NT, 2>(e1, A2, wave, lane); A2.sm[2] = A2.re[2] + A2.im[2]; }
@@ -516,17 +520,17 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
     STAMP(3);
     const double n2w = t18_colsum_max<NT>(A2);
     if (lane == 0) red[wave] = n2w;
-    if constexpr (!HERM) {   // general matrices: ||A||_1 and ||A3||_1 as well
+    if constexpr (!CHEB) {   // general matrices: ||A||_1 and ||A3||_1 as well
         const double n1w = t18_colsum_max<NT>(As), n3w = t18_colsum_max<NT>(A3);
         if (lane == 0) { red[NT + wave] = n3w; red[2 * NT + wave] = n1w; }
     }
     __syncthreads();                                                          // everybody is done reading A
     t18_store_slots<LD, NS, NT>(R, A3, wave, lane);                           // planes = A3 (Hermitian: with the mirrored tiles)
-    if constexpr (HERM) t18_store_adjoint<LD, NT>(R, A3.re[1], A3.im[1], wave, lane, -1.0);
+    if constexpr (SYM) t18_store_adjoint<LD, NT>(R, A3.re[1], A3.im[1], wave, lane, -1.0);
 #pragma unroll
     for (int t = 0; t < NS; ++t) A3.sm[t] = A3.re[t] + A3.im[t];
     __syncthreads();
-    if constexpr (HERM) t18_load_slot_last<LD, NT>(R, A3, wave, lane);
+    if constexpr (SYM) t18_load_slot_last<LD, NT>(R, A3, wave, lane);
     T18_STOP_AT(4, U, A3);
     STAMP(4);
     // ---- A6 = A3 A3 ----
@@ -538,12 +542,14 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
     }
     T18_STOP_AT(5, U, A6);
     STAMP(5);
-    if constexpr (HERM) {
+    if constexpr (SYM) {
         if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A6.re[2], A6.im[2], wave, lane, 1.0);
         rot_exch_write<NT>(e2, A6.re[1], A6.im[1], wave, lane, 1.0);
         __syncthreads();                                                      // (also: everybody is done reading the planes)
         if constexpr (NT == 4) t18_exch_add<NT, 2>(e1, A6, wave, lane);
         t18_exch_read_last<NT>(e2, A6, wave, lane);
+    }
+    if constexpr (CHEB) {
         const double n6w = t18_colsum_max<NT>(A6);
         if (lane == 0) red[NT + wave] = n6w;
     }
@@ -553,14 +559,14 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
     STAMP(6);
     int s = 0;
     {
-        double n2 = red[0], nq = red[NT], n1 = HERM ? 0.0 : red[2 * NT];
+        double n2 = red[0], nq = red[NT], n1 = CHEB ? 0.0 : red[2 * NT];
 #pragma unroll
         for (int w = 1; w < NT; ++w) {
             n2 = fmax(n2, red[w]); nq = fmax(nq, red[NT + w]);
-            if constexpr (!HERM) n1 = fmax(n1, red[2 * NT + w]);
+            if constexpr (!CHEB) n1 = fmax(n1, red[2 * NT + w]);
         }
         n2 *= 1.0 + 1e-9; nq *= 1.0 + 1e-9;   // (rounding of the computed powers)
-        if constexpr (HERM) {   // beta = min(sqrt ||A2||, ||A6||^(1/6)) <= theta 2^s
+        if constexpr (CHEB) {   // beta = min(sqrt ||A2||, ||A6||^(1/6)) <= theta 2^s
             double t2 = CF::THETA * CF::THETA, t6 = t2 * t2 * t2;
             while (!(n2 <= t2 || nq <= t6) && s < 64) { ++s; t2 *= 4.0; t6 *= 64.0; }
         } else {                // alpha = min(||A||, max(||A2||^(1/2), ||A3||^(1/3))) <= theta 2^s
@@ -679,7 +685,7 @@ __device__ __forceinline__ void t18_store_u_slot(const ExpmArgs &a, const int ce
 // same trajectories run concurrently on one XCD: H0_k stays in that XCD's L2).  The credited statistics (Pade order and
 // squarings Julia's exp! would use) come from the 1-norm bound of the operators or, outside its certifying
 // window, from the measured norm, exactly as in expm_persistent; the executed work is counted separately.
-template <int NT, bool HERM>
+template <int NT, bool SYM, bool CHEB>
 __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
     using LY = T18Lds<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -698,7 +704,7 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
     int prev = -1;
     const int first = lo + ((int)blockIdx.x >> 3);
     if (first < hi) {
-        if constexpr (HERM) {
+        if constexpr (SYM) {
             T18FormA<64 * NT, NT> fa(a, smem, first, tid0);
             fa.issue();
             fa.commit();
@@ -732,9 +738,9 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
         STAMP(1);
         const int next = cell + per_x;
         const bool have_next = next < hi;
-        if constexpr (HERM) {
+        if constexpr (SYM) {
             T18FormA<64 * NT, NT> fa(a, smem, have_next ? next : cell, tid);   // (no next cell: the same tiles again, not committed)
-            expm_t18_cell<NT, true>(smem, wave, lane, U, s, bad,
+            expm_t18_cell<NT, true, true>(smem, wave, lane, U, s, bad,
                 [&](int sk, int r) { if (r == 0 && prev >= 0) t18_store_u_slot<NT>(a, prev, wave, lane, Uprev, sk); },
                 [&](int sk, int r) { if (sk == 1 && r == 0) fa.issue(); });   // (fenced by scheduling barriers on both sides)
             STAMP(11);
@@ -744,7 +750,7 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
         } else {
             // (general matrices: the result is stored at once -- carried into the next cell's first product it costs 64
             // registers there, and this variant runs at the register limit: 84 bytes of scratch per lane with it)
-            expm_t18_cell<NT, false>(smem, wave, lane, U, s, bad, T18NoHook(), T18NoHook());
+            expm_t18_cell<NT, false, CHEB>(smem, wave, lane, U, s, bad, T18NoHook(), T18NoHook());
 #pragma unroll
             for (int sl = 0; sl < NT; ++sl) {
                 Strip<NT> Us;
@@ -754,7 +760,7 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
             __syncthreads();
             if (have_next) t18_form_a_general<64 * NT, NT>(a, smem, next, tid);   // (all elements: not fetched ahead)
         }
-        if constexpr (HERM) {
+        if constexpr (SYM) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) { Uprev.re[t] = U.re[t]; Uprev.im[t] = U.im[t]; }
             prev = cell;
@@ -779,7 +785,7 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
             if (st_ord[o]) stat_add(a.stats, 3 + o, (unsigned long long)st_ord[o]);
         if (st_max > 0) atomicMax(&a.flags[1], st_max);
         // executed matrix instructions (all waves), squarings and cells of this path
-        stat_add(a.stats, 12, (unsigned long long)NT * ((unsigned long long)st_cells * (HERM ? T18Count<NT>::CELL : T18Count<NT>::CELL_GENERAL)
+        stat_add(a.stats, 12, (unsigned long long)NT * ((unsigned long long)st_cells * (SYM ? T18Count<NT>::CELL : T18Count<NT>::CELL_GENERAL)
                                                          + (unsigned long long)st_sq * T18Count<NT>::GP));
         stat_add(a.stats, 13, (unsigned long long)st_sq);
         stat_add(a.stats, 14, (unsigned long long)st_cells);

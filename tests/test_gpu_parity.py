@@ -269,10 +269,16 @@ def test_pivoted_fallback_for_unsafe_pade_denominators(g, ref, monkeypatch):
     x = np.array([np.pi, 0.3, np.pi / 2 * 2])     # A = -i pi sigma_x (+ tiny drift) on steps 0 and 2
     psi0 = np.array([[1, 0]], complex)
     tgt = np.array([[0.6, 0.8j]], complex)
+    Jr, Gr, taur = ref.evaluate(H0, Hc, tlist, x, psi0, tgt, gradient_method=ref.GRADGEN)
+    monkeypatch.setenv("GRAPE_EXPM_T18", "0")     # the Pade kernels (the default exponential is the inverse-free polynomial)
     with g.GrapeHip(H0, Hc, tlist, psi0, tgt) as h:
         J, G, tau = h.eval(x)
         assert h.work()["pivoted_cells"] >= 2
-    Jr, Gr, taur = ref.evaluate(H0, Hc, tlist, x, psi0, tgt, gradient_method=ref.GRADGEN)
+    assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr)
+    monkeypatch.delenv("GRAPE_EXPM_T18")
+    with g.GrapeHip(H0, Hc, tlist, psi0, tgt) as h:   # polynomial route: no denominator, nothing to pivot
+        J, G, tau = h.eval(x)
+        assert h.work()["pivoted_cells"] == 0 and h.work()["t18_cells"] == 3
     assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr)
     # N = 64: a cyclic-shift generator (every diagonal tile of q(A) is badly conditioned)
     N = 64
@@ -281,12 +287,15 @@ def test_pivoted_fallback_for_unsafe_pade_denominators(g, ref, monkeypatch):
     from grape_jl_amd import synth
     pr = synth.make_problem(N, 1, 3, 1, seed=5)
     pr["H0"] = (2.0 * Hs + 0.01 * pr["H0"][0])[None]
-    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"]) as h:
-        J, G, tau = h.eval(pr["pulsevals"])
-        npiv = h.work()["pivoted_cells"]
     Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
                                 gradient_method=ref.TAYLOR)
-    assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr), npiv
+    for t18 in ("0", "1"):
+        monkeypatch.setenv("GRAPE_EXPM_T18", t18)
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"]) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            npiv = h.work()["pivoted_cells"]
+        assert abs(J - Jr) <= TOL_J and abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr), (t18, npiv)
+    monkeypatch.delenv("GRAPE_EXPM_T18")
     # blocked path (N > 64): a two-level pi-pulse embedded in a 70-level system zeroes two diagonal entries of q(A)
     N = 70
     pr = synth.make_problem(N, 1, 3, 2, seed=6)
