@@ -1253,7 +1253,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(hipMemset(h->d_fw, 0, (size_t)K * (N_T + 1) * NP * 16));
     CCHK(hipMemset(h->d_bw, 0, (size_t)K * (N_T + 1) * NP * 16));
     CCHK(hipMemset(h->d_tg, 0, (size_t)K * L * N_T * 16));
-    h->h_pin_doubles = (size_t)L * N_T + 2 * K + 16;
+    h->h_pin_doubles = (size_t)2 * L * N_T + 2 * K + 16;   // pulses | forward outputs (2K + 8) | gradient (single-wait grape_eval)
     if (p->Dpen && p->lambda_b != 0.0) {
         h->have_gb = true;
         const int Kd = p->dpen_per_traj ? K : 1;
@@ -1857,6 +1857,32 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
         return GRAPE_ERR_INVALID;
     }
     const bool multi = !h->shards.empty();
+    if (!multi && G && !h->large) {
+        // One device, functional and gradient: the whole evaluation is enqueued without a host round trip in the middle --
+        // the backward half takes f = sum_k w_k tau_k straight from the device-side sums of the forward half (this handle
+        // owns all trajectories), and ONE wait at the end reads J's sums, tau, G and the error flags.  (A small system is
+        // launch- and latency-bound: at C2 the wait between the halves was a tenth of the evaluation.)
+        phase_begin(h, 5, h->stream);
+        h->in_eval = true;
+        h->want_bw = true;
+        int rc = forward_enqueue(h, pulsevals);
+        h->in_eval = false;
+        if (rc) { h->n_fwd++; return rc; }
+        rc = backward_device_impl(h, h->d_out + 2 * (size_t)h->K, h->d_G, h->stream, nullptr);
+        if (rc) { h->n_fwd++; return rc; }
+        // (G is staged behind the forward outputs: the forward staging area is read after the wait)
+        double *gpin = h->h_pin + (size_t)h->L * h->N_T + 2 * (size_t)h->K + 8;
+        HIPCHK(h, hipMemcpyAsync(gpin, h->d_G, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToHost, h->stream));
+        phase_end(h, 5, h->stream);
+        h->n_fwd++;
+        rc = grape_check(h, h->stream);
+        if (rc) return rc;
+        if (tau) memcpy(tau, h->h_pin + (size_t)h->L * h->N_T, (size_t)2 * h->K * 8);
+        *J = functional_from_sums(h, forward_sums(h));
+        memcpy(G, gpin, (size_t)h->L * h->N_T * 8);
+        if (psiT) return grape_get_final_states(h, psiT);
+        return GRAPE_OK;
+    }
     if (!multi) phase_begin(h, 5, h->stream);
     h->in_eval = true;  // keep the forward slot open until the whole evaluation has been recorded
     h->want_bw = G != nullptr;   // functional only: no backward sweep alongside the forward one
