@@ -67,6 +67,15 @@ struct grape_handle {
     bool herm = false;           // all generators Hermitian: A = -i dt H is skew-Hermitian (expm uses the symmetry)
     bool t18 = false;            // inverse-free polynomial exponential (grape_t18.hip.h)
     bool t18_small = true;       // ... also for N <= 32 (GRAPE_EXPM_T18_SMALL=0: the Pade kernels there)
+    // four-product degree-16 route for Hermitian generators at 32 < N <= 64 (GRAPE_EXPM_T16=0: off).  Cells whose spectral
+    // bound is beyond its range are listed by the kernel and redone by a launch of the degree-18 variant behind it (four
+    // products lost per listed cell), so the route is only TRIED while it pays: grape_check reads how many cells of the last
+    // evaluation were listed; above a quarter the next t16_hold evaluations go straight to the degree-18 route, then one
+    // probes again.
+    bool t16 = true, t16_live = true;
+    int t16_hold = 0;
+    long t16_tried = 0, t16_fell = 0;   // of the last evaluation that tried
+    int *d_celllist = nullptr;          // [KC * N_T] the listed cells (counter: d_flags[4])
     // diagnostic switches, read ONCE in grape_create (never in the evaluation path: getenv is not thread-safe against setenv)
     bool expm_persist = true;    // GRAPE_EXPM_PERSIST=0: one workgroup per cell instead of the persistent Pade kernel
     int expm_lds_pad_kb = 0;     // GRAPE_EXPM_LDS_PAD: extra dynamic LDS of the Pade kernels (fewer cells per CU)
@@ -199,7 +208,7 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 
 // Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
 // unit grape_t18.hip), persistent grid
-extern "C" int grape_t18_launch(int NT, int herm, const void *args, size_t args_size, void *stream, int blocks);
+extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream);
 #endif
@@ -849,7 +858,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -975,6 +984,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             h->t18 = !(envt && !atoi(envt));
             const char *envs2 = getenv("GRAPE_EXPM_T18_SMALL");
             h->t18_small = !(envs2 && !atoi(envs2));
+            const char *env16 = getenv("GRAPE_EXPM_T16");
+            h->t16 = !(env16 && !atoi(env16));
         }
         {
             const char *envp = getenv("GRAPE_EXPM_PERSIST"), *envl = getenv("GRAPE_EXPM_LDS_PAD"), *envx = getenv("GRAPE_CHEBY_XMODE");
@@ -1213,8 +1224,9 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_tg, (size_t)K * L * N_T));
     CCHK(dmalloc(&h->d_out, (size_t)2 * K + 8));
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
-    CCHK(dmalloc(&h->d_flags, 4)); CCHK(dmalloc(&h->d_stats, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS));
+    CCHK(dmalloc(&h->d_flags, 8)); CCHK(dmalloc(&h->d_stats, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
+    if (h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT >= 3) CCHK(dmalloc(&h->d_celllist, (size_t)K * N_T));
     if (h->large && h->series) {
         // cooperative polynomial sweeps (grape_cheby.hip.h): S = NP / 16 siblings per trajectory on one XCD, at most one
         // workgroup per CU; the trajectories go through the kernel in rounds of `cheby_round`
@@ -1248,7 +1260,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             CCHK(dmalloc(&h->d_coop, (size_t)2 * K));
         }
     }
-    CCHK(hipMemset(h->d_flags, 0, 4 * sizeof(int)));
+    CCHK(hipMemset(h->d_flags, 0, 8 * sizeof(int)));
     CCHK(hipMemset(h->d_stats, 0, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS * sizeof(unsigned long long)));
     CCHK(hipMemset(h->d_fw, 0, (size_t)K * (N_T + 1) * NP * 16));
     CCHK(hipMemset(h->d_bw, 0, (size_t)K * (N_T + 1) * NP * 16));
@@ -1289,7 +1301,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     // HIP's last-error is sticky per host thread: a failure elsewhere in the process (another handle's failed
     // allocation, a bad device ordinal) must not be reported by the launch checks of this evaluation
     (void)hipGetLastError();
-    HIPCHK(h, hipMemsetAsync(h->d_flags, 0, 4 * sizeof(int), s));
+    HIPCHK(h, hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), s));
     HIPCHK(h, hipMemsetAsync(h->d_stats, 0, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS * sizeof(unsigned long long), s));
     if (d_pulsevals != h->d_eps)
         HIPCHK(h, hipMemcpyAsync(h->d_eps, d_pulsevals, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToDevice, s));
@@ -1322,7 +1334,13 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             const int per_cu = h->NT == 1 ? 10 : h->NT == 2 ? 4 : 1;
             const int t18_blocks = 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * per_cu, (ncell + 7) / 8));
             if (h->t18 && (h->NT >= 3 || h->t18_small)) {
-                e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, &ea, sizeof(ea), (void *)s, t18_blocks);
+                const bool t16 = h->d_celllist && h->t16_live;
+                ea.cell_list = h->d_celllist; ea.listed = 0;
+                e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, t16 ? 1 : 0, &ea, sizeof(ea), (void *)s, t18_blocks);
+                if (t16 && e == hipSuccess) {   // the cells it listed, by the degree-18 variant (none: the launch ends at once)
+                    ea.listed = 1;
+                    e = (hipError_t)grape_t18_launch(h->NT, 1, 0, &ea, sizeof(ea), (void *)s, t18_blocks);
+                }
             } else
             switch (h->NT) {
                 case 1: e = launch_expm<1>(ea, h->herm, s, 0, h->expm_lds_pad_kb); break;
@@ -1612,12 +1630,19 @@ int grape_check(grape_handle *h, void *stream_) {
         }
         return GRAPE_OK;
     }
-    int flags[4];
+    int flags[8];
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_));
     HIPCHK(h, hipMemcpy(flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
     // blocked path: the squaring plan follows the counts seen on the device (one spare launch costs microseconds)
     if (h->large && !h->series) h->sq_plan = std::max(2, flags[1] + 1);
+    // four-product route: tried in the evaluation just checked (flags[5] cells, flags[4] of them fell back)?
+    if (flags[5] > 0) {
+        h->t16_tried = flags[5]; h->t16_fell = flags[4];
+        if (4L * flags[4] > (long)flags[5]) { h->t16_live = false; h->t16_hold = 32; }
+    } else if (!h->t16_live && --h->t16_hold <= 0) {
+        h->t16_live = true;
+    }
     return status_from_flags(h, flags[0]);
 }
 
@@ -2038,10 +2063,10 @@ int grape_reset_timings(grape_handle *h) {
 int grape_get_work(grape_handle *h, double *out, int n) {
     if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
     if (!h->shards.empty()) {   // every entry is a count: the shards add up
-        const int m = n < 13 ? n : 13;
+        const int m = n < 14 ? n : 14;
         std::fill(out, out + m, 0.0);
         for (grape_handle *c : h->shards) {
-            double cw[13] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+            double cw[14] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
             const int rc = grape_get_work(c, cw, m);
             if (rc < 0) return multi_fail(h, c, rc);
             for (int i = 0; i < m; ++i) out[i] += cw[i];
@@ -2076,6 +2101,7 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     // mode of the ExpProp request: 0 the propagators are materialised, 1 they did not fit the device and the evaluation
     // runs matrix-free (see grape_create)
     if (n > 12) out[12] = h->u_fallback ? 1.0 : 0.0;
+    if (n > 13) out[13] = (double)st[15];   // cells of [11] that took the four-product degree-16 route
     return 4;
 }
 

@@ -65,6 +65,10 @@ struct ExpmArgs {
     int *cellflag;       // [K*N_T] set by the fast kernel for cells that need the pivoted solve
     const double *n1;    // nullptr or 1-norms: [n1_k] of H0_k (per trajectory), then [Kc][L] of the control operators
     int n1_k;
+    // polynomial kernel (grape_t18.hip.h): cells the four-product route must hand to the five-product one are appended
+    // to cell_list (counter: flags[4]); `listed` != 0: this launch works through that list instead of all cells
+    int *cell_list;
+    int listed;
 #ifdef GRAPE_DIAG
     int ablate;  // diagnostic builds only (tools/ablate.sh): bit0 skip invert16, bit1 skip solve
     unsigned long long *stamps;  // [nblocks][16] s_memtime at phase boundaries (diagnostic builds only)

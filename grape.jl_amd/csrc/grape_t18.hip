@@ -12,25 +12,26 @@
 namespace {
 #include "grape_t18.hip.h"
 
-template <int NT, bool SYM, bool CHEB>
+template <int NT, bool SYM, bool CHEB, bool T16 = false>
 hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
     static size_t lds_set[64] = {0};
     const size_t lds = sizeof(double) * (size_t)T18Lds<NT>::TOTAL;
     int dev = 0;
     hipGetDevice(&dev);
     if (lds_set[dev & 63] < lds) {
-        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT, SYM, CHEB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)expm_t18_kernel<NT, SYM, CHEB, T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_set[dev & 63] = lds;
     }
-    hipLaunchKernelGGL((expm_t18_kernel<NT, SYM, CHEB>), dim3(blocks), dim3(NT * 64), lds, s, a);
+    hipLaunchKernelGGL((expm_t18_kernel<NT, SYM, CHEB, T16>), dim3(blocks), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
 
 // args: the ExpmArgs of grape_kernels.hip.h (same header on both sides), passed as bytes because the type of this unit
 // lives in an anonymous namespace
-extern "C" int grape_t18_launch(int NT, int herm, const void *args, size_t args_size, void *stream, int blocks) {
+// t16: Hermitian generators, three or four tiles per side -- the variant that tries the four-product route first
+extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks) {
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
@@ -40,8 +41,8 @@ extern "C" int grape_t18_launch(int NT, int herm, const void *args, size_t args_
     switch (NT) {
         case 1: return (int)(herm ? launch<1, false, true>(a, s, blocks) : launch<1, false, false>(a, s, blocks));
         case 2: return (int)(herm ? launch<2, false, true>(a, s, blocks) : launch<2, false, false>(a, s, blocks));
-        case 3: return (int)(herm ? launch<3, true, true>(a, s, blocks) : launch<3, false, false>(a, s, blocks));
-        default: return (int)(herm ? launch<4, true, true>(a, s, blocks) : launch<4, false, false>(a, s, blocks));
+        case 3: return (int)(herm ? (t16 ? launch<3, true, true, true>(a, s, blocks) : launch<3, true, true>(a, s, blocks)) : launch<3, false, false>(a, s, blocks));
+        default: return (int)(herm ? (t16 ? launch<4, true, true, true>(a, s, blocks) : launch<4, true, true>(a, s, blocks)) : launch<4, false, false>(a, s, blocks));
     }
 }
 #ifdef GRAPE_DIAG

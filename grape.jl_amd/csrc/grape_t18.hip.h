@@ -125,10 +125,13 @@ __device__ __forceinline__ void t18_gemm(Acc3<NS> &q, const double *__restrict__
     // and ONE MORE per slot for the third plane: 16 PL bytes exceed the 16-bit offset field of ds_read, and with a single
     // base the compiler kept a table of per-k-step addresses in accumulation registers -- three v_accvgpr_read per
     // k-step, i.e. vector instructions between the matrix instructions of every k-step (8 % of a product)
-    const double *__restrict__ xp[NS], *__restrict__ xq[NS];
+    // (pointers in the LDS address space by TYPE: behind the register pin below the compiler no longer sees where a generic
+    // pointer came from and reads the third plane with flat_load -- 64-bit addresses, the vector-memory path and its counter)
+    typedef const double __attribute__((address_space(3))) *lds_cptr;
+    lds_cptr xp[NS], xq[NS];
 #pragma unroll
     for (int so = 0; so < NS; ++so) {
-        xp[so] = R + (lane & 15) * LD + (lane >> 4) + 16 * ((wave + so) % NT) * LD;
+        xp[so] = (lds_cptr)(R + (lane & 15) * LD + (lane >> 4) + 16 * ((wave + so) % NT) * LD);
         xq[so] = xp[so] + 2 * PL;
         // (NT = 4: keep it a register of its own -- folded back into xp[so] + constant it is the table again; NT = 3: all
         // three planes are within the offset field of one base)
@@ -653,6 +656,159 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
     }
 }
 
+// ---- four products instead of five: degree 16, Hermitian generators with rho(H dt) <= T16_THETA, no scaling ----
+//     A2 = A A                                                   (Hermitian square, as above)
+//     y0 = (c1 A2 + c2 A) A2                                     (general products from here on: the operands mix the
+//     y1 = (y0 + c3 A2 + c4 A)(y0 + c5 A2) + c6 y0 + c7 A2        Hermitian and the skew-Hermitian powers)
+//     p  = (y1 + c8 A2 + c9 A)(y1 + c10 y0 + c11 A) + c12 y1 + c13 y0 + c14 A2 + c15 A + c16 I
+// (grape_t18_coeffs.h).  3.6 instead of 4.25 general-product equivalents per cell, one exchange of mirrored tiles instead
+// of three, and the rounding error of the order-13 Pade approximant (1.2e-16 max element at N = 64, rho = 1; the degree-18
+// coefficient set gives 1.1e-15: its constant terms cancel from -4.3 to 1).
+// The form is evaluated AS WRITTEN: folding c3 A2 + c4 A into the start value of the second product (and likewise for
+// the third) would make each left operand the previous result and spare two combination passes, but the last
+// combination then cancels 25 A against 24 A -- 1.4e-15, measured (tools/t16_rounding.py).
+// The spectral bound comes from y0 itself: with spec(H dt) = {lam}, y0 = c1 H^4 + i c2 H^3 (dt absorbed), so
+//     ||y0||_F^2 = c1^2 m8 + c2^2 m6,   Re <A2, y0>_F = -c1 m6,   m_p = sum lam^p >= rho^p
+// -- two sums over the register strips give m8 = sum lam^8 without any further product, and rho <= m8^(1/8)
+// (1.17-1.24 rho at N = 64 for a semicircle spectrum, where sqrt ||A2||_1 is 1.8 rho).  The cell is evaluated whatever the
+// bound says and the verdict returned: a cell with m8 > theta^8 (and ||A2||_1 > theta^2) has to be redone by the degree-18
+// route -- in ANOTHER launch.  With the fallback inside this cell (an early return and the other cell function behind it)
+// the register allocation of both routes fell apart: 780 bytes of scratch per lane and 24.7 instead of 16.5 ms at the
+// headline configuration, where no cell needs it.
+template <int NT>
+struct T16Count {
+    static constexpr int CELL = T18Count<NT>::SQH + 3 * T18Count<NT>::GP;    // matrix instructions per wave
+    static constexpr int WASTED = T18Count<NT>::SQH + T18Count<NT>::GP;      // ... of a cell that was handed back
+};
+
+template <int NT, class HookFirst, class HookLast>
+__device__ __forceinline__ bool expm_t16_cell(double *smem, const int wave, const int lane_in, Strip3M<NT> &U, HookFirst hook_first,
+                                              HookLast hook_last) {
+    // (per-lane addresses are recomputed per stage from a pinned copy of the lane index: shared between the stages they
+    // stay alive through the whole cell -- some 50 registers that this cell does not have)
+#define T16_FRESH_LANE(l) int l = lane_in; asm volatile("" : "+v"(l))
+    using LY = T18Lds<NT>;
+    constexpr int LD = LY::LD, NS = NT - 1;
+    constexpr bool HALF = NT == 4;
+    static_assert(NT >= 3, "tile symmetry needs at least three tiles per side");
+    double *R = smem, *e1 = smem + LY::E1, *e2 = smem + LY::E2, *red = smem + LY::RED;
+    const T18NoHook nohook;
+    Strip3M<NT> As, A2, Y0;
+    int lane = lane_in;
+    t18_load_strip<LD, NT>(R, As, wave, lane);
+    // ---- A2 = A A ----
+    {
+        Acc3<NS> q;
+        acc3_zero(q);
+        t18_gemm<LD, NS, NT, HALF>(q, R, As, wave, lane, hook_first);
+        t18_combine<NS, NT>(q, A2);
+    }
+    if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A2.re[2], A2.im[2], wave, lane, 1.0);   // partial sum of tile (w+2, w) -> wave w+2
+    rot_exch_write<NT>(e2, A2.re[1], A2.im[1], wave, lane, 1.0);                             // mirrored tile -> wave w+1
+    __syncthreads();                                                          // (also: everybody is done reading A)
+    if constexpr (NT == 4) t18_exch_add<NT, 2>(e1, A2, wave, lane);
+    t18_exch_read_last<NT>(e2, A2, wave, lane);
+    Acc3<NT> q;
+    { T16_FRESH_LANE(l2); lane = l2; }
+    // ---- y0 = (c1 A2 + c2 A) A2: the combination goes to the planes, A2 -- alive to the end anyway -- is the right operand ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        U.re[t] = T16_C1 * A2.re[t] + T16_C2 * As.re[t];
+        U.im[t] = T16_C1 * A2.im[t] + T16_C2 * As.im[t];
+        A2.sm[t] = A2.re[t] + A2.im[t];
+    }
+    t18_store_slots<LD, NT, NT>(R, U, wave, lane);
+    __syncthreads();
+    acc3_zero(q);
+    t18_gemm<LD, NT, NT, false>(q, R, A2, wave, lane, nohook);
+    t18_combine<NT, NT>(q, Y0);
+    // ---- spectral bound ----
+    {
+        double f = 0., g = 0.;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f = fma(Y0.re[t][r], Y0.re[t][r], f); f = fma(Y0.im[t][r], Y0.im[t][r], f);
+                g = fma(A2.re[t][r], Y0.re[t][r], g); g = fma(A2.im[t][r], Y0.im[t][r], g);
+            }
+        f = wave_sum(f);
+        g = wave_sum(g);
+        const double n2w = t18_colsum_max<NT>(A2);
+        if (lane == 0) { red[wave] = f; red[NT + wave] = g; red[2 * NT + wave] = n2w; }
+    }
+    __syncthreads();                                                          // (also: everybody is done reading the planes)
+    bool ok;
+    {
+        double F = red[0], G = red[NT], n2 = red[2 * NT];
+#pragma unroll
+        for (int w = 1; w < NT; ++w) { F += red[w]; G += red[NT + w]; n2 = fmax(n2, red[2 * NT + w]); }
+        const double m6 = -G / T16_C1;                                        // sum lam^6
+        const double m8 = (F - (T16_C2 * T16_C2) * m6) / (T16_C1 * T16_C1);   // sum lam^8 (cancellation: 55 ulp of F, far inside the 1e-9)
+        constexpr double th2 = T16_THETA * T16_THETA, th8 = th2 * th2 * th2 * th2;
+        ok = (n2 * (1.0 + 1e-9) <= th2) || (m6 >= 0. && m8 * (1.0 + 1e-9) <= th8);   // (NaN: neither)
+    }
+    ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+    { T16_FRESH_LANE(l3); lane = l3; }
+    // ---- y1 = (y0 + c3 A2 + c4 A)(y0 + c5 A2) + c6 y0 + c7 A2 ----
+    // (the right operand takes the place of y0, which comes back as operand - c5 A2 behind the product: with y0 AND the
+    // operand alive the product runs 32 doubles per lane above what the register file holds beside A, A2 and the accumulators)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        U.re[t] = Y0.re[t] + T16_C3 * A2.re[t] + T16_C4 * As.re[t];
+        U.im[t] = Y0.im[t] + T16_C3 * A2.im[t] + T16_C4 * As.im[t];
+        const d4 vr = T16_C6 * Y0.re[t] + T16_C7 * A2.re[t], vi = T16_C6 * Y0.im[t] + T16_C7 * A2.im[t];
+        q.p1[t] = vr; q.p2[t] = (d4){0., 0., 0., 0.}; q.p3[t] = vr + vi;       // re = p1 - p2, im = p3 - p1 - p2
+        Y0.re[t] += T16_C5 * A2.re[t];
+        Y0.im[t] += T16_C5 * A2.im[t];
+        Y0.sm[t] = Y0.re[t] + Y0.im[t];
+    }
+    t18_store_slots<LD, NT, NT>(R, U, wave, lane);                            // planes = y0 + c3 A2 + c4 A
+    __syncthreads();
+    t18_gemm<LD, NT, NT, false>(q, R, Y0, wave, lane, nohook);
+    Strip3M<NT> &Y1 = U;
+    t18_combine<NT, NT>(q, Y1);
+    // ---- p = (y1 + c8 A2 + c9 A)(y1 + c10 y0 + c11 A) + c12 y1 + c13 y0 + c14 A2 + c15 A + c16 I ----
+    __syncthreads();                                                          // everybody is done reading the planes
+    { T16_FRESH_LANE(l4); lane = l4; }
+    {
+        const int cdiag = lane & 15, rgd = lane >> 4;   // the diagonal tile is slot 0: row 4r + rg == column c
+        constexpr int PL = LY::PL;
+        double *x = R + (lane >> 4) * LD + 16 * wave + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const d4 y0r = Y0.re[t] - T16_C5 * A2.re[t], y0i = Y0.im[t] - T16_C5 * A2.im[t];
+            const d4 xr = Y1.re[t] + T16_C8 * A2.re[t] + T16_C9 * As.re[t], xi = Y1.im[t] + T16_C8 * A2.im[t] + T16_C9 * As.im[t];
+            const int tb = (wave + t) % NT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                     // planes = y1 + c8 A2 + c9 A, tile by tile
+                const int o = (16 * tb + 4 * r) * LD;
+                x[o] = xr[r]; x[PL + o] = xi[r]; x[2 * PL + o] = xr[r] + xi[r];
+            }
+            d4 vr = T16_C12 * Y1.re[t] + T16_C13 * y0r + T16_C14 * A2.re[t] + T16_C15 * As.re[t];
+            const d4 vi = T16_C12 * Y1.im[t] + T16_C13 * y0i + T16_C14 * A2.im[t] + T16_C15 * As.im[t];
+            if (t == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * r + rgd == cdiag) vr[r] += T16_C16;
+            }
+            q.p1[t] = vr; q.p2[t] = (d4){0., 0., 0., 0.}; q.p3[t] = vr + vi;
+            Y0.re[t] = Y1.re[t] + T16_C10 * y0r + T16_C11 * As.re[t];         // right operand in place
+            Y0.im[t] = Y1.im[t] + T16_C10 * y0i + T16_C11 * As.im[t];
+            Y0.sm[t] = Y0.re[t] + Y0.im[t];
+        }
+    }
+    __syncthreads();
+#ifdef T16_NOHOOK
+    t18_gemm<LD, NT, NT, false>(q, R, Y0, wave, lane, nohook);
+#else
+    t18_gemm<LD, NT, NT, false>(q, R, Y0, wave, lane, hook_last);
+#endif
+    t18_combine<NT, NT>(q, U);
+    return ok;
+#undef T16_FRESH_LANE
+}
+
 // store of a rotated strip as U_kn (row-major interleaved complex)
 template <int NT>
 __device__ __forceinline__ void t18_store_u(const ExpmArgs &a, const int cell, const int wave, const int lane, const Strip3M<NT> &T) {
@@ -685,8 +841,13 @@ __device__ __forceinline__ void t18_store_u_slot(const ExpmArgs &a, const int ce
 // same trajectories run concurrently on one XCD: H0_k stays in that XCD's L2).  The credited statistics (Pade order and
 // squarings Julia's exp! would use) come from the 1-norm bound of the operators or, outside its certifying
 // window, from the measured norm, exactly as in expm_persistent; the executed work is counted separately.
-template <int NT, bool SYM, bool CHEB>
+// T16 (Hermitian generators, NT >= 3): every cell takes the four-product route; those whose spectral bound is beyond T16_THETA
+// are appended to a.cell_list (flags[4] counts them, flags[5] the cells tried) and redone by a launch of the five-product
+// variant with a.listed set, which the host issues behind this one (no cell listed: a launch that ends at once).  From the
+// two counts the host decides whether the next evaluation tries the four-product route again.
+template <int NT, bool SYM, bool CHEB, bool T16 = false>
 __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
+    static_assert(!T16 || SYM, "the four-product route is a Hermitian-generator route");
     using LY = T18Lds<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid0 = threadIdx.x, lane0 = tid0 & 63;
@@ -694,7 +855,14 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
     const int ncell = a.K * a.N_T;
     const int x = blockIdx.x & 7, per_x = gridDim.x >> 3;
     const int lo = (int)((long)x * ncell / 8), hi = (int)((long)(x + 1) * ncell / 8);
-    int st_s = 0, st_max = 0, st_ord[5] = {0, 0, 0, 0, 0}, st_sq = 0, st_cells = 0;
+    // the cells of this workgroup: positions idx0, idx0 + step, ... < end of its XCD's range of cells or, for a launch
+    // that works through the hand-over list of the four-product variant, of that list
+    const bool listed = a.listed != 0;
+    const int step = listed ? (int)gridDim.x : per_x;
+    const int end = listed ? min(__builtin_amdgcn_readfirstlane(a.flags[4]), ncell) : hi;
+    const int idx0 = listed ? (int)blockIdx.x : lo + ((int)blockIdx.x >> 3);
+    auto cell_at = [&](int i) -> int { return listed ? __builtin_amdgcn_readfirstlane(a.cell_list[i]) : i; };
+    int st_s = 0, st_max = 0, st_ord[5] = {0, 0, 0, 0, 0}, st_sq = 0, st_cells = 0, st_t16 = 0;
     bool any_bad = false;
     // Software pipeline over the cells of this workgroup: the result of cell c is stored between the matrix instructions
     // of the first product of cell c+1, the operator tiles of cell c+1 are requested in front of the last product of
@@ -702,8 +870,8 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
     Strip<NT> Uprev;
     strip_zero(Uprev);
     int prev = -1;
-    const int first = lo + ((int)blockIdx.x >> 3);
-    if (first < hi) {
+    const int first = idx0 < end ? cell_at(idx0) : 0;
+    if (idx0 < end) {
         if constexpr (SYM) {
             T18FormA<64 * NT, NT> fa(a, smem, first, tid0);
             fa.issue();
@@ -713,36 +881,45 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
         }
     }
     __syncthreads();
-    for (int cell = first; cell < hi; cell += per_x) {
+    for (int idx = idx0; idx < end; idx += step) {
+        const int cell = cell_at(idx);
         int lane = lane0, tid = tid0;
         asm volatile("" : "+v"(lane), "+v"(tid));   // per-lane addresses are recomputed per cell (see expm_persistent)
 #ifdef GRAPE_DIAG
-        if (tid == 0) g_diag_off[blockIdx.x & 1023] = (cell != first + per_x);
+        if (tid == 0) g_diag_off[blockIdx.x & 1023] = (idx != idx0 + step);
         __syncthreads();
 #endif
         STAMP(0);
         // credited work: what Julia's exp! would do for this cell (order and squarings from ||A||_1)
-        const double bound = expm_norm_bound(a, cell);
-        double nA = bound;
-        if (!(bound > 2.1 && bound <= 5.4)) nA = t18_norm1<NT>(smem, tid);
-        int sj = 0;
-        if (nA > 5.4) {
-            const double r = nA / 5.4;
-            const int e = ilogb(r);
-            sj = (r == ldexp(1.0, e)) ? e : e + 1;
+        int sj = 0, oj = 0;
+        if (!listed) {   // (a listed cell was credited by the launch that listed it)
+            const double bound = expm_norm_bound(a, cell);
+            double nA = bound;
+            if (!(bound > 2.1 && bound <= 5.4)) nA = t18_norm1<NT>(smem, tid);
+            if (nA > 5.4) {
+                const double r = nA / 5.4;
+                const int e = ilogb(r);
+                sj = (r == ldexp(1.0, e)) ? e : e + 1;
+            }
+            oj = nA > 2.1 ? 4 : nA > 0.95 ? 3 : nA > 0.25 ? 2 : nA > 0.015 ? 1 : 0;
         }
-        const int oj = nA > 2.1 ? 4 : nA > 0.95 ? 3 : nA > 0.25 ? 2 : nA > 0.015 ? 1 : 0;
         Strip3M<NT> U;
         int s;
         bool bad;
         STAMP(1);
-        const int next = cell + per_x;
-        const bool have_next = next < hi;
+        const bool have_next = idx + step < end;
+        const int next = have_next ? cell_at(idx + step) : cell;
         if constexpr (SYM) {
-            T18FormA<64 * NT, NT> fa(a, smem, have_next ? next : cell, tid);   // (no next cell: the same tiles again, not committed)
-            expm_t18_cell<NT, true, true>(smem, wave, lane, U, s, bad,
-                [&](int sk, int r) { if (r == 0 && prev >= 0) t18_store_u_slot<NT>(a, prev, wave, lane, Uprev, sk); },
-                [&](int sk, int r) { if (sk == 1 && r == 0) fa.issue(); });   // (fenced by scheduling barriers on both sides)
+            T18FormA<64 * NT, NT> fa(a, smem, next, tid);   // (no next cell: the same tiles again, not committed)
+            auto store_prev = [&](int sk, int r) { if (r == 0 && prev >= 0) t18_store_u_slot<NT>(a, prev, wave, lane, Uprev, sk); };
+            auto fetch_next = [&](int sk, int r) { if (sk == 1 && r == 0) fa.issue(); };   // (fenced by scheduling barriers on both sides)
+            if constexpr (T16) {
+                s = 0; bad = false;
+                if (expm_t16_cell<NT>(smem, wave, lane, U, store_prev, fetch_next)) st_t16 += 1;
+                else if (tid == 0) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
+            } else {
+                expm_t18_cell<NT, true, true>(smem, wave, lane, U, s, bad, store_prev, fetch_next);
+            }
             STAMP(11);
             __syncthreads();   // everybody is done reading the planes
             STAMP(12);
@@ -766,7 +943,7 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
             prev = cell;
         }
         any_bad |= bad;
-        st_s += sj; st_max = max(st_max, sj); st_ord[oj] += 1;
+        st_s += sj; st_max = max(st_max, sj); st_ord[oj] += listed ? 0 : 1;
         st_sq += s; st_cells += 1;
         __syncthreads();
         STAMP(13);
@@ -784,11 +961,17 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
         for (int o = 0; o < 5; ++o)
             if (st_ord[o]) stat_add(a.stats, 3 + o, (unsigned long long)st_ord[o]);
         if (st_max > 0) atomicMax(&a.flags[1], st_max);
-        // executed matrix instructions (all waves), squarings and cells of this path
-        stat_add(a.stats, 12, (unsigned long long)NT * ((unsigned long long)st_cells * (SYM ? T18Count<NT>::CELL : T18Count<NT>::CELL_GENERAL)
-                                                         + (unsigned long long)st_sq * T18Count<NT>::GP));
+        // executed matrix instructions (all waves), squarings and cells of this path (four-product variant: every cell is
+        // executed, the cells handed over are counted by the launch that redoes them)
+        unsigned long long mi = (unsigned long long)st_cells * (T16 ? T16Count<NT>::CELL : SYM ? T18Count<NT>::CELL : T18Count<NT>::CELL_GENERAL)
+                                + (unsigned long long)st_sq * T18Count<NT>::GP;
+        if constexpr (T16) {
+            stat_add(a.stats, 15, (unsigned long long)st_t16);
+            atomicAdd(&a.flags[5], st_cells);
+        }
+        stat_add(a.stats, 12, (unsigned long long)NT * mi);
         stat_add(a.stats, 13, (unsigned long long)st_sq);
-        stat_add(a.stats, 14, (unsigned long long)st_cells);
+        stat_add(a.stats, 14, (unsigned long long)(T16 ? st_t16 : st_cells));
         if (any_bad) atomicOr(&a.flags[0], 64);
     }
 }

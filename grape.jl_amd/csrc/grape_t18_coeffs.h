@@ -52,3 +52,28 @@
 #define T18T_E2 -0.092336461936711859281
 #define T18T_E3 -0.01693649390020817172
 #define T18T_E6 -0.00001400867981820361598
+
+// Four-product degree-16 evaluation (tools/t16_coeffs.py; scheme of Sastre 2018, the m = 15+ formulas):
+//     A2 = A A,  y0 = A2 (c1 A2 + c2 A),  y1 = (y0 + c3 A2 + c4 A)(y0 + c5 A2) + c6 y0 + c7 A2
+//     p(A) = (y1 + c8 A2 + c9 A)(y1 + c10 y0 + c11 A) + c12 y1 + c13 y0 + c14 A2 + c15 A + c16 I
+//   * T16_C* : Hermitian generators with spectrum in [-T16_THETA, T16_THETA]: the coefficients 0..15 are those of the
+//              degree-15 Chebyshev truncation of exp on the segment minus the part of the dependent top term b16 x^16
+//              (b16 = c1^4 = 0.53 / 16!) that lower degrees can absorb; |p(-i lam) - exp(-i lam)| <= 8.9e-17 for
+//              |lam| <= 1.36.  No scaling: cells beyond the bound take the degree-18 route.
+#define T16_THETA 1.36
+#define T16_C1 0.0003990485980387312666
+#define T16_C2 0.0029228143276988285886
+#define T16_C3 -0.0077470178547223424775
+#define T16_C4 0.40523011494938120965
+#define T16_C5 0.032514297214079020788
+#define T16_C6 5.6985532981688705678
+#define T16_C7 0.022467770221737013362
+#define T16_C8 0.2375283509963317365
+#define T16_C9 2.1834336740729687939
+#define T16_C10 -5.7548650707099555138
+#define T16_C11 -0.024893888233397960765
+#define T16_C12 10.136883359859348227
+#define T16_C13 -61.008736429296066557
+#define T16_C14 0.32660098775353450156
+#define T16_C15 0.9999999999999999025
+#define T16_C16 0.99999999999999991128

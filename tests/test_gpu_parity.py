@@ -704,3 +704,70 @@ def test_exponential_paths_differential_on_random_grids(g, ref, case, monkeypatc
     Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], gradient_method=ref.TAYLOR)
     assert abs(res["persist"][0] - Jr) <= TOL_J and np.abs(res["persist"][1] - Gr).max() <= tol_G(Gr)
     assert abs(res["t18"][0] - Jr) <= TOL_J and np.abs(res["t18"][1] - Gr).max() <= tol_G(Gr)
+
+
+@pytest.mark.parametrize("N", (64, 48))
+def test_four_product_route_hands_cells_beyond_its_bound_to_the_five_product_route(g, ref, N, monkeypatch):
+    """Hermitian generators, 32 < N <= 64: the degree-16 four-product polynomial (grape_t18.hip.h, expm_t16_cell) is valid for
+    spectral radii up to 1.36 and proves that per cell from sum lam^8; cells beyond the bound are listed and redone by the
+    degree-18 five-product launch behind it.  A time grid with mostly unit steps and some steps of 1.6 and 2.5 mixes both
+    kinds: every cell is exponentiated exactly once as far as the counters go, results agree with the five-product route
+    alone (GRAPE_EXPM_T16=0), with the Pade route and with the C restatement."""
+    from grape_jl_amd import synth
+    L, N_T, K = 2, 300, 4                               # 1200 cells >= 4 x 256: persistent grid with several cells per workgroup
+    pr = synth.make_problem(N, L, N_T, K, seed=1600 + N)
+    dts = np.ones(N_T)
+    dts[3::7] = 1.6
+    dts[5::11] = 2.5
+    tl = np.concatenate([[0.0], np.cumsum(dts)])
+    args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
+    sample = [(0, 0), (1, 3), (2, 5), (3, N_T - 1), (1, 10), (2, 16)]
+    res = {}
+    for name, env in (("t16", {}), ("t18", {"GRAPE_EXPM_T16": "0"}), ("pade", {"GRAPE_EXPM_T18": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with g.GrapeHip(*args) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            res[name] = (J, G.copy(), tau.copy(), np.stack([h.propagator(k, n) for k, n in sample]), h.work())
+        for k in env:
+            monkeypatch.delenv(k)
+    w = res["t16"][4]
+    big = int((dts > 1.5).sum()) * K
+    assert w["t18_cells"] == K * N_T                       # every cell counted once: four-product cells + redone cells
+    assert 0 < w["t16_cells"] <= K * N_T - big             # no cell with a step of 1.6 or more passes the bound (rho dt >= 1.5)
+    assert w["t16_cells"] >= 0.8 * (K * N_T - big)         # ... and the unit steps do (rho about 1, bound about 1.2)
+    assert res["t18"][4]["t16_cells"] == 0
+    assert w["flop_expm"] == res["t18"][4]["flop_expm"] == res["pade"][4]["flop_expm"]     # credited work: route-independent
+    for other in ("t18", "pade"):
+        assert abs(res["t16"][0] - res[other][0]) <= TOL_J
+        assert np.abs(res["t16"][1] - res[other][1]).max() <= tol_G(res[other][1])
+        assert np.abs(res["t16"][2] - res[other][2]).max() <= TOL_TAU
+        assert np.abs(res["t16"][3] - res[other][3]).max() <= 1e-14
+    U = res["t16"][3]
+    assert np.abs(np.einsum("nij,nik->njk", U.conj(), U) - np.eye(N)).max() <= 5e-15
+    ns = 12
+    xs = pr["pulsevals"].reshape(L, N_T)[:, :ns].reshape(-1)
+    with g.GrapeHip(pr["H0"], pr["Hc"], tl[: ns + 1], pr["psi0"], pr["target"], pr["weights"]) as hs:
+        Js, Gs, taus = hs.eval(xs)
+        assert 0 < hs.work()["t16_cells"] < K * ns
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], tl[: ns + 1], xs, pr["psi0"], pr["target"], pr["weights"],
+                                gradient_method=ref.TAYLOR)
+    assert abs(Js - Jr) <= TOL_J and np.abs(taus - taur).max() <= TOL_TAU and np.abs(Gs - Gr).max() <= tol_G(Gr)
+
+
+def test_four_product_route_is_given_up_while_it_does_not_pay(g, monkeypatch):
+    """More than a quarter of the cells beyond the bound of the four-product route: the evaluations that follow go straight to
+    the five-product kernel (no cell is exponentiated twice), with bit-identical results -- the redoing launch runs the same
+    cell function."""
+    from grape_jl_amd import synth
+    N, L, N_T, K = 64, 2, 300, 4
+    pr = synth.make_problem(N, L, N_T, K, seed=1664)
+    tl = np.arange(N_T + 1) * 1.8                        # every cell beyond 1.36
+    with g.GrapeHip(pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"]) as h:
+        J1, G1, tau1 = h.eval(pr["pulsevals"])
+        w1 = h.work()
+        J2, G2, tau2 = h.eval(pr["pulsevals"])
+        w2 = h.work()
+    assert w1["t16_cells"] == 0 and w1["t18_cells"] == K * N_T and w2["t16_cells"] == 0 and w2["t18_cells"] == K * N_T
+    assert w2["t18_mfma_flop"] < 0.6 * w1["t18_mfma_flop"]          # first evaluation: 3.6 + 4.25 product equivalents per cell
+    assert J1 == J2 and np.array_equal(G1, G2) and np.array_equal(tau1, tau2)

@@ -14,9 +14,10 @@ if nonherm:
     pr = synth.make_problem(N_, L_, NT_, K or K0_, seed=synth.BASE_SEED ^ int(cid[1:]), hermitian=False)
 else:
     pr = synth.make_config(cid, K=K)
+VAR = os.environ.get("AB_VAR", "GRAPE_EXPM_T18")   # AB_VAR=GRAPE_EXPM_T16: four- against five-product polynomial
 hs = []
 for v in (0, 1):
-    os.environ["GRAPE_EXPM_T18"] = str(v)
+    os.environ[VAR] = str(v)
     hs.append(g.GrapeHip(pr['H0'], pr['Hc'], pr['tlist'], pr['psi0'], pr['target'], pr['weights']))
 res = {0: [], 1: []}
 out = {}
@@ -36,7 +37,7 @@ for (k, n) in [(0, 0), (pr['K'] - 1, pr['N_T'] - 1), (pr['K'] // 2, pr['N_T'] //
     N = pr['N']
     print(f"U[{k},{n}]: max|dU| {np.abs(U0 - U1).max():.3e}  unitarity pade {np.abs(U0.conj().T @ U0 - np.eye(N)).max():.3e}  t18 {np.abs(U1.conj().T @ U1 - np.eye(N)).max():.3e}")
 for v in (0, 1):
-    print(f"GRAPE_EXPM_T18={v}:")
+    print(f"{VAR}={v}:")
     for r in res[v]:
         print("   ", r)
     print("    work", hs[v].work())
