@@ -67,7 +67,7 @@ struct grape_handle {
     bool herm = false;           // all generators Hermitian: A = -i dt H is skew-Hermitian (expm uses the symmetry)
     bool t18 = false;            // inverse-free polynomial exponential (grape_t18.hip.h)
     bool t18_small = true;       // ... also for N <= 32 (GRAPE_EXPM_T18_SMALL=0: the Pade kernels there)
-    // four-product degree-16 route for Hermitian generators at 32 < N <= 64 (GRAPE_EXPM_T16=0: off).  Cells whose spectral
+    // four-product degree-16 route for Hermitian generators at 16 < N <= 64 (GRAPE_EXPM_T16=0: off).  Cells whose spectral
     // bound is beyond its range are listed by the kernel and redone by a launch of the degree-18 variant behind it (four
     // products lost per listed cell), so the route is only TRIED while it pays: grape_check reads how many cells of the last
     // evaluation were listed; above a quarter the next t16_hold evaluations go straight to the degree-18 route, then one
@@ -1226,7 +1226,9 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_flags, 8)); CCHK(dmalloc(&h->d_stats, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
-    if (h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT >= 3) CCHK(dmalloc(&h->d_celllist, (size_t)K * N_T));
+    // (N <= 16 stays with five products: one tile per side is latency-bound -- the kernel gains nothing from the shorter
+    // polynomial and the second launch costs 10 us of an evaluation of 0.4 ms; measured at C2: 0.079 -> 0.098 ms)
+    if (h->t16 && h->t18 && h->herm && !h->large && !h->series && (h->NT >= 3 || (h->NT == 2 && h->t18_small))) CCHK(dmalloc(&h->d_celllist, (size_t)K * N_T));
     if (h->large && h->series) {
         // cooperative polynomial sweeps (grape_cheby.hip.h): S = NP / 16 siblings per trajectory on one XCD, at most one
         // workgroup per CU; the trajectories go through the kernel in rounds of `cheby_round`

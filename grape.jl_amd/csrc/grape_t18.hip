@@ -30,7 +30,7 @@ hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
 
 // args: the ExpmArgs of grape_kernels.hip.h (same header on both sides), passed as bytes because the type of this unit
 // lives in an anonymous namespace
-// t16: Hermitian generators, three or four tiles per side -- the variant that tries the four-product route first
+// t16: Hermitian generators -- the variant that takes the four-product route and lists the cells beyond its range
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks) {
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
@@ -39,8 +39,8 @@ extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, siz
     // Hermitian generators: Chebyshev coefficient set and spectral scaling for every size, the tile symmetry from three
     // tiles per side on; general matrices: Taylor set
     switch (NT) {
-        case 1: return (int)(herm ? launch<1, false, true>(a, s, blocks) : launch<1, false, false>(a, s, blocks));
-        case 2: return (int)(herm ? launch<2, false, true>(a, s, blocks) : launch<2, false, false>(a, s, blocks));
+        case 1: return (int)(herm ? (t16 ? launch<1, false, true, true>(a, s, blocks) : launch<1, false, true>(a, s, blocks)) : launch<1, false, false>(a, s, blocks));
+        case 2: return (int)(herm ? (t16 ? launch<2, false, true, true>(a, s, blocks) : launch<2, false, true>(a, s, blocks)) : launch<2, false, false>(a, s, blocks));
         case 3: return (int)(herm ? (t16 ? launch<3, true, true, true>(a, s, blocks) : launch<3, true, true>(a, s, blocks)) : launch<3, false, false>(a, s, blocks));
         default: return (int)(herm ? (t16 ? launch<4, true, true, true>(a, s, blocks) : launch<4, true, true>(a, s, blocks)) : launch<4, false, false>(a, s, blocks));
     }

@@ -677,20 +677,22 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
 // headline configuration, where no cell needs it.
 template <int NT>
 struct T16Count {
-    static constexpr int CELL = T18Count<NT>::SQH + 3 * T18Count<NT>::GP;    // matrix instructions per wave
-    static constexpr int WASTED = T18Count<NT>::SQH + T18Count<NT>::GP;      // ... of a cell that was handed back
+    static constexpr int CELL = T18Count<NT>::SQH + 3 * T18Count<NT>::GP;    // matrix instructions per wave (tile symmetry)
+    static constexpr int CELL_NOSYM = 4 * T18Count<NT>::GP;
 };
 
-template <int NT, class HookFirst, class HookLast>
+// SYM as in expm_t18_cell: the tile symmetry of the Hermitian square (NT >= 3); without it all NT row tiles of A2 come
+// from the matrix instructions (NT <= 2, where no wave computes an off-diagonal tile it could mirror).
+template <int NT, bool SYM, class HookFirst, class HookLast>
 __device__ __forceinline__ bool expm_t16_cell(double *smem, const int wave, const int lane_in, Strip3M<NT> &U, HookFirst hook_first,
                                               HookLast hook_last) {
     // (per-lane addresses are recomputed per stage from a pinned copy of the lane index: shared between the stages they
     // stay alive through the whole cell -- some 50 registers that this cell does not have)
 #define T16_FRESH_LANE(l) int l = lane_in; asm volatile("" : "+v"(l))
     using LY = T18Lds<NT>;
-    constexpr int LD = LY::LD, NS = NT - 1;
-    constexpr bool HALF = NT == 4;
-    static_assert(NT >= 3, "tile symmetry needs at least three tiles per side");
+    constexpr int LD = LY::LD, NS = SYM ? NT - 1 : NT;
+    constexpr bool HALF = SYM && NT == 4;
+    static_assert(!SYM || NT >= 3, "tile symmetry needs at least three tiles per side");
     double *R = smem, *e1 = smem + LY::E1, *e2 = smem + LY::E2, *red = smem + LY::RED;
     const T18NoHook nohook;
     Strip3M<NT> As, A2, Y0;
@@ -703,11 +705,15 @@ __device__ __forceinline__ bool expm_t16_cell(double *smem, const int wave, cons
         t18_gemm<LD, NS, NT, HALF>(q, R, As, wave, lane, hook_first);
         t18_combine<NS, NT>(q, A2);
     }
-    if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A2.re[2], A2.im[2], wave, lane, 1.0);   // partial sum of tile (w+2, w) -> wave w+2
-    rot_exch_write<NT>(e2, A2.re[1], A2.im[1], wave, lane, 1.0);                             // mirrored tile -> wave w+1
+    if constexpr (SYM) {
+        if constexpr (NT == 4) rot_exch_write<NT, 2>(e1, A2.re[2], A2.im[2], wave, lane, 1.0);   // partial sum of tile (w+2, w) -> wave w+2
+        rot_exch_write<NT>(e2, A2.re[1], A2.im[1], wave, lane, 1.0);                             // mirrored tile -> wave w+1
+    }
     __syncthreads();                                                          // (also: everybody is done reading A)
-    if constexpr (NT == 4) t18_exch_add<NT, 2>(e1, A2, wave, lane);
-    t18_exch_read_last<NT>(e2, A2, wave, lane);
+    if constexpr (SYM) {
+        if constexpr (NT == 4) t18_exch_add<NT, 2>(e1, A2, wave, lane);
+        t18_exch_read_last<NT>(e2, A2, wave, lane);
+    }
     Acc3<NT> q;
     { T16_FRESH_LANE(l2); lane = l2; }
     // ---- y0 = (c1 A2 + c2 A) A2: the combination goes to the planes, A2 -- alive to the end anyway -- is the right operand ----
@@ -841,13 +847,13 @@ __device__ __forceinline__ void t18_store_u_slot(const ExpmArgs &a, const int ce
 // same trajectories run concurrently on one XCD: H0_k stays in that XCD's L2).  The credited statistics (Pade order and
 // squarings Julia's exp! would use) come from the 1-norm bound of the operators or, outside its certifying
 // window, from the measured norm, exactly as in expm_persistent; the executed work is counted separately.
-// T16 (Hermitian generators, NT >= 3): every cell takes the four-product route; those whose spectral bound is beyond T16_THETA
+// T16 (Hermitian generators): every cell takes the four-product route; those whose spectral bound is beyond T16_THETA
 // are appended to a.cell_list (flags[4] counts them, flags[5] the cells tried) and redone by a launch of the five-product
 // variant with a.listed set, which the host issues behind this one (no cell listed: a launch that ends at once).  From the
 // two counts the host decides whether the next evaluation tries the four-product route again.
 template <int NT, bool SYM, bool CHEB, bool T16 = false>
 __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
-    static_assert(!T16 || SYM, "the four-product route is a Hermitian-generator route");
+    static_assert(!T16 || CHEB, "the four-product route is a Hermitian-generator route");
     using LY = T18Lds<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid0 = threadIdx.x, lane0 = tid0 & 63;
@@ -915,7 +921,7 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
             auto fetch_next = [&](int sk, int r) { if (sk == 1 && r == 0) fa.issue(); };   // (fenced by scheduling barriers on both sides)
             if constexpr (T16) {
                 s = 0; bad = false;
-                if (expm_t16_cell<NT>(smem, wave, lane, U, store_prev, fetch_next)) st_t16 += 1;
+                if (expm_t16_cell<NT, true>(smem, wave, lane, U, store_prev, fetch_next)) st_t16 += 1;
                 else if (tid == 0) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
             } else {
                 expm_t18_cell<NT, true, true>(smem, wave, lane, U, s, bad, store_prev, fetch_next);
@@ -927,7 +933,13 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
         } else {
             // (general matrices: the result is stored at once -- carried into the next cell's first product it costs 64
             // registers there, and this variant runs at the register limit: 84 bytes of scratch per lane with it)
-            expm_t18_cell<NT, false, CHEB>(smem, wave, lane, U, s, bad, T18NoHook(), T18NoHook());
+            if constexpr (T16) {
+                s = 0; bad = false;
+                if (expm_t16_cell<NT, false>(smem, wave, lane, U, T18NoHook(), T18NoHook())) st_t16 += 1;
+                else if (tid == 0) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;
+            } else {
+                expm_t18_cell<NT, false, CHEB>(smem, wave, lane, U, s, bad, T18NoHook(), T18NoHook());
+            }
 #pragma unroll
             for (int sl = 0; sl < NT; ++sl) {
                 Strip<NT> Us;
@@ -963,7 +975,7 @@ __global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
         if (st_max > 0) atomicMax(&a.flags[1], st_max);
         // executed matrix instructions (all waves), squarings and cells of this path (four-product variant: every cell is
         // executed, the cells handed over are counted by the launch that redoes them)
-        unsigned long long mi = (unsigned long long)st_cells * (T16 ? T16Count<NT>::CELL : SYM ? T18Count<NT>::CELL : T18Count<NT>::CELL_GENERAL)
+        unsigned long long mi = (unsigned long long)st_cells * (T16 ? (SYM ? T16Count<NT>::CELL : T16Count<NT>::CELL_NOSYM) : SYM ? T18Count<NT>::CELL : T18Count<NT>::CELL_GENERAL)
                                 + (unsigned long long)st_sq * T18Count<NT>::GP;
         if constexpr (T16) {
             stat_add(a.stats, 15, (unsigned long long)st_t16);

@@ -234,7 +234,7 @@ int grape_reset_timings(grape_handle *h);
  * generators (grape_t18.hip.h), [10] its squarings, [11] its cells, [12] 1 when prop_method = GRAPE_PROP_EXP was asked for
  * but the propagators (KC N_T NP^2 16 bytes) do not fit the device and the handle evaluates matrix-free instead of
  * failing in hipMalloc (same results to rounding; shards of a composite handle: the number of shards in that mode),
- * [13] the cells of [11] that took the four-product degree-16 route (Hermitian generators, 32 < N <= 64, spectral bound
+ * [13] the cells of [11] that took the four-product degree-16 route (Hermitian generators, 16 < N <= 64, spectral bound
  * within its range) (entries beyond n are not written). */
 int grape_get_work(grape_handle *h, double *out, int n);
 
