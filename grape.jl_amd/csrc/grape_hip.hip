@@ -588,7 +588,7 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         fa.A = A; fa.s_cell = h->d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
         fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0_; fa.rep = h->d_rep;
         fa.norm1 = h->d_dinv;   // (the inverse slots of the Pade route are idle here: ||A||_1 per cell)
-        hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(256), 0, s, fa);
+        hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(1024), 0, s, fa);
         LGCHK(hipGetLastError());
         const LgView vA = lg_full(A, NP), vA2 = lg_full(A2, NP), vA3 = lg_full(A3, NP), vA6 = lg_full(A6, NP),
                      vB1 = lg_full(B1, NP), vB5 = lg_full(B5, NP), vA9 = lg_full(A9, NP), vL = lg_full(Lm, NP), vT = lg_full(T, NP);
@@ -665,7 +665,7 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
         fa.H0f = h->d_H0f; fa.Hcf = h->d_Hcf; fa.eps = h->d_eps; fa.shape = h->d_shape; fa.dts = h->d_dts;
         fa.A = A; fa.s_cell = h->d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
         fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0; fa.rep = h->d_rep;
-        hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(256), 0, s, fa);
+        hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(1024), 0, s, fa);
         LGCHK(hipGetLastError());
         const LgView vA = lg_full(A, NP), vA2 = lg_full(A2, NP), vA4 = lg_full(A4, NP), vA6 = lg_full(A6, NP),
                      vW = lg_full(W, NP), vZ = lg_full(Z, NP), vT = lg_full(T, NP), vV = lg_full(V, NP), vU = lg_full(Uo, NP);

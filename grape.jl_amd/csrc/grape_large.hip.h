@@ -245,10 +245,13 @@ struct LgFormArgs {
     double *norm1;        // polynomial route (lg_t18_scale_kernel decides the scaling): ||A||_1 per cell goes here, the
                           // Pade squaring count is only CREDITED (statistics), s_cell and flags[1] are left alone
 };
-__global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
-    __shared__ double colsum[256];
+// 1024 threads per cell: thread (part, j) forms rows part, part + 4, ... of column j.  (With 256 threads -- one per column,
+// 256 rows each -- a launch lasted as long as ONE workgroup's chain of 32 load round trips: 0.63 ms per chunk of 889 cells,
+// 1 TB/s for a kernel that only writes; round 3.)
+__global__ void __launch_bounds__(1024) lg_form_kernel(LgFormArgs a) {
+    __shared__ double colsum[1024];
     __shared__ double snorm;
-    const int tid = threadIdx.x, NP = a.NP;
+    const int tid = threadIdx.x & 255, part = threadIdx.x >> 8, NP = a.NP;
     const int cell = a.cell0 + blockIdx.x;
     const int kc = cell / a.N_T, n = cell - kc * a.N_T;
     const int k = a.rep ? a.rep[kc] : kc;
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
         e[l] = a.eps[(size_t)l * a.N_T + n];
         if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
     }
-    // thread j owns column j (NP <= 256): column sums need no reduction.  ONE pass over the (L2-resident) operators:
+    // thread (part, j) owns every fourth row of column j (NP <= 256).  ONE pass over the (L2-resident) operators:
     // A is written unscaled together with the column sums of |a_ij| for the 1-norm; the scaling A / 2^s of scaling and
     // squaring is applied as a per-cell power of two where A is consumed (LgGemmArgs::scale_s: A*A and A*T) --
     // exact in binary, and the operators are read once instead of twice.  Rows are unrolled by 8 so that 8 (1 + L)
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
     double cs = 0.;
     if (tid < NP) {
 #pragma unroll 8
-        for (int i = 0; i < NP; ++i) {
+        for (int i = part; i < NP; i += 4) {
             double ar, ai;
             element(i, ar, ai);
             cs += sqrt(ar * ar + ai * ai);
@@ -288,9 +291,11 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
             A[pp + o] = ai;
         }
     }
-    colsum[tid] = tid < NP ? cs : 0.;
+    colsum[threadIdx.x] = tid < NP ? cs : 0.;
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x < 256) colsum[tid] = (colsum[tid] + colsum[256 + tid]) + (colsum[512 + tid] + colsum[768 + tid]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
         double m = 0.;
         for (int j = 0; j < NP; ++j) m = fmax(m, colsum[j]);
         snorm = m;
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(256) lg_form_kernel(LgFormArgs a) {
         const int ex = ilogb(r);
         s = (r == ldexp(1.0, ex)) ? ex : ex + 1;
     }
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         stat_add(a.stats, 0, (unsigned long long)s);
         stat_add(a.stats, 7, 1ull);   // the blocked path always evaluates (or is credited with) the order-13 approximant
         if (a.norm1) {
