@@ -276,6 +276,10 @@ def main():
             sweep_kernel = "sweep_coop_kernel (several workgroups per trajectory, forward then backward)"
         if N > 64:
             expm_kernel = "lg_gemm_kernel chain (blocked path)"
+        elif work.get("t16_cells", 0.0) > 0.0:
+            redone = work["t18_cells"] - work["t16_cells"]
+            expm_kernel = ("expm_t18_kernel<%d,...,T16> (inverse-free degree-16 polynomial, four products; %d of %d cells beyond "
+                           "its spectral bound redone by the five-product launch)" % ((N + 15) // 16, redone, work["t18_cells"]))
         elif work.get("t18_cells", 0.0) > 0.0:
             expm_kernel = "expm_t18_kernel<%d> (inverse-free degree-18 polynomial, five products)" % ((N + 15) // 16)
         else:
@@ -324,8 +328,8 @@ def main():
                                  "<= 1).  algorithmic_frac = the credited work of SURVEY 8d (what Julia's exp! would do for "
                                  "the same cells: order-13 Pade with 8N^3 per complex GEMM) per second / peak; it exceeds frac "
                                  "because this build executes less than it is credited for: complex products are 3 real MFMA "
-                                 "products (3M), Hermitian symmetry supplies a quarter of the tiles of three products, and "
-                                 "Hermitian generators take a five-product polynomial without the Pade solve",
+                                 "products (3M), Hermitian symmetry supplies a quarter of the tiles of the symmetric products, and "
+                                 "Hermitian generators take a four- or five-product polynomial without the Pade solve",
                          "flop_model": "SURVEY 8d F_exp = (g+s)*8N^3 + (32/3)N^3 per cell, g = 6 for Pade order 13"},
             "phases_ms": {k: round(v, 4) for k, v in tm.items() if v >= 0},
             "phase_b": {"kernel": sweep_kernel,
