@@ -74,11 +74,14 @@ typedef enum {
 
 /* prop_method keyword of the reference (workspace.jl:222-232 -> QuantumPropagators.init_prop) */
 typedef enum {
-    GRAPE_PROP_EXP = 0,    /* ExpProp: U_n = exp(-i H_n dt_n) materialised on MFMA: N > 32 by an inverse-free degree-18
-                              polynomial in five products with scaling and squaring (Chebyshev coefficients and a spectral
-                              bound for Hermitian generators, Taylor coefficients otherwise), N <= 32 and GRAPE_EXPM_T18=0
-                              by the order-13 Pade approximant as in Julia's exp!.  Propagators that do not fit the device
-                              make the handle evaluate matrix-free (grape_get_work[12]).                           */
+    GRAPE_PROP_EXP = 0,    /* ExpProp: U_n = exp(-i H_n dt_n) materialised on MFMA by an inverse-free polynomial with scaling
+                              and squaring: Hermitian generators, 16 < N <= 64 -- degree 16 in four products for the cells
+                              whose spectral radius a per-cell bound proves <= 1.36, degree 18 in five products (Chebyshev
+                              coefficients, spectral scaling) for the others and for every other size; general matrices
+                              -- degree-18 Taylor polynomial.  GRAPE_EXPM_T16=0: five products everywhere;
+                              GRAPE_EXPM_T18=0: the order-13 Pade approximant as in Julia's exp! (parity reference).
+                              Propagators that do not fit the device make the handle evaluate matrix-free
+                              (grape_get_work[12]).                                                                */
     GRAPE_PROP_SERIES = 1  /* matrix-free polynomial propagator on the state vector (the role of the reference's
                               Cheby / Newton methods, README.md:55), no U: N <= 64 power series of exp(-i H_n dt_n) Psi
                               summed to prop_tolerance, O(N^2) per term; 64 < N <= 256 cooperative Chebyshev sweeps
