@@ -606,12 +606,12 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         oa.A = A; oa.A2 = A2; oa.A3 = A3; oa.A6 = A6; oa.B1 = B1; oa.B5 = B5; oa.B4 = B4; oa.B3 = B3; oa.B2 = B2;
         oa.s_cell = h->d_scell; oa.NP = NP; oa.per_cell = 2 * pp; oa.n = nel;
         if (hm) {
-            const double a_[3] = {T18_A1, T18_A2, T18_A3}, e_[3] = {T18_E2, T18_E3, T18_E6}, b_[4] = {T18_B1, T18_B2, T18_B3, T18_B6};
+            const double a_[3] = {T18_A1, T18_A2, T18_A3}, e_[3] = {T18_E2, T18_E3, T18_E6}, b_[5] = {T18_B0, T18_B1, T18_B2, T18_B3, T18_B6};
             const double c_[5] = {T18_C0, T18_C1, T18_C2, T18_C3, T18_C6}, d_[5] = {T18_D0, T18_D1, T18_D2, T18_D3, T18_D6};
             memcpy(oa.a, a_, sizeof(a_)); memcpy(oa.e, e_, sizeof(e_)); memcpy(oa.b, b_, sizeof(b_));
             memcpy(oa.c, c_, sizeof(c_)); memcpy(oa.d, d_, sizeof(d_));
         } else {
-            const double a_[3] = {T18T_A1, T18T_A2, T18T_A3}, e_[3] = {T18T_E2, T18T_E3, T18T_E6}, b_[4] = {T18T_B1, T18T_B2, T18T_B3, T18T_B6};
+            const double a_[3] = {T18T_A1, T18T_A2, T18T_A3}, e_[3] = {T18T_E2, T18T_E3, T18T_E6}, b_[5] = {T18T_B0, T18T_B1, T18T_B2, T18T_B3, T18T_B6};
             const double c_[5] = {T18T_C0, T18T_C1, T18T_C2, T18T_C3, T18T_C6}, d_[5] = {T18T_D0, T18T_D1, T18T_D2, T18T_D3, T18T_D6};
             memcpy(oa.a, a_, sizeof(a_)); memcpy(oa.e, e_, sizeof(e_)); memcpy(oa.b, b_, sizeof(b_));
             memcpy(oa.c, c_, sizeof(c_)); memcpy(oa.d, d_, sizeof(d_));

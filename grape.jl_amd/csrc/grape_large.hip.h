@@ -386,7 +386,7 @@ struct LgT18OperandsArgs {
     const double *A, *A2, *A3, *A6;
     double *B1, *B5, *B4, *B3, *B2;
     const int *s_cell;
-    double a[3], e[3], b[4], c[5], d[5];   // b: A, A2, A3, A6;  c, d: I, A, A2, A3, A6
+    double a[3], e[3], b[5], c[5], d[5];   // b, c, d: I, A, A2, A3, A6
     int NP;
     size_t per_cell;   // 2 * NP * NP
     size_t n;          // per_cell * cells
@@ -403,7 +403,7 @@ __global__ void lg_t18_operands_kernel(LgT18OperandsArgs a) {
         a.B5[i] = a.e[0] * x2 + a.e[1] * x3 + a.e[2] * x6;
         a.B4[i] = a.d[1] * x1 + a.d[2] * x2 + a.d[3] * x3 + a.d[4] * x6 + (diag ? a.d[0] : 0.0);
         a.B3[i] = a.c[1] * x1 + a.c[2] * x2 + a.c[3] * x3 + a.c[4] * x6 + (diag ? a.c[0] : 0.0);
-        a.B2[i] = a.b[0] * x1 + a.b[1] * x2 + a.b[2] * x3 + a.b[3] * x6;
+        a.B2[i] = a.b[1] * x1 + a.b[2] * x2 + a.b[3] * x3 + a.b[4] * x6 + (diag ? a.b[0] : 0.0);
     }
 }
 // Dinv = inverse of the 64x64 block (jb, jb) of Q, one workgroup per cell (fused-kernel solver, P = I)

@@ -12,7 +12,7 @@
 //     A2 = A A, A3 = A A2, A6 = A3 A3                  (Hermitian / skew-Hermitian: NT - 1 of NT row tiles per strip)
 //     B1 = a1 A + a2 A2 + a3 A3,  B5 = e2 A2 + e3 A3 + e6 A6,  B4 = d0 I + d1 A + d2 A2 + d3 A3 + d6 A6
 //     A9 = B1 B5 + B4                                   (general product)
-//     B3 = c0 I + c1 A + c2 A2 + c3 A3 + c6 A6,  B2 = b1 A + b2 A2 + b3 A3 + b6 A6
+//     B3 = c0 I + c1 A + c2 A2 + c3 A3 + c6 A6,  B2 = b0 I + b1 A + b2 A2 + b3 A3 + b6 A6   (d0 = 0, b0 = 1)
 //     p(A) = B2 + (B3 + A9) A9                          (general product)
 // 768 matrix instructions per wave at N = 64 against 816 + 264 (products + solve) of the Pade route, and none of them
 // waits for a tile inversion.
@@ -51,12 +51,12 @@ template <bool HERM> struct T18Coef;
 template <> struct T18Coef<true> {
     static constexpr double A1 = T18_A1, A2 = T18_A2, A3 = T18_A3, B1 = T18_B1, B2 = T18_B2, B3 = T18_B3, B6 = T18_B6,
         C0 = T18_C0, C1 = T18_C1, C2 = T18_C2, C3 = T18_C3, C6 = T18_C6, D0 = T18_D0, D1 = T18_D1, D2 = T18_D2, D3 = T18_D3,
-        D6 = T18_D6, E2 = T18_E2, E3 = T18_E3, E6 = T18_E6, THETA = T18_THETA;
+        D6 = T18_D6, E2 = T18_E2, E3 = T18_E3, E6 = T18_E6, B0 = T18_B0, THETA = T18_THETA;
 };
 template <> struct T18Coef<false> {
     static constexpr double A1 = T18T_A1, A2 = T18T_A2, A3 = T18T_A3, B1 = T18T_B1, B2 = T18T_B2, B3 = T18T_B3, B6 = T18T_B6,
         C0 = T18T_C0, C1 = T18T_C1, C2 = T18T_C2, C3 = T18T_C3, C6 = T18T_C6, D0 = T18T_D0, D1 = T18T_D1, D2 = T18T_D2, D3 = T18T_D3,
-        D6 = T18T_D6, E2 = T18T_E2, E3 = T18T_E3, E6 = T18T_E6, THETA = T18T_THETA;
+        D6 = T18T_D6, E2 = T18T_E2, E3 = T18T_E3, E6 = T18T_E6, B0 = T18T_B0, THETA = T18T_THETA;
 };
 
 // LDS carve: ONE left-operand region of three planes (re, im, re + im; leading dimension NP + 2), two exchange areas
@@ -611,7 +611,7 @@ __device__ __forceinline__ void expm_t18_cell(double *smem, const int wave, cons
         if (t == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (4 * r + rgd == cdiag) { b4r[r] += CF::D0; B3.re[0][r] += CF::C0; }
+                if (4 * r + rgd == cdiag) { b4r[r] += CF::D0; B3.re[0][r] += CF::C0; B2.re[0][r] += CF::B0; }   // (d0 = 0, b0 = 1: see grape_t18_coeffs.h)
         }
         // A9 = B1 B5 + B4 through the start values: re = p1 - p2, im = p3 - p1 - p2
         q.p1[t] = b4r; q.p2[t] = (d4){0., 0., 0., 0.}; q.p3[t] = b4r + b4i;

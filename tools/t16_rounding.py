@@ -1,9 +1,10 @@
 """Rounding error of the polynomial evaluation schemes of the Hermitian exponential, against an extended-precision
-reference (numpy, no GPU): the five-product degree-18 scheme with the Chebyshev coefficient set of grape_t18_coeffs.h, the
-four-product degree-16 scheme as written there, the same scheme in the "shifted" form that was tried and rejected
-(grape_t18.hip.h, expm_t16_cell), and scipy's order-13 Pade approximant.
+reference (numpy, no GPU): the five-product degree-18 scheme with the Chebyshev coefficient set of grape_t18_coeffs.h
+(d0 = 0, b0 = 1: the identity is added at the end) and with the set of the first round-3 version (published form, b0 = 0:
+the identity is the product (c0 + d0) d0), the four-product degree-16 scheme as written in the header, the same scheme in
+the "shifted" form that was tried and rejected (grape_t18.hip.h, expm_t16_cell), and scipy's order-13 Pade approximant.
 
-python3 tools/t16_rounding.py [N]      max |element error| for spectral radii 0.5, 1.0, 1.2, 1.36
+python3 tools/t16_rounding.py [N]      max |element error| for spectral radii 0.5, 1.0, 1.2, 1.36, 2.0
 """
 import re, sys, os
 import numpy as np
@@ -12,13 +13,15 @@ import scipy.linalg as sl
 HDR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "grape.jl_amd", "csrc", "grape_t18_coeffs.h")
 txt = open(HDR).read()
 c18 = {m.group(1).lower(): float(m.group(2)) for m in re.finditer(r"#define\s+T18_([A-E]\d)\s+(-?[\d.eE+-]+)", txt)}
+# Chebyshev set of the first round-3 version (published form: no constant in B2, d0 != 0)
+c18_first = dict(a1=-0.10036558103014462001, a2=-0.007456351650625886579, a3=-0.00083091953191006175088, b1=0.24166417193309948294, b2=1.1119704726210786376, b3=0.29736195952844853785, b6=-0.000564510422238531483, c0=-4.2636626654470864734, c1=1.7157463766850012865, c2=0.073686948027488562391, c3=-0.0033650385206633560936, c6=0.000033927981037541774044, d0=-0.22288835997489735785, d1=-0.24222749901747747758, d2=0.050668391204088569683, d3=0.023404567895744140748, d6=-0.000010355013205937047443, e2=-0.13912895765004587534, e3=-0.013910627366173824328, e6=-0.000014649629174709440602, b0=0.0)
 c16 = [float(re.search(r"#define\s+T16_C%d\s+(-?[\d.eE+-]+)" % i, txt).group(1)) for i in range(1, 17)]
 
 
 def t18(A, v=c18):
     I = np.eye(len(A)); A2 = A @ A; A3 = A2 @ A; A6 = A3 @ A3
     B1 = v['a1'] * A + v['a2'] * A2 + v['a3'] * A3
-    B2 = v['b1'] * A + v['b2'] * A2 + v['b3'] * A3 + v['b6'] * A6
+    B2 = v['b0'] * I + v['b1'] * A + v['b2'] * A2 + v['b3'] * A3 + v['b6'] * A6
     B3 = v['c0'] * I + v['c1'] * A + v['c2'] * A2 + v['c3'] * A3 + v['c6'] * A6
     B4 = v['d0'] * I + v['d1'] * A + v['d2'] * A2 + v['d3'] * A3 + v['d6'] * A6
     B5 = v['e2'] * A2 + v['e3'] * A3 + v['e6'] * A6
@@ -59,15 +62,15 @@ def reference(A):
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     rng = np.random.default_rng(0)
-    print("N = %d; max |element error|:  rho   degree-18   degree-16   degree-16 shifted   Pade-13 (scipy)" % N)
-    for rho in (0.5, 1.0, 1.2, 1.36):
-        e = np.zeros(4)
+    print("N = %d; max |element error|:  rho   degree-18   degree-18 first version   degree-16   degree-16 shifted   Pade-13 (scipy)" % N)
+    for rho in (0.5, 1.0, 1.2, 1.36, 2.0):
+        e = np.zeros(5)
         for _ in range(3):
             X = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N)); H = X + X.conj().T
             H *= rho / np.abs(np.linalg.eigvalsh(H)).max()
             A = -1j * H; U = reference(A)
-            e = np.maximum(e, [float(np.abs(f(A) - U).max()) for f in (t18, t16, t16_shifted, sl.expm)])
-        print("    %.2f   %.2e   %.2e   %.2e   %.2e" % (rho, *e))
+            e = np.maximum(e, [float(np.abs(f(A) - U).max()) for f in (t18, lambda M: t18(M, c18_first), t16, t16_shifted, sl.expm)])
+        print("    %.2f   %.2e   %.2e   %.2e   %.2e   %.2e" % (rho, *e))
 
 
 if __name__ == "__main__":
