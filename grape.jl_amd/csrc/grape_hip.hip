@@ -1338,7 +1338,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             if (h->t18 && (h->NT >= 3 || h->t18_small)) {
                 const bool t16 = h->d_celllist && h->t16_live;
                 ea.cell_list = h->d_celllist; ea.listed = 0;
-                e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, t16 ? 1 : 0, &ea, sizeof(ea), (void *)s, t18_blocks);
+                // (three tiles per side, four-product variant: 256 registers and 72 KB -- two workgroups per CU)
+                const int blocks16 = (t16 && h->NT == 3) ? 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * 2, (ncell + 7) / 8)) : t18_blocks;
+                e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, t16 ? 1 : 0, &ea, sizeof(ea), (void *)s, blocks16);
                 if (t16 && e == hipSuccess) {   // the cells it listed, by the degree-18 variant (none: the launch ends at once)
                     ea.listed = 1;
                     e = (hipError_t)grape_t18_launch(h->NT, 1, 0, &ea, sizeof(ea), (void *)s, t18_blocks);
@@ -1632,10 +1634,12 @@ int grape_check(grape_handle *h, void *stream_) {
         }
         return GRAPE_OK;
     }
-    int flags[8];
+    // the flags travel to pinned memory on the caller's stream and ONE wait serves both (a blocking hipMemcpy behind the
+    // stream synchronisation was a second round trip of ~10 us: 3 % of a C2 evaluation)
+    int *flags = (int *)(h->h_pin + h->h_pin_doubles - 4);
     HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_));
-    HIPCHK(h, hipMemcpy(flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost));
     // blocked path: the squaring plan follows the counts seen on the device (one spare launch costs microseconds)
     if (h->large && !h->series) h->sq_plan = std::max(2, flags[1] + 1);
     // four-product route: tried in the evaluation just checked (flags[5] cells, flags[4] of them fell back)?

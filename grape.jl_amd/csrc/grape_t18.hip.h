@@ -65,7 +65,9 @@ template <int NT>
 struct T18Lds {
     static constexpr int NP = 16 * NT, LD = NP + 2, NTH = NT * 64;
     static constexpr int PL = NP * LD;          // doubles per plane
-    static constexpr int E1 = 3 * PL, E2 = E1 + NT * 512, RED = E2 + NT * 512;
+    // (the area of the partial sums exists at four tiles per side only -- without it the three-tile layout is 72 KB and two
+    // workgroups fit a CU)
+    static constexpr int E1 = 3 * PL, E2 = E1 + (NT == 4 ? NT * 512 : 0), RED = E2 + NT * 512;
     static constexpr int TOTAL = RED + NTH + 8 + NP;   // doubles
 };
 
@@ -851,8 +853,10 @@ __device__ __forceinline__ void t18_store_u_slot(const ExpmArgs &a, const int ce
 // are appended to a.cell_list (flags[4] counts them, flags[5] the cells tried) and redone by a launch of the five-product
 // variant with a.listed set, which the host issues behind this one (no cell listed: a launch that ends at once).  From the
 // two counts the host decides whether the next evaluation tries the four-product route again.
+// Three tiles per side, four-product route: 256 registers and 72 KB, TWO workgroups per CU -- three waves leave a SIMD idle
+// and a lone wave cannot hide its own vector and LDS phases; with six waves on four SIMDs two of them are matrix-bound.
 template <int NT, bool SYM, bool CHEB, bool T16 = false>
-__global__ void __launch_bounds__(NT * 64) expm_t18_kernel(ExpmArgs a) {
+__global__ void __launch_bounds__(NT * 64, (T16 && NT == 3) ? 2 : 1) expm_t18_kernel(ExpmArgs a) {
     static_assert(!T16 || CHEB, "the four-product route is a Hermitian-generator route");
     using LY = T18Lds<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
