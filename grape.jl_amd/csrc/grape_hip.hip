@@ -1118,6 +1118,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         const long ncell = (long)h->KC * N_T;
         const long cap = std::max<long>(1, (long)(6.0e9 / (9.0 * 2.0 * pp * 8.0)));
         h->chunk = (int)std::min<long>(ncell, std::min<long>(cap, 4096));
+        if (const char *envc = getenv("GRAPE_LG_CHUNK")) h->chunk = (int)std::max<long>(1, std::min<long>(h->chunk, atol(envc)));   // (experiments: working set against the Infinity Cache)
         for (auto &b : h->d_lg) CCHK(dmalloc(&b, (size_t)h->chunk * 2 * pp));
         CCHK(dmalloc(&h->d_dinv, (size_t)h->chunk * 2 * 4096));
         CCHK(dmalloc(&h->d_scell, (size_t)h->chunk + 1));
