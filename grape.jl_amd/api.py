@@ -60,7 +60,8 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     out = out or library_path()
     srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_t18.hip", "grape_kernels.hip.h", "grape_large.hip.h",
-                                             "grape_series.hip.h", "grape_cheby.hip.h", "grape_t18.hip.h")]
+                                             "grape_series.hip.h", "grape_cheby.hip.h", "grape_t18.hip.h", "grape_t18_coeffs.h",
+                                             "grape_deriv3.hip.h")]
     hdr = os.path.join(_HERE, "..", "include", "grape_hip.h")
     if (not force and os.path.exists(out)
             and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs + [hdr])):

@@ -42,6 +42,9 @@ struct grape_handle {
     double *d_H0f = nullptr, *d_Hcf = nullptr, *d_H0t = nullptr, *d_Hct = nullptr;
     double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;
     double *d_H0q = nullptr, *d_Hcq = nullptr, *d_park2 = nullptr;   // two-pass series kernel: untransposed fragments, parking area
+    // one wave per batch (grape_deriv3.hip.h; Hermitian operators, 32 < N <= 64, L <= 2; GRAPE_DERIV3=0: off)
+    double *d_park3 = nullptr;
+    int deriv3_blocks = 0, deriv3_wpt = 0;
     int deriv2 = 0, deriv2_maxm = 0;
     bool deriv_stream = false;   // GRAPE_DERIV_STREAM=1: matrix-at-a-time products in deriv2_kernel for 3-4 controls as well
     bool deriv_stream_never = false;   // GRAPE_DERIV_STREAM=0: the all-at-once form for more than four controls too (A/B timing)
@@ -209,6 +212,8 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
+extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
+                                   void *stream, int blocks);
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream);
 #endif
@@ -858,7 +863,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
                     h->d_rho, h->d_flags, h->d_stats};
     for (void *b : bufs)
@@ -1110,6 +1115,14 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                 CCHK(hipMemcpy(h->d_Hcq, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
                 h->deriv2_maxm = 64;
                 CCHK(dmalloc(&h->d_park2, (size_t)h->deriv_blocks * h->deriv2_maxm * 2 * NP * 16));
+                const char *env3 = getenv("GRAPE_DERIV3");
+                if (h->herm && !h->large && !h->series && L <= 2 && !(env3 && atoi(env3) == 0)) {
+                    // workgroups per trajectory: as many as it takes to put a workgroup on every CU, at most one per four batches
+                    const int bpk = (N_T + 15) / 16;
+                    h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
+                    h->deriv3_blocks = (int)std::min<long>(h->num_cus, (long)K * h->deriv3_wpt);
+                    CCHK(dmalloc(&h->d_park3, (size_t)h->deriv3_blocks * 4 * h->deriv2_maxm * 2 * NP * 16));
+                }
             }
         }
         CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + (h->large ? 4 : 8)) * 2 * NP * 16));
@@ -1566,6 +1579,10 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
 #ifdef GRAPE_DIAG
         d2.ablate = getenv("GRAPE_DIAG_ABLATE_D2") ? atoi(getenv("GRAPE_DIAG_ABLATE_D2")) : 0;
 #endif
+        if (h->d_park3 && !d2.gpark) {
+            d2.park = h->d_park3;
+            e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, (void *)s, h->deriv3_blocks);
+        } else
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);
     } else if (h->NP >= 48) {
         DerivMfmaArgs dm{};

@@ -11,6 +11,7 @@
 #include <string.h>
 namespace {
 #include "grape_t18.hip.h"
+#include "grape_deriv3.hip.h"
 
 template <int NT, bool SYM, bool CHEB, bool T16 = false>
 hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
@@ -26,7 +27,35 @@ hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
     hipLaunchKernelGGL((expm_t18_kernel<NT, SYM, CHEB, T16>), dim3(blocks), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
 }
+template <int NT, int LMAX>
+hipError_t launch_d3(const Deriv3Args &a, hipStream_t s, int blocks) {
+    static size_t lds_set[64] = {0};
+    const size_t lds = sizeof(double) * (size_t)(1 + LMAX) * D3Lds<NT>::MAT;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (lds_set[dev & 63] < lds) {
+        hipError_t e = hipFuncSetAttribute((const void *)deriv3_kernel<NT, LMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set[dev & 63] = lds;
+    }
+    hipLaunchKernelGGL((deriv3_kernel<NT, LMAX>), dim3(blocks), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
 }  // namespace
+
+// derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators, three or four tiles per side, L <= 2
+extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
+                                   void *stream, int blocks) {
+    if (d2size != sizeof(Deriv2Args)) return (int)hipErrorInvalidValue;
+    Deriv3Args a;
+    memcpy(&a.d, d2args, sizeof(a.d));
+    a.H0f = H0f; a.Hcf = Hcf; a.wpt = wpt;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.d.L < 1 || a.d.L > 2) return (int)hipErrorInvalidValue;
+    if (NT == 3) return (int)(a.d.L == 1 ? launch_d3<3, 1>(a, s, blocks) : launch_d3<3, 2>(a, s, blocks));
+    if (NT == 4) return (int)(a.d.L == 1 ? launch_d3<4, 1>(a, s, blocks) : launch_d3<4, 2>(a, s, blocks));
+    return (int)hipErrorInvalidValue;
+}
 
 // args: the ExpmArgs of grape_kernels.hip.h (same header on both sides), passed as bytes because the type of this unit
 // lives in an anonymous namespace

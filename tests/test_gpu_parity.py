@@ -771,3 +771,39 @@ def test_four_product_route_is_given_up_while_it_does_not_pay(g, monkeypatch):
     assert w1["t16_cells"] == 0 and w1["t18_cells"] == K * N_T and w2["t16_cells"] == 0 and w2["t18_cells"] == K * N_T
     assert w2["t18_mfma_flop"] < 0.6 * w1["t18_mfma_flop"]          # first evaluation: 3.6 + 4.25 product equivalents per cell
     assert J1 == J2 and np.array_equal(G1, G2) and np.array_equal(tau1, tau2)
+
+
+@pytest.mark.parametrize("N,L,N_T,K", [(64, 2, 300, 4), (48, 1, 203, 3), (60, 2, 129, 9), (40, 2, 64, 130)])
+def test_derivative_kernel_with_one_wave_per_batch_matches_the_shared_batch_kernel(g, ref, N, L, N_T, K, monkeypatch):
+    """Hermitian operators, 32 < N <= 64, L <= 2: deriv3_kernel (grape_deriv3.hip.h: one wave per batch of 16 cells, operators
+    as upper-triangle tiles in LDS, mirrored tiles through the negation bit of the matrix instruction) against deriv2_kernel
+    (GRAPE_DERIV3=0) on the same inputs -- same series, same stopping rule, the additions of a cell in the same order: equal
+    to rounding; and both against the C restatement on the first steps.  Shapes: a last batch with unused columns, padded
+    sizes (60 -> 64, 40 -> 48), more trajectories than workgroups, several workgroups per trajectory, shaped amplitudes."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=3300 + N + L)
+    rng = np.random.default_rng(N * 7 + L)
+    tl = np.concatenate([[0.0], np.cumsum(0.6 + 0.8 * rng.random(N_T))])
+    shape = 0.5 + rng.random((L, N_T))
+    res = {}
+    for name, env in (("d3", {}), ("d2", {"GRAPE_DERIV3": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with g.GrapeHip(pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"], shape=shape) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            res[name] = (J, G.copy(), tau.copy(), h.work())
+        for k in env:
+            monkeypatch.delenv(k)
+    assert res["d3"][0] == res["d2"][0] and np.array_equal(res["d3"][2], res["d2"][2])       # the sweeps are the same code
+    assert np.abs(res["d3"][1] - res["d2"][1]).max() <= 1e-13 * max(np.abs(res["d2"][1]).max(), 1e-3)
+    assert res["d3"][3]["deriv_orders"] == res["d2"][3]["deriv_orders"] > 0                    # same stopping decisions
+    ns = 10
+    xs = pr["pulsevals"].reshape(L, N_T)[:, :ns].reshape(-1)
+    Ks = min(K, 3)
+    with g.GrapeHip(pr["H0"][:Ks], pr["Hc"], tl[: ns + 1], pr["psi0"][:Ks], pr["target"][:Ks], pr["weights"][:Ks],
+                    shape=shape[:, :ns]) as hs:
+        Js, Gs, taus = hs.eval(xs)
+    import grape_oracle as go    # (the numpy restatement knows shaped amplitudes)
+    Jr, Gr, taur = go.evaluate_gradient(pr["H0"][:Ks], pr["Hc"], tl[: ns + 1], xs, pr["psi0"][:Ks], pr["target"][:Ks],
+                                        pr["weights"][:Ks], shape=shape[:, :ns])
+    assert abs(Js - Jr) <= TOL_J and np.abs(taus - taur).max() <= TOL_TAU and np.abs(Gs - Gr).max() <= tol_G(Gr)
