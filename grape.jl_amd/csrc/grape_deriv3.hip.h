@@ -23,6 +23,8 @@ struct Deriv3Args {
     Deriv2Args d;             // H0p / Hcp / H0q / Hcq unused
     const double *H0f, *Hcf;  // planar row-major operators [K][2][NP*NP], [Kc][L][2][NP*NP] (ExpmArgs layout)
     int wpt;                  // workgroups per trajectory
+    int skip_if_flagged;      // N <= 32: leave the launch at once when deriv_flag_kernel found a batch that needs sub-steps
+                              // (flags[3] != 0) -- deriv_kernel, launched behind this one, then does every cell
 };
 
 template <int NT>
@@ -109,6 +111,7 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
     constexpr int NP = 16 * NT;
     extern __shared__ __attribute__((aligned(16))) double d3sm[];   // [1 + LMAX][NTILE][2][16][17]
     const Deriv2Args &a = g.d;
+    if (g.skip_if_flagged && a.flags[3] != 0) return;   // (uniform)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, rg = lane >> 4;

@@ -213,7 +213,7 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
-                                   void *stream, int blocks);
+                                   int skip_if_flagged, void *stream, int blocks);
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream);
 #endif
@@ -1127,6 +1127,17 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         }
         CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + (h->large ? 4 : 8)) * 2 * NP * 16));
     }
+    if (NP < 48 && h->herm && L <= 2) {   // one wave per batch also at one and two tiles per side (grape_deriv3.hip.h); the matrix-free
+                                          // mode as well: at these sizes the derivative kernel never used the parked forward terms
+        const char *env3 = getenv("GRAPE_DERIV3");
+        if (!(env3 && atoi(env3) == 0)) {
+            const int bpk = (N_T + 15) / 16;
+            h->deriv2_maxm = 64;
+            h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
+            h->deriv3_blocks = (int)std::min<long>(h->num_cus, (long)K * h->deriv3_wpt);
+            CCHK(dmalloc(&h->d_park3, (size_t)h->deriv3_blocks * 4 * h->deriv2_maxm * 2 * NP * 16));
+        }
+    }
     if (h->large && !h->series) {
         const long ncell = (long)h->KC * N_T;
         const long cap = std::max<long>(1, (long)(6.0e9 / (9.0 * 2.0 * pp * 8.0)));
@@ -1581,7 +1592,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
 #endif
         if (h->d_park3 && !d2.gpark) {
             d2.park = h->d_park3;
-            e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, (void *)s, h->deriv3_blocks);
+            e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, (void *)s, h->deriv3_blocks);
         } else
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);
     } else if (h->NP >= 48) {
@@ -1596,11 +1607,39 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         if (h->sub_theta > 0.0) dm.batch_flag = h->d_batchflag;
         e = launch_deriv_mfma(h->NP, dm, h->deriv_blocks, s);
     } else {
+        if (h->d_park3) {
+            // one wave per batch (deriv3_kernel); cells whose series needs sub-steps are deriv_kernel's: it is launched behind
+            // and ends at once unless deriv_flag_kernel counted such a batch -- in which case deriv3_kernel ends at once
+            Deriv2Args d2{};
+            d2.eps = h->d_eps; d2.shape = h->d_shape; d2.dts = h->d_dts;
+            d2.fw = h->d_fw; d2.bw = h->d_bw; d2.rho = unit ? h->d_ones : h->d_rho; d2.tg = h->d_tg; d2.park = h->d_park3;
+            d2.flags = h->d_flags; d2.stats = h->d_stats;
+            d2.K = h->K; d2.L = h->L; d2.N_T = h->N_T; d2.hc_per_traj = h->p.hc_per_traj;
+            d2.max_order = h->taylor_max_order; d2.maxm = h->deriv2_maxm; d2.tol = h->taylor_tol;
+            d2.batches_per_k = (h->N_T + 15) / 16;
+            d2.nbatch_total = h->K * d2.batches_per_k;
+            const bool sub = h->sub_theta > 0.0;
+            if (sub) {
+                HIPCHK(h, hipMemsetAsync(h->d_flags + 3, 0, sizeof(int), s));
+                DerivFlagArgs fa{};
+                fa.rb = h->d_rb; fa.eps = h->d_eps; fa.shape = h->d_shape; fa.dts = h->d_dts;
+                fa.rb_k = h->K; fa.K = h->K; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj;
+                fa.batches_per_k = d2.batches_per_k; fa.nbatch_total = d2.nbatch_total;
+                fa.sub_theta = h->sub_theta; fa.batch_flag = h->d_batchflag; fa.flags = h->d_flags;
+                hipLaunchKernelGGL(deriv_flag_kernel, dim3((fa.nbatch_total + 255) / 256), dim3(256), 0, s, fa);
+                HIPCHK(h, hipGetLastError());
+            }
+            HIPCHK(h, (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, sub ? 1 : 0, (void *)s,
+                                                      h->deriv3_blocks));
+            da.only_if = sub ? h->d_flags + 3 : nullptr;
+            if (!sub) goto deriv_done;
+        }
         switch (h->NP) {
             case 16: e = launch_deriv<16>(da, nblocks, s); break;
             default: e = launch_deriv<32>(da, nblocks, s); break;
         }
     }
+deriv_done:
     HIPCHK(h, e);
     if (h->NP >= 48 && h->sub_theta > 0.0) {
         // second pass over the batches the fast kernel flagged (cells whose series needs sub-steps); it ends at once

@@ -2323,6 +2323,9 @@ struct DerivArgs {
     const double *rb;
     int rb_k;
     double sub_theta;
+    // nullptr or a counter (flags[3]: batches that need sub-steps): the launch ends at once while it is zero -- deriv3_kernel
+    // (grape_deriv3.hip.h) has done every cell; non-zero: this kernel does all of them
+    const int *only_if;
 };
 
 // Number of sub-steps of the derivative series of one cell.  The series of exp(-i G dt) on the extended vector is
@@ -2505,6 +2508,7 @@ __global__ void __launch_bounds__(NTH) deriv_kernel(DerivArgs a) {
     __shared__ double red[2][NW][LMAX];    // per wave: ||phi_l||^2 of its rows
     __shared__ double redc[2][NW];         // per wave: ||pw||^2 of its rows (sub-stepped cells only)
     __shared__ double2 gsum[NW][LMAX];     // per wave: final <chi'_l | psi> of its rows
+    if (a.only_if && *a.only_if == 0) return;   // (uniform)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = tid % NCH, i = tid / NCH;  // column chunk, row

@@ -43,15 +43,17 @@ hipError_t launch_d3(const Deriv3Args &a, hipStream_t s, int blocks) {
 }
 }  // namespace
 
-// derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators, three or four tiles per side, L <= 2
+// derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators, N <= 64, L <= 2
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
-                                   void *stream, int blocks) {
+                                   int skip_if_flagged, void *stream, int blocks) {
     if (d2size != sizeof(Deriv2Args)) return (int)hipErrorInvalidValue;
     Deriv3Args a;
     memcpy(&a.d, d2args, sizeof(a.d));
-    a.H0f = H0f; a.Hcf = Hcf; a.wpt = wpt;
+    a.H0f = H0f; a.Hcf = Hcf; a.wpt = wpt; a.skip_if_flagged = skip_if_flagged;
     hipStream_t s = (hipStream_t)stream;
     if (a.d.L < 1 || a.d.L > 2) return (int)hipErrorInvalidValue;
+    if (NT == 1) return (int)(a.d.L == 1 ? launch_d3<1, 1>(a, s, blocks) : launch_d3<1, 2>(a, s, blocks));
+    if (NT == 2) return (int)(a.d.L == 1 ? launch_d3<2, 1>(a, s, blocks) : launch_d3<2, 2>(a, s, blocks));
     if (NT == 3) return (int)(a.d.L == 1 ? launch_d3<3, 1>(a, s, blocks) : launch_d3<3, 2>(a, s, blocks));
     if (NT == 4) return (int)(a.d.L == 1 ? launch_d3<4, 1>(a, s, blocks) : launch_d3<4, 2>(a, s, blocks));
     return (int)hipErrorInvalidValue;

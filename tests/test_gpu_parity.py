@@ -807,3 +807,36 @@ def test_derivative_kernel_with_one_wave_per_batch_matches_the_shared_batch_kern
     Jr, Gr, taur = go.evaluate_gradient(pr["H0"][:Ks], pr["Hc"], tl[: ns + 1], xs, pr["psi0"][:Ks], pr["target"][:Ks],
                                         pr["weights"][:Ks], shape=shape[:, :ns])
     assert abs(Js - Jr) <= TOL_J and np.abs(taus - taur).max() <= TOL_TAU and np.abs(Gs - Gr).max() <= tol_G(Gr)
+
+
+@pytest.mark.parametrize("N,L", [(16, 1), (32, 2), (9, 2)])
+def test_small_sizes_one_wave_per_batch_and_the_hand_over_of_sub_stepped_series(g, ref, N, L, monkeypatch):
+    """N <= 32 (Hermitian operators, L <= 2): the derivative overlaps come from deriv3_kernel unless a batch needs a
+    sub-stepped series (||H|| dt above the threshold) -- then deriv_flag_kernel has counted it, deriv3_kernel leaves at once
+    and deriv_kernel, launched behind it, does every cell: bit-identical to GRAPE_DERIV3=0.  Without such a batch the two
+    kernels agree to rounding; either way the result matches the C restatement."""
+    from grape_jl_amd import synth
+    N_T, K = 75, 5
+    pr = synth.make_problem(N, L, N_T, K, seed=4100 + N)
+    for big in (False, True):
+        dts = np.full(N_T, 0.8)
+        if big:
+            dts[[7, 40]] = 9.0                            # ||H|| dt about 9: sub-steps
+        tl = np.concatenate([[0.0], np.cumsum(dts)])
+        args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
+        res = {}
+        for name, env in (("d3", {}), ("old", {"GRAPE_DERIV3": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            with g.GrapeHip(*args) as h:
+                J, G, tau = h.eval(pr["pulsevals"])
+                res[name] = (J, G.copy(), h.work()["deriv_orders"])
+            for k in env:
+                monkeypatch.delenv(k)
+        assert res["d3"][0] == res["old"][0]
+        if big:
+            assert np.array_equal(res["d3"][1], res["old"][1]) and res["d3"][2] == res["old"][2]
+        else:
+            assert np.abs(res["d3"][1] - res["old"][1]).max() <= 1e-13 * max(np.abs(res["old"][1]).max(), 1e-3)
+        Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:])
+        assert abs(res["d3"][0] - Jr) <= TOL_J and np.abs(res["d3"][1] - Gr).max() <= tol_G(Gr)
