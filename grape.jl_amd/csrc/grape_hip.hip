@@ -60,7 +60,8 @@ struct grape_handle {
     // per-evaluation
     double *d_eps = nullptr;
     double2 *d_U = nullptr, *d_fw = nullptr, *d_bw = nullptr, *d_tg = nullptr;
-    double *d_out = nullptr;  // [2K + 4] tau + partial sums (host API)
+    double *d_ret = nullptr;  // slab: d_out | d_G | d_flags | d_stats (see grape_create)
+    double *d_out = nullptr;  // [2K + 8] tau + partial sums (host API)
     double *d_f = nullptr, *d_G = nullptr, *d_rho = nullptr;
     int *d_flags = nullptr;
     int *d_cellflag = nullptr;   // [K*N_T] cells flagged for the pivoted Pade solve
@@ -864,8 +865,8 @@ void grape_destroy(grape_handle *h) {
     for (double *b : h->d_lg)
         if (b) hipFree(b);
     void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
-                    h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_out, h->d_f, h->d_G,
-                    h->d_rho, h->d_flags, h->d_stats};
+                    h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
+                    h->d_rho};
     for (void *b : bufs)
         if (b) hipFree(b);
     if (h->h_pin) hipHostFree(h->h_pin);
@@ -1247,9 +1248,15 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_fw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_bw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_tg, (size_t)K * L * N_T));
-    CCHK(dmalloc(&h->d_out, (size_t)2 * K + 8));
-    CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_G, (size_t)L * N_T)); CCHK(dmalloc(&h->d_rho, (size_t)K));
-    CCHK(dmalloc(&h->d_flags, 8)); CCHK(dmalloc(&h->d_stats, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS));
+    // ONE slab for everything an evaluation hands back or resets: [tau + sums (2K + 8) | G (L N_T) | flags (8 ints) | statistics]
+    // -- the single-wait grape_eval reads the first three with one copy and resets the last two with one memset (every copy or
+    // memset is a launch of its own: 5 us each on a 340-us evaluation at C2)
+    CCHK(dmalloc(&h->d_ret, (size_t)2 * K + 8 + (size_t)L * N_T + 4 + (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS));
+    h->d_out = h->d_ret;
+    h->d_G = h->d_ret + (size_t)2 * K + 8;
+    h->d_flags = (int *)(h->d_G + (size_t)L * N_T);
+    h->d_stats = (unsigned long long *)(h->d_G + (size_t)L * N_T + 4);
+    CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
     // (N <= 16 stays with five products: one tile per side is latency-bound -- the kernel gains nothing from the shorter
     // polynomial and the second launch costs 10 us of an evaluation of 0.4 ms; measured at C2: 0.079 -> 0.098 ms)
@@ -1328,8 +1335,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     // HIP's last-error is sticky per host thread: a failure elsewhere in the process (another handle's failed
     // allocation, a bad device ordinal) must not be reported by the launch checks of this evaluation
     (void)hipGetLastError();
-    HIPCHK(h, hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int), s));
-    HIPCHK(h, hipMemsetAsync(h->d_stats, 0, (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS * sizeof(unsigned long long), s));
+    HIPCHK(h, hipMemsetAsync(h->d_flags, 0, 8 * sizeof(int) + (size_t)GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS * sizeof(unsigned long long), s));   // flags | statistics
     if (d_pulsevals != h->d_eps)
         HIPCHK(h, hipMemcpyAsync(h->d_eps, d_pulsevals, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToDevice, s));
     // ---- phase 0: expm of every cell ----
@@ -1669,6 +1675,28 @@ deriv_done:
 }
 }  // namespace
 
+namespace {
+// flags of the last evaluation in pinned memory: behind the staged pulses, forward outputs and gradient (the layout of the
+// result slab, so that the single-wait grape_eval fetches all of it with one copy)
+int *pinned_flags(grape_handle *h) {
+    return (int *)(h->h_pin + (size_t)2 * h->L * h->N_T + 2 * (size_t)h->K + 8);
+}
+// what the host learns from the flags of an evaluation that has completed: launch plans for the next one, then the status
+int digest_flags(grape_handle *h, const int *flags) {
+    // blocked path: the squaring plan follows the counts seen on the device (one spare launch costs microseconds)
+    if (h->large && !h->series) h->sq_plan = std::max(2, flags[1] + 1);
+    // four-product route: tried in the evaluation just checked (flags[5] cells, flags[4] of them fell back)?
+    if (flags[5] > 0) {
+        h->t16_tried = flags[5]; h->t16_fell = flags[4];
+        if (4L * flags[4] > (long)flags[5]) { h->t16_live = false; h->t16_hold = 32; }
+    } else if (!h->t16_live && --h->t16_hold <= 0) {
+        h->t16_live = true;
+    }
+    return status_from_flags(h, flags[0]);
+}
+
+}  // namespace
+
 extern "C" {
 
 int grape_set_fused_sweeps(grape_handle *h, int on) {
@@ -1693,20 +1721,11 @@ int grape_check(grape_handle *h, void *stream_) {
     }
     // the flags travel to pinned memory on the caller's stream and ONE wait serves both (a blocking hipMemcpy behind the
     // stream synchronisation was a second round trip of ~10 us: 3 % of a C2 evaluation)
-    int *flags = (int *)(h->h_pin + h->h_pin_doubles - 4);
+    int *flags = pinned_flags(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(flags, h->d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream_));
-    // blocked path: the squaring plan follows the counts seen on the device (one spare launch costs microseconds)
-    if (h->large && !h->series) h->sq_plan = std::max(2, flags[1] + 1);
-    // four-product route: tried in the evaluation just checked (flags[5] cells, flags[4] of them fell back)?
-    if (flags[5] > 0) {
-        h->t16_tried = flags[5]; h->t16_fell = flags[4];
-        if (4L * flags[4] > (long)flags[5]) { h->t16_live = false; h->t16_hold = 32; }
-    } else if (!h->t16_live && --h->t16_hold <= 0) {
-        h->t16_live = true;
-    }
-    return status_from_flags(h, flags[0]);
+    return digest_flags(h, flags);
 }
 
 }  // extern "C"
@@ -1716,14 +1735,15 @@ namespace {
 // The host-pointer calls are split into an asynchronous half (copies and launches on the handle's stream) and a
 // half that waits and reads the pinned staging area, so that a handle with several devices can put all of them to work
 // from one host thread before it waits for the first.
-int forward_enqueue(grape_handle *h, const double *pulsevals) {
+int forward_enqueue(grape_handle *h, const double *pulsevals, bool copy_out = true) {
     HIPCHK(h, hipSetDevice(h->device));
     const size_t nl = (size_t)h->L * h->N_T;
     memcpy(h->h_pin, pulsevals, nl * 8);
     HIPCHK(h, hipMemcpyAsync(h->d_eps, h->h_pin, nl * 8, hipMemcpyHostToDevice, h->stream));
     const int rc = grape_forward_device(h, h->d_eps, h->d_out, h->stream);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->h_pin + nl, h->d_out, ((size_t)2 * h->K + 8) * 8, hipMemcpyDeviceToHost, h->stream));
+    if (copy_out)
+        HIPCHK(h, hipMemcpyAsync(h->h_pin + nl, h->d_out, ((size_t)2 * h->K + 8) * 8, hipMemcpyDeviceToHost, h->stream));
     return GRAPE_OK;
 }
 int forward_finish(grape_handle *h, double *tau) {
@@ -1953,17 +1973,19 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
         phase_begin(h, 5, h->stream);
         h->in_eval = true;
         h->want_bw = true;
-        int rc = forward_enqueue(h, pulsevals);
+        int rc = forward_enqueue(h, pulsevals, false);
         h->in_eval = false;
         if (rc) { h->n_fwd++; return rc; }
         rc = backward_device_impl(h, h->d_out + 2 * (size_t)h->K, h->d_G, h->stream, nullptr);
         if (rc) { h->n_fwd++; return rc; }
-        // (G is staged behind the forward outputs: the forward staging area is read after the wait)
-        double *gpin = h->h_pin + (size_t)h->L * h->N_T + 2 * (size_t)h->K + 8;
-        HIPCHK(h, hipMemcpyAsync(gpin, h->d_G, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToHost, h->stream));
+        // forward outputs | G | flags: contiguous in the result slab and in the staging area -- ONE copy
+        const size_t nl_ = (size_t)h->L * h->N_T;
+        double *gpin = h->h_pin + nl_ + 2 * (size_t)h->K + 8;
+        HIPCHK(h, hipMemcpyAsync(h->h_pin + nl_, h->d_ret, ((size_t)2 * h->K + 8 + nl_ + 4) * 8, hipMemcpyDeviceToHost, h->stream));
         phase_end(h, 5, h->stream);
         h->n_fwd++;
-        rc = grape_check(h, h->stream);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        rc = digest_flags(h, pinned_flags(h));
         if (rc) return rc;
         if (tau) memcpy(tau, h->h_pin + (size_t)h->L * h->N_T, (size_t)2 * h->K * 8);
         *J = functional_from_sums(h, forward_sums(h));
