@@ -1638,14 +1638,14 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
             HIPCHK(h, (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, sub ? 1 : 0, (void *)s,
                                                       h->deriv3_blocks));
             da.only_if = sub ? h->d_flags + 3 : nullptr;
-            if (!sub) goto deriv_done;
         }
-        switch (h->NP) {
-            case 16: e = launch_deriv<16>(da, nblocks, s); break;
-            default: e = launch_deriv<32>(da, nblocks, s); break;
+        if (!h->d_park3 || h->sub_theta > 0.0) {   // (no sub-stepping, :taylor route: deriv3_kernel has done every cell)
+            switch (h->NP) {
+                case 16: e = launch_deriv<16>(da, nblocks, s); break;
+                default: e = launch_deriv<32>(da, nblocks, s); break;
+            }
         }
     }
-deriv_done:
     HIPCHK(h, e);
     if (h->NP >= 48 && h->sub_theta > 0.0) {
         // second pass over the batches the fast kernel flagged (cells whose series needs sub-steps); it ends at once

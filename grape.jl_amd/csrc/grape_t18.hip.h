@@ -807,11 +807,7 @@ __device__ __forceinline__ bool expm_t16_cell(double *smem, const int wave, cons
         }
     }
     __syncthreads();
-#ifdef T16_NOHOOK
-    t18_gemm<LD, NT, NT, false>(q, R, Y0, wave, lane, nohook);
-#else
     t18_gemm<LD, NT, NT, false>(q, R, Y0, wave, lane, hook_last);
-#endif
     t18_combine<NT, NT>(q, U);
     return ok;
 #undef T16_FRESH_LANE
