@@ -213,6 +213,11 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
+// deriv3_kernel keeps the upper 16 x 16 tiles (re, im; stride 17) of H0_k and of the L control operators in LDS
+static bool deriv3_fits(int NT, int L) {
+    const size_t mat = (size_t)(NT * (NT + 1) / 2) * 2 * 16 * 17 * sizeof(double);
+    return L >= 1 && L <= 8 && (size_t)(1 + L) * mat <= 160 * 1024;
+}
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
                                    int skip_if_flagged, void *stream, int blocks);
 #ifdef GRAPE_DIAG
@@ -1117,7 +1122,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                 h->deriv2_maxm = 64;
                 CCHK(dmalloc(&h->d_park2, (size_t)h->deriv_blocks * h->deriv2_maxm * 2 * NP * 16));
                 const char *env3 = getenv("GRAPE_DERIV3");
-                if (h->herm && !h->large && !h->series && L <= 2 && !(env3 && atoi(env3) == 0)) {
+                if (h->herm && !h->large && !h->series && deriv3_fits(h->NT, L) && !(env3 && atoi(env3) == 0)) {
                     // workgroups per trajectory: as many as it takes to put a workgroup on every CU, at most one per four batches
                     const int bpk = (N_T + 15) / 16;
                     h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
@@ -1128,7 +1133,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         }
         CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + (h->large ? 4 : 8)) * 2 * NP * 16));
     }
-    if (NP < 48 && h->herm && L <= 2) {   // one wave per batch also at one and two tiles per side (grape_deriv3.hip.h); the matrix-free
+    if (NP < 48 && h->herm && deriv3_fits(h->NT, L)) {   // one wave per batch also at one and two tiles per side (grape_deriv3.hip.h); the matrix-free
                                           // mode as well: at these sizes the derivative kernel never used the parked forward terms
         const char *env3 = getenv("GRAPE_DERIV3");
         if (!(env3 && atoi(env3) == 0)) {

@@ -30,7 +30,8 @@ hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
 template <int NT, int LMAX>
 hipError_t launch_d3(const Deriv3Args &a, hipStream_t s, int blocks) {
     static size_t lds_set[64] = {0};
-    const size_t lds = sizeof(double) * (size_t)(1 + LMAX) * D3Lds<NT>::MAT;
+    const size_t lds = sizeof(double) * (size_t)(1 + a.d.L) * D3Lds<NT>::MAT;   // the operators actually present
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     int dev = 0;
     hipGetDevice(&dev);
     if (lds_set[dev & 63] < lds) {
@@ -43,7 +44,7 @@ hipError_t launch_d3(const Deriv3Args &a, hipStream_t s, int blocks) {
 }
 }  // namespace
 
-// derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators, N <= 64, L <= 2
+// derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators whose upper tiles fit the LDS
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
                                    int skip_if_flagged, void *stream, int blocks) {
     if (d2size != sizeof(Deriv2Args)) return (int)hipErrorInvalidValue;
@@ -51,11 +52,19 @@ extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, co
     memcpy(&a.d, d2args, sizeof(a.d));
     a.H0f = H0f; a.Hcf = Hcf; a.wpt = wpt; a.skip_if_flagged = skip_if_flagged;
     hipStream_t s = (hipStream_t)stream;
-    if (a.d.L < 1 || a.d.L > 2) return (int)hipErrorInvalidValue;
-    if (NT == 1) return (int)(a.d.L == 1 ? launch_d3<1, 1>(a, s, blocks) : launch_d3<1, 2>(a, s, blocks));
-    if (NT == 2) return (int)(a.d.L == 1 ? launch_d3<2, 1>(a, s, blocks) : launch_d3<2, 2>(a, s, blocks));
-    if (NT == 3) return (int)(a.d.L == 1 ? launch_d3<3, 1>(a, s, blocks) : launch_d3<3, 2>(a, s, blocks));
-    if (NT == 4) return (int)(a.d.L == 1 ? launch_d3<4, 1>(a, s, blocks) : launch_d3<4, 2>(a, s, blocks));
+    const int L = a.d.L;
+    if (L < 1 || L > 8) return (int)hipErrorInvalidValue;
+    // more than two controls where the operators still fit the LDS: N <= 32 up to eight, N <= 48 up to five
+#define D3_CASES(NT_)                                                                                                   \
+    if (NT == NT_) {                                                                                                    \
+        if (L == 1) return (int)launch_d3<NT_, 1>(a, s, blocks);                                                        \
+        if (L == 2) return (int)launch_d3<NT_, 2>(a, s, blocks);                                                        \
+        if (L <= 4) return (int)launch_d3<NT_, 4>(a, s, blocks);                                                        \
+        return (int)launch_d3<NT_, 8>(a, s, blocks);                                                                    \
+    }
+    D3_CASES(1) D3_CASES(2) D3_CASES(3)
+#undef D3_CASES
+    if (NT == 4 && L <= 2) return (int)(L == 1 ? launch_d3<4, 1>(a, s, blocks) : launch_d3<4, 2>(a, s, blocks));
     return (int)hipErrorInvalidValue;
 }
 

@@ -773,9 +773,10 @@ def test_four_product_route_is_given_up_while_it_does_not_pay(g, monkeypatch):
     assert J1 == J2 and np.array_equal(G1, G2) and np.array_equal(tau1, tau2)
 
 
-@pytest.mark.parametrize("N,L,N_T,K", [(64, 2, 300, 4), (48, 1, 203, 3), (60, 2, 129, 9), (40, 2, 64, 130)])
+@pytest.mark.parametrize("N,L,N_T,K", [(64, 2, 300, 4), (48, 1, 203, 3), (60, 2, 129, 9), (40, 2, 64, 130), (48, 4, 100, 3),
+                                      (36, 5, 50, 2)])
 def test_derivative_kernel_with_one_wave_per_batch_matches_the_shared_batch_kernel(g, ref, N, L, N_T, K, monkeypatch):
-    """Hermitian operators, 32 < N <= 64, L <= 2: deriv3_kernel (grape_deriv3.hip.h: one wave per batch of 16 cells, operators
+    """Hermitian operators, 32 < N <= 64, L <= 2 (N <= 48: L <= 5): deriv3_kernel (grape_deriv3.hip.h: one wave per batch of 16 cells, operators
     as upper-triangle tiles in LDS, mirrored tiles through the negation bit of the matrix instruction) against deriv2_kernel
     (GRAPE_DERIV3=0) on the same inputs -- same series, same stopping rule, the additions of a cell in the same order: equal
     to rounding; and both against the C restatement on the first steps.  Shapes: a last batch with unused columns, padded
@@ -809,9 +810,9 @@ def test_derivative_kernel_with_one_wave_per_batch_matches_the_shared_batch_kern
     assert abs(Js - Jr) <= TOL_J and np.abs(taus - taur).max() <= TOL_TAU and np.abs(Gs - Gr).max() <= tol_G(Gr)
 
 
-@pytest.mark.parametrize("N,L", [(16, 1), (32, 2), (9, 2)])
+@pytest.mark.parametrize("N,L", [(16, 1), (32, 2), (9, 2), (16, 4), (30, 6), (4, 8)])
 def test_small_sizes_one_wave_per_batch_and_the_hand_over_of_sub_stepped_series(g, ref, N, L, monkeypatch):
-    """N <= 32 (Hermitian operators, L <= 2): the derivative overlaps come from deriv3_kernel unless a batch needs a
+    """N <= 32 (Hermitian operators, L <= 8): the derivative overlaps come from deriv3_kernel unless a batch needs a
     sub-stepped series (||H|| dt above the threshold) -- then deriv_flag_kernel has counted it, deriv3_kernel leaves at once
     and deriv_kernel, launched behind it, does every cell: bit-identical to GRAPE_DERIV3=0.  Without such a batch the two
     kernels agree to rounding; either way the result matches the C restatement."""

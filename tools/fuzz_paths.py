@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 worst = 0.0
 for case in range(cases):
     N = int(rng.choice([2, 3, 5, 8, 15, 16, 17, 24, 31, 32, 33, 40, 47, 48, 49, 56, 63, 64]))
-    L = int(rng.integers(1, 3)); N_T = int(rng.choice([1, 2, 7, 15, 16, 17, 31, 33, 64, 90])); K = int(rng.integers(1, 7))
+    L = int(rng.choice([1, 1, 2, 2, 3, 4, 6, 8])); N_T = int(rng.choice([1, 2, 7, 15, 16, 17, 31, 33, 64, 90])); K = int(rng.integers(1, 7))
     scale = float(rng.choice([0.05, 0.4, 1.0, 1.3, 2.2, 5.0]))
     pr = synth.make_problem(N, L, N_T, K, seed=int(rng.integers(1 << 30)))
     tl = np.concatenate([[0.0], np.cumsum(scale * (0.5 + rng.random(N_T)))])
