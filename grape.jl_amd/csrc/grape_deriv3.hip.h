@@ -13,6 +13,8 @@
 //     131 KB for three matrices at N = 64 -- the full matrices would need 196 KB); a tile below the diagonal is read
 //     transposed from its mirror image, and its conjugation costs nothing: P2 is issued with the negation bit of its left
 //     operand (the BLGP field of v_mfma_f64), P3 takes the difference re - im as left operand.  Pass 2 needs H^dagger = H: the same tiles.
+//     A general (non-Hermitian) drift H0_k beside Hermitian control operators -- effective Hamiltonians with decay -- is
+//     stored with all its tiles (H0G); pass 2 then reads EVERY tile of it the mirrored way.
 //   * k loops: matrix instructions, LDS reads and ONE vector addition per left operand (the operand sum of the 3M scheme;
 //     a third LDS plane does not fit).
 // Everything else (stopping rule, parked terms u_a, order of the additions within a cell) is deriv2_kernel's.
@@ -46,8 +48,13 @@ __device__ __forceinline__ void d3_finish(D3Vec<NT> &) {}
 // v_mfma_f64 reads its BLGP field as negation bits of (A, B, C): c - a b without a vector instruction
 #define MFMA64_NEGA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 1)
 
-// q (re, im) = M v for the Hermitian matrix M whose upper tiles are at `mat` (LDS)
-template <int NT>
+// storage of a matrix in LDS and the way a product reads it
+enum { D3_HERM = 0,      // Hermitian matrix, upper tiles: M v (tiles below the diagonal from their mirror images)
+       D3_FULL = 1,      // general matrix, all NT x NT tiles row by row: M v
+       D3_FULL_ADJ = 2   // ... : M^dagger v (every tile from its transposed position, conjugated)
+};
+// q (re, im) = M v (or M^dagger v) for the matrix at `mat` (LDS)
+template <int NT, int MODE = D3_HERM>
 __device__ __forceinline__ void d3_product(Strip<NT> &q, const double *mat, const D3Vec<NT> &v, const int lane) {
     using LY = D3Lds<NT>;
     typedef const double __attribute__((address_space(3))) *lds_cptr;
@@ -55,11 +62,14 @@ __device__ __forceinline__ void d3_product(Strip<NT> &q, const double *mat, cons
     // per-lane bases of a fragment: direct tile element [m][4 r + kq], mirrored tile element [4 r + kq][m]
     lds_cptr bd = (lds_cptr)(mat + (lane & 15) * LDT + (lane >> 4));
     lds_cptr bm = (lds_cptr)(mat + (lane >> 4) * LDT + (lane & 15));
+    // is the fragment of (row tile rt, k tile kt) read directly, or transposed and conjugated from tile (kt, rt)?
+    auto direct = [](int rt, int kt) constexpr { return MODE == D3_FULL ? true : MODE == D3_FULL_ADJ ? false : rt <= kt; };
+    auto tile_of = [](int ti, int tj) constexpr { return MODE == D3_HERM ? LY::tile(ti, tj) : ti * NT + tj; };
     auto frag_re = [&](int rt, int kt, int r) __attribute__((always_inline)) -> double {
-        return rt <= kt ? bd[(LY::tile(rt, kt) * 2) * TILE + 4 * r] : bm[(LY::tile(kt, rt) * 2) * TILE + 4 * r * LDT];
+        return direct(rt, kt) ? bd[(tile_of(rt, kt) * 2) * TILE + 4 * r] : bm[(tile_of(kt, rt) * 2) * TILE + 4 * r * LDT];
     };
     auto frag_im = [&](int rt, int kt, int r) __attribute__((always_inline)) -> double {   // (mirrored: the stored value, sign handled below)
-        return rt <= kt ? bd[(LY::tile(rt, kt) * 2 + 1) * TILE + 4 * r] : bm[(LY::tile(kt, rt) * 2 + 1) * TILE + 4 * r * LDT];
+        return direct(rt, kt) ? bd[(tile_of(rt, kt) * 2 + 1) * TILE + 4 * r] : bm[(tile_of(kt, rt) * 2 + 1) * TILE + 4 * r * LDT];
     };
     d4 p1[NT], p2[NT], p3[NT];
 #pragma unroll
@@ -76,7 +86,7 @@ __device__ __forceinline__ void d3_product(Strip<NT> &q, const double *mat, cons
             const double bre = v.re[kt][r], bim = v.im[kt][r], bsm = bre + bim;
             double as[NT];
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) as[rt] = rt <= kt ? are[rt] + aim[rt] : are[rt] - aim[rt];
+            for (int rt = 0; rt < NT; ++rt) as[rt] = direct(rt, kt) ? are[rt] + aim[rt] : are[rt] - aim[rt];
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) p1[rt] = MFMA64(are[rt], bre, p1[rt]);
             __builtin_amdgcn_sched_barrier(0);
@@ -86,7 +96,7 @@ __device__ __forceinline__ void d3_product(Strip<NT> &q, const double *mat, cons
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rt = 0; rt < NT; ++rt) p2[rt] = rt <= kt ? MFMA64(aim[rt], bim, p2[rt]) : MFMA64_NEGA(aim[rt], bim, p2[rt]);
+            for (int rt = 0; rt < NT; ++rt) p2[rt] = direct(rt, kt) ? MFMA64(aim[rt], bim, p2[rt]) : MFMA64_NEGA(aim[rt], bim, p2[rt]);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
 #pragma unroll
@@ -105,10 +115,13 @@ __device__ __forceinline__ void d3_product(Strip<NT> &q, const double *mat, cons
     }
 }
 
-template <int NT, int LMAX>
+// H0G: the drift H0_k is a general matrix (effective non-Hermitian Hamiltonians: decay terms) while the control operators
+// are Hermitian -- H0_k is stored with all its tiles, pass 1 reads it directly and pass 2 as its adjoint
+template <int NT, int LMAX, bool H0G = false>
 __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
     using LY = D3Lds<NT>;
     constexpr int NP = 16 * NT;
+    constexpr int H0SZ = H0G ? NT * NT * 2 * LY::TILE : LY::MAT;   // doubles of the drift in LDS; control l follows at H0SZ + l MAT
     extern __shared__ __attribute__((aligned(16))) double d3sm[];   // [1 + LMAX][NTILE][2][16][17]
     const Deriv2Args &a = g.d;
     if (g.skip_if_flagged && a.flags[3] != 0) return;   // (uniform)
@@ -132,9 +145,13 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                    for (int tj = ti; tj < NT; ++tj) {
+                    for (int tj = 0; tj < NT; ++tj) {
+                        const bool full = H0G && m == 0;
+                        if (tj < ti && !full) continue;
                         const size_t o = (size_t)(16 * ti + row) * NP + 16 * tj + col;
-                        double *dst = d3sm + (size_t)m * LY::MAT + (size_t)LY::tile(ti, tj) * 2 * LY::TILE + row * LY::LDT + col;
+                        const int q_ = full ? ti * NT + tj : LY::tile(ti, tj);
+                        double *dst = d3sm + (m == 0 ? (size_t)0 : (size_t)H0SZ + (size_t)(m - 1) * LY::MAT) + (size_t)q_ * 2 * LY::TILE
+                                      + row * LY::LDT + col;
                         dst[0] = src[o];
                         dst[LY::TILE] = src[pp + o];
                     }
@@ -155,13 +172,16 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
                 e[l] = l < L ? a.eps[(size_t)l * a.N_T + nc] * sh[l] : 0.;
             }
             // H v = H0 v + sum_l e_l mu_l v, one matrix at a time; `each(l, q)` sees mu_l v before it is folded in
-            auto apply = [&](const D3Vec<NT> &v, Strip<NT> &sum, auto each) __attribute__((always_inline)) {
-                d3_product<NT>(sum, d3sm, v, lane);
+            // (adj: pass 2 applies H^dagger -- the same tiles for Hermitian operators, the adjoint reading of a general drift)
+            auto apply = [&](const D3Vec<NT> &v, Strip<NT> &sum, auto each, auto adj) __attribute__((always_inline)) {
+                if constexpr (!H0G) d3_product<NT, D3_HERM>(sum, d3sm, v, lane);
+                else if constexpr (decltype(adj)::value) d3_product<NT, D3_FULL_ADJ>(sum, d3sm, v, lane);
+                else d3_product<NT, D3_FULL>(sum, d3sm, v, lane);
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) {
                     if (l < L) {
                         Strip<NT> q;
-                        d3_product<NT>(q, d3sm + (size_t)(1 + l) * LY::MAT, v, lane);
+                        d3_product<NT, D3_HERM>(q, d3sm + (size_t)H0SZ + (size_t)l * LY::MAT, v, lane);
                         each(l, q);
 #pragma unroll
                         for (int t = 0; t < NT; ++t) { sum.re[t] += e[l] * q.re[t]; sum.im[t] += e[l] * q.im[t]; }
@@ -184,7 +204,7 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
             int M = 0, converged = 0;
             for (int m = 1; m <= mcap; ++m) {   // forms u_m
                 Strip<NT> sum;
-                apply(v, sum, [](int, const Strip<NT> &) {});
+                apply(v, sum, [](int, const Strip<NT> &) {}, std::false_type());
                 const double sfac = dt / (double)m;
                 double nn = 0.;
 #pragma unroll
@@ -243,7 +263,7 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
 #pragma unroll
                     for (int ll = 0; ll < LMAX; ++ll)
                         if (ll == l) { dr[ll] += inv * sr; di[ll] += inv * si; }
-                });
+                }, std::true_type());
                 if (aa > 0) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {   // chi + (i s)(x + i y) = chi - s y + i s x

@@ -45,6 +45,7 @@ struct grape_handle {
     // one wave per batch (grape_deriv3.hip.h; Hermitian operators, 32 < N <= 64, L <= 2; GRAPE_DERIV3=0: off)
     double *d_park3 = nullptr;
     int deriv3_blocks = 0, deriv3_wpt = 0;
+    bool deriv3_h0g = false;     // general drift beside Hermitian control operators (all tiles of H0_k in LDS)
     int deriv2 = 0, deriv2_maxm = 0;
     bool deriv_stream = false;   // GRAPE_DERIV_STREAM=1: matrix-at-a-time products in deriv2_kernel for 3-4 controls as well
     bool deriv_stream_never = false;   // GRAPE_DERIV_STREAM=0: the all-at-once form for more than four controls too (A/B timing)
@@ -69,6 +70,7 @@ struct grape_handle {
     // propagators U_cn; KC == K (d_cls == nullptr) for ensembles of distinct generators
     int KC = 0;
     bool herm = false;           // all generators Hermitian: A = -i dt H is skew-Hermitian (expm uses the symmetry)
+    bool herm_ctrl = false;      // every control operator is Hermitian (the drift may not be)
     bool t18 = false;            // inverse-free polynomial exponential (grape_t18.hip.h)
     bool t18_small = true;       // ... also for N <= 32 (GRAPE_EXPM_T18_SMALL=0: the Pade kernels there)
     // four-product degree-16 route for Hermitian generators at 16 < N <= 64 (GRAPE_EXPM_T16=0: off).  Cells whose spectral
@@ -214,12 +216,14 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
 // deriv3_kernel keeps the upper 16 x 16 tiles (re, im; stride 17) of H0_k and of the L control operators in LDS
-static bool deriv3_fits(int NT, int L) {
-    const size_t mat = (size_t)(NT * (NT + 1) / 2) * 2 * 16 * 17 * sizeof(double);
+// (general drift: all NT x NT tiles of H0_k, three and four tiles per side and at most two controls)
+static bool deriv3_fits(int NT, int L, bool h0_general = false) {
+    const size_t tile = (size_t)2 * 16 * 17 * sizeof(double), mat = (size_t)(NT * (NT + 1) / 2) * tile;
+    if (h0_general) return NT >= 3 && NT <= 4 && L >= 1 && L <= 2 && (size_t)NT * NT * tile + (size_t)L * mat <= 160 * 1024;
     return L >= 1 && L <= 8 && (size_t)(1 + L) * mat <= 160 * 1024;
 }
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
-                                   int skip_if_flagged, void *stream, int blocks);
+                                   int skip_if_flagged, int h0_general, void *stream, int blocks);
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream);
 #endif
@@ -983,9 +987,10 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                         if (ar != br || ai != -bi) { herm = false; break; }
                     }
             };
-            for (int k = 0; k < p->K && herm; ++k) is_herm(p->H0 + (size_t)k * 2 * p->N * p->N);
             const int nhc = (p->hc_per_traj ? p->K : 1) * p->L;
             for (int q = 0; q < nhc && herm; ++q) is_herm(p->Hc + (size_t)q * 2 * p->N * p->N);
+            h->herm_ctrl = herm;   // (the control operators alone: a general drift beside Hermitian controls has its own derivative kernel)
+            for (int k = 0; k < p->K && herm; ++k) is_herm(p->H0 + (size_t)k * 2 * p->N * p->N);
             const char *envh = getenv("GRAPE_NO_HERM");
             h->herm = herm && !(envh && atoi(envh));
             // GRAPE_EXPM_T18=0: Hermitian generators through the order-13 Pade kernel as well (parity reference, A/B timing)
@@ -1122,7 +1127,9 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                 h->deriv2_maxm = 64;
                 CCHK(dmalloc(&h->d_park2, (size_t)h->deriv_blocks * h->deriv2_maxm * 2 * NP * 16));
                 const char *env3 = getenv("GRAPE_DERIV3");
-                if (h->herm && !h->large && !h->series && deriv3_fits(h->NT, L) && !(env3 && atoi(env3) == 0)) {
+                const char *envnh = getenv("GRAPE_NO_HERM");
+                h->deriv3_h0g = !h->herm && h->herm_ctrl && !(envnh && atoi(envnh));
+                if ((h->herm || h->deriv3_h0g) && !h->large && !h->series && deriv3_fits(h->NT, L, h->deriv3_h0g) && !(env3 && atoi(env3) == 0)) {
                     // workgroups per trajectory: as many as it takes to put a workgroup on every CU, at most one per four batches
                     const int bpk = (N_T + 15) / 16;
                     h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
@@ -1603,7 +1610,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
 #endif
         if (h->d_park3 && !d2.gpark) {
             d2.park = h->d_park3;
-            e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, (void *)s, h->deriv3_blocks);
+            e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, h->deriv3_h0g ? 1 : 0, (void *)s, h->deriv3_blocks);
         } else
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);
     } else if (h->NP >= 48) {
@@ -1640,7 +1647,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
                 hipLaunchKernelGGL(deriv_flag_kernel, dim3((fa.nbatch_total + 255) / 256), dim3(256), 0, s, fa);
                 HIPCHK(h, hipGetLastError());
             }
-            HIPCHK(h, (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, sub ? 1 : 0, (void *)s,
+            HIPCHK(h, (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, sub ? 1 : 0, 0, (void *)s,
                                                       h->deriv3_blocks));
             da.only_if = sub ? h->d_flags + 3 : nullptr;
         }

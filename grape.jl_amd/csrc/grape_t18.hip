@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 namespace {
 #include "grape_t18.hip.h"
 #include "grape_deriv3.hip.h"
@@ -27,26 +28,27 @@ hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
     hipLaunchKernelGGL((expm_t18_kernel<NT, SYM, CHEB, T16>), dim3(blocks), dim3(NT * 64), lds, s, a);
     return hipGetLastError();
 }
-template <int NT, int LMAX>
+template <int NT, int LMAX, bool H0G = false>
 hipError_t launch_d3(const Deriv3Args &a, hipStream_t s, int blocks) {
     static size_t lds_set[64] = {0};
-    const size_t lds = sizeof(double) * (size_t)(1 + a.d.L) * D3Lds<NT>::MAT;   // the operators actually present
+    // the operators actually present (a general drift with all its tiles)
+    const size_t lds = sizeof(double) * ((H0G ? (size_t)NT * NT * 2 * D3Lds<NT>::TILE : (size_t)D3Lds<NT>::MAT) + (size_t)a.d.L * D3Lds<NT>::MAT);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     int dev = 0;
     hipGetDevice(&dev);
     if (lds_set[dev & 63] < lds) {
-        hipError_t e = hipFuncSetAttribute((const void *)deriv3_kernel<NT, LMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)deriv3_kernel<NT, LMAX, H0G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_set[dev & 63] = lds;
     }
-    hipLaunchKernelGGL((deriv3_kernel<NT, LMAX>), dim3(blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((deriv3_kernel<NT, LMAX, H0G>), dim3(blocks), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
 
 // derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators whose upper tiles fit the LDS
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
-                                   int skip_if_flagged, void *stream, int blocks) {
+                                   int skip_if_flagged, int h0_general, void *stream, int blocks) {
     if (d2size != sizeof(Deriv2Args)) return (int)hipErrorInvalidValue;
     Deriv3Args a;
     memcpy(&a.d, d2args, sizeof(a.d));
@@ -54,6 +56,12 @@ extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, co
     hipStream_t s = (hipStream_t)stream;
     const int L = a.d.L;
     if (L < 1 || L > 8) return (int)hipErrorInvalidValue;
+    if (h0_general) {   // general drift, Hermitian controls: three and four tiles per side, up to two controls
+        if (L > 2) return (int)hipErrorInvalidValue;
+        if (NT == 3) return (int)(L == 1 ? launch_d3<3, 1, true>(a, s, blocks) : launch_d3<3, 2, true>(a, s, blocks));
+        if (NT == 4) return (int)(L == 1 ? launch_d3<4, 1, true>(a, s, blocks) : launch_d3<4, 2, true>(a, s, blocks));
+        return (int)hipErrorInvalidValue;
+    }
     // more than two controls where the operators still fit the LDS: N <= 32 up to eight, N <= 48 up to five
 #define D3_CASES(NT_)                                                                                                   \
     if (NT == NT_) {                                                                                                    \

@@ -841,3 +841,34 @@ def test_small_sizes_one_wave_per_batch_and_the_hand_over_of_sub_stepped_series(
             assert np.abs(res["d3"][1] - res["old"][1]).max() <= 1e-13 * max(np.abs(res["old"][1]).max(), 1e-3)
         Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:])
         assert abs(res["d3"][0] - Jr) <= TOL_J and np.abs(res["d3"][1] - Gr).max() <= tol_G(Gr)
+
+
+@pytest.mark.parametrize("N,L,N_T,K", [(64, 2, 100, 3), (48, 1, 75, 5), (44, 2, 33, 2)])
+def test_general_drift_with_hermitian_controls_one_wave_per_batch(g, ref, N, L, N_T, K, monkeypatch):
+    """A non-Hermitian drift H0_k (effective Hamiltonian with decay) beside Hermitian control operators: deriv3_kernel keeps
+    ALL tiles of H0_k in LDS, reads them directly in pass 1 and as the adjoint -- every tile transposed, conjugated through
+    the negation bit of the matrix instruction -- in pass 2 (grape_deriv3.hip.h, H0G).  Against deriv2_kernel
+    (GRAPE_DERIV3=0) and the C restatement."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=5100 + N, hermitian=False)
+    tl = pr["tlist"] * 0.7
+    args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
+    res = {}
+    for name, env in (("d3", {}), ("d2", {"GRAPE_DERIV3": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with g.GrapeHip(*args) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            res[name] = (J, G.copy(), h.work()["deriv_orders"])
+        for k in env:
+            monkeypatch.delenv(k)
+    assert res["d3"][0] == res["d2"][0] and res["d3"][2] == res["d2"][2] > 0
+    assert np.abs(res["d3"][1] - res["d2"][1]).max() <= 1e-13 * max(np.abs(res["d2"][1]).max(), 1e-3)
+    ns = 12
+    xs = pr["pulsevals"].reshape(L, N_T)[:, :ns].reshape(-1)
+    with g.GrapeHip(pr["H0"], pr["Hc"], tl[: ns + 1], pr["psi0"], pr["target"], pr["weights"]) as hs:
+        Js, Gs, taus = hs.eval(xs)
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], tl[: ns + 1], xs, pr["psi0"], pr["target"], pr["weights"],
+                                gradient_method=ref.TAYLOR)
+    assert abs(Js - Jr) <= TOL_J * max(1.0, abs(Jr)) and np.abs(taus - taur).max() <= TOL_TAU * max(1.0, np.abs(taur).max())
+    assert np.abs(Gs - Gr).max() <= tol_G(Gr)
