@@ -82,6 +82,7 @@ struct grape_handle {
     int t16_hold = 0;
     long t16_tried = 0, t16_fell = 0;   // of the last evaluation that tried
     int *d_celllist = nullptr;          // [KC * N_T] the listed cells (counter: d_flags[4])
+    double *d_Sf = nullptr;             // [N_T][2][NP*NP] summed control operators of every time step (polynomial kernel, L > 2)
     // diagnostic switches, read ONCE in grape_create (never in the evaluation path: getenv is not thread-safe against setenv)
     bool expm_persist = true;    // GRAPE_EXPM_PERSIST=0: one workgroup per cell instead of the persistent Pade kernel
     int expm_lds_pad_kb = 0;     // GRAPE_EXPM_LDS_PAD: extra dynamic LDS of the Pade kernels (fewer cells per CU)
@@ -873,7 +874,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_Sf, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -1270,6 +1271,9 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     h->d_stats = (unsigned long long *)(h->d_G + (size_t)L * N_T + 4);
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
+    // more than two controls shared by all trajectories: the cell fetches H0_k and ONE summed operator S_n (ctrl_sum_kernel)
+    if (h->t18 && !h->large && !h->series && L > 2 && !p->hc_per_traj && (h->NT >= 3 || h->t18_small))
+        CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * NP * NP));
     // (N <= 16 stays with five products: one tile per side is latency-bound -- the kernel gains nothing from the shorter
     // polynomial and the second launch costs 10 us of an evaluation of 0.4 ms; measured at C2: 0.079 -> 0.098 ms)
     if (h->t16 && h->t18 && h->herm && !h->large && !h->series && (h->NT >= 3 || (h->NT == 2 && h->t18_small))) CCHK(dmalloc(&h->d_celllist, (size_t)K * N_T));
@@ -1379,6 +1383,14 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             const int per_cu = h->NT == 1 ? 10 : h->NT == 2 ? 4 : 1;
             const int t18_blocks = 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * per_cu, (ncell + 7) / 8));
             if (h->t18 && (h->NT >= 3 || h->t18_small)) {
+                if (h->d_Sf) {   // S_n = sum_l eps_ln shape_ln H_l for every time step (50 us at C3 with six controls)
+                    CtrlSumArgs ca{};
+                    ca.Hcf = h->d_Hcf; ca.eps = h->d_eps; ca.shape = h->d_shape; ca.Sf = h->d_Sf;
+                    ca.L = h->L; ca.N_T = h->N_T; ca.pp2 = 2 * h->NP * h->NP;
+                    hipLaunchKernelGGL(ctrl_sum_kernel, dim3(h->N_T), dim3(256), 0, s, ca);
+                    HIPCHK(h, hipGetLastError());
+                    ea.Sf = h->d_Sf;
+                }
                 const bool t16 = h->d_celllist && h->t16_live;
                 ea.cell_list = h->d_celllist; ea.listed = 0;
                 // (three tiles per side, four-product variant: 256 registers and 72 KB -- two workgroups per CU)

@@ -69,11 +69,35 @@ struct ExpmArgs {
     // to cell_list (counter: flags[4]); `listed` != 0: this launch works through that list instead of all cells
     int *cell_list;
     int listed;
+    // polynomial kernel, more than two controls shared by all trajectories: S_n = sum_l eps_ln shape_ln H_l, formed once per
+    // evaluation by ctrl_sum_kernel ([N_T][2][NP*NP], planar like Hcf) -- the cell then fetches H0_k and S_n, whatever L
+    const double *Sf;
 #ifdef GRAPE_DIAG
     int ablate;  // diagnostic builds only (tools/ablate.sh): bit0 skip invert16, bit1 skip solve
     unsigned long long *stamps;  // [nblocks][16] s_memtime at phase boundaries (diagnostic builds only)
 #endif
 };
+
+// S_n = sum_l eps_ln shape_ln H_l for every time step (see ExpmArgs::Sf): one workgroup per step
+struct CtrlSumArgs {
+    const double *Hcf, *eps, *shape;
+    double *Sf;
+    int L, N_T, pp2;   // pp2 = 2 NP^2 doubles per operator
+};
+__global__ void __launch_bounds__(256) ctrl_sum_kernel(CtrlSumArgs a) {
+    const int n = blockIdx.x;
+    double e[8];
+    for (int l = 0; l < a.L; ++l) e[l] = a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0);
+    double2 *dst = (double2 *)(a.Sf + (size_t)n * a.pp2);
+    for (int i = threadIdx.x; i < a.pp2 / 2; i += blockDim.x) {
+        double2 acc = make_double2(0., 0.);
+        for (int l = 0; l < a.L; ++l) {
+            const double2 h = ((const double2 *)(a.Hcf + (size_t)l * a.pp2))[i];
+            acc.x = fma(e[l], h.x, acc.x); acc.y = fma(e[l], h.y, acc.y);
+        }
+        dst[i] = acc;
+    }
+}
 
 // A column strip of an NP x NP complex matrix held by one wave in MFMA C/D layout:
 // lane l holds rows 16*t + 4*r + (l>>4) (t = row tile, r = register) of column 16*w + (l&15).

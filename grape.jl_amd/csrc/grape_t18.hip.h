@@ -321,8 +321,10 @@ struct T18FormA {
         const int kc = cell / a.N_T;
         const int k = a.rep ? a.rep[kc] : kc;
         const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
-        const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
-        const size_t o1 = a.L > 1 ? (size_t)2 * HALF : 0;   // (one control: the same tile again, unused)
+        // (a.Sf: the controls of this time step are already summed -- ONE "control" with coefficient 1, see ExpmArgs)
+        const double2 *hc = a.Sf ? (const double2 *)(a.Sf + (size_t)(cell - kc * a.N_T) * 2 * NP * NP)
+                                 : (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
+        const size_t o1 = (a.L > 1 && !a.Sf) ? (size_t)2 * HALF : 0;   // (one control: the same tile again, unused)
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             int i, j; bool dg;
@@ -338,11 +340,13 @@ struct T18FormA {
         const int k = a.rep ? a.rep[kc] : kc;
         const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
         const double dt = a.dts[n];
+        const int L = a.Sf ? 1 : a.L;
         double e[8];
-        for (int l = 0; l < a.L; ++l) {
+        for (int l = 0; l < L; ++l) {
             e[l] = a.eps[(size_t)l * a.N_T + n];
             if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
         }
+        if (a.Sf) e[0] = 1.0;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             int i, j; bool dg;
@@ -350,12 +354,12 @@ struct T18FormA {
             double2 xr = hr[u], xi = hi[u];
             xr.x = fma(e[0], c0r[u].x, xr.x); xr.y = fma(e[0], c0r[u].y, xr.y);
             xi.x = fma(e[0], c0i[u].x, xi.x); xi.y = fma(e[0], c0i[u].y, xi.y);
-            if (a.L > 1) {
+            if (L > 1) {
                 xr.x = fma(e[1], c1r[u].x, xr.x); xr.y = fma(e[1], c1r[u].y, xr.y);
                 xi.x = fma(e[1], c1i[u].x, xi.x); xi.y = fma(e[1], c1i[u].y, xi.y);
             }
             const int off = (i * NP + j) >> 1;
-            for (int l = 2; l < a.L; ++l) {   // (more than two controls: fetched here)
+            for (int l = 2; l < L; ++l) {   // (more than two controls, per trajectory: fetched here)
                 const double2 cr = hc[(size_t)l * 2 * HALF + off], ci = hc[(size_t)l * 2 * HALF + HALF + off];
                 xr.x = fma(e[l], cr.x, xr.x); xr.y = fma(e[l], cr.y, xr.y);
                 xi.x = fma(e[l], ci.x, xi.x); xi.y = fma(e[l], ci.y, xi.y);
@@ -385,14 +389,17 @@ __device__ __forceinline__ void t18_form_a_general(const ExpmArgs &a, double *R,
     const int kc = cell / a.N_T, n = cell - kc * a.N_T;
     const int k = a.rep ? a.rep[kc] : kc;
     const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
-    const double2 *hc = (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
-    const size_t o1 = a.L > 1 ? (size_t)2 * HALF : 0;
+    const double2 *hc = a.Sf ? (const double2 *)(a.Sf + (size_t)n * 2 * NP * NP)
+                             : (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
+    const int L = a.Sf ? 1 : a.L;   // (summed controls: one "control" with coefficient 1)
+    const size_t o1 = L > 1 ? (size_t)2 * HALF : 0;
     const double dt = a.dts[n];
     double e[8];
-    for (int l = 0; l < a.L; ++l) {
+    for (int l = 0; l < L; ++l) {
         e[l] = a.eps[(size_t)l * a.N_T + n];
         if (a.shape) e[l] *= a.shape[(size_t)l * a.N_T + n];
     }
+    if (a.Sf) e[0] = 1.0;
     for (int b = 0; b < NBATCH; ++b) {
         double2 hr[NU], hi[NU], c0r[NU], c0i[NU], c1r[NU], c1i[NU];
 #pragma unroll
@@ -408,11 +415,11 @@ __device__ __forceinline__ void t18_form_a_general(const ExpmArgs &a, double *R,
             double2 xr = hr[u], xi = hi[u];
             xr.x = fma(e[0], c0r[u].x, xr.x); xr.y = fma(e[0], c0r[u].y, xr.y);
             xi.x = fma(e[0], c0i[u].x, xi.x); xi.y = fma(e[0], c0i[u].y, xi.y);
-            if (a.L > 1) {
+            if (L > 1) {
                 xr.x = fma(e[1], c1r[u].x, xr.x); xr.y = fma(e[1], c1r[u].y, xr.y);
                 xi.x = fma(e[1], c1i[u].x, xi.x); xi.y = fma(e[1], c1i[u].y, xi.y);
             }
-            for (int l = 2; l < a.L; ++l) {
+            for (int l = 2; l < L; ++l) {
                 const double2 cr = hc[(size_t)l * 2 * HALF + off], ci = hc[(size_t)l * 2 * HALF + HALF + off];
                 xr.x = fma(e[l], cr.x, xr.x); xr.y = fma(e[l], cr.y, xr.y);
                 xi.x = fma(e[l], ci.x, xi.x); xi.y = fma(e[l], ci.y, xi.y);
