@@ -771,6 +771,14 @@ def test_four_product_route_is_given_up_while_it_does_not_pay(g, monkeypatch):
     assert w1["t16_cells"] == 0 and w1["t18_cells"] == K * N_T and w2["t16_cells"] == 0 and w2["t18_cells"] == K * N_T
     assert w2["t18_mfma_flop"] < 0.6 * w1["t18_mfma_flop"]          # first evaluation: 3.6 + 4.25 product equivalents per cell
     assert J1 == J2 and np.array_equal(G1, G2) and np.array_equal(tau1, tau2)
+    # ... and is probed again after 32 evaluations: pulses change during an optimisation, the bound may hold later
+    with g.GrapeHip(pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"]) as h:
+        flop = []
+        for _ in range(36):
+            h.eval(pr["pulsevals"])
+            flop.append(h.work()["t18_mfma_flop"])
+    assert flop[0] == w1["t18_mfma_flop"] and all(f == w2["t18_mfma_flop"] for f in flop[1:33])
+    assert flop[33] == flop[0] and flop[34] == flop[1]
 
 
 @pytest.mark.parametrize("N,L,N_T,K", [(64, 2, 300, 4), (48, 1, 203, 3), (60, 2, 129, 9), (40, 2, 64, 130), (48, 4, 100, 3),
