@@ -2208,7 +2208,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
     // The tiles of the next D steps are in flight in a ring of registers with STATIC indices (the time loop is unrolled D
     // times).  A ring that is shifted with register moves makes every step wait for the newest load (s_waitcnt vmcnt(0)):
     // the sweeps then run at one memory latency per step whatever the depth.
-    constexpr int D = NP == 64 ? 2 : 3;   // (measured at the C3 shape: N = 64 2.98 / 3.07 ms with 2 / 3, N = 48 2.30 / 2.14, N = 32 1.33 / 1.24)
+    // (measured at the C3 shape, forward + backward in one launch: N = 64 2.74 / 2.82 / 2.82 ms with 2 / 3 / 4; N = 48 2.04 / 1.91 /
+    // 3.86 ms with 3 / 4 / 6 -- six tiles spill --, N = 32 1.22 / 1.15 / 1.12 ms with 3 / 4 / 6)
+    constexpr int D = NP == 64 ? 2 : NP == 48 ? 4 : 6;
     double2 un[D][RW];
 #pragma unroll
     for (int d = 0; d < D; ++d)
