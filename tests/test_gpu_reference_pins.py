@@ -122,5 +122,7 @@ def test_badly_scaled_nonnormal_generator_no_balancing_deviation(g, ref, monkeyp
         with g.GrapeHip(B[None], Hc, tlist, psi, psi) as h:
             h.eval(np.zeros(1), gradient=False)
             Ub = h.propagator(0, 0)
-        assert np.abs(Ub - exact_b).max() / np.abs(exact_b).max() < lim, t18
+        err_b = np.abs(Ub - exact_b).max() / np.abs(exact_b).max()
+        print("well-scaled matrix, GRAPE_EXPM_T18=%s: relative error %.2e" % (t18, err_b))
+        assert err_b < lim, (t18, err_b)
     monkeypatch.delenv("GRAPE_EXPM_T18")
