@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -56,23 +57,52 @@ def library_path() -> str:
     return os.path.join(_CSRC, _LIBNAME)
 
 
+def build_asm(verbose: bool = False) -> str:
+    """Generate, assemble and wrap the hand-allocated gfx950 kernel (csrc/asm/gen_t16.py): .s -> code object -> an object
+    file that carries the code object as bytes (grape_asm_co_start / _end), linked into the library."""
+    asm_dir = os.path.join(_CSRC, "asm")
+    s_path, o_path = os.path.join(asm_dir, "expm_t16_asm.s"), os.path.join(asm_dir, "expm_t16_asm.o")
+    co_path, emb_s, emb_o = os.path.join(asm_dir, "expm_t16_asm.co"), os.path.join(asm_dir, "asm_embed.S"), os.path.join(asm_dir, "asm_embed.o")
+    gen = subprocess.run([sys.executable, os.path.join(asm_dir, "gen_t16.py"), s_path], capture_output=True, text=True)
+    if verbose or gen.returncode:
+        print(gen.stdout, gen.stderr)
+    if gen.returncode:
+        raise RuntimeError("gen_t16.py failed")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    cmds = [[os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s_path, "-o", o_path],
+            [os.path.join(llvm, "ld.lld"), "-shared", o_path, "-o", co_path]]
+    with open(emb_s, "w") as f:
+        f.write('\t.section .rodata\n\t.globl grape_asm_co_start\n\t.globl grape_asm_co_end\n\t.p2align 12\n'
+                'grape_asm_co_start:\n\t.incbin "expm_t16_asm.co"\ngrape_asm_co_end:\n\t.byte 0\n'
+                '\t.section .note.GNU-stack,"",@progbits\n')
+    cmds.append(["gcc", "-c", "-fPIC", "asm_embed.S", "-o", "asm_embed.o"])
+    for c in cmds:
+        res = subprocess.run(c, capture_output=True, text=True, cwd=asm_dir)
+        if verbose or res.returncode:
+            print(" ".join(c), res.stdout, res.stderr)
+        if res.returncode:
+            raise RuntimeError("assembling the gfx950 kernel failed")
+    return emb_o
+
+
 def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     out = out or library_path()
     srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_t18.hip", "grape_kernels.hip.h", "grape_large.hip.h",
                                              "grape_series.hip.h", "grape_cheby.hip.h", "grape_t18.hip.h", "grape_t18_coeffs.h",
-                                             "grape_deriv3.hip.h")]
+                                             "grape_deriv3.hip.h", os.path.join("asm", "gen_t16.py"), os.path.join("asm", "gcn.py"))]
     hdr = os.path.join(_HERE, "..", "include", "grape_hip.h")
     if (not force and os.path.exists(out)
             and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs + [hdr])):
         return out
-    # two translation units (built side by side): the inverse-free exponential kernel takes a code-generation switch the
-    # rest of the library cannot be compiled with (see grape_t18.hip)
+    # three pieces (built side by side): the inverse-free exponential kernel takes a code-generation switch the rest of
+    # the library cannot be compiled with (see grape_t18.hip); the assembly kernel is generated and assembled (build_asm)
     base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + list(extra_flags)
     objs = [os.path.join(_CSRC, "grape_hip.o"), os.path.join(_CSRC, "grape_t18.o")]
     cmds = [base + ["-c", srcs[0], "-o", objs[0]],
             base + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-c", srcs[1], "-o", objs[1]]]
     procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for c in cmds]
+    objs.append(build_asm(verbose))
     outs = [p.communicate()[0] for p in procs]
     if verbose or any(p.returncode for p in procs):
         print("\n".join(outs))

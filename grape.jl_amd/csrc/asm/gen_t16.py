@@ -1,0 +1,953 @@
+"""gen_t16.py -- generator of expm_t16_asm: the four-product (degree 16) exponential of a cell, Hermitian generators,
+49 <= N <= 64 (four 16-row tiles per side), as hand-allocated gfx950 assembly.
+
+What it replaces: the `exp` inside ExpProp's prop_step! (/root/reference/src/optimize.jl:732) for all K*N_T cells of an
+evaluation; C++ twin with the same arithmetic: expm_t18_kernel<4, true, true, true> (grape_t18.hip.h, expm_t16_cell).
+
+    A2 = A A,  y0 = (c1 A2 + c2 A) A2,  y1 = (y0 + c3 A2 + c4 A)(y0 + c5 A2) + c6 y0 + c7 A2
+    p  = (y1 + c8 A2 + c9 A)(y1 + c10 y0 + c11 A) + c12 y1 + c13 y0 + c14 A2 + c15 A + c16 I        (grape_t18_coeffs.h)
+
+Why assembly: a v_mfma_f64_16x16x4 holds the vector ALU for its 64 cycles and nothing a wave issues to
+the VALU hides under it, so every compiler-inserted register move between the two halves of the 512-register file and
+every address computation is paid in full; the C++ kernel carries ~2000 of them per cell and wave.  Here the register
+file is laid out once:
+
+  vector half   v0..v31    per-lane addresses (LDS operand / strip / exchange, global offsets), fixed for the kernel
+                v32..v159  16 tiles: right operand of the running product (re, im, re+im), temporaries, previous result
+                v160..v255 12 tiles: the accumulators p1, p2, p3 of the 3M scheme -- start values and results are
+                           formed in place by the VALU, no v_accvgpr move ever touches them
+  accum. half   a0..a23    left-operand fragments of the current k-step (ds_read writes them, the MFMA reads them)
+                a24..a255  A (whole cell), parked A2, the next cell's operator tiles (global_load writes them)
+
+and the k loops contain matrix instructions, LDS reads, scalar instructions and (first / last product) global stores and
+loads only.  Every linear combination reads A from the accumulation half with v_accvgpr_read (the only moves left:
+~480 per cell and wave against ~1240 + address arithmetic).
+
+LDS: one region of 64 rows x (re[64] | im[64] | re+im[64] | 2 pad) doubles (all three planes of a row within the 16-bit
+offset field of one address register), two exchange areas, reduction scratch: 132.6 KB.
+
+The instruction list is executed by the emulator of gcn.py against numpy (tests/test_asm_kernel.py) -- this container
+has no GPU -- and the same list is printed as the .s file the library embeds.
+"""
+import os
+import re
+import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gcn import Prog, Reg, V, A, S, VCC, EXEC, Neg, Abs, kernel_text  # noqa: E402
+
+NT = 4
+NP = 64
+LDB = (3 * NP + 2) * 8          # bytes per LDS row: re | im | sm | pad
+PLB = NP * 8                    # byte offset of the next plane inside a row
+TROW = 16 * LDB                 # 16 rows
+PLANES = NP * LDB               # 99328
+E1 = PLANES                     # exchange area of the half sums (4 waves x 512 doubles)
+E2 = E1 + 4 * 512 * 8           # exchange area of the mirrored tiles
+RED = E2 + 4 * 512 * 8          # 16 doubles of reduction scratch
+LDS_BYTES = RED + 16 * 8
+KERNARG = 80
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def t16_coeffs():
+    txt = open(os.path.join(HERE, "..", "grape_t18_coeffs.h")).read()
+    c = {}
+    for m in re.finditer(r"#define\s+T16_(C\d+|THETA)\s+([-+0-9.eE]+)", txt):
+        c[m.group(1)] = float(m.group(2))
+    assert len(c) == 17, c
+    return c
+
+
+def dbits(x):
+    b = struct.unpack("<Q", struct.pack("<d", x))[0]
+    return b & 0xFFFFFFFF, b >> 32
+
+
+# upper block triangle, row by row (T18FormA::tile_i / tile_j)
+TILES = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (3, 3)]
+
+
+class Pool:
+    """tiles of 8 registers"""
+
+    def __init__(self, cls, tiles):
+        self.cls = cls
+        self.free_tiles = sorted(tiles)
+        self.all = set(tiles)
+
+    def alloc(self, n=1, at=None):
+        """n CONSECUTIVE tiles (lowest fit), or the tiles starting at `at`"""
+        if at is not None:
+            want = list(range(at, at + n))
+            assert all(t in self.free_tiles for t in want), (self.cls, at, n, self.free_tiles)
+            for t in want:
+                self.free_tiles.remove(t)
+            return Reg(self.cls, 8 * at, 8 * n)
+        for t in self.free_tiles:
+            if all(t + j in self.free_tiles for j in range(n)):
+                for j in range(n):
+                    self.free_tiles.remove(t + j)
+                return Reg(self.cls, 8 * t, 8 * n)
+        raise RuntimeError(f"pool {self.cls} exhausted ({n} tiles wanted, free: {self.free_tiles})")
+
+    def free(self, reg):
+        assert reg.cls == self.cls and reg.idx % 8 == 0 and reg.n % 8 == 0
+        for t in range(reg.idx // 8, (reg.idx + reg.n) // 8):
+            assert t in self.all and t not in self.free_tiles, (self.cls, t)
+            self.free_tiles.append(t)
+        self.free_tiles.sort()
+
+    def nfree(self):
+        return len(self.free_tiles)
+
+
+class Gen:
+    def __init__(self, name="expm_t16_asm", stop_after=None, diag=False):
+        self.p = Prog(name)
+        self.c = t16_coeffs()
+        self.stop_after = stop_after     # diagnostic builds: leave the cell after phase n (timing by truncation)
+        self.diag = diag
+        # ---- scalar registers ----
+        self.s_H0, self.s_Sf, self.s_dts, self.s_U = S(4, 2), S(6, 2), S(8, 2), S(10, 2)
+        self.s_verdict, self.s_rep = S(12, 2), S(14, 2)
+        self.s_KC, self.s_NT, self.s_nblk = S(16), S(17), S(18)
+        self.s_wave, self.s_idx, self.s_end, self.s_step = S(20), S(21), S(22), S(23)
+        self.s_kc, self.s_n, self.s_cell = S(24), S(25), S(26)          # current cell
+        self.s_nkc, self.s_nn, self.s_ncell = S(27), S(28), S(29)       # next cell (clamped to the current one at the end)
+        self.s_pcell = S(30)
+        self.s_hi = S(31)                                                # wave >> 1
+        self.s_ub = [S(32 + 2 * i, 2) for i in range(4)]                 # U bases of the previous cell, per slot
+        self.s_toff = [S(40 + u) for u in range(5)]                      # byte offsets of this wave pair's operator tiles
+        self.s_hb, self.s_sb = S(46, 2), S(48, 2)                        # H0 / S base of the next cell
+        self.s_t0, self.s_t1 = S(50, 2), S(52, 2)                        # tile bases (rotating)
+        self.s_dt = S(54, 2)
+        self.s_pmask = S(56, 2)                                          # exec of the previous-result stores (0: no previous cell)
+        self.s_tmp = [S(58 + i) for i in range(6)]                       # s58..s63
+        self.s_dmask = [S(64 + 2 * r, 2) for r in range(4)]              # lanes holding a diagonal element in register r of slot 0
+        self.s_c = {i: S(72 + 2 * (i - 1), 2) for i in range(1, 16)}     # c1..c15 at s72..s101
+        self.s_k = S(3)                                                  # representative trajectory of the next cell
+        self.s_save = S(0, 2)                                            # saved exec (s0:1 free after the argument load)
+        # ---- persistent vector registers ----
+        self.v_tid, self.v_lane = V(0), V(1)
+        self.v_AA = [[V(2 + 4 * so + sk) for sk in range(4)] for so in range(4)]
+        self.v_SA = [V(18 + sl) for sl in range(4)]
+        self.v_EW1, self.v_EW2, self.v_ER, self.v_RD = V(22), V(23), V(24), V(25)
+        self.v_UO1, self.v_UO2 = V(26), V(27)
+        self.v_GO, self.v_GOI = V(28), V(29)
+        self.v_CP, self.v_CM = V(30), V(31)
+        self.vp = Pool("v", range(4, 32))      # tiles 4..31 = v32..v255
+        self.ap = Pool("a", range(3, 32))      # tiles 3..31 = a24..a255
+        self.aop = [[A(8 * pl + 2 * so, 2) for so in range(4)] for pl in range(3)]   # [plane][slot]
+        self.QT = list(range(20, 32))          # accumulator tiles (v160..v255)
+        self.UT = 4                            # previous result: tiles 4..11 (v32..v95)
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def ssel(self, dst, a, b):
+        """dst = scc ? a : b for constants (a SALU instruction encodes one literal only)"""
+        inline = lambda x: -16 <= x <= 64
+        if not inline(a) and not inline(b):
+            self.p.salu("s_mov_b32", self.s_tmp[3], a)
+            a = self.s_tmp[3]
+        self.p.salu("s_cselect_b32", dst, a, b)
+
+    def set_exec(self, lo, hi):
+        """exec = hi:lo (scalars or constants), through a scalar pair"""
+        self.p.salu("s_mov_b32", self.s_tmp[4], lo)
+        self.p.salu("s_mov_b32", self.s_tmp[5], hi)
+        self.p.salu("s_mov_b64", EXEC, S(self.s_tmp[4].idx, 2))
+
+    def smov64(self, dst, x):
+        lo, hi = dbits(x)
+        self.p.salu("s_mov_b32", dst.sub(0), lo)
+        self.p.salu("s_mov_b32", dst.sub(1), hi)
+
+    def prologue(self):
+        p = self.p
+        p.s_load(16, S(4, 16), S(0, 2), 0)
+        p.valu("v_and_b32", self.v_tid, 0x3FF, V(0))
+        p.valu("v_and_b32", self.v_lane, 63, self.v_tid)
+        t = self.vp.alloc()                      # temporaries of the prologue
+        vc, vrg, vw, vx, vy, vidx = (t.sub(i) for i in range(6))
+        p.valu("v_lshrrev_b32", vw, 6, self.v_tid)
+        p.v_readfirstlane(self.s_wave, vw)
+        p.salu("s_lshr_b32", self.s_hi, self.s_wave, 1)
+        p.valu("v_and_b32", vc, 15, self.v_lane)
+        p.valu("v_lshrrev_b32", vrg, 4, self.v_lane)
+        # left-operand fragments: lane (i = c, kq = rg) reads row 16 tr + c, column 16 tk + 4 r + kq
+        p.valu("v_mul_u32_u24", vx, LDB, vc)
+        p.valu("v_lshl_add_u32", vx, vrg, 3, vx)                         # c LDB + 8 rg
+        for so in range(4):
+            for sk in range(4):
+                p.salu("s_add_u32", self.s_tmp[0], self.s_wave, so)
+                p.salu("s_and_b32", self.s_tmp[0], self.s_tmp[0], 3)
+                p.salu("s_mul_i32", self.s_tmp[0], self.s_tmp[0], TROW)
+                p.salu("s_add_u32", self.s_tmp[1], self.s_wave, sk)
+                p.salu("s_and_b32", self.s_tmp[1], self.s_tmp[1], 3)
+                p.salu("s_lshl_b32", self.s_tmp[1], self.s_tmp[1], 7)
+                p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], self.s_tmp[1])
+                p.valu("v_add_u32", self.v_AA[so][sk], self.s_tmp[0], vx)
+        # strips (C/D layout): lane (c, rg), slot sl, register r: row 16 ((w + sl) & 3) + 4 r + rg, column 16 w + c
+        p.valu("v_mul_u32_u24", vy, LDB, vrg)
+        p.valu("v_lshl_add_u32", vy, vc, 3, vy)                          # rg LDB + 8 c
+        for sl in range(4):
+            p.salu("s_add_u32", self.s_tmp[0], self.s_wave, sl)
+            p.salu("s_and_b32", self.s_tmp[0], self.s_tmp[0], 3)
+            p.salu("s_mul_i32", self.s_tmp[0], self.s_tmp[0], TROW)
+            p.salu("s_lshl_b32", self.s_tmp[1], self.s_wave, 7)
+            p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], self.s_tmp[1])
+            p.valu("v_add_u32", self.v_SA[sl], self.s_tmp[0], vy)
+        # exchange areas: the writer stores its tile in the READER's register layout (rot_exch_write):
+        # double index ((w + d) & 3) 512 + (16 (c & 3) + rg) 4 + (c >> 2), element r at + 16 r, imaginary parts at + 256
+        p.valu("v_and_b32", vx, 3, vc)
+        p.valu("v_lshl_add_u32", vx, vx, 4, vrg)                         # 16 (c & 3) + rg
+        p.valu("v_lshrrev_b32", vy, 2, vc)
+        p.valu("v_lshl_add_u32", vx, vx, 2, vy)                          # ... * 4 + (c >> 2)
+        p.valu("v_lshlrev_b32", vx, 3, vx)                               # bytes
+        for d, dst, area in ((1, self.v_EW1, E2), (2, self.v_EW2, E1)):
+            p.salu("s_add_u32", self.s_tmp[0], self.s_wave, d)
+            p.salu("s_and_b32", self.s_tmp[0], self.s_tmp[0], 3)
+            p.salu("s_lshl_b32", self.s_tmp[0], self.s_tmp[0], 12)
+            p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], area)
+            p.valu("v_add_u32", dst, self.s_tmp[0], vx)
+        p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 12)
+        p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], E1)
+        p.valu("v_lshlrev_b32", vx, 5, self.v_lane)
+        p.valu("v_add_u32", self.v_ER, self.s_tmp[0], vx)                # E1 + 4096 w + 32 lane
+        p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 3)
+        p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], RED)
+        p.valu("v_mov_b32", self.v_RD, self.s_tmp[0])
+        # result stores: element (16 tb + 4 r + rg, 16 w + c), 16 bytes each, rows of 1024 bytes
+        p.valu("v_lshlrev_b32", vx, 10, vrg)
+        p.valu("v_lshl_add_u32", vx, vc, 4, vx)
+        p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 8)
+        p.valu("v_add_u32", vx, self.s_tmp[0], vx)
+        p.valu("v_add_u32", self.v_UO1, 4096, vx)
+        p.valu("v_add_u32", self.v_UO2, 12288, vx)
+        # operator tiles: element pair idx = tid & 127 of a tile: row idx >> 3, columns 2 (idx & 7), + 1
+        p.valu("v_and_b32", vidx, 127, self.v_tid)
+        p.valu("v_lshrrev_b32", vx, 3, vidx)                             # row
+        p.valu("v_and_b32", vy, 7, vidx)                                 # column pair
+        p.valu("v_lshlrev_b32", self.v_GO, 9, vx)
+        p.valu("v_lshl_add_u32", self.v_GO, vy, 4, self.v_GO)            # (row 64 + 2 cp) 8
+        p.valu("v_add_u32", self.v_GOI, NP * NP * 8, self.v_GO)
+        p.valu("v_mul_u32_u24", self.v_CP, LDB, vx)
+        p.valu("v_lshl_add_u32", self.v_CP, vy, 4, self.v_CP)            # row LDB + 2 cp 8
+        p.valu("v_mul_u32_u24", self.v_CM, 2 * LDB, vy)
+        p.valu("v_lshl_add_u32", self.v_CM, vx, 3, self.v_CM)            # 2 cp LDB + row 8
+        # diagonal elements of slot 0: register r of lane (c, rg) is row 4 r + rg of the diagonal tile
+        for r in range(4):
+            p.valu("v_add_u32", vx, 4 * r, vrg)
+            p.v_cmp("v_cmp_eq_u32", self.s_dmask[r], vx, vc)
+        self.vp.free(t)
+        # tiles of this wave pair (waves 0, 1: tiles 2u; waves 2, 3: tiles 2u + 1)
+        p.s_cmp("s_cmp_eq_u32", self.s_hi, 0)
+        for u in range(5):
+            (i0, j0), (i1, j1) = TILES[2 * u], TILES[2 * u + 1]
+            self.ssel(self.s_toff[u], (16 * i0 * NP + 16 * j0) * 8, (16 * i1 * NP + 16 * j1) * 8)
+        for i in range(1, 16):
+            self.smov64(self.s_c[i], self.c[f"C{i}"])
+        p.s_waitcnt(lgkm=0)
+        # cells of this workgroup: XCD x = wg & 7 walks [lo, hi) of the cells with stride nblk / 8 (expm_t18_kernel)
+        wg = S(2)
+        t0, t1, t2 = self.s_tmp[0], self.s_tmp[1], self.s_tmp[2]
+        p.salu("s_mul_i32", t2, self.s_KC, self.s_NT)                    # ncell
+        p.salu("s_and_b32", t0, wg, 7)
+        p.salu("s_mul_i32", t1, t0, t2)
+        p.salu("s_lshr_b32", t1, t1, 3)                                  # lo
+        p.salu("s_add_u32", t0, t0, 1)
+        p.salu("s_mul_i32", t0, t0, t2)
+        p.salu("s_lshr_b32", self.s_end, t0, 3)                          # hi
+        p.salu("s_lshr_b32", self.s_step, self.s_nblk, 3)
+        p.salu("s_lshr_b32", t0, wg, 3)
+        p.salu("s_add_u32", self.s_idx, t1, t0)
+        p.s_cmp("s_cmp_ge_u32", self.s_idx, self.s_end)
+        p.s_branch("s_cbranch_scc1", "L_end")
+        # (kc, n) of the first cell: restoring division, 32 steps
+        q, r, i = self.s_kc, self.s_n, t0
+        p.salu("s_mov_b32", q, 0)
+        p.salu("s_mov_b32", r, 0)
+        p.salu("s_mov_b32", i, 31)
+        p.label("L_div")
+        p.salu("s_lshl_b32", r, r, 1)
+        p.salu("s_lshr_b32", t1, self.s_idx, i)
+        p.salu("s_and_b32", t1, t1, 1)
+        p.salu("s_or_b32", r, r, t1)
+        p.s_cmp("s_cmp_ge_u32", r, self.s_NT)
+        p.s_branch("s_cbranch_scc0", "L_div_skip")
+        p.salu("s_sub_u32", r, r, self.s_NT)
+        p.salu("s_lshl_b32", t1, 1, i)
+        p.salu("s_or_b32", q, q, t1)
+        p.label("L_div_skip")
+        p.salu("s_sub_u32", i, i, 1)
+        p.s_cmp("s_cmp_ge_i32", i, 0)
+        p.s_branch("s_cbranch_scc1", "L_div")
+        p.salu("s_mov_b32", self.s_cell, self.s_idx)
+        p.salu("s_mov_b64", self.s_pmask, 0)
+
+    # ---- scalars of a cell ----
+    def cell_bases(self, kc, n):
+        """H0 / S bases and dt of cell (kc, n) -> s_hb, s_sb, s_dt (three scalar loads; caller waits)"""
+        p = self.p
+        t0, t1 = self.s_tmp[0], self.s_tmp[1]
+        # k = rep ? rep[kc] : kc
+        p.salu("s_mov_b32", self.s_k, kc)
+        p.s_cmp("s_cmp_lg_u64", self.s_rep, 0)
+        lab = f"L_norep_{len(p.ins)}"
+        p.s_branch("s_cbranch_scc0", lab)
+        p.salu("s_lshl_b32", t0, kc, 2)
+        p.s_load(1, self.s_k, self.s_rep, t0)
+        p.label(lab)
+        p.salu("s_lshl_b32", t0, n, 3)
+        p.s_load(2, self.s_dt, self.s_dts, t0)
+        p.salu("s_lshl_b32", t0, n, 16)                                  # n * 2 NP^2 * 8 = n << 16
+        p.salu("s_lshr_b32", t1, n, 16)
+        p.salu("s_add_u32", self.s_sb.sub(0), self.s_Sf.sub(0), t0)
+        p.salu("s_addc_u32", self.s_sb.sub(1), self.s_Sf.sub(1), t1)
+        p.s_waitcnt(lgkm=0)
+        p.salu("s_lshl_b32", t0, self.s_k, 16)
+        p.salu("s_lshr_b32", t1, self.s_k, 16)
+        p.salu("s_add_u32", self.s_hb.sub(0), self.s_H0.sub(0), t0)
+        p.salu("s_addc_u32", self.s_hb.sub(1), self.s_H0.sub(1), t1)
+
+    def fetch(self, u, dst):
+        """operator tiles u of the cell whose bases are in s_hb / s_sb: H0 re, H0 im, S re, S im (4 registers each)"""
+        p = self.p
+        p.salu("s_add_u32", self.s_t0.sub(0), self.s_hb.sub(0), self.s_toff[u])
+        p.salu("s_addc_u32", self.s_t0.sub(1), self.s_hb.sub(1), 0)
+        p.salu("s_add_u32", self.s_t1.sub(0), self.s_sb.sub(0), self.s_toff[u])
+        p.salu("s_addc_u32", self.s_t1.sub(1), self.s_sb.sub(1), 0)
+        p.global_load(4, dst.sub(0, 4), self.v_GO, self.s_t0)
+        p.global_load(4, dst.sub(4, 4), self.v_GOI, self.s_t0)
+        p.global_load(4, dst.sub(8, 4), self.v_GO, self.s_t1)
+        p.global_load(4, dst.sub(12, 4), self.v_GOI, self.s_t1)
+
+    def commit(self, pf):
+        """A = -i dt (H0 + S) of the fetched tiles (pf[u]: 16 registers, either half of the file) into the three planes,
+        both triangles (T18FormA::commit with the summed controls: xr = fma(1, s, h) = h + s)"""
+        p = self.p
+        ta, tb, tc = self.vp.alloc(), self.vp.alloc(), self.vp.alloc()
+        for u in range(5):
+            src = pf[u]
+            hr, hi_, sr, si = ta.sub(0, 4), ta.sub(4, 4), tb.sub(0, 4), tb.sub(4, 4)
+            for j, dst in enumerate((hr, hi_, sr, si)):
+                for e in range(4):
+                    p.valu("v_accvgpr_read_b32" if src.cls == "a" else "v_mov_b32", dst.sub(e), src.sub(4 * j + e))
+            ar, ai, sm = tc.sub(0, 4), hr, hi_            # results: ar in fresh registers, ai / sm over the inputs
+            xr0, xr1, xi0, xi1 = sr.d(0), sr.d(1), si.d(0), si.d(1)
+            p.valu("v_add_f64", xr0, hr.d(0), sr.d(0))
+            p.valu("v_add_f64", xr1, hr.d(1), sr.d(1))
+            p.valu("v_add_f64", xi0, hi_.d(0), si.d(0))
+            p.valu("v_add_f64", xi1, hi_.d(1), si.d(1))
+            p.valu("v_mul_f64", ar.d(0), self.s_dt, xi0)
+            p.valu("v_mul_f64", ar.d(1), self.s_dt, xi1)
+            p.valu("v_mul_f64", ai.d(0), Neg(self.s_dt), xr0)
+            p.valu("v_mul_f64", ai.d(1), Neg(self.s_dt), xr1)
+            p.valu("v_add_f64", sm.d(0), ar.d(0), ai.d(0))
+            p.valu("v_add_f64", sm.d(1), ar.d(1), ai.d(1))
+            # addresses of this tile: scalar part by wave pair
+            (i0, j0), (i1, j1) = TILES[2 * u], TILES[2 * u + 1]
+            va, vm = tc.sub(4), tc.sub(5)
+            p.s_cmp("s_cmp_eq_u32", self.s_hi, 0)
+            self.ssel(self.s_tmp[0], 16 * i0 * LDB + 16 * j0 * 8, 16 * i1 * LDB + 16 * j1 * 8)
+            self.ssel(self.s_tmp[1], 16 * j0 * LDB + 16 * i0 * 8, 16 * j1 * LDB + 16 * i1 * 8)
+            p.valu("v_add_u32", va, self.s_tmp[0], self.v_CP)
+            p.valu("v_add_u32", vm, self.s_tmp[1], self.v_CM)
+            p.ds_write(128, va, ar, 0)
+            p.ds_write(128, va, ai, PLB)
+            p.ds_write(128, va, sm, 2 * PLB)
+            # mirrored tile a_ji = -conj(a_ij): re -> -ar, im -> ai, sum -> ai - ar; not for diagonal tiles
+            d0, d1 = i0 == j0, i1 == j1
+            if not (d0 and d1):
+                nar, ms = sr, si
+                p.valu("v_mul_f64", nar.d(0), ar.d(0), -1.0)
+                p.valu("v_mul_f64", nar.d(1), ar.d(1), -1.0)
+                p.valu("v_add_f64", ms.d(0), ai.d(0), Neg(ar.d(0)))
+                p.valu("v_add_f64", ms.d(1), ai.d(1), Neg(ar.d(1)))
+                if d0 or d1:
+                    # one of the two wave pairs holds a diagonal tile: its lanes sit this out
+                    p.salu("s_mov_b64", self.s_save, EXEC)
+                    p.s_cmp("s_cmp_eq_u32", self.s_hi, 0 if d0 else 1)
+                    lab = f"L_mirror_{u}_{len(p.ins)}"
+                    p.s_branch("s_cbranch_scc1", lab)
+                for e in range(2):
+                    p.ds_write(64, vm, nar.d(e), e * LDB)
+                    p.ds_write(64, vm, ai.d(e), e * LDB + PLB)
+                    p.ds_write(64, vm, ms.d(e), e * LDB + 2 * PLB)
+                if d0 or d1:
+                    p.label(lab)
+        for t in (ta, tb, tc):
+            self.vp.free(t)
+
+    # ---- strips ----
+    def load_strip_A(self):
+        """A from the planes into the accumulation half: re, im, re + im, four slots each (right operand of A2 = A A)"""
+        p = self.p
+        self.As_re, self.As_im, self.As_sm = self.ap.alloc(4), self.ap.alloc(4), self.ap.alloc(4)
+        for sl in range(4):
+            for r in range(4):
+                for pl, S_ in enumerate((self.As_re, self.As_im, self.As_sm)):
+                    p.ds_read(64, S_.sub(8 * sl, 8).d(r), self.v_SA[sl], 4 * r * LDB + pl * PLB)
+
+    def product(self, Q, B, half_last=False, init=None, hook=None):
+        """Q[so] = (p1, p2, p3) += X B over the rotated k order; X in the planes, B = (re, im, sm) tile lists by slot.
+        init: set of (so, j) accumulators that hold a start value (the others start from the literal 0)."""
+        p = self.p
+        NS = len(Q)
+        started = set(init or ())
+
+        def nslots(sk):
+            return NS - 1 if (half_last and 2 * sk >= NT) else NS
+
+        def rd(pl, so, sk, r):
+            p.ds_read(64, self.aop[pl][so], self.v_AA[so][sk], 32 * r + pl * PLB)
+
+        for pl in range(3):
+            for so in range(NS):
+                rd(pl, so, 0, 0)
+        for sk in range(4):
+            for r in range(4):
+                if hook:
+                    hook(sk, r)
+                ns = nslots(sk)
+                more = not (sk == 3 and r == 3)
+                nsk, nr = (sk, r + 1) if r < 3 else (sk + 1, 0)
+                nsn = nslots(nsk) if more else 0
+                for pl in range(3):
+                    for so in range(ns):
+                        acc = Q[so][pl]
+                        c = acc if (so, pl) in started else 0
+                        started.add((so, pl))
+                        p.mfma(acc, self.aop[pl][so], B[pl][sk].d(r), c)
+                    for so in range(nsn):
+                        rd(pl, so, nsk, nr)
+
+    def store_planes(self, sl, r, xr, xi, xs):
+        a = self.v_SA[sl]
+        self.p.ds_write(64, a, xr, 4 * r * LDB)
+        self.p.ds_write(64, a, xi, 4 * r * LDB + PLB)
+        self.p.ds_write(64, a, xs, 4 * r * LDB + 2 * PLB)
+
+    @staticmethod
+    def interleave(streams):
+        """round-robin merge of independent instruction streams (lists of thunks): dependent fp64 instructions of one
+        stream end up len(streams) issue slots apart"""
+        streams = [list(s) for s in streams]
+        while any(streams):
+            for s in streams:
+                if s:
+                    s.pop(0)()
+
+    def acc_read(self, dst, src):
+        """a double from the accumulation half"""
+        self.p.valu("v_accvgpr_read_b32", dst.sub(0), src.sub(0))
+        self.p.valu("v_accvgpr_read_b32", dst.sub(1), src.sub(1))
+
+    def acc_write(self, dst, src):
+        self.p.valu("v_accvgpr_write_b32", dst.sub(0), src.sub(0))
+        self.p.valu("v_accvgpr_write_b32", dst.sub(1), src.sub(1))
+
+    def wave_reduce(self, x, tmp, op):
+        """x (a double per lane) -> reduced over the wave in lane 63 (op: v_add_f64 / v_max_f64); tmp: a free pair"""
+        p = self.p
+        for ctrl, rm in (("quad_perm:[1,0,3,2]", 0xF), ("quad_perm:[2,3,0,1]", 0xF), ("row_half_mirror", 0xF), ("row_mirror", 0xF),
+                         ("row_bcast:15", 0xA), ("row_bcast:31", 0xC)):
+            if rm != 0xF:
+                # lanes outside the row mask keep their own value: adding / maxing 'x op x' must not happen -- give them
+                # the neutral element by copying x first and letting the masked rows overwrite
+                p.valu("v_mov_b32", tmp.sub(0), 0)
+                p.valu("v_mov_b32", tmp.sub(1), 0 if op == "v_add_f64" else 0xFFF00000)   # 0 / -inf
+            p.dpp_mov(tmp.sub(0), x.sub(0), ctrl, row_mask=rm)
+            p.dpp_mov(tmp.sub(1), x.sub(1), ctrl, row_mask=rm)
+            p.valu(op, x, x, tmp)
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def cell(self):
+        p, c = self.p, self.s_c
+        vp, ap = self.vp, self.ap
+        stop = self.stop_after
+        Qt = [[V(8 * self.QT[3 * so + j], 8) for j in range(3)] for so in range(4)]   # Qt[so] = (p1, p2, p3)
+        for t in self.QT:
+            vp.free_tiles.remove(t)
+        Uprev = V(8 * self.UT, 64)
+        for t in range(self.UT, self.UT + 8):
+            vp.free_tiles.remove(t)
+
+        # ================= A2 = A A (Hermitian square: slots 0..2, slot 2 half) + stores of the previous result ==========
+        self.load_strip_A()
+        As = (self.As_re, self.As_im, self.As_sm)
+
+        def hook_store(sk, r):
+            if r != 0:
+                return
+            # slot sk of the previous result: four 16-byte stores per lane (t18_store_u_slot)
+            p.salu("s_mov_b64", self.s_save, EXEC)
+            p.salu("s_mov_b64", EXEC, self.s_pmask)
+            for rr in range(4):
+                p.global_store(4, self.v_UO1 if rr < 2 else self.v_UO2, Uprev.sub(16 * sk + 4 * rr, 4), self.s_ub[sk],
+                               -4096 if rr % 2 == 0 else 0, nt=False)
+            p.salu("s_mov_b64", EXEC, self.s_save)
+
+        B_As = [[S_.sub(8 * sl, 8) for sl in range(4)] for S_ in As]
+        self.product(Qt[:3], B_As, half_last=True, hook=hook_store)
+        ap.free(self.As_sm)
+        vp.free(Uprev)
+        if stop == 1:
+            return self.bail(Qt)
+        # combine slots 0..2; A2 lives in the vector half (right operand of the second product)
+        A2re, A2im, A2sm = [vp.alloc() for _ in range(4)], [vp.alloc() for _ in range(4)], [vp.alloc() for _ in range(4)]
+        streams = []
+        for sl in range(3):
+            for r in range(4):
+                p1, p2, p3 = (Qt[sl][j].d(r) for j in range(3))
+                re_, im_ = A2re[sl].d(r), A2im[sl].d(r)
+                streams.append([lambda re_=re_, p1=p1, p2=p2: p.valu("v_add_f64", re_, p1, Neg(p2)),
+                                lambda im_=im_, p3=p3, p1=p1: p.valu("v_add_f64", im_, p3, Neg(p1)),
+                                lambda im_=im_, p2=p2: p.valu("v_add_f64", im_, im_, Neg(p2))])
+        for g in range(0, len(streams), 4):
+            self.interleave(streams[g:g + 4])
+        # exchange: half sum of slot 2 -> wave w + 2, slot-1 tile -> wave w + 1 (its mirrored slot 3); plain values, the
+        # reader conjugates
+        for r in range(4):
+            p.ds_write(64, self.v_EW2, A2re[2].d(r), 128 * r)
+            p.ds_write(64, self.v_EW2, A2im[2].d(r), 2048 + 128 * r)
+            p.ds_write(64, self.v_EW1, A2re[1].d(r), 128 * r)
+            p.ds_write(64, self.v_EW1, A2im[1].d(r), 2048 + 128 * r)
+        p.s_waitcnt(lgkm=0)
+        p.s_barrier()                                   # (also: everybody is done reading A)
+        txr, txi = vp.alloc(), vp.alloc()
+        for h in range(2):
+            p.ds_read(128, txr.sub(4 * h, 4), self.v_ER, 16 * h)
+            p.ds_read(128, txi.sub(4 * h, 4), self.v_ER, 2048 + 16 * h)
+            p.ds_read(128, A2re[3].sub(4 * h, 4), self.v_ER, (E2 - E1) + 16 * h)
+            p.ds_read(128, A2im[3].sub(4 * h, 4), self.v_ER, (E2 - E1) + 2048 + 16 * h)
+        for r in range(4):
+            p.valu("v_add_f64", A2re[2].d(r), A2re[2].d(r), txr.d(r))
+            p.valu("v_add_f64", A2im[2].d(r), A2im[2].d(r), Neg(txi.d(r)))
+        for r in range(4):
+            p.valu("v_mul_f64", A2im[3].d(r), A2im[3].d(r), -1.0)
+        vp.free(txr)
+        vp.free(txi)
+        # planes <- c1 A2 + c2 A ; A2.sm
+        tt = [vp.alloc(), vp.alloc()]
+        streams = []
+        for sl in range(4):
+            for r in range(4):
+                k = len(streams) % 4
+                asr, asi, xs = tt[k // 2].sub(4 * (k % 2), 4).d(0), tt[k // 2].sub(4 * (k % 2), 4).d(1), A2sm[sl].d(r)
+                # (xr, xi are formed in the registers of the A reads; xs borrows A2.sm's register before A2.sm is formed)
+                a2r, a2i = A2re[sl].d(r), A2im[sl].d(r)
+                ar_, ai_ = self.As_re.sub(8 * sl, 8).d(r), self.As_im.sub(8 * sl, 8).d(r)
+                st = [lambda asr=asr, ar_=ar_: self.acc_read(asr, ar_),
+                      lambda asi=asi, ai_=ai_: self.acc_read(asi, ai_),
+                      lambda asr=asr: p.valu("v_mul_f64", asr, c[2], asr),
+                      lambda asi=asi: p.valu("v_mul_f64", asi, c[2], asi),
+                      lambda asr=asr, a2r=a2r: p.valu("v_fma_f64", asr, c[1], a2r, asr),
+                      lambda asi=asi, a2i=a2i: p.valu("v_fma_f64", asi, c[1], a2i, asi),
+                      lambda xs=xs, asr=asr, asi=asi: p.valu("v_add_f64", xs, asr, asi),
+                      lambda sl=sl, r=r, asr=asr, asi=asi, xs=xs: self.store_planes(sl, r, asr, asi, xs)]
+                streams.append(st)
+        for g in range(0, 16, 4):
+            self.interleave(streams[g:g + 4])
+        for sl in range(4):
+            for r in range(4):
+                p.valu("v_add_f64", A2sm[sl].d(r), A2re[sl].d(r), A2im[sl].d(r))
+        for t in tt:
+            vp.free(t)
+        p.s_waitcnt(lgkm=0)
+        p.s_barrier()
+        if stop == 2:
+            return self.bail(Qt, extra_free=A2re + A2im + A2sm)
+        # ================= y0 = (c1 A2 + c2 A) A2 =====================================================================
+        self.product(Qt, [A2re, A2im, A2sm])
+        for t in A2sm:
+            vp.free(t)
+        if stop == 3:
+            return self.bail(Qt, extra_free=A2re + A2im)
+        # ---- y0 in place (p1 <- re, p3 <- im), sums for the spectral bound ----
+        facc, gacc, cacc = vp.alloc(), vp.alloc(), vp.alloc()        # f0..f3, g0..g3, column sums (4 streams)
+        for acc in (facc, gacc, cacc):
+            for j in range(8):
+                p.valu("v_mov_b32", acc.sub(j), 0)
+        streams = []
+        for sl in range(4):
+            for r in range(4):
+                k = len(streams) % 4
+                p1, p2, p3 = (Qt[sl][j].d(r) for j in range(3))
+                a2r, a2i = A2re[sl].d(r), A2im[sl].d(r)
+                f, g_, cs = facc.d(k), gacc.d(k), cacc.d(k)
+                streams.append([
+                    lambda p3=p3, p1=p1: p.valu("v_add_f64", p3, p3, Neg(p1)),
+                    lambda p1=p1, p2=p2: p.valu("v_add_f64", p1, p1, Neg(p2)),          # y0.re
+                    lambda p3=p3, p2=p2: p.valu("v_add_f64", p3, p3, Neg(p2)),          # y0.im
+                    lambda cs=cs, a2r=a2r: p.valu("v_add_f64", cs, cs, Abs(a2r)),
+                    lambda f=f, p1=p1: p.valu("v_fma_f64", f, p1, p1, f),
+                    lambda g_=g_, a2r=a2r, p1=p1: p.valu("v_fma_f64", g_, a2r, p1, g_),
+                    lambda cs=cs, a2i=a2i: p.valu("v_add_f64", cs, cs, Abs(a2i)),
+                    lambda f=f, p3=p3: p.valu("v_fma_f64", f, p3, p3, f),
+                    lambda g_=g_, a2i=a2i, p3=p3: p.valu("v_fma_f64", g_, a2i, p3, g_)])
+        for g in range(0, 16, 4):
+            self.interleave(streams[g:g + 4])
+        f, g_, cs = facc.d(0), gacc.d(0), cacc.d(0)
+        for k in range(1, 4):
+            p.valu("v_add_f64", f, f, facc.d(k))
+            p.valu("v_add_f64", g_, g_, gacc.d(k))
+            p.valu("v_add_f64", cs, cs, cacc.d(k))
+        # column sums over the four lane rows with ONE matrix instruction: ones(16 x 4) times the 4 x 16 block of the
+        # per-lane sums puts sum_k cs[16 k + j] into every row of column j
+        ones, ct = cacc.d(1), vp.alloc(1)
+        lo, hi = dbits(1.0)
+        p.valu("v_mov_b32", ones.sub(0), lo)
+        p.valu("v_mov_b32", ones.sub(1), hi)
+        p.mfma(ct, ones, cs, 0)
+        tmp = cacc.d(2)
+        self.wave_reduce(f, tmp, "v_add_f64")
+        self.wave_reduce(g_, tmp, "v_add_f64")
+        mx = cacc.d(3)
+        p.valu("v_mov_b64", mx, ct.d(0))
+        # (columns: the 16 lanes of a row; the rows hold the same sums)
+        for ctrl in ("quad_perm:[1,0,3,2]", "quad_perm:[2,3,0,1]", "row_half_mirror", "row_mirror"):
+            p.dpp_mov(tmp.sub(0), mx.sub(0), ctrl)
+            p.dpp_mov(tmp.sub(1), mx.sub(1), ctrl)
+            p.valu("v_max_f64", mx, mx, tmp)
+        # lane 63 publishes: red[w] = f, red[4 + w] = g, red[8 + w] = n2
+        p.salu("s_mov_b64", self.s_save, EXEC)
+        self.set_exec(0, 0x80000000)
+        p.ds_write(64, self.v_RD, f, 0)
+        p.ds_write(64, self.v_RD, g_, 32)
+        p.ds_write(64, self.v_RD, mx, 64)
+        p.salu("s_mov_b64", EXEC, self.s_save)
+        for t in (ct, cacc, facc, gacc):
+            vp.free(t)
+        p.s_waitcnt(lgkm=0)
+        p.s_barrier()                                   # everybody is done reading the planes; the sums are published
+        # ---- verdict of the spectral bound (every lane computes the same numbers) ----
+        vtf, vtg, vt2, vz = vp.alloc(), vp.alloc(), vp.alloc(), vp.alloc()
+        p.valu("v_mov_b32", vz.sub(0), RED)
+        for h in range(2):          # red[0..3] = f, red[4..7] = g, red[8..11] = n2 of the four waves
+            p.ds_read(128, vtf.sub(4 * h, 4), vz.sub(0), 16 * h)
+            p.ds_read(128, vtg.sub(4 * h, 4), vz.sub(0), 32 + 16 * h)
+            p.ds_read(128, vt2.sub(4 * h, 4), vz.sub(0), 64 + 16 * h)
+        F, G, N2 = vtf.d(0), vtg.d(0), vt2.d(0)
+        for k in range(1, 4):
+            p.valu("v_add_f64", F, F, vtf.d(k))
+            p.valu("v_add_f64", G, G, vtg.d(k))
+            p.valu("v_max_f64", N2, N2, vt2.d(k))
+        th = self.c["THETA"]
+        c1, c2 = self.c["C1"], self.c["C2"]
+        k0, k1, k2 = S(58, 2), S(60, 2), S(62, 2)
+        self.smov64(k0, -1.0 / c1)
+        p.valu("v_mul_f64", G, G, k0)                                  # m6 = -G / c1
+        self.smov64(k1, c2 * c2)
+        p.valu("v_fma_f64", F, Neg(G), k1, F)                          # F - c2^2 m6
+        self.smov64(k2, (1.0 + 1e-9) / (c1 * c1))
+        p.valu("v_mul_f64", F, F, k2)                                  # m8 (1 + 1e-9)
+        self.smov64(k0, th ** 8)
+        p.v_cmp("v_cmp_le_f64", S(58, 2), F, k0)                       # m8 (1 + 1e-9) <= theta^8 (NaN: false)
+        p.v_cmp("v_cmp_ge_f64", S(60, 2), G, 0)                        # m6 >= 0
+        p.salu("s_and_b64", S(58, 2), S(58, 2), S(60, 2))
+        self.smov64(k2, th * th / (1.0 + 1e-9))
+        p.v_cmp("v_cmp_le_f64", S(60, 2), N2, k2)                      # n2 (1 + 1e-9) <= theta^2
+        p.salu("s_or_b64", S(58, 2), S(58, 2), S(60, 2))               # ok (per lane, all lanes alike)
+        # verdict[cell] = !ok, lane 0 of wave 0
+        p.valu("v_cndmask_b32", vz.sub(1), 1, 0, S(58, 2))
+        p.salu("s_lshl_b32", self.s_tmp[2], self.s_cell, 2)
+        p.valu("v_mov_b32", vz.sub(2), self.s_tmp[2])
+        p.salu("s_mov_b64", self.s_save, EXEC)
+        p.s_cmp("s_cmp_eq_u32", self.s_wave, 0)
+        p.salu("s_cselect_b32", self.s_tmp[4], 1, 0)
+        p.salu("s_mov_b32", self.s_tmp[5], 0)
+        p.salu("s_mov_b64", EXEC, S(self.s_tmp[4].idx, 2))
+        p.global_store(1, vz.sub(2), vz.sub(1), self.s_verdict)
+        p.salu("s_mov_b64", EXEC, self.s_save)
+        for t in (vtf, vtg, vt2, vz):
+            vp.free(t)
+        # ---- planes <- y0 + c3 A2 + c4 A; right operand y0 + c5 A2; start values c6 y0 + c7 A2; A2 parked ----
+        self.A2p_re, self.A2p_im = ap.alloc(4), ap.alloc(4)
+        Bre, Bim, Bsm = [None] * 4, [None] * 4, [None] * 4
+        tt = [vp.alloc(), vp.alloc()]
+        for sl in range(4):
+            Bre[sl], Bim[sl], Bsm[sl] = vp.alloc(), vp.alloc(), vp.alloc()
+            streams = []
+            for r in range(4):
+                k = r
+                y0r, p2, y0i = (Qt[sl][j].d(r) for j in range(3))
+                a2r, a2i = A2re[sl].d(r), A2im[sl].d(r)
+                asr, asi = tt[k // 2].sub(4 * (k % 2), 4).d(0), tt[k // 2].sub(4 * (k % 2), 4).d(1)
+                xs = p2                                             # (p2 is dead: it restarts from the literal 0)
+                br, bi, bs = Bre[sl].d(r), Bim[sl].d(r), Bsm[sl].d(r)
+                ar_, ai_ = self.As_re.sub(8 * sl, 8).d(r), self.As_im.sub(8 * sl, 8).d(r)
+                pr, pi_ = self.A2p_re.sub(8 * sl, 8).d(r), self.A2p_im.sub(8 * sl, 8).d(r)
+                streams.append([
+                    lambda asr=asr, ar_=ar_: self.acc_read(asr, ar_),
+                    lambda asi=asi, ai_=ai_: self.acc_read(asi, ai_),
+                    lambda pr=pr, a2r=a2r: self.acc_write(pr, a2r),
+                    lambda pi_=pi_, a2i=a2i: self.acc_write(pi_, a2i),
+                    lambda br=br, a2r=a2r, y0r=y0r: p.valu("v_fma_f64", br, c[5], a2r, y0r),
+                    lambda bi=bi, a2i=a2i, y0i=y0i: p.valu("v_fma_f64", bi, c[5], a2i, y0i),
+                    lambda asr=asr: p.valu("v_mul_f64", asr, c[4], asr),
+                    lambda asi=asi: p.valu("v_mul_f64", asi, c[4], asi),
+                    lambda asr=asr, a2r=a2r: p.valu("v_fma_f64", asr, c[3], a2r, asr),
+                    lambda asi=asi, a2i=a2i: p.valu("v_fma_f64", asi, c[3], a2i, asi),
+                    lambda asr=asr, y0r=y0r: p.valu("v_add_f64", asr, asr, y0r),
+                    lambda asi=asi, y0i=y0i: p.valu("v_add_f64", asi, asi, y0i),
+                    lambda bs=bs, br=br, bi=bi: p.valu("v_add_f64", bs, br, bi),
+                    lambda xs=xs, asr=asr, asi=asi: p.valu("v_add_f64", xs, asr, asi),
+                    lambda sl=sl, r=r, asr=asr, asi=asi, xs=xs: self.store_planes(sl, r, asr, asi, xs),
+                    # start values: p1 <- c6 y0.re + c7 A2.re, p3 <- p1 + c6 y0.im + c7 A2.im
+                    lambda y0r=y0r: p.valu("v_mul_f64", y0r, c[6], y0r),
+                    lambda y0i=y0i: p.valu("v_mul_f64", y0i, c[6], y0i),
+                    lambda y0r=y0r, a2r=a2r: p.valu("v_fma_f64", y0r, c[7], a2r, y0r),
+                    lambda y0i=y0i, a2i=a2i: p.valu("v_fma_f64", y0i, c[7], a2i, y0i),
+                    lambda y0i=y0i, y0r=y0r: p.valu("v_add_f64", y0i, y0i, y0r)])
+            self.interleave(streams)
+            vp.free(A2re[sl])
+            vp.free(A2im[sl])
+        for t in tt:
+            vp.free(t)
+        p.s_waitcnt(lgkm=0)
+        p.s_barrier()
+        if stop == 4:
+            return self.bail(Qt, extra_free=Bre + Bim + Bsm, parked=True)
+        # ================= y1 = (y0 + c3 A2 + c4 A)(y0 + c5 A2) + c6 y0 + c7 A2 ======================================
+        init13 = {(so, j) for so in range(4) for j in (0, 2)}
+        self.product(Qt, [Bre, Bim, Bsm], init=init13)
+        if stop == 5:
+            return self.bail(Qt, extra_free=Bre + Bim + Bsm, parked=True)
+        # ---- y1 in place ----
+        streams = []
+        for sl in range(4):
+            for r in range(4):
+                p1, p2, p3 = (Qt[sl][j].d(r) for j in range(3))
+                streams.append([lambda p3=p3, p1=p1: p.valu("v_add_f64", p3, p3, Neg(p1)),
+                                lambda p1=p1, p2=p2: p.valu("v_add_f64", p1, p1, Neg(p2)),
+                                lambda p3=p3, p2=p2: p.valu("v_add_f64", p3, p3, Neg(p2))])
+        for g in range(0, 16, 4):
+            self.interleave(streams[g:g + 4])
+        p.s_barrier()                                   # everybody is done reading the planes
+        # ---- planes <- y1 + c8 A2 + c9 A; right operand y1 + c10 y0 + c11 A (in place of y0 + c5 A2);
+        #      start values c12 y1 + c13 y0 + c14 A2 + c15 A + c16 I ----
+        k16 = S(58, 2)
+        self.smov64(k16, self.c["C16"])
+        tt = [vp.alloc() for _ in range(4)]
+        for sl in range(4):
+            streams = []
+            for r in range(4):
+                k = r
+                y1r, p2, y1i = (Qt[sl][j].d(r) for j in range(3))
+                br, bi, bs = Bre[sl].d(r), Bim[sl].d(r), Bsm[sl].d(r)
+                T = tt[k]
+                asr, asi, a2r, a2i = T.d(0), T.d(1), T.d(2), T.d(3)
+                xr, xi, xs = bs, p2, None
+                ar_, ai_ = self.As_re.sub(8 * sl, 8).d(r), self.As_im.sub(8 * sl, 8).d(r)
+                pr, pi_ = self.A2p_re.sub(8 * sl, 8).d(r), self.A2p_im.sub(8 * sl, 8).d(r)
+                st = [
+                    lambda asr=asr, ar_=ar_: self.acc_read(asr, ar_),
+                    lambda asi=asi, ai_=ai_: self.acc_read(asi, ai_),
+                    lambda a2r=a2r, pr=pr: self.acc_read(a2r, pr),
+                    lambda a2i=a2i, pi_=pi_: self.acc_read(a2i, pi_),
+                    # y0 = (y0 + c5 A2) - c5 A2, in place
+                    lambda br=br, a2r=a2r: p.valu("v_fma_f64", br, c[5], Neg(a2r), br),
+                    lambda bi=bi, a2i=a2i: p.valu("v_fma_f64", bi, c[5], Neg(a2i), bi),
+                    # left operand -> planes (xr in B.sm's register, xi in p2's, the sum over xr)
+                    lambda xr=xr, a2r=a2r, y1r=y1r: p.valu("v_fma_f64", xr, c[8], a2r, y1r),
+                    lambda xi=xi, a2i=a2i, y1i=y1i: p.valu("v_fma_f64", xi, c[8], a2i, y1i),
+                    lambda xr=xr, asr=asr: p.valu("v_fma_f64", xr, c[9], asr, xr),
+                    lambda xi=xi, asi=asi: p.valu("v_fma_f64", xi, c[9], asi, xi),
+                ]
+                # the sum needs a register of its own until the stores have read it: a2r / a2i are still needed, so the
+                # start values are formed first into a2r / a2i ... order below
+                st += [
+                    # start values: vr = c12 y1r + c13 y0r + c14 a2r + c15 asr  (accumulated in a2r's register)
+                    lambda a2r=a2r: p.valu("v_mul_f64", a2r, c[14], a2r),
+                    lambda a2i=a2i: p.valu("v_mul_f64", a2i, c[14], a2i),
+                    lambda a2r=a2r, asr=asr: p.valu("v_fma_f64", a2r, c[15], asr, a2r),
+                    lambda a2i=a2i, asi=asi: p.valu("v_fma_f64", a2i, c[15], asi, a2i),
+                    lambda a2r=a2r, br=br: p.valu("v_fma_f64", a2r, c[13], br, a2r),
+                    lambda a2i=a2i, bi=bi: p.valu("v_fma_f64", a2i, c[13], bi, a2i),
+                    lambda a2r=a2r, y1r=y1r: p.valu("v_fma_f64", a2r, c[12], y1r, a2r),
+                    lambda a2i=a2i, y1i=y1i: p.valu("v_fma_f64", a2i, c[12], y1i, a2i),
+                    # right operand in place: y1 + c10 y0 + c11 A
+                    lambda br=br, y1r=y1r: p.valu("v_fma_f64", br, c[10], br, y1r),
+                    lambda bi=bi, y1i=y1i: p.valu("v_fma_f64", bi, c[10], bi, y1i),
+                    lambda br=br, asr=asr: p.valu("v_fma_f64", br, c[11], asr, br),
+                    lambda bi=bi, asi=asi: p.valu("v_fma_f64", bi, c[11], asi, bi),
+                    # the plane sum into A's (now dead) register, then the three stores
+                    lambda asr=asr, xr=xr, xi=xi: p.valu("v_add_f64", asr, xr, xi),
+                    lambda sl=sl, r=r, xr=xr, xi=xi, asr=asr: self.store_planes(sl, r, xr, xi, asr),
+                ]
+                if sl == 0:
+                    def diag(a2r=a2r, r=r):
+                        p.salu("s_mov_b64", self.s_save, EXEC)
+                        p.salu("s_mov_b64", EXEC, self.s_dmask[r])
+                        p.valu("v_add_f64", a2r, a2r, k16)
+                        p.salu("s_mov_b64", EXEC, self.s_save)
+                    st.append(diag)
+                st += [
+                    lambda y1r=y1r, a2r=a2r: p.valu("v_mov_b64", y1r, a2r),                       # p1 <- vr
+                    lambda y1i=y1i, a2r=a2r, a2i=a2i: p.valu("v_add_f64", y1i, a2r, a2i),         # p3 <- vr + vi
+                ]
+                streams.append(st)
+            self.interleave(streams)
+        # B.sm (its registers carried the left operand until the stores had read them: the stores are issued, and the
+        # hazard tracker keeps the overwrite two states behind them)
+        for sl in range(4):
+            for r in range(4):
+                p.valu("v_add_f64", Bsm[sl].d(r), Bre[sl].d(r), Bim[sl].d(r))
+        for t in tt:
+            vp.free(t)
+        ap.free(self.A2p_re)
+        ap.free(self.A2p_im)
+        p.s_waitcnt(lgkm=0)
+        p.s_barrier()
+        if stop == 6:
+            return self.bail(Qt, extra_free=Bre + Bim + Bsm)
+        # ================= p = (y1 + c8 A2 + c9 A)(y1 + c10 y0 + c11 A) + ... ; the next cell's operator tiles ==========
+        pf = [ap.alloc(2) for _ in range(5)]
+
+        def hook_fetch(sk, r):
+            if sk == 1 and r == 0:
+                for u in range(5):
+                    self.fetch(u, pf[u])
+
+        self.product(Qt, [Bre, Bim, Bsm], init=init13, hook=hook_fetch)
+        for t in Bre + Bim + Bsm:
+            vp.free(t)
+        ap.free(self.As_re)
+        ap.free(self.As_im)
+        # ---- result, interleaved (re, im) per element: the layout of the 16-byte stores ----
+        Un = vp.alloc(8, at=self.UT)
+        streams = []
+        for sl in range(4):
+            for r in range(4):
+                p1, p2, p3 = (Qt[sl][j].d(r) for j in range(3))
+                ur, ui = Un.sub(16 * sl + 4 * r, 2), Un.sub(16 * sl + 4 * r + 2, 2)
+                streams.append([lambda ur=ur, p1=p1, p2=p2: p.valu("v_add_f64", ur, p1, Neg(p2)),
+                                lambda ui=ui, p3=p3, p1=p1: p.valu("v_add_f64", ui, p3, Neg(p1)),
+                                lambda ui=ui, p2=p2: p.valu("v_add_f64", ui, ui, Neg(p2))])
+        for g in range(0, 16, 4):
+            self.interleave(streams[g:g + 4])
+        p.s_barrier()                                   # everybody is done reading the planes
+        self.end_of_cell(pf, Qt, Un)
+
+    def bail(self, Qt, extra_free=(), parked=False):
+        """diagnostic truncation: release what the skipped phases would have released; the result is garbage"""
+        vp, ap = self.vp, self.ap
+        for t in extra_free:
+            vp.free(t)
+        if parked:
+            ap.free(self.A2p_re)
+            ap.free(self.A2p_im)
+        ap.free(self.As_re)
+        ap.free(self.As_im)
+        if self.stop_after == 1:
+            pass
+        Un = vp.alloc(8, at=self.UT)
+        pf = [ap.alloc(2) for _ in range(5)]
+        for u in range(5):
+            self.fetch(u, pf[u])
+        self.p.s_barrier()
+        self.end_of_cell(pf, Qt, Un)
+
+    def end_of_cell(self, pf, Qt, Un):
+        p, vp, ap = self.p, self.vp, self.ap
+        self.commit(pf)
+        for x in pf:
+            ap.free(x)
+        vp.free(Un)
+        for t in self.QT:
+            vp.free_tiles.append(t)
+        vp.free_tiles.sort()
+        p.s_waitcnt(vm=0, lgkm=0)
+        p.s_barrier()
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def advance(self):
+        """(nkc, nn, ncell) = the cell after (kc, n, cell), clamped to the current one behind the last"""
+        p = self.p
+        p.salu("s_add_u32", self.s_tmp[2], self.s_idx, self.s_step)
+        p.salu("s_mov_b32", self.s_nkc, self.s_kc)
+        p.salu("s_mov_b32", self.s_nn, self.s_n)
+        p.salu("s_mov_b32", self.s_ncell, self.s_cell)
+        p.s_cmp("s_cmp_ge_u32", self.s_tmp[2], self.s_end)
+        lab = f"L_adv_{len(p.ins)}"
+        p.s_branch("s_cbranch_scc1", lab)
+        p.salu("s_add_u32", self.s_ncell, self.s_cell, self.s_step)
+        p.salu("s_add_u32", self.s_nn, self.s_n, self.s_step)
+        p.label(lab + "_w")
+        p.s_cmp("s_cmp_lt_u32", self.s_nn, self.s_NT)
+        p.s_branch("s_cbranch_scc1", lab)
+        p.salu("s_sub_u32", self.s_nn, self.s_nn, self.s_NT)
+        p.salu("s_add_u32", self.s_nkc, self.s_nkc, 1)
+        p.s_branch("s_branch", lab + "_w")
+        p.label(lab)
+
+    def u_bases(self, cell):
+        """U + cell * 65536 + tb * 16384 for the slots of this wave"""
+        p = self.p
+        t0, t1 = self.s_tmp[0], self.s_tmp[1]
+        for sl in range(4):
+            p.salu("s_lshl_b32", t0, cell, 16)
+            p.salu("s_lshr_b32", t1, cell, 16)
+            p.salu("s_add_u32", self.s_ub[sl].sub(0), self.s_U.sub(0), t0)
+            p.salu("s_addc_u32", self.s_ub[sl].sub(1), self.s_U.sub(1), t1)
+            p.salu("s_add_u32", t0, self.s_wave, sl)
+            p.salu("s_and_b32", t0, t0, 3)
+            p.salu("s_lshl_b32", t0, t0, 14)
+            p.salu("s_add_u32", self.s_ub[sl].sub(0), self.s_ub[sl].sub(0), t0)
+            p.salu("s_addc_u32", self.s_ub[sl].sub(1), self.s_ub[sl].sub(1), 0)
+
+    def build(self):
+        p = self.p
+        self.prologue()
+        # first cell: fetch and commit its A
+        self.cell_bases(self.s_kc, self.s_n)
+        pf = [self.ap.alloc(2) for _ in range(5)]
+        for u in range(5):
+            self.fetch(u, pf[u])
+        self.commit(pf)
+        for x in pf:
+            self.ap.free(x)
+        p.s_waitcnt(vm=0, lgkm=0)
+        p.s_barrier()
+        p.label("L_cell")
+        self.advance()
+        self.cell_bases(self.s_nkc, self.s_nn)          # bases and dt of the NEXT cell (used by the last product / commit)
+        self.cell()
+        # loop-carried scalars
+        self.u_bases(self.s_cell)
+        p.salu("s_mov_b64", self.s_pmask, -1)
+        p.salu("s_mov_b32", self.s_kc, self.s_nkc)
+        p.salu("s_mov_b32", self.s_n, self.s_nn)
+        p.salu("s_mov_b32", self.s_cell, self.s_ncell)
+        p.salu("s_add_u32", self.s_idx, self.s_idx, self.s_step)
+        p.s_cmp("s_cmp_lt_u32", self.s_idx, self.s_end)
+        p.s_branch("s_cbranch_scc1", "L_cell")
+        # the last result
+        Uprev = V(8 * self.UT, 64)
+        for sk in range(4):
+            for rr in range(4):
+                p.global_store(4, self.v_UO1 if rr < 2 else self.v_UO2, Uprev.sub(16 * sk + 4 * rr, 4), self.s_ub[sk],
+                               -4096 if rr % 2 == 0 else 0)
+        p.label("L_end")
+        p.s_endpgm()
+        return p
+
+
+def generate(path=None, **kw):
+    g = Gen(**kw)
+    prog = g.build()
+    text = kernel_text(prog, KERNARG, LDS_BYTES)
+    if path:
+        with open(path, "w") as f:
+            f.write(text)
+    return g, prog, text
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "expm_t16_asm.s")
+    g, prog, _ = generate(out)
+    print(f"{out}: {len(prog.ins)} lines, {prog.count('mfma')} matrix instructions, {prog.count('valu') + prog.count('dpp')} vector, "
+          f"{prog.count('lds')} LDS, {prog.count('vmem')} global, {prog.auto_nops} wait states inserted")

@@ -82,6 +82,9 @@ struct grape_handle {
     int t16_hold = 0;
     long t16_tried = 0, t16_fell = 0;   // of the last evaluation that tried
     int *d_celllist = nullptr;          // [KC * N_T] the listed cells (counter: d_flags[4])
+    // the four-product route as hand-allocated assembly (asm/gen_t16.py; GRAPE_EXPM_ASM=0: the C++ kernel): four tiles
+    // per side, Hermitian generators, controls shared by the trajectories
+    bool asm16 = false;
     double *d_Sf = nullptr;             // [N_T][2][NP*NP] summed control operators of every time step (polynomial kernel, L > 2)
     // diagnostic switches, read ONCE in grape_create (never in the evaluation path: getenv is not thread-safe against setenv)
     bool expm_persist = true;    // GRAPE_EXPM_PERSIST=0: one workgroup per cell instead of the persistent Pade kernel
@@ -216,6 +219,7 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
+extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks);
 // deriv3_kernel keeps the upper 16 x 16 tiles (re, im; stride 17) of H0_k and of the L control operators in LDS
 // (general drift: all NT x NT tiles of H0_k, three and four tiles per side and at most two controls)
 static bool deriv3_fits(int NT, int L, bool h0_general = false) {
@@ -1003,6 +1007,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             h->t18_small = !(envs2 && !atoi(envs2));
             const char *env16 = getenv("GRAPE_EXPM_T16");
             h->t16 = !(env16 && !atoi(env16));
+            const char *enva = getenv("GRAPE_EXPM_ASM");
+            h->asm16 = !(enva && !atoi(enva));
         }
         {
             const char *envp = getenv("GRAPE_EXPM_PERSIST"), *envl = getenv("GRAPE_EXPM_LDS_PAD"), *envx = getenv("GRAPE_CHEBY_XMODE");
@@ -1272,7 +1278,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
     // more than two controls shared by all trajectories: the cell fetches H0_k and ONE summed operator S_n (ctrl_sum_kernel)
-    if (h->t18 && !h->large && !h->series && L > 2 && !p->hc_per_traj && (h->NT >= 3 || h->t18_small))
+    h->asm16 = h->asm16 && h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT == 4 && !p->hc_per_traj && (long)K * N_T < (1L << 28);
+    if (h->t18 && !h->large && !h->series && (L > 2 || h->asm16) && !p->hc_per_traj && (h->NT >= 3 || h->t18_small))
         CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * NP * NP));
     // (N <= 16 stays with five products: one tile per side is latency-bound -- the kernel gains nothing from the shorter
     // polynomial and the second launch costs 10 us of an evaluation of 0.4 ms; measured at C2: 0.079 -> 0.098 ms)
@@ -1395,7 +1402,10 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                 ea.cell_list = h->d_celllist; ea.listed = 0;
                 // (three tiles per side, four-product variant: 256 registers and 72 KB -- two workgroups per CU)
                 const int blocks16 = (t16 && h->NT == 3) ? 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * 2, (ncell + 7) / 8)) : t18_blocks;
-                e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, t16 ? 1 : 0, &ea, sizeof(ea), (void *)s, blocks16);
+                if (t16 && h->asm16)   // (the verdicts of the assembly kernel go through the flag array of the Pade path)
+                    e = (hipError_t)grape_t16_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, t18_blocks);
+                else
+                    e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, t16 ? 1 : 0, &ea, sizeof(ea), (void *)s, blocks16);
                 if (t16 && e == hipSuccess) {   // the cells it listed, by the degree-18 variant (none: the launch ends at once)
                     ea.listed = 1;
                     e = (hipError_t)grape_t18_launch(h->NT, 1, 0, &ea, sizeof(ea), (void *)s, t18_blocks);

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <type_traits>
+#include <mutex>
 namespace {
 #include "grape_t18.hip.h"
 #include "grape_deriv3.hip.h"
@@ -74,6 +75,143 @@ extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, co
 #undef D3_CASES
     if (NT == 4 && L <= 2) return (int)(L == 1 ? launch_d3<4, 1>(a, s, blocks) : launch_d3<4, 2>(a, s, blocks));
     return (int)hipErrorInvalidValue;
+}
+
+// ---- the four-product route as hand-allocated assembly (asm/gen_t16.py -> expm_t16_asm.co, embedded by asm_embed.S) ----
+// Four tiles per side, Hermitian generators, controls shared by the trajectories (the cell fetches H0_k and the summed
+// controls S_n).  The assembly kernel does the arithmetic and writes one verdict per cell (0: inside the spectral bound);
+// t16_post_kernel behind it lists the cells beyond the bound for the five-product launch and books the statistics the
+// C++ kernel books in its cell loop (credited work of Julia's exp!, executed matrix instructions).
+extern "C" const unsigned char grape_asm_co_start[], grape_asm_co_end[];
+namespace {
+struct T16AsmArgs {           // kernel argument block of expm_t16_asm (gen_t16.py: KERNARG = 80 bytes)
+    const double *H0f, *Sf, *dts;
+    double2 *U;
+    int *verdict;
+    const int *rep;
+    int KC, N_T, nblk, pad0;
+    unsigned long long pad1[2];
+};
+static_assert(sizeof(T16AsmArgs) == 80, "argument block of the assembly kernel");
+
+// ||A||_1 of A = -i dt (H0_k + S_n) from the operator planes (t18_norm1 on the same numbers), all 256 threads
+__device__ __forceinline__ double t16_post_norm1(const ExpmArgs &a, const int cell, double *red, const int tid) {
+    constexpr int NP = 64;
+    const int kc = cell / a.N_T, n = cell - kc * a.N_T, k = a.rep ? a.rep[kc] : kc;
+    const double *h0 = a.H0f + (size_t)k * 2 * NP * NP, *sn = a.Sf + (size_t)n * 2 * NP * NP;
+    const double dt = a.dts[n];
+    const int j = tid & 63, part = tid >> 6;
+    double sum = 0.;
+    for (int i = part; i < NP; i += 4) {
+        const double xr = dt * (h0[NP * NP + i * NP + j] + sn[NP * NP + i * NP + j]), xi = -dt * (h0[i * NP + j] + sn[i * NP + j]);
+        sum += fast_sqrt(xr * xr + xi * xi);
+    }
+    red[tid] = sum;
+    __syncthreads();
+    if (tid < 64) {
+        double c = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c = fmax(c, __shfl_xor(c, off, 64));
+        if (tid == 0) red[256] = c;
+    }
+    __syncthreads();
+    const double nA = red[256];
+    __syncthreads();
+    return nA;
+}
+
+__global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *verdict) {
+    __shared__ double red[264];
+    __shared__ int todo[256], ntodo;
+    __shared__ unsigned long long cnt[8];   // squarings, max, orders 0..4, accepted cells
+    const int tid = threadIdx.x, ncell = a.K * a.N_T;
+    if (tid < 8) cnt[tid] = 0;
+    if (tid == 0) ntodo = 0;
+    __syncthreads();
+    auto credit = [&](double nA) {          // what Julia's exp! would do for this cell (order and squarings from ||A||_1)
+        int sj = 0;
+        if (nA > 5.4) {
+            const double r = nA / 5.4;
+            const int e = ilogb(r);
+            sj = (r == ldexp(1.0, e)) ? e : e + 1;
+        }
+        const int oj = nA > 2.1 ? 4 : nA > 0.95 ? 3 : nA > 0.25 ? 2 : nA > 0.015 ? 1 : 0;
+        if (sj) { atomicAdd(&cnt[0], (unsigned long long)sj); atomicMax(&cnt[1], (unsigned long long)sj); }
+        atomicAdd(&cnt[2 + oj], 1ull);
+    };
+    const int cell = blockIdx.x * 256 + tid;
+    if (cell < ncell) {
+        const double bound = expm_norm_bound(a, cell);
+        if (bound > 2.1 && bound <= 5.4) credit(bound);
+        else todo[atomicAdd(&ntodo, 1)] = cell;
+        if (verdict[cell]) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
+        else atomicAdd(&cnt[7], 1ull);
+    }
+    __syncthreads();
+    const int nt = ntodo;
+    for (int q = 0; q < nt; ++q) {
+        const double nA = t16_post_norm1(a, todo[q], red, tid);
+        if (tid == 0) credit(nA);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int here = min(256, ncell - (int)blockIdx.x * 256);
+        if (cnt[0]) stat_add(a.stats, 0, cnt[0]);
+        for (int o = 0; o < 5; ++o)
+            if (cnt[2 + o]) stat_add(a.stats, 3 + o, cnt[2 + o]);
+        if (cnt[1]) atomicMax(&a.flags[1], (int)cnt[1]);
+        // executed matrix instructions of the assembly kernel: four waves x (120 + 3 * 192 + 1 for the column sums) per cell
+        stat_add(a.stats, 12, (unsigned long long)here * 4ull * (unsigned long long)(T16Count<4>::CELL + 1));
+        stat_add(a.stats, 14, cnt[7]);
+        stat_add(a.stats, 15, cnt[7]);
+        atomicAdd(&a.flags[5], here);
+    }
+}
+
+struct AsmModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+};
+hipError_t asm_function(int dev, hipFunction_t *fn) {
+    static AsmModule mods[64];
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
+    AsmModule &m = mods[dev & 63];
+    if (!m.fn) {
+        hipError_t e = hipModuleLoadData(&m.mod, (const void *)grape_asm_co_start);
+        if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn, m.mod, "expm_t16_asm");
+        if (e != hipSuccess) return e;
+    }
+    *fn = m.fn;
+    return hipSuccess;
+}
+}  // namespace
+
+// args: ExpmArgs with Sf set (summed controls of every time step) and cell_list / flags / stats as for the C++ kernel
+extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks) {
+    if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
+    ExpmArgs a;
+    memcpy(&a, args, sizeof(a));
+    if (!a.Sf || a.hc_per_traj || !verdict || blocks < 8 || (blocks & 7)) return (int)hipErrorInvalidValue;
+    const long ncell = (long)a.K * a.N_T;
+    if (ncell <= 0 || ncell >= (1L << 28)) return (int)hipErrorInvalidValue;   // (32-bit cell arithmetic in the kernel)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipFunction_t fn;
+    e = asm_function(dev, &fn);
+    if (e != hipSuccess) return (int)e;
+    T16AsmArgs k{};
+    k.H0f = a.H0f; k.Sf = a.Sf; k.dts = a.dts; k.U = a.U; k.verdict = verdict; k.rep = a.rep;
+    k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks;
+    size_t size = sizeof(k);
+    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    hipStream_t s = (hipStream_t)stream;
+    e = hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(t16_post_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, (const int *)verdict);
+    return (int)hipGetLastError();
 }
 
 // args: the ExpmArgs of grape_kernels.hip.h (same header on both sides), passed as bytes because the type of this unit
