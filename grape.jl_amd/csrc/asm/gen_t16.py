@@ -23,8 +23,14 @@ and the k loops contain matrix instructions, LDS reads, scalar instructions and 
 loads only.  Every linear combination reads A from the accumulation half with v_accvgpr_read (the only moves left:
 ~480 per cell and wave against ~1240 + address arithmetic).
 
-LDS: one region of 64 rows x (re[64] | im[64] | re+im[64] | 2 pad) doubles (all three planes of a row within the 16-bit
-offset field of one address register), two exchange areas, reduction scratch: 132.6 KB.
+LDS: one region of 64 COLUMN records (re[64] | im[64] | re+im[64] | 2 pad doubles: all three planes of a column within
+the 16-bit offset field of one address register), two exchange areas, reduction scratch: 132.6 KB.  Column-major, because
+the four elements a lane holds of a 16 x 16 tile are four rows of ONE column: with the rows of a tile stored in the order
+4 rg + r they are 32 contiguous bytes, two ds_write_b128 / ds_read_b128 instead of four 64-bit accesses (an LDS
+instruction outside the shadow of a matrix instruction costs ~28 cycles of a lone wave, whatever its width: measured).
+The columns of a 16-column block are stored in the order (j >> 1) + 8 (j & 1): a 16-lane store group (16 columns) covers
+16 distinct 4-bank groups, and the two columns a half-wave of a left-operand read covers (k, k + 1) lie 8 records =
+32 banks apart -- both access patterns are free of bank conflicts.
 
 The instruction list is executed by the emulator of gcn.py against numpy (tests/test_asm_kernel.py) -- this container
 has no GPU -- and the same list is printed as the .s file the library embeds.
@@ -44,8 +50,10 @@ PLB = NP * 8                    # byte offset of the next plane inside a row
 TROW = 16 * LDB                 # 16 rows
 PLANES = NP * LDB               # 99328
 E1 = PLANES                     # exchange area of the half sums (4 waves x 512 doubles)
-E2 = E1 + 4 * 512 * 8           # exchange area of the mirrored tiles
-RED = E2 + 4 * 512 * 8          # 16 doubles of reduction scratch
+EXH = 256 * 8 + 128             # bytes of the real (imaginary) parts of a tile in an exchange area: 256 doubles + the skew
+EXW = 2 * EXH                   # bytes per wave of an exchange area
+E2 = E1 + 4 * EXW               # exchange area of the mirrored tiles
+RED = E2 + 4 * EXW              # 16 doubles of reduction scratch
 LDS_BYTES = RED + 16 * 8
 KERNARG = 80
 
@@ -64,6 +72,16 @@ def t16_coeffs():
 def dbits(x):
     b = struct.unpack("<Q", struct.pack("<d", x))[0]
     return b & 0xFFFFFFFF, b >> 32
+
+
+def pcol(j):
+    """record index of column j inside a 16-column block of the planes"""
+    return (j >> 1) + 8 * (j & 1)
+
+
+def qrow(i):
+    """position of row i inside a 16-row tile of a column record: the rows 4 r + rg, r = 0..3, of a lane are contiguous"""
+    return 4 * (i & 3) + (i >> 2)
 
 
 # upper block triangle, row by row (T18FormA::tile_i / tile_j)
@@ -105,11 +123,29 @@ class Pool:
 
 
 class Gen:
-    def __init__(self, name="expm_t16_asm", stop_after=None, diag=False):
+    NSTAMP = 16
+    # order of the column records inside a 16-column block: identity.  (The permutation (j >> 1) + 8 (j & 1) frees the
+    # fragment reads of their 2-way bank conflict but gives the 16-byte strip stores one -- stores are banked over 32
+    # banks in groups of 8 lanes -- and the stores are what a cell waits for: measured.)
+    PCOL_PERM = False
+    KSTEP = 2 if PCOL_PERM else 4          # column records between the fragments of consecutive k-steps
+
+    def v_pcol(self, dst, src, tmp):
+        p = self.p
+        if not self.PCOL_PERM:
+            p.valu("v_mov_b32", dst, src)
+            return
+        p.valu("v_and_b32", dst, 1, src)
+        p.valu("v_lshlrev_b32", dst, 3, dst)
+        p.valu("v_lshrrev_b32", tmp, 1, src)
+        p.valu("v_add_u32", dst, dst, tmp)
+
+    def __init__(self, name="expm_t16_asm", stop_after=None, diag=False, opts=None):
         self.p = Prog(name)
         self.c = t16_coeffs()
         self.stop_after = stop_after     # diagnostic builds: leave the cell after phase n (timing by truncation)
-        self.diag = diag
+        self.diag = diag                 # diagnostic builds: s_memtime stamps at the phase boundaries of every cell
+        self.opts = dict(opts or {})
         # ---- scalar registers ----
         self.s_H0, self.s_Sf, self.s_dts, self.s_U = S(4, 2), S(6, 2), S(8, 2), S(10, 2)
         self.s_verdict, self.s_rep = S(12, 2), S(14, 2)
@@ -117,8 +153,8 @@ class Gen:
         self.s_wave, self.s_idx, self.s_end, self.s_step = S(20), S(21), S(22), S(23)
         self.s_kc, self.s_n, self.s_cell = S(24), S(25), S(26)          # current cell
         self.s_nkc, self.s_nn, self.s_ncell = S(27), S(28), S(29)       # next cell (clamped to the current one at the end)
-        self.s_pcell = S(30)
-        self.s_hi = S(31)                                                # wave >> 1
+        self.s_hi = S(19)                                                # wave >> 1
+        self.s_diag = S(30, 2)                                           # diagnostic builds: stamp area of this wave
         self.s_ub = [S(32 + 2 * i, 2) for i in range(4)]                 # U bases of the previous cell, per slot
         self.s_toff = [S(40 + u) for u in range(5)]                      # byte offsets of this wave pair's operator tiles
         self.s_hb, self.s_sb = S(46, 2), S(48, 2)                        # H0 / S base of the next cell
@@ -159,6 +195,23 @@ class Gen:
         self.p.salu("s_mov_b32", self.s_tmp[5], hi)
         self.p.salu("s_mov_b64", EXEC, S(self.s_tmp[4].idx, 2))
 
+    def stamp(self, i):
+        """diagnostic builds: shader clock at this point -> stamp area [wg][wave][i] (lane 0; the last cell's values stay)"""
+        if not self.diag:
+            return
+        p = self.p
+        t = self.vp.alloc()
+        p.s_memtime(S(58, 2))
+        p.s_waitcnt(lgkm=0)
+        p.valu("v_mov_b32", t.sub(0), S(58))
+        p.valu("v_mov_b32", t.sub(1), S(59))
+        p.valu("v_mov_b32", t.sub(2), 0)
+        p.salu("s_mov_b64", self.s_save, EXEC)
+        self.set_exec(1, 0)
+        p.global_store(2, t.sub(2), t.sub(0, 2), self.s_diag, 8 * i)
+        p.salu("s_mov_b64", EXEC, self.s_save)
+        self.vp.free(t)
+
     def smov64(self, dst, x):
         lo, hi = dbits(x)
         self.p.salu("s_mov_b32", dst.sub(0), lo)
@@ -176,46 +229,58 @@ class Gen:
         p.salu("s_lshr_b32", self.s_hi, self.s_wave, 1)
         p.valu("v_and_b32", vc, 15, self.v_lane)
         p.valu("v_lshrrev_b32", vrg, 4, self.v_lane)
-        # left-operand fragments: lane (i = c, kq = rg) reads row 16 tr + c, column 16 tk + 4 r + kq
-        p.valu("v_mul_u32_u24", vx, LDB, vc)
-        p.valu("v_lshl_add_u32", vx, vrg, 3, vx)                         # c LDB + 8 rg
+        # left-operand fragments: lane (i = c, kq = rg) reads row 16 tr + c, column 16 tk + 4 r + kq:
+        # record (16 tk + pcol(4 r + kq)) = 16 tk + 2 r + pcol(kq), position 16 tr + qrow(c)
+        vpc = t.sub(6)
+        self.v_pcol(vpc, vrg, vx)                                        # pcol(rg)
+        p.valu("v_mul_u32_u24", vx, LDB, vpc)
+        p.valu("v_and_b32", vpc, 3, vc)
+        p.valu("v_lshlrev_b32", vpc, 2, vpc)
+        p.valu("v_lshrrev_b32", vy, 2, vc)
+        p.valu("v_add_u32", vpc, vpc, vy)                                # qrow(c)
+        p.valu("v_lshl_add_u32", vx, vpc, 3, vx)                         # pcol(rg) LDB + 8 qrow(c)
         for so in range(4):
             for sk in range(4):
-                p.salu("s_add_u32", self.s_tmp[0], self.s_wave, so)
+                p.salu("s_add_u32", self.s_tmp[0], self.s_wave, sk)
                 p.salu("s_and_b32", self.s_tmp[0], self.s_tmp[0], 3)
                 p.salu("s_mul_i32", self.s_tmp[0], self.s_tmp[0], TROW)
-                p.salu("s_add_u32", self.s_tmp[1], self.s_wave, sk)
+                p.salu("s_add_u32", self.s_tmp[1], self.s_wave, so)
                 p.salu("s_and_b32", self.s_tmp[1], self.s_tmp[1], 3)
                 p.salu("s_lshl_b32", self.s_tmp[1], self.s_tmp[1], 7)
                 p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], self.s_tmp[1])
                 p.valu("v_add_u32", self.v_AA[so][sk], self.s_tmp[0], vx)
-        # strips (C/D layout): lane (c, rg), slot sl, register r: row 16 ((w + sl) & 3) + 4 r + rg, column 16 w + c
-        p.valu("v_mul_u32_u24", vy, LDB, vrg)
-        p.valu("v_lshl_add_u32", vy, vc, 3, vy)                          # rg LDB + 8 c
+        # strips (C/D layout): lane (c, rg), slot sl, register r: row 16 ((w + sl) & 3) + 4 r + rg, column 16 w + c:
+        # record 16 w + pcol(c), position 16 ((w + sl) & 3) + 4 rg + r
+        self.v_pcol(vpc, vc, vy)                                         # pcol(c)
+        p.valu("v_mul_u32_u24", vy, LDB, vpc)
+        p.valu("v_lshl_add_u32", vy, vrg, 5, vy)                         # pcol(c) LDB + 32 rg
         for sl in range(4):
             p.salu("s_add_u32", self.s_tmp[0], self.s_wave, sl)
             p.salu("s_and_b32", self.s_tmp[0], self.s_tmp[0], 3)
-            p.salu("s_mul_i32", self.s_tmp[0], self.s_tmp[0], TROW)
-            p.salu("s_lshl_b32", self.s_tmp[1], self.s_wave, 7)
+            p.salu("s_lshl_b32", self.s_tmp[0], self.s_tmp[0], 7)
+            p.salu("s_mul_i32", self.s_tmp[1], self.s_wave, TROW)
             p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], self.s_tmp[1])
             p.valu("v_add_u32", self.v_SA[sl], self.s_tmp[0], vy)
         # exchange areas: the writer stores its tile in the READER's register layout (rot_exch_write):
         # double index ((w + d) & 3) 512 + (16 (c & 3) + rg) 4 + (c >> 2), element r at + 16 r, imaginary parts at + 256
-        p.valu("v_and_b32", vx, 3, vc)
-        p.valu("v_lshl_add_u32", vx, vx, 4, vrg)                         # 16 (c & 3) + rg
+        # (+ 32 bytes per reader lane row 16 (c & 3): the 16 lanes of a store group then cover 16 distinct bank pairs)
+        p.valu("v_and_b32", vpc, 3, vc)
+        p.valu("v_lshl_add_u32", vx, vpc, 4, vrg)                        # 16 (c & 3) + rg
         p.valu("v_lshrrev_b32", vy, 2, vc)
         p.valu("v_lshl_add_u32", vx, vx, 2, vy)                          # ... * 4 + (c >> 2)
         p.valu("v_lshlrev_b32", vx, 3, vx)                               # bytes
+        p.valu("v_lshl_add_u32", vx, vpc, 5, vx)                         # + 32 (c & 3)
         for d, dst, area in ((1, self.v_EW1, E2), (2, self.v_EW2, E1)):
             p.salu("s_add_u32", self.s_tmp[0], self.s_wave, d)
             p.salu("s_and_b32", self.s_tmp[0], self.s_tmp[0], 3)
-            p.salu("s_lshl_b32", self.s_tmp[0], self.s_tmp[0], 12)
+            p.salu("s_mul_i32", self.s_tmp[0], self.s_tmp[0], EXW)
             p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], area)
             p.valu("v_add_u32", dst, self.s_tmp[0], vx)
-        p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 12)
+        p.salu("s_mul_i32", self.s_tmp[0], self.s_wave, EXW)
         p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], E1)
         p.valu("v_lshlrev_b32", vx, 5, self.v_lane)
-        p.valu("v_add_u32", self.v_ER, self.s_tmp[0], vx)                # E1 + 4096 w + 32 lane
+        p.valu("v_lshl_add_u32", vx, vrg, 5, vx)                         # 32 lane + 32 (lane >> 4)
+        p.valu("v_add_u32", self.v_ER, self.s_tmp[0], vx)                # E1 + EXW w + 32 lane + 32 (lane >> 4)
         p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 3)
         p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], RED)
         p.valu("v_mov_b32", self.v_RD, self.s_tmp[0])
@@ -226,17 +291,31 @@ class Gen:
         p.valu("v_add_u32", vx, self.s_tmp[0], vx)
         p.valu("v_add_u32", self.v_UO1, 4096, vx)
         p.valu("v_add_u32", self.v_UO2, 12288, vx)
-        # operator tiles: element pair idx = tid & 127 of a tile: row idx >> 3, columns 2 (idx & 7), + 1
+        # operator tiles: element pair idx = tid & 127 of a tile: row idx & 15, columns 2 (idx >> 4), + 1
         p.valu("v_and_b32", vidx, 127, self.v_tid)
-        p.valu("v_lshrrev_b32", vx, 3, vidx)                             # row
-        p.valu("v_and_b32", vy, 7, vidx)                                 # column pair
+        # (16 consecutive lanes = the 16 rows of one column pair: a 16-lane store group then writes 16 consecutive positions
+        # of ONE column record -- no bank conflict for the direct elements, two-way for the mirrored ones; with eight
+        # column pairs of one row in consecutive lanes both were four-way: tools/asm_lds_model.py)
+        p.valu("v_and_b32", vx, 15, vidx)                                # row
+        p.valu("v_lshrrev_b32", vy, 4, vidx)                             # column pair
         p.valu("v_lshlrev_b32", self.v_GO, 9, vx)
         p.valu("v_lshl_add_u32", self.v_GO, vy, 4, self.v_GO)            # (row 64 + 2 cp) 8
         p.valu("v_add_u32", self.v_GOI, NP * NP * 8, self.v_GO)
-        p.valu("v_mul_u32_u24", self.v_CP, LDB, vx)
-        p.valu("v_lshl_add_u32", self.v_CP, vy, 4, self.v_CP)            # row LDB + 2 cp 8
-        p.valu("v_mul_u32_u24", self.v_CM, 2 * LDB, vy)
-        p.valu("v_lshl_add_u32", self.v_CM, vx, 3, self.v_CM)            # 2 cp LDB + row 8
+        # direct elements (row, 2 cp), (row, 2 cp + 1): records pcol(2 cp) = cp and cp + 8, position qrow(row)
+        p.valu("v_and_b32", vpc, 3, vx)
+        p.valu("v_lshlrev_b32", vpc, 2, vpc)
+        p.valu("v_lshrrev_b32", self.v_CP, 2, vx)
+        p.valu("v_add_u32", vpc, vpc, self.v_CP)                         # qrow(row)
+        p.valu("v_mul_u32_u24", self.v_CP, LDB * (1 if self.PCOL_PERM else 2), vy)
+        p.valu("v_lshl_add_u32", self.v_CP, vpc, 3, self.v_CP)           # pcol(2 cp) LDB + 8 qrow(row)
+        # mirrored elements (2 cp, row), (2 cp + 1, row): record pcol(row), positions qrow(2 cp) = 8 (cp & 1) + (cp >> 1), + 4
+        self.v_pcol(vpc, vx, self.v_CM)                                  # pcol(row)
+        p.valu("v_mul_u32_u24", self.v_CM, LDB, vpc)
+        p.valu("v_and_b32", vpc, 1, vy)
+        p.valu("v_lshlrev_b32", vpc, 3, vpc)
+        p.valu("v_lshrrev_b32", vx, 1, vy)
+        p.valu("v_add_u32", vpc, vpc, vx)                                # qrow(2 cp)
+        p.valu("v_lshl_add_u32", self.v_CM, vpc, 3, self.v_CM)           # pcol(row) LDB + 8 qrow(2 cp)
         # diagonal elements of slot 0: register r of lane (c, rg) is row 4 r + rg of the diagonal tile
         for r in range(4):
             p.valu("v_add_u32", vx, 4 * r, vrg)
@@ -286,45 +365,71 @@ class Gen:
         p.s_branch("s_cbranch_scc1", "L_div")
         p.salu("s_mov_b32", self.s_cell, self.s_idx)
         p.salu("s_mov_b64", self.s_pmask, 0)
+        if self.diag:
+            p.s_load(2, self.s_diag, S(0, 2), 64)
+            p.salu("s_lshl_b32", t0, wg, 2)
+            p.salu("s_add_u32", t0, t0, self.s_wave)
+            p.salu("s_mul_i32", t0, t0, 8 * self.NSTAMP)
+            p.s_waitcnt(lgkm=0)
+            p.salu("s_add_u32", self.s_diag.sub(0), self.s_diag.sub(0), t0)
+            p.salu("s_addc_u32", self.s_diag.sub(1), self.s_diag.sub(1), 0)
 
     # ---- scalars of a cell ----
-    def cell_bases(self, kc, n):
-        """H0 / S bases and dt of cell (kc, n) -> s_hb, s_sb, s_dt (three scalar loads; caller waits)"""
+    def cell_bases_issue(self, kc, n):
+        """scalars of cell (kc, n), first half: k = rep ? rep[kc] : kc and dt are requested (no branch: without the class
+        table the load reads dts[0] and its result is discarded); S base"""
         p = self.p
         t0, t1 = self.s_tmp[0], self.s_tmp[1]
-        # k = rep ? rep[kc] : kc
-        p.salu("s_mov_b32", self.s_k, kc)
         p.s_cmp("s_cmp_lg_u64", self.s_rep, 0)
-        lab = f"L_norep_{len(p.ins)}"
-        p.s_branch("s_cbranch_scc0", lab)
+        p.salu("s_cselect_b32", self.s_t0.sub(0), self.s_rep.sub(0), self.s_dts.sub(0))
+        p.salu("s_cselect_b32", self.s_t0.sub(1), self.s_rep.sub(1), self.s_dts.sub(1))
         p.salu("s_lshl_b32", t0, kc, 2)
-        p.s_load(1, self.s_k, self.s_rep, t0)
-        p.label(lab)
+        p.salu("s_cselect_b32", t0, t0, 0)
+        p.s_load(1, self.s_k, self.s_t0, t0)
         p.salu("s_lshl_b32", t0, n, 3)
         p.s_load(2, self.s_dt, self.s_dts, t0)
         p.salu("s_lshl_b32", t0, n, 16)                                  # n * 2 NP^2 * 8 = n << 16
         p.salu("s_lshr_b32", t1, n, 16)
         p.salu("s_add_u32", self.s_sb.sub(0), self.s_Sf.sub(0), t0)
         p.salu("s_addc_u32", self.s_sb.sub(1), self.s_Sf.sub(1), t1)
+
+    def cell_bases_finish(self, kc):
+        """second half: H0 base from k (waits for the scalar loads)"""
+        p = self.p
+        t0, t1 = self.s_tmp[0], self.s_tmp[1]
         p.s_waitcnt(lgkm=0)
+        p.s_cmp("s_cmp_lg_u64", self.s_rep, 0)
+        p.salu("s_cselect_b32", self.s_k, self.s_k, kc)
         p.salu("s_lshl_b32", t0, self.s_k, 16)
         p.salu("s_lshr_b32", t1, self.s_k, 16)
         p.salu("s_add_u32", self.s_hb.sub(0), self.s_H0.sub(0), t0)
         p.salu("s_addc_u32", self.s_hb.sub(1), self.s_H0.sub(1), t1)
 
-    def fetch(self, u, dst):
-        """operator tiles u of the cell whose bases are in s_hb / s_sb: H0 re, H0 im, S re, S im (4 registers each)"""
+    def cell_bases(self, kc, n):
+        self.cell_bases_issue(kc, n)
+        self.cell_bases_finish(kc)
+
+    def fetch(self, u, dst, half=None):
+        """operator tiles u of the cell whose bases are in s_hb / s_sb: H0 re, H0 im (half 0), S re, S im (half 1),
+        4 registers each"""
         p = self.p
-        p.salu("s_add_u32", self.s_t0.sub(0), self.s_hb.sub(0), self.s_toff[u])
-        p.salu("s_addc_u32", self.s_t0.sub(1), self.s_hb.sub(1), 0)
-        p.salu("s_add_u32", self.s_t1.sub(0), self.s_sb.sub(0), self.s_toff[u])
-        p.salu("s_addc_u32", self.s_t1.sub(1), self.s_sb.sub(1), 0)
-        p.global_load(4, dst.sub(0, 4), self.v_GO, self.s_t0)
-        p.global_load(4, dst.sub(4, 4), self.v_GOI, self.s_t0)
-        p.global_load(4, dst.sub(8, 4), self.v_GO, self.s_t1)
-        p.global_load(4, dst.sub(12, 4), self.v_GOI, self.s_t1)
+        if half in (None, 0):
+            p.salu("s_add_u32", self.s_t0.sub(0), self.s_hb.sub(0), self.s_toff[u])
+            p.salu("s_addc_u32", self.s_t0.sub(1), self.s_hb.sub(1), 0)
+            p.global_load(4, dst.sub(0, 4), self.v_GO, self.s_t0)
+            p.global_load(4, dst.sub(4, 4), self.v_GOI, self.s_t0)
+        if half in (None, 1):
+            p.salu("s_add_u32", self.s_t1.sub(0), self.s_sb.sub(0), self.s_toff[u])
+            p.salu("s_addc_u32", self.s_t1.sub(1), self.s_sb.sub(1), 0)
+            p.global_load(4, dst.sub(8, 4), self.v_GO, self.s_t1)
+            p.global_load(4, dst.sub(12, 4), self.v_GOI, self.s_t1)
 
     def commit(self, pf):
+        self.p.tag = "commit"
+        self._commit(pf)
+        self.p.tag = ""
+
+    def _commit(self, pf):
         """A = -i dt (H0 + S) of the fetched tiles (pf[u]: 16 registers, either half of the file) into the three planes,
         both triangles (T18FormA::commit with the summed controls: xr = fma(1, s, h) = h + s)"""
         p = self.p
@@ -351,13 +456,15 @@ class Gen:
             (i0, j0), (i1, j1) = TILES[2 * u], TILES[2 * u + 1]
             va, vm = tc.sub(4), tc.sub(5)
             p.s_cmp("s_cmp_eq_u32", self.s_hi, 0)
-            self.ssel(self.s_tmp[0], 16 * i0 * LDB + 16 * j0 * 8, 16 * i1 * LDB + 16 * j1 * 8)
-            self.ssel(self.s_tmp[1], 16 * j0 * LDB + 16 * i0 * 8, 16 * j1 * LDB + 16 * i1 * 8)
+            self.ssel(self.s_tmp[0], 16 * j0 * LDB + 16 * i0 * 8, 16 * j1 * LDB + 16 * i1 * 8)      # direct: column block tj, rows ti
+            self.ssel(self.s_tmp[1], 16 * i0 * LDB + 16 * j0 * 8, 16 * i1 * LDB + 16 * j1 * 8)      # mirrored: column block ti, rows tj
             p.valu("v_add_u32", va, self.s_tmp[0], self.v_CP)
             p.valu("v_add_u32", vm, self.s_tmp[1], self.v_CM)
-            p.ds_write(128, va, ar, 0)
-            p.ds_write(128, va, ai, PLB)
-            p.ds_write(128, va, sm, 2 * PLB)
+            cstep = (8 if self.PCOL_PERM else 1) * LDB       # from column 2 cp to column 2 cp + 1
+            for e in range(2):
+                p.ds_write(64, va, ar.d(e), e * cstep)
+                p.ds_write(64, va, ai.d(e), e * cstep + PLB)
+                p.ds_write(64, va, sm.d(e), e * cstep + 2 * PLB)
             # mirrored tile a_ji = -conj(a_ij): re -> -ar, im -> ai, sum -> ai - ar; not for diagonal tiles
             d0, d1 = i0 == j0, i1 == j1
             if not (d0 and d1):
@@ -373,27 +480,28 @@ class Gen:
                     lab = f"L_mirror_{u}_{len(p.ins)}"
                     p.s_branch("s_cbranch_scc1", lab)
                 for e in range(2):
-                    p.ds_write(64, vm, nar.d(e), e * LDB)
-                    p.ds_write(64, vm, ai.d(e), e * LDB + PLB)
-                    p.ds_write(64, vm, ms.d(e), e * LDB + 2 * PLB)
+                    p.ds_write(64, vm, nar.d(e), 32 * e)
+                    p.ds_write(64, vm, ai.d(e), 32 * e + PLB)
+                    p.ds_write(64, vm, ms.d(e), 32 * e + 2 * PLB)
                 if d0 or d1:
                     p.label(lab)
         for t in (ta, tb, tc):
             self.vp.free(t)
 
     # ---- strips ----
-    def load_strip_A(self):
-        """A from the planes into the accumulation half: re, im, re + im, four slots each (right operand of A2 = A A)"""
-        p = self.p
-        self.As_re, self.As_im, self.As_sm = self.ap.alloc(4), self.ap.alloc(4), self.ap.alloc(4)
-        for sl in range(4):
-            for r in range(4):
-                for pl, S_ in enumerate((self.As_re, self.As_im, self.As_sm)):
-                    p.ds_read(64, S_.sub(8 * sl, 8).d(r), self.v_SA[sl], 4 * r * LDB + pl * PLB)
-
-    def product(self, Q, B, half_last=False, init=None, hook=None):
+    def product(self, Q, B, half_last=False, init=None, hook=None, bload=None, fused=None):
         """Q[so] = (p1, p2, p3) += X B over the rotated k order; X in the planes, B = (re, im, sm) tile lists by slot.
-        init: set of (so, j) accumulators that hold a start value (the others start from the literal 0)."""
+        init: set of (so, j) accumulators that hold a start value (the others start from the literal 0).
+        bload(pl, sk, r): the right operand of k-step (sk, r) comes from the planes too (A2 = A A) and is requested with the
+        left-operand fragments of that k-step.
+        fused = {valu(sl), stores(sl) -> thunks, after_first(), post()}: the linear combinations that FORM the left operand
+        are part of this product.  An LDS store moves its registers to the LDS at ~80 bytes per clock and CU whatever its
+        width (the three planes of a cell: 1.2 K cycles), and nothing but a matrix instruction hides that transfer.  So
+        k-block 0 -- the columns THIS wave writes; a wave's LDS operations execute in order, no barrier -- runs slot by
+        slot: valu(0), stores of row tile 0, valu(1), then the twelve matrix instructions of output slot 0 with the stores
+        of row tile 1 and the fragment requests of slot 1 in their shadow, valu(2), slot 1 with the stores of row tile 2,
+        ...  Only the first row tile's stores are exposed.  The barrier that makes the other waves' columns visible
+        stands behind k-block 0: the skew of the waves hides under its 48 matrix instructions."""
         p = self.p
         NS = len(Q)
         started = set(init or ())
@@ -402,39 +510,100 @@ class Gen:
             return NS - 1 if (half_last and 2 * sk >= NT) else NS
 
         def rd(pl, so, sk, r):
-            p.ds_read(64, self.aop[pl][so], self.v_AA[so][sk], 32 * r + pl * PLB)
+            p.tag = "fragment"
+            p.ds_read(64, self.aop[pl][so], self.v_AA[so][sk], self.KSTEP * r * LDB + pl * PLB)
+            p.tag = ""
 
-        for pl in range(3):
-            for so in range(NS):
-                rd(pl, so, 0, 0)
-        for sk in range(4):
+        def mma(so, pl, a, b):
+            acc = Q[so][pl]
+            c = acc if (so, pl) in started else 0
+            started.add((so, pl))
+            p.mfma(acc, a, b, c)
+
+        sk0 = 0
+        if fused:
+            assert NS == 4 and not half_last and not bload
+
+            def rdk(pl, so, r):      # k-block 0, slot by slot: the twelve fragment registers hold [plane][k-step] of ONE slot
+                p.tag = "fragment"
+                p.ds_read(64, self.aop[pl][r], self.v_AA[so][0], self.KSTEP * r * LDB + pl * PLB)
+                p.tag = ""
+
+            fused["valu"](0)
+            for st in fused["stores"](0):
+                st()
+            if fused.get("after_first"):
+                fused["after_first"]()
             for r in range(4):
-                if hook:
-                    hook(sk, r)
+                for pl in range(3):
+                    rdk(pl, 0, r)
+            for so in range(4):
+                gaps = [[] for _ in range(12)]       # what rides behind matrix instruction j = 3 r + pl of this slot
+                if so < 3:
+                    fused["valu"](so + 1)
+                    pend = list(fused["stores"](so + 1))          # (pl, h) in the order (0,0) (0,1) (1,0) (1,1) (2,0) (2,1)
+                    for q, st in enumerate(pend):
+                        gaps[4 * (q // 2) + (q % 2)].append(st)
+                    last = {pl: (4 * pl + 1 if pend else 0) for pl in range(3)}
+                    # fragment (pl, r) of the next slot: behind the two stores of its plane and behind the matrix
+                    # instruction that was the last reader of its register
+                    for r in range(4):
+                        for pl in range(3):
+                            gaps[max(last[pl], 3 * r + pl)].append(lambda pl=pl, r=r: rdk(pl, so + 1, r))
+                j = 0
+                for r in range(4):
+                    for pl in range(3):
+                        mma(so, pl, self.aop[pl][r], B[pl][0].d(r))
+                        for f in gaps[j]:
+                            f()
+                        j += 1
+            if fused.get("post"):
+                fused["post"]()
+            p.s_barrier()
+            sk0 = 1
+        for pl in range(3):
+            for so in range(nslots(sk0)):
+                rd(pl, so, sk0, 0)
+            if bload:
+                bload(pl, sk0, 0)
+        for sk in range(sk0, 4):
+            for r in range(4):
                 ns = nslots(sk)
                 more = not (sk == 3 and r == 3)
                 nsk, nr = (sk, r + 1) if r < 3 else (sk + 1, 0)
                 nsn = nslots(nsk) if more else 0
                 for pl in range(3):
                     for so in range(ns):
-                        acc = Q[so][pl]
-                        c = acc if (so, pl) in started else 0
-                        started.add((so, pl))
-                        p.mfma(acc, self.aop[pl][so], B[pl][sk].d(r), c)
+                        mma(so, pl, self.aop[pl][so], B[pl][sk].d(r))
+                        if hook and pl == 0 and so == 0:
+                            hook(sk, r)        # (behind the first matrix instruction of the k-step: its issue slots are free)
                     for so in range(nsn):
                         rd(pl, so, nsk, nr)
+                    if bload and more:
+                        bload(pl, nsk, nr)
 
-    def store_planes(self, sl, r, xr, xi, xs):
+    def plane_stores(self, sl, xr, xi, xs):
+        """the six 16-byte stores of row tile (w + sl) & 3 of this wave's column strip (xr, xi, xs: tiles), as thunks"""
+        if self.opts.get("nostore"):     # (ablation: results wrong)
+            return []
         a = self.v_SA[sl]
-        self.p.ds_write(64, a, xr, 4 * r * LDB)
-        self.p.ds_write(64, a, xi, 4 * r * LDB + PLB)
-        self.p.ds_write(64, a, xs, 4 * r * LDB + 2 * PLB)
 
-    @staticmethod
-    def interleave(streams):
+        def st(h, pl, x):
+            self.p.tag = "strip store"
+            self.p.ds_write(128, a, x.sub(4 * h, 4), 16 * h + pl * PLB)
+            self.p.tag = ""
+        # (plane by plane: the fragment requests of a plane follow its two stores)
+        return [lambda h=h, pl=pl, x=x: st(h, pl, x) for pl, x in enumerate((xr, xi, xs)) for h in range(2)]
+
+    def interleave(self, streams):
         """round-robin merge of independent instruction streams (lists of thunks): dependent fp64 instructions of one
         stream end up len(streams) issue slots apart"""
         streams = [list(s) for s in streams]
+        if self.opts.get("serial"):      # (ablation: no interleaving of the element streams)
+            for s in streams:
+                for f in s:
+                    f()
+            return
         while any(streams):
             for s in streams:
                 if s:
@@ -442,10 +611,18 @@ class Gen:
 
     def acc_read(self, dst, src):
         """a double from the accumulation half"""
+        if self.opts.get("noacc"):       # (ablation: results wrong)
+            self.p.valu("v_mov_b32", dst.sub(0), dst.sub(0))
+            self.p.valu("v_mov_b32", dst.sub(1), dst.sub(1))
+            return
         self.p.valu("v_accvgpr_read_b32", dst.sub(0), src.sub(0))
         self.p.valu("v_accvgpr_read_b32", dst.sub(1), src.sub(1))
 
     def acc_write(self, dst, src):
+        if self.opts.get("noacc"):
+            self.p.valu("v_mov_b32", src.sub(0), src.sub(0))
+            self.p.valu("v_mov_b32", src.sub(1), src.sub(1))
+            return
         self.p.valu("v_accvgpr_write_b32", dst.sub(0), src.sub(0))
         self.p.valu("v_accvgpr_write_b32", dst.sub(1), src.sub(1))
 
@@ -467,7 +644,6 @@ class Gen:
     def cell(self):
         p, c = self.p, self.s_c
         vp, ap = self.vp, self.ap
-        stop = self.stop_after
         Qt = [[V(8 * self.QT[3 * so + j], 8) for j in range(3)] for so in range(4)]   # Qt[so] = (p1, p2, p3)
         for t in self.QT:
             vp.free_tiles.remove(t)
@@ -476,27 +652,49 @@ class Gen:
             vp.free_tiles.remove(t)
 
         # ================= A2 = A A (Hermitian square: slots 0..2, slot 2 half) + stores of the previous result ==========
-        self.load_strip_A()
+        self.stamp(0)
+        self.As_re, self.As_im, self.As_sm = ap.alloc(4), ap.alloc(4), ap.alloc(4)
         As = (self.As_re, self.As_im, self.As_sm)
 
         def hook_store(sk, r):
-            if r != 0:
-                return
-            # slot sk of the previous result: four 16-byte stores per lane (t18_store_u_slot)
+            # element r of slot sk of the previous result: one 16-byte store per lane and k-step (t18_store_u_slot)
             p.salu("s_mov_b64", self.s_save, EXEC)
             p.salu("s_mov_b64", EXEC, self.s_pmask)
-            for rr in range(4):
-                p.global_store(4, self.v_UO1 if rr < 2 else self.v_UO2, Uprev.sub(16 * sk + 4 * rr, 4), self.s_ub[sk],
-                               -4096 if rr % 2 == 0 else 0, nt=False)
+            p.global_store(4, self.v_UO1 if r < 2 else self.v_UO2, Uprev.sub(16 * sk + 4 * r, 4), self.s_ub[sk],
+                           -4096 if r % 2 == 0 else 0)
             p.salu("s_mov_b64", EXEC, self.s_save)
 
+        def bload_A(pl, sk, r):
+            # the right operand of A2 = A A is A's own column strip: requested k-step by k-step into the accumulation
+            # half, where it stays for the linear combinations of the whole cell
+            if r % 2 == 0:
+                p.tag = "strip load"
+                p.ds_read(128, As[pl].sub(8 * sk + 2 * r, 4), self.v_SA[sk], 8 * r + pl * PLB)
+                p.tag = ""
+
         B_As = [[S_.sub(8 * sl, 8) for sl in range(4)] for S_ in As]
-        self.product(Qt[:3], B_As, half_last=True, hook=hook_store)
+        self.product(Qt[:3], B_As, half_last=True, hook=hook_store, bload=bload_A)
         ap.free(self.As_sm)
         vp.free(Uprev)
-        if stop == 1:
-            return self.bail(Qt)
-        # combine slots 0..2; A2 lives in the vector half (right operand of the second product)
+        self.stamp(1)
+        As_re, As_im = self.As_re, self.As_im
+
+        def A_(sl, r):          # A in the accumulation half
+            return As_re.sub(8 * sl, 8).d(r), As_im.sub(8 * sl, 8).d(r)
+
+        def in_place_y(sl_list):
+            """p1 <- p1 - p2 (real part), p3 <- p3 - p1 - p2 (imaginary part) of the 3M partial products"""
+            streams = []
+            for sl in sl_list:
+                for r in range(4):
+                    p1, p2, p3 = (Qt[sl][j].d(r) for j in range(3))
+                    streams.append([lambda p3=p3, p1=p1: p.valu("v_add_f64", p3, p3, Neg(p1)),
+                                    lambda p1=p1, p2=p2: p.valu("v_add_f64", p1, p1, Neg(p2)),
+                                    lambda p3=p3, p2=p2: p.valu("v_add_f64", p3, p3, Neg(p2))])
+            for g in range(0, len(streams), 4):
+                self.interleave(streams[g:g + 4])
+
+        # ---- A2: slots 0..2 from the partial products; A2 lives in the vector half (right operand of the second product) ----
         A2re, A2im, A2sm = [vp.alloc() for _ in range(4)], [vp.alloc() for _ in range(4)], [vp.alloc() for _ in range(4)]
         streams = []
         for sl in range(3):
@@ -512,60 +710,54 @@ class Gen:
         # reader conjugates
         for r in range(4):
             p.ds_write(64, self.v_EW2, A2re[2].d(r), 128 * r)
-            p.ds_write(64, self.v_EW2, A2im[2].d(r), 2048 + 128 * r)
+            p.ds_write(64, self.v_EW2, A2im[2].d(r), EXH + 128 * r)
             p.ds_write(64, self.v_EW1, A2re[1].d(r), 128 * r)
-            p.ds_write(64, self.v_EW1, A2im[1].d(r), 2048 + 128 * r)
+            p.ds_write(64, self.v_EW1, A2im[1].d(r), EXH + 128 * r)
         p.s_waitcnt(lgkm=0)
         p.s_barrier()                                   # (also: everybody is done reading A)
+        # scalars of the NEXT cell (its operator bases, dt): requested here, needed by the last product
+        self.advance()
+        self.cell_bases_issue(self.s_nkc, self.s_nn)
         txr, txi = vp.alloc(), vp.alloc()
         for h in range(2):
             p.ds_read(128, txr.sub(4 * h, 4), self.v_ER, 16 * h)
-            p.ds_read(128, txi.sub(4 * h, 4), self.v_ER, 2048 + 16 * h)
+            p.ds_read(128, txi.sub(4 * h, 4), self.v_ER, EXH + 16 * h)
             p.ds_read(128, A2re[3].sub(4 * h, 4), self.v_ER, (E2 - E1) + 16 * h)
-            p.ds_read(128, A2im[3].sub(4 * h, 4), self.v_ER, (E2 - E1) + 2048 + 16 * h)
-        for r in range(4):
-            p.valu("v_add_f64", A2re[2].d(r), A2re[2].d(r), txr.d(r))
-            p.valu("v_add_f64", A2im[2].d(r), A2im[2].d(r), Neg(txi.d(r)))
-        for r in range(4):
-            p.valu("v_mul_f64", A2im[3].d(r), A2im[3].d(r), -1.0)
-        vp.free(txr)
-        vp.free(txi)
-        # planes <- c1 A2 + c2 A ; A2.sm
-        tt = [vp.alloc(), vp.alloc()]
-        streams = []
-        for sl in range(4):
-            for r in range(4):
-                k = len(streams) % 4
-                asr, asi, xs = tt[k // 2].sub(4 * (k % 2), 4).d(0), tt[k // 2].sub(4 * (k % 2), 4).d(1), A2sm[sl].d(r)
-                # (xr, xi are formed in the registers of the A reads; xs borrows A2.sm's register before A2.sm is formed)
-                a2r, a2i = A2re[sl].d(r), A2im[sl].d(r)
-                ar_, ai_ = self.As_re.sub(8 * sl, 8).d(r), self.As_im.sub(8 * sl, 8).d(r)
-                st = [lambda asr=asr, ar_=ar_: self.acc_read(asr, ar_),
-                      lambda asi=asi, ai_=ai_: self.acc_read(asi, ai_),
-                      lambda asr=asr: p.valu("v_mul_f64", asr, c[2], asr),
-                      lambda asi=asi: p.valu("v_mul_f64", asi, c[2], asi),
-                      lambda asr=asr, a2r=a2r: p.valu("v_fma_f64", asr, c[1], a2r, asr),
-                      lambda asi=asi, a2i=a2i: p.valu("v_fma_f64", asi, c[1], a2i, asi),
-                      lambda xs=xs, asr=asr, asi=asi: p.valu("v_add_f64", xs, asr, asi),
-                      lambda sl=sl, r=r, asr=asr, asi=asi, xs=xs: self.store_planes(sl, r, asr, asi, xs)]
-                streams.append(st)
-        for g in range(0, 16, 4):
-            self.interleave(streams[g:g + 4])
-        for sl in range(4):
-            for r in range(4):
-                p.valu("v_add_f64", A2sm[sl].d(r), A2re[sl].d(r), A2im[sl].d(r))
-        for t in tt:
-            vp.free(t)
-        p.s_waitcnt(lgkm=0)
-        p.s_barrier()
-        if stop == 2:
-            return self.bail(Qt, extra_free=A2re + A2im + A2sm)
+            p.ds_read(128, A2im[3].sub(4 * h, 4), self.v_ER, (E2 - E1) + EXH + 16 * h)
+        self.stamp(2)
         # ================= y0 = (c1 A2 + c2 A) A2 =====================================================================
-        self.product(Qt, [A2re, A2im, A2sm])
-        for t in A2sm:
+        # (left operand in tt[0] / tt[1], its plane sum in the p2 accumulator of the slot, which restarts from the literal 0)
+        tt = [vp.alloc(), vp.alloc()]
+
+        def valu2(sl):
+            if sl == 2:     # slots 2 and 3 need what the other waves sent (requested behind the barrier)
+                for r in range(4):
+                    p.valu("v_add_f64", A2re[2].d(r), A2re[2].d(r), txr.d(r))
+                    p.valu("v_add_f64", A2im[2].d(r), A2im[2].d(r), Neg(txi.d(r)))
+                for r in range(4):
+                    p.valu("v_mul_f64", A2im[3].d(r), A2im[3].d(r), -1.0)
+                vp.free(txr)
+                vp.free(txi)
+            streams = []
+            for r in range(4):
+                xr, xi, xs = tt[0].d(r), tt[1].d(r), Qt[sl][1].d(r)
+                a2r, a2i = A2re[sl].d(r), A2im[sl].d(r)
+                ar_, ai_ = A_(sl, r)
+                streams.append([lambda xr=xr, ar_=ar_: self.acc_read(xr, ar_),
+                                lambda xi=xi, ai_=ai_: self.acc_read(xi, ai_),
+                                lambda xr=xr: p.valu("v_mul_f64", xr, c[2], xr),
+                                lambda xi=xi: p.valu("v_mul_f64", xi, c[2], xi),
+                                lambda xr=xr, a2r=a2r: p.valu("v_fma_f64", xr, c[1], a2r, xr),
+                                lambda xi=xi, a2i=a2i: p.valu("v_fma_f64", xi, c[1], a2i, xi),
+                                lambda xs=xs, xr=xr, xi=xi: p.valu("v_add_f64", xs, xr, xi),
+                                lambda r=r, a2r=a2r, a2i=a2i: p.valu("v_add_f64", A2sm[sl].d(r), a2r, a2i)])
+            self.interleave(streams)
+
+        self.product(Qt, [A2re, A2im, A2sm], fused={"valu": valu2, "stores": lambda sl: self.plane_stores(sl, tt[0], tt[1], Qt[sl][1])})
+        for t in tt + A2sm:
             vp.free(t)
-        if stop == 3:
-            return self.bail(Qt, extra_free=A2re + A2im)
+        self.cell_bases_finish(self.s_nkc)
+        self.stamp(3)
         # ---- y0 in place (p1 <- re, p3 <- im), sums for the spectral bound ----
         facc, gacc, cacc = vp.alloc(), vp.alloc(), vp.alloc()        # f0..f3, g0..g3, column sums (4 streams)
         for acc in (facc, gacc, cacc):
@@ -623,6 +815,7 @@ class Gen:
             vp.free(t)
         p.s_waitcnt(lgkm=0)
         p.s_barrier()                                   # everybody is done reading the planes; the sums are published
+        self.stamp(4)
         # ---- verdict of the spectral bound (every lane computes the same numbers) ----
         vtf, vtg, vt2, vz = vp.alloc(), vp.alloc(), vp.alloc(), vp.alloc()
         p.valu("v_mov_b32", vz.sub(0), RED)
@@ -664,38 +857,37 @@ class Gen:
         p.salu("s_mov_b64", EXEC, self.s_save)
         for t in (vtf, vtg, vt2, vz):
             vp.free(t)
-        # ---- planes <- y0 + c3 A2 + c4 A; right operand y0 + c5 A2; start values c6 y0 + c7 A2; A2 parked ----
+        # ================= y1 = (y0 + c3 A2 + c4 A)(y0 + c5 A2) + c6 y0 + c7 A2 ======================================
+        # planes <- y0 + c3 A2 + c4 A; right operand y0 + c5 A2; start values c6 y0 + c7 A2; A2 parked in the accumulation half
         self.A2p_re, self.A2p_im = ap.alloc(4), ap.alloc(4)
         Bre, Bim, Bsm = [None] * 4, [None] * 4, [None] * 4
         tt = [vp.alloc(), vp.alloc()]
-        for sl in range(4):
+
+        def valu3(sl):
             Bre[sl], Bim[sl], Bsm[sl] = vp.alloc(), vp.alloc(), vp.alloc()
             streams = []
             for r in range(4):
-                k = r
-                y0r, p2, y0i = (Qt[sl][j].d(r) for j in range(3))
+                y0r, xs, y0i = (Qt[sl][j].d(r) for j in range(3))       # (p2 is dead: it restarts from the literal 0)
                 a2r, a2i = A2re[sl].d(r), A2im[sl].d(r)
-                asr, asi = tt[k // 2].sub(4 * (k % 2), 4).d(0), tt[k // 2].sub(4 * (k % 2), 4).d(1)
-                xs = p2                                             # (p2 is dead: it restarts from the literal 0)
+                xr, xi = tt[0].d(r), tt[1].d(r)
                 br, bi, bs = Bre[sl].d(r), Bim[sl].d(r), Bsm[sl].d(r)
-                ar_, ai_ = self.As_re.sub(8 * sl, 8).d(r), self.As_im.sub(8 * sl, 8).d(r)
+                ar_, ai_ = A_(sl, r)
                 pr, pi_ = self.A2p_re.sub(8 * sl, 8).d(r), self.A2p_im.sub(8 * sl, 8).d(r)
                 streams.append([
-                    lambda asr=asr, ar_=ar_: self.acc_read(asr, ar_),
-                    lambda asi=asi, ai_=ai_: self.acc_read(asi, ai_),
+                    lambda xr=xr, ar_=ar_: self.acc_read(xr, ar_),
+                    lambda xi=xi, ai_=ai_: self.acc_read(xi, ai_),
                     lambda pr=pr, a2r=a2r: self.acc_write(pr, a2r),
                     lambda pi_=pi_, a2i=a2i: self.acc_write(pi_, a2i),
                     lambda br=br, a2r=a2r, y0r=y0r: p.valu("v_fma_f64", br, c[5], a2r, y0r),
                     lambda bi=bi, a2i=a2i, y0i=y0i: p.valu("v_fma_f64", bi, c[5], a2i, y0i),
-                    lambda asr=asr: p.valu("v_mul_f64", asr, c[4], asr),
-                    lambda asi=asi: p.valu("v_mul_f64", asi, c[4], asi),
-                    lambda asr=asr, a2r=a2r: p.valu("v_fma_f64", asr, c[3], a2r, asr),
-                    lambda asi=asi, a2i=a2i: p.valu("v_fma_f64", asi, c[3], a2i, asi),
-                    lambda asr=asr, y0r=y0r: p.valu("v_add_f64", asr, asr, y0r),
-                    lambda asi=asi, y0i=y0i: p.valu("v_add_f64", asi, asi, y0i),
+                    lambda xr=xr: p.valu("v_mul_f64", xr, c[4], xr),
+                    lambda xi=xi: p.valu("v_mul_f64", xi, c[4], xi),
+                    lambda xr=xr, a2r=a2r: p.valu("v_fma_f64", xr, c[3], a2r, xr),
+                    lambda xi=xi, a2i=a2i: p.valu("v_fma_f64", xi, c[3], a2i, xi),
+                    lambda xr=xr, y0r=y0r: p.valu("v_add_f64", xr, xr, y0r),
+                    lambda xi=xi, y0i=y0i: p.valu("v_add_f64", xi, xi, y0i),
                     lambda bs=bs, br=br, bi=bi: p.valu("v_add_f64", bs, br, bi),
-                    lambda xs=xs, asr=asr, asi=asi: p.valu("v_add_f64", xs, asr, asi),
-                    lambda sl=sl, r=r, asr=asr, asi=asi, xs=xs: self.store_planes(sl, r, asr, asi, xs),
+                    lambda xs=xs, xr=xr, xi=xi: p.valu("v_add_f64", xs, xr, xi),
                     # start values: p1 <- c6 y0.re + c7 A2.re, p3 <- p1 + c6 y0.im + c7 A2.im
                     lambda y0r=y0r: p.valu("v_mul_f64", y0r, c[6], y0r),
                     lambda y0i=y0i: p.valu("v_mul_f64", y0i, c[6], y0i),
@@ -705,43 +897,33 @@ class Gen:
             self.interleave(streams)
             vp.free(A2re[sl])
             vp.free(A2im[sl])
+
+        init13 = {(so, j) for so in range(4) for j in (0, 2)}
+        self.stamp(5)
+        self.product(Qt, [Bre, Bim, Bsm], init=init13,
+                     fused={"valu": valu3, "stores": lambda sl: self.plane_stores(sl, tt[0], tt[1], Qt[sl][1])})
         for t in tt:
             vp.free(t)
-        p.s_waitcnt(lgkm=0)
-        p.s_barrier()
-        if stop == 4:
-            return self.bail(Qt, extra_free=Bre + Bim + Bsm, parked=True)
-        # ================= y1 = (y0 + c3 A2 + c4 A)(y0 + c5 A2) + c6 y0 + c7 A2 ======================================
-        init13 = {(so, j) for so in range(4) for j in (0, 2)}
-        self.product(Qt, [Bre, Bim, Bsm], init=init13)
-        if stop == 5:
-            return self.bail(Qt, extra_free=Bre + Bim + Bsm, parked=True)
+        self.stamp(6)
         # ---- y1 in place ----
-        streams = []
-        for sl in range(4):
-            for r in range(4):
-                p1, p2, p3 = (Qt[sl][j].d(r) for j in range(3))
-                streams.append([lambda p3=p3, p1=p1: p.valu("v_add_f64", p3, p3, Neg(p1)),
-                                lambda p1=p1, p2=p2: p.valu("v_add_f64", p1, p1, Neg(p2)),
-                                lambda p3=p3, p2=p2: p.valu("v_add_f64", p3, p3, Neg(p2))])
-        for g in range(0, 16, 4):
-            self.interleave(streams[g:g + 4])
+        in_place_y(range(4))
         p.s_barrier()                                   # everybody is done reading the planes
-        # ---- planes <- y1 + c8 A2 + c9 A; right operand y1 + c10 y0 + c11 A (in place of y0 + c5 A2);
-        #      start values c12 y1 + c13 y0 + c14 A2 + c15 A + c16 I ----
+        self.stamp(7)
+        # ================= p = (y1 + c8 A2 + c9 A)(y1 + c10 y0 + c11 A) + c12 y1 + c13 y0 + c14 A2 + c15 A + c16 I ==========
+        # planes <- y1 + c8 A2 + c9 A (real part in B.sm's registers, imaginary part in p2's, the plane sum in tt[0]);
+        # right operand y1 + c10 y0 + c11 A in place of y0 + c5 A2; start values in place of y1
+        self.stamp(8)
         k16 = S(58, 2)
         self.smov64(k16, self.c["C16"])
         tt = [vp.alloc() for _ in range(4)]
-        for sl in range(4):
+
+        def valu4(sl):
             streams = []
             for r in range(4):
-                k = r
-                y1r, p2, y1i = (Qt[sl][j].d(r) for j in range(3))
-                br, bi, bs = Bre[sl].d(r), Bim[sl].d(r), Bsm[sl].d(r)
-                T = tt[k]
-                asr, asi, a2r, a2i = T.d(0), T.d(1), T.d(2), T.d(3)
-                xr, xi, xs = bs, p2, None
-                ar_, ai_ = self.As_re.sub(8 * sl, 8).d(r), self.As_im.sub(8 * sl, 8).d(r)
+                y1r, xi, y1i = (Qt[sl][j].d(r) for j in range(3))
+                br, bi, xr = Bre[sl].d(r), Bim[sl].d(r), Bsm[sl].d(r)
+                asr, asi, a2r, a2i = tt[0].d(r), tt[1].d(r), tt[2].d(r), tt[3].d(r)
+                ar_, ai_ = A_(sl, r)
                 pr, pi_ = self.A2p_re.sub(8 * sl, 8).d(r), self.A2p_im.sub(8 * sl, 8).d(r)
                 st = [
                     lambda asr=asr, ar_=ar_: self.acc_read(asr, ar_),
@@ -751,16 +933,12 @@ class Gen:
                     # y0 = (y0 + c5 A2) - c5 A2, in place
                     lambda br=br, a2r=a2r: p.valu("v_fma_f64", br, c[5], Neg(a2r), br),
                     lambda bi=bi, a2i=a2i: p.valu("v_fma_f64", bi, c[5], Neg(a2i), bi),
-                    # left operand -> planes (xr in B.sm's register, xi in p2's, the sum over xr)
+                    # left operand
                     lambda xr=xr, a2r=a2r, y1r=y1r: p.valu("v_fma_f64", xr, c[8], a2r, y1r),
                     lambda xi=xi, a2i=a2i, y1i=y1i: p.valu("v_fma_f64", xi, c[8], a2i, y1i),
                     lambda xr=xr, asr=asr: p.valu("v_fma_f64", xr, c[9], asr, xr),
                     lambda xi=xi, asi=asi: p.valu("v_fma_f64", xi, c[9], asi, xi),
-                ]
-                # the sum needs a register of its own until the stores have read it: a2r / a2i are still needed, so the
-                # start values are formed first into a2r / a2i ... order below
-                st += [
-                    # start values: vr = c12 y1r + c13 y0r + c14 a2r + c15 asr  (accumulated in a2r's register)
+                    # start values: vr = c14 a2r + c15 asr + c13 y0r + c12 y1r (terms of order one: no cancellation)
                     lambda a2r=a2r: p.valu("v_mul_f64", a2r, c[14], a2r),
                     lambda a2i=a2i: p.valu("v_mul_f64", a2i, c[14], a2i),
                     lambda a2r=a2r, asr=asr: p.valu("v_fma_f64", a2r, c[15], asr, a2r),
@@ -774,9 +952,8 @@ class Gen:
                     lambda bi=bi, y1i=y1i: p.valu("v_fma_f64", bi, c[10], bi, y1i),
                     lambda br=br, asr=asr: p.valu("v_fma_f64", br, c[11], asr, br),
                     lambda bi=bi, asi=asi: p.valu("v_fma_f64", bi, c[11], asi, bi),
-                    # the plane sum into A's (now dead) register, then the three stores
+                    # the plane sum into A's (now dead) register
                     lambda asr=asr, xr=xr, xi=xi: p.valu("v_add_f64", asr, xr, xi),
-                    lambda sl=sl, r=r, xr=xr, xi=xi, asr=asr: self.store_planes(sl, r, xr, xi, asr),
                 ]
                 if sl == 0:
                     def diag(a2r=a2r, r=r):
@@ -791,30 +968,31 @@ class Gen:
                 ]
                 streams.append(st)
             self.interleave(streams)
-        # B.sm (its registers carried the left operand until the stores had read them: the stores are issued, and the
-        # hazard tracker keeps the overwrite two states behind them)
-        for sl in range(4):
-            for r in range(4):
-                p.valu("v_add_f64", Bsm[sl].d(r), Bre[sl].d(r), Bim[sl].d(r))
+
+        def bsm(sl_list):
+            # B.sm: its registers carried the real part of the left operand until the stores of that row tile were issued
+            for sl in sl_list:
+                for r in range(4):
+                    p.valu("v_add_f64", Bsm[sl].d(r), Bre[sl].d(r), Bim[sl].d(r))
+
+        pf = [ap.alloc(2) for _ in range(5)]
+
+        def hook_fetch(sk, r):
+            # two 16-byte loads per lane and k-step, k-steps 4..13: operator tiles u of the next cell
+            ki = 4 * sk + r - 4
+            if 0 <= ki < 10:
+                self.fetch(ki // 2, pf[ki // 2], half=ki % 2)
+
+        self.product(Qt, [Bre, Bim, Bsm], init=init13, hook=hook_fetch,
+                     fused={"valu": valu4, "stores": lambda sl: self.plane_stores(sl, Bsm[sl], Qt[sl][1], tt[0]),
+                            "after_first": lambda: bsm([0]), "post": lambda: bsm([1, 2, 3])})
         for t in tt:
             vp.free(t)
         ap.free(self.A2p_re)
         ap.free(self.A2p_im)
-        p.s_waitcnt(lgkm=0)
-        p.s_barrier()
-        if stop == 6:
-            return self.bail(Qt, extra_free=Bre + Bim + Bsm)
-        # ================= p = (y1 + c8 A2 + c9 A)(y1 + c10 y0 + c11 A) + ... ; the next cell's operator tiles ==========
-        pf = [ap.alloc(2) for _ in range(5)]
-
-        def hook_fetch(sk, r):
-            if sk == 1 and r == 0:
-                for u in range(5):
-                    self.fetch(u, pf[u])
-
-        self.product(Qt, [Bre, Bim, Bsm], init=init13, hook=hook_fetch)
         for t in Bre + Bim + Bsm:
             vp.free(t)
+        self.stamp(9)
         ap.free(self.As_re)
         ap.free(self.As_im)
         # ---- result, interleaved (re, im) per element: the layout of the 16-byte stores ----
@@ -830,25 +1008,7 @@ class Gen:
         for g in range(0, 16, 4):
             self.interleave(streams[g:g + 4])
         p.s_barrier()                                   # everybody is done reading the planes
-        self.end_of_cell(pf, Qt, Un)
-
-    def bail(self, Qt, extra_free=(), parked=False):
-        """diagnostic truncation: release what the skipped phases would have released; the result is garbage"""
-        vp, ap = self.vp, self.ap
-        for t in extra_free:
-            vp.free(t)
-        if parked:
-            ap.free(self.A2p_re)
-            ap.free(self.A2p_im)
-        ap.free(self.As_re)
-        ap.free(self.As_im)
-        if self.stop_after == 1:
-            pass
-        Un = vp.alloc(8, at=self.UT)
-        pf = [ap.alloc(2) for _ in range(5)]
-        for u in range(5):
-            self.fetch(u, pf[u])
-        self.p.s_barrier()
+        self.stamp(10)
         self.end_of_cell(pf, Qt, Un)
 
     def end_of_cell(self, pf, Qt, Un):
@@ -856,12 +1016,13 @@ class Gen:
         self.commit(pf)
         for x in pf:
             ap.free(x)
-        vp.free(Un)
+        p.s_waitcnt(vm=0, lgkm=0)
+        p.s_barrier()
+        self.stamp(11)
+        vp.free(Un)           # (the result stays where it is: the next cell's first product stores it)
         for t in self.QT:
             vp.free_tiles.append(t)
         vp.free_tiles.sort()
-        p.s_waitcnt(vm=0, lgkm=0)
-        p.s_barrier()
 
     # -----------------------------------------------------------------------------------------------------------------
     def advance(self):
@@ -913,8 +1074,6 @@ class Gen:
         p.s_waitcnt(vm=0, lgkm=0)
         p.s_barrier()
         p.label("L_cell")
-        self.advance()
-        self.cell_bases(self.s_nkc, self.s_nn)          # bases and dt of the NEXT cell (used by the last product / commit)
         self.cell()
         # loop-carried scalars
         self.u_bases(self.s_cell)

@@ -124,34 +124,45 @@ __global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *ve
     __shared__ double red[264];
     __shared__ int todo[256], ntodo;
     __shared__ unsigned long long cnt[8];   // squarings, max, orders 0..4, accepted cells
-    const int tid = threadIdx.x, ncell = a.K * a.N_T;
+    const int tid = threadIdx.x, lane = tid & 63, ncell = a.K * a.N_T;
     if (tid < 8) cnt[tid] = 0;
     if (tid == 0) ntodo = 0;
     __syncthreads();
-    auto credit = [&](double nA) {          // what Julia's exp! would do for this cell (order and squarings from ||A||_1)
-        int sj = 0;
-        if (nA > 5.4) {
-            const double r = nA / 5.4;
-            const int e = ilogb(r);
-            sj = (r == ldexp(1.0, e)) ? e : e + 1;
-        }
-        const int oj = nA > 2.1 ? 4 : nA > 0.95 ? 3 : nA > 0.25 ? 2 : nA > 0.015 ? 1 : 0;
-        if (sj) { atomicAdd(&cnt[0], (unsigned long long)sj); atomicMax(&cnt[1], (unsigned long long)sj); }
-        atomicAdd(&cnt[2 + oj], 1ull);
+    // what Julia's exp! would do for a cell (order and squarings from ||A||_1), as in the cell loop of expm_t18_kernel
+    auto order_of = [](double nA) { return nA > 2.1 ? 4 : nA > 0.95 ? 3 : nA > 0.25 ? 2 : nA > 0.015 ? 1 : 0; };
+    auto squarings_of = [](double nA) {
+        if (!(nA > 5.4)) return 0;
+        const double r = nA / 5.4;
+        const int e = ilogb(r);
+        return (r == ldexp(1.0, e)) ? e : e + 1;
     };
     const int cell = blockIdx.x * 256 + tid;
-    if (cell < ncell) {
-        const double bound = expm_norm_bound(a, cell);
-        if (bound > 2.1 && bound <= 5.4) credit(bound);
-        else todo[atomicAdd(&ntodo, 1)] = cell;
-        if (verdict[cell]) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
-        else atomicAdd(&cnt[7], 1ull);
+    const bool valid = cell < ncell;
+    double bound = 0.0;
+    bool cert = false, ok = false;
+    if (valid) {
+        bound = expm_norm_bound(a, cell);
+        cert = bound > 2.1 && bound <= 5.4;
+        ok = verdict[cell] == 0;
+        if (!cert) todo[atomicAdd(&ntodo, 1)] = cell;
+        if (!ok) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
+    }
+    // (counts per wave by ballot: one shared-memory atomic per wave and counter instead of one per thread -- with every
+    // thread on the same counter this kernel took 0.6 ms at the headline configuration)
+    const unsigned long long m_cert = __ballot(cert), m_ok = __ballot(valid && ok);
+    if (lane == 0) {
+        if (m_cert) atomicAdd(&cnt[2 + 4], (unsigned long long)__popcll(m_cert));   // certified cells: order 13, no squaring
+        if (m_ok) atomicAdd(&cnt[7], (unsigned long long)__popcll(m_ok));
     }
     __syncthreads();
     const int nt = ntodo;
-    for (int q = 0; q < nt; ++q) {
+    for (int q = 0; q < nt; ++q) {          // cells outside the certifying window: the measured norm
         const double nA = t16_post_norm1(a, todo[q], red, tid);
-        if (tid == 0) credit(nA);
+        if (tid == 0) {
+            const int sj = squarings_of(nA);
+            if (sj) { cnt[0] += (unsigned long long)sj; cnt[1] = max(cnt[1], (unsigned long long)sj); }
+            cnt[2 + order_of(nA)] += 1ull;
+        }
     }
     __syncthreads();
     if (tid == 0) {
