@@ -881,7 +881,7 @@ class Emu:
             sa = a - (1 << 32) if a >> 31 else a
             sb = b - (1 << 32) if b >> 31 else b
             w.scc = int({"s_cmp_lt_i32": sa < sb, "s_cmp_ge_i32": sa >= sb, "s_cmp_eq_u32": a == b, "s_cmp_lg_u32": a != b,
-                         "s_cmp_lt_u32": a < b, "s_cmp_ge_u32": a >= b, "s_cmp_gt_i32": sa > sb, "s_cmp_le_i32": sa <= sb,
+                         "s_cmp_lt_u32": a < b, "s_cmp_ge_u32": a >= b, "s_cmp_gt_u32": a > b, "s_cmp_le_u32": a <= b, "s_cmp_gt_i32": sa > sb, "s_cmp_le_i32": sa <= sb,
                          "s_cmp_eq_i32": a == b, "s_cmp_lg_i32": a != b}[op])
         elif op == "s_cselect_b32":
             self.wr_s32(w, d, self.rd_s32(w, s[0]) if w.scc else self.rd_s32(w, s[1]))

@@ -333,6 +333,13 @@ class Gen:
         wg = S(2)
         t0, t1, t2 = self.s_tmp[0], self.s_tmp[1], self.s_tmp[2]
         p.salu("s_mul_i32", t2, self.s_KC, self.s_NT)                    # ncell
+        # the plan of this evaluation (t16_plan_kernel): more than a quarter of the cells predicted beyond the range of
+        # the four-product route -> the route is not tried, the five-product launch behind this kernel walks all cells
+        p.s_load(2, self.s_t0, S(0, 2), 72)
+        p.s_load(1, self.s_tmp[3], self.s_t0, 24)                        # flags[6]
+        p.salu("s_lshl_b32", self.s_tmp[3], self.s_tmp[3], 2)
+        p.s_cmp("s_cmp_gt_u32", self.s_tmp[3], t2)
+        p.s_branch("s_cbranch_scc1", "L_end")
         p.salu("s_and_b32", t0, wg, 7)
         p.salu("s_mul_i32", t1, t0, t2)
         p.salu("s_lshr_b32", t1, t1, 3)                                  # lo

@@ -75,12 +75,12 @@ struct grape_handle {
     bool t18_small = true;       // ... also for N <= 32 (GRAPE_EXPM_T18_SMALL=0: the Pade kernels there)
     // four-product degree-16 route for Hermitian generators at 16 < N <= 64 (GRAPE_EXPM_T16=0: off).  Cells whose spectral
     // bound is beyond its range are listed by the kernel and redone by a launch of the degree-18 variant behind it (four
-    // products lost per listed cell), so the route is only TRIED while it pays: grape_check reads how many cells of the last
-    // evaluation were listed; above a quarter the next t16_hold evaluations go straight to the degree-18 route, then one
-    // probes again.
-    bool t16 = true, t16_live = true;
-    int t16_hold = 0;
-    long t16_tried = 0, t16_fell = 0;   // of the last evaluation that tried
+    // products lost per listed cell), so the route is only TRIED where it pays -- decided per evaluation ON THE DEVICE from
+    // the pulse values alone (t16_plan_kernel: a spectral-radius estimate from the Gram matrices below); no state of the
+    // handle enters, the same pulses always take the same route (round-3 advisor finding: the host-side switch of round 3
+    // made the bits of an evaluation depend on the evaluations before it).
+    bool t16 = true;
+    double *d_gram = nullptr;           // [KC][(L + 1)^2] Re tr(O_a^dagger O_b), O = (H0_k, H_1 .. H_L) of every generator class
     int *d_celllist = nullptr;          // [KC * N_T] the listed cells (counter: d_flags[4])
     // the four-product route as hand-allocated assembly (asm/gen_t16.py; GRAPE_EXPM_ASM=0: the C++ kernel): four tiles
     // per side, Hermitian generators, controls shared by the trajectories
@@ -878,7 +878,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_Sf, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -1283,7 +1283,28 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * NP * NP));
     // (N <= 16 stays with five products: one tile per side is latency-bound -- the kernel gains nothing from the shorter
     // polynomial and the second launch costs 10 us of an evaluation of 0.4 ms; measured at C2: 0.079 -> 0.098 ms)
-    if (h->t16 && h->t18 && h->herm && !h->large && !h->series && (h->NT >= 3 || (h->NT == 2 && h->t18_small))) CCHK(dmalloc(&h->d_celllist, (size_t)K * N_T));
+    if (h->t16 && h->t18 && h->herm && !h->large && !h->series && (h->NT >= 3 || (h->NT == 2 && h->t18_small))) {
+        CCHK(dmalloc(&h->d_celllist, (size_t)K * N_T));
+        // Gram matrices of the operators of every generator class (plan of the four-product route, t16_plan_kernel)
+        const int M = L + 1, KCn = h->KC;
+        std::vector<double> gram((size_t)KCn * M * M);
+        std::vector<int> repk(KCn, -1);
+        for (int k = K - 1; k >= 0; --k) repk[h->cls.empty() ? k : h->cls[k]] = k;   // first trajectory of the class
+        const size_t nn2 = (size_t)2 * N * N;
+        for (int kc = 0; kc < KCn; ++kc) {
+            const int k = repk[kc] < 0 ? kc : repk[kc];
+            auto op = [&](int a) { return a == 0 ? p->H0 + (size_t)k * nn2 : p->Hc + ((size_t)(p->hc_per_traj ? k : 0) * L + (a - 1)) * nn2; };
+            for (int a = 0; a < M; ++a)
+                for (int b = a; b < M; ++b) {
+                    const double *x = op(a), *y = op(b);
+                    double sum = 0.;
+                    for (size_t i = 0; i < nn2; ++i) sum += x[i] * y[i];
+                    gram[((size_t)kc * M + a) * M + b] = gram[((size_t)kc * M + b) * M + a] = sum;
+                }
+        }
+        CCHK(dmalloc(&h->d_gram, gram.size()));
+        CCHK(hipMemcpy(h->d_gram, gram.data(), gram.size() * 8, hipMemcpyHostToDevice));
+    }
     if (h->large && h->series) {
         // cooperative polynomial sweeps (grape_cheby.hip.h): S = NP / 16 siblings per trajectory on one XCD, at most one
         // workgroup per CU; the trajectories go through the kernel in rounds of `cheby_round`
@@ -1398,8 +1419,15 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                     HIPCHK(h, hipGetLastError());
                     ea.Sf = h->d_Sf;
                 }
-                const bool t16 = h->d_celllist && h->t16_live;
+                const bool t16 = h->d_celllist != nullptr;
                 ea.cell_list = h->d_celllist; ea.listed = 0;
+                if (t16) {   // the plan of this evaluation: flags[6] = cells predicted beyond the range of the four-product route
+                    T16PlanArgs pa{};
+                    pa.gram = h->d_gram; pa.eps = h->d_eps; pa.shape = h->d_shape; pa.dts = h->d_dts; pa.flags = h->d_flags;
+                    pa.KC = h->KC; pa.L = h->L; pa.N_T = h->N_T; pa.N = h->N;
+                    hipLaunchKernelGGL(t16_plan_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, pa);
+                    HIPCHK(h, hipGetLastError());
+                }
                 // (three tiles per side, four-product variant: 256 registers and 72 KB -- two workgroups per CU)
                 const int blocks16 = (t16 && h->NT == 3) ? 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * 2, (ncell + 7) / 8)) : t18_blocks;
                 if (t16 && h->asm16)   // (the verdicts of the assembly kernel go through the flag array of the Pade path)
@@ -1719,13 +1747,6 @@ int *pinned_flags(grape_handle *h) {
 int digest_flags(grape_handle *h, const int *flags) {
     // blocked path: the squaring plan follows the counts seen on the device (one spare launch costs microseconds)
     if (h->large && !h->series) h->sq_plan = std::max(2, flags[1] + 1);
-    // four-product route: tried in the evaluation just checked (flags[5] cells, flags[4] of them fell back)?
-    if (flags[5] > 0) {
-        h->t16_tried = flags[5]; h->t16_fell = flags[4];
-        if (4L * flags[4] > (long)flags[5]) { h->t16_live = false; h->t16_hold = 32; }
-    } else if (!h->t16_live && --h->t16_hold <= 0) {
-        h->t16_live = true;
-    }
     return status_from_flags(h, flags[0]);
 }
 

@@ -78,6 +78,44 @@ struct ExpmArgs {
 #endif
 };
 
+// ---- which cells may take the four-product route (grape_t18.hip.h, asm/gen_t16.py) ----
+// The route certifies a cell by a bound on its spectral radius and hands the others to the five-product route, at the
+// price of the four products already spent.  Whether it is TRIED is decided per evaluation, on the device, from the pulse
+// values alone (no history of the handle enters: the same pulses take the same route and give the same bits):
+//     ||H_kn dt||_F^2 = dt^2 e^T G_k e,   e = (1, eps_n1 s_n1, .., eps_nL s_nL),   G_k[a][b] = Re tr(O_a^dagger O_b)
+// (Gram matrix of the operators of generator class k, from grape_create), and for a spectrum that fills [-R, R] like a
+// semicircle sum lam^2 = N R^2 / 4, i.e. R_est = 2 ||H dt||_F / sqrt(N).  flags[6] counts the cells with
+// R_est > T16_PLAN_R (NaN included); when they are more than a quarter of the evaluation the four-product kernels leave
+// at once and the five-product launch behind them walks all cells instead of a hand-over list (t16_skipped()).
+// The estimate decides speed only: a cell it lets through is still certified (or handed over) by the kernel's own bound.
+#define T16_PLAN_R 1.12   // the kernel's bound m8^(1/8) is ~1.17 R for a semicircle: 1.17 * 1.12 * 1.03 < 1.36
+struct T16PlanArgs {
+    const double *gram;   // [KC][(L + 1)^2]
+    const double *eps, *shape, *dts;
+    int *flags;
+    int KC, L, N_T, N;
+};
+__global__ void __launch_bounds__(256) t16_plan_kernel(T16PlanArgs a) {
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    bool out = false;
+    if (cell < a.KC * a.N_T) {
+        const int kc = cell / a.N_T, n = cell - kc * a.N_T, M = a.L + 1;
+        const double *G = a.gram + (size_t)kc * M * M;
+        double e[9];
+        e[0] = 1.0;
+        for (int l = 0; l < a.L; ++l) e[1 + l] = a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0);
+        double m2 = 0.;
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < M; ++j) m2 += e[i] * e[j] * G[i * M + j];
+        const double dt = a.dts[n];
+        const double r = 2.0 * fabs(dt) * sqrt(fmax(m2, 0.0) / (double)a.N);
+        out = !(r <= T16_PLAN_R);
+    }
+    const unsigned long long m = __ballot(out);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[6], (int)__popcll(m));
+}
+__device__ __forceinline__ bool t16_skipped(const int *flags, const int ncell) { return 4L * flags[6] > (long)ncell; }
+
 // S_n = sum_l eps_ln shape_ln H_l for every time step (see ExpmArgs::Sf): one workgroup per step
 struct CtrlSumArgs {
     const double *Hcf, *eps, *shape;

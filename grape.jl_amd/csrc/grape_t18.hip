@@ -90,7 +90,8 @@ struct T16AsmArgs {           // kernel argument block of expm_t16_asm (gen_t16.
     int *verdict;
     const int *rep;
     int KC, N_T, nblk, pad0;
-    unsigned long long pad1[2];
+    unsigned long long *diag;   // diagnostic builds: stamp area
+    const int *flags;           // flags[6]: cells predicted beyond the route's range (t16_plan_kernel)
 };
 static_assert(sizeof(T16AsmArgs) == 80, "argument block of the assembly kernel");
 
@@ -125,6 +126,7 @@ __global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *ve
     __shared__ int todo[256], ntodo;
     __shared__ unsigned long long cnt[8];   // squarings, max, orders 0..4, accepted cells
     const int tid = threadIdx.x, lane = tid & 63, ncell = a.K * a.N_T;
+    if (t16_skipped(a.flags, ncell)) return;   // the route was not tried: the five-product launch books all cells
     if (tid < 8) cnt[tid] = 0;
     if (tid == 0) ntodo = 0;
     __syncthreads();
@@ -215,7 +217,7 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
     if (e != hipSuccess) return (int)e;
     T16AsmArgs k{};
     k.H0f = a.H0f; k.Sf = a.Sf; k.dts = a.dts; k.U = a.U; k.verdict = verdict; k.rep = a.rep;
-    k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks;
+    k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks; k.flags = a.flags;
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     hipStream_t s = (hipStream_t)stream;

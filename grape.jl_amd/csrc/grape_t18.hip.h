@@ -870,7 +870,11 @@ __global__ void __launch_bounds__(NT * 64, (T16 && NT == 3) ? 2 : 1) expm_t18_ke
     const int lo = (int)((long)x * ncell / 8), hi = (int)((long)(x + 1) * ncell / 8);
     // the cells of this workgroup: positions idx0, idx0 + step, ... < end of its XCD's range of cells or, for a launch
     // that works through the hand-over list of the four-product variant, of that list
-    const bool listed = a.listed != 0;
+    // (the plan of this evaluation, t16_plan_kernel: with more than a quarter of the cells predicted beyond the range of the
+    // four-product route that route is not tried -- its kernel leaves, the launch behind it walks all cells, not a list)
+    const bool skip16 = a.cell_list != nullptr && t16_skipped(a.flags, ncell);
+    if (T16 && skip16) return;
+    const bool listed = a.listed != 0 && !skip16;
     const int step = listed ? (int)gridDim.x : per_x;
     const int end = listed ? min(__builtin_amdgcn_readfirstlane(a.flags[4]), ncell) : hi;
     const int idx0 = listed ? (int)blockIdx.x : lo + ((int)blockIdx.x >> 3);

@@ -38,7 +38,7 @@ def make_inputs(N, KC, N_T, seed, scale=1.0):
     return H0, Sn, dts, H0f, Sf
 
 
-def run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, rep=None):
+def run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, rep=None, skipped_cells=0):
     g = gcn.GlobalMem()
     a_H0, _ = g.add("H0f", H0f)
     a_Sf, _ = g.add("Sf", Sf)
@@ -48,7 +48,8 @@ def run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, rep=None):
     a_rep = 0
     if rep is not None:
         a_rep, _ = g.add("rep", np.asarray(rep, np.int32))
-    karg = struct.pack("<QQQQQQiiii", a_H0, a_Sf, a_dt, a_U, a_v, a_rep, KC, N_T, nblk, 0) + b"\0" * 16
+    a_f, _ = g.add("flags", np.array([0, 0, 0, 0, 0, 0, skipped_cells, 0], np.int32))
+    karg = struct.pack("<QQQQQQiiiiQQ", a_H0, a_Sf, a_dt, a_U, a_v, a_rep, KC, N_T, nblk, 0, 0, a_f)
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     stats = {"instr": 0, "mfma": 0}
     for wg in range(nblk):
@@ -111,6 +112,16 @@ def test_cells_beyond_the_bound_are_reported_and_classes_are_followed(program):
                 assert err < 2e-15 and verdict[kc * N_T + n] == 0
             else:
                 assert verdict[kc * N_T + n] == 1      # handed to the five-product route (its value here is not used)
+
+
+def test_kernel_leaves_at_once_when_the_plan_skips_the_route(program):
+    """flags[6] (cells predicted beyond the range, t16_plan_kernel) above a quarter of the evaluation: nothing is written"""
+    _, prog, _ = program
+    H0, Sn, dts, H0f, Sf = make_inputs(64, 1, 4, seed=2)
+    U, verdict, stats = run_kernel(prog, H0f, Sf, dts, 1, 4, 8, skipped_cells=2)
+    assert np.isnan(U).all() and (verdict == -1).all() and stats["mfma"] == 0
+    U, verdict, stats = run_kernel(prog, H0f, Sf, dts * 0.5, 1, 4, 8, skipped_cells=1)
+    assert not np.isnan(U).any() and (verdict == 0).all()
 
 
 def test_text_assembles_for_gfx950(program, tmp_path):

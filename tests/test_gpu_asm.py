@@ -1,0 +1,100 @@
+"""The four-product exponential as hand-allocated gfx950 assembly (grape.jl_amd/csrc/asm/gen_t16.py; the default for Hermitian
+generators with 49 <= N <= 64 and shared control operators) against its C++ twin (GRAPE_EXPM_ASM=0, expm_t18_kernel<4,...,T16>)
+on identical inputs, through the C ABI -- needs an MI355X.  The two kernels evaluate the same formulas; their roundings
+differ in the order of a few sums, so propagators agree to a few 1e-16 and J, G to the suite's parity tolerance.
+(What the kernel computes is checked against scipy in the emulator, tests/test_asm_kernel.py, and against the oracle by the
+whole parity suite, which runs on the assembly kernel wherever it applies.)"""
+import os
+
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import grape_jl_amd as mod
+    assert os.path.exists(mod.library_path()), "HIP extension missing: the product path has no fallback"
+    return mod
+
+
+def run(g, pr, asm, props=True, **kw):
+    old = os.environ.get("GRAPE_EXPM_ASM")
+    os.environ["GRAPE_EXPM_ASM"] = "1" if asm else "0"      # (read once, in grape_create)
+    try:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            J2, G2, _ = h.eval(pr["pulsevals"])
+            assert J2 == J and np.array_equal(G, G2)        # repeatable bit for bit
+            K, N_T = pr["H0"].shape[0], len(pr["tlist"]) - 1
+            U = np.stack([h.propagator(k, n) for k in range(K) for n in range(N_T)]) if props else None
+            return J, G, tau, U, h.work()
+    finally:
+        if old is None:
+            os.environ.pop("GRAPE_EXPM_ASM", None)
+        else:
+            os.environ["GRAPE_EXPM_ASM"] = old
+
+
+@pytest.mark.parametrize("N,L,N_T,K", [(64, 2, 2, 1), (64, 2, 9, 3), (49, 1, 5, 2), (57, 2, 11, 2), (64, 1, 40, 16)])
+def test_assembly_kernel_against_its_twin(g, N, L, N_T, K):
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=31 + N)
+    a = run(g, pr, True)
+    b = run(g, pr, False)
+    assert np.abs(a[3] - b[3]).max() < 2e-15
+    assert abs(a[0] - b[0]) <= 1e-13 and np.abs(a[2] - b[2]).max() <= 1e-13
+    assert np.abs(a[1] - b[1]).max() <= 1e-12 * max(np.abs(b[1]).max(), 1e-3)
+    # every cell inside the bound of the four-product route (spectral radius ~ 1), on both paths; the assembly kernel
+    # executes one matrix instruction more per wave and cell (the column sums of the bound)
+    assert a[4]["t16_cells"] == b[4]["t16_cells"] == K * N_T
+    assert a[4]["t18_mfma_flop"] == pytest.approx(b[4]["t18_mfma_flop"] * 697.0 / 696.0, rel=1e-12)
+    assert a[4]["flop_expm"] == b[4]["flop_expm"] and a[4]["squarings"] == b[4]["squarings"]     # credited work: Julia's exp!
+    # against scipy on a few cells
+    for k, n in [(0, 0), (K - 1, N_T - 1)]:
+        e = pr["pulsevals"].reshape(L, N_T)[:, n]
+        H = pr["H0"][k] + sum(e[l] * pr["Hc"][l] for l in range(L))
+        assert np.abs(a[3][k * N_T + n] - expm(-1j * (pr["tlist"][n + 1] - pr["tlist"][n]) * H)).max() < 2e-14
+
+
+def test_cells_beyond_the_bound_are_handed_to_the_five_product_route(g):
+    """non-uniform grid: steps of 0.5 .. 2.4; the long ones are beyond rho <= 1.36 and are redone by the listed launch"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 2, 24, 3, seed=77)
+    rng = np.random.default_rng(5)
+    steps = 0.5 + 0.4 * rng.random(24)
+    steps[[2, 9, 17, 21]] = 2.0 + 0.4 * rng.random(4)      # a sixth of the cells: below the quarter at which the route is skipped
+    pr["tlist"] = np.concatenate([[0.0], np.cumsum(steps)])
+    a = run(g, pr, True)
+    b = run(g, pr, False)
+    n_long = int((steps > 1.5).sum()) * 3
+    assert a[4]["t16_cells"] == b[4]["t16_cells"] == 3 * 24 - n_long
+    assert np.abs(a[3] - b[3]).max() < 5e-15
+    assert abs(a[0] - b[0]) <= 1e-12 and np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
+    uni = max(np.abs(u.conj().T @ u - np.eye(64)).max() for u in a[3])
+    assert uni < 1e-14
+
+
+def test_generator_classes_and_small_norm_cells(g):
+    """four trajectories under ONE generator (one class: the kernel follows the class table) and steps short enough that
+    the credited statistics need the measured norm (bound below the certifying window)"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 2, 10, 4, seed=12, dt=0.05)
+    pr["H0"][:] = pr["H0"][0]
+    a = run(g, pr, True)
+    b = run(g, pr, False)
+    assert np.abs(a[3] - b[3]).max() < 2e-15 and abs(a[0] - b[0]) <= 1e-13
+    assert a[4]["expm_cells"] == b[4]["expm_cells"] == 10          # one class: ten exponentials, not forty
+    assert a[4]["flop_expm"] == b[4]["flop_expm"]                  # low-order Pade credited from the measured norm on both paths
+
+
+def test_six_controls_and_per_trajectory_controls(g):
+    """more than two shared controls: same kernel (it fetches the summed controls); per-trajectory controls: C++ kernel"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 6, 8, 3, seed=5)
+    a = run(g, pr, True)
+    b = run(g, pr, False)
+    assert np.abs(a[3] - b[3]).max() < 2e-15 and abs(a[0] - b[0]) <= 1e-13
+    assert np.abs(a[1] - b[1]).max() <= 1e-12 * max(np.abs(b[1]).max(), 1e-3)

@@ -729,6 +729,8 @@ def test_four_product_route_hands_cells_beyond_its_bound_to_the_five_product_rou
         with g.GrapeHip(*args) as h:
             J, G, tau = h.eval(pr["pulsevals"])
             res[name] = (J, G.copy(), tau.copy(), np.stack([h.propagator(k, n) for k, n in sample]), h.work())
+            Jrep, Grep, _ = h.eval(pr["pulsevals"])          # the same pulses: the same route, the same bits
+            assert Jrep == J and np.array_equal(Grep, G) and h.work()["t16_cells"] == res[name][4]["t16_cells"]
         for k in env:
             monkeypatch.delenv(k)
     w = res["t16"][4]
@@ -755,10 +757,12 @@ def test_four_product_route_hands_cells_beyond_its_bound_to_the_five_product_rou
     assert abs(Js - Jr) <= TOL_J and np.abs(taus - taur).max() <= TOL_TAU and np.abs(Gs - Gr).max() <= tol_G(Gr)
 
 
-def test_four_product_route_is_given_up_while_it_does_not_pay(g, monkeypatch):
-    """More than a quarter of the cells beyond the bound of the four-product route: the evaluations that follow go straight to
-    the five-product kernel (no cell is exponentiated twice), with bit-identical results -- the redoing launch runs the same
-    cell function."""
+def test_four_product_route_is_planned_from_the_pulses_alone(g, monkeypatch):
+    """Whether the four-product route is tried is decided per evaluation on the device, from the pulse values (t16_plan_kernel:
+    a spectral-radius estimate from the Gram matrices of the operators) -- never from what the handle evaluated before
+    (round-3 advisor finding).  With more than a quarter of the cells predicted beyond the bound the route is skipped: no
+    cell is exponentiated twice and the work is that of the five-product route alone (GRAPE_EXPM_T16=0: same kernel, same
+    cell function).  The same pulses give the same bits whatever was evaluated in between."""
     from grape_jl_amd import synth
     N, L, N_T, K = 64, 2, 300, 4
     pr = synth.make_problem(N, L, N_T, K, seed=1664)
@@ -768,17 +772,33 @@ def test_four_product_route_is_given_up_while_it_does_not_pay(g, monkeypatch):
         w1 = h.work()
         J2, G2, tau2 = h.eval(pr["pulsevals"])
         w2 = h.work()
-    assert w1["t16_cells"] == 0 and w1["t18_cells"] == K * N_T and w2["t16_cells"] == 0 and w2["t18_cells"] == K * N_T
-    assert w2["t18_mfma_flop"] < 0.6 * w1["t18_mfma_flop"]          # first evaluation: 3.6 + 4.25 product equivalents per cell
-    assert J1 == J2 and np.array_equal(G1, G2) and np.array_equal(tau1, tau2)
-    # ... and is probed again after 32 evaluations: pulses change during an optimisation, the bound may hold later
+    monkeypatch.setenv("GRAPE_EXPM_T16", "0")
     with g.GrapeHip(pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"]) as h:
-        flop = []
-        for _ in range(36):
-            h.eval(pr["pulsevals"])
-            flop.append(h.work()["t18_mfma_flop"])
-    assert flop[0] == w1["t18_mfma_flop"] and all(f == w2["t18_mfma_flop"] for f in flop[1:33])
-    assert flop[33] == flop[0] and flop[34] == flop[1]
+        J0, G0, tau0 = h.eval(pr["pulsevals"])
+        w0 = h.work()
+    monkeypatch.delenv("GRAPE_EXPM_T16")
+    assert w1["t16_cells"] == 0 and w1["t18_cells"] == K * N_T and w2["t16_cells"] == 0 and w2["t18_cells"] == K * N_T
+    assert w1["t18_mfma_flop"] == w2["t18_mfma_flop"] == w0["t18_mfma_flop"]      # skipped from the FIRST evaluation on
+    assert w1["flop_expm"] == w0["flop_expm"]
+    assert J1 == J2 and np.array_equal(G1, G2) and np.array_equal(tau1, tau2)
+    # (against the handle without the route: equal up to the rounding of H0 + S_n, the summed controls this handle's
+    # kernels fetch, against H0 + eps_1 H_1 + eps_2 H_2)
+    assert abs(J1 - J0) <= 1e-13 and np.abs(G1 - G0).max() <= 1e-13 * max(np.abs(G0).max(), 1e-3) and np.abs(tau1 - tau0).max() <= 1e-13
+    # pulses inside the range, pulses beyond it (the controls scaled up: the route is skipped), the first pulses again
+    tl1 = np.arange(N_T + 1) * 1.0
+    big = 8.0 * pr["pulsevals"]
+    with g.GrapeHip(pr["H0"], pr["Hc"], tl1, pr["psi0"], pr["target"], pr["weights"]) as h:
+        Ja, Ga, _ = h.eval(pr["pulsevals"])
+        wa = h.work()
+        Jb, Gb, _ = h.eval(big)
+        wb = h.work()
+        Jc, Gc, _ = h.eval(pr["pulsevals"])
+        wc = h.work()
+    with g.GrapeHip(pr["H0"], pr["Hc"], tl1, pr["psi0"], pr["target"], pr["weights"]) as h:
+        Jd, Gd, _ = h.eval(big)
+    assert wa["t16_cells"] == K * N_T and wb["t16_cells"] == 0 and wc["t16_cells"] == K * N_T
+    assert Ja == Jc and np.array_equal(Ga, Gc) and wa["t18_mfma_flop"] == wc["t18_mfma_flop"]
+    assert Jb == Jd and np.array_equal(Gb, Gd)
 
 
 @pytest.mark.parametrize("N,L,N_T,K", [(64, 2, 300, 4), (48, 1, 203, 3), (60, 2, 129, 9), (40, 2, 64, 130), (48, 4, 100, 3),

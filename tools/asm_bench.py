@@ -41,6 +41,7 @@ def main():
     nblk = 256
     NST = 16
     diag = torch.zeros(nblk * 4 * NST, device=dev, dtype=torch.int64)
+    flags = torch.zeros(8, device=dev, dtype=torch.int32)
     sample = [0, 1, N_T - 1, N_T, (K * N_T) // 2 + 3, K * N_T - 1]
     ref = {c: torch.linalg.matrix_exp(-1j * dts[c % N_T] * (H0[c // N_T] + Sn[c % N_T])) for c in sample}
     first = None
@@ -50,7 +51,7 @@ def main():
         chk(hip.hipModuleLoadData(C.byref(mod), data), "hipModuleLoadData")
         chk(hip.hipModuleGetFunction(C.byref(fn), mod, b"expm_t16_asm"), "hipModuleGetFunction")
         karg = struct.pack("<QQQQQQiiiiQQ", H0f.data_ptr(), Sf.data_ptr(), dts.data_ptr(), U.data_ptr(), verdict.data_ptr(), 0,
-                           K, N_T, nblk, 0, diag.data_ptr(), 0)
+                           K, N_T, nblk, 0, diag.data_ptr(), flags.data_ptr())
         buf = C.create_string_buffer(karg, len(karg))
         size = C.c_size_t(len(karg))
         extra = (C.c_void_p * 5)(1, C.addressof(buf), 2, C.addressof(size), 3)

@@ -11,7 +11,8 @@ H0, Sn, dts, H0f, Sf = make_inputs(64, KC, N_T, seed=3)
 gm = gcn.GlobalMem()
 a = [gm.add(n, x)[0] for n, x in (("H0f", H0f), ("Sf", Sf), ("dts", dts * 0.7))]
 a_U, U = gm.add("U", np.zeros((KC * N_T, 64, 64, 2))); a_v, _ = gm.add("v", np.zeros(KC * N_T, np.int32))
-a_k, _ = gm.add("k", np.frombuffer(struct.pack("<QQQQQQiiiiQQ", *a, a_U, a_v, 0, KC, N_T, nblk, 0, 0, 0), np.uint8).copy())
+a_f, _ = gm.add("flags", np.zeros(8, np.int32))
+a_k, _ = gm.add("k", np.frombuffer(struct.pack("<QQQQQQiiiiQQ", *a, a_U, a_v, 0, KC, N_T, nblk, 0, 0, a_f), np.uint8).copy())
 e = gcn.Emu(prog, gm, a_k, wg_id=0, check_races=False)
 e.run()
 ncell = 3
