@@ -85,6 +85,9 @@ struct grape_handle {
     // the four-product route as hand-allocated assembly (asm/gen_t16.py; GRAPE_EXPM_ASM=0: the C++ kernel): four tiles
     // per side, Hermitian generators, controls shared by the trajectories
     bool asm16 = false;
+    // the stream of the last device-pointer call: the getters that read device buffers wait for the device when it was
+    // not the handle's own stream (a caller's non-blocking stream is not ordered against a blocking copy)
+    bool foreign_stream = false;
     double *d_Sf = nullptr;             // [N_T][2][NP*NP] summed control operators of every time step (polynomial kernel, L > 2)
     // diagnostic switches, read ONCE in grape_create (never in the evaluation path: getenv is not thread-safe against setenv)
     bool expm_persist = true;    // GRAPE_EXPM_PERSIST=0: one workgroup per cell instead of the persistent Pade kernel
@@ -1150,7 +1153,10 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     if (NP < 48 && h->herm && deriv3_fits(h->NT, L)) {   // one wave per batch also at one and two tiles per side (grape_deriv3.hip.h); the matrix-free
                                           // mode as well: at these sizes the derivative kernel never used the parked forward terms
         const char *env3 = getenv("GRAPE_DERIV3");
-        if (!(env3 && atoi(env3) == 0)) {
+        // (gradient_method = :taylor with taylor_grad_max_order beyond the 64 terms this kernel parks: deriv_kernel, which
+        // honours any order -- the reference lets the user set it, src/optimize.jl:612, 914; round-3 advisor finding)
+        const bool deep_taylor = p->gradient_method != GRAPE_GRAD_GRADGEN && h->taylor_max_order > 64;
+        if (!(env3 && atoi(env3) == 0) && !deep_taylor) {
             const int bpk = (N_T + 15) / 16;
             h->deriv2_maxm = 64;
             h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
@@ -1375,6 +1381,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     if (!h || !d_pulsevals || !d_out) return GRAPE_ERR_INVALID;
     if (!h->shards.empty()) { h->err = "device-pointer entry points need a single-device handle (ndev <= 1)"; return GRAPE_ERR_INVALID; }
     hipStream_t s = (hipStream_t)stream_;
+    h->foreign_stream = s != h->stream;
     HIPCHK(h, hipSetDevice(h->device));
     // HIP's last-error is sticky per host thread: a failure elsewhere in the process (another handle's failed
     // allocation, a bad device ordinal) must not be reported by the launch checks of this evaluation
@@ -1865,13 +1872,25 @@ int multi_enqueue(grape_handle *h, F fn) {
     const size_t G = h->shards.size();
     std::vector<int> rcs(G, 0);
     const auto t0 = std::chrono::steady_clock::now();
-    if (h->multi_threads && G > 1) {
+    std::vector<char> started(G, 0);
+    bool threaded = h->multi_threads && G > 1;
+    if (threaded) {
         std::vector<std::thread> pool;
         pool.reserve(G);
-        for (size_t g = 0; g < G; ++g) pool.emplace_back([&, g]() { rcs[g] = fn(h->shards[g], g); });
+        try {   // (std::thread's constructor may throw std::system_error: nothing may cross the extern "C" boundary)
+            for (size_t g = 0; g < G; ++g) {
+                pool.emplace_back([&, g]() { rcs[g] = fn(h->shards[g], g); });
+                started[g] = 1;
+            }
+        } catch (...) {
+            threaded = false;   // the shards without a thread are enqueued from this one, below
+        }
         for (auto &t : pool) t.join();
-    } else {
+    }
+    if (!threaded) {
         for (size_t g = 0; g < G; ++g) {
+            if (started[g]) continue;
+            started[g] = 1;
             rcs[g] = fn(h->shards[g], g);
             if (rcs[g]) break;
         }
@@ -1879,7 +1898,13 @@ int multi_enqueue(grape_handle *h, F fn) {
     h->host_enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     h->host_enqueue_calls += 1;
     for (size_t g = 0; g < G; ++g)
-        if (rcs[g]) return multi_fail(h, h->shards[g], rcs[g]);
+        if (rcs[g]) {
+            // a shard failed: the launches and asynchronous copies of the OTHER shards are still in flight, some of them
+            // from the caller's pageable buffers (xi, chi), which the caller may free after the error return -- wait
+            for (size_t q = 0; q < G; ++q)
+                if (started[q] && q != g && hipSetDevice(h->shards[q]->device) == hipSuccess) (void)hipStreamSynchronize(h->shards[q]->stream);
+            return multi_fail(h, h->shards[g], rcs[g]);
+        }
     return GRAPE_OK;
 }
 
@@ -1991,7 +2016,9 @@ int grape_get_sums(grape_handle *h, double sums[8]) {
         return GRAPE_OK;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // (the handle's stream only: other handles of the process keep running)
+    // (the handle's stream only: other handles of the process keep running -- unless the last device-pointer call ran on a
+    // stream of the caller's, which a blocking copy is not ordered against: then the device)
+    HIPCHK(h, h->foreign_stream ? hipDeviceSynchronize() : hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(sums, h->d_out + 2 * (size_t)h->K, 8 * sizeof(double), hipMemcpyDeviceToHost));
     return GRAPE_OK;
 }
@@ -2007,7 +2034,7 @@ int grape_get_final_states(grape_handle *h, double *psiT) {
         return GRAPE_OK;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, h->foreign_stream ? hipDeviceSynchronize() : hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy2D(psiT, (size_t)h->N * 16, h->d_fw + (size_t)h->N_T * h->NP,
                           (size_t)(h->N_T + 1) * h->NP * 16, (size_t)h->N * 16, h->K, hipMemcpyDeviceToHost));
     return GRAPE_OK;
@@ -2203,14 +2230,15 @@ int grape_reset_timings(grape_handle *h) {
 int grape_get_work(grape_handle *h, double *out, int n) {
     if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
     if (!h->shards.empty()) {   // every entry is a count: the shards add up
-        const int m = n < 14 ? n : 14;
+        const int m = n < 15 ? n : 15;
         std::fill(out, out + m, 0.0);
         for (grape_handle *c : h->shards) {
-            double cw[14] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+            double cw[15] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
             const int rc = grape_get_work(c, cw, m);
             if (rc < 0) return multi_fail(h, c, rc);
             for (int i = 0; i < m; ++i) out[i] += cw[i];
         }
+        if (m > 14 && out[14] > 0.0) out[14] = 1.0;   // (a flag, not a count)
         return 4;
     }
     HIPCHK(h, hipSetDevice(h->device));
@@ -2242,6 +2270,7 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     // runs matrix-free (see grape_create)
     if (n > 12) out[12] = h->u_fallback ? 1.0 : 0.0;
     if (n > 13) out[13] = (double)st[15];   // cells of [11] that took the four-product degree-16 route
+    if (n > 14) out[14] = h->asm16 ? 1.0 : 0.0;   // the four-product route of this handle is the hand-allocated assembly kernel
     return 4;
 }
 

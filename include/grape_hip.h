@@ -27,10 +27,11 @@
  *     sum_k of the gradient, optimize.jl:579) are exposed by the split-phase calls below so that
  *     the host can all-reduce them (RCCL) between phases.
  *   - several GPUs behind ONE handle (ABI v4, grape_problem.ndev / .devices): the K trajectories of the
- *     handle are dealt to the devices in contiguous blocks, every host-pointer entry point drives all of
- *     them from the calling thread (asynchronous launches on one stream per device) and performs the two
- *     reductions itself in a fixed order -- the caller never sees the devices, exactly like the
- *     transparent `@threadsif` loops over k of optimize.jl:720, 876.
+ *     handle are dealt to the devices in contiguous blocks, every host-pointer entry point enqueues the work
+ *     of all of them (one host thread per device, asynchronous launches on one stream per device; the
+ *     calling thread waits and reads back) and performs the two reductions itself in a fixed order -- the
+ *     caller never sees the devices, exactly like the transparent `@threadsif` loops over k of
+ *     optimize.jl:720, 876.
  */
 #ifndef GRAPE_HIP_H
 #define GRAPE_HIP_H
@@ -238,7 +239,9 @@ int grape_reset_timings(grape_handle *h);
  * but the propagators (KC N_T NP^2 16 bytes) do not fit the device and the handle evaluates matrix-free instead of
  * failing in hipMalloc (same results to rounding; shards of a composite handle: the number of shards in that mode),
  * [13] the cells of [11] that took the four-product degree-16 route (Hermitian generators, 16 < N <= 64, spectral bound
- * within its range) (entries beyond n are not written). */
+ * within its range), [14] 1 if the four-product route of this handle is the hand-allocated assembly kernel (csrc/asm/gen_t16.py:
+ * Hermitian generators, 49 <= N <= 64, control operators shared by the trajectories; GRAPE_EXPM_ASM=0: the C++ kernel)
+ * (entries beyond n are not written). */
 int grape_get_work(grape_handle *h, double *out, int n);
 
 const char *grape_last_error(grape_handle *h); /* h may be NULL: error of the last failed create */

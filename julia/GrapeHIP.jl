@@ -1,4 +1,4 @@
-# GrapeHIP.jl -- thin `ccall` glue between GRAPE.jl and libgrape_hip.so (include/grape_hip.h, ABI v4).
+# GrapeHIP.jl -- thin `ccall` glue between GRAPE.jl and libgrape_hip.so (include/grape_hip.h, ABI v5).
 #
 # NOT EXECUTED in this repository's CI: the build image has no Julia toolchain.  It is written
 # against the C ABI and the reference's own interfaces and shows exactly what a GRAPE.jl maintainer
@@ -201,6 +201,10 @@ function make_fg!(h::Handle, wrk)
     # evaluated here on the stored forward states, the array xi_k(t_n) goes to grape_backward_xi (ABI v5)
     g_b, xi = get(kw, :g_b, nothing), get(kw, :xi, nothing)
     xi_route = has_gb && isnothing(h.keep[8])                              # (keep[8]: the operator D handed to Handle(...))
+    # (the reference derives a missing xi by automatic differentiation, src/workspace.jl:313-316; this glue has no AD
+    # hook: say so HERE, at construction, not as a MethodError on `nothing` inside fg!)
+    xi_route && isnothing(xi) && error("GrapeHIP.make_fg!: a running cost g_b given as a callback needs xi " *
+                                       "(xi(state, trajectory, tlist, n) = -∂g_b/∂⟨Ψ|); pass xi = ... or hand the operator D to Handle(...)")
     N_T = length(tlist) - 1
     fw = xi_route ? Array{ComplexF64}(undef, N, N_T + 1, K) : nothing      # Ψ_k(t_n): [K][N_T+1][N] on the C side
     xi_arr = xi_route ? zeros(ComplexF64, N, N_T + 1, K) : nothing

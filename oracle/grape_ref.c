@@ -48,8 +48,28 @@ enum { GRAPE_REF_GRADGEN = 0, GRAPE_REF_TAYLOR = 1, GRAPE_REF_FRECHET = 2 };
 
 /* ---------- dense kernels (column-major) ---------- */
 
+/* Optional BLAS / LAPACK underneath the dense kernels (timed CPU baseline of bench.py: the reference runs Julia's exp! on
+ * OpenBLAS, so the stated baseline should too).  grape_ref_set_blas() receives the Fortran-interface entry points
+ * zgemm_ and zgesv_ (LP64) of a library the CALLER has loaded -- oracle/grape_ref.py passes the OpenBLAS that scipy
+ * bundles, set to one thread: the parallelism stays the OpenMP loop over trajectories, as in the reference
+ * (src/optimize.jl:720, 876).  NULL pointers (the default) select the plain C loops below. */
+typedef void (*zgemm_fn)(const char *, const char *, const int *, const int *, const int *, const cplx *, const cplx *, const int *,
+                         const cplx *, const int *, const cplx *, cplx *, const int *);
+typedef void (*zgesv_fn)(const int *, const int *, cplx *, const int *, int *, cplx *, const int *, int *);
+static zgemm_fn blas_zgemm = NULL;
+static zgesv_fn blas_zgesv = NULL;
+void grape_ref_set_blas(void *zgemm, void *zgesv_) {
+    blas_zgemm = (zgemm_fn)zgemm;
+    blas_zgesv = (zgesv_fn)zgesv_;
+}
+
 /* C = A*B (n x n) */
 static void zgemm_nn(int n, const cplx *restrict A, const cplx *restrict B, cplx *restrict C) {
+    if (blas_zgemm) {
+        const cplx one = 1.0, zero = 0.0;
+        blas_zgemm("N", "N", &n, &n, &n, &one, A, &n, B, &n, &zero, C, &n);
+        return;
+    }
     memset(C, 0, sizeof(cplx) * (size_t)n * n);
     for (int j = 0; j < n; ++j) {
         cplx *restrict cj = C + (size_t)j * n;
@@ -91,6 +111,13 @@ static double norm1(int n, const cplx *A) {
 
 /* Solve Q X = P in place (X overwrites P): LU with partial pivoting (LAPACK gesv). */
 static int zgesv(int n, cplx *restrict Q, cplx *restrict P) {
+    if (blas_zgesv) {
+        int info = 0;
+        int *ipiv = (int *)malloc(sizeof(int) * (size_t)n);
+        blas_zgesv(&n, &n, Q, &n, ipiv, P, &n, &info);
+        free(ipiv);
+        return info ? -1 : 0;
+    }
     for (int k = 0; k < n; ++k) {
         int p = k;
         double best = cabs(Q[(size_t)k * n + k]);

@@ -146,3 +146,34 @@ def evaluate_chi(H0, Hc, tlist, pulsevals, psi0, target, chi, weights=None, grad
 
 def max_threads():
     return lib().grape_ref_max_threads()
+
+
+_blas = None
+
+
+def use_openblas(on=True):
+    """Put the OpenBLAS that scipy bundles (zgemm_, zgesv_; ONE BLAS thread: the parallelism stays the OpenMP loop over
+    trajectories) underneath the dense kernels of the restatement, or go back to the plain C loops.  Returns a description
+    of the library, or None if it cannot be found.  Timed CPU baseline of bench.py only."""
+    global _blas
+    if not on:
+        lib().grape_ref_set_blas(None, None)
+        return None
+    if _blas is None:
+        import glob
+        import scipy
+        cands = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so"))
+        for path in cands:
+            try:
+                so = C.CDLL(path, mode=C.RTLD_GLOBAL)
+                zgemm, zgesv = C.cast(so.scipy_zgemm_, C.c_void_p), C.cast(so.scipy_zgesv_, C.c_void_p)
+                so.scipy_openblas_set_num_threads(1)
+                so.scipy_openblas_get_config.restype = C.c_char_p
+                _blas = (so, zgemm, zgesv, "scipy-bundled " + so.scipy_openblas_get_config().decode().strip())
+                break
+            except (OSError, AttributeError):
+                continue
+    if _blas is None:
+        return None
+    lib().grape_ref_set_blas(_blas[1], _blas[2])
+    return _blas[3]

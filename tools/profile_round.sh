@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 mkdir -p gpurun_out
-tag=${1:-r03}
+tag=${1:-r04}
 python3 bench.py > gpurun_out/${tag}_bench_C3.json 2> gpurun_out/${tag}_bench_C3.err &&
 python3 bench.py --config C2 --steps 50 --warmup 5 > gpurun_out/${tag}_bench_C2.json 2> gpurun_out/${tag}_bench_C2.err &&
 python3 bench.py --config C5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_C5.json 2> gpurun_out/${tag}_bench_C5.err &&
@@ -20,4 +20,7 @@ done
 # secondary lines: six controls and non-Hermitian generators at the headline shape
 python3 bench.py --config C3L6 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_L6.json 2> gpurun_out/${tag}_bench_C3_L6.err
 python3 bench.py --config C3 --nonhermitian --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_nonherm.json 2> gpurun_out/${tag}_bench_C3_nonherm.err
+# the cliff of the four-product route: every cell beyond its range (dt = 1.5: five products) and with one squaring (dt = 2)
+python3 bench.py --config C3 --dt 1.5 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_dt1p5.json 2> gpurun_out/${tag}_bench_C3_dt1p5.err
+python3 bench.py --config C3 --dt 2.0 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_dt2.json 2> gpurun_out/${tag}_bench_C3_dt2.err
 exit $rc
