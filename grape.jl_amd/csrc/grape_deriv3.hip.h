@@ -289,7 +289,12 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
             }
             if (lane == 0) {
                 const bool redone = a.batch_flag && a.batch_flag[batch];
-                if (!converged && !redone) atomicOr(&a.flags[0], 4);
+                // (not converged within the terms this kernel parks while taylor_grad_max_order allows more: flags[7] asks for
+                // deriv_kernel, which is launched behind this kernel and honours any order; round-3 advisor finding)
+                if (!converged && !redone) {
+                    if (a.deep_redo && a.max_order > mcap) atomicAdd(&a.flags[7], 1);
+                    else atomicOr(&a.flags[0], 4);
+                }
                 if (!redone) stat_add(a.stats, 8, (unsigned long long)M * (unsigned long long)min(16, a.N_T - n0));
             }
         }

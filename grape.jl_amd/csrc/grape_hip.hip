@@ -88,6 +88,9 @@ struct grape_handle {
     // the stream of the last device-pointer call: the getters that read device buffers wait for the device when it was
     // not the handle's own stream (a caller's non-blocking stream is not ordered against a blocking copy)
     bool foreign_stream = false;
+    // the assembly route books its credited statistics (Pade order / squarings Julia's exp! would use) on demand, in
+    // grape_get_work: outside the certifying window of the operator-norm bound they need the norm of every cell
+    bool credit_pending = false;
     double *d_Sf = nullptr;             // [N_T][2][NP*NP] summed control operators of every time step (polynomial kernel, L > 2)
     // diagnostic switches, read ONCE in grape_create (never in the evaluation path: getenv is not thread-safe against setenv)
     bool expm_persist = true;    // GRAPE_EXPM_PERSIST=0: one workgroup per cell instead of the persistent Pade kernel
@@ -223,6 +226,7 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
 extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks);
+extern "C" int grape_t16_credit_launch(const void *args, size_t args_size, void *stream);
 // deriv3_kernel keeps the upper 16 x 16 tiles (re, im; stride 17) of H0_k and of the L control operators in LDS
 // (general drift: all NT x NT tiles of H0_k, three and four tiles per side and at most two controls)
 static bool deriv3_fits(int NT, int L, bool h0_general = false) {
@@ -1153,10 +1157,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     if (NP < 48 && h->herm && deriv3_fits(h->NT, L)) {   // one wave per batch also at one and two tiles per side (grape_deriv3.hip.h); the matrix-free
                                           // mode as well: at these sizes the derivative kernel never used the parked forward terms
         const char *env3 = getenv("GRAPE_DERIV3");
-        // (gradient_method = :taylor with taylor_grad_max_order beyond the 64 terms this kernel parks: deriv_kernel, which
-        // honours any order -- the reference lets the user set it, src/optimize.jl:612, 914; round-3 advisor finding)
-        const bool deep_taylor = p->gradient_method != GRAPE_GRAD_GRADGEN && h->taylor_max_order > 64;
-        if (!(env3 && atoi(env3) == 0) && !deep_taylor) {
+        if (!(env3 && atoi(env3) == 0)) {
             const int bpk = (N_T + 15) / 16;
             h->deriv2_maxm = 64;
             h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
@@ -1437,8 +1438,11 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                 }
                 // (three tiles per side, four-product variant: 256 registers and 72 KB -- two workgroups per CU)
                 const int blocks16 = (t16 && h->NT == 3) ? 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * 2, (ncell + 7) / 8)) : t18_blocks;
-                if (t16 && h->asm16)   // (the verdicts of the assembly kernel go through the flag array of the Pade path)
+                h->credit_pending = false;
+                if (t16 && h->asm16) {   // (the verdicts of the assembly kernel go through the flag array of the Pade path)
                     e = (hipError_t)grape_t16_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, t18_blocks);
+                    h->credit_pending = true;
+                }
                 else
                     e = (hipError_t)grape_t18_launch(h->NT, h->herm ? 1 : 0, t16 ? 1 : 0, &ea, sizeof(ea), (void *)s, blocks16);
                 if (t16 && e == hipSuccess) {   // the cells it listed, by the degree-18 variant (none: the launch ends at once)
@@ -1682,6 +1686,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         if (h->sub_theta > 0.0) dm.batch_flag = h->d_batchflag;
         e = launch_deriv_mfma(h->NP, dm, h->deriv_blocks, s);
     } else {
+        bool deep = false;
         if (h->d_park3) {
             // one wave per batch (deriv3_kernel); cells whose series needs sub-steps are deriv_kernel's: it is launched behind
             // and ends at once unless deriv_flag_kernel counted such a batch -- in which case deriv3_kernel ends at once
@@ -1694,6 +1699,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
             d2.batches_per_k = (h->N_T + 15) / 16;
             d2.nbatch_total = h->K * d2.batches_per_k;
             const bool sub = h->sub_theta > 0.0;
+            d2.deep_redo = (!sub && h->taylor_max_order > h->deriv2_maxm) ? 1 : 0;
             if (sub) {
                 HIPCHK(h, hipMemsetAsync(h->d_flags + 3, 0, sizeof(int), s));
                 DerivFlagArgs fa{};
@@ -1707,8 +1713,12 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
             HIPCHK(h, (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, sub ? 1 : 0, 0, (void *)s,
                                                       h->deriv3_blocks));
             da.only_if = sub ? h->d_flags + 3 : nullptr;
+            // gradient_method = :taylor with taylor_grad_max_order beyond the terms deriv3_kernel parks (the reference's default
+            // is 100, src/optimize.jl:914): a batch that is not converged by then raises flags[7] and deriv_kernel, which
+            // honours any order, redoes the evaluation's derivatives behind it (it leaves at once while flags[7] is zero)
+            if (d2.deep_redo) { deep = true; da.only_if = h->d_flags + 7; }
         }
-        if (!h->d_park3 || h->sub_theta > 0.0) {   // (no sub-stepping, :taylor route: deriv3_kernel has done every cell)
+        if (!h->d_park3 || h->sub_theta > 0.0 || deep) {   // (no sub-stepping, :taylor route: deriv3_kernel has done every cell)
             switch (h->NP) {
                 case 16: e = launch_deriv<16>(da, nblocks, s); break;
                 default: e = launch_deriv<32>(da, nblocks, s); break;
@@ -2243,6 +2253,16 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
+    if (h->credit_pending) {   // credited work of the assembly route's last evaluation: pulses, S_n and flags are still in place
+        ExpmArgs ea{};
+        ea.H0f = h->d_H0f; ea.Hcf = h->d_Hcf; ea.eps = h->d_eps; ea.shape = h->d_shape; ea.dts = h->d_dts;
+        ea.flags = h->d_flags; ea.stats = h->d_stats; ea.Sf = h->d_Sf;
+        ea.K = h->KC; ea.rep = h->d_rep; ea.L = h->L; ea.N_T = h->N_T; ea.hc_per_traj = h->p.hc_per_traj;
+        ea.n1 = h->d_n1; ea.n1_k = h->K;
+        HIPCHK(h, (hipError_t)grape_t16_credit_launch(&ea, sizeof(ea), (void *)h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->credit_pending = false;
+    }
     unsigned long long sh[GRAPE_STAT_SHARDS * GRAPE_STAT_SLOTS], st[GRAPE_STAT_SLOTS] = {0};
     HIPCHK(h, hipMemcpy(sh, h->d_stats, sizeof(sh), hipMemcpyDeviceToHost));
     for (int q = 0; q < GRAPE_STAT_SHARDS; ++q)

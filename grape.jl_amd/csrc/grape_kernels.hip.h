@@ -88,7 +88,7 @@ struct ExpmArgs {
 // R_est > T16_PLAN_R (NaN included); when they are more than a quarter of the evaluation the four-product kernels leave
 // at once and the five-product launch behind them walks all cells instead of a hand-over list (t16_skipped()).
 // The estimate decides speed only: a cell it lets through is still certified (or handed over) by the kernel's own bound.
-#define T16_PLAN_R 1.12   // the kernel's bound m8^(1/8) is ~1.17 R for a semicircle: 1.17 * 1.12 * 1.03 < 1.36
+#define T16_PLAN_R 1.15   // the kernel's bound m8^(1/8) is 3.5^(1/8) = 1.17 R for a semicircle: 1.17 * 1.15 * 1.01 < 1.36
 struct T16PlanArgs {
     const double *gram;   // [KC][(L + 1)^2]
     const double *eps, *shape, *dts;
@@ -3315,6 +3315,9 @@ struct Deriv2Args {
     // batches with a cell that needs sub-steps (deriv_flag_kernel) are redone by deriv_sub_kernel afterwards: whatever
     // this kernel writes for them is overwritten, only its non-convergence flag has to stay down
     const int *batch_flag;     // nullptr or [nbatch_total]
+    // deriv3_kernel at one and two tiles per side: a series that is not converged within the terms the kernel parks, while
+    // max_order allows more, raises flags[7] instead of the non-convergence error -- deriv_kernel redoes the derivatives
+    int deep_redo;
 #ifdef GRAPE_DIAG
     int ablate;                // diagnostic builds only: bit0 no parking traffic (results wrong)
 #endif

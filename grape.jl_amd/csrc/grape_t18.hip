@@ -121,16 +121,39 @@ __device__ __forceinline__ double t16_post_norm1(const ExpmArgs &a, const int ce
     return nA;
 }
 
+// behind the assembly kernel, every evaluation: the cells beyond the bound go to the hand-over list; executed work
 __global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *verdict) {
-    __shared__ double red[264];
-    __shared__ int todo[256], ntodo;
-    __shared__ unsigned long long cnt[8];   // squarings, max, orders 0..4, accepted cells
     const int tid = threadIdx.x, lane = tid & 63, ncell = a.K * a.N_T;
     if (t16_skipped(a.flags, ncell)) return;   // the route was not tried: the five-product launch books all cells
+    const int cell = blockIdx.x * 256 + tid;
+    const bool valid = cell < ncell;
+    const bool ok = valid && verdict[cell] == 0;
+    if (valid && !ok) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
+    const unsigned long long m_ok = __ballot(ok), m_valid = __ballot(valid);
+    if (lane == 0 && m_valid) {
+        // executed matrix instructions of the assembly kernel: four waves x (120 + 3 * 192 + 1 for the column sums) per cell
+        stat_add(a.stats, 12, (unsigned long long)__popcll(m_valid) * 4ull * (unsigned long long)(T16Count<4>::CELL + 1));
+        if (m_ok) {
+            stat_add(a.stats, 14, (unsigned long long)__popcll(m_ok));
+            stat_add(a.stats, 15, (unsigned long long)__popcll(m_ok));
+        }
+        atomicAdd(&a.flags[5], (int)__popcll(m_valid));
+    }
+}
+
+// ON DEMAND (grape_get_work): the credited work of the cells the assembly kernel processed -- what Julia's exp! would do
+// for them, order and squarings from ||A||_1, the rule of the cell loop of expm_t18_kernel.  Outside the certifying window
+// of the operator-norm bound the norm has to be measured: 128 KB of operator planes per cell from L2, 0.6 ms at the
+// headline configuration when done in every evaluation -- and nothing but grape_get_work reads the result.
+__global__ void __launch_bounds__(256) t16_credit_kernel(ExpmArgs a) {
+    __shared__ double red[264];
+    __shared__ int todo[256], ntodo;
+    __shared__ unsigned long long cnt[8];   // squarings, max, orders 0..4
+    const int tid = threadIdx.x, lane = tid & 63, ncell = a.K * a.N_T;
+    if (t16_skipped(a.flags, ncell)) return;
     if (tid < 8) cnt[tid] = 0;
     if (tid == 0) ntodo = 0;
     __syncthreads();
-    // what Julia's exp! would do for a cell (order and squarings from ||A||_1), as in the cell loop of expm_t18_kernel
     auto order_of = [](double nA) { return nA > 2.1 ? 4 : nA > 0.95 ? 3 : nA > 0.25 ? 2 : nA > 0.015 ? 1 : 0; };
     auto squarings_of = [](double nA) {
         if (!(nA > 5.4)) return 0;
@@ -139,23 +162,14 @@ __global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *ve
         return (r == ldexp(1.0, e)) ? e : e + 1;
     };
     const int cell = blockIdx.x * 256 + tid;
-    const bool valid = cell < ncell;
-    double bound = 0.0;
-    bool cert = false, ok = false;
-    if (valid) {
-        bound = expm_norm_bound(a, cell);
+    bool cert = false;
+    if (cell < ncell) {
+        const double bound = expm_norm_bound(a, cell);
         cert = bound > 2.1 && bound <= 5.4;
-        ok = verdict[cell] == 0;
         if (!cert) todo[atomicAdd(&ntodo, 1)] = cell;
-        if (!ok) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
     }
-    // (counts per wave by ballot: one shared-memory atomic per wave and counter instead of one per thread -- with every
-    // thread on the same counter this kernel took 0.6 ms at the headline configuration)
-    const unsigned long long m_cert = __ballot(cert), m_ok = __ballot(valid && ok);
-    if (lane == 0) {
-        if (m_cert) atomicAdd(&cnt[2 + 4], (unsigned long long)__popcll(m_cert));   // certified cells: order 13, no squaring
-        if (m_ok) atomicAdd(&cnt[7], (unsigned long long)__popcll(m_ok));
-    }
+    const unsigned long long m_cert = __ballot(cert);
+    if (lane == 0 && m_cert) atomicAdd(&cnt[2 + 4], (unsigned long long)__popcll(m_cert));   // certified: order 13, no squaring
     __syncthreads();
     const int nt = ntodo;
     for (int q = 0; q < nt; ++q) {          // cells outside the certifying window: the measured norm
@@ -168,16 +182,10 @@ __global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *ve
     }
     __syncthreads();
     if (tid == 0) {
-        const int here = min(256, ncell - (int)blockIdx.x * 256);
         if (cnt[0]) stat_add(a.stats, 0, cnt[0]);
         for (int o = 0; o < 5; ++o)
             if (cnt[2 + o]) stat_add(a.stats, 3 + o, cnt[2 + o]);
         if (cnt[1]) atomicMax(&a.flags[1], (int)cnt[1]);
-        // executed matrix instructions of the assembly kernel: four waves x (120 + 3 * 192 + 1 for the column sums) per cell
-        stat_add(a.stats, 12, (unsigned long long)here * 4ull * (unsigned long long)(T16Count<4>::CELL + 1));
-        stat_add(a.stats, 14, cnt[7]);
-        stat_add(a.stats, 15, cnt[7]);
-        atomicAdd(&a.flags[5], here);
     }
 }
 
@@ -224,6 +232,17 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
     e = hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(t16_post_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, (const int *)verdict);
+    return (int)hipGetLastError();
+}
+
+// credited statistics of the last evaluation of the assembly route, on demand (see t16_credit_kernel)
+extern "C" int grape_t16_credit_launch(const void *args, size_t args_size, void *stream) {
+    if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
+    ExpmArgs a;
+    memcpy(&a, args, sizeof(a));
+    if (!a.Sf) return (int)hipErrorInvalidValue;
+    const long ncell = (long)a.K * a.N_T;
+    hipLaunchKernelGGL(t16_credit_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -900,3 +900,24 @@ def test_general_drift_with_hermitian_controls_one_wave_per_batch(g, ref, N, L, 
                                 gradient_method=ref.TAYLOR)
     assert abs(Js - Jr) <= TOL_J * max(1.0, abs(Jr)) and np.abs(taus - taur).max() <= TOL_TAU * max(1.0, np.abs(taur).max())
     assert np.abs(Gs - Gr).max() <= tol_G(Gr)
+
+
+def test_taylor_route_honours_max_order_beyond_the_parked_terms(g, ref):
+    """gradient_method = :taylor, N <= 32, a step large enough that the recursion of taylor_grad_step! needs more than the 64
+    terms deriv3_kernel parks but fewer than taylor_grad_max_order (reference default 100, src/optimize.jl:914): the
+    one-wave-per-batch kernel asks for deriv_kernel, which honours any order, instead of reporting non-convergence (round-3
+    advisor finding).  The plain series loses digits like e^(||H|| dt) -- in the restatement too: compared at 1e-5."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(8, 1, 3, 2, seed=90)
+    tl = pr["tlist"] * 19.5                              # ||H|| dt ~ 20: ~70 terms
+    args = (pr["H0"], pr["Hc"], tl, pr["psi0"], pr["target"], pr["weights"])
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], tl, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                gradient_method=ref.TAYLOR)
+    with g.GrapeHip(*args, gradient_method=1) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        orders = h.work()["deriv_orders"] / h.work()["cells"]
+    assert orders > 64
+    assert abs(J - Jr) <= 1e-9 and np.abs(G - Gr).max() <= 1e-5 * max(np.abs(Gr).max(), 1e-3)
+    with g.GrapeHip(*args, gradient_method=1, taylor_max_order=40) as h:     # ... and the reference's error when it is not enough
+        with pytest.raises(g.GrapeHipError):
+            h.eval(pr["pulsevals"])
