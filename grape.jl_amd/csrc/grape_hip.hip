@@ -91,6 +91,13 @@ struct grape_handle {
     // the assembly route books its credited statistics (Pade order / squarings Julia's exp! would use) on demand, in
     // grape_get_work: outside the certifying window of the operator-norm bound they need the norm of every cell
     bool credit_pending = false;
+    // balancing of general (non-Hermitian) generators, the role of gebal in Julia's exp!: ONE diagonal
+    // similarity D = diag(2^e) for the whole handle, chosen at grape_create from sum_k |H0_k| + sum_l |H_l| by gebal's
+    // scaling loop; the handle then works on D^-1 H D, D^-1 Psi0, D target (every quantity of the path -- tau, J, the
+    // gradient -- is invariant) and the entry points that hand states or propagators across the boundary transform
+    // them back.  Empty: no balancing (Hermitian operators are balanced: the loop returns the identity).
+    std::vector<double> bal;
+    std::vector<double> bal_stage_chi, bal_stage_xi;   // D chi, D xi of the caller's arrays (backward_enqueue)
     double *d_Sf = nullptr;             // [N_T][2][NP*NP] summed control operators of every time step (polynomial kernel, L > 2)
     // diagnostic switches, read ONCE in grape_create (never in the evaluation path: getenv is not thread-safe against setenv)
     bool expm_persist = true;    // GRAPE_EXPM_PERSIST=0: one workgroup per cell instead of the persistent Pade kernel
@@ -303,6 +310,44 @@ hipError_t launch_series(const SeriesArgs &a, bool backward, hipStream_t s) {
     else SERIES_CASE(0);
 #undef SERIES_CASE
     return hipGetLastError();
+}
+
+// The scaling half of LAPACK gebal (2-norm form, factors of two, 5 % rule) on a real non-negative N x N matrix
+// (column-major): d with M <- D^-1 M D balanced.  All ones for a symmetric matrix.
+std::vector<double> gebal_scaling(int N, std::vector<double> M) {
+    std::vector<double> d((size_t)N, 1.0);
+    const double radix = 2.0, sfmin1 = 2.2250738585072014e-308 / 2.220446049250313e-16, sfmax1 = 1.0 / sfmin1;
+    const double sfmin2 = sfmin1 * radix, sfmax2 = 1.0 / sfmin2;
+    for (bool noconv = true; noconv;) {
+        noconv = false;
+        for (int i = 0; i < N; ++i) {
+            double c = 0., r = 0., ca = 0., ra = 0.;
+            for (int j = 0; j < N; ++j) {
+                const double cji = M[(size_t)i * N + j], rij = M[(size_t)j * N + i];
+                c += cji * cji; r += rij * rij;
+                ca = std::max(ca, cji); ra = std::max(ra, rij);
+            }
+            c = std::sqrt(c); r = std::sqrt(r);
+            if (c == 0.0 || r == 0.0) continue;
+            double g = r / radix, f = 1.0;
+            const double s0 = c + r;
+            while (c < g && std::max(f, std::max(c, ca)) < sfmax2 && std::min(r, std::min(g, ra)) > sfmin2) {
+                f *= radix; c *= radix; ca *= radix; r /= radix; g /= radix; ra /= radix;
+            }
+            g = c / radix;
+            while (g >= r && std::max(r, ra) < sfmax2 && std::min(std::min(f, c), std::min(g, ca)) > sfmin2) {
+                f /= radix; c /= radix; g /= radix; ca /= radix; r *= radix; ra *= radix;
+            }
+            if (c + r >= 0.95 * s0) continue;
+            if (f < 1.0 && d[i] < 1.0 && f * d[i] <= sfmin1) continue;
+            if (f > 1.0 && d[i] > 1.0 && d[i] >= sfmax1 / f) continue;
+            d[i] *= f;
+            noconv = true;
+            for (int j = 0; j < N; ++j) M[(size_t)j * N + i] /= f;   // row i
+            for (int j = 0; j < N; ++j) M[(size_t)i * N + j] *= f;   // column i
+        }
+    }
+    return d;
 }
 
 // 2-norm estimate of an N x N complex column-major matrix: power iteration on M^dagger M (deterministic start),
@@ -928,8 +973,56 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     if (p->ndev < 0 || p->ndev > 64) { g_create_error = "ndev out of range (0..64)"; return GRAPE_ERR_INVALID; }
     if (p->ndev > 1) return multi_create(out, p);
 
+    // ---- balancing (see grape_handle::bal): the problem the handle is built from is D^-1 H D, D^-1 Psi0, D target, D Dpen D ----
+    std::vector<double> bal, b_H0, b_Hc, b_psi0, b_target, b_Dpen;
+    grape_problem pbal = *p;
+    {
+        const char *envb = getenv("GRAPE_BALANCE");
+        const int N = p->N, K = p->K, L = p->L, Kc = p->hc_per_traj ? K : 1;
+        const size_t nn = (size_t)N * N;
+        if (!(envb && atoi(envb) == 0)) {
+            std::vector<double> M(nn, 0.0);
+            auto add = [&](const double *op) { for (size_t q = 0; q < nn; ++q) M[q] += std::hypot(op[2 * q], op[2 * q + 1]); };
+            for (int k = 0; k < K; ++k) add(p->H0 + 2 * (size_t)k * nn);
+            for (int q = 0; q < Kc * L; ++q) add(p->Hc + 2 * (size_t)q * nn);
+            bal = gebal_scaling(N, M);
+            bool ident = true;
+            for (double x : bal) ident = ident && x == 1.0;
+            if (ident) bal.clear();
+        }
+        if (!bal.empty()) {
+            auto similar = [&](const double *src, size_t count, std::vector<double> &dst, bool congruence) {
+                dst.assign(src, src + 2 * count * nn);
+                for (size_t m = 0; m < count; ++m)
+                    for (int j = 0; j < N; ++j)
+                        for (int i = 0; i < N; ++i) {   // element (row i, column j), column-major
+                            const double f = congruence ? bal[i] * bal[j] : bal[j] / bal[i];
+                            dst[2 * (m * nn + (size_t)j * N + i)] *= f;
+                            dst[2 * (m * nn + (size_t)j * N + i) + 1] *= f;
+                        }
+            };
+            similar(p->H0, (size_t)K, b_H0, false);
+            similar(p->Hc, (size_t)Kc * L, b_Hc, false);
+            b_psi0.assign(p->psi0, p->psi0 + 2 * (size_t)K * N);
+            b_target.assign(p->target, p->target + 2 * (size_t)K * N);
+            for (int k = 0; k < K; ++k)
+                for (int i = 0; i < N; ++i)
+                    for (int c = 0; c < 2; ++c) {
+                        b_psi0[2 * ((size_t)k * N + i) + c] /= bal[i];
+                        b_target[2 * ((size_t)k * N + i) + c] *= bal[i];
+                    }
+            pbal.H0 = b_H0.data(); pbal.Hc = b_Hc.data(); pbal.psi0 = b_psi0.data(); pbal.target = b_target.data();
+            if (p->Dpen) {
+                similar(p->Dpen, p->dpen_per_traj ? (size_t)K : 1, b_Dpen, true);
+                pbal.Dpen = b_Dpen.data();
+            }
+            p = &pbal;
+        }
+    }
+
     grape_handle *h = new grape_handle();
     h->p = *p;
+    h->bal = bal;
     h->N = p->N; h->L = p->L; h->K = p->K; h->N_T = p->N_T;
     h->K_total = p->K_total > 0 ? p->K_total : p->K;
     h->NT = (p->N + 15) / 16; h->NP = 16 * h->NT;
@@ -1829,6 +1922,16 @@ const double *forward_sums(const grape_handle *h) { return h->h_pin + (size_t)h-
 int backward_enqueue(grape_handle *h, const double f_total[2], const double *chi, const double *xi = nullptr,
                      double lambda_b = 0.0) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->bal.empty()) {   // chi~ = D chi, xi~ = D xi (the backward recursion runs with U~^dagger = D U^dagger D^-1)
+        auto scaled = [&](const double *src, size_t rows, std::vector<double> &dst) {
+            dst.assign(src, src + 2 * rows * h->N);
+            for (size_t r = 0; r < rows; ++r)
+                for (int i = 0; i < h->N; ++i) { dst[2 * (r * h->N + i)] *= h->bal[i]; dst[2 * (r * h->N + i) + 1] *= h->bal[i]; }
+            return dst.data();
+        };
+        if (chi) chi = scaled(chi, (size_t)h->K, h->bal_stage_chi);
+        if (xi) xi = scaled(xi, (size_t)h->K * (h->N_T + 1), h->bal_stage_xi);
+    }
     if (xi) {   // [K][N_T+1][N] complex -> d_xi [K][N_T+1][NP] (zero padded); trapezoid weights of optimize.jl:727-750
         const size_t rows = (size_t)h->K * (h->N_T + 1);
         if (!h->d_xi) HIPCHK(h, dmalloc(&h->d_xi, rows * h->NP));
@@ -2047,6 +2150,9 @@ int grape_get_final_states(grape_handle *h, double *psiT) {
     HIPCHK(h, h->foreign_stream ? hipDeviceSynchronize() : hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy2D(psiT, (size_t)h->N * 16, h->d_fw + (size_t)h->N_T * h->NP,
                           (size_t)(h->N_T + 1) * h->NP * 16, (size_t)h->N * 16, h->K, hipMemcpyDeviceToHost));
+    if (!h->bal.empty())   // Psi = D Psi~
+        for (int k = 0; k < h->K; ++k)
+            for (int i = 0; i < h->N; ++i) { psiT[2 * ((size_t)k * h->N + i)] *= h->bal[i]; psiT[2 * ((size_t)k * h->N + i) + 1] *= h->bal[i]; }
     return GRAPE_OK;
 }
 
@@ -2157,6 +2263,25 @@ int grape_get_storage(grape_handle *h, int which, double *out) {
             }
         }
     }
+    if (!h->bal.empty()) {
+        // forward states Psi = D Psi~; backward states chi = D^-1 chi~, normalised like the reference's (||chi_k(T)|| = 1 in
+        // the caller's frame: the stored ones are normalised in the balanced frame)
+        const size_t per_k = (size_t)(h->N_T + 1) * h->N;
+        for (int k = 0; k < h->K; ++k) {
+            double *o = out + 2 * (size_t)k * per_k;
+            for (size_t j = 0; j < per_k; ++j) {
+                const double f = which == 0 ? h->bal[j % h->N] : 1.0 / h->bal[j % h->N];
+                o[2 * j] *= f; o[2 * j + 1] *= f;
+            }
+            if (which == 1) {
+                double nrm = 0.;
+                const double *last = o + 2 * (size_t)h->N_T * h->N;
+                for (int i = 0; i < 2 * h->N; ++i) nrm += last[i] * last[i];
+                nrm = std::sqrt(nrm);
+                if (nrm > 0.) for (size_t j = 0; j < 2 * per_k; ++j) o[j] /= nrm;
+            }
+        }
+    }
     return GRAPE_OK;
 }
 
@@ -2181,8 +2306,9 @@ int grape_get_propagator(grape_handle *h, int k, int n, double *out) {
     HIPCHK(h, hipMemcpy(tmp.data(), h->d_U + ((size_t)h->cls[k] * h->N_T + n) * pp, pp * 16, hipMemcpyDeviceToHost));
     for (int j = 0; j < h->N; ++j)
         for (int i = 0; i < h->N; ++i) {
-            out[2 * ((size_t)j * h->N + i)] = tmp[2 * ((size_t)i * h->NP + j)];
-            out[2 * ((size_t)j * h->N + i) + 1] = tmp[2 * ((size_t)i * h->NP + j) + 1];
+            const double f = h->bal.empty() ? 1.0 : h->bal[i] / h->bal[j];   // U = D U~ D^-1 (exact: powers of two)
+            out[2 * ((size_t)j * h->N + i)] = f * tmp[2 * ((size_t)i * h->NP + j)];
+            out[2 * ((size_t)j * h->N + i) + 1] = f * tmp[2 * ((size_t)i * h->NP + j) + 1];
         }
     return GRAPE_OK;
 }

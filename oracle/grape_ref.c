@@ -20,10 +20,9 @@
  * (block upper-triangular generator, densified by ExpProp) and Julia's stdlib
  * `LinearAlgebra.exp` (Higham 2005 scaling-and-squaring Pade, orders 3/5/7/9 for
  * ||A||_1 <= 2.1 and order 13 with s = ceil(log2(||A||_1 / 5.4)) squarings otherwise,
- * solved with LAPACK gesv = LU with partial pivoting).  They are restated here from their
- * published algorithms.  Deviation: Julia's `exp!` first balances the matrix (LAPACK
- * gebal 'B': permutation + power-of-two diagonal scaling); that is an exact similarity
- * transform, changes results only at rounding level, and is omitted.
+ * solved with LAPACK gesv = LU with partial pivoting), behind LAPACK's gebal('B') balancing
+ * (permutation + power-of-two diagonal scaling, undone on the result) as in Julia's `exp!`.
+ * They are restated here from their published algorithms.
  *
  * PARITY: no numeric golden vectors exist in the reference and Julia is absent from this
  * image, so bit-level parity with the Julia run is UNPINNED.  This file is pinned instead
@@ -168,11 +167,136 @@ static const double PADE13[] = {64764752532480000., 32382376266240000., 77717703
                                 670442572800., 33522128640., 1323241920., 40840800., 960960.,
                                 16380., 182., 1.};
 
-/* E = exp(A), A is n x n column-major and is destroyed.  Higham (2005) as in Julia's exp!.
+/* ---- balancing: LAPACK zgebal('B') as called by Julia's exp! (stdlib LinearAlgebra, dense.jl: `ilo, ihi, scale =
+ * LAPACK.gebal!('B', A)` in front of the Pade evaluation, the inverse transformation behind it).  Restated from the
+ * published algorithm (Parlett & Reinsch 1969; LAPACK 3.5+ form with 2-norms of the rows / columns and the factors
+ * SCLFAC = 2, FACTOR = 0.95): first the permutations that push rows isolating an eigenvalue to the bottom and such columns
+ * to the left, then powers of two d_i with A <- D^-1 A D until no row / column pair improves by 5 %.  Exact in floating
+ * point (powers of two), so exp(A) = P D exp(A_bal) D^-1 P^T holds to the rounding of the exponential alone.
+ * scale[j]: for ilo <= j <= ihi the factor d_j, outside the index of the row / column j was swapped with (0-based here). */
+static int balance_on = 1;
+void grape_ref_set_balance(int on) { balance_on = on; }
+
+static void swap_rc(int n, cplx *A, int a, int b, int lcols, int kstart) {
+    /* columns a <-> b over rows 0..lcols, rows a <-> b over columns kstart..n-1 (zgebal's exchange) */
+    if (a == b) return;
+    for (int i = 0; i <= lcols; ++i) { cplx t = A[(size_t)a * n + i]; A[(size_t)a * n + i] = A[(size_t)b * n + i]; A[(size_t)b * n + i] = t; }
+    for (int j = kstart; j < n; ++j) { cplx t = A[(size_t)j * n + a]; A[(size_t)j * n + a] = A[(size_t)j * n + b]; A[(size_t)j * n + b] = t; }
+}
+
+static void zgebal(int n, cplx *A, int *ilo_, int *ihi_, double *scale) {
+    int k = 0, l = n - 1;   /* active block k..l */
+    /* rows isolating an eigenvalue -> bottom */
+    for (int again = 1; again && l >= 0;) {
+        again = 0;
+        for (int i = l; i >= 0; --i) {
+            int canswap = 1;
+            for (int j = 0; j <= l; ++j)
+                if (i != j && (creal(A[(size_t)j * n + i]) != 0.0 || cimag(A[(size_t)j * n + i]) != 0.0)) { canswap = 0; break; }
+            if (canswap) {
+                scale[l] = (double)i;
+                swap_rc(n, A, i, l, l, k);
+                again = 1;
+                /* (one row left: LAPACK leaves with ILO = IHI = 1 and SCALE(1) = 1, which is its own index AND the factor one) */
+                if (l == 0) { scale[0] = 1.0; *ilo_ = 0; *ihi_ = 0; return; }
+                --l;
+                break;
+            }
+        }
+    }
+    /* columns isolating an eigenvalue -> left */
+    for (int again = 1; again;) {
+        again = 0;
+        for (int j = k; j <= l; ++j) {
+            int canswap = 1;
+            for (int i = k; i <= l; ++i)
+                if (i != j && (creal(A[(size_t)j * n + i]) != 0.0 || cimag(A[(size_t)j * n + i]) != 0.0)) { canswap = 0; break; }
+            if (canswap) {
+                scale[k] = (double)j;
+                swap_rc(n, A, j, k, l, k);
+                again = 1;
+                ++k;
+                break;
+            }
+        }
+    }
+    for (int i = k; i <= l; ++i) scale[i] = 1.0;
+    const double radix = 2.0, sfmin1 = 2.2250738585072014e-308 / 2.220446049250313e-16, sfmax1 = 1.0 / sfmin1;
+    const double sfmin2 = sfmin1 * radix, sfmax2 = 1.0 / sfmin2;
+    for (int noconv = 1; noconv;) {
+        noconv = 0;
+        for (int i = k; i <= l; ++i) {
+            double c = 0.0, r = 0.0, ca = 0.0, ra = 0.0;
+            for (int j = k; j <= l; ++j) {
+                const cplx cji = A[(size_t)i * n + j], rij = A[(size_t)j * n + i];   /* column i, row i inside the block */
+                c += creal(cji) * creal(cji) + cimag(cji) * cimag(cji);
+                r += creal(rij) * creal(rij) + cimag(rij) * cimag(rij);
+            }
+            c = sqrt(c); r = sqrt(r);
+            for (int j = 0; j <= l; ++j) ca = fmax(ca, cabs(A[(size_t)i * n + j]));      /* izamax over A(1:l, i) */
+            for (int j = k; j < n; ++j) ra = fmax(ra, cabs(A[(size_t)j * n + i]));       /* izamax over A(i, k:n) */
+            if (c == 0.0 || r == 0.0) continue;
+            double g = r / radix, f = 1.0;
+            const double s = c + r;
+            while (c < g && fmax(f, fmax(c, ca)) < sfmax2 && fmin(r, fmin(g, ra)) > sfmin2) {
+                f *= radix; c *= radix; ca *= radix; r /= radix; g /= radix; ra /= radix;
+            }
+            g = c / radix;
+            while (g >= r && fmax(r, ra) < sfmax2 && fmin(fmin(f, c), fmin(g, ca)) > sfmin2) {
+                f /= radix; c /= radix; g /= radix; ca /= radix; r *= radix; ra *= radix;
+            }
+            if (c + r >= 0.95 * s) continue;
+            if (f < 1.0 && scale[i] < 1.0 && f * scale[i] <= sfmin1) continue;
+            if (f > 1.0 && scale[i] > 1.0 && scale[i] >= sfmax1 / f) continue;
+            scale[i] *= f;
+            noconv = 1;
+            const double gi = 1.0 / f;
+            for (int j = k; j < n; ++j) A[(size_t)j * n + i] *= gi;      /* row i */
+            for (int j = 0; j <= l; ++j) A[(size_t)i * n + j] *= f;      /* column i */
+        }
+    }
+    *ilo_ = k; *ihi_ = l;
+}
+
+/* X <- P D X D^-1 P^T (Julia's exp!: `X[j, :] *= scale[j]`, `X[:, j] /= scale[j]` for ilo <= j <= ihi, then the swaps undone) */
+static void zgebak_exp(int n, cplx *X, int ilo, int ihi, const double *scale) {
+    for (int j = ilo; j <= ihi; ++j) {
+        const double sj = scale[j], isj = 1.0 / sj;
+        for (int c = 0; c < n; ++c) X[(size_t)c * n + j] *= sj;
+        for (int r = 0; r < n; ++r) X[(size_t)j * n + r] *= isj;
+    }
+    for (int j = ilo - 1; j >= 0; --j) {
+        const int m = (int)scale[j];
+        if (m == j) continue;
+        for (int c = 0; c < n; ++c) { cplx t = X[(size_t)c * n + j]; X[(size_t)c * n + j] = X[(size_t)c * n + m]; X[(size_t)c * n + m] = t; }
+        for (int r = 0; r < n; ++r) { cplx t = X[(size_t)j * n + r]; X[(size_t)j * n + r] = X[(size_t)m * n + r]; X[(size_t)m * n + r] = t; }
+    }
+    for (int j = ihi + 1; j < n; ++j) {
+        const int m = (int)scale[j];
+        if (m == j) continue;
+        for (int c = 0; c < n; ++c) { cplx t = X[(size_t)c * n + j]; X[(size_t)c * n + j] = X[(size_t)c * n + m]; X[(size_t)c * n + m] = t; }
+        for (int r = 0; r < n; ++r) { cplx t = X[(size_t)j * n + r]; X[(size_t)j * n + r] = X[(size_t)m * n + r]; X[(size_t)m * n + r] = t; }
+    }
+}
+
+static int expm_core(int n, cplx *A, cplx *E, cplx *w, int *squarings);
+
+/* E = exp(A), A is n x n column-major and is destroyed.  Higham (2005) behind gebal balancing, as in Julia's exp!.
  * work: 6*n*n cplx.  Returns the Pade order used (negative on singular solve);
  * *squarings receives s. */
 int grape_ref_expm(int n, double *A_, double *E_, double *work_, int *squarings) {
     cplx *A = (cplx *)A_, *E = (cplx *)E_, *w = (cplx *)work_;
+    if (!balance_on) return expm_core(n, A, E, w, squarings);
+    double *scale = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int ilo = 0, ihi = n - 1;
+    zgebal(n, A, &ilo, &ihi, scale);
+    const int order = expm_core(n, A, E, w, squarings);
+    if (order >= 0) zgebak_exp(n, E, ilo, ihi, scale);
+    free(scale);
+    return order;
+}
+
+static int expm_core(int n, cplx *A, cplx *E, cplx *w, int *squarings) {
     const size_t nn = (size_t)n * n;
     cplx *A2 = w, *U = w + nn, *V = w + 2 * nn, *T = w + 3 * nn, *A4 = w + 4 * nn, *A6 = w + 5 * nn;
     const double nA = norm1(n, A);
