@@ -46,7 +46,7 @@ struct ChebyArgs {
     const double *rb;     // [K + Kc*L] 2-norm estimates: r0_k, then r_(kc,l)
     unsigned long long *stats;   // [10] += terms, [11] += (sub-)steps
     double2 *xch;         // [K][4][NP] exchange slots of the recursion vectors, armed with the sentinel at launch
-    int *xcc;             // [K][16] XCC id of every sibling's CU (-1 at launch)
+    int *xcc;             // [K][32] XCC id of every sibling's CU (-1 at launch)
     int xmode;            // XCD-local accesses: bit 0 stores, bit 1 loads (0: device scope throughout)
     double tol;           // terms below tol are dropped (1e-17: converged to rounding)
     int L, hc_per_traj, NP, herm, k0, kn;   // this launch covers the trajectories [k0, k0 + kn)
@@ -120,7 +120,7 @@ __device__ __forceinline__ void cheby_coop_body(const ChebyArgs &a, const int k,
     __shared__ int xl;
     // ---- do all siblings of this trajectory share an XCD (and with it an L2)? ----
     if (tid == 0) {
-        int *xc = a.xcc + (size_t)k * 16;
+        int *xc = a.xcc + (size_t)k * 32;
         const int mine = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);   // HW_REG_XCC_ID[3:0]
         __hip_atomic_store(&xc[s], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int same = 1;

@@ -150,7 +150,7 @@ struct grape_handle {
     int sq_plan = 2;             // blocked path: squaring launches issued per chunk (adapted by grape_check, see expm_large)
     // matrix-free propagator for 64 < N <= 256 (grape_cheby.hip.h): exchange slots, counters, launch plan
     double2 *d_xch = nullptr;    // [2][K][4][NP]  (forward, backward), armed with the sentinel before every launch
-    int *d_xcc = nullptr;        // [2][K][16] XCC ids of the siblings (which XCD does each workgroup run on?)
+    int *d_xcc = nullptr;        // [2][K][32] XCC ids of the siblings (which XCD does each workgroup run on?)
     int cheby_S = 0, cheby_round = 0, cheby_pair = 0;   // siblings per trajectory, trajectories per launch, both directions in one launch
     double2 *d_chi_in = nullptr; // [K][N] host-supplied boundary states of grape_backward_chi (allocated on first use)
     // several GPUs behind one handle (grape_problem.ndev > 1): this handle owns no device memory, its trajectories
@@ -485,10 +485,12 @@ hipError_t launch_deriv_mfma(int NP, const DerivMfmaArgs &a, int nblocks, hipStr
             if (a.L <= 4) return launch_dm<64, 4, false, false>(a, nblocks, s);   // 5 vectors x 2 do not fit in LDS
             return launch_dm<64, 8, false, false>(a, nblocks, s);
         case 128:
+            if (a.L > 4) return hipErrorInvalidValue;
             if (a.L == 1) return launch_dm<128, 1, false, false>(a, nblocks, s);
             if (a.L == 2) return launch_dm<128, 2, false, false>(a, nblocks, s);
             return launch_dm<128, 4, false, false>(a, nblocks, s);
         case 256:
+            if (a.L > 4) return hipErrorInvalidValue;
             if (a.L == 1) return launch_dm<256, 1, false, false>(a, nblocks, s);
             if (a.L == 2) return launch_dm<256, 2, false, false>(a, nblocks, s);
             return launch_dm<256, 4, false, false>(a, nblocks, s);
@@ -500,7 +502,7 @@ hipError_t launch_deriv_mfma(int NP, const DerivMfmaArgs &a, int nblocks, hipStr
 template <int NP, int LMAX, bool CACHE, bool STREAM = false>
 hipError_t launch_d2(const Deriv2Args &a, int nblocks, hipStream_t s) {
     constexpr int NW = NP / 16 <= 8 ? NP / 16 : 8;
-    const size_t lds = sizeof(double) * 2 * 2 * NP * 16;
+    const size_t lds = sizeof(double) * (NP > 256 ? 1 : 2) * 2 * NP * 16;   // (NP = 512: one vector block, see deriv2_kernel)
     static LdsLimit lim;
     int dev = 0;
     hipGetDevice(&dev);
@@ -529,11 +531,17 @@ hipError_t launch_deriv2(int NP, const Deriv2Args &a, int nblocks, hipStream_t s
         case 128:
             if (a.L == 1) return launch_d2<128, 1, false>(a, nblocks, s);
             if (a.L == 2) return launch_d2<128, 2, false>(a, nblocks, s);
+            if (a.L > 4) return launch_d2<128, 8, false, true>(a, nblocks, s);
             return stream_l ? launch_d2<128, 4, false, true>(a, nblocks, s) : launch_d2<128, 4, false>(a, nblocks, s);
         case 256:
             if (a.L == 1) return launch_d2<256, 1, false>(a, nblocks, s);
             if (a.L == 2) return launch_d2<256, 2, false>(a, nblocks, s);
+            if (a.L > 4) return launch_d2<256, 8, false, true>(a, nblocks, s);
             return stream_l ? launch_d2<256, 4, false, true>(a, nblocks, s) : launch_d2<256, 4, false>(a, nblocks, s);
+        case 512:   // matrix-free propagator only: the products one matrix at a time (fewest live registers)
+            if (a.L <= 2) return launch_d2<512, 2, false, true>(a, nblocks, s);
+            if (a.L <= 4) return launch_d2<512, 4, false, true>(a, nblocks, s);
+            return launch_d2<512, 8, false, true>(a, nblocks, s);
         default:
             return hipErrorInvalidValue;
     }
@@ -552,9 +560,9 @@ hipError_t launch_deriv_sub(int NP, const DerivSubArgs &a, int nblocks, hipStrea
         if (L == 1) return launch_ds<NP_, 1>(a, nblocks, s);                 \
         if (L == 2) return launch_ds<NP_, 2>(a, nblocks, s);                 \
         if (L <= 4) return launch_ds<NP_, 4>(a, nblocks, s);                 \
-        return NP_ <= 64 ? launch_ds<NP_, 8>(a, nblocks, s) : hipErrorInvalidValue;
+        return launch_ds<NP_, 8>(a, nblocks, s);
     switch (NP) {
-        DS_CASE(48) DS_CASE(64) DS_CASE(128) DS_CASE(256)
+        DS_CASE(48) DS_CASE(64) DS_CASE(128) DS_CASE(256) DS_CASE(512)
         default: return hipErrorInvalidValue;
     }
 #undef DS_CASE
@@ -838,7 +846,7 @@ hipError_t launch_cheby(grape_handle *h, const SweepArgs *sf, const SweepArgs *s
     hipLaunchKernelGGL(cheby_arm_kernel, dim3(256), dim3(256), 0, s, (unsigned long long *)h->d_xch, (size_t)2 * K * 4 * NP * 2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(h->d_xcc, 0xFF, (size_t)2 * K * 16 * sizeof(int), s);
+    e = hipMemsetAsync(h->d_xcc, 0xFF, (size_t)2 * K * 32 * sizeof(int), s);
     if (e != hipSuccess) return e;
     auto fill = [&](ChebyArgs &c, const SweepArgs &sa, bool backward) {
         c.s = sa;
@@ -846,7 +854,7 @@ hipError_t launch_cheby(grape_handle *h, const SweepArgs *sf, const SweepArgs *s
         c.Hc = backward ? h->d_Hct : h->d_Hcf;
         c.eps = h->d_eps; c.shape = h->d_shape; c.dts = h->d_dts; c.rb = h->d_rb; c.stats = h->d_stats;
         c.xch = h->d_xch + (backward ? (size_t)K * 4 * NP : 0);
-        c.xcc = h->d_xcc + (backward ? (size_t)K * 16 : 0);
+        c.xcc = h->d_xcc + (backward ? (size_t)K * 32 : 0);
         // XCD-local stores (sc0: they land in the XCD's L2, where the siblings' device-scope polls find them) are the
         // default -- C5 shard sweeps 175 -> 141 ms; XCD-local LOADS (buffer_inv sc0 + sc0 load) never saw the data
         // on gfx950 and are not used
@@ -954,12 +962,10 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         g_create_error = "invalid problem dimensions or null array";
         return GRAPE_ERR_INVALID;
     }
-    if (p->N > 256) {
-        g_create_error = "N > 256 is not supported by this build (fused kernel: N <= 64, blocked path: N <= 256)";
-        return GRAPE_ERR_INVALID;
-    }
-    if (p->N > 64 && p->L > 4) {
-        g_create_error = "L > 4 with N > 64 is not supported by this build";
+    if (p->N > 512 || (p->N > 256 && p->prop_method != GRAPE_PROP_SERIES)) {
+        g_create_error = "N > 512 is not supported by this build, and 256 < N <= 512 only with prop_method = GRAPE_PROP_SERIES "
+                         "(the matrix-free polynomial propagator the reference recommends beyond small systems, README.md:55; "
+                         "materialised propagators: fused kernels N <= 64, blocked path N <= 256)";
         return GRAPE_ERR_INVALID;
     }
     if (p->L > 8) { g_create_error = "L > 8 is not supported by this build"; return GRAPE_ERR_INVALID; }
@@ -1030,7 +1036,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
     if (h->NP == 48 && (p->prop_method == GRAPE_PROP_SERIES || (getenv("GRAPE_NO_NT3") && atoi(getenv("GRAPE_NO_NT3"))))) {
         h->NT = 4; h->NP = 64;
     }
-    if (p->N > 64) { h->large = true; h->NP = p->N <= 128 ? 128 : 256; h->NT = h->NP / 16; }
+    if (p->N > 64) { h->large = true; h->NP = p->N <= 128 ? 128 : (p->N <= 256 ? 256 : 512); h->NT = h->NP / 16; }
     h->device = p->device;
     if (p->chi_min_norm > 0) h->chi_min_norm = p->chi_min_norm;
     if (p->taylor_tolerance > 0) h->taylor_tol = p->taylor_tolerance;
@@ -1223,7 +1229,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         if (const char *envb = getenv("GRAPE_DERIV_BLOCKS")) h->deriv_blocks = (int)std::min<long>(nbatch, std::max(1, atoi(envb)));
         {   // two-pass series kernel (deriv2_kernel): untransposed fragments and the u_a parking area
             const char *env = getenv("GRAPE_DERIV2");
-            h->deriv2 = !(env && atoi(env) == 0);
+            // (more than four controls beyond N = 64 and the 512-wide padding exist in the two-pass kernel only)
+            h->deriv2 = !(env && atoi(env) == 0) || (h->large && (L > 4 || NP > 256));
             if (h->deriv2) {
                 pack(p->H0, K, pk, false);
                 CCHK(dmalloc(&h->d_H0q, pk.size()));
@@ -1245,7 +1252,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                 }
             }
         }
-        CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + (h->large ? 4 : 8)) * 2 * NP * 16));
+        CCHK(dmalloc(&h->d_vecs, (size_t)h->deriv_blocks * 2 * (1 + 8) * 2 * NP * 16));
     }
     if (NP < 48 && h->herm && deriv3_fits(h->NT, L)) {   // one wave per batch also at one and two tiles per side (grape_deriv3.hip.h); the matrix-free
                                           // mode as well: at these sizes the derivative kernel never used the parked forward terms
@@ -1418,7 +1425,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         if (!h->cheby_pair) h->fuse = false;   // the two directions do not fit side by side: sequential sweeps
         h->cheby_round = 8 * std::max(1, per_xcd / ((h->cheby_pair ? 2 : 1) * S));
         CCHK(dmalloc(&h->d_xch, (size_t)2 * K * 4 * NP));
-        CCHK(dmalloc(&h->d_xcc, (size_t)2 * K * 16));
+        CCHK(dmalloc(&h->d_xcc, (size_t)2 * K * 32));
     }
     if (h->large && !h->series) {
         // cooperative sweeps when the trajectories alone cannot fill the chip: S siblings per trajectory,

@@ -3327,9 +3327,13 @@ struct Deriv2Args {
 // running sum at once (H w = H0 w + sum_l e_l mu_l w; pass 2 also takes the overlap of mu_l^dagger w with u_a), so that the
 // partial products of a single matrix are live instead of those of all 1 + L: with all of them live the kernel needs
 // 24 (1 + L) accumulator registers and spills from L = 5 on (644 bytes of scratch per lane at L = 6).
+// NP = 512 (matrix-free propagator for 256 < N <= 512): ONE vector block instead of the ping-pong pair -- two of them are
+// 262 KB, the LDS has 160.  A wave then keeps the new rows of its row tiles in registers until every wave is done reading
+// the old block (one more barrier per series order).
 template <int NP, int LMAX, bool CACHE_A, bool STREAM_L = false>
 __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kernel(Deriv2Args a) {
-    extern __shared__ __attribute__((aligned(16))) double dsm2[];   // [2][2][NP*16] ping-pong vector block
+    extern __shared__ __attribute__((aligned(16))) double dsm2[];   // [2][2][NP*16] ping-pong vector block ([1][2][NP*16] at NP = 512)
+    constexpr bool ONEBUF = NP > 256;
     constexpr int RT = NP / 16, KS = NP / 4;
     constexpr int NW = RT <= 8 ? RT : 8, TPW = RT / NW, NV = 1 + LMAX;
     static_assert(RT % NW == 0, "row tiles must divide evenly over the waves");
@@ -3477,9 +3481,10 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
         __syncthreads();
         for (int m = 1; m <= mcap; ++m) {   // forms u_m
             const double *vc = dsm2 + (size_t)cur * 2 * vplane;
-            double *vn = dsm2 + (size_t)(cur ^ 1) * 2 * vplane;
+            double *vn = dsm2 + (size_t)(ONEBUF ? cur : cur ^ 1) * 2 * vplane;
             const double sfac = dt / (double)m;
             double nn = 0.;
+            double keep_r[ONEBUF ? TPW : 1][4], keep_i[ONEBUF ? TPW : 1][4];
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt) {
                 const int rt = wave + tt * NW;
@@ -3500,13 +3505,24 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                 for (int r = 0; r < 4; ++r) {
                     const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
                     const double ur = sfac * pi[0][r], ui = -sfac * pr[0][r];   // (-i s)(x + i y) = s y - i s x
-                    vn[o] = ur; vn[vplane + o] = ui;
+                    if constexpr (ONEBUF) { keep_r[ONEBUF ? tt : 0][r] = ur; keep_i[ONEBUF ? tt : 0][r] = ui; }
+                    else { vn[o] = ur; vn[vplane + o] = ui; }
 #ifdef GRAPE_DIAG
                     if (!(a.ablate & 1))
 #endif
                     if (m < a.maxm) { park[(size_t)m * 2 * vplane + o] = ur; park[(size_t)m * 2 * vplane + vplane + o] = ui; }
                     nn += ur * ur + ui * ui;
                 }
+            }
+            if constexpr (ONEBUF) {
+                __syncthreads();   // every wave is done reading the block
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const size_t o = (size_t)(16 * (wave + tt * NW) + 4 * r + rg) * 16 + c;
+                        vn[o] = keep_r[ONEBUF ? tt : 0][r]; vn[vplane + o] = keep_i[ONEBUF ? tt : 0][r];
+                    }
             }
             nn += __shfl_xor(nn, 16, 64);
             nn += __shfl_xor(nn, 32, 64);
@@ -3515,7 +3531,7 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
             double tot = 0.;
 #pragma unroll
             for (int w = 0; w < NW; ++w) tot += redn[m & 1][w][c];
-            cur ^= 1;
+            if constexpr (!ONEBUF) cur ^= 1;
             M = m;
             // ||u_m|| < tol for every cell of the batch (identical decision in every wave: same LDS values)
             if (m >= 2 && __all(tot < a.tol * a.tol)) { converged = 1; break; }
@@ -3545,8 +3561,9 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
         for (int l = 0; l < LMAX; ++l) { dr[l] = 0.; di[l] = 0.; }
         for (int aa = M - 1; aa >= 0; --aa) {
             const double *vc = dsm2 + (size_t)cur * 2 * vplane;
-            double *vn = dsm2 + (size_t)(cur ^ 1) * 2 * vplane;
+            double *vn = dsm2 + (size_t)(ONEBUF ? cur : cur ^ 1) * 2 * vplane;
             const double inv = 1.0 / (double)(aa + 1), sfac = dt * inv;
+            double keep_r[ONEBUF ? TPW : 1][4], keep_i[ONEBUF ? TPW : 1][4];
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt) {
                 const int rt = wave + tt * NW;
@@ -3601,13 +3618,26 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {   // chi + (i s)(x + i y) = chi - s y + i s x
                         const size_t o = (size_t)(16 * rt + 4 * r + rg) * 16 + c;
-                        vn[o] = chr[tt][r] - sfac * pi[0][r];
-                        vn[vplane + o] = chi_[tt][r] + sfac * pr[0][r];
+                        const double wr_ = chr[tt][r] - sfac * pi[0][r], wi_ = chi_[tt][r] + sfac * pr[0][r];
+                        if constexpr (ONEBUF) { keep_r[ONEBUF ? tt : 0][r] = wr_; keep_i[ONEBUF ? tt : 0][r] = wi_; }
+                        else { vn[o] = wr_; vn[vplane + o] = wi_; }
                     }
                 }
             }
+            if constexpr (ONEBUF) {
+                __syncthreads();   // every wave is done reading the block
+                if (aa > 0) {
+#pragma unroll
+                    for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const size_t o = (size_t)(16 * (wave + tt * NW) + 4 * r + rg) * 16 + c;
+                            vn[o] = keep_r[ONEBUF ? tt : 0][r]; vn[vplane + o] = keep_i[ONEBUF ? tt : 0][r];
+                        }
+                }
+            }
             __syncthreads();
-            cur ^= 1;
+            if constexpr (!ONEBUF) cur ^= 1;
         }
         // ---- tau_grads = rho (-i dt s_l) sum_a <mu_l^dagger w_a | u_a> / (a+1) ----
 #pragma unroll

@@ -169,8 +169,17 @@ def test_error_behaviour(g):
         with pytest.raises(g.GrapeHipError) as ei:
             h.eval(pr["pulsevals"])
         assert ei.value.code == -5
-    with pytest.raises(g.GrapeHipError):  # N > 256 is refused loudly, not emulated
-        pr = synth.make_problem(257, 1, 2, 1, seed=1)
+    # the size envelope is refused loudly, not emulated: materialised propagators up to N = 256, the matrix-free propagator
+    # up to N = 512, at most eight controls
+    pr = synth.make_problem(257, 1, 2, 1, seed=1)
+    with pytest.raises(g.GrapeHipError) as ei:
+        g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"])
+    assert "GRAPE_PROP_SERIES" in str(ei.value)
+    pr = synth.make_problem(513, 1, 2, 1, seed=1)
+    with pytest.raises(g.GrapeHipError):
+        g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], prop_method=g.PROP_SERIES)
+    pr = synth.make_problem(20, 9, 2, 1, seed=1)
+    with pytest.raises(g.GrapeHipError):
         g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"])
 
 

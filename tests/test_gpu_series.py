@@ -280,3 +280,20 @@ def test_chebyshev_spectral_interval_is_guaranteed(g, ref):
     Jr, Gr, taur = ref.evaluate(H0, Hc, tl, x, psi0, target, np.ones(K))
     assert np.abs(np.linalg.norm(fw, axis=2) - 1.0).max() <= 1e-11
     assert abs(J - Jr) <= 1e-11 and np.abs(tau - taur).max() <= 1e-11 and np.abs(G - Gr).max() <= 10 * tol_G(Gr)
+
+
+@pytest.mark.parametrize("N,L,K,N_T,pm", [(320, 2, 2, 3, "series"), (512, 1, 2, 3, "series"), (128, 6, 2, 3, "series"),
+                                           (128, 6, 2, 3, "exp"), (200, 8, 1, 2, "exp")])
+def test_size_envelope_of_round_4(g, ref, N, L, K, N_T, pm):
+    """The reference has no size cap and steers larger systems to its polynomial propagators (README.md:55,
+    docs/src/tutorial.md:308).  Round 4: prop_method = GRAPE_PROP_SERIES up to N = 512 (cooperative Chebyshev sweeps with 32
+    sibling workgroups per trajectory; derivative kernel with ONE vector block in LDS), and up to eight controls beyond
+    N = 64 on both propagators -- against the C restatement's :taylor route."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=4000 + N + L)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    Jr, Gr, taur = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], gradient_method=ref.TAYLOR)
+    with g.GrapeHip(*args, prop_method=g.PROP_SERIES if pm == "series" else g.PROP_EXP) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+    assert abs(J - Jr) <= 1e-12 and np.abs(tau - taur).max() <= 1e-12
+    assert np.abs(G - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)
