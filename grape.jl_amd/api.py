@@ -236,10 +236,13 @@ class GrapeHip:
             p.dpen_per_traj = int(D.ndim == 3)
             p.lambda_b = self.lambda_b
         self._devices = None
-        if devices is not None and len(devices) > 1:
+        if devices is not None and len(devices) >= 1:
+            # (one ordinal: the plain single-device handle on that device -- unless GRAPE_MULTI_RCCL=1 asks for the composite
+            # handle with a one-rank communicator, the exercise of the collective code path on a single GPU)
             self._devices = np.ascontiguousarray(devices, dtype=np.int32)
             p.ndev = len(self._devices)
             p.devices = self._devices.ctypes.data
+            p.device = int(self._devices[0])
         self._h = C.c_void_p()
         rc = self._lib.grape_create(C.byref(self._h), C.byref(p))
         if rc:
@@ -367,11 +370,13 @@ class GrapeHip:
         return out
 
     def timings(self):
-        ms = np.full(7, -1.0)
-        self._lib.grape_get_timings(self._h, ms.ctypes.data, 7)
+        ms = np.full(8, -1.0)
+        self._lib.grape_get_timings(self._h, ms.ctypes.data, 8)
         out = dict(zip(["expm", "forward", "backward", "deriv", "reduce", "total"], ms[:6].tolist()))
         if ms[6] >= 0.0:   # several devices behind this handle: host wall time of the enqueue halves per evaluation
             out["host_enqueue"] = float(ms[6])
+        if ms[7] >= 0.0:   # ... and their reductions are RCCL all-reduces: latency of the gradient all-reduce
+            out["gradient_allreduce_us"] = float(ms[7]) * 1e3
         return out
 
     def reset_timings(self):

@@ -13,6 +13,10 @@
 #include "grape_series.hip.h"
 #include "grape_cheby.hip.h"
 
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <mutex>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -158,6 +162,16 @@ struct grape_handle {
     std::vector<grape_handle *> shards;
     std::vector<int> shard_lo;
     std::vector<int> shard_dev;
+    // composite handle: the two cross-shard reductions (8 partial sums between the sweeps, the gradient at the end) as
+    // RCCL all-reduces on the shard streams (ncclCommInitAll: one communicator rank per device of this process) when the
+    // shard devices are distinct; otherwise, or with GRAPE_MULTI_RCCL=0, or when RCCL cannot be loaded: staged through
+    // pinned host memory and added in shard order.  d_red: [8 + L N_T] all-reduced copies per shard.
+    bool use_rccl = false;
+    std::vector<void *> comms;
+    std::vector<double *> d_red;
+    hipEvent_t ar0 = nullptr, ar1 = nullptr;   // around shard 0's gradient all-reduce
+    double allreduce_ms = 0.0;
+    long allreduce_calls = 0;
     std::vector<double> h_multi;   // host scratch of the composite: pulses, per-shard gradients
     bool multi_threads = true;     // composite: the enqueue half of every shard from its own host thread (GRAPE_MULTI_THREADS=0:
                                    // one after the other from the calling thread)
@@ -310,6 +324,38 @@ hipError_t launch_series(const SeriesArgs &a, bool backward, hipStream_t s) {
     else SERIES_CASE(0);
 #undef SERIES_CASE
     return hipGetLastError();
+}
+
+// RCCL, loaded at run time (no link dependency: a process that never builds a multi-device handle never touches it; a
+// process that already carries RCCL -- PyTorch does -- gets that copy)
+struct RcclApi {
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+const RcclApi &rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+        api.CommInitAll = (decltype(api.CommInitAll))dlsym(lib, "ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(lib, "ncclCommDestroy");
+        api.AllReduce = (decltype(api.AllReduce))dlsym(lib, "ncclAllReduce");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(lib, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(lib, "ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(lib, "ncclGetErrorString");
+        api.ok = api.CommInitAll && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd;
+    });
+    return api;
 }
 
 // The scaling half of LAPACK gebal (2-norm form, factors of two, 5 % rule) on a real non-negative N x N matrix
@@ -929,7 +975,14 @@ const char *grape_last_error(grape_handle *h) { return h ? h->err.c_str() : g_cr
 
 void grape_destroy(grape_handle *h) {
     if (!h) return;
-    if (!h->shards.empty()) {
+    if (!h->shards.empty() || !h->comms.empty()) {
+        for (size_t g = 0; g < h->comms.size(); ++g) {
+            if (g < h->shards.size()) { hipSetDevice(h->shards[g]->device); hipStreamSynchronize(h->shards[g]->stream); }
+            if (h->comms[g]) rccl_api().CommDestroy((ncclComm_t)h->comms[g]);
+            if (g < h->d_red.size() && h->d_red[g]) hipFree(h->d_red[g]);
+        }
+        if (h->ar0) hipEventDestroy(h->ar0);
+        if (h->ar1) hipEventDestroy(h->ar1);
         for (grape_handle *c : h->shards) grape_destroy(c);
         delete h;
         return;
@@ -978,6 +1031,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
         if (!(p->tlist[n + 1] > p->tlist[n])) { g_create_error = "tlist must be strictly increasing"; return GRAPE_ERR_INVALID; }
     if (p->ndev < 0 || p->ndev > 64) { g_create_error = "ndev out of range (0..64)"; return GRAPE_ERR_INVALID; }
     if (p->ndev > 1) return multi_create(out, p);
+    if (p->ndev == 1 && getenv("GRAPE_MULTI_RCCL") && atoi(getenv("GRAPE_MULTI_RCCL")) == 1)
+        return multi_create(out, p);   // one shard behind a one-rank communicator: the collective code path on a single GPU
 
     // ---- balancing (see grape_handle::bal): the problem the handle is built from is D^-1 H D, D^-1 Psi0, D target, D Dpen D ----
     std::vector<double> bal, b_H0, b_Hc, b_psi0, b_target, b_Dpen;
@@ -1927,7 +1982,7 @@ int forward_finish(grape_handle *h, double *tau) {
 const double *forward_sums(const grape_handle *h) { return h->h_pin + (size_t)h->L * h->N_T + 2 * (size_t)h->K; }
 
 int backward_enqueue(grape_handle *h, const double f_total[2], const double *chi, const double *xi = nullptr,
-                     double lambda_b = 0.0) {
+                     double lambda_b = 0.0, bool copy_out = true) {
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->bal.empty()) {   // chi~ = D chi, xi~ = D xi (the backward recursion runs with U~^dagger = D U^dagger D^-1)
         auto scaled = [&](const double *src, size_t rows, std::vector<double> &dst) {
@@ -1968,12 +2023,13 @@ int backward_enqueue(grape_handle *h, const double f_total[2], const double *chi
     const int rc = backward_device_impl(h, h->d_f, h->d_G, h->stream, d_chi);
     h->xi_user = nullptr;
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_G, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToHost, h->stream));
+    if (copy_out) HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_G, (size_t)h->L * h->N_T * 8, hipMemcpyDeviceToHost, h->stream));
     return GRAPE_OK;
 }
 int backward_finish(grape_handle *h, double *G, bool accumulate) {
     const int rc = grape_check(h, h->stream);
     if (rc) return rc;
+    if (!G) return GRAPE_OK;
     const size_t nl = (size_t)h->L * h->N_T;
     if (accumulate) for (size_t i = 0; i < nl; ++i) G[i] += h->h_pin[i];
     else memcpy(G, h->h_pin, nl * 8);
@@ -2028,18 +2084,52 @@ int multi_enqueue(grape_handle *h, F fn) {
     return GRAPE_OK;
 }
 
+// one all-reduce (sum) of `count` doubles per shard, src(c) -> d_red[g] + off, on the shard streams; timed on shard 0
+template <typename Src>
+int multi_allreduce(grape_handle *h, Src src, size_t off, size_t count, bool timed) {
+    const RcclApi &api = rccl_api();
+    if (timed) { hipSetDevice(h->shards[0]->device); hipEventRecord(h->ar0, h->shards[0]->stream); }
+    ncclResult_t r = api.GroupStart();
+    for (size_t g = 0; g < h->shards.size() && r == ncclSuccess; ++g) {
+        grape_handle *c = h->shards[g];
+        hipSetDevice(c->device);
+        r = api.AllReduce(src(c), h->d_red[g] + off, count, ncclDouble, ncclSum, (ncclComm_t)h->comms[g], c->stream);
+    }
+    const ncclResult_t re = api.GroupEnd();
+    if (r == ncclSuccess) r = re;
+    if (r != ncclSuccess) {
+        h->err = std::string("RCCL all-reduce failed: ") + (api.GetErrorString ? api.GetErrorString(r) : "?");
+        return GRAPE_ERR_HIP;
+    }
+    if (timed) { hipSetDevice(h->shards[0]->device); hipEventRecord(h->ar1, h->shards[0]->stream); }
+    return GRAPE_OK;
+}
+
 int multi_forward(grape_handle *h, const double *pulsevals, double *tau) {
     {
         const bool want_bw = h->want_bw;
         const int rc = multi_enqueue(h, [&](grape_handle *c, size_t) {
             c->want_bw = want_bw;
-            const int r = forward_enqueue(c, pulsevals);
+            const int r = forward_enqueue(c, pulsevals, !h->use_rccl);
             c->want_bw = true;
             return r;
         });
         if (rc) return rc;
     }
-    double *sums = h->h_multi.data();   // [8]: shard sums added in shard order (fixed: reproducible)
+    if (h->use_rccl) {
+        // the 8 partial sums of every shard: RCCL all-reduce on the shard streams, then the slab copies (tau of the shard
+        // and, in the place of its partial sums, the totals)
+        const int rc = multi_allreduce(h, [](grape_handle *c) { return (const void *)(c->d_out + 2 * (size_t)c->K); }, 0, 8, false);
+        if (rc) return rc;
+        for (size_t g = 0; g < h->shards.size(); ++g) {
+            grape_handle *c = h->shards[g];
+            const size_t nl = (size_t)c->L * c->N_T;
+            HIPCHK(h, hipSetDevice(c->device));
+            HIPCHK(h, hipMemcpyAsync(c->h_pin + nl, c->d_out, (size_t)2 * c->K * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(h, hipMemcpyAsync(c->h_pin + nl + 2 * (size_t)c->K, h->d_red[g], 8 * 8, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    double *sums = h->h_multi.data();   // [8]: shard sums added in shard order (fixed: reproducible) / the all-reduced totals
     std::fill(sums, sums + 8, 0.0);
     int again = 0;
     for (size_t g = 0; g < h->shards.size(); ++g) {
@@ -2048,7 +2138,8 @@ int multi_forward(grape_handle *h, const double *pulsevals, double *tau) {
         if (rc == GRAPE_ERR_AGAIN) { again = 1; h->err = c->err; continue; }   // every shard adapts its own plan
         if (rc) return multi_fail(h, c, rc);
         const double *cs = forward_sums(c);
-        for (int i = 0; i < 8; ++i) sums[i] += cs[i];
+        if (h->use_rccl) { if (g == 0) for (int i = 0; i < 8; ++i) sums[i] = cs[i]; }
+        else for (int i = 0; i < 8; ++i) sums[i] += cs[i];
     }
     if (again) return GRAPE_ERR_AGAIN;
     h->have_forward = true;
@@ -2060,9 +2151,29 @@ int multi_backward(grape_handle *h, const double f_total[2], const double *chi, 
     {
         const int rc = multi_enqueue(h, [&](grape_handle *c, size_t g) {
             return backward_enqueue(c, f_total, chi ? chi + 2 * (size_t)h->shard_lo[g] * h->N : nullptr,
-                                    xi ? xi + 2 * (size_t)h->shard_lo[g] * (h->N_T + 1) * h->N : nullptr, lambda_b);
+                                    xi ? xi + 2 * (size_t)h->shard_lo[g] * (h->N_T + 1) * h->N : nullptr, lambda_b, !h->use_rccl);
         });
         if (rc) return rc;
+    }
+    if (h->use_rccl) {
+        // sum over k of optimize.jl:579 across the shards: RCCL all-reduce of the L N_T doubles on the shard streams; the
+        // total comes back from shard 0 (the summation order is RCCL's, fixed for a given set of devices)
+        const size_t nl = (size_t)h->L * h->N_T;
+        int rc = multi_allreduce(h, [](grape_handle *c) { return (const void *)c->d_G; }, 8, nl, true);
+        if (rc) return rc;
+        grape_handle *c0 = h->shards[0];
+        HIPCHK(h, hipSetDevice(c0->device));
+        HIPCHK(h, hipMemcpyAsync(c0->h_pin, h->d_red[0] + 8, nl * 8, hipMemcpyDeviceToHost, c0->stream));
+        for (size_t g = 0; g < h->shards.size(); ++g) {
+            rc = backward_finish(h->shards[g], g == 0 ? G : nullptr, false);
+            if (rc) return multi_fail(h, h->shards[g], rc);
+        }
+        float ms = 0.f;
+        if (hipSetDevice(c0->device) == hipSuccess && hipEventElapsedTime(&ms, h->ar0, h->ar1) == hipSuccess) {
+            h->allreduce_ms += ms;
+            h->allreduce_calls += 1;
+        }
+        return GRAPE_OK;
     }
     for (size_t g = 0; g < h->shards.size(); ++g) {   // sum over k of optimize.jl:579 across the shards, in shard order
         grape_handle *c = h->shards[g];
@@ -2333,6 +2444,9 @@ int grape_get_timings(grape_handle *h, double *ms, int n) {
         // [6]: host wall time of the enqueue halves (forward + backward) per evaluation -- what the calling thread spends
         // before the first device can be waited for
         if (n > kPhases) { ms[kPhases] = h->host_enqueue_calls ? 2.0 * h->host_enqueue_ms / h->host_enqueue_calls : -1.0; cnt = kPhases + 1; }
+        // [7]: RCCL all-reduce of the gradient across the shards, HIP events on shard 0's stream (includes waiting for the
+        // slowest shard); -1: the reductions are host-staged
+        if (n > kPhases + 1) { ms[kPhases + 1] = (h->use_rccl && h->allreduce_calls) ? h->allreduce_ms / h->allreduce_calls : -1.0; cnt = kPhases + 2; }
         return cnt;
     }
     HIPCHK(h, hipSetDevice(h->device));
@@ -2359,6 +2473,7 @@ int grape_reset_timings(grape_handle *h) {
             if (rc) return multi_fail(h, c, rc);
         }
         h->host_enqueue_ms = 0.0;
+        h->allreduce_ms = 0.0; h->allreduce_calls = 0;
         h->host_enqueue_calls = 0;
         return GRAPE_OK;
     }
@@ -2470,6 +2585,28 @@ int multi_create(grape_handle **out, const grape_problem *p) {
         h->shard_dev.push_back(cp.device);
     }
     h->shard_lo.push_back(p->K);
+    {   // RCCL for the two reductions when every shard has a device of its own
+        const char *envr = getenv("GRAPE_MULTI_RCCL");
+        bool distinct = true;
+        for (int a = 0; a < G; ++a)
+            for (int b = a + 1; b < G; ++b) distinct = distinct && h->shard_dev[a] != h->shard_dev[b];
+        if (distinct && !(envr && atoi(envr) == 0) && rccl_api().ok) {
+            std::vector<ncclComm_t> cs((size_t)G);
+            if (rccl_api().CommInitAll(cs.data(), G, h->shard_dev.data()) == ncclSuccess) {
+                h->use_rccl = true;
+                for (int g = 0; g < G && h->use_rccl; ++g) {
+                    h->comms.push_back((void *)cs[g]);
+                    double *buf = nullptr;
+                    if (hipSetDevice(h->shard_dev[g]) != hipSuccess ||
+                        hipMalloc((void **)&buf, (8 + (size_t)p->L * p->N_T) * sizeof(double)) != hipSuccess) h->use_rccl = false;
+                    h->d_red.push_back(buf);
+                }
+                if (h->use_rccl && (hipSetDevice(h->shard_dev[0]) != hipSuccess || hipEventCreate(&h->ar0) != hipSuccess ||
+                                    hipEventCreate(&h->ar1) != hipSuccess)) h->use_rccl = false;
+            }
+            (void)hipGetLastError();
+        }
+    }
     *out = h;
     return GRAPE_OK;
 }

@@ -29,9 +29,10 @@
  *   - several GPUs behind ONE handle (ABI v4, grape_problem.ndev / .devices): the K trajectories of the
  *     handle are dealt to the devices in contiguous blocks, every host-pointer entry point enqueues the work
  *     of all of them (one host thread per device, asynchronous launches on one stream per device; the
- *     calling thread waits and reads back) and performs the two reductions itself in a fixed order -- the
- *     caller never sees the devices, exactly like the transparent `@threadsif` loops over k of
- *     optimize.jl:720, 876.
+ *     calling thread waits and reads back) and performs the two reductions itself -- RCCL all-reduces on the
+ *     shard streams (one communicator rank per device, ncclCommInitAll) when every shard has a device of its
+ *     own, otherwise staged through pinned host memory in shard order -- the caller never sees the devices,
+ *     exactly like the transparent `@threadsif` loops over k of optimize.jl:720, 876.
  */
 #ifndef GRAPE_HIP_H
 #define GRAPE_HIP_H
@@ -226,8 +227,9 @@ int grape_get_storage(grape_handle *h, int which /*0 fw, 1 bw*/, double *out /* 
  * kernels were launched on, AVERAGED over the evaluations since the last grape_reset_timings
  * (at most the 64 most recent): [0] expm kernel, [1] forward sweep, [2] backward sweep,
  * [3] cell derivatives, [4] reduction, [5] whole grape_eval; handles with several devices (ndev > 1) also [6] the host
- * wall time of the enqueue halves per evaluation (every shard is enqueued from its own host thread).  Synchronises
- * the device.
+ * wall time of the enqueue halves per evaluation (every shard is enqueued from its own host thread) and [7] the latency of
+ * the RCCL all-reduce of the gradient across the shards (HIP events on the first shard's stream; -1 when the reductions
+ * are host-staged: repeated device ordinals, GRAPE_MULTI_RCCL=0, RCCL not loadable).  Synchronises the device.
  * Returns the number of entries written. */
 int grape_get_timings(grape_handle *h, double *ms, int n);
 int grape_reset_timings(grape_handle *h);
