@@ -258,7 +258,7 @@ def main():
             pmc_file = cands[-1] if cands else None
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file))) if pmc_file else {"kernels": {}}
             for kname, d in pmc["kernels"].items():   # the dominant kernel of phase A of THIS configuration
-                if any(t in kname for t in ("expm_t18_kernel", "expm_pade_kernel", "expm_persistent_kernel", "lg_gemm_kernel")) \
+                if any(t in kname for t in ("expm_t16_asm", "expm_t18_kernel", "expm_pade_kernel", "expm_persistent_kernel", "lg_gemm_kernel")) \
                         and d.get("MfmaUtil_percent", 0) > 1:
                     traffic = d.get("hbm_bytes_per_launch")
                     hw_util = d.get("MfmaUtil_percent")
