@@ -58,22 +58,26 @@ def library_path() -> str:
 
 
 def build_asm(verbose: bool = False) -> str:
-    """Generate, assemble and wrap the hand-allocated gfx950 kernel (csrc/asm/gen_t16.py): .s -> code object -> an object
-    file that carries the code object as bytes (grape_asm_co_start / _end), linked into the library."""
+    """Generate, assemble and wrap the hand-allocated gfx950 kernels (csrc/asm/gen_t16.py, gen_d3.py): .s -> one code object
+    -> an object file that carries the code object as bytes (grape_asm_co_start / _end), linked into the library."""
     asm_dir = os.path.join(_CSRC, "asm")
-    s_path, o_path = os.path.join(asm_dir, "expm_t16_asm.s"), os.path.join(asm_dir, "expm_t16_asm.o")
-    co_path, emb_s, emb_o = os.path.join(asm_dir, "expm_t16_asm.co"), os.path.join(asm_dir, "asm_embed.S"), os.path.join(asm_dir, "asm_embed.o")
-    gen = subprocess.run([sys.executable, os.path.join(asm_dir, "gen_t16.py"), s_path], capture_output=True, text=True)
-    if verbose or gen.returncode:
-        print(gen.stdout, gen.stderr)
-    if gen.returncode:
-        raise RuntimeError("gen_t16.py failed")
+    kernels = (("gen_t16.py", "expm_t16_asm"), ("gen_d3.py", "deriv3_asm"))
+    co_path, emb_s, emb_o = os.path.join(asm_dir, "grape_asm.co"), os.path.join(asm_dir, "asm_embed.S"), os.path.join(asm_dir, "asm_embed.o")
     llvm = "/opt/rocm/lib/llvm/bin"
-    cmds = [[os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s_path, "-o", o_path],
-            [os.path.join(llvm, "ld.lld"), "-shared", o_path, "-o", co_path]]
+    cmds, objs = [], []
+    for gen_py, name in kernels:
+        s_path, o_path = os.path.join(asm_dir, name + ".s"), os.path.join(asm_dir, name + ".o")
+        gen = subprocess.run([sys.executable, os.path.join(asm_dir, gen_py), s_path], capture_output=True, text=True)
+        if verbose or gen.returncode:
+            print(gen.stdout, gen.stderr)
+        if gen.returncode:
+            raise RuntimeError(gen_py + " failed")
+        cmds.append([os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s_path, "-o", o_path])
+        objs.append(o_path)
+    cmds.append([os.path.join(llvm, "ld.lld"), "-shared"] + objs + ["-o", co_path])
     with open(emb_s, "w") as f:
         f.write('\t.section .rodata\n\t.globl grape_asm_co_start\n\t.globl grape_asm_co_end\n\t.p2align 12\n'
-                'grape_asm_co_start:\n\t.incbin "expm_t16_asm.co"\ngrape_asm_co_end:\n\t.byte 0\n'
+                'grape_asm_co_start:\n\t.incbin "grape_asm.co"\ngrape_asm_co_end:\n\t.byte 0\n'
                 '\t.section .note.GNU-stack,"",@progbits\n')
     cmds.append(["gcc", "-c", "-fPIC", "asm_embed.S", "-o", "asm_embed.o"])
     for c in cmds:
@@ -81,7 +85,7 @@ def build_asm(verbose: bool = False) -> str:
         if verbose or res.returncode:
             print(" ".join(c), res.stdout, res.stderr)
         if res.returncode:
-            raise RuntimeError("assembling the gfx950 kernel failed")
+            raise RuntimeError("assembling the gfx950 kernels failed")
     return emb_o
 
 
@@ -90,7 +94,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     out = out or library_path()
     srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_t18.hip", "grape_kernels.hip.h", "grape_large.hip.h",
                                              "grape_series.hip.h", "grape_cheby.hip.h", "grape_t18.hip.h", "grape_t18_coeffs.h",
-                                             "grape_deriv3.hip.h", os.path.join("asm", "gen_t16.py"), os.path.join("asm", "gcn.py"))]
+                                             "grape_deriv3.hip.h", os.path.join("asm", "gen_t16.py"), os.path.join("asm", "gen_d3.py"), os.path.join("asm", "gcn.py"))]
     hdr = os.path.join(_HERE, "..", "include", "grape_hip.h")
     if (not force and os.path.exists(out)
             and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs + [hdr])):

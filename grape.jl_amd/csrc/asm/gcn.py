@@ -141,12 +141,24 @@ class Prog:
         self.vm_q = []
         self.auto_waits = 0
         self.tag = ""                  # free-form label copied into the LDS instructions (bank-conflict statistics by phase)
+        # join points wait for the outstanding LOADS only: stores behind the last load stay in flight (nothing depends on
+        # them; the counters are relative to the tail of the queue, so older operations the model forgot never make a
+        # later wait too weak)
+        self.soft_vm_flush = False
 
     # ---- low level ----
     def flush_waits(self):
         """join points: nothing may be outstanding (the queues are only exact in straight-line code)"""
-        if self.lgkm_q or self.vm_q:
-            self.s_waitcnt(vm=0 if self.vm_q else None, lgkm=0 if self.lgkm_q else None)
+        vm = 0 if self.vm_q else None
+        if self.soft_vm_flush and self.vm_q:
+            loads = [pos for pos, e in enumerate(self.vm_q) if e["regs"]]
+            vm = min(len(self.vm_q) - loads[-1] - 1, 63) if loads else None
+            if vm is None:
+                self.vm_q.clear()
+        if self.lgkm_q or vm is not None:
+            self.s_waitcnt(vm=vm, lgkm=0 if self.lgkm_q else None)
+        if self.soft_vm_flush:
+            self.vm_q.clear()
 
     def label(self, name):
         assert name not in self.labels
@@ -351,8 +363,8 @@ class Prog:
         return self._mk("v_mov_b32_dpp", dst, [src], "dpp", {"ctrl": ctrl, "row_mask": row_mask, "bank_mask": bank_mask,
                                                             "bound_ctrl": bound_ctrl}, extra, reads=_regs_of(dst))
 
-    def mfma(self, d, a, b, c):
-        """v_mfma_f64_16x16x4_f64 d, a, b, c   (c: the same 8-register tile as d, or 0)"""
+    def mfma(self, d, a, b, c, neg_a=False):
+        """v_mfma_f64_16x16x4_f64 d, a, b, c   (c: the same 8-register tile as d, or 0; neg_a: the negation bit of A)"""
         roles = {}
         for key in _regs_of(a) + _regs_of(b):
             roles[key] = "ab"
@@ -360,7 +372,8 @@ class Prog:
             for key in _regs_of(c):
                 roles[key] = "c"
         ctile = (d.cls, d.idx)
-        return self._mk("v_mfma_f64_16x16x4_f64", d, [a, b, c], "mfma", {"_roles": roles, "_ctile": ctile})
+        return self._mk("v_mfma_f64_16x16x4_f64", d, [a, b, c], "mfma", {"_roles": roles, "_ctile": ctile, "neg_a": neg_a},
+                        " neg:[1,0,0]" if neg_a else "")
 
     # ---- LDS ----
     def ds_read(self, bits, dst, addr, offset=0):
@@ -388,6 +401,12 @@ class Prog:
         if ndw > 2:
             mods["_wide_store"] = data.regs()
         return self._mk(op, None, [voff, data, sbase], "vmem", mods, (f" offset:{offset}" if offset else "") + (" nt" if nt else ""))
+
+    def global_atomic(self, op, voff, data, sbase, offset=0):
+        """global_atomic_{add, or, add_x2} without return: memory[s[base] + voff + offset] op= data"""
+        assert op in ("global_atomic_add", "global_atomic_or", "global_atomic_add_x2")
+        return self._mk(op, None, [voff, data, sbase], "vmem", {"offset": offset, "ndw": data.n, "atomic": op},
+                        f" offset:{offset}" if offset else "")
 
     # ---- output ----
     def text(self):
@@ -876,6 +895,8 @@ class Emu:
             w.scc = int(r != 0)
         elif op == "s_cmp_lg_u64":
             w.scc = int(self.rd_s64(w, s[0]) != self.rd_s64(w, s[1]))
+        elif op == "s_cmp_eq_u64":
+            w.scc = int(self.rd_s64(w, s[0]) == self.rd_s64(w, s[1]))
         elif op.startswith("s_cmp_"):
             a, b = self.rd_s32(w, s[0]), self.rd_s32(w, s[1])
             sa = a - (1 << 32) if a >> 31 else a
@@ -883,6 +904,8 @@ class Emu:
             w.scc = int({"s_cmp_lt_i32": sa < sb, "s_cmp_ge_i32": sa >= sb, "s_cmp_eq_u32": a == b, "s_cmp_lg_u32": a != b,
                          "s_cmp_lt_u32": a < b, "s_cmp_ge_u32": a >= b, "s_cmp_gt_u32": a > b, "s_cmp_le_u32": a <= b, "s_cmp_gt_i32": sa > sb, "s_cmp_le_i32": sa <= sb,
                          "s_cmp_eq_i32": a == b, "s_cmp_lg_i32": a != b}[op])
+        elif op == "s_cselect_b64":
+            self.wr_s64(w, d, self.rd_s64(w, s[0]) if w.scc else self.rd_s64(w, s[1]))
         elif op == "s_cselect_b32":
             self.wr_s32(w, d, self.rd_s32(w, s[0]) if w.scc else self.rd_s32(w, s[1]))
         else:
@@ -928,6 +951,9 @@ class Emu:
             lo, hi = f[s[0].idx].copy(), f[s[0].idx + 1].copy()
             self.wr32(w, d.sub(0), lo)
             self.wr32(w, d.sub(1), hi)
+        elif op == "v_min_u32":
+            a, b = self.rd32(w, s[0]), self.rd32(w, s[1])
+            self.wr32(w, d, np.minimum(a, b))
         elif op in ("v_add_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_mul_u32_u24",
                     "v_mul_lo_u32"):
             a, b = self.rd32(w, s[0]).astype(np.uint64), self.rd32(w, s[1]).astype(np.uint64)
@@ -944,12 +970,14 @@ class Emu:
         elif op.startswith("v_cmp_") and op.endswith("_f64"):
             a, b = self.rd64f(w, s[0]), self.rd64f(w, s[1])
             with np.errstate(invalid="ignore"):
-                r = {"v_cmp_le_f64": a <= b, "v_cmp_lt_f64": a < b, "v_cmp_ge_f64": a >= b, "v_cmp_gt_f64": a > b}[op]
+                r = {"v_cmp_le_f64": a <= b, "v_cmp_lt_f64": a < b, "v_cmp_ge_f64": a >= b, "v_cmp_gt_f64": a > b,
+                     "v_cmp_nlt_f64": ~(a < b)}[op]
             val = int(sum(1 << l for l in range(NL) if r[l] and w.exec[l]))
             self.wr_s64(w, d, val)
         elif op.startswith("v_cmp_") and op.endswith("_u32"):
             a, b = self.rd32(w, s[0]), self.rd32(w, s[1])
-            r = {"v_cmp_eq_u32": a == b, "v_cmp_lt_u32": a < b, "v_cmp_ne_u32": a != b}[op]
+            r = {"v_cmp_eq_u32": a == b, "v_cmp_lt_u32": a < b, "v_cmp_ne_u32": a != b, "v_cmp_gt_u32": a > b,
+                 "v_cmp_le_u32": a <= b, "v_cmp_ge_u32": a >= b}[op]
             val = int(sum(1 << l for l in range(NL) if r[l] and w.exec[l]))
             self.wr_s64(w, d, val)
         elif op == "v_cndmask_b32":
@@ -1024,6 +1052,8 @@ class Emu:
         else:
             assert c == 0
             Cm = np.zeros((16, 16))
+        if i.mods.get("neg_a"):
+            Am = -Am
         Dm = Cm + Am @ Bm
         allm = np.ones(NL, bool)
         for r in range(4):
@@ -1112,5 +1142,14 @@ class Emu:
                 u8, o = self.g.find(int(addr[l]), 4 * ndw)
                 if int(addr[l]) % 4:
                     raise EmuError("misaligned global store")
-                u8[o:o + 4 * ndw] = np.array([f[dreg.idx + j][l] for j in range(ndw)], np.uint32).view(np.uint8)
+                val = np.array([f[dreg.idx + j][l] for j in range(ndw)], np.uint32)
+                at = i.mods.get("atomic")
+                if at == "global_atomic_add":
+                    u8[o:o + 4].view(np.uint32)[0] += val[0]
+                elif at == "global_atomic_or":
+                    u8[o:o + 4].view(np.uint32)[0] |= val[0]
+                elif at == "global_atomic_add_x2":
+                    u8[o:o + 8].view(np.uint64)[0] += val.view(np.uint64)[0]
+                else:
+                    u8[o:o + 4 * ndw] = val.view(np.uint8)
             w.vm.append({"regs": []})

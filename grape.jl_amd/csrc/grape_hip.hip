@@ -1303,7 +1303,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                     const int bpk = (N_T + 15) / 16;
                     h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
                     h->deriv3_blocks = (int)std::min<long>(h->num_cus, (long)K * h->deriv3_wpt);
-                    CCHK(dmalloc(&h->d_park3, (size_t)h->deriv3_blocks * 4 * h->deriv2_maxm * 2 * NP * 16));
+                    CCHK(dmalloc(&h->d_park3, (size_t)h->deriv3_blocks * 4 * (h->deriv2_maxm + 1) * 2 * NP * 16));   // (+ 1: the assembly kernel parks every order it forms)
                 }
             }
         }
@@ -1317,7 +1317,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
             h->deriv2_maxm = 64;
             h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
             h->deriv3_blocks = (int)std::min<long>(h->num_cus, (long)K * h->deriv3_wpt);
-            CCHK(dmalloc(&h->d_park3, (size_t)h->deriv3_blocks * 4 * h->deriv2_maxm * 2 * NP * 16));
+            CCHK(dmalloc(&h->d_park3, (size_t)h->deriv3_blocks * 4 * (h->deriv2_maxm + 1) * 2 * NP * 16));   // (+ 1: the assembly kernel parks every order it forms)
         }
     }
     if (h->large && !h->series) {

@@ -11,6 +11,8 @@
 #include <string.h>
 #include <type_traits>
 #include <mutex>
+#include <vector>
+#include <stdlib.h>
 namespace {
 #include "grape_t18.hip.h"
 #include "grape_deriv3.hip.h"
@@ -47,6 +49,8 @@ hipError_t launch_d3(const Deriv3Args &a, hipStream_t s, int blocks) {
 }
 }  // namespace
 
+namespace { hipError_t launch_d3_asm(const Deriv3Args &a, hipStream_t s, int blocks); }
+
 // derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators whose upper tiles fit the LDS
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
                                    int skip_if_flagged, int h0_general, void *stream, int blocks) {
@@ -73,7 +77,14 @@ extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, co
     }
     D3_CASES(1) D3_CASES(2) D3_CASES(3)
 #undef D3_CASES
-    if (NT == 4 && L <= 2) return (int)(L == 1 ? launch_d3<4, 1>(a, s, blocks) : launch_d3<4, 2>(a, s, blocks));
+    if (NT == 4 && L <= 2) {
+        // four tiles per side: the hand-allocated assembly kernel (asm/gen_d3.py); GRAPE_DERIV3_ASM=0 keeps the compiled
+        // kernel (same series, same stopping rule -- the differential tests run both)
+        const char *env = getenv("GRAPE_DERIV3_ASM");
+        const bool use_asm = !(env && atoi(env) == 0);
+        if (use_asm && !skip_if_flagged && !a.d.gpark) return (int)launch_d3_asm(a, s, blocks);
+        return (int)(L == 1 ? launch_d3<4, 1>(a, s, blocks) : launch_d3<4, 2>(a, s, blocks));
+    }
     return (int)hipErrorInvalidValue;
 }
 
@@ -189,11 +200,13 @@ __global__ void __launch_bounds__(256) t16_credit_kernel(ExpmArgs a) {
     }
 }
 
+constexpr int D3_INV_TABLE = 2048;
 struct AsmModule {
     hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr;
+    hipFunction_t fn = nullptr, fn_d3 = nullptr;
+    double *inv = nullptr;      // 1 / m, m < D3_INV_TABLE
 };
-hipError_t asm_function(int dev, hipFunction_t *fn) {
+hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr) {
     static AsmModule mods[64];
     static std::mutex mtx;
     std::lock_guard<std::mutex> lock(mtx);
@@ -201,11 +214,67 @@ hipError_t asm_function(int dev, hipFunction_t *fn) {
     if (!m.fn) {
         hipError_t e = hipModuleLoadData(&m.mod, (const void *)grape_asm_co_start);
         if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn_d3, m.mod, "deriv3_asm");
+        if (e != hipSuccess) return e;
+        // 1 / m for the series orders (the kernel reads them with scalar loads; gfx9 has no scalar floating point)
+        std::vector<double> tab(D3_INV_TABLE);
+        tab[0] = 0.0;
+        for (int i = 1; i < D3_INV_TABLE; ++i) tab[i] = 1.0 / (double)i;
+        e = hipMalloc((void **)&m.inv, sizeof(double) * D3_INV_TABLE);
+        if (e != hipSuccess) return e;
+        e = hipMemcpy(m.inv, tab.data(), sizeof(double) * D3_INV_TABLE, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn, m.mod, "expm_t16_asm");
         if (e != hipSuccess) return e;
     }
-    *fn = m.fn;
+    if (fn) *fn = m.fn;
+    if (fn_d3) *fn_d3 = m.fn_d3;
+    if (inv) *inv = m.inv;
     return hipSuccess;
+}
+}  // namespace
+
+namespace {
+struct D3AsmArgs {            // kernel argument block of deriv3_asm (gen_d3.py: KERNARG = 160 bytes)
+    const double *H0f, *Hcf, *eps, *shape, *dts;
+    const double2 *fw, *bw;
+    const double *rho;
+    double2 *tg;
+    double *park;             // [blocks][4][slots][NP][16] complex
+    int *flags;
+    unsigned long long *stats;
+    const int *batch_flag;
+    const double *inv;        // 1 / m
+    int K, L, N_T, hc_per_traj, wpt, batches_per_k, mcap, slots;
+    double tol2;
+    int deep, nblocks;
+};
+static_assert(sizeof(D3AsmArgs) == 160, "argument block of the assembly kernel");
+
+hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks) {
+    const Deriv2Args &a = g.d;
+    if (a.L < 1 || a.L > 2 || blocks < 1 || a.maxm + 2 > D3_INV_TABLE) return hipErrorInvalidValue;
+    if ((long)a.N_T + 1 >= (1L << 21) || (long)a.K * a.L * a.N_T >= (1L << 27)) return hipErrorInvalidValue;   // (32-bit offsets in the kernel)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipFunction_t fn;
+    const double *inv;
+    e = asm_function(dev, nullptr, &fn, &inv);
+    if (e != hipSuccess) return e;
+    D3AsmArgs k{};
+    k.H0f = g.H0f; k.Hcf = g.Hcf; k.eps = a.eps; k.shape = a.shape; k.dts = a.dts; k.fw = a.fw; k.bw = a.bw; k.rho = a.rho;
+    k.tg = a.tg; k.park = a.park; k.flags = a.flags; k.stats = a.stats; k.batch_flag = a.batch_flag; k.inv = inv;
+    k.K = a.K; k.L = a.L; k.N_T = a.N_T; k.hc_per_traj = a.hc_per_traj; k.wpt = g.wpt; k.batches_per_k = a.batches_per_k;
+    // the parking area holds maxm + 1 terms per wave (grape_create): every order the kernel forms has a slot
+    k.mcap = a.max_order < a.maxm ? a.max_order : a.maxm;
+    k.slots = a.maxm + 1;
+    k.tol2 = a.tol * a.tol;
+    k.deep = (a.deep_redo && a.max_order > k.mcap) ? 1 : 0;
+    k.nblocks = blocks;
+    size_t size = sizeof(k);
+    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
 }
 }  // namespace
 

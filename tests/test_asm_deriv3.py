@@ -1,0 +1,196 @@
+"""The hand-allocated gfx950 assembly kernel of the derivative overlaps (grape.jl_amd/csrc/asm/gen_d3.py) executed by the
+lane-accurate emulator of gcn.py -- this container has no GPU -- against (a) a numpy restatement of the two-pass series
+the kernel follows, term by term, and (b) the Frechet derivative of the matrix exponential (scipy), i.e. the quantity the
+reference's gradient generators deliver (/root/reference/src/optimize.jl:876-911).
+
+Checks: tau_grads of every cell (full batches, a ragged last batch, several trajectories and workgroups, one and two
+controls, operators per trajectory or shared), the booked series orders, the non-convergence flag, no register touched
+while a load into it is outstanding, no missing wait state, and that the text assembles."""
+import os
+import shutil
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grape.jl_amd", "csrc", "asm"))
+import gcn  # noqa: E402
+import gen_d3  # noqa: E402
+
+NP = 64
+
+
+def planar(H):
+    return np.stack([np.stack([h.real, h.imag]) for h in H]).astype(np.float64)
+
+
+def make_inputs(N, K, L, N_T, seed, hc_per_traj=False, shape=False, dt_scale=1.0):
+    rng = np.random.default_rng(seed)
+
+    def herm(s):
+        X = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+        H = (X + X.conj().T) / (4 * np.sqrt(N)) * s
+        P = np.zeros((NP, NP), complex)
+        P[:N, :N] = H
+        return P
+
+    def states(n):
+        X = np.zeros((n, NP), complex)
+        X[:, :N] = rng.normal(size=(n, N)) + 1j * rng.normal(size=(n, N))
+        return X / np.linalg.norm(X, axis=1, keepdims=True)
+    d = {"N": N, "K": K, "L": L, "N_T": N_T, "hc_per_traj": int(hc_per_traj)}
+    d["H0"] = np.stack([herm(1.0) for _ in range(K)])
+    d["Hc"] = np.stack([herm(0.7) for _ in range((K if hc_per_traj else 1) * L)]).reshape((K if hc_per_traj else 1), L, NP, NP)
+    d["eps"] = rng.normal(size=(L, N_T))
+    d["shape"] = 0.5 + rng.random((L, N_T)) if shape else None
+    d["dts"] = (0.5 + rng.random(N_T)) * dt_scale
+    d["fw"] = np.stack([states(N_T + 1) for _ in range(K)])
+    d["bw"] = np.stack([states(N_T + 1) for _ in range(K)])
+    d["rho"] = 0.5 + rng.random(K)
+    return d
+
+
+def run_kernel(prog, d, nblk, wpt, mcap=40, tol=1e-16, deep=0, batch_flag=None):
+    K, L, N_T = d["K"], d["L"], d["N_T"]
+    g = gcn.GlobalMem()
+    a_H0, _ = g.add("H0f", planar(d["H0"]))
+    a_Hc, _ = g.add("Hcf", planar(d["Hc"].reshape(-1, NP, NP)))
+    a_eps, _ = g.add("eps", d["eps"])
+    a_shape = 0
+    if d["shape"] is not None:
+        a_shape, _ = g.add("shape", d["shape"])
+    a_dts, _ = g.add("dts", d["dts"])
+
+    def il(x):
+        return np.stack([x.real, x.imag], axis=-1).astype(np.float64)
+    a_fw, _ = g.add("fw", il(d["fw"]))
+    a_bw, _ = g.add("bw", il(d["bw"]))
+    a_rho, _ = g.add("rho", d["rho"])
+    a_tg, tg = g.add("tg", np.full((K, L, N_T, 2), np.nan))
+    slots = mcap + 1
+    a_park, _ = g.add("park", np.full(nblk * 4 * slots * NP * 16 * 2, np.nan))
+    a_flags, flags = g.add("flags", np.zeros(8, np.int32))
+    a_stats, stats = g.add("stats", np.zeros(64 * 16, np.uint64))
+    a_bf = 0
+    bpk = (N_T + 15) // 16
+    if batch_flag is not None:
+        a_bf, _ = g.add("batch_flag", np.asarray(batch_flag, np.int32))
+    a_inv, _ = g.add("inv", np.array([0.0] + [1.0 / m for m in range(1, 1026)]))
+    karg = struct.pack("<14Q8idii", a_H0, a_Hc, a_eps, a_shape, a_dts, a_fw, a_bw, a_rho, a_tg, a_park, a_flags, a_stats, a_bf, a_inv,
+                       K, L, N_T, d["hc_per_traj"], wpt, bpk, mcap, slots, tol * tol, deep, nblk)
+    assert len(karg) == gen_d3.KERNARG
+    a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
+    info = {"instr": 0, "mfma": 0}
+    for wg in range(nblk):
+        e = gcn.Emu(prog, g, a_k, wg_id=wg, lds_bytes=3 * gen_d3.MAT_B)
+        info["instr"] += e.run()
+        info["mfma"] += e.mfma_count
+    return tg[..., 0] + 1j * tg[..., 1], flags, stats.reshape(64, 16), info
+
+
+def series_reference(d, mcap=40, tol=1e-16):
+    """the two-pass series of the kernel, cell by cell; the stopping rule is a batch's (16 cells stop together)"""
+    K, L, N_T = d["K"], d["L"], d["N_T"]
+    tg = np.zeros((K, L, N_T), complex)
+    orders = np.zeros((K, (N_T + 15) // 16), int)
+    for k in range(K):
+        for b in range((N_T + 15) // 16):
+            cells = range(16 * b, min(N_T, 16 * b + 16))
+            us, Hs = {}, {}
+            for n in cells:
+                mu = d["Hc"][k if d["hc_per_traj"] else 0]
+                sh = d["shape"][:, n] if d["shape"] is not None else np.ones(L)
+                Hs[n] = d["H0"][k] + sum(d["eps"][l, n] * sh[l] * mu[l] for l in range(L))
+                us[n] = [d["fw"][k, n]]
+            M = 0
+            for m in range(1, mcap + 1):
+                for n in cells:
+                    us[n].append(-1j * d["dts"][n] / m * (Hs[n] @ us[n][-1]))
+                M = m
+                if m >= 2 and all(np.linalg.norm(us[n][-1]) ** 2 < tol * tol for n in cells):
+                    break
+            orders[k, b] = M
+            for n in cells:
+                mu = d["Hc"][k if d["hc_per_traj"] else 0]
+                sh = d["shape"][:, n] if d["shape"] is not None else np.ones(L)
+                chi = d["bw"][k, n + 1]
+                w = chi.copy()
+                D = np.zeros(L, complex)
+                for a in range(M - 1, -1, -1):
+                    for l in range(L):
+                        D[l] += np.vdot(mu[l] @ w, us[n][a]) / (a + 1)      # <mu_l^dagger w | u_a>, mu Hermitian
+                    if a > 0:
+                        w = chi + 1j * d["dts"][n] / (a + 1) * (Hs[n] @ w)
+                for l in range(L):
+                    tg[k, l, n] = d["rho"][k] * (-1j * d["dts"][n] * sh[l]) * D[l]
+    return tg, orders
+
+
+def frechet_reference(d):
+    """rho <chi(t_{n+1})| dU_n / d eps_l |Psi(t_n)>, U_n = exp(-i H_n dt_n)"""
+    K, L, N_T = d["K"], d["L"], d["N_T"]
+    tg = np.zeros((K, L, N_T), complex)
+    for k in range(K):
+        mu = d["Hc"][k if d["hc_per_traj"] else 0]
+        for n in range(N_T):
+            sh = d["shape"][:, n] if d["shape"] is not None else np.ones(L)
+            H = d["H0"][k] + sum(d["eps"][l, n] * sh[l] * mu[l] for l in range(L))
+            for l in range(L):
+                dU = scipy.linalg.expm_frechet(-1j * d["dts"][n] * H, -1j * d["dts"][n] * sh[l] * mu[l], compute_expm=False)
+                tg[k, l, n] = d["rho"][k] * np.vdot(d["bw"][k, n + 1], dU @ d["fw"][k, n])
+    return tg
+
+
+@pytest.fixture(scope="module")
+def program():
+    return gen_d3.generate()
+
+
+def test_generated_program_has_no_missing_wait_states(program):
+    _, prog, _ = program
+    assert gcn.check_hazards(prog) == 0
+    # two applications of H (pass 1, pass 2): 3 operators x 192 matrix instructions each, + 5 column sums
+    assert prog.count("mfma") == 2 * 3 * 192 + 5
+
+
+@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 2, 2, 20, 2, 1, False, False), (50, 1, 1, 37, 2, 2, True, True)])
+def test_emulated_kernel_matches_the_series_and_the_frechet_derivative(program, N, K, L, N_T, nblk, wpt, hcpt, shape):
+    _, prog, _ = program
+    d = make_inputs(N, K, L, N_T, seed=N + L, hc_per_traj=hcpt, shape=shape)
+    tg, flags, stats, info = run_kernel(prog, d, nblk, wpt)
+    ref, orders = series_reference(d)
+    assert np.isfinite(tg.view(float)).all()
+    scale = np.abs(ref).max()
+    assert np.abs(tg - ref).max() < 2e-15 * max(1.0, scale) * 8, np.abs(tg - ref).max()
+    fre = frechet_reference(d)
+    assert np.abs(tg - fre).max() < 1e-13, np.abs(tg - fre).max()
+    assert flags[0] == 0 and flags[7] == 0
+    cells = [[min(16, N_T - 16 * b) for b in range((N_T + 15) // 16)] for _ in range(K)]
+    assert int(stats[:, 8].sum()) == int((orders * np.array(cells)).sum())
+
+
+def test_series_that_does_not_converge_within_the_parked_terms_is_flagged(program):
+    _, prog, _ = program
+    d = make_inputs(64, 1, 1, 5, seed=3, dt_scale=6.0)
+    _, flags, stats, _ = run_kernel(prog, d, 1, 1, mcap=6)
+    assert flags[0] == 4 and flags[7] == 0
+    assert int(stats[:, 8].sum()) == 6 * 5
+    _, flags, _, _ = run_kernel(prog, d, 1, 1, mcap=6, deep=1)
+    assert flags[0] == 0 and flags[7] == 1
+    # a batch the sub-step kernel redoes anyway: neither flagged nor booked
+    _, flags, stats, _ = run_kernel(prog, d, 1, 1, mcap=6, batch_flag=[1])
+    assert flags[0] == 0 and flags[7] == 0 and int(stats[:, 8].sum()) == 0
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang"), reason="no assembler")
+def test_text_assembles(program, tmp_path):
+    _, _, text = program
+    src = tmp_path / "deriv3_asm.s"
+    src.write_text(text)
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src),
+                    "-o", str(tmp_path / "d3.o")], check=True)
+    assert shutil.which("true")

@@ -98,3 +98,54 @@ def test_six_controls_and_per_trajectory_controls(g):
     b = run(g, pr, False)
     assert np.abs(a[3] - b[3]).max() < 2e-15 and abs(a[0] - b[0]) <= 1e-13
     assert np.abs(a[1] - b[1]).max() <= 1e-12 * max(np.abs(b[1]).max(), 1e-3)
+
+
+# ---- the derivative overlaps as assembly (asm/gen_d3.py) against deriv3_kernel<4, L> (GRAPE_DERIV3_ASM=0) ----
+def run_d3(g, pr, asm, **kw):
+    old = os.environ.get("GRAPE_DERIV3_ASM")
+    os.environ["GRAPE_DERIV3_ASM"] = "1" if asm else "0"     # (read at every launch)
+    try:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            J2, G2, _ = h.eval(pr["pulsevals"])
+            assert J2 == J and np.array_equal(G, G2)         # repeatable bit for bit
+            return J, G, tau, h.work()
+    finally:
+        if old is None:
+            os.environ.pop("GRAPE_DERIV3_ASM", None)
+        else:
+            os.environ["GRAPE_DERIV3_ASM"] = old
+
+
+@pytest.mark.parametrize("N,L,N_T,K,kw", [
+    (64, 2, 2, 1, {}), (64, 2, 37, 3, {}), (49, 1, 21, 2, {}), (57, 2, 100, 5, {}), (64, 1, 40, 16, {}),
+    (64, 2, 33, 2, {"shape": True}), (60, 2, 18, 3, {"per_traj": True}), (64, 2, 50, 300, {})])
+def test_derivative_kernel_against_its_twin(g, N, L, N_T, K, kw):
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=7 + N + L)
+    args = {}
+    if kw.get("shape"):
+        args["shape"] = 0.5 + np.random.default_rng(3).random((L, N_T))
+    if kw.get("per_traj"):
+        rng = np.random.default_rng(4)
+        pr["Hc"] = np.stack([pr["Hc"] * (1.0 + 0.1 * rng.random()) for _ in range(K)])
+    a = run_d3(g, pr, True, **args)
+    b = run_d3(g, pr, False, **args)
+    assert a[0] == b[0]                                      # the sweeps are the same code on both sides
+    gs = max(np.abs(b[1]).max(), 1e-3)
+    assert np.abs(a[1] - b[1]).max() <= 2e-14 * gs, np.abs(a[1] - b[1]).max() / gs
+    assert a[3]["deriv_orders"] == b[3]["deriv_orders"] and a[3]["flop_deriv"] == b[3]["flop_deriv"]
+
+
+def test_derivative_kernel_taylor_route_and_its_order_limit(g):
+    """gradient_method = :taylor with a small order limit: both kernels stop at the limit and raise the same error"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 2, 20, 2, seed=19)
+    res = []
+    for asm in (True, False):
+        a = run_d3(g, pr, asm, gradient_method=g.GRAD_TAYLOR, taylor_max_order=40)
+        res.append(a)
+    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-14 * max(np.abs(res[1][1]).max(), 1e-3)
+    for asm in (True, False):
+        with pytest.raises(g.GrapeHipError, match="GRAPE_ERR_TAYLOR"):
+            run_d3(g, pr, asm, gradient_method=g.GRAD_TAYLOR, taylor_max_order=5)
