@@ -40,7 +40,7 @@ class Reg:
         return [(self.cls, self.idx + i) for i in range(self.n)]
 
     def __str__(self):
-        if self.cls in ("vcc", "exec"):
+        if self.cls in ("vcc", "exec", "m0"):
             return self.cls
         return f"{self.cls}{self.idx}" if self.n == 1 else f"{self.cls}[{self.idx}:{self.idx + self.n - 1}]"
 
@@ -61,6 +61,7 @@ def S(i, n=1):
 
 VCC = Reg("vcc", 0, 2)
 EXEC = Reg("exec", 0, 2)
+M0 = Reg("m0", 0, 1)     # (emulator: scalar register 124)
 
 
 class Neg:
@@ -104,6 +105,8 @@ def _regs_of(o):
         return o.regs()
     if isinstance(o, Reg) and o.cls == "vcc":
         return [("s", 106), ("s", 107)]
+    if isinstance(o, Reg) and o.cls == "m0":
+        return [("s", 124)]
     return []
 
 
@@ -402,6 +405,16 @@ class Prog:
             mods["_wide_store"] = data.regs()
         return self._mk(op, None, [voff, data, sbase], "vmem", mods, (f" offset:{offset}" if offset else "") + (" nt" if nt else ""))
 
+    def global_load_lds(self, voff, sbase):
+        """global_load_lds_dwordx4: LDS[M0 + 16 lane] <- 16 bytes at s[base] + voff, per active lane; no register
+        destination; counted by vmcnt (the data is in LDS once the count has passed it -- then a barrier, then the reads).
+        M0 must have been written at least one wait state earlier."""
+        st = self.last.get(("s", 124))
+        if st is not None and self.state - st[1] - 1 < 1:
+            self.nop(1)
+        return self._mk("global_load_lds_dwordx4", None, [voff, sbase], "vmem", {"offset": 0, "ndw": 4, "lds_dma": True},
+                        reads=[("s", 124)])
+
     def global_atomic(self, op, voff, data, sbase, offset=0):
         """global_atomic_{add, or, add_x2} without return: memory[s[base] + voff + offset] op= data"""
         assert op in ("global_atomic_add", "global_atomic_or", "global_atomic_add_x2")
@@ -561,7 +574,7 @@ class Wave:
         self.wid = wid
         self.v = np.zeros((256, NL), np.uint32)
         self.a = np.zeros((256, NL), np.uint32)
-        self.s = np.zeros(108, np.uint32)     # 106/107: vcc
+        self.s = np.zeros(128, np.uint32)     # 106/107: vcc, 124: m0
         self.exec = np.ones(NL, bool)
         self.scc = 0
         self.pc = 0
@@ -596,6 +609,7 @@ class Emu:
         self.lr_epoch = np.zeros(nw, np.int64)
         self.check_races = check_races
         self.mfma_count = 0
+        self.dma_pending = np.zeros(nw, np.int32)   # LDS words with an LDS-DMA write in flight
         self.lds_cycles = {}      # op -> [instructions, LDS-array cycles] by the banking rules of the CDNA4 guide (lds_array_cycles)
 
     # ---- register access ----
@@ -662,6 +676,8 @@ class Emu:
 
     def rd_s32(self, w, o):
         if isinstance(o, Reg):
+            if o.cls == "m0":
+                return int(w.s[124])
             if o.cls == "s":
                 self._chk(w, "s", o.idx, 1, "read")
                 return int(w.s[o.idx])
@@ -685,6 +701,9 @@ class Emu:
         raise EmuError(f"bad scalar operand {o}")
 
     def wr_s32(self, w, dst, val):
+        if dst.cls == "m0":
+            w.s[124] = val & 0xFFFFFFFF
+            return
         self._chk(w, "s", dst.idx, 1, "write")
         w.s[dst.idx] = val & 0xFFFFFFFF
 
@@ -1076,6 +1095,9 @@ class Emu:
             if (addr[act] % min(nb, 8) != 0).any():
                 raise EmuError(f"misaligned LDS read [{i.text}]")
             self._lds_touch(w, addr[act], nb, False)
+            wd = np.unique(np.concatenate([(addr[act] + b) >> 3 for b in range(0, nb, 8)]))
+            if self.dma_pending[wd].any():
+                raise EmuError(f"wave {w.wid} pc {w.pc}: LDS read of a word with an LDS-DMA write in flight [{i.text}]")
             lds32 = self.lds.view(np.uint32)
             ai = np.where(act, addr >> 2, 0)
             data = np.stack([lds32[ai + j] for j in range(nb // 4)])
@@ -1109,6 +1131,34 @@ class Emu:
 
     def vmem(self, w, i):
         ndw, off = i.mods["ndw"], i.mods["offset"]
+        if i.mods.get("lds_dma"):
+            voff, sbase = i.src
+            base = self.rd_s64(w, sbase)
+            addr = base + self.rd32(w, voff).astype(np.int64)
+            m0 = int(w.s[124])
+            act = np.nonzero(w.exec)[0]
+            dst = np.array([m0 + 16 * int(l) for l in act], np.int64)
+            if len(dst) and (dst.max() + 16 > self.lds_bytes or (dst % 16).any()):
+                raise EmuError(f"LDS-DMA destination out of bounds or misaligned [{i.text}] m0={m0}")
+            data = np.zeros((len(act), 16), np.uint8)
+            for n, l in enumerate(act):
+                u8, o = self.g.find(int(addr[l]), 16)
+                if int(addr[l]) % 16:
+                    raise EmuError("misaligned LDS-DMA source")
+                data[n] = u8[o:o + 16]
+            self._lds_touch(w, dst, 16, True)
+            words = np.concatenate([dst >> 3, (dst >> 3) + 1]) if len(dst) else np.zeros(0, np.int64)
+            self.dma_pending[words] += 1
+
+            def apply(dst=dst, data=data, words=words, wid=w.wid):
+                for n in range(len(dst)):
+                    self.lds[dst[n]:dst[n] + 16] = data[n]
+                self.dma_pending[words] -= 1
+                # visible to other waves only behind a barrier that follows the wait
+                self.lw_epoch[words] = self.epoch
+                self.lw_wave[words] = wid
+            w.vm.append({"regs": [], "apply": apply})
+            return
         if i.op.startswith("global_load"):
             voff, sbase = i.src
             base = self.rd_s64(w, sbase)

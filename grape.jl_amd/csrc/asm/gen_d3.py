@@ -239,13 +239,19 @@ class GenD3:
         else:
             self.p.ds_read(64, dst, self.v_BM[op], tile_index(kt, rt) * 2 * TILE_B + pl * TILE_B + 4 * r * LDT * 8)
 
-    def product(self, op, hook=None):
-        """P[j][rt] = (p1, p2, p3) of (operator op) x (vector block in VEC); Hermitian operator, upper tiles in LDS"""
-        p = self.p
+    def prefetch(self, op):
+        """the fragments of the first k-step of a product, requested ahead of the vector work that precedes it"""
         for rt in range(4):
             self.frag_read(op, 0, rt, 0, 0)
         for rt in range(4):
             self.frag_read(op, 1, rt, 0, 0)
+
+    def product(self, op, hook=None, pre=False):
+        """P[j][rt] = (p1, p2, p3) of (operator op) x (vector block in VEC); Hermitian operator, upper tiles in LDS
+        (pre: the first fragments are already on their way)"""
+        p = self.p
+        if not pre:
+            self.prefetch(op)
         first = True
         for kt in range(4):
             for r in range(4):
@@ -296,15 +302,18 @@ class GenD3:
     def apply_H(self, overlap_of=None, hook=None):
         """SUM = H0 v + sum_l e_l mu_l v, one operator at a time (the controls that exist: L is a run-time value)"""
         p = self.p
-        self.product(0, hook)
+        self.product(0, hook, pre=True)      # (every path into an application of H has requested the first fragments)
+        self.prefetch(1)
         self.combine(0)
         for op in range(1, 1 + self.LMAX):
             lab = None
-            if op >= 2 or self.LMAX >= 1:
+            if op >= 2:                      # (there is always a first control)
                 lab = f"L_skipop_{op}_{len(p.ins)}"
                 p.s_cmp("s_cmp_lt_u32", self.s_L, op)
                 p.s_branch("s_cbranch_scc1", lab)
-            self.product(op)
+            self.product(op, pre=True)
+            if op < self.LMAX:
+                self.prefetch(op + 1)        # (of a control that may not exist: the LDS behind the last operator is allocated)
             self.combine(op, (lambda op=op: overlap_of(op)) if overlap_of else None)
             if lab:
                 p.label(lab)
@@ -425,6 +434,7 @@ class GenD3:
         load_block(self.v_fwoff, self.s_fwb, None, True)
         p.salu("s_mov_b32", self.s_m, 1)
         p.salu("s_mov_b32", self.s_conv, 0)
+        self.prefetch(0)
         p.label("L_pass1")
         self.apply_H()
         # 1 / m, park bases of order m
@@ -432,6 +442,7 @@ class GenD3:
         p.s_load(2, self.s_invm, self.s_inv, self.s_t[0])
         self.park_bases(self.s_m)
         p.s_waitcnt(lgkm=0)
+        self.prefetch(0)                     # (of the next order's first product, under the vector work below)
         p.valu("v_mul_f64", self.v_sfac, self.v_dt, self.s_invm)
         p.valu("v_mov_b32", self.v_nn.sub(0), 0)
         p.valu("v_mov_b32", self.v_nn.sub(1), 0)
@@ -474,6 +485,7 @@ class GenD3:
                 p.valu("v_mov_b32", reg.sub(0), 0)
                 p.valu("v_mov_b32", reg.sub(1), 0)
         p.salu("s_sub_u32", self.s_m, self.s_M, 1)           # aa
+        self.prefetch(0)
         p.label("L_pass2")
         p.salu("s_add_u32", self.s_t[0], self.s_m, 1)
         p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 3)
@@ -515,6 +527,7 @@ class GenD3:
         p.s_cmp("s_cmp_eq_u32", self.s_m, 0)
         p.s_branch("s_cbranch_scc1", "L_pass2_done")
         # w <- chi + (i s)(x + i y) = chi - s y + i s x,  s = dt / (aa + 1)
+        self.prefetch(0)
         p.valu("v_mul_f64", self.v_sfac, self.v_dt, self.s_invm)
         for t in range(4):
             for r in range(4):

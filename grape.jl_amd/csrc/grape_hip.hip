@@ -1298,7 +1298,11 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                 const char *env3 = getenv("GRAPE_DERIV3");
                 const char *envnh = getenv("GRAPE_NO_HERM");
                 h->deriv3_h0g = !h->herm && h->herm_ctrl && !(envnh && atoi(envnh));
-                if ((h->herm || h->deriv3_h0g) && !h->large && !h->series && deriv3_fits(h->NT, L, h->deriv3_h0g) && !(env3 && atoi(env3) == 0)) {
+                // four tiles per side and more than two controls: the operators do not fit the LDS; the assembly kernel
+                // streams them through it (asm/gen_d3s.py; GRAPE_DERIV3S=0: deriv2_kernel's STREAM_L form, the twin)
+                const char *env3s = getenv("GRAPE_DERIV3S");
+                const bool streamed = h->herm && h->NT == 4 && L > 2 && L <= 8 && !(env3s && atoi(env3s) == 0);
+                if ((h->herm || h->deriv3_h0g) && !h->large && !h->series && (deriv3_fits(h->NT, L, h->deriv3_h0g) || streamed) && !(env3 && atoi(env3) == 0)) {
                     // workgroups per trajectory: as many as it takes to put a workgroup on every CU, at most one per four batches
                     const int bpk = (N_T + 15) / 16;
                     h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));

@@ -77,6 +77,10 @@ extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, co
     }
     D3_CASES(1) D3_CASES(2) D3_CASES(3)
 #undef D3_CASES
+    if (NT == 4 && L > 2) {     // the streamed-controls assembly kernel; no compiled twin (the operators do not fit the LDS)
+        if (skip_if_flagged || a.d.gpark) return (int)hipErrorInvalidValue;
+        return (int)launch_d3_asm(a, s, blocks);
+    }
     if (NT == 4 && L <= 2) {
         // four tiles per side: the hand-allocated assembly kernel (asm/gen_d3.py); GRAPE_DERIV3_ASM=0 keeps the compiled
         // kernel (same series, same stopping rule -- the differential tests run both)
@@ -203,10 +207,11 @@ __global__ void __launch_bounds__(256) t16_credit_kernel(ExpmArgs a) {
 constexpr int D3_INV_TABLE = 2048;
 struct AsmModule {
     hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr, fn_d3 = nullptr;
+    hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr;
     double *inv = nullptr;      // 1 / m, m < D3_INV_TABLE
 };
-hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr) {
+hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr,
+                        hipFunction_t *fn_d3s = nullptr) {
     static AsmModule mods[64];
     static std::mutex mtx;
     std::lock_guard<std::mutex> lock(mtx);
@@ -216,19 +221,29 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn_d3, m.mod, "deriv3_asm");
         if (e != hipSuccess) return e;
-        // 1 / m for the series orders (the kernel reads them with scalar loads; gfx9 has no scalar floating point)
-        std::vector<double> tab(D3_INV_TABLE);
+        e = hipModuleGetFunction(&m.fn_d3s, m.mod, "deriv3s_asm");
+        if (e != hipSuccess) return e;
+        // 1 / m for the series orders (the kernels read them with scalar loads; gfx9 has no scalar floating point); behind
+        // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
+        std::vector<double> tab(D3_INV_TABLE + 20);
         tab[0] = 0.0;
         for (int i = 1; i < D3_INV_TABLE; ++i) tab[i] = 1.0 / (double)i;
-        e = hipMalloc((void **)&m.inv, sizeof(double) * D3_INV_TABLE);
+        int *pt = (int *)(tab.data() + D3_INV_TABLE);
+        int np_ = 0;
+        for (int ti = 0; ti < 4; ++ti)
+            for (int tj = ti; tj < 4; ++tj)
+                for (int plane = 0; plane < 2; ++plane)
+                    for (int half = 0; half < 2; ++half) pt[np_++] = plane * 64 * 64 * 8 + ti * 16 * 64 * 8 + tj * 16 * 8;
+        e = hipMalloc((void **)&m.inv, sizeof(double) * tab.size());
         if (e != hipSuccess) return e;
-        e = hipMemcpy(m.inv, tab.data(), sizeof(double) * D3_INV_TABLE, hipMemcpyHostToDevice);
+        e = hipMemcpy(m.inv, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn, m.mod, "expm_t16_asm");
         if (e != hipSuccess) return e;
     }
     if (fn) *fn = m.fn;
     if (fn_d3) *fn_d3 = m.fn_d3;
+    if (fn_d3s) *fn_d3s = m.fn_d3s;
     if (inv) *inv = m.inv;
     return hipSuccess;
 }
@@ -253,15 +268,16 @@ static_assert(sizeof(D3AsmArgs) == 160, "argument block of the assembly kernel")
 
 hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks) {
     const Deriv2Args &a = g.d;
-    if (a.L < 1 || a.L > 2 || blocks < 1 || a.maxm + 2 > D3_INV_TABLE) return hipErrorInvalidValue;
+    if (a.L < 1 || a.L > 8 || blocks < 1 || a.maxm + 2 > D3_INV_TABLE) return hipErrorInvalidValue;
     if ((long)a.N_T + 1 >= (1L << 21) || (long)a.K * a.L * a.N_T >= (1L << 27)) return hipErrorInvalidValue;   // (32-bit offsets in the kernel)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    hipFunction_t fn;
+    hipFunction_t fn, fn_s;
     const double *inv;
-    e = asm_function(dev, nullptr, &fn, &inv);
+    e = asm_function(dev, nullptr, &fn, &inv, &fn_s);
     if (e != hipSuccess) return e;
+    if (a.L > 2) fn = fn_s;     // more than two controls: the operators stream through the LDS (asm/gen_d3s.py)
     D3AsmArgs k{};
     k.H0f = g.H0f; k.Hcf = g.Hcf; k.eps = a.eps; k.shape = a.shape; k.dts = a.dts; k.fw = a.fw; k.bw = a.bw; k.rho = a.rho;
     k.tg = a.tg; k.park = a.park; k.flags = a.flags; k.stats = a.stats; k.batch_flag = a.batch_flag; k.inv = inv;

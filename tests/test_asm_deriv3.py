@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "grape.jl_amd", "csrc", "asm"))
 import gcn  # noqa: E402
 import gen_d3  # noqa: E402
+import gen_d3s  # noqa: E402
 
 NP = 64
 
@@ -54,7 +55,7 @@ def make_inputs(N, K, L, N_T, seed, hc_per_traj=False, shape=False, dt_scale=1.0
     return d
 
 
-def run_kernel(prog, d, nblk, wpt, mcap=40, tol=1e-16, deep=0, batch_flag=None):
+def run_kernel(prog, d, nblk, wpt, mcap=40, tol=1e-16, deep=0, batch_flag=None, lds_bytes=3 * gen_d3.MAT_B):
     K, L, N_T = d["K"], d["L"], d["N_T"]
     g = gcn.GlobalMem()
     a_H0, _ = g.add("H0f", planar(d["H0"]))
@@ -79,27 +80,37 @@ def run_kernel(prog, d, nblk, wpt, mcap=40, tol=1e-16, deep=0, batch_flag=None):
     bpk = (N_T + 15) // 16
     if batch_flag is not None:
         a_bf, _ = g.add("batch_flag", np.asarray(batch_flag, np.int32))
-    a_inv, _ = g.add("inv", np.array([0.0] + [1.0 / m for m in range(1, 1026)]))
+    # 1 / m, then the piece table of the streamed kernel (grape_t18.hip lays the same buffer out)
+    tab = np.zeros(gen_d3s.INV_TABLE * 8 + 40 * 4, np.uint8)
+    tab[:gen_d3s.INV_TABLE * 8].view(np.float64)[1:] = 1.0 / np.arange(1, gen_d3s.INV_TABLE)
+    tab[gen_d3s.INV_TABLE * 8:].view(np.int32)[:] = gen_d3s.piece_table()
+    a_inv, _ = g.add("inv", tab)
     karg = struct.pack("<14Q8idii", a_H0, a_Hc, a_eps, a_shape, a_dts, a_fw, a_bw, a_rho, a_tg, a_park, a_flags, a_stats, a_bf, a_inv,
                        K, L, N_T, d["hc_per_traj"], wpt, bpk, mcap, slots, tol * tol, deep, nblk)
     assert len(karg) == gen_d3.KERNARG
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     info = {"instr": 0, "mfma": 0}
     for wg in range(nblk):
-        e = gcn.Emu(prog, g, a_k, wg_id=wg, lds_bytes=3 * gen_d3.MAT_B)
+        e = gcn.Emu(prog, g, a_k, wg_id=wg, lds_bytes=lds_bytes)
         info["instr"] += e.run()
         info["mfma"] += e.mfma_count
     return tg[..., 0] + 1j * tg[..., 1], flags, stats.reshape(64, 16), info
 
 
-def series_reference(d, mcap=40, tol=1e-16):
-    """the two-pass series of the kernel, cell by cell; the stopping rule is a batch's (16 cells stop together)"""
+def series_reference(d, mcap=40, tol=1e-16, group_wpt=None):
+    """the two-pass series of the kernel, cell by cell; the stopping rule is a batch's (16 cells stop together) -- or, for
+    the streamed kernel (group_wpt = workgroups per trajectory), that of the four batches a workgroup walks in lockstep"""
     K, L, N_T = d["K"], d["L"], d["N_T"]
     tg = np.zeros((K, L, N_T), complex)
-    orders = np.zeros((K, (N_T + 15) // 16), int)
+    bpk = (N_T + 15) // 16
+    orders = np.zeros((K, bpk), int)
+    groups = [[b] for b in range(bpk)]
+    if group_wpt:
+        groups = [list(range(b0, min(bpk, b0 + 4))) for part in range(group_wpt) for b0 in range(4 * part, bpk, 4 * group_wpt)]
     for k in range(K):
-        for b in range((N_T + 15) // 16):
-            cells = range(16 * b, min(N_T, 16 * b + 16))
+        for grp in groups:
+            cells = [n for b in grp for n in range(16 * b, min(N_T, 16 * b + 16))]
+            b = grp
             us, Hs = {}, {}
             for n in cells:
                 mu = d["Hc"][k if d["hc_per_traj"] else 0]
@@ -194,3 +205,41 @@ def test_text_assembles(program, tmp_path):
     subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src),
                     "-o", str(tmp_path / "d3.o")], check=True)
     assert shutil.which("true")
+
+
+# ---- the streamed-controls kernel (more than two controls: gen_d3s.py) ----
+@pytest.fixture(scope="module")
+def program_s():
+    return gen_d3s.generate()
+
+
+def test_streamed_program_has_no_missing_wait_states(program_s):
+    _, prog, _ = program_s
+    assert gcn.check_hazards(prog) == 0
+    # pass 1 and pass 2: the H0 product and ONE control product each (a run-time loop), + column sums
+    assert prog.count("mfma") == 2 * 2 * 192 + 3
+    assert gen_d3s.LDS_BYTES <= 160 * 1024
+
+
+@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 1, 3, 70, 1, 1, False, False), (50, 2, 1, 20, 3, 2, True, True),
+                                                            (64, 1, 6, 16, 1, 1, False, True)])
+def test_streamed_kernel_matches_the_series_and_the_frechet_derivative(program_s, N, K, L, N_T, nblk, wpt, hcpt, shape):
+    _, prog, _ = program_s
+    d = make_inputs(N, K, L, N_T, seed=N + L, hc_per_traj=hcpt, shape=shape)
+    tg, flags, stats, info = run_kernel(prog, d, nblk, wpt, lds_bytes=gen_d3s.LDS_BYTES)
+    ref, orders = series_reference(d, group_wpt=wpt)
+    assert np.isfinite(tg.view(float)).all()
+    assert np.abs(tg - ref).max() < 2e-15 * max(1.0, np.abs(ref).max()) * 8, np.abs(tg - ref).max()
+    fre = frechet_reference(d)
+    assert np.abs(tg - fre).max() < 1e-13, np.abs(tg - fre).max()
+    assert flags[0] == 0 and flags[7] == 0
+    cells = [[min(16, N_T - 16 * b) for b in range((N_T + 15) // 16)] for _ in range(K)]
+    assert int(stats[:, 8].sum()) == int((orders * np.array(cells)).sum())
+
+
+def test_streamed_kernel_flags_a_series_that_does_not_converge(program_s):
+    _, prog, _ = program_s
+    d = make_inputs(64, 1, 3, 5, seed=3, dt_scale=6.0)
+    _, flags, stats, _ = run_kernel(prog, d, 1, 1, mcap=6, lds_bytes=gen_d3s.LDS_BYTES)
+    assert flags[0] == 4 and flags[7] == 0
+    assert int(stats[:, 8].sum()) == 6 * 5

@@ -149,3 +149,50 @@ def test_derivative_kernel_taylor_route_and_its_order_limit(g):
     for asm in (True, False):
         with pytest.raises(g.GrapeHipError, match="GRAPE_ERR_TAYLOR"):
             run_d3(g, pr, asm, gradient_method=g.GRAD_TAYLOR, taylor_max_order=5)
+
+
+# ---- more than two controls at four tiles per side: the streamed-controls assembly kernel (asm/gen_d3s.py) against
+# deriv2_kernel's STREAM_L form (GRAPE_DERIV3S=0, read in grape_create) ----
+def run_d3s(g, pr, asm, **kw):
+    old = os.environ.get("GRAPE_DERIV3S")
+    os.environ["GRAPE_DERIV3S"] = "1" if asm else "0"
+    try:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            J2, G2, _ = h.eval(pr["pulsevals"])
+            assert J2 == J and np.array_equal(G, G2)         # repeatable bit for bit
+            return J, G, tau, h.work()
+    finally:
+        if old is None:
+            os.environ.pop("GRAPE_DERIV3S", None)
+        else:
+            os.environ["GRAPE_DERIV3S"] = old
+
+
+@pytest.mark.parametrize("N,L,N_T,K,kw", [
+    (64, 3, 2, 1, {}), (64, 6, 37, 3, {}), (49, 4, 21, 2, {}), (57, 8, 100, 5, {}), (64, 5, 70, 16, {"shape": True}),
+    (60, 3, 18, 3, {"per_traj": True}), (64, 6, 50, 300, {})])
+def test_streamed_derivative_kernel_against_the_compiled_kernel(g, N, L, N_T, K, kw):
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=11 + N + L)
+    args = {}
+    if kw.get("shape"):
+        args["shape"] = 0.5 + np.random.default_rng(3).random((L, N_T))
+    if kw.get("per_traj"):
+        rng = np.random.default_rng(4)
+        pr["Hc"] = np.stack([pr["Hc"] * (1.0 + 0.1 * rng.random()) for _ in range(K)])
+    a = run_d3s(g, pr, True, **args)
+    b = run_d3s(g, pr, False, **args)
+    assert a[0] == b[0]
+    gs = max(np.abs(b[1]).max(), 1e-3)
+    assert np.abs(a[1] - b[1]).max() <= 5e-14 * gs, np.abs(a[1] - b[1]).max() / gs
+    # the four batches of a workgroup stop together: never fewer orders than the per-batch rule, at most one more per batch
+    assert b[3]["deriv_orders"] <= a[3]["deriv_orders"] <= b[3]["deriv_orders"] + K * N_T
+
+
+def test_streamed_derivative_kernel_order_limit(g):
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 4, 20, 2, seed=19)
+    for asm in (True, False):
+        with pytest.raises(g.GrapeHipError, match="GRAPE_ERR_TAYLOR"):
+            run_d3s(g, pr, asm, gradient_method=g.GRAD_TAYLOR, taylor_max_order=5)
