@@ -452,7 +452,7 @@ def check_hazards(prog):
     return p.missing
 
 
-def kernel_text(prog, kernarg_size, lds_bytes, n_sgpr=102, wg_size=256):
+def kernel_text(prog, kernarg_size, lds_bytes, n_sgpr=102, wg_size=256, n_vgpr=256, n_agpr=256):
     """complete .s file: code + kernel descriptor + metadata (code object v6 conventions of ROCm 7.2 hipcc)"""
     name = prog.name
     return f"""\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
@@ -486,9 +486,9 @@ def kernel_text(prog, kernarg_size, lds_bytes, n_sgpr=102, wg_size=256):
 \t\t.amdhsa_system_sgpr_workgroup_id_z 0
 \t\t.amdhsa_system_sgpr_workgroup_info 0
 \t\t.amdhsa_system_vgpr_workitem_id 0
-\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_vgpr {n_vgpr + n_agpr}
 \t\t.amdhsa_next_free_sgpr {n_sgpr}
-\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_accum_offset {n_vgpr}
 \t\t.amdhsa_reserve_vcc 1
 \t\t.amdhsa_float_round_mode_32 0
 \t\t.amdhsa_float_round_mode_16_64 0
@@ -510,7 +510,7 @@ def kernel_text(prog, kernarg_size, lds_bytes, n_sgpr=102, wg_size=256):
 \t.amdgpu_metadata
 ---
 amdhsa.kernels:
-  - .agpr_count:     256
+  - .agpr_count:     {n_agpr}
     .args:
       - .offset:         0
         .size:           {kernarg_size}
@@ -526,7 +526,7 @@ amdhsa.kernels:
     .symbol:         {name}.kd
     .uniform_work_group_size: 1
     .uses_dynamic_stack: false
-    .vgpr_count:     512
+    .vgpr_count:     {n_vgpr + n_agpr}
     .vgpr_spill_count: 0
     .wavefront_size: 64
 amdhsa.target:   amdgcn-amd-amdhsa--gfx950

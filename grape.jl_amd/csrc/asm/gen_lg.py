@@ -1,0 +1,472 @@
+"""gen_lg.py -- generator of lg_gemm_asm: the batched complex block product of the blocked path (64 < N <= 256) as
+hand-allocated gfx950 assembly.
+
+What it replaces: lg_gemm_kernel (grape_large.hip.h) for the products of the polynomial route of the blocked exponential
+(expm_large_t18 in grape_hip.hip: A2 = A A, A3 = A2 A, A6 = A3 A3, A9 = B1 B5 + B4 [and B3 + A9], p = B2 + (B3 + A9) A9),
+i.e. the five products of U_n = exp(-i H_n dt) per cell that stand for Julia's exp! in
+/root/reference/src/optimize.jl:732 (prop_step! -> ExpProp).  Same grid (one workgroup per 64 x 64 output block, the blocks
+of a cell on one XCD), same 3M arithmetic, same epilogue terms; the squaring launches and the Pade route keep the compiled
+kernel, which is also the differential twin (GRAPE_LG_ASM=0).
+
+Why assembly: the compiled kernel loads a 64-wide k-block, synchronises, multiplies, synchronises -- its matrix pipe is
+56.7 % busy (profiles/r03_pmc_summary_C5.json) because nothing is in flight while it multiplies.  Here
+
+  * the left operand's k-blocks (64 rows x 32 columns, re and im) arrive by LDS-DMA into a two-stage ring, one k-block
+    ahead, written lane-linear with the bank swizzle on the SOURCE address (16-byte granule g of row i sits at g ^ (i & 15):
+    the fragment reads of 16 rows x 4 columns are conflict-free);
+  * the right operand's strip (32 rows x this wave's 16 columns) is loaded one k-block ahead into a second register set;
+  * a k-step is 12 matrix instructions, 8 LDS reads and 5 vector additions (the operand sums of the 3M scheme);
+  * two workgroups per CU (128 + 128 registers per lane, 64 KB of LDS each) cover each other's prologue and epilogue.
+
+Matrices are whole planar arrays ([cell][re | im][NP][NP], NP = 128 or 256), as the polynomial route passes them.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gcn import Prog, Reg, V, A, S, VCC, EXEC, M0, Neg, kernel_text  # noqa: E402
+
+KERNARG = 144
+STAGE_B = 32768                  # one k-block of the left operand: [re | im][64 rows][32 columns]
+LDS_BYTES = 2 * STAGE_B
+KSTEPS = 8                       # k-steps (of 4) per k-block
+TLD = 65                         # row stride (doubles) of the transposition plane of the mirrored block
+
+
+class GenLG:
+    def __init__(self, name="lg_gemm_asm"):
+        self.p = Prog(name)
+        self.p.soft_vm_flush = True
+        # ---- scalars ----
+        self.s_X, self.s_Y, self.s_C, self.s_C2, self.s_A0, self.s_A1, self.s_U, self.s_smax = (S(4 + 2 * i, 2) for i in range(8))
+        self.s_coef = [S(20, 2), S(22, 2)]
+        self.s_coef2 = [S(24, 2), S(26, 2)]
+        self.s_NP, self.s_NB, self.s_ncell, self.s_herm, self.s_nadd, self.s_uif, self.s_percell = (S(32 + i) for i in range(7))
+        self.s_cell, self.s_bi, self.s_bj, self.s_useu = S(40), S(41), S(42), S(43)
+        self.s_xp, self.s_yp, self.s_yq = S(44, 2), S(46, 2), S(48, 2)
+        self.s_ldsw, self.s_rowstep, self.s_kb, self.s_nkb = S(50), S(51), S(52), S(53)
+        self.s_a, self.s_b = S(54, 2), S(56, 2)
+        self.s_t = [S(58 + i) for i in range(8)]
+        self.s_save = S(66, 2)
+        self.s_cellb = S(68, 2)
+        self.s_wave = S(70)
+        self.s_planeb = S(71)
+        self.s_Cb, self.s_C2b, self.s_A0b, self.s_A1b, self.s_Ub = (S(72 + 2 * i, 2) for i in range(5))
+        self.s_boff, self.s_boffT = S(82), S(83)
+        self.s_sg, self.s_nsg = S(84, 2), S(86, 2)
+        self.s_smaxv = S(88)
+        # ---- per-lane ----
+        self.v_tid, self.v_lane = V(0), V(1)
+        self.v_AB = [V(2 + r) for r in range(KSTEPS)]
+        self.v_GP = [V(10 + k) for k in range(4)]
+        self.v_voff = V(14)
+        self.v_tw, self.v_tr = V(15), V(16)           # transposition plane: write / read address of this lane
+        self.v_o = [V(17 + r) for r in range(4)]
+        self.f_re = [V(22 + 2 * rt, 2) for rt in range(4)]
+        self.f_im = [V(30 + 2 * rt, 2) for rt in range(4)]
+        self.f_sm = [V(38 + 2 * rt, 2) for rt in range(4)]
+        self.B = [[[V(46 + 32 * b + 4 * r + 2 * pl, 2) for pl in range(2)] for r in range(KSTEPS)] for b in range(2)]   # B[buf][r][re|im]
+        self.v_bsm = V(110, 2)
+        self.T = V(112, 16)                            # temporaries (prologue, epilogue)
+        self.P = [[A(8 * (4 * j + rt), 8) for rt in range(4)] for j in range(3)]
+        self.E = V(46, 64)                             # epilogue: the block's elements [t][r] (vr, vi), over the B buffers
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def add64(self, dst, base, lo, hi=0):
+        self.p.salu("s_add_u32", dst.sub(0), base.sub(0), lo)
+        self.p.salu("s_addc_u32", dst.sub(1), base.sub(1), hi)
+
+    def sub64(self, dst, base, lo):
+        self.p.salu("s_sub_u32", dst.sub(0), base.sub(0), lo)
+        self.p.salu("s_subb_u32", dst.sub(1), base.sub(1), 0)
+
+    def mul64(self, dst, a, b):
+        self.p.salu("s_mul_hi_u32", dst.sub(1), a, b)
+        self.p.salu("s_mul_i32", dst.sub(0), a, b)
+
+    def udiv(self, q, r, num, den, tag):
+        p = self.p
+        i, t = self.s_t[6], self.s_t[7]
+        p.salu("s_mov_b32", q, 0)
+        p.salu("s_mov_b32", r, 0)
+        p.salu("s_mov_b32", i, 31)
+        p.label(f"L_div_{tag}")
+        p.salu("s_lshl_b32", r, r, 1)
+        p.salu("s_lshr_b32", t, num, i)
+        p.salu("s_and_b32", t, t, 1)
+        p.salu("s_or_b32", r, r, t)
+        p.s_cmp("s_cmp_ge_u32", r, den)
+        p.s_branch("s_cbranch_scc0", f"L_div_skip_{tag}")
+        p.salu("s_sub_u32", r, r, den)
+        p.salu("s_lshl_b32", t, 1, i)
+        p.salu("s_or_b32", q, q, t)
+        p.label(f"L_div_skip_{tag}")
+        p.salu("s_sub_u32", i, i, 1)
+        p.s_cmp("s_cmp_ge_i32", i, 0)
+        p.s_branch("s_cbranch_scc1", f"L_div_{tag}")
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def prologue(self):
+        p = self.p
+        p.s_load(16, S(4, 16), S(0, 2), 0)
+        p.s_load(8, S(20, 8), S(0, 2), 64)
+        p.s_load(4, S(28, 4), S(0, 2), 96)
+        p.s_load(8, S(32, 8), S(0, 2), 112)
+        p.valu("v_and_b32", self.v_tid, 0x3FF, V(0))
+        p.valu("v_and_b32", self.v_lane, 63, self.v_tid)
+        t = self.T
+        vc, vrg, vw, vh, vx, vy = (t.sub(i) for i in range(6))
+        p.valu("v_lshrrev_b32", vw, 6, self.v_tid)
+        p.v_readfirstlane(self.s_wave, vw)
+        p.valu("v_and_b32", vc, 15, self.v_lane)
+        p.valu("v_lshrrev_b32", vrg, 4, self.v_lane)
+        p.valu("v_lshrrev_b32", vh, 1, vrg)
+        p.s_waitcnt(lgkm=0)
+        # ---- which block: the blocks of a cell share blockIdx % 8 (one XCD, one L2) ----
+        wg = S(2)
+        p.salu("s_and_b32", self.s_t[0], wg, 7)
+        p.salu("s_lshr_b32", self.s_t[1], wg, 3)
+        self.udiv(self.s_t[2], self.s_t[3], self.s_t[1], self.s_percell, "pc")
+        p.salu("s_lshl_b32", self.s_cell, self.s_t[2], 3)
+        p.salu("s_add_u32", self.s_cell, self.s_cell, self.s_t[0])
+        p.s_cmp("s_cmp_ge_u32", self.s_cell, self.s_ncell)
+        p.s_branch("s_cbranch_scc1", "L_end")
+        p.s_cmp("s_cmp_eq_u32", self.s_herm, 0)
+        p.s_branch("s_cbranch_scc1", "L_full")
+        # upper triangle, row by row
+        p.salu("s_mov_b32", self.s_bi, 0)
+        p.label("L_tri")
+        p.salu("s_sub_u32", self.s_t[4], self.s_NB, self.s_bi)
+        p.s_cmp("s_cmp_lt_u32", self.s_t[3], self.s_t[4])
+        p.s_branch("s_cbranch_scc1", "L_tri_done")
+        p.salu("s_sub_u32", self.s_t[3], self.s_t[3], self.s_t[4])
+        p.salu("s_add_u32", self.s_bi, self.s_bi, 1)
+        p.s_branch("s_branch", "L_tri")
+        p.label("L_tri_done")
+        p.salu("s_add_u32", self.s_bj, self.s_bi, self.s_t[3])
+        p.s_branch("s_branch", "L_have_block")
+        p.label("L_full")
+        self.udiv(self.s_bi, self.s_bj, self.s_t[3], self.s_NB, "nb")
+        p.label("L_have_block")
+        # the result goes to U (interleaved) when there is one -- and, last product of the route, no cell needs a squaring
+        p.s_cmp("s_cmp_lg_u64", self.s_U, 0)
+        p.salu("s_cselect_b32", self.s_useu, 1, 0)
+        p.s_cmp("s_cmp_eq_u32", self.s_uif, 0)
+        p.s_branch("s_cbranch_scc1", "L_have_u")
+        p.s_load(1, self.s_smaxv, self.s_smax, 0)
+        p.s_waitcnt(lgkm=0)
+        p.s_cmp("s_cmp_lg_u32", self.s_smaxv, 0)
+        p.salu("s_cselect_b32", self.s_useu, 0, self.s_useu)
+        p.label("L_have_u")
+        # ---- per-lane constants ----
+        for r in range(KSTEPS):     # fragment (row 16 rt + c, k-step r): c 256 + (((2 r | h) ^ c) << 4) + (rg & 1) 8
+            p.valu("v_or_b32", vx, 2 * r, vh)
+            p.valu("v_xor_b32", vx, vx, vc)
+            p.valu("v_lshlrev_b32", vx, 4, vx)
+            p.valu("v_and_b32", vy, 1, vrg)
+            p.valu("v_lshl_add_u32", vx, vy, 3, vx)
+            p.valu("v_lshl_add_u32", self.v_AB[r], vc, 8, vx)
+        p.valu("v_lshrrev_b32", vx, 4, self.v_lane)                  # row of the lane inside a piece (0 .. 3)
+        p.valu("v_mul_lo_u32", vy, vx, self.s_NP)
+        p.valu("v_lshlrev_b32", vy, 3, vy)                            # (i >> 4) NP 8
+        for k in range(4):          # piece pattern k = q & 3: granule (i & 15) ^ (4 k + (i >> 4))
+            p.valu("v_add_u32", t.sub(6), 4 * k, vx)
+            p.valu("v_and_b32", t.sub(7), 15, self.v_lane)
+            p.valu("v_xor_b32", t.sub(6), t.sub(6), t.sub(7))
+            p.valu("v_lshl_add_u32", self.v_GP[k], t.sub(6), 4, vy)
+        # element (row 4 r + rg [+ 16 t], column 16 w + c) of a 64 x 64 block: (rg NP + 16 w + c) 8
+        p.valu("v_lshl_add_u32", vx, vw, 4, vc)                       # 16 w + c
+        p.valu("v_mul_lo_u32", vy, vrg, self.s_NP)
+        p.valu("v_add_u32", vy, vy, vx)
+        p.valu("v_lshlrev_b32", self.v_voff, 3, vy)
+        p.valu("v_mul_u32_u24", vy, TLD, vrg)
+        p.valu("v_add_u32", vy, vy, vx)
+        p.valu("v_lshlrev_b32", self.v_tw, 3, vy)                     # (rg 65 + 16 w + c) 8
+        p.valu("v_mul_u32_u24", vy, TLD, vx)
+        p.valu("v_add_u32", vy, vy, vrg)
+        p.valu("v_lshlrev_b32", self.v_tr, 3, vy)                     # ((16 w + c) 65 + rg) 8
+        # ---- scalar bases ----
+        p.salu("s_mul_i32", self.s_planeb, self.s_NP, self.s_NP)
+        p.salu("s_lshl_b32", self.s_planeb, self.s_planeb, 3)         # bytes of a plane
+        p.salu("s_lshl_b32", self.s_t[0], self.s_planeb, 1)
+        self.mul64(self.s_cellb, self.s_cell, self.s_t[0])
+        p.salu("s_lshl_b32", self.s_rowstep, self.s_NP, 5)            # 4 rows: 4 NP 8 bytes
+        # X: this wave's pieces: plane w >> 1, rows 4 j, j = (w & 1) 8 + q
+        self.add64(self.s_xp, self.s_X, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        p.salu("s_mul_i32", self.s_t[0], self.s_bi, self.s_NP)
+        p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 9)             # bi 64 NP 8
+        self.add64(self.s_xp, self.s_xp, self.s_t[0])
+        p.salu("s_lshr_b32", self.s_t[1], self.s_wave, 1)
+        p.salu("s_mul_i32", self.s_t[0], self.s_t[1], self.s_planeb)
+        self.add64(self.s_xp, self.s_xp, self.s_t[0])
+        p.salu("s_and_b32", self.s_t[2], self.s_wave, 1)
+        p.salu("s_lshl_b32", self.s_t[0], self.s_rowstep, 3)
+        p.salu("s_mul_i32", self.s_t[0], self.s_t[0], self.s_t[2])
+        self.add64(self.s_xp, self.s_xp, self.s_t[0])
+        p.salu("s_lshl_b32", self.s_ldsw, self.s_t[1], 14)
+        p.salu("s_lshl_b32", self.s_t[2], self.s_t[2], 13)
+        p.salu("s_add_u32", self.s_ldsw, self.s_ldsw, self.s_t[2])
+        # Y: rows k, columns bj 64 + ...
+        self.add64(self.s_yp, self.s_Y, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        p.salu("s_lshl_b32", self.s_t[0], self.s_bj, 9)
+        self.add64(self.s_yp, self.s_yp, self.s_t[0])
+        self.add64(self.s_yq, self.s_yp, self.s_planeb)
+        p.salu("s_lshl_b32", self.s_nkb, self.s_NB, 1)
+        for j in range(3):
+            for rt in range(4):
+                for i in range(8):
+                    p.valu("v_accvgpr_write_b32", self.P[j][rt].sub(i), 0)
+
+    # ---- loads of a k-block, in pieces ------------------------------------------------------------------------------
+    def dma_piece(self, q, stage):
+        p = self.p
+        if q == 0:
+            p.salu("s_mov_b64", self.s_a, self.s_xp)
+        else:
+            self.add64(self.s_a, self.s_a, self.s_rowstep)
+        p.salu("s_add_u32", M0, self.s_ldsw, stage * STAGE_B + q * 1024)
+        p.global_load_lds(self.v_GP[q & 3], self.s_a)
+
+    def b_loads(self, r, buf):
+        p = self.p
+        p.global_load(2, self.B[buf][r][0], self.v_voff, self.s_yp)
+        p.global_load(2, self.B[buf][r][1], self.v_voff, self.s_yq)
+        self.add64(self.s_yp, self.s_yp, self.s_rowstep)
+        self.add64(self.s_yq, self.s_yq, self.s_rowstep)
+
+    def frag_read(self, pl, rt, r, stage):
+        dst = (self.f_re if pl == 0 else self.f_im)[rt]
+        self.p.ds_read(64, dst, self.v_AB[r], stage * STAGE_B + pl * 16384 + rt * 4096)
+
+    def kblock(self, par, prefetch=True):
+        """the 8 k-steps of a k-block (stage and B set `par`); requests of the next k-block in its first steps"""
+        p = self.p
+        for rt in range(4):
+            self.frag_read(0, rt, 0, par)
+        for rt in range(4):
+            self.frag_read(1, rt, 0, par)
+        for r in range(KSTEPS):
+            more = r < KSTEPS - 1
+            for rt in range(4):
+                p.valu("v_add_f64", self.f_sm[rt], self.f_re[rt], self.f_im[rt])
+            p.valu("v_add_f64", self.v_bsm, self.B[par][r][0], self.B[par][r][1])
+            for rt in range(4):
+                p.mfma(self.P[0][rt], self.f_re[rt], self.B[par][r][0], self.P[0][rt])
+                if prefetch and rt == 0 and r < 4:
+                    self.dma_piece(2 * r, par ^ 1)
+                    self.dma_piece(2 * r + 1, par ^ 1)
+            if more:
+                for rt in range(4):
+                    self.frag_read(0, rt, r + 1, par)
+            for rt in range(4):
+                p.mfma(self.P[1][rt], self.f_im[rt], self.B[par][r][1], self.P[1][rt])
+                if prefetch and rt == 0 and r < 4:
+                    self.b_loads(2 * r, par ^ 1)
+                    self.b_loads(2 * r + 1, par ^ 1)
+            if more:
+                for rt in range(4):
+                    self.frag_read(1, rt, r + 1, par)
+            for rt in range(4):
+                p.mfma(self.P[2][rt], self.f_sm[rt], self.v_bsm, self.P[2][rt])
+
+    def block_top(self, par):
+        """the k-block at s_kb + par: its operands have landed; where the next one comes from (the last k-block asks for
+        itself again: its prefetch is never used, and stays inside the arrays)"""
+        p = self.p
+        p.s_waitcnt(vm=0, lgkm=0)
+        p.s_barrier()
+        p.salu("s_add_u32", self.s_t[0], self.s_kb, par + 1)
+        p.salu("s_lshl_b32", self.s_t[2], self.s_rowstep, 3)
+        p.s_cmp("s_cmp_lt_u32", self.s_t[0], self.s_nkb)
+        p.salu("s_cselect_b32", self.s_t[1], 256, 0)                 # next k-block: 32 columns on
+        p.salu("s_cselect_b32", self.s_t[2], 0, self.s_t[2])         # last: back over the 32 rows just requested
+        self.add64(self.s_xp, self.s_xp, self.s_t[1])
+        self.sub64(self.s_yp, self.s_yp, self.s_t[2])
+        self.sub64(self.s_yq, self.s_yq, self.s_t[2])
+
+    # ---- epilogue ----------------------------------------------------------------------------------------------------
+    def elem(self, t, r):
+        return self.E.sub(4 * (4 * t + r), 4)
+
+    def combine_all(self):
+        """E[t][r] = (p1 - p2, p3 - p1 - p2)"""
+        p = self.p
+        for t in range(4):
+            for r in range(4):
+                e = self.elem(t, r)
+                tmp = self.T.sub(0, 6)
+                for j in range(3):
+                    for hw in range(2):
+                        p.valu("v_accvgpr_read_b32", tmp.sub(2 * j + hw), self.P[j][t].d(r).sub(hw))
+                p1, p2, p3 = tmp.sub(0, 2), tmp.sub(2, 2), tmp.sub(4, 2)
+                p.valu("v_add_f64", e.sub(0, 2), p1, Neg(p2))
+                p.valu("v_add_f64", e.sub(2, 2), p3, Neg(p1))
+                p.valu("v_add_f64", e.sub(2, 2), e.sub(2, 2), Neg(p2))
+
+    def offsets(self, t, boff):
+        """v_o[r] = per-lane byte offset of element (16 t + 4 r + rg, 16 w + c) of the block at boff"""
+        p = self.p
+        for r in range(4):
+            p.salu("s_mul_i32", self.s_t[0], self.s_NP, (16 * t + 4 * r) * 8)
+            p.salu("s_add_u32", self.s_t[0], self.s_t[0], boff)
+            p.valu("v_add_u32", self.v_o[r], self.s_t[0], self.v_voff)
+
+    def store_block(self, tag, to_u_allowed):
+        """E -> C (planar) or U (interleaved)"""
+        p = self.p
+        if to_u_allowed:
+            p.s_cmp("s_cmp_lg_u32", self.s_useu, 0)
+            p.s_branch("s_cbranch_scc1", f"L_store_u_{tag}")
+        for t in range(4):
+            self.offsets(t, self.s_boff)
+            for r in range(4):
+                e = self.elem(t, r)
+                p.global_store(2, self.v_o[r], e.sub(0, 2), self.s_Cb)
+                p.global_store(2, self.v_o[r], e.sub(2, 2), self.s_b)          # im plane: s_b = Cb + plane
+        if to_u_allowed:
+            p.s_branch("s_branch", f"L_store_done_{tag}")
+            p.label(f"L_store_u_{tag}")
+            for t in range(4):
+                self.offsets(t, self.s_boff)
+                for r in range(4):
+                    p.valu("v_lshlrev_b32", self.v_o[r], 1, self.v_o[r])
+                    p.global_store(4, self.v_o[r], self.elem(t, r), self.s_Ub)
+            p.label(f"L_store_done_{tag}")
+
+    def epilogue(self):
+        p = self.p
+        # bases
+        self.add64(self.s_Cb, self.s_C, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        self.add64(self.s_b, self.s_Cb, self.s_planeb)
+        self.mul64(self.s_a, self.s_cell, self.s_planeb)             # cell NP NP 8 -> x 2: 16 bytes per element of U
+        p.salu("s_lshl_b64", self.s_a, self.s_a, 1)
+        self.add64(self.s_Ub, self.s_U, self.s_a.sub(0), self.s_a.sub(1))
+        p.salu("s_mul_i32", self.s_boff, self.s_bi, self.s_NP)
+        p.salu("s_add_u32", self.s_boff, self.s_boff, self.s_bj)
+        p.salu("s_lshl_b32", self.s_boff, self.s_boff, 9)            # (bi 64 NP + bj 64) 8
+        self.combine_all()
+        p.s_cmp("s_cmp_eq_u32", self.s_nadd, 0)
+        p.s_branch("s_cbranch_scc1", "L_epi_plain")
+        # ---- epilogue terms: E += coef[q] Add_q; second output C2 = E + coef2[q] Add_q ----
+        self.add64(self.s_A0b, self.s_A0, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        self.add64(self.s_A1b, self.s_A1, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        self.add64(self.s_C2b, self.s_C2, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        for t in range(4):
+            self.offsets(t, self.s_boff)
+            x0 = [self.T.sub(4 * r, 4) for r in range(4)]               # Add_0 (re, im) of the four elements
+            for r in range(4):
+                p.global_load(2, x0[r].sub(0, 2), self.v_o[r], self.s_A0b)
+            self.add64(self.s_a, self.s_A0b, self.s_planeb)
+            for r in range(4):
+                p.global_load(2, x0[r].sub(2, 2), self.v_o[r], self.s_a)
+            lab1 = f"L_one_add_{t}"
+            # second output starts from E (before its own terms are added): W = E + coef2_0 x0 [+ coef2_1 x1]
+            w = [V(22 + 4 * r, 4) for r in range(4)]                    # over the (idle) fragment registers
+            for r in range(4):
+                e = self.elem(t, r)
+                for pl in range(2):
+                    p.valu("v_fma_f64", e.sub(2 * pl, 2), x0[r].sub(2 * pl, 2), self.s_coef[0], e.sub(2 * pl, 2))
+                    p.valu("v_fma_f64", w[r].sub(2 * pl, 2), x0[r].sub(2 * pl, 2), self.s_coef2[0], e.sub(2 * pl, 2))
+            p.s_cmp("s_cmp_lt_u32", self.s_nadd, 2)
+            p.s_branch("s_cbranch_scc1", lab1)
+            for r in range(4):
+                p.global_load(2, x0[r].sub(0, 2), self.v_o[r], self.s_A1b)
+            self.add64(self.s_a, self.s_A1b, self.s_planeb)
+            for r in range(4):
+                p.global_load(2, x0[r].sub(2, 2), self.v_o[r], self.s_a)
+            for r in range(4):
+                e = self.elem(t, r)
+                for pl in range(2):
+                    # (the second output takes the first output's terms too: C2 = C + sum coef2 Add)
+                    p.valu("v_fma_f64", w[r].sub(2 * pl, 2), x0[r].sub(2 * pl, 2), self.s_coef[1], w[r].sub(2 * pl, 2))
+                    p.valu("v_fma_f64", w[r].sub(2 * pl, 2), x0[r].sub(2 * pl, 2), self.s_coef2[1], w[r].sub(2 * pl, 2))
+                    p.valu("v_fma_f64", e.sub(2 * pl, 2), x0[r].sub(2 * pl, 2), self.s_coef[1], e.sub(2 * pl, 2))
+            p.label(lab1)
+            lab2 = f"L_no_c2_{t}"
+            p.s_cmp("s_cmp_eq_u64", self.s_C2, 0)
+            p.s_branch("s_cbranch_scc1", lab2)
+            self.add64(self.s_a, self.s_C2b, self.s_planeb)
+            for r in range(4):
+                p.global_store(2, self.v_o[r], w[r].sub(0, 2), self.s_C2b)
+                p.global_store(2, self.v_o[r], w[r].sub(2, 2), self.s_a)
+            p.label(lab2)
+        self.store_block("adds", True)
+        p.s_branch("s_branch", "L_end")
+        # ---- plain product (Hermitian / skew-Hermitian results also store the mirrored block) ----
+        p.label("L_epi_plain")
+        self.store_block("plain", True)
+        p.s_cmp("s_cmp_eq_u32", self.s_herm, 0)
+        p.s_branch("s_cbranch_scc1", "L_end")
+        p.s_cmp("s_cmp_eq_u32", self.s_bi, self.s_bj)
+        p.s_branch("s_cbranch_scc1", "L_end")
+        # block (bj, bi) = sgn conj(transpose): one plane at a time through the idle LDS
+        lo1, hi1 = 0, 0x3FF00000
+        p.s_cmp("s_cmp_gt_i32", self.s_herm, 0)
+        p.salu("s_cselect_b32", self.s_t[0], 0, 0x80000000)
+        p.salu("s_mov_b32", self.s_sg.sub(0), 0)
+        p.salu("s_or_b32", self.s_sg.sub(1), self.s_t[0], hi1)
+        p.salu("s_mov_b32", self.s_nsg.sub(0), 0)
+        p.salu("s_xor_b32", self.s_nsg.sub(1), self.s_sg.sub(1), 0x80000000)
+        p.salu("s_mul_i32", self.s_boffT, self.s_bj, self.s_NP)
+        p.salu("s_add_u32", self.s_boffT, self.s_boffT, self.s_bi)
+        p.salu("s_lshl_b32", self.s_boffT, self.s_boffT, 9)
+        for pl in range(2):
+            p.s_waitcnt(lgkm=0)
+            p.s_barrier()
+            for t in range(4):
+                for r in range(4):
+                    p.ds_write(64, self.v_tw, self.elem(t, r).sub(2 * pl, 2), (16 * t + 4 * r) * TLD * 8)
+            p.s_waitcnt(lgkm=0)
+            p.s_barrier()
+            for t in range(4):
+                for r in range(4):
+                    p.ds_read(64, self.elem(t, r).sub(2 * pl, 2), self.v_tr, (16 * t + 4 * r) * 8)
+        for t in range(4):
+            self.offsets(t, self.s_boffT)
+            for r in range(4):
+                e = self.elem(t, r)
+                p.valu("v_mul_f64", e.sub(0, 2), e.sub(0, 2), self.s_sg)
+                p.valu("v_mul_f64", e.sub(2, 2), e.sub(2, 2), self.s_nsg)
+                p.global_store(2, self.v_o[r], e.sub(0, 2), self.s_Cb)
+                p.global_store(2, self.v_o[r], e.sub(2, 2), self.s_b)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def build(self):
+        p = self.p
+        self.prologue()
+        # k-block 0 into stage 0 / B set 0
+        for q in range(8):
+            self.dma_piece(q, 0)
+        for r in range(KSTEPS):
+            self.b_loads(r, 0)
+        p.salu("s_mov_b32", self.s_kb, 0)
+        p.label("L_loop")
+        for par in range(2):
+            self.block_top(par)
+            self.kblock(par)
+        p.salu("s_add_u32", self.s_kb, self.s_kb, 2)
+        p.s_cmp("s_cmp_lt_u32", self.s_kb, self.s_nkb)
+        p.s_branch("s_cbranch_scc1", "L_loop")
+        self.epilogue()
+        p.label("L_end")
+        p.s_endpgm()
+        top = max((i for ins in p.ins for c, i in (ins.reads + ins.writes) if c in ("v", "a")), default=0)
+        assert top < 128, top
+        return p
+
+
+def generate(path=None, **kw):
+    g = GenLG(**kw)
+    prog = g.build()
+    text = kernel_text(prog, KERNARG, LDS_BYTES, n_sgpr=96, n_vgpr=128, n_agpr=128)
+    if path:
+        with open(path, "w") as f:
+            f.write(text)
+    return g, prog, text
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "lg_gemm_asm.s")
+    g, prog, _ = generate(out)
+    print(f"{out}: {len(prog.ins)} lines, {prog.count('mfma')} matrix instructions, {prog.count('valu')} vector, "
+          f"{prog.count('lds')} LDS, {prog.count('vmem')} global, {prog.auto_nops} wait states inserted")

@@ -257,6 +257,7 @@ static bool deriv3_fits(int NT, int L, bool h0_general = false) {
 }
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
                                    int skip_if_flagged, int h0_general, void *stream, int blocks);
+extern "C" int grape_lg_asm_launch(const void *k, size_t size, unsigned blocks, void *stream);
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream);
 #endif
@@ -627,6 +628,51 @@ void phase_end(grape_handle *h, int i, hipStream_t s) {
 // ---- blocked Pade-13 for 64 < N <= 256: one launch per product, cells in chunks ----
 LgView lg_full(double *p, int NP) { return LgView{p, (size_t)2 * NP * NP, (size_t)NP * NP, NP, 0, 0}; }
 
+// the products of the polynomial route as assembly (asm/gen_lg.py: lg_gemm_asm; GRAPE_LG_ASM=0: the compiled kernel, its
+// twin).  The assembly kernel takes whole planar arrays, at most two epilogue terms, no beta / identity terms and none of
+// the squaring logic; everything else stays with lg_gemm_kernel.
+struct LgAsmArgs {
+    const double *X, *Y;
+    double *C, *C2;
+    const double *Add0, *Add1;
+    double2 *Uout;
+    const int *smax_ptr;
+    double coef[2], coef2[2], cI, cI2;
+    int NP, NB, ncell, herm, nadd, u_if_smax0, per_cell, pad;
+};
+static_assert(sizeof(LgAsmArgs) == 144, "argument block of lg_gemm_asm");
+bool lg_asm_enabled() {
+    const char *e = getenv("GRAPE_LG_ASM");   // (read at every launch: the differential tests switch it between evaluations)
+    return !(e && atoi(e) == 0);
+}
+bool lg_full_view(const LgView &v, int NP) {
+    return v.p && v.rb == 0 && v.cb == 0 && v.ld == NP && v.plane == (size_t)NP * NP && v.cell_stride == (size_t)2 * NP * NP;
+}
+// true: launched (err holds the status); false: not eligible
+bool lg_try_asm(hipStream_t s, const LgGemmArgs &a, hipError_t *err) {
+    if (!lg_asm_enabled()) return false;
+    const int NP = a.C.ld, NB = a.nbi;
+    if ((NP != 128 && NP != 256) || a.nbj != NB || a.kblocks != NB || NB * 64 != NP) return false;
+    if (a.alpha != 1.0 || a.beta != 0.0 || a.cI != 0.0 || a.cI2 != 0.0 || a.s_cell || a.scale_s || a.skip_bi != -1 || a.nadd > 2) return false;
+    if (a.smax_ptr && !a.u_if_smax0) return false;
+    if (a.herm && (a.nadd || a.Uout || a.C2.p)) return false;
+    if (a.Uout && a.u_np != NP) return false;
+    if (!lg_full_view(a.X, NP) || !lg_full_view(a.Y, NP) || !lg_full_view(a.C, NP)) return false;
+    if (a.C2.p && !lg_full_view(a.C2, NP)) return false;
+    for (int i = 0; i < a.nadd; ++i)
+        if (!lg_full_view(a.Add[i], NP)) return false;
+    LgAsmArgs k{};
+    k.X = a.X.p; k.Y = a.Y.p; k.C = a.C.p; k.C2 = a.C2.p;
+    k.Add0 = a.nadd > 0 ? a.Add[0].p : nullptr; k.Add1 = a.nadd > 1 ? a.Add[1].p : nullptr;
+    k.Uout = a.Uout; k.smax_ptr = a.smax_ptr;
+    for (int i = 0; i < a.nadd; ++i) { k.coef[i] = a.coef[i]; k.coef2[i] = a.coef2[i]; }
+    k.NP = NP; k.NB = NB; k.ncell = a.ncell; k.herm = a.herm; k.nadd = a.nadd; k.u_if_smax0 = a.u_if_smax0;
+    k.per_cell = a.herm ? NB * (NB + 1) / 2 : NB * NB;
+    const int groups = (a.ncell + 7) / 8;
+    *err = (hipError_t)grape_lg_asm_launch(&k, sizeof(k), (unsigned)(groups * 8 * k.per_cell), (void *)s);
+    return true;
+}
+
 hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, LgView C, int kblocks, double alpha,
                    double beta, int nadd = 0, const LgView *add = nullptr, const double *coef = nullptr,
                    double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0, int herm = 0,
@@ -643,6 +689,8 @@ hipError_t lg_gemm(hipStream_t s, int nc, int nbi, int nbj, LgView X, LgView Y, 
     a.nbi = nbi; a.nbj = nbj; a.ncell = nc;
     const int groups = (nc + 7) / 8;   // cells are dealt to the 8 XCDs in groups
     const int per_cell = a.herm ? nbi * (nbi + 1) / 2 : nbi * nbj;
+    hipError_t easm;
+    if (lg_try_asm(s, a, &easm)) return easm;
     hipLaunchKernelGGL(lg_gemm_kernel, dim3(groups * 8 * per_cell), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -665,6 +713,8 @@ hipError_t lg_gemm_poly(hipStream_t s, int nc, int NB, LgView X, LgView Y, LgVie
     a.nbi = NB; a.nbj = NB; a.ncell = nc;
     const int groups = (nc + 7) / 8;
     const int per_cell = a.herm ? NB * (NB + 1) / 2 : NB * NB;
+    hipError_t easm;
+    if (lg_try_asm(s, a, &easm)) return easm;
     hipLaunchKernelGGL(lg_gemm_kernel, dim3(groups * 8 * per_cell), dim3(256), 0, s, a);
     return hipGetLastError();
 }

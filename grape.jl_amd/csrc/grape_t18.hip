@@ -207,11 +207,11 @@ __global__ void __launch_bounds__(256) t16_credit_kernel(ExpmArgs a) {
 constexpr int D3_INV_TABLE = 2048;
 struct AsmModule {
     hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr;
+    hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr;
     double *inv = nullptr;      // 1 / m, m < D3_INV_TABLE
 };
 hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr,
-                        hipFunction_t *fn_d3s = nullptr) {
+                        hipFunction_t *fn_d3s = nullptr, hipFunction_t *fn_lg = nullptr) {
     static AsmModule mods[64];
     static std::mutex mtx;
     std::lock_guard<std::mutex> lock(mtx);
@@ -222,6 +222,8 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         e = hipModuleGetFunction(&m.fn_d3, m.mod, "deriv3_asm");
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn_d3s, m.mod, "deriv3s_asm");
+        if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn_lg, m.mod, "lg_gemm_asm");
         if (e != hipSuccess) return e;
         // 1 / m for the series orders (the kernels read them with scalar loads; gfx9 has no scalar floating point); behind
         // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
@@ -244,6 +246,7 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
     if (fn) *fn = m.fn;
     if (fn_d3) *fn_d3 = m.fn_d3;
     if (fn_d3s) *fn_d3s = m.fn_d3s;
+    if (fn_lg) *fn_lg = m.fn_lg;
     if (inv) *inv = m.inv;
     return hipSuccess;
 }
@@ -293,6 +296,23 @@ hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks) {
     return hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
 }
 }  // namespace
+
+// batched complex block product of the blocked path (asm/gen_lg.py): `k` is the 144-byte argument block of lg_gemm_asm,
+// filled by the caller (grape_hip.hip: lg_asm_args), one workgroup per 64 x 64 output block
+extern "C" int grape_lg_asm_launch(const void *k, size_t size, unsigned blocks, void *stream) {
+    if (size != 144 || blocks == 0) return (int)hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipFunction_t fn;
+    e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, &fn);
+    if (e != hipSuccess) return (int)e;
+    unsigned char buf[144];
+    memcpy(buf, k, sizeof(buf));
+    size_t sz = sizeof(buf);
+    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    return (int)hipModuleLaunchKernel(fn, blocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, cfg);
+}
 
 // args: ExpmArgs with Sf set (summed controls of every time step) and cell_list / flags / stats as for the C++ kernel
 extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks) {

@@ -221,7 +221,7 @@ def test_streamed_program_has_no_missing_wait_states(program_s):
     assert gen_d3s.LDS_BYTES <= 160 * 1024
 
 
-@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 1, 3, 70, 1, 1, False, False), (50, 2, 1, 20, 3, 2, True, True),
+@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 1, 3, 37, 1, 1, False, False), (50, 2, 1, 20, 3, 2, True, True),
                                                             (64, 1, 6, 16, 1, 1, False, True)])
 def test_streamed_kernel_matches_the_series_and_the_frechet_derivative(program_s, N, K, L, N_T, nblk, wpt, hcpt, shape):
     _, prog, _ = program_s

@@ -1,0 +1,127 @@
+"""The batched complex block product of the blocked path as gfx950 assembly (grape.jl_amd/csrc/asm/gen_lg.py), executed
+by the lane-accurate emulator of gcn.py -- this container has no GPU -- against numpy on the same planar matrices.
+
+Checks: plain, Hermitian and skew-Hermitian products (upper block triangle + mirrored blocks), the epilogue terms with a
+second output, the hand-over of the last product to U (interleaved) or C depending on the device-side squaring count, the
+block-to-XCD mapping of the grid, no register touched while a load is outstanding, no LDS word shared inside a barrier
+epoch or read while an LDS-DMA write is in flight, no missing wait state, and that the text assembles."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "grape.jl_amd", "csrc", "asm"))
+import gcn  # noqa: E402
+import gen_lg  # noqa: E402
+
+
+def planar(M):
+    return np.stack([np.stack([m.real, m.imag]) for m in M]).astype(np.float64)
+
+
+def unplanar(P):
+    return P[:, 0] + 1j * P[:, 1]
+
+
+def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False, uif=0, smax=0):
+    ncell, NB = X.shape[0], NP // 64
+    g = gcn.GlobalMem()
+    a_X, _ = g.add("X", planar(X))
+    a_Y, _ = g.add("Y", planar(Y)) if Y is not X else (a_X, None)
+    a_C, C = g.add("C", np.full((ncell, 2, NP, NP), np.nan))
+    a_C2, C2 = (g.add("C2", np.full((ncell, 2, NP, NP), np.nan)) if c2 else (0, None))
+    a_add = [0, 0]
+    for i, ad in enumerate(adds):
+        a_add[i], _ = g.add(f"Add{i}", planar(ad))
+    a_U, U = (g.add("U", np.full((ncell, NP, NP, 2), np.nan)) if uout else (0, None))
+    a_s, _ = g.add("smax", np.array([smax, 0], np.int32))
+    cf = list(coef) + [0.0] * (2 - len(coef))
+    cf2 = list(coef2) + [0.0] * (2 - len(coef2))
+    per_cell = NB * (NB + 1) // 2 if herm else NB * NB
+    karg = struct.pack("<8Q6d8i", a_X, a_Y, a_C, a_C2, a_add[0], a_add[1], a_U, a_s, cf[0], cf[1], cf2[0], cf2[1], 0.0, 0.0,
+                       NP, NB, ncell, herm, len(adds), uif, per_cell, 0)
+    assert len(karg) == gen_lg.KERNARG
+    a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
+    groups = (ncell + 7) // 8
+    mf = 0
+    for wg in range(groups * 8 * per_cell):
+        if (wg & 7) >= ncell and groups == 1:
+            continue           # (leaves at once: checked for one such workgroup in the mapping test)
+        e = gcn.Emu(prog, g, a_k, wg_id=wg, lds_bytes=gen_lg.LDS_BYTES)
+        e.run()
+        mf += e.mfma_count
+    return unplanar(C), (unplanar(C2) if c2 else None), (U[..., 0] + 1j * U[..., 1] if uout else None), mf
+
+
+def rnd(rng, n, NP, kind=None):
+    M = (rng.normal(size=(n, NP, NP)) + 1j * rng.normal(size=(n, NP, NP))) / np.sqrt(NP)
+    if kind == "skew":      # A = -i dt H
+        M = -1j * (M + M.conj().transpose(0, 2, 1)) / 2
+    return M
+
+
+@pytest.fixture(scope="module")
+def program():
+    return gen_lg.generate()
+
+
+def test_program_has_no_missing_wait_states_and_assembles(program, tmp_path):
+    _, prog, text = program
+    assert gcn.check_hazards(prog) == 0
+    assert prog.count("mfma") == 2 * 8 * 12          # two k-blocks per loop iteration, 8 k-steps, 12 matrix instructions each
+    if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        src = tmp_path / "lg.s"
+        src.write_text(text)
+        subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src),
+                        "-o", str(tmp_path / "lg.o")], check=True)
+
+
+def test_hermitian_and_skew_hermitian_products(program):
+    """A2 = A A (Hermitian result) and A3 = A2 A (skew-Hermitian) of a skew-Hermitian A: upper blocks computed, the rest mirrored"""
+    _, prog, _ = program
+    rng = np.random.default_rng(1)
+    NP = 128
+    A = rnd(rng, 1, NP, "skew")
+    C, _, _, mf = run(prog, NP, A, A, herm=1)
+    ref = A @ A
+    assert np.abs(C - ref).max() < 2e-15 * NP ** 0.5
+    assert np.abs(C - C.conj().transpose(0, 2, 1))[:, :64, 64:].max() == 0.0   # the lower block is a copy of the upper one
+    assert mf == 3 * 4 * 4 * 96                                           # 3 blocks x 4 waves x 4 k-blocks x 96
+    C3, _, _, _ = run(prog, NP, ref, A, herm=-1)
+    assert np.abs(C3 - ref @ A).max() < 2e-15 * NP ** 0.5
+    assert np.abs(C3 + C3.conj().transpose(0, 2, 1))[:, :64, 64:].max() == 0.0
+
+
+def test_epilogue_terms_second_output_and_grid_mapping(program):
+    """A9 = B1 B5 + B4 with B3 + A9 as second output (two cells: one per XCD slot; the other six slots leave at once)"""
+    _, prog, _ = program
+    rng = np.random.default_rng(2)
+    NP = 128
+    B1, B5, B4, B3 = (rnd(rng, 2, NP) for _ in range(4))
+    C, C2, _, _ = run(prog, NP, B1, B5, adds=(B4, B3), coef=(1.0, 0.0), coef2=(0.0, 1.0), c2=True)
+    ref = B1 @ B5 + B4
+    assert np.abs(C - ref).max() < 4e-15 and np.abs(C2 - (ref + B3)).max() < 4e-15
+    # a workgroup whose cell does not exist
+    g = gcn.GlobalMem()
+    karg = struct.pack("<8Q6d8i", *([0] * 8), *([0.0] * 6), NP, 2, 2, 0, 0, 0, 4, 0)
+    a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
+    e = gcn.Emu(prog, g, a_k, wg_id=5, lds_bytes=gen_lg.LDS_BYTES)
+    assert e.run() < 10000 and e.mfma_count == 0
+
+
+@pytest.mark.parametrize("smax", [0, 1])
+def test_last_product_goes_to_u_unless_a_cell_needs_a_squaring(program, smax):
+    _, prog, _ = program
+    rng = np.random.default_rng(3)
+    NP = 128
+    L_, A9, B2 = (rnd(rng, 1, NP) for _ in range(3))
+    C, _, U, _ = run(prog, NP, L_, A9, adds=(B2,), coef=(0.5,), uout=True, uif=1, smax=smax)
+    ref = L_ @ A9 + 0.5 * B2
+    if smax == 0:
+        assert np.abs(U - ref).max() < 4e-15 and np.isnan(C.real).all()
+    else:
+        assert np.abs(C - ref).max() < 4e-15 and np.isnan(U.real).all()

@@ -196,3 +196,43 @@ def test_streamed_derivative_kernel_order_limit(g):
     for asm in (True, False):
         with pytest.raises(g.GrapeHipError, match="GRAPE_ERR_TAYLOR"):
             run_d3s(g, pr, asm, gradient_method=g.GRAD_TAYLOR, taylor_max_order=5)
+
+
+# ---- blocked path (64 < N <= 256): the products of the polynomial route as assembly (asm/gen_lg.py) against
+# lg_gemm_kernel (GRAPE_LG_ASM=0, read at every launch) ----
+def run_lg(g, pr, asm, props=True, **kw):
+    old = os.environ.get("GRAPE_LG_ASM")
+    os.environ["GRAPE_LG_ASM"] = "1" if asm else "0"
+    try:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            J2, G2, _ = h.eval(pr["pulsevals"])
+            assert J2 == J and np.array_equal(G, G2)
+            K, N_T = pr["H0"].shape[0], len(pr["tlist"]) - 1
+            U = np.stack([h.propagator(k, n) for k in range(K) for n in range(N_T)]) if props else None
+            return J, G, tau, U, h.work()
+    finally:
+        if old is None:
+            os.environ.pop("GRAPE_LG_ASM", None)
+        else:
+            os.environ["GRAPE_LG_ASM"] = old
+
+
+@pytest.mark.parametrize("N,L,N_T,K,dt,herm", [(256, 2, 3, 2, 1.0, True), (128, 2, 5, 3, 1.0, True), (200, 4, 4, 11, 0.8, True),
+                                               (100, 1, 9, 2, 3.0, True), (256, 2, 3, 2, 1.0, False), (128, 1, 4, 9, 2.5, False)])
+def test_blocked_products_against_the_compiled_kernel(g, N, L, N_T, K, dt, herm):
+    """Hermitian and general generators, one and four 64-blocks per side, more cells than one XCD group, steps that need
+    squarings (those launches stay with the compiled kernel on both sides)"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=41 + N + L, dt=dt, hermitian=herm)
+    a = run_lg(g, pr, True)
+    b = run_lg(g, pr, False)
+    assert np.abs(a[3] - b[3]).max() < 5e-14, np.abs(a[3] - b[3]).max()
+    assert abs(a[0] - b[0]) <= 1e-12 and np.abs(a[1] - b[1]).max() <= 1e-11 * max(np.abs(b[1]).max(), 1e-3)
+    if herm:
+        uni = max(np.abs(u.conj().T @ u - np.eye(N)).max() for u in a[3])
+        assert uni < 5e-14
+    from scipy.linalg import expm
+    e = pr["pulsevals"].reshape(L, N_T)[:, 0]
+    H = pr["H0"][0] + sum(e[l] * pr["Hc"][l] for l in range(L))
+    assert np.abs(a[3][0] - expm(-1j * (pr["tlist"][1] - pr["tlist"][0]) * H)).max() < 1e-12

@@ -811,10 +811,11 @@ def test_four_product_route_is_planned_from_the_pulses_alone(g, monkeypatch):
 
 
 @pytest.mark.parametrize("N,L,N_T,K", [(64, 2, 300, 4), (48, 1, 203, 3), (60, 2, 129, 9), (40, 2, 64, 130), (48, 4, 100, 3),
-                                      (36, 5, 50, 2)])
+                                      (36, 5, 50, 2), (64, 3, 100, 3), (64, 4, 70, 2), (60, 5, 50, 2), (64, 6, 129, 2)])
 def test_derivative_kernel_with_one_wave_per_batch_matches_the_shared_batch_kernel(g, ref, N, L, N_T, K, monkeypatch):
     """Hermitian operators, 32 < N <= 64, L <= 2 (N <= 48: L <= 5): deriv3_kernel (grape_deriv3.hip.h: one wave per batch of 16 cells, operators
-    as upper-triangle tiles in LDS, mirrored tiles through the negation bit of the matrix instruction) against deriv2_kernel
+    as upper-triangle tiles in LDS, mirrored tiles through the negation bit of the matrix instruction; at four tiles per
+    side the assembly kernels of asm/gen_d3.py and, for three to eight controls, asm/gen_d3s.py) against deriv2_kernel
     (GRAPE_DERIV3=0) on the same inputs -- same series, same stopping rule, the additions of a cell in the same order: equal
     to rounding; and both against the C restatement on the first steps.  Shapes: a last batch with unused columns, padded
     sizes (60 -> 64, 40 -> 48), more trajectories than workgroups, several workgroups per trajectory, shaped amplitudes."""
@@ -834,7 +835,10 @@ def test_derivative_kernel_with_one_wave_per_batch_matches_the_shared_batch_kern
             monkeypatch.delenv(k)
     assert res["d3"][0] == res["d2"][0] and np.array_equal(res["d3"][2], res["d2"][2])       # the sweeps are the same code
     assert np.abs(res["d3"][1] - res["d2"][1]).max() <= 1e-13 * max(np.abs(res["d2"][1]).max(), 1e-3)
-    assert res["d3"][3]["deriv_orders"] == res["d2"][3]["deriv_orders"] > 0                    # same stopping decisions
+    if N > 48 and L > 2:     # streamed controls: the four batches of a workgroup stop together (never earlier than each alone)
+        assert res["d2"][3]["deriv_orders"] <= res["d3"][3]["deriv_orders"] <= res["d2"][3]["deriv_orders"] + K * N_T
+    else:
+        assert res["d3"][3]["deriv_orders"] == res["d2"][3]["deriv_orders"] > 0                # same stopping decisions
     ns = 10
     xs = pr["pulsevals"].reshape(L, N_T)[:, :ns].reshape(-1)
     Ks = min(K, 3)
