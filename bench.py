@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--nonhermitian", action="store_true",
                     help="the same shape with non-Hermitian generators (Liouvillian-like; secondary lines in profiles/)")
+    ap.add_argument("--nonhermitian-controls", action="store_true",
+                    help="with --nonhermitian: the control operators are general matrices as well (secondary line)")
     ap.add_argument("--dt", type=float, default=None,
                     help="time step of the synthetic grid instead of 1.0 (secondary lines: the cells leave the range of the "
                          "four-product exponential at dt ~ 1.2 and need a squaring beyond dt ~ 1.7)")
@@ -170,6 +172,10 @@ def main():
     K_local = args.traj_per_gpu or per_gpu_default.get(args.config, K0)
     K_total = K_local * world
     pr = synth.make_config(args.config, K=K_local, k_offset=rank * K_local, hermitian=not args.nonhermitian)
+    if args.nonhermitian_controls:
+        import numpy as _np
+        _rng = _np.random.default_rng(synth.BASE_SEED + 77)
+        pr["Hc"] = pr["Hc"] + 0.1 * (_rng.normal(size=pr["Hc"].shape) + 1j * _rng.normal(size=pr["Hc"].shape)) / _np.sqrt(N)
     if args.dt is not None:
         pr["tlist"] = pr["tlist"] * args.dt
     h = g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"],
@@ -324,7 +330,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: N={N}, L={L} controls, N_T={N_T} time steps, "
                                    f"{K_local} trajectories per GPU ({K_total} total), J_T_sm, ExpProp"
-                                   + (", NON-HERMITIAN generators" if args.nonhermitian else ""),
+                                   + (", NON-HERMITIAN generators" if args.nonhermitian else "")
+                                   + (" (general control operators too)" if args.nonhermitian_controls else ""),
                        "gradient_method": "gradgen (exact derivative via the series of the gradient-generator "
                                           "propagator on the extended state)",
                        "one_eval": f"one shard evaluation = functional + full gradient of {K_local} trajectories; "

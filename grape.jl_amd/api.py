@@ -61,7 +61,7 @@ def build_asm(verbose: bool = False) -> str:
     """Generate, assemble and wrap the hand-allocated gfx950 kernels (csrc/asm/gen_t16.py, gen_d3.py): .s -> one code object
     -> an object file that carries the code object as bytes (grape_asm_co_start / _end), linked into the library."""
     asm_dir = os.path.join(_CSRC, "asm")
-    kernels = (("gen_t16.py", "expm_t16_asm"), ("gen_d3.py", "deriv3_asm"), ("gen_d3s.py", "deriv3s_asm"),
+    kernels = (("gen_t16.py", "expm_t16_asm"), ("gen_d3.py", "deriv3_asm"), ("gen_d3s.py", "deriv3s_asm"), ("gen_d3s.py", "deriv3g_asm"),
                ("gen_lg.py", "lg_gemm_asm"))
     co_path, emb_s, emb_o = os.path.join(asm_dir, "grape_asm.co"), os.path.join(asm_dir, "asm_embed.S"), os.path.join(asm_dir, "asm_embed.o")
     llvm = "/opt/rocm/lib/llvm/bin"

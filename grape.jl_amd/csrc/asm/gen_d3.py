@@ -231,10 +231,14 @@ class GenD3:
                 p.label(lab)
 
     # ---------------------------------------------------------------------------------------------------------------
+    def mir(self, rt, kt):
+        """the left-operand tile (rt, kt) is read as the conjugate transpose of the stored tile (kt, rt)"""
+        return rt > kt
+
     def frag_read(self, op, pl, rt, kt, r):
         """request fragment (row tile rt, k-step (kt, r)) of plane pl of operator op"""
         dst = (self.f_re if pl == 0 else self.f_im)[rt]
-        if rt <= kt:
+        if not self.mir(rt, kt):
             self.p.ds_read(64, dst, self.v_BD[op], tile_index(rt, kt) * 2 * TILE_B + pl * TILE_B + 32 * r)
         else:
             self.p.ds_read(64, dst, self.v_BM[op], tile_index(kt, rt) * 2 * TILE_B + pl * TILE_B + 4 * r * LDT * 8)
@@ -258,7 +262,7 @@ class GenD3:
                 more = not (kt == 3 and r == 3)
                 nkt, nr = (kt, r + 1) if r < 3 else (kt + 1, 0)
                 for rt in range(4):      # operand sums of the 3M scheme: re + im, mirrored tiles (conjugated): re - im
-                    p.valu("v_add_f64", self.f_as[rt], self.f_re[rt], self.f_im[rt] if rt <= kt else Neg(self.f_im[rt]))
+                    p.valu("v_add_f64", self.f_as[rt], self.f_re[rt], Neg(self.f_im[rt]) if self.mir(rt, kt) else self.f_im[rt])
                 for rt in range(4):
                     p.mfma(self.P[0][rt], self.f_re[rt], self.VEC[0][kt].d(r), 0 if first else self.P[0][rt])
                     if hook and rt == 0:
@@ -267,7 +271,7 @@ class GenD3:
                     for rt in range(4):
                         self.frag_read(op, 0, rt, nkt, nr)
                 for rt in range(4):
-                    p.mfma(self.P[1][rt], self.f_im[rt], self.VEC[1][kt].d(r), 0 if first else self.P[1][rt], neg_a=rt > kt)
+                    p.mfma(self.P[1][rt], self.f_im[rt], self.VEC[1][kt].d(r), 0 if first else self.P[1][rt], neg_a=self.mir(rt, kt))
                 if more:
                     for rt in range(4):
                         self.frag_read(op, 1, rt, nkt, nr)

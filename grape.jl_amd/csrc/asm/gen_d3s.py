@@ -46,9 +46,15 @@ def piece_table():
 
 
 class GenD3S(GenD3):
+    OP_B, NSLOT, AHEAD, LACC, NPIECE = OP_B, NSLOT, 2, LMAX_S, 10     # Hermitian operators: upper tiles, three slots, two steps ahead
+    general = False
+
     def __init__(self, name="deriv3s_asm", opts=None):
         super().__init__(name=name, LMAX=2, opts=opts)
-        self.lds_bytes = LDS_BYTES
+        self.FLAGS = self.NSLOT * self.OP_B
+        self.ACC = self.FLAGS + 64
+        self.lds_bytes = self.ACC + 4 * self.LACC * 1024
+        self.adjoint = False                     # general operators: pass 2 applies H^dagger
         # scalars (beyond GenD3's): piece offsets of this wave, ring state
         self.s_src = S(0, 2)                     # source of the operator being fetched (the kernel argument pointer is dead by then)
         self.s_sd = S(3)                         # LDS base of the slot being filled
@@ -120,18 +126,12 @@ class GenD3S(GenD3):
         p.valu("v_lshlrev_b32", self.v_poff, 8, vrg)
         p.valu("v_lshl_add_u32", self.v_poff, vc, 4, self.v_poff)
         p.s_waitcnt(lgkm=0)
-        # private accumulators: ACC + wave 8192 + lane 16
-        p.salu("s_lshl_b32", self.s_t[0], self.s_wave, 13)
-        p.salu("s_add_u32", self.s_t[0], self.s_t[0], ACC)
+        # private accumulators: ACC + wave (LACC KB) + lane 16
+        p.salu("s_mul_i32", self.s_t[0], self.s_wave, self.LACC * 1024)
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.ACC)
         p.valu("v_lshlrev_b32", self.v_acc, 4, self.v_lane)
         p.valu("v_add_u32", self.v_acc, self.s_t[0], self.v_acc)
-        # this wave's ten pieces of every operator: p = 10 wave + q; their source offsets from the table behind 1 / m
-        p.salu("s_mul_i32", self.s_wb, self.s_wave, 10 * 1024)
-        p.salu("s_mul_i32", self.s_t[0], self.s_wave, 40)
-        p.salu("s_add_u32", self.s_t[0], self.s_t[0], INV_TABLE * 8)
-        self.add64(self.s_a, self.s_inv, self.s_t[0])
-        p.s_load(8, S(92, 8), self.s_a, 0)
-        p.s_load(2, S(100, 2), self.s_a, 32)
+        self.piece_setup()
         # parking area of this wave
         wg = S(2)
         p.salu("s_lshl_b32", self.s_t[0], wg, 2)
@@ -142,6 +142,16 @@ class GenD3S(GenD3):
         self.add64(self.s_pw, self.s_park, self.s_b.sub(0), self.s_b.sub(1))
         p.salu("s_mov_b32", self.s_slot, wg)
         p.s_waitcnt(lgkm=0)
+
+    def piece_setup(self):
+        """this wave's ten pieces of every operator: p = 10 wave + q; their source offsets from the table behind 1 / m"""
+        p = self.p
+        p.salu("s_mul_i32", self.s_wb, self.s_wave, 10 * 1024)
+        p.salu("s_mul_i32", self.s_t[0], self.s_wave, 40)
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], INV_TABLE * 8)
+        self.add64(self.s_a, self.s_inv, self.s_t[0])
+        p.s_load(8, S(92, 8), self.s_a, 0)
+        p.s_load(2, S(100, 2), self.s_a, 32)
 
     # ---- the operator ring -------------------------------------------------------------------------------------------
     def op_source(self, c_reg):
@@ -173,6 +183,13 @@ class GenD3S(GenD3):
         p.salu("s_add_u32", M0, self.s_t[4], q * 1024)
         p.global_load_lds(self.v_goff[q & 1], self.s_a)
 
+    def pieces_at(self, ks):
+        """the DMA requests issued behind the first matrix instruction of k-step ks: one step ahead (two slots) they must
+        be out early -- the wait at the next step's top is for the LAST of them; two steps ahead one per k-step will do"""
+        per = 2 if self.AHEAD == 1 else 1
+        for q in range(per * ks, min(per * ks + per, self.NPIECE)):
+            self.piece(q)
+
     def advance(self, c_out, r_out, c_in, r_in, by):
         """(c, r) advanced by `by` steps: c modulo 1 + L, r modulo 3"""
         p = self.p
@@ -183,8 +200,8 @@ class GenD3S(GenD3):
         p.salu("s_cselect_b32", self.s_t[6], self.s_t[5], 0)
         p.salu("s_sub_u32", c_out, c_out, self.s_t[6])
         p.salu("s_add_u32", r_out, r_in, by)
-        p.s_cmp("s_cmp_ge_u32", r_out, NSLOT)
-        p.salu("s_cselect_b32", self.s_t[6], NSLOT, 0)
+        p.s_cmp("s_cmp_ge_u32", r_out, self.NSLOT)
+        p.salu("s_cselect_b32", self.s_t[6], self.NSLOT, 0)
         p.salu("s_sub_u32", r_out, r_out, self.s_t[6])
 
     def step_top(self):
@@ -193,10 +210,10 @@ class GenD3S(GenD3):
         p = self.p
         p.s_waitcnt(vm=0, lgkm=0)
         p.s_barrier()
-        self.advance(self.s_t[2], self.s_t[3], self.s_c, self.s_r, 2)
-        p.salu("s_mul_i32", self.s_sd, self.s_t[3], OP_B)
+        self.advance(self.s_t[2], self.s_t[3], self.s_c, self.s_r, self.AHEAD)
+        p.salu("s_mul_i32", self.s_sd, self.s_t[3], self.OP_B)
         self.op_source(self.s_t[2])
-        p.salu("s_mul_i32", self.s_t[0], self.s_r, OP_B)
+        p.salu("s_mul_i32", self.s_t[0], self.s_r, self.OP_B)
         for r in range(4):
             p.valu("v_add_u32", self.v_BDd[r], self.s_t[0], self.v_BDs[r])
             p.valu("v_add_u32", self.v_BMd[r], self.s_t[0], self.v_BMs[r])
@@ -209,11 +226,11 @@ class GenD3S(GenD3):
         p = self.p
         p.s_waitcnt(lgkm=0)
         p.s_barrier()
-        for c in range(2):
+        for c in range(self.AHEAD):
             p.salu("s_mov_b32", self.s_t[2], c)
-            p.salu("s_mov_b32", self.s_sd, c * OP_B)
+            p.salu("s_mov_b32", self.s_sd, c * self.OP_B)
             self.op_source(self.s_t[2])
-            for q in range(10):
+            for q in range(self.NPIECE):
                 self.piece(q)
         p.salu("s_mov_b32", self.s_c, 0)
         p.salu("s_mov_b32", self.s_r, 0)
@@ -221,10 +238,13 @@ class GenD3S(GenD3):
     # ---- products ----------------------------------------------------------------------------------------------------
     def frag_read(self, op, pl, rt, kt, r):
         dst = (self.f_re if pl == 0 else self.f_im)[rt]
-        if rt <= kt:
-            self.p.ds_read(64, dst, self.v_BDd[r], tile_index(rt, kt) * 4096 + pl * 2048)
+        if not self.mir(rt, kt):
+            self.p.ds_read(64, dst, self.v_BDd[r], self.tile(rt, kt) * 4096 + pl * 2048)
         else:
-            self.p.ds_read(64, dst, self.v_BMd[r], tile_index(kt, rt) * 4096 + pl * 2048)
+            self.p.ds_read(64, dst, self.v_BMd[r], self.tile(kt, rt) * 4096 + pl * 2048)
+
+    def tile(self, ti, tj):
+        return tile_index(ti, tj)
 
     def combine_s(self, h0, overlap=None):
         """q = (p1 - p2, p3 - p1 - p2); H0: sum = q; control: [overlap] and sum += e q"""
@@ -274,8 +294,7 @@ class GenD3S(GenD3):
         p = self.p
 
         def hook(ks):
-            if ks < 10:
-                self.piece(ks)
+            self.pieces_at(ks)
             if uload:
                 t, r = divmod(ks, 4)
                 p.global_load(4, self.ULAND.sub(4 * ks, 4), self.v_poff, self.s_pb[t], r * 1024)
@@ -291,7 +310,7 @@ class GenD3S(GenD3):
         p.label(f"L_ctl_{tag}")
         self.step_top()
         self.load_e()
-        self.product(1, lambda ks: self.piece(ks) if ks < 10 else None)
+        self.product(1, self.pieces_at)
         p.valu("v_mul_f64", self.v_ecur, self.v_ecur, self.v_shcur)
         self.combine_s(False, overlap)
         self.step_end()
@@ -364,6 +383,7 @@ class GenD3S(GenD3):
                         p.global_store(4, self.v_poff, x, self.s_pb[t], r * 1024)
 
         # ================= pass 1 =====================================================================================
+        self.adjoint = False
         load_block(self.v_fwoff, self.s_fwb, None, True)
         p.salu("s_mov_b32", self.s_m, 1)
         p.salu("s_mov_b32", self.s_myconv, 0)
@@ -376,7 +396,7 @@ class GenD3S(GenD3):
         p.salu("s_add_u32", self.s_t[0], self.s_m, 1)       # parity of m - 1
         p.salu("s_and_b32", self.s_t[0], self.s_t[0], 1)
         p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 5)
-        p.salu("s_add_u32", self.s_t[0], self.s_t[0], FLAGS)
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.FLAGS)
         p.valu("v_mov_b32", self.TMP[1].sub(0), self.s_t[0])
         p.ds_read(128, fl.sub(0, 4), self.TMP[1].sub(0))
         p.ds_read(128, fl.sub(4, 4), self.TMP[1].sub(0), 16)
@@ -424,7 +444,7 @@ class GenD3S(GenD3):
         p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 5)
         p.salu("s_lshl_b32", self.s_t[1], self.s_wave, 3)
         p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.s_t[1])
-        p.salu("s_add_u32", self.s_t[0], self.s_t[0], FLAGS)
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.FLAGS)
         p.valu("v_mov_b32", self.TMP[1].sub(0), self.s_t[0])
         p.valu("v_mov_b32", self.TMP[1].sub(1), self.s_myconv)
         p.salu("s_mov_b64", self.s_save, EXEC)
@@ -437,11 +457,12 @@ class GenD3S(GenD3):
         p.salu("s_sub_u32", self.s_M, self.s_m, 1)
 
         # ================= pass 2 =====================================================================================
+        self.adjoint = True
         load_block(self.v_bwoff, self.s_bwb, self.CHI, False)
         z = self.TMP[2].sub(0, 4)
         for i in range(4):
             p.valu("v_mov_b32", z.sub(i), 0)
-        for l in range(LMAX_S):
+        for l in range(self.LACC):
             p.ds_write(128, self.v_acc, z, l * 1024)
         p.salu("s_sub_u32", self.s_m, self.s_M, 1)           # aa
         p.s_branch("s_branch", "L_pass2_entry")
@@ -615,8 +636,42 @@ class GenD3S(GenD3):
         return p
 
 
-def generate(path=None, **kw):
-    g = GenD3S(**kw)
+class GenD3G(GenD3S):
+    """General (non-Hermitian) drift and / or control operators: ALL sixteen tiles of an operator (64 KB) in a ring of two
+    slots, one step ahead; pass 1 reads every tile directly, pass 2 applies the adjoint -- every tile transposed, conjugated
+    through the negation bit of the matrix instruction and the sign of the operand sum (reference: the adjoint generator of
+    the backward propagation, /root/reference/src/optimize.jl:868-874).  Up to seven controls (the LDS left beside the ring
+    holds the accumulators of seven)."""
+    OP_B, NSLOT, AHEAD, LACC, NPIECE = 16 * 4096, 2, 1, 7, 16
+    general = True
+
+    def __init__(self, name="deriv3g_asm", opts=None):
+        super().__init__(name=name, opts=opts)
+        self.s_wsrc = self.s_poffs[0]            # wave * 8192: row tile `wave` of the source (no piece table: all tiles exist)
+
+    def mir(self, rt, kt):
+        return self.adjoint
+
+    def tile(self, ti, tj):
+        return ti * NT + tj
+
+    def piece_setup(self):
+        # this wave's sixteen pieces of every operator: row tile ti = wave; q -> column tile q >> 2, plane (q >> 1) & 1, half q & 1
+        p = self.p
+        p.salu("s_mul_i32", self.s_wb, self.s_wave, 16 * 1024)
+        p.salu("s_lshl_b32", self.s_wsrc, self.s_wave, 13)
+
+    def piece(self, q):
+        p = self.p
+        self.add64(self.s_a, self.s_src, self.s_wsrc)
+        self.add64(self.s_a, self.s_a, (q >> 2) * 128 + ((q >> 1) & 1) * NP * NP * 8)
+        p.salu("s_add_u32", self.s_t[4], self.s_sd, self.s_wb)
+        p.salu("s_add_u32", M0, self.s_t[4], q * 1024)
+        p.global_load_lds(self.v_goff[q & 1], self.s_a)
+
+
+def generate(path=None, general=False, **kw):
+    g = (GenD3G if general else GenD3S)(**kw)
     prog = g.build()
     text = kernel_text(prog, KERNARG, g.lds_bytes, n_sgpr=102)
     if path:
@@ -627,6 +682,6 @@ def generate(path=None, **kw):
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "deriv3s_asm.s")
-    g, prog, _ = generate(out)
+    g, prog, _ = generate(out, general="deriv3g" in os.path.basename(out))
     print(f"{out}: {len(prog.ins)} lines, {prog.count('mfma')} matrix instructions, {prog.count('valu')} vector, "
           f"{prog.count('lds')} LDS, {prog.count('vmem')} global, {prog.auto_nops} wait states inserted")

@@ -26,7 +26,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gcn import Prog, Reg, V, A, S, VCC, EXEC, M0, Neg, kernel_text  # noqa: E402
 
-KERNARG = 144
+KERNARG = 152
 STAGE_B = 32768                  # one k-block of the left operand: [re | im][64 rows][32 columns]
 LDS_BYTES = 2 * STAGE_B
 KSTEPS = 8                       # k-steps (of 4) per k-block
@@ -41,7 +41,8 @@ class GenLG:
         self.s_X, self.s_Y, self.s_C, self.s_C2, self.s_A0, self.s_A1, self.s_U, self.s_smax = (S(4 + 2 * i, 2) for i in range(8))
         self.s_coef = [S(20, 2), S(22, 2)]
         self.s_coef2 = [S(24, 2), S(26, 2)]
-        self.s_NP, self.s_NB, self.s_ncell, self.s_herm, self.s_nadd, self.s_uif, self.s_percell = (S(32 + i) for i in range(7))
+        self.s_NP, self.s_NB, self.s_ncell, self.s_herm, self.s_nadd, self.s_uif, self.s_percell, self.s_mpc = (S(32 + i) for i in range(8))
+        self.s_mnb = S(90)                       # reciprocals (floor(2^32 / d) + 1) of per_cell and NB: quotients by one multiplication
         self.s_cell, self.s_bi, self.s_bj, self.s_useu = S(40), S(41), S(42), S(43)
         self.s_xp, self.s_yp, self.s_yq = S(44, 2), S(46, 2), S(48, 2)
         self.s_ldsw, self.s_rowstep, self.s_kb, self.s_nkb = S(50), S(51), S(52), S(53)
@@ -84,26 +85,12 @@ class GenLG:
         self.p.salu("s_mul_hi_u32", dst.sub(1), a, b)
         self.p.salu("s_mul_i32", dst.sub(0), a, b)
 
-    def udiv(self, q, r, num, den, tag):
+    def udiv(self, q, r, num, den, magic):
+        """q, r = num / den, num % den for num < 2^24 (den <= 16): q = mulhi(num, floor(2^32 / den) + 1)"""
         p = self.p
-        i, t = self.s_t[6], self.s_t[7]
-        p.salu("s_mov_b32", q, 0)
-        p.salu("s_mov_b32", r, 0)
-        p.salu("s_mov_b32", i, 31)
-        p.label(f"L_div_{tag}")
-        p.salu("s_lshl_b32", r, r, 1)
-        p.salu("s_lshr_b32", t, num, i)
-        p.salu("s_and_b32", t, t, 1)
-        p.salu("s_or_b32", r, r, t)
-        p.s_cmp("s_cmp_ge_u32", r, den)
-        p.s_branch("s_cbranch_scc0", f"L_div_skip_{tag}")
-        p.salu("s_sub_u32", r, r, den)
-        p.salu("s_lshl_b32", t, 1, i)
-        p.salu("s_or_b32", q, q, t)
-        p.label(f"L_div_skip_{tag}")
-        p.salu("s_sub_u32", i, i, 1)
-        p.s_cmp("s_cmp_ge_i32", i, 0)
-        p.s_branch("s_cbranch_scc1", f"L_div_{tag}")
+        p.salu("s_mul_hi_u32", q, num, magic)
+        p.salu("s_mul_i32", self.s_t[7], q, den)
+        p.salu("s_sub_u32", r, num, self.s_t[7])
 
     # ---------------------------------------------------------------------------------------------------------------
     def prologue(self):
@@ -112,6 +99,7 @@ class GenLG:
         p.s_load(8, S(20, 8), S(0, 2), 64)
         p.s_load(4, S(28, 4), S(0, 2), 96)
         p.s_load(8, S(32, 8), S(0, 2), 112)
+        p.s_load(2, S(90, 2), S(0, 2), 144)
         p.valu("v_and_b32", self.v_tid, 0x3FF, V(0))
         p.valu("v_and_b32", self.v_lane, 63, self.v_tid)
         t = self.T
@@ -126,7 +114,7 @@ class GenLG:
         wg = S(2)
         p.salu("s_and_b32", self.s_t[0], wg, 7)
         p.salu("s_lshr_b32", self.s_t[1], wg, 3)
-        self.udiv(self.s_t[2], self.s_t[3], self.s_t[1], self.s_percell, "pc")
+        self.udiv(self.s_t[2], self.s_t[3], self.s_t[1], self.s_percell, self.s_mpc)
         p.salu("s_lshl_b32", self.s_cell, self.s_t[2], 3)
         p.salu("s_add_u32", self.s_cell, self.s_cell, self.s_t[0])
         p.s_cmp("s_cmp_ge_u32", self.s_cell, self.s_ncell)
@@ -146,7 +134,7 @@ class GenLG:
         p.salu("s_add_u32", self.s_bj, self.s_bi, self.s_t[3])
         p.s_branch("s_branch", "L_have_block")
         p.label("L_full")
-        self.udiv(self.s_bi, self.s_bj, self.s_t[3], self.s_NB, "nb")
+        self.udiv(self.s_bi, self.s_bj, self.s_t[3], self.s_NB, self.s_mnb)
         p.label("L_have_block")
         # the result goes to U (interleaved) when there is one -- and, last product of the route, no cell needs a squaring
         p.s_cmp("s_cmp_lg_u64", self.s_U, 0)

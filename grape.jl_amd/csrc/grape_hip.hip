@@ -50,6 +50,7 @@ struct grape_handle {
     double *d_park3 = nullptr;
     int deriv3_blocks = 0, deriv3_wpt = 0;
     bool deriv3_h0g = false;     // general drift beside Hermitian control operators (all tiles of H0_k in LDS)
+    bool deriv3_general = false; // general operators at four tiles per side: the streamed assembly kernel with all tiles
     int deriv2 = 0, deriv2_maxm = 0;
     bool deriv_stream = false;   // GRAPE_DERIV_STREAM=1: matrix-at-a-time products in deriv2_kernel for 3-4 controls as well
     bool deriv_stream_never = false;   // GRAPE_DERIV_STREAM=0: the all-at-once form for more than four controls too (A/B timing)
@@ -638,9 +639,11 @@ struct LgAsmArgs {
     double2 *Uout;
     const int *smax_ptr;
     double coef[2], coef2[2], cI, cI2;
-    int NP, NB, ncell, herm, nadd, u_if_smax0, per_cell, pad;
+    int NP, NB, ncell, herm, nadd, u_if_smax0, per_cell;
+    unsigned magic_pc, magic_nb;   // floor(2^32 / d) + 1 of per_cell and NB: the kernel divides by one multiplication
+    int pad;
 };
-static_assert(sizeof(LgAsmArgs) == 144, "argument block of lg_gemm_asm");
+static_assert(sizeof(LgAsmArgs) == 152, "argument block of lg_gemm_asm");
 bool lg_asm_enabled() {
     const char *e = getenv("GRAPE_LG_ASM");   // (read at every launch: the differential tests switch it between evaluations)
     return !(e && atoi(e) == 0);
@@ -668,7 +671,10 @@ bool lg_try_asm(hipStream_t s, const LgGemmArgs &a, hipError_t *err) {
     for (int i = 0; i < a.nadd; ++i) { k.coef[i] = a.coef[i]; k.coef2[i] = a.coef2[i]; }
     k.NP = NP; k.NB = NB; k.ncell = a.ncell; k.herm = a.herm; k.nadd = a.nadd; k.u_if_smax0 = a.u_if_smax0;
     k.per_cell = a.herm ? NB * (NB + 1) / 2 : NB * NB;
+    k.magic_pc = (unsigned)((1ull << 32) / (unsigned)k.per_cell + 1);
+    k.magic_nb = (unsigned)((1ull << 32) / (unsigned)NB + 1);
     const int groups = (a.ncell + 7) / 8;
+    if ((long)groups * 8 * k.per_cell >= (1L << 24)) return false;
     *err = (hipError_t)grape_lg_asm_launch(&k, sizeof(k), (unsigned)(groups * 8 * k.per_cell), (void *)s);
     return true;
 }
@@ -1352,7 +1358,13 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                 // streams them through it (asm/gen_d3s.py; GRAPE_DERIV3S=0: deriv2_kernel's STREAM_L form, the twin)
                 const char *env3s = getenv("GRAPE_DERIV3S");
                 const bool streamed = h->herm && h->NT == 4 && L > 2 && L <= 8 && !(env3s && atoi(env3s) == 0);
-                if ((h->herm || h->deriv3_h0g) && !h->large && !h->series && (deriv3_fits(h->NT, L, h->deriv3_h0g) || streamed) && !(env3 && atoi(env3) == 0)) {
+                // four tiles per side, general drift and / or general control operators (up to seven controls): all tiles of
+                // every operator stream through the LDS and pass 2 applies the adjoint (asm/gen_d3s.py GenD3G;
+                // GRAPE_DERIV3G=0: deriv3_kernel's H0G form where it applies, else deriv2_kernel)
+                const char *env3g = getenv("GRAPE_DERIV3G");
+                h->deriv3_general = !h->herm && h->NT == 4 && L <= 7 && !(env3g && atoi(env3g) == 0);
+                if ((h->herm || h->deriv3_h0g || h->deriv3_general) && !h->large && !h->series
+                    && (deriv3_fits(h->NT, L, h->deriv3_h0g) || streamed || h->deriv3_general) && !(env3 && atoi(env3) == 0)) {
                     // workgroups per trajectory: as many as it takes to put a workgroup on every CU, at most one per four batches
                     const int bpk = (N_T + 15) / 16;
                     h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
@@ -1880,7 +1892,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
 #endif
         if (h->d_park3 && !d2.gpark) {
             d2.park = h->d_park3;
-            e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, h->deriv3_h0g ? 1 : 0, (void *)s, h->deriv3_blocks);
+            e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, h->deriv3_general ? 2 : (h->deriv3_h0g ? 1 : 0), (void *)s, h->deriv3_blocks);
         } else
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);
     } else if (h->NP >= 48) {

@@ -49,7 +49,7 @@ hipError_t launch_d3(const Deriv3Args &a, hipStream_t s, int blocks) {
 }
 }  // namespace
 
-namespace { hipError_t launch_d3_asm(const Deriv3Args &a, hipStream_t s, int blocks); }
+namespace { hipError_t launch_d3_asm(const Deriv3Args &a, hipStream_t s, int blocks, bool general = false); }
 
 // derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators whose upper tiles fit the LDS
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
@@ -61,6 +61,10 @@ extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, co
     hipStream_t s = (hipStream_t)stream;
     const int L = a.d.L;
     if (L < 1 || L > 8) return (int)hipErrorInvalidValue;
+    if (h0_general == 2) {   // general operators at four tiles per side: the streamed assembly kernel with all tiles
+        if (NT != 4 || skip_if_flagged || a.d.gpark) return (int)hipErrorInvalidValue;
+        return (int)launch_d3_asm(a, s, blocks, true);
+    }
     if (h0_general) {   // general drift, Hermitian controls: three and four tiles per side, up to two controls
         if (L > 2) return (int)hipErrorInvalidValue;
         if (NT == 3) return (int)(L == 1 ? launch_d3<3, 1, true>(a, s, blocks) : launch_d3<3, 2, true>(a, s, blocks));
@@ -207,11 +211,11 @@ __global__ void __launch_bounds__(256) t16_credit_kernel(ExpmArgs a) {
 constexpr int D3_INV_TABLE = 2048;
 struct AsmModule {
     hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr;
+    hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr, fn_d3g = nullptr;
     double *inv = nullptr;      // 1 / m, m < D3_INV_TABLE
 };
 hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr,
-                        hipFunction_t *fn_d3s = nullptr, hipFunction_t *fn_lg = nullptr) {
+                        hipFunction_t *fn_d3s = nullptr, hipFunction_t *fn_lg = nullptr, hipFunction_t *fn_d3g = nullptr) {
     static AsmModule mods[64];
     static std::mutex mtx;
     std::lock_guard<std::mutex> lock(mtx);
@@ -224,6 +228,8 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         e = hipModuleGetFunction(&m.fn_d3s, m.mod, "deriv3s_asm");
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn_lg, m.mod, "lg_gemm_asm");
+        if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn_d3g, m.mod, "deriv3g_asm");
         if (e != hipSuccess) return e;
         // 1 / m for the series orders (the kernels read them with scalar loads; gfx9 has no scalar floating point); behind
         // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
@@ -247,6 +253,7 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
     if (fn_d3) *fn_d3 = m.fn_d3;
     if (fn_d3s) *fn_d3s = m.fn_d3s;
     if (fn_lg) *fn_lg = m.fn_lg;
+    if (fn_d3g) *fn_d3g = m.fn_d3g;
     if (inv) *inv = m.inv;
     return hipSuccess;
 }
@@ -269,18 +276,19 @@ struct D3AsmArgs {            // kernel argument block of deriv3_asm (gen_d3.py:
 };
 static_assert(sizeof(D3AsmArgs) == 160, "argument block of the assembly kernel");
 
-hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks) {
+hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks, bool general) {
     const Deriv2Args &a = g.d;
-    if (a.L < 1 || a.L > 8 || blocks < 1 || a.maxm + 2 > D3_INV_TABLE) return hipErrorInvalidValue;
+    if (a.L < 1 || a.L > (general ? 7 : 8) || blocks < 1 || a.maxm + 2 > D3_INV_TABLE) return hipErrorInvalidValue;
     if ((long)a.N_T + 1 >= (1L << 21) || (long)a.K * a.L * a.N_T >= (1L << 27)) return hipErrorInvalidValue;   // (32-bit offsets in the kernel)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    hipFunction_t fn, fn_s;
+    hipFunction_t fn, fn_s, fn_g;
     const double *inv;
-    e = asm_function(dev, nullptr, &fn, &inv, &fn_s);
+    e = asm_function(dev, nullptr, &fn, &inv, &fn_s, nullptr, &fn_g);
     if (e != hipSuccess) return e;
     if (a.L > 2) fn = fn_s;     // more than two controls: the operators stream through the LDS (asm/gen_d3s.py)
+    if (general) fn = fn_g;     // general operators: all tiles, streamed; pass 2 applies the adjoint
     D3AsmArgs k{};
     k.H0f = g.H0f; k.Hcf = g.Hcf; k.eps = a.eps; k.shape = a.shape; k.dts = a.dts; k.fw = a.fw; k.bw = a.bw; k.rho = a.rho;
     k.tg = a.tg; k.park = a.park; k.flags = a.flags; k.stats = a.stats; k.batch_flag = a.batch_flag; k.inv = inv;
@@ -297,17 +305,17 @@ hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks) {
 }
 }  // namespace
 
-// batched complex block product of the blocked path (asm/gen_lg.py): `k` is the 144-byte argument block of lg_gemm_asm,
+// batched complex block product of the blocked path (asm/gen_lg.py): `k` is the 152-byte argument block of lg_gemm_asm,
 // filled by the caller (grape_hip.hip: lg_asm_args), one workgroup per 64 x 64 output block
 extern "C" int grape_lg_asm_launch(const void *k, size_t size, unsigned blocks, void *stream) {
-    if (size != 144 || blocks == 0) return (int)hipErrorInvalidValue;
+    if (size != 152 || blocks == 0) return (int)hipErrorInvalidValue;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     hipFunction_t fn;
     e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, &fn);
     if (e != hipSuccess) return (int)e;
-    unsigned char buf[144];
+    unsigned char buf[152];
     memcpy(buf, k, sizeof(buf));
     size_t sz = sizeof(buf);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

@@ -29,12 +29,14 @@ def planar(H):
     return np.stack([np.stack([h.real, h.imag]) for h in H]).astype(np.float64)
 
 
-def make_inputs(N, K, L, N_T, seed, hc_per_traj=False, shape=False, dt_scale=1.0):
+def make_inputs(N, K, L, N_T, seed, hc_per_traj=False, shape=False, dt_scale=1.0, general=False):
     rng = np.random.default_rng(seed)
 
     def herm(s):
         X = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
         H = (X + X.conj().T) / (4 * np.sqrt(N)) * s
+        if general:     # a non-Hermitian part of a third of the size
+            H = H + (rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))) / (12 * np.sqrt(N)) * s
         P = np.zeros((NP, NP), complex)
         P[:N, :N] = H
         return P
@@ -133,9 +135,9 @@ def series_reference(d, mcap=40, tol=1e-16, group_wpt=None):
                 D = np.zeros(L, complex)
                 for a in range(M - 1, -1, -1):
                     for l in range(L):
-                        D[l] += np.vdot(mu[l] @ w, us[n][a]) / (a + 1)      # <mu_l^dagger w | u_a>, mu Hermitian
+                        D[l] += np.vdot(mu[l].conj().T @ w, us[n][a]) / (a + 1)      # <mu_l^dagger w | u_a>
                     if a > 0:
-                        w = chi + 1j * d["dts"][n] / (a + 1) * (Hs[n] @ w)
+                        w = chi + 1j * d["dts"][n] / (a + 1) * (Hs[n].conj().T @ w)
                 for l in range(L):
                     tg[k, l, n] = d["rho"][k] * (-1j * d["dts"][n] * sh[l]) * D[l]
     return tg, orders
@@ -243,3 +245,25 @@ def test_streamed_kernel_flags_a_series_that_does_not_converge(program_s):
     _, flags, stats, _ = run_kernel(prog, d, 1, 1, mcap=6, lds_bytes=gen_d3s.LDS_BYTES)
     assert flags[0] == 4 and flags[7] == 0
     assert int(stats[:, 8].sum()) == 6 * 5
+
+
+# ---- general (non-Hermitian) operators: all tiles in a ring of two slots, pass 2 applies the adjoint (GenD3G) ----
+@pytest.fixture(scope="module")
+def program_g():
+    return gen_d3s.generate(general=True)
+
+
+@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 1, 2, 37, 1, 1, False, False), (50, 2, 3, 20, 3, 2, True, True)])
+def test_general_operator_kernel_matches_the_series_and_the_frechet_derivative(program_g, N, K, L, N_T, nblk, wpt, hcpt, shape):
+    g_, prog, _ = program_g
+    assert gcn.check_hazards(prog) == 0 and g_.lds_bytes <= 160 * 1024
+    d = make_inputs(N, K, L, N_T, seed=N + L, hc_per_traj=hcpt, shape=shape, general=True)
+    tg, flags, stats, info = run_kernel(prog, d, nblk, wpt, lds_bytes=g_.lds_bytes)
+    ref, orders = series_reference(d, group_wpt=wpt)
+    assert np.isfinite(tg.view(float)).all()
+    assert np.abs(tg - ref).max() < 2e-15 * max(1.0, np.abs(ref).max()) * 8, np.abs(tg - ref).max()
+    fre = frechet_reference(d)
+    assert np.abs(tg - fre).max() < 1e-13, np.abs(tg - fre).max()
+    assert flags[0] == 0 and flags[7] == 0
+    cells = [[min(16, N_T - 16 * b) for b in range((N_T + 15) // 16)] for _ in range(K)]
+    assert int(stats[:, 8].sum()) == int((orders * np.array(cells)).sum())

@@ -42,8 +42,8 @@ def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False
     cf = list(coef) + [0.0] * (2 - len(coef))
     cf2 = list(coef2) + [0.0] * (2 - len(coef2))
     per_cell = NB * (NB + 1) // 2 if herm else NB * NB
-    karg = struct.pack("<8Q6d8i", a_X, a_Y, a_C, a_C2, a_add[0], a_add[1], a_U, a_s, cf[0], cf[1], cf2[0], cf2[1], 0.0, 0.0,
-                       NP, NB, ncell, herm, len(adds), uif, per_cell, 0)
+    karg = struct.pack("<8Q6d8iIi", a_X, a_Y, a_C, a_C2, a_add[0], a_add[1], a_U, a_s, cf[0], cf[1], cf2[0], cf2[1], 0.0, 0.0,
+                       NP, NB, ncell, herm, len(adds), uif, per_cell, (1 << 32) // per_cell + 1, ((1 << 32) // NB + 1) & 0xFFFFFFFF, 0)
     assert len(karg) == gen_lg.KERNARG
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     groups = (ncell + 7) // 8
@@ -107,7 +107,7 @@ def test_epilogue_terms_second_output_and_grid_mapping(program):
     assert np.abs(C - ref).max() < 4e-15 and np.abs(C2 - (ref + B3)).max() < 4e-15
     # a workgroup whose cell does not exist
     g = gcn.GlobalMem()
-    karg = struct.pack("<8Q6d8i", *([0] * 8), *([0.0] * 6), NP, 2, 2, 0, 0, 0, 4, 0)
+    karg = struct.pack("<8Q6d8iIi", *([0] * 8), *([0.0] * 6), NP, 2, 2, 0, 0, 0, 4, (1 << 32) // 4 + 1, (1 << 32) // 2 + 1, 0)
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     e = gcn.Emu(prog, g, a_k, wg_id=5, lds_bytes=gen_lg.LDS_BYTES)
     assert e.run() < 10000 and e.mfma_count == 0

@@ -236,3 +236,38 @@ def test_blocked_products_against_the_compiled_kernel(g, N, L, N_T, K, dt, herm)
     e = pr["pulsevals"].reshape(L, N_T)[:, 0]
     H = pr["H0"][0] + sum(e[l] * pr["Hc"][l] for l in range(L))
     assert np.abs(a[3][0] - expm(-1j * (pr["tlist"][1] - pr["tlist"][0]) * H)).max() < 1e-12
+
+
+# ---- general drift and / or general control operators at four tiles per side: the streamed assembly kernel with all
+# tiles (asm/gen_d3s.py GenD3G) against the compiled kernels (GRAPE_DERIV3G=0, read in grape_create) ----
+def run_d3g(g, pr, asm, **kw):
+    old = os.environ.get("GRAPE_DERIV3G")
+    os.environ["GRAPE_DERIV3G"] = "1" if asm else "0"
+    try:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            J2, G2, _ = h.eval(pr["pulsevals"])
+            assert J2 == J and np.array_equal(G, G2)
+            return J, G, tau, h.work()
+    finally:
+        if old is None:
+            os.environ.pop("GRAPE_DERIV3G", None)
+        else:
+            os.environ["GRAPE_DERIV3G"] = old
+
+
+@pytest.mark.parametrize("N,L,N_T,K,ctrl", [(64, 2, 37, 3, False), (64, 2, 50, 2, True), (57, 4, 21, 2, True), (64, 7, 33, 2, False),
+                                            (50, 1, 100, 5, True), (64, 2, 40, 300, True)])
+def test_general_operator_derivative_kernel_against_the_compiled_kernels(g, N, L, N_T, K, ctrl):
+    """ctrl: the control operators are general as well (else: a general drift beside Hermitian controls)"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=23 + N + L, dt=0.7, hermitian=False)
+    if ctrl:
+        rng = np.random.default_rng(9)
+        pr["Hc"] = pr["Hc"] + 0.2 * (rng.normal(size=pr["Hc"].shape) + 1j * rng.normal(size=pr["Hc"].shape)) / np.sqrt(N)
+    a = run_d3g(g, pr, True)
+    b = run_d3g(g, pr, False)
+    assert a[0] == b[0]
+    gs = max(np.abs(b[1]).max(), 1e-3)
+    assert np.abs(a[1] - b[1]).max() <= 5e-14 * gs, np.abs(a[1] - b[1]).max() / gs
+    assert b[3]["deriv_orders"] <= a[3]["deriv_orders"] <= b[3]["deriv_orders"] + K * N_T

@@ -20,6 +20,9 @@ done
 # secondary lines: six controls and non-Hermitian generators at the headline shape
 python3 bench.py --config C3L6 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_L6.json 2> gpurun_out/${tag}_bench_C3_L6.err
 python3 bench.py --config C3 --nonhermitian --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_nonherm.json 2> gpurun_out/${tag}_bench_C3_nonherm.err
+# general control operators as well (the streamed all-tiles derivative kernel), and its compiled twin
+python3 bench.py --config C3 --nonhermitian --nonhermitian-controls --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_nonherm_ctrl.json 2> gpurun_out/${tag}_bench_C3_nonherm_ctrl.err
+GRAPE_DERIV3G=0 python3 bench.py --config C3 --nonhermitian --nonhermitian-controls --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_nonherm_ctrl_compiled.json 2> gpurun_out/${tag}_bench_C3_nonherm_ctrl_compiled.err
 # the cliff of the four-product route: every cell beyond its range (dt = 1.5: five products) and with one squaring (dt = 2)
 python3 bench.py --config C3 --dt 1.5 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_dt1p5.json 2> gpurun_out/${tag}_bench_C3_dt1p5.err
 python3 bench.py --config C3 --dt 2.0 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_dt2.json 2> gpurun_out/${tag}_bench_C3_dt2.err
