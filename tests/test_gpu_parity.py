@@ -903,7 +903,12 @@ def test_general_drift_with_hermitian_controls_one_wave_per_batch(g, ref, N, L, 
             res[name] = (J, G.copy(), h.work()["deriv_orders"])
         for k in env:
             monkeypatch.delenv(k)
-    assert res["d3"][0] == res["d2"][0] and res["d3"][2] == res["d2"][2] > 0
+    assert res["d3"][0] == res["d2"][0]
+    if N > 48:   # four tiles per side: the streamed all-tiles assembly kernel (asm/gen_d3s.py GenD3G) -- the four batches of a
+                 # workgroup stop together, never earlier than each alone
+        assert 0 < res["d2"][2] <= res["d3"][2] <= res["d2"][2] + K * N_T
+    else:
+        assert res["d3"][2] == res["d2"][2] > 0
     assert np.abs(res["d3"][1] - res["d2"][1]).max() <= 1e-13 * max(np.abs(res["d2"][1]).max(), 1e-3)
     ns = 12
     xs = pr["pulsevals"].reshape(L, N_T)[:, :ns].reshape(-1)
