@@ -223,11 +223,11 @@ def test_streamed_program_has_no_missing_wait_states(program_s):
     assert gen_d3s.LDS_BYTES <= 160 * 1024
 
 
-@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 1, 3, 37, 1, 1, False, False), (50, 2, 1, 20, 3, 2, True, True),
+@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 1, 3, 20, 1, 1, False, False), (50, 2, 1, 20, 3, 2, True, True),
                                                             (64, 1, 6, 16, 1, 1, False, True)])
 def test_streamed_kernel_matches_the_series_and_the_frechet_derivative(program_s, N, K, L, N_T, nblk, wpt, hcpt, shape):
     _, prog, _ = program_s
-    d = make_inputs(N, K, L, N_T, seed=N + L, hc_per_traj=hcpt, shape=shape)
+    d = make_inputs(N, K, L, N_T, seed=N + L, hc_per_traj=hcpt, shape=shape, dt_scale=0.4)      # (short steps: fewer orders to emulate)
     tg, flags, stats, info = run_kernel(prog, d, nblk, wpt, lds_bytes=gen_d3s.LDS_BYTES)
     ref, orders = series_reference(d, group_wpt=wpt)
     assert np.isfinite(tg.view(float)).all()
@@ -253,11 +253,11 @@ def program_g():
     return gen_d3s.generate(general=True)
 
 
-@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 1, 2, 37, 1, 1, False, False), (50, 2, 3, 20, 3, 2, True, True)])
+@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape", [(64, 1, 2, 20, 1, 1, False, False), (50, 1, 3, 20, 2, 2, True, True)])
 def test_general_operator_kernel_matches_the_series_and_the_frechet_derivative(program_g, N, K, L, N_T, nblk, wpt, hcpt, shape):
     g_, prog, _ = program_g
     assert gcn.check_hazards(prog) == 0 and g_.lds_bytes <= 160 * 1024
-    d = make_inputs(N, K, L, N_T, seed=N + L, hc_per_traj=hcpt, shape=shape, general=True)
+    d = make_inputs(N, K, L, N_T, seed=N + L, hc_per_traj=hcpt, shape=shape, general=True, dt_scale=0.4)
     tg, flags, stats, info = run_kernel(prog, d, nblk, wpt, lds_bytes=g_.lds_bytes)
     ref, orders = series_reference(d, group_wpt=wpt)
     assert np.isfinite(tg.view(float)).all()
