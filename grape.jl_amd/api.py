@@ -62,7 +62,7 @@ def build_asm(verbose: bool = False) -> str:
     -> an object file that carries the code object as bytes (grape_asm_co_start / _end), linked into the library."""
     asm_dir = os.path.join(_CSRC, "asm")
     kernels = (("gen_t16.py", "expm_t16_asm"), ("gen_d3.py", "deriv3_asm"), ("gen_d3s.py", "deriv3s_asm"), ("gen_d3s.py", "deriv3g_asm"),
-               ("gen_lg.py", "lg_gemm_asm"))
+               ("gen_lg.py", "lg_gemm_asm"), ("gen_d4.py", "deriv4_asm_128"), ("gen_d4.py", "deriv4_asm_256"))
     co_path, emb_s, emb_o = os.path.join(asm_dir, "grape_asm.co"), os.path.join(asm_dir, "asm_embed.S"), os.path.join(asm_dir, "asm_embed.o")
     llvm = "/opt/rocm/lib/llvm/bin"
     cmds, objs = [], []
@@ -95,7 +95,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     out = out or library_path()
     srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_t18.hip", "grape_kernels.hip.h", "grape_large.hip.h",
                                              "grape_series.hip.h", "grape_cheby.hip.h", "grape_t18.hip.h", "grape_t18_coeffs.h",
-                                             "grape_deriv3.hip.h", os.path.join("asm", "gen_t16.py"), os.path.join("asm", "gen_d3.py"), os.path.join("asm", "gen_d3s.py"), os.path.join("asm", "gen_lg.py"), os.path.join("asm", "gcn.py"))]
+                                             "grape_deriv3.hip.h", os.path.join("asm", "gen_t16.py"), os.path.join("asm", "gen_d3.py"), os.path.join("asm", "gen_d3s.py"), os.path.join("asm", "gen_lg.py"), os.path.join("asm", "gen_d4.py"), os.path.join("asm", "gcn.py"))]
     hdr = os.path.join(_HERE, "..", "include", "grape_hip.h")
     if (not force and os.path.exists(out)
             and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs + [hdr])):

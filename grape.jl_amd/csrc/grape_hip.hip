@@ -46,6 +46,10 @@ struct grape_handle {
     double *d_H0f = nullptr, *d_Hcf = nullptr, *d_H0t = nullptr, *d_Hct = nullptr;
     double *d_H0p = nullptr, *d_Hcp = nullptr, *d_vecs = nullptr;
     double *d_H0q = nullptr, *d_Hcq = nullptr, *d_park2 = nullptr;   // two-pass series kernel: untransposed fragments, parking area
+    // blocked path, derivative kernel as assembly (asm/gen_d4.py): fragments with three planes (re, im, re + im) of the
+    // operators (pass 1) and of their adjoints (pass 2; Hermitian operators: the same arrays)
+    double *d_H0q3 = nullptr, *d_Hcq3 = nullptr, *d_H0p3 = nullptr, *d_Hcp3 = nullptr;
+    int deriv4_blocks = 0;
     // one wave per batch (grape_deriv3.hip.h; Hermitian operators, 32 < N <= 64, L <= 2; GRAPE_DERIV3=0: off)
     double *d_park3 = nullptr;
     int deriv3_blocks = 0, deriv3_wpt = 0;
@@ -259,6 +263,8 @@ static bool deriv3_fits(int NT, int L, bool h0_general = false) {
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
                                    int skip_if_flagged, int h0_general, void *stream, int blocks);
 extern "C" int grape_lg_asm_launch(const void *k, size_t size, unsigned blocks, void *stream);
+extern "C" int grape_deriv4_launch(int NP, const void *d2args, size_t d2size, const double *H0q3, const double *Hcq3, const double *H0p3,
+                                   const double *Hcp3, void *stream, int blocks);
 #ifdef GRAPE_DIAG
 extern "C" void grape_t18_set_stamps(unsigned long long *d_stamps, void *stream);
 #endif
@@ -1047,11 +1053,13 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
         if (b) hipFree(b);
+    if (h->d_H0p3 && h->d_H0p3 != h->d_H0q3) hipFree(h->d_H0p3);   // (Hermitian operators: the adjoint arrays ARE the plain ones)
+    if (h->d_Hcp3 && h->d_Hcp3 != h->d_Hcq3) hipFree(h->d_Hcp3);
     if (h->h_pin) hipHostFree(h->h_pin);
     for (auto &ring : h->ph)
         for (auto &p : ring) {
@@ -1350,7 +1358,48 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                 CCHK(dmalloc(&h->d_Hcq, pk.size()));
                 CCHK(hipMemcpy(h->d_Hcq, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
                 h->deriv2_maxm = 64;
-                CCHK(dmalloc(&h->d_park2, (size_t)h->deriv_blocks * h->deriv2_maxm * 2 * NP * 16));
+                // blocked path: the assembly derivative kernel (asm/gen_d4.py; GRAPE_DERIV4=0: deriv2_kernel, its twin) walks the
+                // batches with one workgroup per CU and parks maxm + 1 terms per workgroup
+                const char *env4 = getenv("GRAPE_DERIV4");
+                if (h->large && !h->series && (NP == 128 || NP == 256) && !(env4 && atoi(env4) == 0)) {
+                    h->deriv4_blocks = (int)std::min<long>(nbatch, h->num_cus);
+                    const int RT3 = NP / 16, KS3 = NP / 4;
+                    auto pack3 = [&](const double *src, int nmat, std::vector<double> &dst, bool dagger) {
+                        // [mat][rt][ks][re | im | re + im][lane]: element (row 16 rt + (lane & 15), column 4 ks + (lane >> 4)) of the
+                        // matrix, or of its conjugate transpose (H column-major: H[i][j] at j N + i)
+                        dst.assign((size_t)nmat * RT3 * KS3 * 192, 0.0);
+                        for (int mtx = 0; mtx < nmat; ++mtx)
+                            for (int rt = 0; rt < RT3; ++rt)
+                                for (int ks = 0; ks < KS3; ++ks)
+                                    for (int ln = 0; ln < 64; ++ln) {
+                                        const int row = 16 * rt + (ln & 15), col = 4 * ks + (ln >> 4);
+                                        if (row >= N || col >= N) continue;
+                                        const size_t so = dagger ? 2 * ((size_t)mtx * nn + (size_t)row * N + col)
+                                                                 : 2 * ((size_t)mtx * nn + (size_t)col * N + row);
+                                        const double re = src[so], im = dagger ? -src[so + 1] : src[so + 1];
+                                        const size_t o = (((size_t)mtx * RT3 + rt) * KS3 + ks) * 192 + ln;
+                                        dst[o] = re; dst[o + 64] = im; dst[o + 128] = re + im;
+                                    }
+                    };
+                    std::vector<double> pk3;
+                    pack3(p->H0, K, pk3, false);
+                    CCHK(dmalloc(&h->d_H0q3, pk3.size()));
+                    CCHK(hipMemcpy(h->d_H0q3, pk3.data(), pk3.size() * 8, hipMemcpyHostToDevice));
+                    pack3(p->Hc, Kc * L, pk3, false);
+                    CCHK(dmalloc(&h->d_Hcq3, pk3.size()));
+                    CCHK(hipMemcpy(h->d_Hcq3, pk3.data(), pk3.size() * 8, hipMemcpyHostToDevice));
+                    if (h->herm) {   // H^dagger = H: one set of arrays
+                        h->d_H0p3 = h->d_H0q3; h->d_Hcp3 = h->d_Hcq3;
+                    } else {
+                        pack3(p->H0, K, pk3, true);
+                        CCHK(dmalloc(&h->d_H0p3, pk3.size()));
+                        CCHK(hipMemcpy(h->d_H0p3, pk3.data(), pk3.size() * 8, hipMemcpyHostToDevice));
+                        pack3(p->Hc, Kc * L, pk3, true);
+                        CCHK(dmalloc(&h->d_Hcp3, pk3.size()));
+                        CCHK(hipMemcpy(h->d_Hcp3, pk3.data(), pk3.size() * 8, hipMemcpyHostToDevice));
+                    }
+                }
+                CCHK(dmalloc(&h->d_park2, std::max((size_t)h->deriv_blocks * h->deriv2_maxm, (size_t)h->deriv4_blocks * (h->deriv2_maxm + 1)) * 2 * NP * 16));
                 const char *env3 = getenv("GRAPE_DERIV3");
                 const char *envnh = getenv("GRAPE_NO_HERM");
                 h->deriv3_h0g = !h->herm && h->herm_ctrl && !(envnh && atoi(envnh));
@@ -1893,6 +1942,8 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         if (h->d_park3 && !d2.gpark) {
             d2.park = h->d_park3;
             e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, h->deriv3_general ? 2 : (h->deriv3_h0g ? 1 : 0), (void *)s, h->deriv3_blocks);
+        } else if (h->deriv4_blocks && !d2.gpark) {
+            e = (hipError_t)grape_deriv4_launch(h->NP, &d2, sizeof(d2), h->d_H0q3, h->d_Hcq3, h->d_H0p3, h->d_Hcp3, (void *)s, h->deriv4_blocks);
         } else
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);
     } else if (h->NP >= 48) {

@@ -211,11 +211,12 @@ __global__ void __launch_bounds__(256) t16_credit_kernel(ExpmArgs a) {
 constexpr int D3_INV_TABLE = 2048;
 struct AsmModule {
     hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr, fn_d3g = nullptr;
+    hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr, fn_d3g = nullptr, fn_d4[2] = {nullptr, nullptr};
     double *inv = nullptr;      // 1 / m, m < D3_INV_TABLE
 };
 hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr,
-                        hipFunction_t *fn_d3s = nullptr, hipFunction_t *fn_lg = nullptr, hipFunction_t *fn_d3g = nullptr) {
+                        hipFunction_t *fn_d3s = nullptr, hipFunction_t *fn_lg = nullptr, hipFunction_t *fn_d3g = nullptr,
+                        hipFunction_t *fn_d4 = nullptr, int d4_index = 0) {
     static AsmModule mods[64];
     static std::mutex mtx;
     std::lock_guard<std::mutex> lock(mtx);
@@ -230,6 +231,10 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         e = hipModuleGetFunction(&m.fn_lg, m.mod, "lg_gemm_asm");
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn_d3g, m.mod, "deriv3g_asm");
+        if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn_d4[0], m.mod, "deriv4_asm_128");
+        if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn_d4[1], m.mod, "deriv4_asm_256");
         if (e != hipSuccess) return e;
         // 1 / m for the series orders (the kernels read them with scalar loads; gfx9 has no scalar floating point); behind
         // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
@@ -254,6 +259,7 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
     if (fn_d3s) *fn_d3s = m.fn_d3s;
     if (fn_lg) *fn_lg = m.fn_lg;
     if (fn_d3g) *fn_d3g = m.fn_d3g;
+    if (fn_d4) *fn_d4 = m.fn_d4[d4_index & 1];
     if (inv) *inv = m.inv;
     return hipSuccess;
 }
@@ -304,6 +310,52 @@ hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks, bool ge
     return hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
 }
 }  // namespace
+
+// derivative overlaps of the blocked path (asm/gen_d4.py): one workgroup per batch, operator fragments with three planes
+namespace {
+struct D4AsmArgs {            // kernel argument block of deriv4_asm_{128,256} (gen_d4.py: KERNARG = 176 bytes)
+    const double *H0q, *Hcq, *H0p, *Hcp, *eps, *shape, *dts;
+    const double2 *fw, *bw;
+    const double *rho;
+    double2 *tg;
+    double *park;             // [blocks][slots][NP][16] complex
+    int *flags;
+    unsigned long long *stats;
+    const int *batch_flag;
+    const double *inv;        // 1 / m
+    int K, L, N_T, hc_per_traj, nbatch_total, batches_per_k, mcap, slots;
+    double tol2;
+    int deep, nblocks;
+};
+static_assert(sizeof(D4AsmArgs) == 176, "argument block of the assembly kernel");
+}  // namespace
+extern "C" int grape_deriv4_launch(int NP, const void *d2args, size_t d2size, const double *H0q3, const double *Hcq3, const double *H0p3,
+                                   const double *Hcp3, void *stream, int blocks) {
+    if (d2size != sizeof(Deriv2Args) || (NP != 128 && NP != 256) || blocks < 1) return (int)hipErrorInvalidValue;
+    Deriv2Args a;
+    memcpy(&a, d2args, sizeof(a));
+    if (a.L < 1 || a.L > 8 || a.gpark || a.maxm + 2 > D3_INV_TABLE || !H0q3 || !Hcq3 || !H0p3 || !Hcp3) return (int)hipErrorInvalidValue;
+    if ((long)a.N_T + 1 >= (1L << 19) || (long)a.K * a.L * a.N_T >= (1L << 27) || a.nbatch_total >= (1 << 24)) return (int)hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipFunction_t fn;
+    const double *inv;
+    e = asm_function(dev, nullptr, nullptr, &inv, nullptr, nullptr, nullptr, &fn, NP == 256);
+    if (e != hipSuccess) return (int)e;
+    D4AsmArgs k{};
+    k.H0q = H0q3; k.Hcq = Hcq3; k.H0p = H0p3; k.Hcp = Hcp3; k.eps = a.eps; k.shape = a.shape; k.dts = a.dts; k.fw = a.fw; k.bw = a.bw;
+    k.rho = a.rho; k.tg = a.tg; k.park = a.park; k.flags = a.flags; k.stats = a.stats; k.batch_flag = a.batch_flag; k.inv = inv;
+    k.K = a.K; k.L = a.L; k.N_T = a.N_T; k.hc_per_traj = a.hc_per_traj; k.nbatch_total = a.nbatch_total; k.batches_per_k = a.batches_per_k;
+    k.mcap = a.max_order < a.maxm ? a.max_order : a.maxm;
+    k.slots = a.maxm + 1;
+    k.tol2 = a.tol * a.tol;
+    k.deep = 0;
+    k.nblocks = blocks;
+    size_t size = sizeof(k);
+    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    return (int)hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, cfg);
+}
 
 // batched complex block product of the blocked path (asm/gen_lg.py): `k` is the 152-byte argument block of lg_gemm_asm,
 // filled by the caller (grape_hip.hip: lg_asm_args), one workgroup per 64 x 64 output block

@@ -271,3 +271,44 @@ def test_general_operator_derivative_kernel_against_the_compiled_kernels(g, N, L
     gs = max(np.abs(b[1]).max(), 1e-3)
     assert np.abs(a[1] - b[1]).max() <= 5e-14 * gs, np.abs(a[1] - b[1]).max() / gs
     assert b[3]["deriv_orders"] <= a[3]["deriv_orders"] <= b[3]["deriv_orders"] + K * N_T
+
+
+# ---- blocked path: the derivative kernel as assembly (asm/gen_d4.py) against deriv2_kernel (GRAPE_DERIV4=0, read in
+# grape_create) ----
+def run_d4(g, pr, asm, **kw):
+    old = os.environ.get("GRAPE_DERIV4")
+    os.environ["GRAPE_DERIV4"] = "1" if asm else "0"
+    try:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            J2, G2, _ = h.eval(pr["pulsevals"])
+            assert J2 == J and np.array_equal(G, G2)
+            return J, G, tau, h.work()
+    finally:
+        if old is None:
+            os.environ.pop("GRAPE_DERIV4", None)
+        else:
+            os.environ["GRAPE_DERIV4"] = old
+
+
+@pytest.mark.parametrize("N,L,N_T,K,herm,kw", [
+    (256, 2, 20, 2, True, {}), (128, 1, 37, 3, True, {}), (200, 4, 16, 5, True, {"shape": True}), (100, 6, 33, 2, True, {}),
+    (256, 3, 17, 2, False, {}), (129, 2, 40, 7, False, {"general_controls": True}), (128, 8, 5, 2, True, {"per_traj": True}),
+    (65, 2, 300, 40, True, {})])
+def test_blocked_derivative_kernel_against_the_compiled_kernel(g, N, L, N_T, K, herm, kw):
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=61 + N + L, dt=0.8, hermitian=herm)
+    args = {}
+    rng = np.random.default_rng(5)
+    if kw.get("shape"):
+        args["shape"] = 0.5 + rng.random((L, N_T))
+    if kw.get("general_controls"):
+        pr["Hc"] = pr["Hc"] + 0.2 * (rng.normal(size=pr["Hc"].shape) + 1j * rng.normal(size=pr["Hc"].shape)) / np.sqrt(N)
+    if kw.get("per_traj"):
+        pr["Hc"] = np.stack([pr["Hc"] * (1.0 + 0.1 * rng.random()) for _ in range(K)])
+    a = run_d4(g, pr, True, **args)
+    b = run_d4(g, pr, False, **args)
+    assert a[0] == b[0]                                      # exponentials and sweeps are the same code on both sides
+    gs = max(np.abs(b[1]).max(), 1e-3)
+    assert np.abs(a[1] - b[1]).max() <= 5e-14 * gs, np.abs(a[1] - b[1]).max() / gs
+    assert a[3]["deriv_orders"] == b[3]["deriv_orders"] > 0    # same stopping rule: a batch of 16 cells stops together
