@@ -8,8 +8,10 @@ matrix pipe 62 % busy and spends 30 % of its wave cycles waiting for operator fr
 
 Layout of the work: one workgroup = one batch of 16 consecutive cells at a time; its four waves own the row tiles
 w, w + 4, .. of every result (TPW = NP / 64 row tiles per wave).
-  * left operands: the operators, fragment-packed with THREE planes per (row tile, k-step) -- re, im, re + im (the operand
-    sum of the 3M scheme is packed on the host: no vector instruction touches a fragment) -- streamed from L2 by each wave
+  * left operands: the operators, fragment-packed with THREE values per element and (row tile, k-step) -- (re, im) interleaved
+    per lane, then re + im (the operand sum of the 3M scheme is packed on the host: no vector instruction touches a fragment;
+    one 16-byte and one 8-byte load per fragment: the eight k-steps of the ring are 56 loads, within the 63 the counter of
+    outstanding loads can tell apart) -- streamed from L2 by each wave
     for its own row tiles into a ring of eight k-steps in the ACCUMULATION half of the register file (global loads land
     there, matrix instructions read their left operand there).  The stream runs through the operators H0, mu_1 .. mu_L,
     H0, .. of a pass without a break: the ring is refilled across product and order boundaries.
@@ -27,7 +29,7 @@ from gcn import Prog, Reg, V, A, S, VCC, EXEC, Neg, kernel_text  # noqa: E402
 from gen_d3 import dbits  # noqa: E402
 
 KERNARG = 176
-FRAG_B = 3 * 512                 # bytes of one (row tile, k-step) fragment: re | im | re + im, 64 lanes each
+FRAG_B = 3 * 512                 # bytes of one (row tile, k-step) fragment: 64 lanes x (re, im), then 64 lanes x (re + im)
 RING = 8                         # k-steps in the ring = k-steps per loop iteration
 
 
@@ -64,7 +66,7 @@ class GenD4:
         # ---- per-lane ----
         self.v_tid, self.v_lane = V(0), V(1)
         self.v_b, self.v_b2 = V(2), V(3)
-        self.v_aoff = [V(4 + t) for t in range(4)]
+        self.v_a16, self.v_a8 = V(4), V(5)               # lane 16 / lane 8: the (re, im) pair / the sum of a fragment
         self.v_fwoff, self.v_bwoff, self.v_poff, self.v_tgoff, self.v_nc8 = V(8), V(9), V(10), V(11), V(12)
         self.v_w, self.v_w2, self.v_acc = V(13), V(14), V(15)
         self.v_dt, self.v_e, self.v_sh, self.v_sfac, self.v_nn = V(16, 2), V(18, 2), V(20, 2), V(22, 2), V(24, 2)
@@ -81,7 +83,8 @@ class GenD4:
         self.RINGR = [[[A((slot * TPW + t) * 6 + 2 * pl, 2) for pl in range(3)] for t in range(TPW)] for slot in range(RING)]
         self.ULAND = A(RING * TPW * 6, 16 * TPW)         # element e = 4 t + r: re (2), im (2)
         assert RING * TPW * 6 + 16 * TPW <= 256
-        self.NLOAD = 3 * TPW                              # fragment loads per k-step
+        self.NLOAD = 2 * TPW                              # fragment loads per k-step
+        self.s_fb = [self.s_b, S(70, 2), S(72, 2), S(76, 2)]   # fragment base of the k-step being requested, per row tile
 
     # ---------------------------------------------------------------------------------------------------------------
     def add64(self, dst, base, lo, hi=0):
@@ -136,11 +139,9 @@ class GenD4:
         p.valu("v_lshlrev_b32", self.v_b, 7, vrg)
         p.valu("v_lshl_add_u32", self.v_b, vc, 3, self.v_b)
         p.valu("v_add_u32", self.v_b2, 2 * self.PL, self.v_b)
-        # left-operand fragments: lane 8 + t (4 KS FRAG_B)   (row tile w + 4 t; the wave's w KS FRAG_B is in the scalar base)
-        for tt in range(self.TPW):
-            p.valu("v_lshlrev_b32", self.v_aoff[tt], 3, self.v_lane)
-            if tt:
-                p.valu("v_add_u32", self.v_aoff[tt], tt * 4 * self.KS * FRAG_B, self.v_aoff[tt])
+        # left-operand fragments: lane 16 for the (re, im) pairs, 1024 + lane 8 for the sums (row tiles: scalar bases)
+        p.valu("v_lshlrev_b32", self.v_a16, 4, self.v_lane)
+        p.valu("v_lshlrev_b32", self.v_a8, 3, self.v_lane)
         # own rows of the vector block: row 16 (w + 4 t) + 4 r + rg, column c: (16 w + rg) 128 + c 8 [+ t 8192 + r 512]
         p.valu("v_lshl_add_u32", t.sub(3), vw, 4, vrg)
         p.valu("v_lshlrev_b32", self.v_w, 7, t.sub(3))
@@ -206,13 +207,18 @@ class GenD4:
         p.s_cmp("s_cmp_eq_u32", c_reg, 0)
         p.salu("s_cselect_b64", dst, self.s_h0, self.s_a)
 
-    def frag_loads(self, slot, q, plane):
-        """fragments (plane) of the k-step at s_pf + q FRAG_B for every row tile of the wave -> ring slot"""
+    def frag_loads(self, slot, q, part):
+        """fragments of the k-step at s_pf + q FRAG_B for every row tile of the wave -> ring slot; part 0: the (re, im) pairs
+        (behind the matrix instructions that read re and im of the slot), part 1: the sums"""
         p = self.p
-        if plane == 0:
-            self.add64(self.s_b, self.s_pf, q * FRAG_B)
+        if part == 0:
+            for t in range(self.TPW):
+                self.add64(self.s_fb[t], self.s_pf, q * FRAG_B + t * 4 * self.KS * FRAG_B)
         for t in range(self.TPW):
-            p.global_load(2, self.RINGR[slot][t][plane], self.v_aoff[t], self.s_b, plane * 512)
+            if part == 0:
+                p.global_load(4, Reg("a", self.RINGR[slot][t][0].idx, 4), self.v_a16, self.s_fb[t])
+            else:
+                p.global_load(2, self.RINGR[slot][t][2], self.v_a8, self.s_fb[t], 1024)
 
     def start_stream(self):
         """start of a pass: the ring takes k-steps 0 .. 7 of H0; the stream stands at its k-step 8"""
@@ -221,8 +227,8 @@ class GenD4:
         p.salu("s_mov_b32", self.s_c, 0)
         p.salu("s_mov_b64", self.s_pf, self.s_h0)
         for q in range(RING):
-            for pl in range(3):
-                self.frag_loads(q, q, pl)
+            for part in range(2):
+                self.frag_loads(q, q, part)
         self.add64(self.s_pf, self.s_pf, RING * FRAG_B)
 
     # ---- one product: P = (operator at the head of the stream) x (vector block in LDS) ---------------------------------
@@ -262,7 +268,8 @@ class GenD4:
                     p.mfma(self.P[pl][t], self.RINGR[q][t][pl], self.B[buf][pl], self.P[pl][t])
                     if hook and t == 0 and pl == 0:
                         hook(q)
-                self.frag_loads(q, q, pl)
+                if pl >= 1:
+                    self.frag_loads(q, q, pl - 1)
         self.add64(self.s_pf, self.s_pf, RING * FRAG_B)
         p.valu("v_add_u32", self.v_bc, RING * 512, self.v_bc)
         p.valu("v_add_u32", self.v_b2c, RING * 512, self.v_b2c)

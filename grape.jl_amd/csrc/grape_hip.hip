@@ -1365,8 +1365,8 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                     h->deriv4_blocks = (int)std::min<long>(nbatch, h->num_cus);
                     const int RT3 = NP / 16, KS3 = NP / 4;
                     auto pack3 = [&](const double *src, int nmat, std::vector<double> &dst, bool dagger) {
-                        // [mat][rt][ks][re | im | re + im][lane]: element (row 16 rt + (lane & 15), column 4 ks + (lane >> 4)) of the
-                        // matrix, or of its conjugate transpose (H column-major: H[i][j] at j N + i)
+                        // [mat][rt][ks][64 lanes x (re, im) | 64 lanes x (re + im)]: element (row 16 rt + (lane & 15), column
+                        // 4 ks + (lane >> 4)) of the matrix, or of its conjugate transpose (H column-major: H[i][j] at j N + i)
                         dst.assign((size_t)nmat * RT3 * KS3 * 192, 0.0);
                         for (int mtx = 0; mtx < nmat; ++mtx)
                             for (int rt = 0; rt < RT3; ++rt)
@@ -1378,7 +1378,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                                                                  : 2 * ((size_t)mtx * nn + (size_t)col * N + row);
                                         const double re = src[so], im = dagger ? -src[so + 1] : src[so + 1];
                                         const size_t o = (((size_t)mtx * RT3 + rt) * KS3 + ks) * 192 + ln;
-                                        dst[o] = re; dst[o + 64] = im; dst[o + 128] = re + im;
+                                        dst[o + ln] = re; dst[o + ln + 1] = im; dst[o + 128] = re + im;   // (o = base + ln: pairs at 2 ln, sums at 128 + ln)
                                     }
                     };
                     std::vector<double> pk3;

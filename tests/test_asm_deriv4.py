@@ -19,17 +19,17 @@ from test_asm_deriv3 import series_reference, frechet_reference  # noqa: E402
 
 
 def pack3(mats, NP, dagger):
-    """[mat][rt][ks][re | im | re + im][64 lanes]: lane ln holds element (row 16 rt + (ln & 15), column 4 ks + (ln >> 4)) of the
-    matrix (dagger: of its conjugate transpose) -- the host's packing for deriv4_asm (grape_hip.hip: pack3)"""
+    """[mat][rt][ks][64 lanes x (re, im) | 64 lanes x (re + im)]: lane ln holds element (row 16 rt + (ln & 15), column
+    4 ks + (ln >> 4)) of the matrix (dagger: of its conjugate transpose) -- the host's packing for deriv4_asm (grape_hip.hip: pack3)"""
     RT, KS = NP // 16, NP // 4
-    out = np.zeros((len(mats), RT, KS, 3, 64))
+    out = np.zeros((len(mats), RT, KS, 192))
     ln = np.arange(64)
     for m, H in enumerate(mats):
         X = H.conj().T if dagger else H
         for rt in range(RT):
             for ks in range(KS):
                 v = X[16 * rt + (ln & 15), 4 * ks + (ln >> 4)]
-                out[m, rt, ks, 0], out[m, rt, ks, 1], out[m, rt, ks, 2] = v.real, v.imag, v.real + v.imag
+                out[m, rt, ks, 0:128:2], out[m, rt, ks, 1:128:2], out[m, rt, ks, 128:] = v.real, v.imag, v.real + v.imag
     return out
 
 
