@@ -7,14 +7,14 @@ sys.path.insert(0, '.')
 import grape_jl_amd as g
 from grape_jl_amd import synth
 
-OFF = {"GRAPE_EXPM_ASM": "0", "GRAPE_DERIV3_ASM": "0", "GRAPE_DERIV3S": "0", "GRAPE_DERIV3G": "0", "GRAPE_LG_ASM": "0"}
+OFF = {"GRAPE_EXPM_ASM": "0", "GRAPE_DERIV3_ASM": "0", "GRAPE_DERIV3S": "0", "GRAPE_DERIV3G": "0", "GRAPE_LG_ASM": "0", "GRAPE_DERIV4": "0"}
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 worst = 0.0
 for case in range(cases):
-    big = rng.integers(0, 6) == 0
+    big = rng.integers(0, 3) == 0
     if big:
-        N = int(rng.choice([65, 100, 128, 129, 200, 256])); L = int(rng.choice([1, 2, 4])); N_T = int(rng.choice([1, 3, 9])); K = int(rng.integers(1, 12))
+        N = int(rng.choice([65, 100, 128, 129, 200, 256])); L = int(rng.choice([1, 2, 4])); N_T = int(rng.choice([1, 3, 9, 17, 40])); K = int(rng.integers(1, 12)); L = int(rng.choice([1, 2, 4, 6, 8]))
     else:
         N = int(rng.integers(49, 65)); L = int(rng.choice([1, 2, 2, 3, 4, 5, 6, 7, 8])); N_T = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 90, 130]))
         K = int(rng.choice([1, 2, 3, 5, 9, 40]))
