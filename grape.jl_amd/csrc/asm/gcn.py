@@ -595,7 +595,7 @@ class Wave:
 
 
 class Emu:
-    def __init__(self, prog, gmem, kernarg_addr, wg_id=0, nwaves=4, lds_bytes=160 * 1024, check_races=True):
+    def __init__(self, prog, gmem, kernarg_addr, wg_id=0, nwaves=4, lds_bytes=160 * 1024, check_races=True, lds_stats=False):
         self.prog, self.g = prog, gmem
         self.lds = np.zeros(lds_bytes, np.uint8)
         self.lds_bytes = lds_bytes
@@ -610,7 +610,9 @@ class Emu:
         self.check_races = check_races
         self.mfma_count = 0
         self.dma_pending = np.zeros(nw, np.int32)   # LDS words with an LDS-DMA write in flight
-        self.lds_cycles = {}      # op -> [instructions, LDS-array cycles] by the banking rules of the CDNA4 guide (lds_array_cycles)
+        # op -> [instructions, LDS-array cycles] by the banking rules of the CDNA4 guide (lds_array_cycles); a Python loop over
+        # the lanes of every LDS instruction: only on request (tools/asm_lds_model.py)
+        self.lds_cycles = {} if lds_stats else None
 
     # ---- register access ----
     def _chk(self, w, cls, idx, n, what):
@@ -642,8 +644,7 @@ class Emu:
         if isinstance(o, Reg):
             if o.cls in ("v", "a"):
                 self._chk(w, o.cls, o.idx, 2, "read")
-                f = w.file(o.cls)
-                x = (f[o.idx].astype(np.uint64) | (f[o.idx + 1].astype(np.uint64) << np.uint64(32))).view(np.float64).copy()
+                x = np.ascontiguousarray(w.file(o.cls)[o.idx:o.idx + 2].T).view(np.float64).ravel()   # (lo, hi) per lane, little endian
             elif o.cls == "s":
                 self._chk(w, "s", o.idx, 2, "read")
                 bits = int(w.s[o.idx]) | (int(w.s[o.idx + 1]) << 32)
@@ -670,9 +671,13 @@ class Emu:
         self._chk(w, dst.cls, dst.idx, 2, "write")
         f = w.file(dst.cls)
         m = w.exec if mask is None else mask
-        u = np.asarray(val, np.float64).view(np.uint64)
-        f[dst.idx][m] = (u & np.uint64(0xFFFFFFFF)).astype(np.uint32)[m]
-        f[dst.idx + 1][m] = (u >> np.uint64(32)).astype(np.uint32)[m]
+        pair = np.ascontiguousarray(val, np.float64).view(np.uint32).reshape(NL, 2)
+        if m.all():
+            f[dst.idx] = pair[:, 0]
+            f[dst.idx + 1] = pair[:, 1]
+        else:
+            f[dst.idx][m] = pair[m, 0]
+            f[dst.idx + 1][m] = pair[m, 1]
 
     def rd_s32(self, w, o):
         if isinstance(o, Reg):
@@ -1063,20 +1068,22 @@ class Emu:
         bv = self.rd64f(w, b)    # lane l: B[k = l >> 4][j = l & 15]
         Am = av.reshape(4, 16).T             # [i][k]
         Bm = bv.reshape(4, 16)               # [k][j]
-        if isinstance(c, Reg):
-            Cm = np.zeros((16, 16))
-            for r in range(4):
-                cv = self.rd64f(w, c.d(r))   # lane l: C[4r + (l >> 4)][l & 15]
-                Cm[4 * r:4 * r + 4, :] = cv.reshape(4, 16)
-        else:
-            assert c == 0
-            Cm = np.zeros((16, 16))
         if i.mods.get("neg_a"):
             Am = -Am
-        Dm = Cm + Am @ Bm
-        allm = np.ones(NL, bool)
-        for r in range(4):
-            self.wr64f(w, d.d(r), Dm[4 * r:4 * r + 4, :].reshape(NL), mask=allm)
+        Dm = Am @ Bm
+        if isinstance(c, Reg):
+            # register r of the tile, lane l: C[4 r + (l >> 4)][l & 15] -- the eight registers at once
+            self._chk(w, c.cls, c.idx, 8, "read")
+            fc = w.file(c.cls)[c.idx:c.idx + 8]
+            cv = (fc[0::2].astype(np.uint64) | (fc[1::2].astype(np.uint64) << np.uint64(32))).view(np.float64)   # [r][lane]
+            Dm = Dm + cv.reshape(16, 16)
+        else:
+            assert c == 0
+        self._chk(w, d.cls, d.idx, 8, "write")
+        u = np.ascontiguousarray(Dm.reshape(4, NL)).view(np.uint64)
+        fd = w.file(d.cls)
+        fd[d.idx:d.idx + 8:2] = (u & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        fd[d.idx + 1:d.idx + 8:2] = (u >> np.uint64(32)).astype(np.uint32)
         self.mfma_count += 1
 
     def ldsop(self, w, i):
@@ -1129,6 +1136,15 @@ class Emu:
                 lds32[(addr[act] >> 2) + j] = f[dreg.idx + j][act]
             w.lgkm.append({"regs": [], "write": True})
 
+    def _span(self, addrs, nbytes):
+        """(uint8 view, offsets) when the accesses [a, a + nbytes) of all lanes fall into ONE buffer, else None"""
+        lo, hi = int(addrs.min()), int(addrs.max()) + nbytes
+        try:
+            u8, o0 = self.g.find(lo, hi - lo)
+        except EmuError:
+            return None
+        return u8, (addrs - lo) + o0
+
     def vmem(self, w, i):
         ndw, off = i.mods["ndw"], i.mods["offset"]
         if i.mods.get("lds_dma"):
@@ -1141,11 +1157,15 @@ class Emu:
             if len(dst) and (dst.max() + 16 > self.lds_bytes or (dst % 16).any()):
                 raise EmuError(f"LDS-DMA destination out of bounds or misaligned [{i.text}] m0={m0}")
             data = np.zeros((len(act), 16), np.uint8)
-            for n, l in enumerate(act):
-                u8, o = self.g.find(int(addr[l]), 16)
-                if int(addr[l]) % 16:
-                    raise EmuError("misaligned LDS-DMA source")
-                data[n] = u8[o:o + 16]
+            if len(act) and (addr[act] % 16).any():
+                raise EmuError("misaligned LDS-DMA source")
+            sp = self._span(addr[act], 16) if len(act) else None
+            if sp is not None:
+                data = sp[0][sp[1][:, None] + np.arange(16)[None, :]]
+            else:
+                for n, l in enumerate(act):
+                    u8, o = self.g.find(int(addr[l]), 16)
+                    data[n] = u8[o:o + 16]
             self._lds_touch(w, dst, 16, True)
             words = np.concatenate([dst >> 3, (dst >> 3) + 1]) if len(dst) else np.zeros(0, np.int64)
             self.dma_pending[words] += 1
@@ -1165,11 +1185,17 @@ class Emu:
             addr = base + self.rd32(w, voff).astype(np.int64) + off
             act = w.exec
             data = np.zeros((ndw, NL), np.uint32)
-            for l in np.nonzero(act)[0]:
-                u8, o = self.g.find(int(addr[l]), 4 * ndw)
-                if o % min(4 * ndw, 16) != 0 and (int(addr[l]) % 4) != 0:
-                    raise EmuError("misaligned global load")
-                data[:, l] = u8[o:o + 4 * ndw].view(np.uint32)
+            lanes = np.nonzero(act)[0]
+            if len(lanes) and (addr[lanes] % 4).any():
+                raise EmuError("misaligned global load")
+            sp = self._span(addr[lanes], 4 * ndw) if len(lanes) else None
+            if sp is not None:
+                byts = np.ascontiguousarray(sp[0][sp[1][:, None] + np.arange(4 * ndw)[None, :]])
+                data[:, lanes] = byts.view(np.uint32).T
+            else:
+                for l in lanes:
+                    u8, o = self.g.find(int(addr[l]), 4 * ndw)
+                    data[:, l] = u8[o:o + 4 * ndw].view(np.uint32)
             regs = i.dst.regs()
             for key in regs:
                 if key in w.poison:
@@ -1188,7 +1214,15 @@ class Emu:
             addr = base + self.rd32(w, voff).astype(np.int64) + off
             self._chk(w, dreg.cls, dreg.idx, dreg.n, "read")
             f = w.file(dreg.cls)
-            for l in np.nonzero(w.exec)[0]:
+            lanes = np.nonzero(w.exec)[0]
+            sp = self._span(addr[lanes], 4 * ndw) if len(lanes) and not i.mods.get("atomic") else None
+            if sp is not None:      # plain store, one buffer: vectorised scatter (lanes of one instruction do not overlap)
+                if (addr[lanes] % 4).any():
+                    raise EmuError("misaligned global store")
+                vals = np.ascontiguousarray(np.stack([f[dreg.idx + j][lanes] for j in range(ndw)], axis=1))   # [lane][dword]
+                sp[0][sp[1][:, None] + np.arange(4 * ndw)[None, :]] = vals.view(np.uint8)
+                lanes = []
+            for l in lanes:
                 u8, o = self.g.find(int(addr[l]), 4 * ndw)
                 if int(addr[l]) % 4:
                     raise EmuError("misaligned global store")

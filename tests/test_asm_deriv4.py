@@ -117,7 +117,7 @@ def test_programs_have_no_missing_wait_states_and_assemble(program128, tmp_path)
                             str(src), "-o", str(tmp_path / f"d4_{NP}.o")], check=True)
 
 
-@pytest.mark.parametrize("N,K,L,N_T,nblk,hcpt,shape,general", [(100, 1, 2, 20, 2, False, False, True), (128, 2, 3, 16, 3, True, True, False)])
+@pytest.mark.parametrize("N,K,L,N_T,nblk,hcpt,shape,general", [(100, 1, 2, 20, 2, False, False, True), (128, 1, 3, 16, 2, True, True, False)])
 def test_emulated_kernel_matches_the_series_and_the_frechet_derivative(program128, N, K, L, N_T, nblk, hcpt, shape, general):
     gen, prog, _ = program128
     d = make_inputs(N, 128, K, L, N_T, seed=N + L, hc_per_traj=hcpt, shape=shape, general=general)

@@ -13,7 +13,7 @@ a = [gm.add(n, x)[0] for n, x in (("H0f", H0f), ("Sf", Sf), ("dts", dts * 0.7))]
 a_U, U = gm.add("U", np.zeros((KC * N_T, 64, 64, 2))); a_v, _ = gm.add("v", np.zeros(KC * N_T, np.int32))
 a_f, _ = gm.add("flags", np.zeros(8, np.int32))
 a_k, _ = gm.add("k", np.frombuffer(struct.pack("<QQQQQQiiiiQQ", *a, a_U, a_v, 0, KC, N_T, nblk, 0, 0, a_f), np.uint8).copy())
-e = gcn.Emu(prog, gm, a_k, wg_id=0, check_races=False)
+e = gcn.Emu(prog, gm, a_k, wg_id=0, check_races=False, lds_stats=True)
 e.run()
 ncell = 3
 print("per cell and wave (ideal = conflict-free array cycles of that instruction):")
