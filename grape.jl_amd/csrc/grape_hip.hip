@@ -1363,6 +1363,7 @@ int grape_create(grape_handle **out, const grape_problem *p) {
                 const char *env4 = getenv("GRAPE_DERIV4");
                 if (h->large && !h->series && (NP == 128 || NP == 256) && !(env4 && atoi(env4) == 0)) {
                     h->deriv4_blocks = (int)std::min<long>(nbatch, h->num_cus);
+                    if (const char *envb4 = getenv("GRAPE_DERIV4_BLOCKS")) h->deriv4_blocks = (int)std::min<long>(nbatch, std::max(1, atoi(envb4)));
                     const int RT3 = NP / 16, KS3 = NP / 4;
                     auto pack3 = [&](const double *src, int nmat, std::vector<double> &dst, bool dagger) {
                         // [mat][rt][ks][64 lanes x (re, im) | 64 lanes x (re + im)]: element (row 16 rt + (lane & 15), column
