@@ -5,7 +5,8 @@ What it replaces: lg_gemm_kernel (grape_large.hip.h) for the products of the pol
 (expm_large_t18 in grape_hip.hip: A2 = A A, A3 = A2 A, A6 = A3 A3, A9 = B1 B5 + B4 [and B3 + A9], p = B2 + (B3 + A9) A9),
 i.e. the five products of U_n = exp(-i H_n dt) per cell that stand for Julia's exp! in
 /root/reference/src/optimize.jl:732 (prop_step! -> ExpProp).  Same grid (one workgroup per 64 x 64 output block, the blocks
-of a cell on one XCD), same 3M arithmetic, same epilogue terms; the squaring launches and the Pade route keep the compiled
+of a cell on one XCD), same 3M arithmetic, same epilogue terms, and the squaring launches of the plan (cells that need no further squaring are
+copied through; the launch follows the device-side count); the Gauss-Jordan launches of the Pade route keep the compiled
 kernel, which is also the differential twin (GRAPE_LG_ASM=0).
 
 Why assembly: the compiled kernel loads a 64-wide k-block, synchronises, multiplies, synchronises -- its matrix pipe is
@@ -26,7 +27,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gcn import Prog, Reg, V, A, S, VCC, EXEC, M0, Neg, kernel_text  # noqa: E402
 
-KERNARG = 152
+KERNARG = 168
 STAGE_B = 32768                  # one k-block of the left operand: [re | im][64 rows][32 columns]
 LDS_BYTES = 2 * STAGE_B
 KSTEPS = 8                       # k-steps (of 4) per k-block
@@ -43,6 +44,9 @@ class GenLG:
         self.s_coef2 = [S(24, 2), S(26, 2)]
         self.s_NP, self.s_NB, self.s_ncell, self.s_herm, self.s_nadd, self.s_uif, self.s_percell, self.s_mpc = (S(32 + i) for i in range(8))
         self.s_mnb = S(90)                       # reciprocals (floor(2^32 / d) + 1) of per_cell and NB: quotients by one multiplication
+        # squaring launches (sq_mode): cells with s_cell[cell] <= sq_iter are copied through, the launch leaves at once when
+        # sq_iter >= *smax_ptr and writes U when it is the last one needed
+        self.s_scell, self.s_sqiter, self.s_sqmode = S(92, 2), S(94), S(95)
         self.s_cell, self.s_bi, self.s_bj, self.s_useu = S(40), S(41), S(42), S(43)
         self.s_xp, self.s_yp, self.s_yq = S(44, 2), S(46, 2), S(48, 2)
         self.s_ldsw, self.s_rowstep, self.s_kb, self.s_nkb = S(50), S(51), S(52), S(53)
@@ -100,6 +104,7 @@ class GenLG:
         p.s_load(4, S(28, 4), S(0, 2), 96)
         p.s_load(8, S(32, 8), S(0, 2), 112)
         p.s_load(2, S(90, 2), S(0, 2), 144)
+        p.s_load(4, S(92, 4), S(0, 2), 152)
         p.valu("v_and_b32", self.v_tid, 0x3FF, V(0))
         p.valu("v_and_b32", self.v_lane, 63, self.v_tid)
         t = self.T
@@ -146,6 +151,16 @@ class GenLG:
         p.s_cmp("s_cmp_lg_u32", self.s_smaxv, 0)
         p.salu("s_cselect_b32", self.s_useu, 0, self.s_useu)
         p.label("L_have_u")
+        p.s_cmp("s_cmp_eq_u32", self.s_sqmode, 0)
+        p.s_branch("s_cbranch_scc1", "L_not_sq")
+        p.s_load(1, self.s_smaxv, self.s_smax, 0)
+        p.s_waitcnt(lgkm=0)
+        p.s_cmp("s_cmp_ge_u32", self.s_sqiter, self.s_smaxv)
+        p.s_branch("s_cbranch_scc1", "L_end")
+        p.salu("s_add_u32", self.s_t[0], self.s_sqiter, 1)
+        p.s_cmp("s_cmp_lg_u32", self.s_t[0], self.s_smaxv)
+        p.salu("s_cselect_b32", self.s_useu, 0, self.s_useu)
+        p.label("L_not_sq")
         # ---- per-lane constants ----
         for r in range(KSTEPS):     # fragment (row 16 rt + c, k-step r): c 256 + (((2 r | h) ^ c) << 4) + (rg & 1) 8
             p.valu("v_or_b32", vx, 2 * r, vh)
@@ -200,6 +215,15 @@ class GenLG:
         self.add64(self.s_yp, self.s_yp, self.s_t[0])
         self.add64(self.s_yq, self.s_yp, self.s_planeb)
         p.salu("s_lshl_b32", self.s_nkb, self.s_NB, 1)
+        # a cell that needs no (further) squaring: its block of X is the result
+        p.s_cmp("s_cmp_eq_u64", self.s_scell, 0)
+        p.s_branch("s_cbranch_scc1", "L_no_copy")
+        p.salu("s_lshl_b32", self.s_t[0], self.s_cell, 2)
+        p.s_load(1, self.s_t[1], self.s_scell, self.s_t[0])
+        p.s_waitcnt(lgkm=0)
+        p.s_cmp("s_cmp_le_i32", self.s_t[1], self.s_sqiter)
+        p.s_branch("s_cbranch_scc1", "L_copy")
+        p.label("L_no_copy")
         for j in range(3):
             for rt in range(4):
                 for i in range(8):
@@ -323,7 +347,27 @@ class GenLG:
 
     def epilogue(self):
         p = self.p
-        # bases
+        self.epi_bases()
+        self.combine_all()
+        self.epilogue_rest()
+
+    def copy_through(self):
+        """L_copy: E <- the block (bi, bj) of X, then the plain store"""
+        p = self.p
+        p.label("L_copy")
+        self.epi_bases()
+        self.add64(self.s_A0b, self.s_X, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        self.add64(self.s_A1b, self.s_A0b, self.s_planeb)
+        for t in range(4):
+            self.offsets(t, self.s_boff)
+            for r in range(4):
+                e = self.elem(t, r)
+                p.global_load(2, e.sub(0, 2), self.v_o[r], self.s_A0b)
+                p.global_load(2, e.sub(2, 2), self.v_o[r], self.s_A1b)
+        p.s_branch("s_branch", "L_epi_plain")
+
+    def epi_bases(self):
+        p = self.p
         self.add64(self.s_Cb, self.s_C, self.s_cellb.sub(0), self.s_cellb.sub(1))
         self.add64(self.s_b, self.s_Cb, self.s_planeb)
         self.mul64(self.s_a, self.s_cell, self.s_planeb)             # cell NP NP 8 -> x 2: 16 bytes per element of U
@@ -332,7 +376,9 @@ class GenLG:
         p.salu("s_mul_i32", self.s_boff, self.s_bi, self.s_NP)
         p.salu("s_add_u32", self.s_boff, self.s_boff, self.s_bj)
         p.salu("s_lshl_b32", self.s_boff, self.s_boff, 9)            # (bi 64 NP + bj 64) 8
-        self.combine_all()
+
+    def epilogue_rest(self):
+        p = self.p
         p.s_cmp("s_cmp_eq_u32", self.s_nadd, 0)
         p.s_branch("s_cbranch_scc1", "L_epi_plain")
         # ---- epilogue terms: E += coef[q] Add_q; second output C2 = E + coef2[q] Add_q ----
@@ -436,6 +482,8 @@ class GenLG:
         p.s_cmp("s_cmp_lt_u32", self.s_kb, self.s_nkb)
         p.s_branch("s_cbranch_scc1", "L_loop")
         self.epilogue()
+        p.s_branch("s_branch", "L_end")
+        self.copy_through()
         p.label("L_end")
         p.s_endpgm()
         top = max((i for ins in p.ins for c, i in (ins.reads + ins.writes) if c in ("v", "a")), default=0)

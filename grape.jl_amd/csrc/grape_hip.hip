@@ -636,8 +636,9 @@ void phase_end(grape_handle *h, int i, hipStream_t s) {
 LgView lg_full(double *p, int NP) { return LgView{p, (size_t)2 * NP * NP, (size_t)NP * NP, NP, 0, 0}; }
 
 // the products of the polynomial route as assembly (asm/gen_lg.py: lg_gemm_asm; GRAPE_LG_ASM=0: the compiled kernel, its
-// twin).  The assembly kernel takes whole planar arrays, at most two epilogue terms, no beta / identity terms and none of
-// the squaring logic; everything else stays with lg_gemm_kernel.
+// twin).  The assembly kernel takes whole planar arrays, at most two epilogue terms and no beta / identity / scaling terms;
+// the squaring launches of the plan (copy-through of finished cells, device-side count) are covered, the Gauss-Jordan
+// launches of the Pade route (block views, skipped rows, scalings) stay with lg_gemm_kernel.
 struct LgAsmArgs {
     const double *X, *Y;
     double *C, *C2;
@@ -648,8 +649,10 @@ struct LgAsmArgs {
     int NP, NB, ncell, herm, nadd, u_if_smax0, per_cell;
     unsigned magic_pc, magic_nb;   // floor(2^32 / d) + 1 of per_cell and NB: the kernel divides by one multiplication
     int pad;
+    const int *s_cell;             // squaring launches: cells with s_cell[cell] <= sq_iter are copied through
+    int sq_iter, sq_mode;          // sq_mode: leave at once when sq_iter >= *smax_ptr, write U when sq_iter == *smax_ptr - 1
 };
-static_assert(sizeof(LgAsmArgs) == 152, "argument block of lg_gemm_asm");
+static_assert(sizeof(LgAsmArgs) == 168, "argument block of lg_gemm_asm");
 bool lg_asm_enabled() {
     const char *e = getenv("GRAPE_LG_ASM");   // (read at every launch: the differential tests switch it between evaluations)
     return !(e && atoi(e) == 0);
@@ -662,8 +665,10 @@ bool lg_try_asm(hipStream_t s, const LgGemmArgs &a, hipError_t *err) {
     if (!lg_asm_enabled()) return false;
     const int NP = a.C.ld, NB = a.nbi;
     if ((NP != 128 && NP != 256) || a.nbj != NB || a.kblocks != NB || NB * 64 != NP) return false;
-    if (a.alpha != 1.0 || a.beta != 0.0 || a.cI != 0.0 || a.cI2 != 0.0 || a.s_cell || a.scale_s || a.skip_bi != -1 || a.nadd > 2) return false;
-    if (a.smax_ptr && !a.u_if_smax0) return false;
+    if (a.alpha != 1.0 || a.beta != 0.0 || a.cI != 0.0 || a.cI2 != 0.0 || a.scale_s || a.skip_bi != -1 || a.nadd > 2) return false;
+    const bool squaring = a.s_cell != nullptr;                  // (launch `sq_iter` of the squaring plan)
+    if (squaring && (a.nadd || a.herm || a.C2.p || a.u_if_smax0)) return false;
+    if (a.smax_ptr && !a.u_if_smax0 && !squaring) return false;
     if (a.herm && (a.nadd || a.Uout || a.C2.p)) return false;
     if (a.Uout && a.u_np != NP) return false;
     if (!lg_full_view(a.X, NP) || !lg_full_view(a.Y, NP) || !lg_full_view(a.C, NP)) return false;
@@ -677,6 +682,7 @@ bool lg_try_asm(hipStream_t s, const LgGemmArgs &a, hipError_t *err) {
     for (int i = 0; i < a.nadd; ++i) { k.coef[i] = a.coef[i]; k.coef2[i] = a.coef2[i]; }
     k.NP = NP; k.NB = NB; k.ncell = a.ncell; k.herm = a.herm; k.nadd = a.nadd; k.u_if_smax0 = a.u_if_smax0;
     k.per_cell = a.herm ? NB * (NB + 1) / 2 : NB * NB;
+    k.s_cell = a.s_cell; k.sq_iter = a.sq_iter; k.sq_mode = (squaring && a.smax_ptr) ? 1 : 0;
     k.magic_pc = (unsigned)((1ull << 32) / (unsigned)k.per_cell + 1);
     k.magic_nb = (unsigned)((1ull << 32) / (unsigned)NB + 1);
     const int groups = (a.ncell + 7) / 8;

@@ -27,7 +27,7 @@ def unplanar(P):
     return P[:, 0] + 1j * P[:, 1]
 
 
-def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False, uif=0, smax=0):
+def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False, uif=0, smax=0, s_cell=None, sq_iter=0):
     ncell, NB = X.shape[0], NP // 64
     g = gcn.GlobalMem()
     a_X, _ = g.add("X", planar(X))
@@ -42,8 +42,12 @@ def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False
     cf = list(coef) + [0.0] * (2 - len(coef))
     cf2 = list(coef2) + [0.0] * (2 - len(coef2))
     per_cell = NB * (NB + 1) // 2 if herm else NB * NB
-    karg = struct.pack("<8Q6d8iIi", a_X, a_Y, a_C, a_C2, a_add[0], a_add[1], a_U, a_s, cf[0], cf[1], cf2[0], cf2[1], 0.0, 0.0,
-                       NP, NB, ncell, herm, len(adds), uif, per_cell, (1 << 32) // per_cell + 1, ((1 << 32) // NB + 1) & 0xFFFFFFFF, 0)
+    a_sc = 0
+    if s_cell is not None:
+        a_sc, _ = g.add("s_cell", np.asarray(s_cell, np.int32))
+    karg = struct.pack("<8Q6d8iIiQii", a_X, a_Y, a_C, a_C2, a_add[0], a_add[1], a_U, a_s, cf[0], cf[1], cf2[0], cf2[1], 0.0, 0.0,
+                       NP, NB, ncell, herm, len(adds), uif, per_cell, (1 << 32) // per_cell + 1, ((1 << 32) // NB + 1) & 0xFFFFFFFF, 0,
+                       a_sc, sq_iter, 1 if s_cell is not None else 0)
     assert len(karg) == gen_lg.KERNARG
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     groups = (ncell + 7) // 8
@@ -107,7 +111,7 @@ def test_epilogue_terms_second_output_and_grid_mapping(program):
     assert np.abs(C - ref).max() < 4e-15 and np.abs(C2 - (ref + B3)).max() < 4e-15
     # a workgroup whose cell does not exist
     g = gcn.GlobalMem()
-    karg = struct.pack("<8Q6d8iIi", *([0] * 8), *([0.0] * 6), NP, 2, 2, 0, 0, 0, 4, (1 << 32) // 4 + 1, (1 << 32) // 2 + 1, 0)
+    karg = struct.pack("<8Q6d8iIiQii", *([0] * 8), *([0.0] * 6), NP, 2, 2, 0, 0, 0, 4, (1 << 32) // 4 + 1, (1 << 32) // 2 + 1, 0, 0, 0, 0)
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     e = gcn.Emu(prog, g, a_k, wg_id=5, lds_bytes=gen_lg.LDS_BYTES)
     assert e.run() < 10000 and e.mfma_count == 0
@@ -125,3 +129,19 @@ def test_last_product_goes_to_u_unless_a_cell_needs_a_squaring(program, smax):
         assert np.abs(U - ref).max() < 4e-15 and np.isnan(C.real).all()
     else:
         assert np.abs(C - ref).max() < 4e-15 and np.isnan(U.real).all()
+
+
+def test_squaring_launches_copy_finished_cells_through_and_follow_the_device_side_count(program):
+    """the plan of squaring launches (expm_large_t18): launch `it` squares the cells with s_cell > it and copies the others,
+    leaves at once when it >= *smax_ptr, and writes U when it is the last one needed"""
+    _, prog, _ = program
+    rng = np.random.default_rng(4)
+    NP = 128
+    X = rnd(rng, 2, NP)
+    C, _, U, mf = run(prog, NP, X, X, uout=True, smax=2, s_cell=[0, 2], sq_iter=0)
+    assert np.abs(C[0] - X[0]).max() == 0.0 and np.abs(C[1] - X[1] @ X[1]).max() < 4e-15 and np.isnan(U.real).all()
+    assert mf == 4 * 4 * 4 * 96                          # one cell squared: 4 blocks x 4 waves x 4 k-blocks x 96
+    C, _, U, _ = run(prog, NP, X, X, uout=True, smax=2, s_cell=[0, 2], sq_iter=1)
+    assert np.abs(U[0] - X[0]).max() == 0.0 and np.abs(U[1] - X[1] @ X[1]).max() < 4e-15 and np.isnan(C.real).all()
+    C, _, U, mf = run(prog, NP, X, X, uout=True, smax=2, s_cell=[0, 2], sq_iter=2)
+    assert np.isnan(C.real).all() and np.isnan(U.real).all() and mf == 0
