@@ -29,7 +29,7 @@ import struct
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gcn import Prog, Reg, V, A, S, VCC, EXEC, Neg, Abs, kernel_text  # noqa: E402
+from gcn import Prog, V, A, S, VCC, EXEC, Neg, kernel_text  # noqa: E402
 
 NT = 4
 NP = 64

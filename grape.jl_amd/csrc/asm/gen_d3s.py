@@ -22,7 +22,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gcn import Prog, Reg, V, A, S, VCC, EXEC, M0, Neg, kernel_text  # noqa: E402
+from gcn import V, S, VCC, EXEC, M0, Neg, kernel_text  # noqa: E402
 from gen_d3 import GenD3, tile_index, dbits, NT, NP, VPLANE_B, KERNARG  # noqa: E402
 
 OP_B = 10 * 4096                 # bytes of an operator in LDS (10 upper tiles x (re, im) x 2 KB)

@@ -25,7 +25,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gcn import Prog, Reg, V, A, S, VCC, EXEC, M0, Neg, kernel_text  # noqa: E402
+from gcn import Prog, V, A, S, M0, Neg, kernel_text  # noqa: E402
 
 KERNARG = 168
 STAGE_B = 32768                  # one k-block of the left operand: [re | im][64 rows][32 columns]

@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "grape.jl_amd", "csrc", "asm"))
 import gcn  # noqa: E402
-from gcn import Prog, V, A, S, M0, EXEC  # noqa: E402
+from gcn import Prog, V, S, M0, EXEC  # noqa: E402
 
 
 def run(p, nwaves=4, data=None):
