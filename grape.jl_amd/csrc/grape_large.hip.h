@@ -392,43 +392,19 @@ struct LgT18OperandsArgs {
     size_t n;          // per_cell * cells
 };
 __global__ void lg_t18_operands_kernel(LgT18OperandsArgs a) {
-    // two elements per thread and iteration (16-byte accesses); NP and per_cell = 2 NP^2 are powers of two on the blocked
-    // path (NP = 128, 256): cell, plane and diagonal by shifts
-    const int lnp = 31 - __clz(a.NP), lpc = 2 * lnp + 1;
-    const size_t n2 = a.n / 2;
-    for (size_t i2 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i2 < n2; i2 += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = 2 * i2;
-        const size_t cell = i >> lpc;
-        const unsigned o = (unsigned)(i & (((size_t)1 << lpc) - 1));
+    const size_t pp = a.per_cell / 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t cell = i / a.per_cell, o = i - cell * a.per_cell;
         const int s = a.s_cell[cell];
         const double f1 = ldexp(1.0, -s), f2 = f1 * f1, f3 = f2 * f1, f6 = f3 * f3;
-        const double2 v1 = *(const double2 *)(a.A + i), v2 = *(const double2 *)(a.A2 + i), v3 = *(const double2 *)(a.A3 + i),
-                      v6 = *(const double2 *)(a.A6 + i);
-        // real plane, row == column: elements o and o + 1 share their row (NP is even)
-        const unsigned row = o >> lnp, col = o & (unsigned)(a.NP - 1);
-        const bool re = (o >> (2 * lnp)) == 0;
-        const bool dg0 = re && row == col, dg1 = re && row == col + 1;
-        double2 b1, b5, b4, b3, b2;
-        {
-            const double x1 = f1 * v1.x, x2 = f2 * v2.x, x3 = f3 * v3.x, x6 = f6 * v6.x;
-            b1.x = a.a[0] * x1 + a.a[1] * x2 + a.a[2] * x3;
-            b5.x = a.e[0] * x2 + a.e[1] * x3 + a.e[2] * x6;
-            b4.x = a.d[1] * x1 + a.d[2] * x2 + a.d[3] * x3 + a.d[4] * x6 + (dg0 ? a.d[0] : 0.0);
-            b3.x = a.c[1] * x1 + a.c[2] * x2 + a.c[3] * x3 + a.c[4] * x6 + (dg0 ? a.c[0] : 0.0);
-            b2.x = a.b[1] * x1 + a.b[2] * x2 + a.b[3] * x3 + a.b[4] * x6 + (dg0 ? a.b[0] : 0.0);
-        }
-        {
-            const double x1 = f1 * v1.y, x2 = f2 * v2.y, x3 = f3 * v3.y, x6 = f6 * v6.y;
-            b1.y = a.a[0] * x1 + a.a[1] * x2 + a.a[2] * x3;
-            b5.y = a.e[0] * x2 + a.e[1] * x3 + a.e[2] * x6;
-            b4.y = a.d[1] * x1 + a.d[2] * x2 + a.d[3] * x3 + a.d[4] * x6 + (dg1 ? a.d[0] : 0.0);
-            b3.y = a.c[1] * x1 + a.c[2] * x2 + a.c[3] * x3 + a.c[4] * x6 + (dg1 ? a.c[0] : 0.0);
-            b2.y = a.b[1] * x1 + a.b[2] * x2 + a.b[3] * x3 + a.b[4] * x6 + (dg1 ? a.b[0] : 0.0);
-        }
-        *(double2 *)(a.B1 + i) = b1; *(double2 *)(a.B5 + i) = b5; *(double2 *)(a.B4 + i) = b4;
-        *(double2 *)(a.B3 + i) = b3; *(double2 *)(a.B2 + i) = b2;
+        const double x1 = f1 * a.A[i], x2 = f2 * a.A2[i], x3 = f3 * a.A3[i], x6 = f6 * a.A6[i];
+        const bool diag = o < pp && (o / a.NP) == (o % a.NP);   // real plane, row == column
+        a.B1[i] = a.a[0] * x1 + a.a[1] * x2 + a.a[2] * x3;
+        a.B5[i] = a.e[0] * x2 + a.e[1] * x3 + a.e[2] * x6;
+        a.B4[i] = a.d[1] * x1 + a.d[2] * x2 + a.d[3] * x3 + a.d[4] * x6 + (diag ? a.d[0] : 0.0);
+        a.B3[i] = a.c[1] * x1 + a.c[2] * x2 + a.c[3] * x3 + a.c[4] * x6 + (diag ? a.c[0] : 0.0);
+        a.B2[i] = a.b[1] * x1 + a.b[2] * x2 + a.b[3] * x3 + a.b[4] * x6 + (diag ? a.b[0] : 0.0);
     }
-}
 }
 // Dinv = inverse of the 64x64 block (jb, jb) of Q, one workgroup per cell (fused-kernel solver, P = I)
 struct LgInvArgs {
