@@ -2612,13 +2612,13 @@ int grape_reset_timings(grape_handle *h) {
 int grape_get_work(grape_handle *h, double *out, int n) {
     if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
     if (!h->shards.empty()) {   // every entry is a count: the shards add up
-        const int m = n < 15 ? n : 15;
+        const int m = n < 17 ? n : 17;
         std::fill(out, out + m, 0.0);
         for (grape_handle *c : h->shards) {
-            double cw[15] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+            double cw[17] = {0.};
             const int rc = grape_get_work(c, cw, m);
             if (rc < 0) return multi_fail(h, c, rc);
-            for (int i = 0; i < m; ++i) out[i] += cw[i];
+            for (int i = 0; i < m; ++i) out[i] = (i == 15 || i == 16) ? cw[i] : out[i] + cw[i];   // ([15], [16]: kernel ids, the same in every shard)
         }
         if (m > 14 && out[14] > 0.0) out[14] = 1.0;   // (a flag, not a count)
         return 4;
@@ -2663,6 +2663,20 @@ int grape_get_work(grape_handle *h, double *out, int n) {
     if (n > 12) out[12] = h->u_fallback ? 1.0 : 0.0;
     if (n > 13) out[13] = (double)st[15];   // cells of [11] that took the four-product degree-16 route
     if (n > 14) out[14] = h->asm16 ? 1.0 : 0.0;   // the four-product route of this handle is the hand-allocated assembly kernel
+    // which derivative kernel the ExpProp route of this handle launches: 0 a compiled one, 1 deriv3_asm, 2 deriv3s_asm (streamed
+    // controls), 3 deriv3g_asm (general operators), 4 deriv4_asm (blocked path); [16]: the products of the blocked polynomial
+    // route are lg_gemm_asm (the two switches that are read per launch are read here)
+    if (n > 15) {
+        double kind = 0.0;
+        if (!h->series && h->d_park3 && h->NT == 4) {
+            const char *e3 = getenv("GRAPE_DERIV3_ASM");
+            if (h->deriv3_general) kind = 3.0;
+            else if (h->L > 2) kind = 2.0;
+            else if (!h->deriv3_h0g && !(e3 && atoi(e3) == 0)) kind = 1.0;
+        } else if (!h->series && h->deriv4_blocks) kind = 4.0;
+        out[15] = kind;
+    }
+    if (n > 16) out[16] = (h->large && !h->series && h->t18 && lg_asm_enabled()) ? 1.0 : 0.0;
     return 4;
 }
 

@@ -135,6 +135,7 @@ def test_derivative_kernel_against_its_twin(g, N, L, N_T, K, kw):
     gs = max(np.abs(b[1]).max(), 1e-3)
     assert np.abs(a[1] - b[1]).max() <= 2e-14 * gs, np.abs(a[1] - b[1]).max() / gs
     assert a[3]["deriv_orders"] == b[3]["deriv_orders"] and a[3]["flop_deriv"] == b[3]["flop_deriv"]
+    assert a[3]["asm_deriv_kernel"] == 1 and b[3]["asm_deriv_kernel"] == 0          # the assembly kernel really ran (no silent twin)
 
 
 def test_derivative_kernel_taylor_route_and_its_order_limit(g):
@@ -188,6 +189,7 @@ def test_streamed_derivative_kernel_against_the_compiled_kernel(g, N, L, N_T, K,
     assert np.abs(a[1] - b[1]).max() <= 5e-14 * gs, np.abs(a[1] - b[1]).max() / gs
     # the four batches of a workgroup stop together: never fewer orders than the per-batch rule, at most one more per batch
     assert b[3]["deriv_orders"] <= a[3]["deriv_orders"] <= b[3]["deriv_orders"] + K * N_T
+    assert a[3]["asm_deriv_kernel"] == 2 and b[3]["asm_deriv_kernel"] == 0
 
 
 def test_streamed_derivative_kernel_order_limit(g):
@@ -228,6 +230,7 @@ def test_blocked_products_against_the_compiled_kernel(g, N, L, N_T, K, dt, herm)
     a = run_lg(g, pr, True)
     b = run_lg(g, pr, False)
     assert np.abs(a[3] - b[3]).max() < 5e-14, np.abs(a[3] - b[3]).max()
+    assert a[4]["asm_blocked_products"] == 1 and b[4]["asm_blocked_products"] == 0
     assert abs(a[0] - b[0]) <= 1e-12 and np.abs(a[1] - b[1]).max() <= 1e-11 * max(np.abs(b[1]).max(), 1e-3)
     if herm:
         uni = max(np.abs(u.conj().T @ u - np.eye(N)).max() for u in a[3])
@@ -271,6 +274,7 @@ def test_general_operator_derivative_kernel_against_the_compiled_kernels(g, N, L
     gs = max(np.abs(b[1]).max(), 1e-3)
     assert np.abs(a[1] - b[1]).max() <= 5e-14 * gs, np.abs(a[1] - b[1]).max() / gs
     assert b[3]["deriv_orders"] <= a[3]["deriv_orders"] <= b[3]["deriv_orders"] + K * N_T
+    assert a[3]["asm_deriv_kernel"] == 3 and b[3]["asm_deriv_kernel"] == 0
 
 
 # ---- blocked path: the derivative kernel as assembly (asm/gen_d4.py) against deriv2_kernel (GRAPE_DERIV4=0, read in
@@ -312,3 +316,4 @@ def test_blocked_derivative_kernel_against_the_compiled_kernel(g, N, L, N_T, K, 
     gs = max(np.abs(b[1]).max(), 1e-3)
     assert np.abs(a[1] - b[1]).max() <= 5e-14 * gs, np.abs(a[1] - b[1]).max() / gs
     assert a[3]["deriv_orders"] == b[3]["deriv_orders"] > 0    # same stopping rule: a batch of 16 cells stops together
+    assert a[3]["asm_deriv_kernel"] == 4 and b[3]["asm_deriv_kernel"] == 0 and a[3]["asm_blocked_products"] == 1
