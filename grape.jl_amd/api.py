@@ -104,8 +104,10 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     # the library cannot be compiled with (see grape_t18.hip); the assembly kernel is generated and assembled (build_asm)
     base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + list(extra_flags)
     objs = [os.path.join(_CSRC, "grape_hip.o"), os.path.join(_CSRC, "grape_t18.o")]
-    cmds = [base + ["-c", srcs[0], "-o", objs[0]],
-            base + ["-mllvm", "-amdgpu-mfma-vgpr-form", "-c", srcs[1], "-o", objs[1]]]
+    # (-cuid: hipcc derives the id of a translation unit -- part of internal symbol names -- from the PATH of its source;
+    # a fixed id makes the library byte-identical wherever the repository is checked out)
+    cmds = [base + ["-cuid=grapehip0", "-c", srcs[0], "-o", objs[0]],
+            base + ["-cuid=grapehip1", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c", srcs[1], "-o", objs[1]]]
     procs = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for c in cmds]
     objs.append(build_asm(verbose))
     outs = [p.communicate()[0] for p in procs]
