@@ -250,6 +250,7 @@ struct LgFormArgs {
 // 1 TB/s for a kernel that only writes; round 3.)
 __global__ void __launch_bounds__(1024) lg_form_kernel(LgFormArgs a) {
     __shared__ double colsum[1024];
+    __shared__ double wmax[4];
     __shared__ double snorm;
     const int tid = threadIdx.x & 255, part = threadIdx.x >> 8, NP = a.NP;
     const int cell = a.cell0 + blockIdx.x;
@@ -293,13 +294,14 @@ __global__ void __launch_bounds__(1024) lg_form_kernel(LgFormArgs a) {
     }
     colsum[threadIdx.x] = tid < NP ? cs : 0.;
     __syncthreads();
-    if (threadIdx.x < 256) colsum[tid] = (colsum[tid] + colsum[256 + tid]) + (colsum[512 + tid] + colsum[768 + tid]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double m = 0.;
-        for (int j = 0; j < NP; ++j) m = fmax(m, colsum[j]);
-        snorm = m;
+    if (threadIdx.x < 256) {   // column sums of the four row parts, then their maximum: waves 0..3 by shuffles, the four waves through LDS
+        double m = tid < NP ? (colsum[tid] + colsum[256 + tid]) + (colsum[512 + tid] + colsum[768 + tid]) : 0.;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) m = fmax(m, __shfl_xor(m, off, 64));
+        if ((tid & 63) == 0) wmax[tid >> 6] = m;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) snorm = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
     __syncthreads();
     const double nA = snorm;
     int s = 0;
