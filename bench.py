@@ -378,7 +378,12 @@ def main():
                                      "model flop / time is not a hardware rate and is not used for the roofline"},
             "deriv_kernel": {"flop_per_launch": work["flop_deriv"], "avg_launch_ms": tm["deriv"],
                              "tflops": work["flop_deriv"] / (tm["deriv"] * 1e-3) * 1e-12 if tm["deriv"] > 0 else None,
-                             "series_orders_per_cell": work["deriv_orders"] / work["cells"]},
+                             "series_orders_per_cell": work["deriv_orders"] / work["cells"],
+                             "kernel": {0: "compiled (deriv3_kernel / deriv2_kernel / deriv_kernel)", 1: "deriv3_asm (csrc/asm/gen_d3.py)",
+                                        2: "deriv3s_asm (streamed controls, csrc/asm/gen_d3s.py)",
+                                        3: "deriv3g_asm (general operators, csrc/asm/gen_d3s.py)",
+                                        4: "deriv4_asm (blocked path, csrc/asm/gen_d4.py)"}.get(int(work.get("asm_deriv_kernel", 0)), "?"),
+                             "blocked_products": "lg_gemm_asm (csrc/asm/gen_lg.py)" if work.get("asm_blocked_products", 0) else None},
             "J": J,
         }
         if not args.no_matrix_free and N <= 256 and world == 1:
