@@ -289,7 +289,8 @@ def main():
         else:
             sweep_kernel = "sweep_coop_kernel (several workgroups per trajectory, forward then backward)"
         if N > 64:
-            expm_kernel = "lg_gemm_kernel chain (blocked path)"
+            expm_kernel = ("lg_gemm_asm" if work.get("asm_blocked_products", 0) else "lg_gemm_kernel") + \
+                          " chain (blocked path: one launch per product of the five-product polynomial)"
         elif work.get("t16_cells", 0.0) > 0.0:
             redone = work["t18_cells"] - work["t16_cells"]
             name = ("expm_t16_asm (hand-allocated gfx950 assembly, csrc/asm/gen_t16.py)" if work.get("asm_kernel", 0.0) > 0.0

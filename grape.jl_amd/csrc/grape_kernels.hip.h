@@ -84,13 +84,18 @@ struct ExpmArgs {
 // values alone (no history of the handle enters: the same pulses take the same route and give the same bits):
 //     ||H_kn dt||_F^2 = dt^2 e^T G_k e,   e = (1, eps_n1 s_n1, .., eps_nL s_nL),   G_k[a][b] = Re tr(O_a^dagger O_b)
 // (Gram matrix of the operators of generator class k, from grape_create), and for a spectrum that fills [-R, R] like a
-// semicircle sum lam^2 = N R^2 / 4, i.e. R_est = 2 ||H dt||_F / sqrt(N).  flags[6] counts the cells with
-// R_est > T16_PLAN_R (NaN included); when they are more than a quarter of the evaluation the four-product kernels leave
-// at once and the five-product launch behind them walks all cells instead of a hand-over list (t16_skipped()).
+// semicircle sum lam^2 = N R^2 / 4, i.e. R_est = 2 ||H dt||_F / sqrt(N).  Spectra of another shape (round 5): the
+// estimate is multiplied by kappa = sum_a |e_a| f_a kappa_a / sum_a |e_a| f_a, f_a = ||O_a||_F, kappa_a the shape factor
+// of operator a from grape_create -- the ratio of its Schatten-8 norm (the quantity the kernel's bound tests) to the
+// value a semicircle of the same Frobenius norm would have: 1 for the ensembles of the benchmarks, >> 1 for a low-rank
+// control on a weak drift (the route is then NOT tried in vain every evaluation), 0.72 for a two-point spectrum.
+// flags[6] counts the cells with kappa R_est > T16_PLAN_R (NaN included); when they are more than a quarter of the
+// evaluation the four-product kernels leave at once and the five-product launch behind them walks all cells instead of
+// a hand-over list (t16_skipped()).
 // The estimate decides speed only: a cell it lets through is still certified (or handed over) by the kernel's own bound.
 #define T16_PLAN_R 1.15   // the kernel's bound m8^(1/8) is 3.5^(1/8) = 1.17 R for a semicircle: 1.17 * 1.15 * 1.01 < 1.36
 struct T16PlanArgs {
-    const double *gram;   // [KC][(L + 1)^2]
+    const double *gram;   // [KC][(L + 1)^2 + (L + 1)]: Gram matrix | shape factors
     const double *eps, *shape, *dts;
     int *flags;
     int KC, L, N_T, N;
@@ -100,15 +105,18 @@ __global__ void __launch_bounds__(256) t16_plan_kernel(T16PlanArgs a) {
     bool out = false;
     if (cell < a.KC * a.N_T) {
         const int kc = cell / a.N_T, n = cell - kc * a.N_T, M = a.L + 1;
-        const double *G = a.gram + (size_t)kc * M * M;
+        const double *G = a.gram + (size_t)kc * (M * M + M), *kap = G + M * M;
         double e[9];
         e[0] = 1.0;
         for (int l = 0; l < a.L; ++l) e[1 + l] = a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0);
-        double m2 = 0.;
-        for (int i = 0; i < M; ++i)
+        double m2 = 0., wk = 0., w = 0.;
+        for (int i = 0; i < M; ++i) {
             for (int j = 0; j < M; ++j) m2 += e[i] * e[j] * G[i * M + j];
+            const double wi = fabs(e[i]) * sqrt(fmax(G[i * M + i], 0.0));
+            w += wi; wk += wi * kap[i];
+        }
         const double dt = a.dts[n];
-        const double r = 2.0 * fabs(dt) * sqrt(fmax(m2, 0.0) / (double)a.N);
+        const double r = 2.0 * fabs(dt) * sqrt(fmax(m2, 0.0) / (double)a.N) * (w > 0.0 ? wk / w : 1.0);
         out = !(r <= T16_PLAN_R);
     }
     const unsigned long long m = __ballot(out);

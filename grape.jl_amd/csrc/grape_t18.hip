@@ -53,7 +53,7 @@ namespace { hipError_t launch_d3_asm(const Deriv3Args &a, hipStream_t s, int blo
 
 // derivative overlaps, one wave per batch (grape_deriv3.hip.h): Hermitian operators whose upper tiles fit the LDS
 extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, const double *H0f, const double *Hcf, int wpt,
-                                   int skip_if_flagged, int h0_general, void *stream, int blocks) {
+                                   int skip_if_flagged, int h0_general, int asm_ok, void *stream, int blocks) {
     if (d2size != sizeof(Deriv2Args)) return (int)hipErrorInvalidValue;
     Deriv3Args a;
     memcpy(&a.d, d2args, sizeof(a.d));
@@ -86,11 +86,10 @@ extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, co
         return (int)launch_d3_asm(a, s, blocks);
     }
     if (NT == 4 && L <= 2) {
-        // four tiles per side: the hand-allocated assembly kernel (asm/gen_d3.py); GRAPE_DERIV3_ASM=0 keeps the compiled
-        // kernel (same series, same stopping rule -- the differential tests run both)
-        const char *env = getenv("GRAPE_DERIV3_ASM");
-        const bool use_asm = !(env && atoi(env) == 0);
-        if (use_asm && !skip_if_flagged && !a.d.gpark) return (int)launch_d3_asm(a, s, blocks);
+        // four tiles per side: the hand-allocated assembly kernel (asm/gen_d3.py); GRAPE_DERIV3_ASM=0 (read once in
+        // grape_create and handed down as asm_ok) keeps the compiled kernel (same series, same stopping rule -- the
+        // differential tests run both)
+        if (asm_ok && !skip_if_flagged && !a.d.gpark) return (int)launch_d3_asm(a, s, blocks);
         return (int)(L == 1 ? launch_d3<4, 1>(a, s, blocks) : launch_d3<4, 2>(a, s, blocks));
     }
     return (int)hipErrorInvalidValue;

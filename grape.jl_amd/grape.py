@@ -354,9 +354,14 @@ class GrapeWrk:
         elif custom:
             inner_wrap = wrap
             wrap = lambda b: inner_wrap(_CustomChiBackend(b, J_T, self.kwargs["chi"], trajs))  # noqa: E731
-        targets = [t.target_state if t.target_state is not None else np.zeros_like(t.initial_state) for t in trajs]
+        # trajectories without a target_state (optimize.jl:753: tau = NaN; legal with a user-defined J_T / chi): no target
+        # array crosses the boundary.  A mix of trajectories with and without one keeps zeros in the gaps.
+        if custom and all(t.target_state is None for t in trajs):
+            targets = None
+        else:
+            targets = np.stack([t.target_state if t.target_state is not None else np.zeros_like(t.initial_state) for t in trajs])
         return wrap(api.GrapeHip(H0, Hc, self.tlist, np.stack([t.initial_state for t in trajs]),
-                            np.stack(targets),
+                            targets,
                             prop_method=prop, prop_tolerance=self.kwargs.get("prop_tolerance", 0.0), shape=shape,
                             weights=np.array([t.weight for t in trajs], dtype=np.float64),
                             functional=_FUNCTIONAL_CODE.get(J_T, api.J_T_SM), gradient_method=method,
@@ -364,6 +369,7 @@ class GrapeWrk:
                             chi_min_norm=self.kwargs.get("chi_min_norm", 0.0),
                             taylor_max_order=self.kwargs.get("taylor_grad_max_order", 0),
                             taylor_tolerance=self.kwargs.get("taylor_grad_tolerance", 0.0),
+                            taylor_check_convergence=self.kwargs.get("taylor_grad_check_convergence", True),  # optimize.jl:917-918
                             device=self.kwargs.get("device", 0),
                             # g_b / xi of the expectation-value family (test_state_running_cost.jl:32-40):
                             # g_b = <Psi|D|Psi>, xi = -D Psi, given as the operator D itself

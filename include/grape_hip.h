@@ -15,7 +15,10 @@
  *
  * Conventions
  *   - plain C, no exceptions, no torch types; every function returns 0 on success or a negative
- *     grape_status; the message of the last failure is available from grape_last_error().
+ *     grape_status; the message of the last failure is available from grape_last_error().  Every entry point is an
+ *     exception barrier: a C++ exception raised by the host side (std::bad_alloc of a staging vector, std::system_error
+ *     of a shard thread) is caught inside the library, everything the call had allocated is released, and the caller
+ *     (a Julia process behind `ccall`) sees GRAPE_ERR_HOST with the exception's message -- never std::terminate.
  *   - complex numbers are interleaved (re, im) doubles == Julia ComplexF64 == C double _Complex.
  *   - matrices are COLUMN-major N x N (Julia Matrix{ComplexF64}); states are length-N vectors.
  *   - pulsevals / G are CONTROL-major: index (l * N_T + n), l < L, n < N_T
@@ -44,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GRAPE_HIP_ABI_VERSION 5
+#define GRAPE_HIP_ABI_VERSION 6
 
 typedef struct grape_handle grape_handle;
 
@@ -56,9 +59,11 @@ typedef enum {
     GRAPE_ERR_SINGULAR = -4,     /* Pade denominator numerically singular                    */
     GRAPE_ERR_TAYLOR = -5,       /* Taylor derivative series did not converge (optimize.jl:644-648) */
     GRAPE_ERR_NO_CONTROLS = -6,  /* L == 0                             (workspace.jl:155-157)*/
-    GRAPE_ERR_AGAIN = -7         /* device-pointer API, N > 64 only: the asynchronous launch plan (number of squaring
+    GRAPE_ERR_AGAIN = -7,        /* device-pointer API, N > 64 only: the asynchronous launch plan (number of squaring
                                     launches) was too short for this evaluation and has been adapted -- repeat the call.
                                     The host-pointer entry points repeat internally and never return this.          */
+    GRAPE_ERR_HOST = -8          /* ABI v6: a host-side C++ exception (out of memory, thread creation) was caught at the
+                                    boundary; nothing of the call is left allocated, the handle (if any) stays usable */
 } grape_status;
 
 /* J_T of QuantumControl.Functionals (docs/src/tutorial.md:349-356, 402) */
@@ -106,7 +111,10 @@ typedef struct {
     const double *Hc;        /* control operators mu_l = dH/d eps_l (see hc_per_traj)           */
     const double *shape;     /* NULL or [L][N_T] real: a_l(eps, t_n) = shape[l][n] * eps_{nl}   */
     const double *psi0;      /* [K][N] complex initial states                                   */
-    const double *target;    /* [K][N] complex target states                                    */
+    const double *target;    /* [K][N] complex target states.  ABI v6: NULL = trajectories without a target_state
+                                (optimize.jl:753: tau_k = NaN) -- legal only with a caller-side J_T / chi pair, i.e.
+                                grape_forward + grape_get_final_states + grape_backward_chi / _xi(chi != NULL);
+                                grape_eval, grape_backward and the built-in functionals need the targets and refuse */
     const double *weights;   /* NULL (all 1) or [K]                                             */
     double chi_min_norm;     /* <= 0 selects the reference default 1e-100 (optimize.jl:846)     */
     int32_t taylor_max_order;/* <= 0 selects 100   (optimize.jl:915)                            */
@@ -125,6 +133,13 @@ typedef struct {
      * device, device+1, ...  An ordinal may repeat (several shards on one GPU).                  */
     int32_t ndev;
     const int32_t *devices;  /* NULL or [ndev] HIP device ordinals                              */
+    /* ABI v6: taylor_grad_check_convergence (optimize.jl:917-918, taylor_grad_step! :611, :631-651).  0 = the reference
+     * default `true`: gradient_method = GRAPE_GRAD_TAYLOR raises GRAPE_ERR_TAYLOR when a series has not reached
+     * taylor_tolerance within taylor_max_order terms.  1 = `check_convergence = false`: the series is cut at
+     * taylor_max_order terms and NO error is raised (terms below taylor_tolerance are still skipped: each of them changes
+     * the result by less than the tolerance; the series kernels of N > 32 hold at most 64 terms -- a larger
+     * taylor_max_order that is actually reached there is reported, not silently cut).  Ignored by GRAPE_GRAD_GRADGEN. */
+    int32_t taylor_no_check;
 } grape_problem;
 
 /* Replaces GrapeWrk(...) data set-up: /root/reference/src/workspace.jl:147-362 */

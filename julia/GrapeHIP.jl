@@ -15,7 +15,7 @@ using QuantumControl.QuantumPropagators.Amplitudes: ShapedAmplitude
 using QuantumControl.Functionals: J_T_sm, J_T_ss, J_T_re
 
 const libgrape = get(ENV, "GRAPE_HIP_LIB", "libgrape_hip.so")
-const ABI_VERSION = 5
+const ABI_VERSION = 6
 
 # mirror of `grape_problem` (include/grape_hip.h); field order and types must match the C struct
 # (tests/test_abi.py compares the field lists)
@@ -47,6 +47,7 @@ struct GrapeProblem
     prop_tolerance::Float64  # <= 0: 1e-17
     ndev::Int32              # > 1: the trajectories are dealt to several GPUs behind this one handle
     devices::Ptr{Int32}      # C_NULL: device, device+1, ...
+    taylor_no_check::Int32   # ABI v6: 1 = taylor_grad_check_convergence = false (optimize.jl:917-918)
 end
 
 mutable struct Handle
@@ -137,7 +138,8 @@ end
 
 Uploads the static problem of a `GrapeWrk` (replaces the buffer set-up of src/workspace.jl:147-362).  Options are
 taken from `wrk.kwargs` exactly where the reference reads them: `gradient_method` (workspace.jl:150), `chi_min_norm`
-(optimize.jl:846), `taylor_grad_max_order` / `taylor_grad_tolerance` (optimize.jl:915-916), `lambda_b` (:833).
+(optimize.jl:846), `taylor_grad_max_order` / `taylor_grad_tolerance` / `taylor_grad_check_convergence` (optimize.jl:915-918),
+`lambda_b` (:833).
 `D` (one matrix or one per trajectory) selects the state running cost of the family `g_b(Ψ) = ⟨Ψ|D|Ψ⟩`, `ξ = −DΨ`
 (test/test_state_running_cost.jl:32-40).  `devices = [0, 1, ...]` spreads the trajectories over several GPUs behind this
 one handle -- the analogue of `use_threads` (optimize.jl:720, 876).
@@ -150,7 +152,9 @@ function Handle(wrk; device = 0, devices = nothing, prop_method = 0, D = nothing
     H0f = reduce(hcat, vec.(H0))                                            # [N*N, K]: K column-major matrices
     Hcf = hc_per_traj ? reduce(hcat, [reduce(hcat, vec.(Hc[k])) for k = 1:K]) : reduce(hcat, vec.(Hc[1]))
     p0 = reduce(hcat, [Vector{ComplexF64}(t.initial_state) for t in wrk.trajectories])
-    tg = reduce(hcat, [Vector{ComplexF64}(t.target_state) for t in wrk.trajectories])
+    # trajectories without a target_state (optimize.jl:753: tau = NaN, legal with a user J_T): no target array at all
+    has_tgt = all(t -> !isnothing(t.target_state), wrk.trajectories)
+    tg = has_tgt ? reduce(hcat, [Vector{ComplexF64}(t.target_state) for t in wrk.trajectories]) : nothing
     weights = Float64[hasproperty(t, :weight) ? t.weight : 1.0 for t in wrk.trajectories]
     shp = isnothing(shape) ? nothing : Matrix{Float64}(shape)               # [N_T, L] column-major == [l][n]
     Df = isnothing(D) ? nothing : (D isa AbstractMatrix ? Matrix{ComplexF64}(D) : reduce(hcat, vec.(Matrix{ComplexF64}.(D))))
@@ -160,11 +164,12 @@ function Handle(wrk; device = 0, devices = nothing, prop_method = 0, D = nothing
     prob = Ref(GrapeProblem(
         ABI_VERSION, N, L, K, 0, N_T, max(functional, 0),
         get(kw, :gradient_method, :gradgen) == :taylor ? 1 : 0, hc_per_traj ? 1 : 0, device,
-        pointer(tlist), pointer(H0f), pointer(Hcf), isnothing(shp) ? C_NULL : pointer(shp), pointer(p0), pointer(tg),
+        pointer(tlist), pointer(H0f), pointer(Hcf), isnothing(shp) ? C_NULL : pointer(shp), pointer(p0), isnothing(tg) ? C_NULL : pointer(tg),
         pointer(weights), get(kw, :chi_min_norm, 0.0), get(kw, :taylor_grad_max_order, 0),
         get(kw, :taylor_grad_tolerance, 0.0), isnothing(Df) ? C_NULL : pointer(Df),
         (D isa AbstractMatrix || isnothing(D)) ? 0 : 1, isnothing(D) ? 0.0 : get(kw, :lambda_b, 1.0), prop_method, 0.0,
-        isnothing(devs) ? 0 : length(devs), isnothing(devs) ? C_NULL : pointer(devs)))
+        isnothing(devs) ? 0 : length(devs), isnothing(devs) ? C_NULL : pointer(devs),
+        get(kw, :taylor_grad_check_convergence, true) ? 0 : 1))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = GC.@preserve keep ccall((:grape_create, libgrape), Cint, (Ref{Ptr{Cvoid}}, Ref{GrapeProblem}), out, prob)
     rc == 0 || error(last_error(C_NULL))

@@ -152,7 +152,7 @@ def evaluate_functional(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
 
 def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
                       functional=FUNCTIONAL_SM, gradient_method="gradgen", shape=None,
-                      taylor_max_order=100, taylor_tol=1e-16, return_parts=False,
+                      taylor_max_order=100, taylor_tol=1e-16, taylor_check_convergence=True, return_parts=False,
                       K_total=None, f_total=None, D=None, lambda_b=1.0, g_b=None, xi=None):
     """optimize.jl:824-1014.  Returns (J, G, tau[, parts]).  State running cost: the operator D of the <Psi|D|Psi> family,
     or the callbacks ``g_b(psi, k, n)`` and ``xi(psi, k, n)`` = -d g_b / d<Psi| (optimize.jl:856-866, 897-908 call
@@ -213,7 +213,8 @@ def evaluate_gradient(H0, Hc, tlist, pulsevals, psi0, target, weights=None,
                 for l in range(L):
                     mu = Hck[l] if sc is None else sc[l] * Hck[l]
                     chi_l = taylor_grad_step(chik, Hdag, mu.conj().T, -dt,
-                                             max_order=taylor_max_order, tolerance=taylor_tol)  # :957-969
+                                             max_order=taylor_max_order, tolerance=taylor_tol,
+                                             check_convergence=taylor_check_convergence)  # :917-918, :957-969
                     tau_grads[k, n, l] = rho[k] * np.vdot(chi_l, psi)  # :970
                 chik = expm(-1j * Hdag * (-dt)) @ chik  # :972
             else:

@@ -364,9 +364,20 @@ static void build_H(int N, int L, const cplx *H0k, const cplx *Hck, const double
     }
 }
 
-/* restatement of taylor_grad_step! (src/optimize.jl:604-653); mats column-major; tmp: 4*N */
+/* taylor_grad_max_order / taylor_grad_tolerance / taylor_grad_check_convergence of the reference
+ * (src/optimize.jl:914-918: defaults 100, 1e-16, true), set by the tests that vary them */
+static int taylor_max_order = 100, taylor_check = 1;
+static double taylor_tol = 1e-16;
+void grape_ref_set_taylor(int max_order, double tol, int check_convergence) {
+    taylor_max_order = max_order > 0 ? max_order : 100;
+    taylor_tol = tol > 0 ? tol : 1e-16;
+    taylor_check = check_convergence != 0;
+}
+
+/* restatement of taylor_grad_step! (src/optimize.jl:604-653); mats column-major; tmp: 4*N.
+ * check == 0 (check_convergence = false, :631, :644-651): all max_order terms, no residual test, no error */
 static int taylor_grad_step(int N, cplx *out, const cplx *psi, const cplx *H, const cplx *mu,
-                            double dt, cplx *tmp, int max_order, double tol) {
+                            double dt, cplx *tmp, int max_order, double tol, int check) {
     cplx *phi = tmp, *phi_prev = tmp + N, *Hn = tmp + 2 * N, *Hn1 = tmp + 3 * N;
     cplx *scratch = (cplx *)malloc(sizeof(cplx) * N);
     zgemv_n(N, mu, psi, phi_prev);
@@ -381,12 +392,13 @@ static int taylor_grad_step(int N, cplx *out, const cplx *psi, const cplx *H, co
         for (int i = 0; i < N; ++i) { phi[i] += scratch[i]; }
         alpha *= -I * dt / n;
         for (int i = 0; i < N; ++i) { out[i] += alpha * phi[i]; nrm += creal(phi[i]) * creal(phi[i]) + cimag(phi[i]) * cimag(phi[i]); }
-        if (cabs(alpha) * sqrt(nrm) < tol) { converged = 1; break; }
+        if (check && cabs(alpha) * sqrt(nrm) < tol) { converged = 1; break; }
         zgemv_n(N, H, Hn1, Hn);
         cplx *t = Hn; Hn = Hn1; Hn1 = t;
         t = phi; phi = phi_prev; phi_prev = t;
     }
     free(scratch);
+    if (!check || max_order <= 1) return 0;   /* :644-651 */
     return converged ? 0 : -2;
 }
 
@@ -591,7 +603,7 @@ static int grape_ref_eval_gb(int N, int L, int K, int N_T, const double *tlist, 
                     memcpy(chi, ext2 + (size_t)L * N, sizeof(cplx) * N);
                 } else {
                     for (int l = 0; l < L; ++l) {
-                        if (taylor_grad_step(N, ext, chi, Hdag, mudag + (size_t)l * nn, -dt, tmp, 100, 1e-16)) err = -2;
+                        if (taylor_grad_step(N, ext, chi, Hdag, mudag + (size_t)l * nn, -dt, tmp, taylor_max_order, taylor_tol, taylor_check)) err = -2;
                         cplx d = 0;
                         for (int i = 0; i < N; ++i) d += conj(ext[i]) * psi[i];
                         tg[((size_t)k * L + l) * N_T + n] = rho * d; /* :970 */

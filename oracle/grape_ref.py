@@ -37,6 +37,12 @@ def lib():
     return _lib
 
 
+def set_taylor(max_order=100, tolerance=1e-16, check_convergence=True):
+    """taylor_grad_max_order / _tolerance / _check_convergence of the reference (optimize.jl:914-918) for the calls that
+    follow (process-wide, like set_balance); call without arguments to restore the defaults."""
+    lib().grape_ref_set_taylor(C.c_int(int(max_order)), C.c_double(float(tolerance)), C.c_int(int(bool(check_convergence))))
+
+
 def expm(A):
     A = np.asarray(A, dtype=np.complex128)
     n = A.shape[0]

@@ -398,3 +398,121 @@ def test_composite_handle_reduces_with_rccl(g, monkeypatch):
         J3, G3, _ = h.eval(pr["pulsevals"])
         assert "gradient_allreduce_us" not in h.timings()
     assert abs(J3 - J0) <= 1e-13 and np.abs(G3 - G0).max() <= 1e-13 * max(np.abs(G0).max(), 1e-3)
+
+
+# ---- ABI v6 (round 5) ----
+def test_trajectories_without_target_states(g, ref):
+    """grape_problem.target == NULL (optimize.jl:753: tau_k = NaN, legal with a user-defined J_T): the caller-side route
+    forward + final_states + backward_chi works and equals the oracle's; everything that needs a target refuses loudly."""
+    from grape_jl_amd import synth
+    for N, L, K, N_T, herm in [(6, 2, 3, 7, True), (64, 2, 4, 6, True), (20, 1, 2, 9, False), (100, 2, 2, 4, True)]:
+        pr = synth.make_problem(N, L, N_T, K, seed=4321 + N, hermitian=herm)
+        J_T, chi = observable_functional(N, K, seed=N)
+        x = pr["pulsevals"]
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], None) as h:
+            tau = h.forward(x)
+            assert np.isnan(tau).all()
+            assert np.isnan(h.sums()[:4]).all()
+            psiT = h.final_states()
+            G = h.backward_chi(np.stack(chi(psiT)))
+            for call in (lambda: h.eval(x), lambda: h.backward(1.0 + 0j)):
+                with pytest.raises(g.GrapeHipError) as ei:
+                    call()
+                assert ei.value.code == -1 and "target" in str(ei.value)
+        args = (pr["H0"], pr["Hc"], pr["tlist"])
+        _, _, _, parts = ref.evaluate(*args, x, pr["psi0"], pr["target"], None, gradient=False, want_parts=True)
+        Gc, _, psiTc, _ = ref.evaluate_chi(*args, x, pr["psi0"], pr["target"], np.stack(chi(parts["psiT"])))
+        assert np.abs(psiT - psiTc).max() <= 1e-12
+        assert np.abs(G - Gc).max() <= tol_G(Gc)
+
+
+def test_custom_functional_without_targets_through_the_mirror(g):
+    """Trajectory(initial_state, generator) without target_state + user J_T / chi: the mirror hands no target array over"""
+    from grape_jl_amd import grape as G
+    H = G.hamiltonian(np.array([[-0.5, 0], [0, 0.5]]), (np.array([[0, 1], [1, 0]]), lambda t: 0.2))
+    tlist = np.linspace(0, 5, 201)
+    traj = G.Trajectory(np.array([1, 0], complex), H)
+    P0 = np.array([[1, 0], [0, 0]], complex)
+    res = G.optimize([traj], tlist, J_T=lambda Psi, tr, tau=None: float(np.real(np.vdot(Psi[0], P0 @ Psi[0]))),
+                     chi=lambda Psi, tr, tau=None: [-(P0 @ Psi[0])], iter_stop=8)
+    assert res.J_T < 1e-3, res
+    assert np.isnan(res.tau_vals).all()
+
+
+@pytest.mark.parametrize("N,L,K,N_T", [(10, 1, 2, 6), (24, 2, 3, 8), (64, 2, 2, 5), (48, 1, 2, 5)])
+def test_taylor_grad_check_convergence_false(g, ref, N, L, K, N_T):
+    """taylor_grad_check_convergence = false (optimize.jl:917-918, taylor_grad_step! :631-651): a series cut at
+    taylor_grad_max_order is not an error and the truncated sum is what the reference returns -- against the C restatement
+    with the same three settings.  With the check on the same call raises, as the reference does (:644-648)."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=99 + N)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    x = pr["pulsevals"]
+    try:
+        for order in (6, 40):      # 6: every series is cut (||H dt|| ~ 1 needs ~19 terms); 40: none is
+            ref.set_taylor(order, 1e-16, False)
+            Jr, Gr, _ = ref.evaluate(*args[:3], x, *args[3:], gradient_method=1)
+            with g.GrapeHip(*args, gradient_method=g.GRAD_TAYLOR, taylor_max_order=order, taylor_check_convergence=False) as h:
+                J, G, _ = h.eval(x)
+            assert abs(J - Jr) <= 1e-12
+            assert np.abs(G - Gr).max() <= tol_G(Gr), (order, np.abs(G - Gr).max())
+        ref.set_taylor()
+        _, Gfull, _ = ref.evaluate(*args[:3], x, *args[3:], gradient_method=1)
+        assert np.abs(Gr - Gfull).max() <= tol_G(Gfull)             # 40 terms had converged
+        ref.set_taylor(6, 1e-16, False)
+        _, G6, _ = ref.evaluate(*args[:3], x, *args[3:], gradient_method=1)
+        assert np.abs(G6 - Gfull).max() > 1e3 * tol_G(Gfull)        # ... and 6 had not: the test above pinned a truncated sum
+    finally:
+        ref.set_taylor()
+    with g.GrapeHip(*args, gradient_method=g.GRAD_TAYLOR, taylor_max_order=6) as h:
+        with pytest.raises(g.GrapeHipError, match="GRAPE_ERR_TAYLOR"):
+            h.eval(x)
+
+
+def test_exception_barrier_with_device_memory_in_flight(g, monkeypatch):
+    """a C++ exception at the END of grape_create -- the handle owns its device buffers, streams and events by then --
+    comes back as GRAPE_ERR_HOST and leaks nothing: free device memory returns to where it was, and the next create works"""
+    import torch
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 2, 200, 16, seed=8)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    with g.GrapeHip(*args) as h:                       # (runtime warm: module loads, pools)
+        h.eval(pr["pulsevals"])
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    monkeypatch.setenv("GRAPE_TEST_HOOKS", "1")
+    monkeypatch.setenv("GRAPE_TEST_THROW_AT", "late")
+    monkeypatch.setenv("GRAPE_TEST_THROW", "bad_alloc")
+    for devices in (None, [0, 0]):                     # plain handle; composite handle (the second shard's create throws too)
+        with pytest.raises(g.GrapeHipError) as ei:
+            g.GrapeHip(*args, devices=devices)
+        assert ei.value.code == -8 and "bad_alloc" in str(ei.value)
+    monkeypatch.delenv("GRAPE_TEST_HOOKS")
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) <= 64 << 20      # 16 x 200 propagators alone are 210 MB
+    with g.GrapeHip(*args) as h:
+        J, G, _ = h.eval(pr["pulsevals"])
+        assert np.isfinite(J) and np.isfinite(G).all()
+
+
+def test_composite_handle_validates_its_first_collective(g, monkeypatch):
+    """the first evaluation of a handle that reduces with RCCL also takes the host-staged sums and compares (advisor
+    finding of round 4: the collective path had never been checked against anything); a second handle on the same device
+    list reuses the cached communicator set"""
+    import time
+    from grape_jl_amd import synth
+    pr = synth.make_problem(16, 1, 10, 4, seed=2)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    monkeypatch.setenv("GRAPE_MULTI_RCCL", "1")
+    t0 = time.perf_counter()
+    with g.GrapeHip(*args, devices=[0]) as h:
+        J1, G1, _ = h.eval(pr["pulsevals"])
+        rccl = "gradient_allreduce_us" in h.timings()
+    t1 = time.perf_counter()
+    with g.GrapeHip(*args, devices=[0]) as h:
+        J2, G2, _ = h.eval(pr["pulsevals"])
+    t2 = time.perf_counter()
+    if not rccl:
+        pytest.skip("RCCL could not be loaded / initialised on this box")
+    assert J1 == J2 and np.array_equal(G1, G2)
+    assert (t2 - t1) < (t1 - t0)                         # no second communicator initialisation
