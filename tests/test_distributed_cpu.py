@@ -134,6 +134,78 @@ def test_again_is_decided_by_all_ranks_together():
     assert got == [(0, True, False), (1, True, False)]
 
 
+class _AgainOracleShard(OracleShard):
+    """A real (oracle-backed) shard on the blocked-path protocol: its FIRST evaluation ends in GRAPE_ERR_AGAIN on the chosen
+    rank only -- as a handle does whose squaring plan was too short -- and the partial gradient it handed out for that
+    evaluation is garbage (the propagators were never finished)."""
+    N = 100
+
+    def __init__(self, *a, again=False):
+        super().__init__(*a)
+        self.again, self.evals, self.checks = again, 0, 0
+
+    def backward(self, f_total):
+        self.evals += 1
+        G = super().backward(f_total)
+        return G + 1e3 if (self.again and self.evals == 1) else G
+
+    def check(self, stream):
+        from grape_jl_amd.api import GrapeHipError
+        self.checks += 1
+        if self.again and self.checks == 1:
+            raise GrapeHipError(-7, "plan too short")
+
+
+def _again_loop_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pr = synth.make_problem(6, 2, 5, 5, seed=42)
+    pr["weights"] = np.array([0.5, 1.0, 1.5, 2.0, 0.25])
+    lo, hi = shard_range(5, world, rank)
+    sh = _AgainOracleShard(pr, lo, hi, 5, 0, again=(rank == 1))
+    ev = ShardedEvaluator(sh, 5, 0, dist=dist)
+    # the step of bench.py / of an optimizer on the sharded path: evaluate, decide TOGETHER, repeat together
+    for attempt in (0, 1):
+        J, G, _ = ev.eval_host(pr["pulsevals"])
+        if not ev.check_collective(0):
+            break
+    # a further, ordinary step: its collectives must pair with the other rank's (they would not if one rank had repeated alone)
+    J2, G2, _ = ev.eval_host(pr["pulsevals"] * 1.01)
+    assert not ev.check_collective(0)
+    q.put((rank, attempt, sh.evals, J, G, J2, G2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_repeating_keeps_the_collectives_of_all_ranks_paired():
+    """The deadlock / mis-pairing the collective decision exists to prevent, end to end: rank 1's shard reports
+    GRAPE_ERR_AGAIN after the first evaluation.  Both ranks repeat the evaluation (attempt == 1 on BOTH), every rank ran
+    three shard evaluations in all, and the gradients of the repeated and of the following step equal the single-process
+    ones -- no all-reduce was paired with another step's."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_again_loop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get() for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    pr = synth.make_problem(6, 2, 5, 5, seed=42)
+    pr["weights"] = np.array([0.5, 1.0, 1.5, 2.0, 0.25])
+    args = (pr["H0"], pr["Hc"], pr["tlist"])
+    Jr, Gr, _ = go.evaluate_gradient(*args, pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], functional=0)
+    Jr2, Gr2, _ = go.evaluate_gradient(*args, pr["pulsevals"] * 1.01, pr["psi0"], pr["target"], pr["weights"], functional=0)
+    for rank, attempt, evals, J, G, J2, G2 in got:
+        assert attempt == 1 and evals == 3, (rank, attempt, evals)
+        assert abs(J - Jr) < 1e-14 and np.abs(G - Gr).max() < 1e-14
+        assert abs(J2 - Jr2) < 1e-14 and np.abs(G2 - Gr2).max() < 1e-14
+
+
 def test_in_handle_reduction_order_is_the_shard_order():
     """Several devices behind ONE handle (grape_problem.ndev): the library adds the shard sums and the partial gradients in
     shard order on the calling thread, whatever order the per-shard host threads finish their enqueue halves in -- the

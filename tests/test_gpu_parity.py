@@ -51,6 +51,24 @@ def test_golden_fixtures(g, path, method):
     assert np.abs(tg - z["tau_grads"]).max() <= 1e-12
 
 
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_reference_outputs_when_present_gpu(g, path):
+    """the HIP path against outputs of GRAPE.jl itself (tests/golden/ref_<name>.json, julia/make_reference_fixtures.jl);
+    skipped while nobody with a Julia installation has produced them -- see tests/test_oracle.py"""
+    from conftest import load_reference_outputs
+    want = load_reference_outputs(path)
+    if want is None:
+        pytest.skip("no reference outputs committed (julia/make_reference_fixtures.jl has not been run)")
+    z = np.load(path)
+    pr = {k: z[k] for k in ("H0", "Hc", "tlist", "pulsevals", "psi0", "target", "weights")}
+    for method, name in ((0, "gradgen"), (1, "taylor")):
+        w = want[name]
+        J, G, tau, psiT, tg = hip_eval(g, pr, int(z["functional"]), method)
+        assert abs(J - w["J"]) <= TOL_J and np.abs(tau - w["tau"]).max() <= TOL_TAU
+        assert np.abs(G - w["G"]).max() <= tol_G(w["G"])
+        assert np.abs(psiT - w["psiT"]).max() <= 1e-12 and np.abs(tg - w["tau_grads"]).max() <= 1e-12
+
+
 CASES = [  # N, L, N_T, K, dt, hermitian, functional
     (2, 1, 40, 1, 0.01, True, 0),     # Pade order 3
     (3, 2, 9, 2, 0.2, False, 1),      # order 5/7, ragged N
@@ -536,6 +554,38 @@ def test_bench_contract_two_rank_rehearsal(g):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
     assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0
+
+
+def test_bench_contract_six_rank_rehearsal_of_config_c4(g):
+    """BASELINE config 4 (128 trajectories per GPU, one rank per GPU) rehearsed with as many ranks as this pool lets one
+    box run against its one GPU -- SIX processes may use the card together, so the driver's 8-rank launch is rehearsed
+    with 6 (768 trajectories instead of 1024; `bench.py --gpus 6 --config C4` under torch.distributed.run, gloo
+    collectives, every rank on device 0).  One JSON line with n_gpus = 6, and the functional value the ranks agree on --
+    formed from the all-reduced sums of six shard handles in six processes -- equals the value ONE handle with all 768
+    trajectories returns, to 1e-14."""
+    import json
+    import subprocess
+    import sys
+    from grape_jl_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRAPE_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "6", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "6", "--config", "C4",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 6 and d["scaling"] == "weak" and "768 total" in d["config"]["workload"]
+    assert abs(d["value"] - 6 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    assert d["gradient_allreduce_latency_us"] > 0.0
+    # the same 768 trajectories (rank r owns [128 r, 128 (r + 1)), synth.make_config(k_offset = 128 r)) behind ONE handle
+    prs = [synth.make_config("C4", K=128, k_offset=128 * r) for r in range(6)]
+    cat = lambda key: np.concatenate([p[key] for p in prs])      # noqa: E731
+    with g.GrapeHip(cat("H0"), prs[0]["Hc"], prs[0]["tlist"], cat("psi0"), cat("target"), cat("weights")) as h:
+        J1, _, _ = h.eval(prs[0]["pulsevals"])
+    assert abs(d["J"] - J1) <= 1e-14, (d["J"], J1)
 
 
 @pytest.mark.parametrize("N,herm", [(33, True), (40, False), (48, True)])

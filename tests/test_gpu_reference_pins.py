@@ -181,3 +181,25 @@ def test_balanced_handle_hands_states_across_the_boundary_in_the_callers_frame(g
     assert np.abs(U - Uref).max() <= 1e-12 * max(1.0, np.abs(Uref).max())
     Gcr, *_ = ref.evaluate_chi(H0, Hc, tl, x, psi0, tgt, chi, weights=w)
     assert np.abs(Gc - Gcr).max() <= 1e-10 * max(np.abs(Gcr).max(), 1e-3)
+
+
+@pytest.mark.parametrize("name", ["nonherm", "herm"])
+@pytest.mark.parametrize("functional", [0, 1, 2])
+@pytest.mark.parametrize("method,prop", [(0, 0), (1, 0), (0, 1)], ids=["gradgen", "taylor", "matrix-free"])
+def test_absolute_pin_against_a_60_digit_evaluation_gpu(g, name, functional, method, prop):
+    """J, tau, G, Psi(T) and every tau_grads entry of the HIP path against the 60-digit mpmath evaluation of the literal
+    block-matrix route (tests/golden/make_mpmath_pin.py; N = 4, L = 2, N_T = 5, K = 2, non-uniform grid, non-Hermitian
+    generators and a Hermitian twin): an absolute pin that does not route through scipy or through the repository's own
+    restatements.  1e-13 of the scale, for both gradient routes and the matrix-free propagator."""
+    from conftest import load_mpmath_pin
+    pr, want = load_mpmath_pin(name)
+    w = want[functional]
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], functional=functional,
+                    gradient_method=method, prop_method=prop) as h:
+        J, G, tau, psiT = h.eval(pr["pulsevals"], want_psiT=True)
+        tg = h.tau_grads()
+    sJ, sG, sT = max(1.0, abs(w["J"])), np.abs(w["G"]).max(), max(1.0, np.abs(w["tau"]).max())
+    assert abs(J - w["J"]) <= 1e-13 * sJ and np.abs(tau - w["tau"]).max() <= 1e-13 * sT
+    assert np.abs(G - w["G"]).max() <= 1e-13 * sG, np.abs(G - w["G"]).max() / sG
+    assert np.abs(psiT - w["psiT"]).max() <= 1e-13 * sT
+    assert np.abs(tg - w["tau_grads"]).max() <= 1e-13 * np.abs(w["tau_grads"]).max()

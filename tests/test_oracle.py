@@ -51,6 +51,55 @@ def test_finite_differences(functional):
         assert abs((Jp - Jm) / (2 * h) - G[idx]) < 2e-9
 
 
+@pytest.mark.parametrize("name", ["nonherm", "herm"])
+@pytest.mark.parametrize("functional", [0, 1, 2])
+def test_absolute_pin_against_a_60_digit_evaluation(ref, name, functional):
+    """The one known-answer test that does not lean on scipy's expm: J, tau, G, Psi(T) and every tau_grads entry of a tiny
+    problem (N = 4, L = 2, N_T = 5, K = 2; non-Hermitian generators on a non-uniform grid, and a Hermitian twin)
+    evaluated by the literal block-matrix route in mpmath at 60 digits (tests/golden/make_mpmath_pin.py).  Both
+    restatements, both gradient routes, to 1e-13 of the scale."""
+    from conftest import load_mpmath_pin
+    pr, want = load_mpmath_pin(name)
+    w = want[functional]
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"])
+    sJ, sG, sT = max(1.0, abs(w["J"])), np.abs(w["G"]).max(), max(1.0, np.abs(w["tau"]).max())
+    for method in ("gradgen", "taylor"):
+        J, G, tau, parts = go.evaluate_gradient(*args, functional, gradient_method=method, return_parts=True)
+        assert abs(J - w["J"]) <= 1e-13 * sJ and np.abs(tau - w["tau"]).max() <= 1e-13 * sT
+        assert np.abs(G - w["G"]).max() <= 1e-13 * sG, (method, np.abs(G - w["G"]).max() / sG)
+        assert np.abs(parts["storage"][:, -1] - w["psiT"]).max() <= 1e-13 * sT
+        tg = np.transpose(parts["tau_grads"], (0, 2, 1))
+        assert np.abs(tg - w["tau_grads"]).max() <= 1e-13 * np.abs(w["tau_grads"]).max()
+    for method in (ref.GRADGEN, ref.TAYLOR):
+        J, G, tau, parts = ref.evaluate(*args, functional, gradient_method=method, want_parts=True)
+        assert abs(J - w["J"]) <= 1e-13 * sJ and np.abs(tau - w["tau"]).max() <= 1e-13 * sT
+        assert np.abs(G - w["G"]).max() <= 1e-13 * sG, (method, np.abs(G - w["G"]).max() / sG)
+        assert np.abs(parts["psiT"] - w["psiT"]).max() <= 1e-13 * sT
+        assert np.abs(parts["tau_grads"] - w["tau_grads"]).max() <= 1e-13 * np.abs(w["tau_grads"]).max()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_reference_outputs_when_present(ref, path):
+    """tests/golden/ref_<name>.json = what GRAPE.jl itself returns for the fixture's inputs (julia/make_reference_fixtures.jl;
+    the build image has no Julia, so the files appear only when a maintainer runs that script).  While they are absent the
+    parity of this repository is pinned to mathematics only ("parity unpinned") and this test is
+    skipped; once present, both restatements are held to the reference at the tolerances of SURVEY.md 8c."""
+    from conftest import load_reference_outputs
+    want = load_reference_outputs(path)
+    if want is None:
+        pytest.skip("no reference outputs committed (julia/make_reference_fixtures.jl has not been run)")
+    z = np.load(path)
+    pr = _pr(z)
+    for method, name in ((ref.GRADGEN, "gradgen"), (ref.TAYLOR, "taylor")):
+        w = want[name]
+        assert np.array_equal(w["pulsevals"], pr["pulsevals"]), "the reference discretised the controls differently"
+        args = (pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"], int(z["functional"]))
+        for J, G, tau in (ref.evaluate(*args, gradient_method=method),
+                          go.evaluate_gradient(*args, gradient_method=name)):
+            assert abs(J - w["J"]) <= 1e-12 and np.abs(tau - w["tau"]).max() <= 1e-12
+            assert np.abs(G - w["G"]).max() <= 1e-10 * max(np.abs(w["G"]).max(), 1e-3)
+
+
 def test_gradgen_equals_taylor_equals_frechet():
     pr = synth.make_problem(12, 2, 6, 2, seed=3)
     a = go.evaluate_gradient(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
