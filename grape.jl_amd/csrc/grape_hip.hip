@@ -95,6 +95,8 @@ struct grape_handle {
     double *d_lg[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_dinv = nullptr;
     int *d_scell = nullptr;
+    double *d_colpart = nullptr;   // [chunk][2][LG_PARTS][NP] partial column sums of two powers (lg_t18_operands2_kernel)
+    bool lg_spec = true;           // GRAPE_LG_SPEC=0: the separate norm pass (lg_t18_scale_kernel) in front of the combinations
     double *d_dts = nullptr, *d_shape = nullptr, *d_weights = nullptr;
     double2 *d_psi0 = nullptr, *d_target = nullptr;
     // per-evaluation
@@ -897,6 +899,13 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
     // x 192 instructions): full products NB^3 blocks, triangular ones NB^2 (NB + 1) / 2
     const unsigned long long blk = 4ull * 192ull;
     const unsigned long long gen = blk * NB * NB * NB, tri = blk * NB * NB * (NB + 1) / 2;
+    if (h->d_Sf) {   // S_n = sum_l eps_ln shape_ln H_l for every time step (lg_form_kernel then reads H0_k and S_n)
+        CtrlSumArgs ca{};
+        ca.Hcf = h->d_Hcf; ca.eps = h->d_eps; ca.shape = h->d_shape; ca.Sf = h->d_Sf;
+        ca.L = h->L; ca.N_T = h->N_T; ca.pp2 = 2 * NP * NP;
+        hipLaunchKernelGGL(ctrl_sum_kernel, dim3(h->N_T, std::max(1, ca.pp2 / 2 / 2048)), dim3(256), 0, s, ca);
+        LGCHK(hipGetLastError());
+    }
     for (long c0_ = 0; c0_ < ncell; c0_ += h->chunk) {
         const int nc = (int)std::min<long>(h->chunk, ncell - c0_);
         const size_t nel = (size_t)nc * 2 * pp;
@@ -905,6 +914,7 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         fa.A = A; fa.s_cell = h->d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
         fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0_; fa.rep = h->d_rep;
         fa.norm1 = h->d_dinv;   // (the inverse slots of the Pade route are idle here: ||A||_1 per cell)
+        fa.Sf = h->d_Sf;
         hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(1024), 0, s, fa);
         LGCHK(hipGetLastError());
         const LgView vA = lg_full(A, NP), vA2 = lg_full(A2, NP), vA3 = lg_full(A3, NP), vA6 = lg_full(A6, NP),
@@ -917,8 +927,10 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         sa.s_cell = h->d_scell; sa.flags = h->d_flags; sa.stats = h->d_stats; sa.NP = NP;
         sa.theta = hm ? T18_THETA : T18T_THETA;
         sa.mfma_per_cell = (hm ? 3 * tri : 3 * gen) + 2 * gen; sa.mfma_per_sq = gen;
-        hipLaunchKernelGGL(lg_t18_scale_kernel, dim3(nc), dim3(256), 0, s, sa);
-        LGCHK(hipGetLastError());
+        if (!h->lg_spec) {
+            hipLaunchKernelGGL(lg_t18_scale_kernel, dim3(nc), dim3(256), 0, s, sa);
+            LGCHK(hipGetLastError());
+        }
         LgT18OperandsArgs oa{};
         oa.A = A; oa.A2 = A2; oa.A3 = A3; oa.A6 = A6; oa.B1 = B1; oa.B5 = B5; oa.B4 = B4; oa.B3 = B3; oa.B2 = B2;
         oa.s_cell = h->d_scell; oa.NP = NP; oa.per_cell = 2 * pp; oa.n = nel;
@@ -933,8 +945,24 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
             memcpy(oa.a, a_, sizeof(a_)); memcpy(oa.e, e_, sizeof(e_)); memcpy(oa.b, b_, sizeof(b_));
             memcpy(oa.c, c_, sizeof(c_)); memcpy(oa.d, d_, sizeof(d_));
         }
-        hipLaunchKernelGGL(lg_t18_operands_kernel, dim3(2048), dim3(256), 0, s, oa);
-        LGCHK(hipGetLastError());
+        if (h->lg_spec) {
+            // combinations for s = 0 with the column sums of A2 and A6 / A3 on the way, the decision, and the combinations once
+            // more for the cells that need a scaling (none at the benchmark's norms: that launch leaves at once)
+            LgT18Operands2Args o2{};
+            o2.o = oa; o2.colpart = h->d_colpart; o2.q_is_a6 = hm ? 1 : 0; o2.redo = 0;
+            hipLaunchKernelGGL(lg_t18_operands2_kernel, dim3((unsigned)nc * LG_PARTS), dim3(256), 0, s, o2);
+            LGCHK(hipGetLastError());
+            LgT18DecideArgs da{};
+            da.colpart = h->d_colpart; da.s = sa;
+            hipLaunchKernelGGL(lg_t18_decide_kernel, dim3(nc), dim3(256), 0, s, da);
+            LGCHK(hipGetLastError());
+            o2.redo = 1;
+            hipLaunchKernelGGL(lg_t18_operands2_kernel, dim3((unsigned)nc * LG_PARTS), dim3(256), 0, s, o2);
+            LGCHK(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(lg_t18_operands_kernel, dim3(2048), dim3(256), 0, s, oa);
+            LGCHK(hipGetLastError());
+        }
         const LgView vB4 = lg_full(B4, NP), vB3 = lg_full(B3, NP), vB2 = lg_full(B2, NP);
         const int *smax_ptr = h->d_flags + 1;
         {   // A9 = B1 B5 + B4 and, from the same launch, B3 + A9 (the left operand of the last product)
@@ -1208,7 +1236,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -1600,12 +1628,24 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     }
     if (h->large && !h->series) {
         const long ncell = (long)h->KC * N_T;
-        const long cap = std::max<long>(1, (long)(6.0e9 / (9.0 * 2.0 * pp * 8.0)));
-        h->chunk = (int)std::min<long>(ncell, std::min<long>(cap, 4096));
+        double scratch_bytes = 6.0e9;
+        if (const char *envg = getenv("GRAPE_LG_SCRATCH_GB")) scratch_bytes = std::max(0.1, atof(envg)) * 1e9;   // (experiments: launch tails against scratch)
+        const long cap = std::max<long>(1, (long)(scratch_bytes / (9.0 * 2.0 * pp * 8.0)));
+        h->chunk = (int)std::min<long>(ncell, std::min<long>(cap, 16384));
         if (const char *envc = getenv("GRAPE_LG_CHUNK")) h->chunk = (int)std::max<long>(1, std::min<long>(h->chunk, atol(envc)));   // (experiments: working set against the Infinity Cache)
         for (auto &b : h->d_lg) CCHK(dmalloc(&b, (size_t)h->chunk * 2 * pp));
         CCHK(dmalloc(&h->d_dinv, (size_t)h->chunk * 2 * 4096));
         CCHK(dmalloc(&h->d_scell, (size_t)h->chunk + 1));
+        {
+            const char *envsp = getenv("GRAPE_LG_SPEC"), *envsn = getenv("GRAPE_LG_SN");
+            h->lg_spec = h->t18 && !(envsp && atoi(envsp) == 0);
+            if (h->lg_spec) CCHK(dmalloc(&h->d_colpart, (size_t)h->chunk * 2 * LG_PARTS * NP));
+            // summed controls of every time step for the generator formation (polynomial route, shared control operators):
+            // N_T 2 NP^2 doubles -- 2.1 GB at C5 -- when that is a small part of what the propagators take anyway
+            const double sn_bytes = (double)N_T * 2.0 * (double)pp * 8.0;
+            if (h->t18 && !p->hc_per_traj && !(envsn && atoi(envsn) == 0) && sn_bytes <= 0.25 * (double)h->KC * N_T * (double)pp * 16.0 + 1e9)
+                CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * pp));
+        }
     }
 
     std::vector<double> dts(N_T);
@@ -1897,7 +1937,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                     CtrlSumArgs ca{};
                     ca.Hcf = h->d_Hcf; ca.eps = h->d_eps; ca.shape = h->d_shape; ca.Sf = h->d_Sf;
                     ca.L = h->L; ca.N_T = h->N_T; ca.pp2 = 2 * h->NP * h->NP;
-                    hipLaunchKernelGGL(ctrl_sum_kernel, dim3(h->N_T), dim3(256), 0, s, ca);
+                    hipLaunchKernelGGL(ctrl_sum_kernel, dim3(h->N_T, std::max(1, ca.pp2 / 2 / 2048)), dim3(256), 0, s, ca);
                     HIPCHK(h, hipGetLastError());
                     ea.Sf = h->d_Sf;
                 }

@@ -130,12 +130,15 @@ struct CtrlSumArgs {
     double *Sf;
     int L, N_T, pp2;   // pp2 = 2 NP^2 doubles per operator
 };
+// (grid: N_T x parts -- a workgroup per step walked 256 dependent-latency iterations per thread at NP = 256: 0.86 ms per
+// evaluation of a C5 shard; with one part per 2048 element pairs the launch is bound by what it writes)
 __global__ void __launch_bounds__(256) ctrl_sum_kernel(CtrlSumArgs a) {
     const int n = blockIdx.x;
     double e[8];
     for (int l = 0; l < a.L; ++l) e[l] = a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0);
     double2 *dst = (double2 *)(a.Sf + (size_t)n * a.pp2);
-    for (int i = threadIdx.x; i < a.pp2 / 2; i += blockDim.x) {
+#pragma unroll 4
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < a.pp2 / 2; i += gridDim.y * blockDim.x) {
         double2 acc = make_double2(0., 0.);
         for (int l = 0; l < a.L; ++l) {
             const double2 h = ((const double2 *)(a.Hcf + (size_t)l * a.pp2))[i];

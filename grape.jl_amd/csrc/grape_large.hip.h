@@ -242,8 +242,12 @@ struct LgFormArgs {
     int *flags;
     int NP, L, N_T, hc_per_traj, cell0;
     const int *rep;       // nullptr or representative trajectory per generator class
-    double *norm1;        // polynomial route (lg_t18_scale_kernel decides the scaling): ||A||_1 per cell goes here, the
+    double *norm1;        // polynomial route (lg_t18_decide_kernel decides the scaling): ||A||_1 per cell goes here, the
                           // Pade squaring count is only CREDITED (statistics), s_cell and flags[1] are left alone
+    const double *Sf;     // nullptr or [N_T][2][NP*NP]: S_n = sum_l eps_ln shape_ln H_l of every time step (ctrl_sum_kernel, once
+                          // per evaluation; control operators shared by the trajectories).  The cell then reads H0_k and S_n --
+                          // two operators instead of 1 + L: the kernel was bound by what one CU pulls from the L2 (10 MB per cell at
+                          // C5: 0.41 ms per chunk of 635 cells where the 0.67 GB it writes take 0.13; round 5)
 };
 // 1024 threads per cell: thread (part, j) forms rows part, part + 4, ... of column j.  (With 256 threads -- one per column,
 // 256 rows each -- a launch lasted as long as ONE workgroup's chain of 32 load round trips: 0.63 ms per chunk of 889 cells,
@@ -271,12 +275,17 @@ __global__ void __launch_bounds__(1024) lg_form_kernel(LgFormArgs a) {
     // squaring is applied as a per-cell power of two where A is consumed (LgGemmArgs::scale_s: A*A and A*T) --
     // exact in binary, and the operators are read once instead of twice.  Rows are unrolled by 8 so that 8 (1 + L)
     // independent loads per plane are in flight (the loop is otherwise bound by one load latency per row).
+    const double *sn = a.Sf ? a.Sf + (size_t)n * 2 * pp : nullptr;
     auto element = [&](int i, double &ar, double &ai) __attribute__((always_inline)) {
         const size_t o = (size_t)i * NP + tid;
         double hr = h0[o], hi = h0[pp + o];
-        for (int l = 0; l < a.L; ++l) {
-            hr = fma(e[l], hc[(size_t)l * 2 * pp + o], hr);
-            hi = fma(e[l], hc[(size_t)l * 2 * pp + pp + o], hi);
+        if (sn) {
+            hr += sn[o]; hi += sn[pp + o];
+        } else {
+            for (int l = 0; l < a.L; ++l) {
+                hr = fma(e[l], hc[(size_t)l * 2 * pp + o], hr);
+                hi = fma(e[l], hc[(size_t)l * 2 * pp + pp + o], hi);
+            }
         }
         ar = dt * hi; ai = -dt * hr;
     };
@@ -408,6 +417,104 @@ __global__ void lg_t18_operands_kernel(LgT18OperandsArgs a) {
         a.B2[i] = a.b[1] * x1 + a.b[2] * x2 + a.b[3] * x3 + a.b[4] * x6 + (diag ? a.b[0] : 0.0);
     }
 }
+// Round 5: the norm pass rides in the combination pass.  lg_t18_scale_kernel read two powers of every cell (33.6 GB per
+// C5-shard evaluation, 6.4 ms) only to find, at the benchmark's norms, that no cell needs a squaring.  Now the combination
+// pass forms B1 .. B5 SPECULATIVELY for s = 0 and takes the column sums of the two powers it reads anyway on its way;
+// lg_t18_decide_kernel turns the partial sums into the squaring count of every cell (same bound, same statistics), and a
+// second launch of the combination pass redoes the cells with s > 0 from the intact powers (it leaves at once for the
+// others: at C5 for all of them).  The partial sums are written per row part and added in a fixed order: the decision of a
+// cell does not depend on the order in which workgroups finish.
+constexpr int LG_PARTS = 16;      // row parts per cell (16 rows each at NP = 256)
+struct LgT18Operands2Args {
+    LgT18OperandsArgs o;
+    double *colpart;       // [ncell][2][LG_PARTS][NP]: column sums of |re| + |im| of P = A2 and Q = A6 (Hermitian) / A3 (general)
+    int q_is_a6;           // 1: Q = A6, 0: Q = A3
+    int redo;              // 0: every cell with s = 0 (+ partial sums); 1: only the cells with s_cell > 0, with their scaling
+};
+__global__ void __launch_bounds__(256) lg_t18_operands2_kernel(LgT18Operands2Args g) {
+    const LgT18OperandsArgs &a = g.o;
+    const int cell = blockIdx.x / LG_PARTS, part = blockIdx.x - cell * LG_PARTS, NP = a.NP, tid = threadIdx.x;
+    int s = 0;
+    if (g.redo) {
+        s = a.s_cell[cell];
+        if (s == 0) return;
+    }
+    if (tid >= NP) return;
+    const size_t pp = a.per_cell / 2, base = (size_t)cell * a.per_cell;
+    const int rows = NP / LG_PARTS, i0 = part * rows;
+    const double f1 = ldexp(1.0, -s), f2 = f1 * f1, f3 = f2 * f1, f6 = f3 * f3;
+    double sp = 0., sq = 0.;
+#pragma unroll 4
+    for (int i = i0; i < i0 + rows; ++i) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const size_t q = base + (size_t)pl * pp + (size_t)i * NP + tid;
+            const double r1 = __builtin_nontemporal_load(a.A + q), r2 = __builtin_nontemporal_load(a.A2 + q);
+            const double r3 = __builtin_nontemporal_load(a.A3 + q), r6 = __builtin_nontemporal_load(a.A6 + q);
+            sp += fabs(r2);
+            sq += fabs(g.q_is_a6 ? r6 : r3);
+            const double x1 = f1 * r1, x2 = f2 * r2, x3 = f3 * r3, x6 = f6 * r6;
+            const bool diag = pl == 0 && i == tid;
+            a.B1[q] = a.a[0] * x1 + a.a[1] * x2 + a.a[2] * x3;
+            a.B5[q] = a.e[0] * x2 + a.e[1] * x3 + a.e[2] * x6;
+            a.B4[q] = a.d[1] * x1 + a.d[2] * x2 + a.d[3] * x3 + a.d[4] * x6 + (diag ? a.d[0] : 0.0);
+            a.B3[q] = a.c[1] * x1 + a.c[2] * x2 + a.c[3] * x3 + a.c[4] * x6 + (diag ? a.c[0] : 0.0);
+            a.B2[q] = a.b[1] * x1 + a.b[2] * x2 + a.b[3] * x3 + a.b[4] * x6 + (diag ? a.b[0] : 0.0);
+        }
+    }
+    if (!g.redo) {
+        double *cp = g.colpart + ((size_t)cell * 2 * LG_PARTS + part) * NP;
+        cp[tid] = sp;
+        cp[(size_t)LG_PARTS * NP + tid] = sq;
+    }
+}
+// the decision of lg_t18_scale_kernel from the partial column sums (one workgroup per cell, thread j owns column j)
+struct LgT18DecideArgs {
+    const double *colpart;
+    LgT18ScaleArgs s;      // P, Q unused
+};
+__global__ void __launch_bounds__(256) lg_t18_decide_kernel(LgT18DecideArgs g) {
+    const LgT18ScaleArgs &a = g.s;
+    __shared__ double cs[2][256];
+    const int tid = threadIdx.x, NP = a.NP;
+    double sp = 0., sq = 0.;
+    if (tid < NP) {
+        const double *cp = g.colpart + (size_t)blockIdx.x * 2 * LG_PARTS * NP;
+        for (int part = 0; part < LG_PARTS; ++part) {   // fixed order
+            sp += cp[(size_t)part * NP + tid];
+            sq += cp[(size_t)(LG_PARTS + part) * NP + tid];
+        }
+    }
+    cs[0][tid] = sp; cs[1][tid] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        double np_ = 0., nq = 0.;
+        bool bad = false;                        // (fmax drops a NaN: a column sum that is not finite is looked for)
+        for (int j = 0; j < NP; ++j) {
+            np_ = fmax(np_, cs[0][j]); nq = fmax(nq, cs[1][j]);
+            bad = bad || !(cs[0][j] <= 1.7e308) || !(cs[1][j] <= 1.7e308);
+        }
+        np_ *= 1.0 + 1e-9; nq *= 1.0 + 1e-9;   // rounding of the computed powers
+        int s = 0;
+        if (!a.norm1) {   // beta <= theta 2^s  <=>  ||A2|| <= (theta 2^s)^2  or  ||A6|| <= (theta 2^s)^6
+            double t2 = a.theta * a.theta, t6 = t2 * t2 * t2;
+            while (!(np_ <= t2 || nq <= t6) && s < 64) { ++s; t2 *= 4.0; t6 *= 64.0; }
+            bad = bad || s >= 64;
+        } else {          // alpha <= theta 2^s  <=>  ||A|| <= theta 2^s  or  (||A2|| <= (theta 2^s)^2 and ||A3|| <= (theta 2^s)^3)
+            const double n1 = a.norm1[blockIdx.x];
+            double t1 = a.theta, t2 = t1 * t1, t3 = t2 * t1;
+            while (!(n1 <= t1 || (np_ <= t2 && nq <= t3)) && s < 64) { ++s; t1 *= 2.0; t2 *= 4.0; t3 *= 8.0; }
+            bad = bad || s >= 64;
+        }
+        if (bad) { s = 0; atomicOr(&a.flags[0], 64); }   // NaN / overflow in the generator
+        a.s_cell[blockIdx.x] = s;
+        atomicMax(&a.flags[1], s);
+        stat_add(a.stats, 12, a.mfma_per_cell + (unsigned long long)s * a.mfma_per_sq);
+        stat_add(a.stats, 13, (unsigned long long)s);
+        stat_add(a.stats, 14, 1ull);
+    }
+}
+
 // Dinv = inverse of the 64x64 block (jb, jb) of Q, one workgroup per cell (fused-kernel solver, P = I)
 struct LgInvArgs {
     LgView Q;         // view positioned at block (jb, jb)
