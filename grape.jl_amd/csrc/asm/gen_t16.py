@@ -34,6 +34,24 @@ The columns of a 16-column block are stored in the order (j >> 1) + 8 (j & 1): a
 
 The instruction list is executed by the emulator of gcn.py against numpy (tests/test_asm_kernel.py) -- this container
 has no GPU -- and the same list is printed as the .s file the library embeds.
+
+Round 5 -- the workgroup is TRAJECTORY-RESIDENT and carries a state along.  The sweeps Psi_n = U_n Psi_(n-1)
+(/root/reference/src/optimize.jl:731-738) and chi_(n-1) = U_n^dagger chi_n (:880-881) read every propagator from HBM
+again, with the matrix pipe idle.  Here a workgroup walks a CONTIGUOUS range of cells (host table `wgtab`: first cell,
+count, step +1 / -1) -- at the headline shape one half of a trajectory, in time order from the end it starts at -- and,
+while the cell's result is still in registers, applies it to a state it keeps in the LDS:
+
+  ascending walk from t = 0      Psi <- U_n Psi, stored to fw[k][n + 1]
+  descending walk from t = T     chi <- U_n^dagger chi from the unit target (the linearity of the concurrent sweeps,
+                                 include/grape_hip.h grape_set_fused_sweeps), stored to bw[k][n]
+
+The result strip of a wave is a COLUMN strip, so the product a wave can form without a reduction across its lanes is
+z_j = sum_i M_ij x_i = (M^T x)_j (16 complex multiply-adds per lane, the four lane rows meet through the LDS).  The
+descending walk keeps conj(chi): conj(U^dagger chi) = U^T conj(chi).  The ascending walk exponentiates A^T = -conj(A)
+instead of A (one sign in the commit; A^T is skew-Hermitian with the same spectrum, every bound and verdict is the same),
+holds M = U^T, forms U Psi = M^T Psi, and stores M transposed -- i.e. U -- in 64-byte pieces.  A cell whose verdict
+fails (it will be redone by the five-product launch) ends the propagation of that walk; how far each end of each
+trajectory got is reported in prog[2][K], and the sweep kernel behind picks up from there.
 """
 import os
 import re
@@ -54,8 +72,14 @@ EXH = 256 * 8 + 128             # bytes of the real (imaginary) parts of a tile 
 EXW = 2 * EXH                   # bytes per wave of an exchange area
 E2 = E1 + 4 * EXW               # exchange area of the mirrored tiles
 RED = E2 + 4 * EXW              # 16 doubles of reduction scratch
-LDS_BYTES = RED + 16 * 8
-KERNARG = 80
+# state of the trajectory this workgroup walks (round 5): two buffers of 64 complex numbers, planar (re[64] | im[64]) with
+# the rows of a 16-row tile in the order qrow (the four rows 4 r + rg of a lane are contiguous), and the partial sums of
+# the mat-vec, (re, im) per lane
+XS0 = RED + 16 * 8
+XS1 = XS0 + 1024
+PART = XS1 + 1024
+LDS_BYTES = PART + 4 * 1024
+KERNARG = 128
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -156,22 +180,28 @@ class Gen:
         self.s_hi = S(19)                                                # wave >> 1
         self.s_diag = S(30, 2)                                           # diagnostic builds: stamp area of this wave
         self.s_ub = [S(32 + 2 * i, 2) for i in range(4)]                 # U bases of the previous cell, per slot
-        self.s_toff = [S(40 + u) for u in range(5)]                      # byte offsets of this wave pair's operator tiles
+        # (the byte offsets of this wave pair's operator tiles are selected in fetch(): round 5 needs their registers)
+        self.s_stp = S(42, 2)                                            # where the next propagated state goes (fw / bw row)
+        self.s_xs = S(44)                                                # LDS offset of the current state buffer
+        self.s_prog = S(45)                                              # steps propagated along the current trajectory
+        self.s_prop = S(2)                                               # bit 0: a state is carried along, bit 1: the verdict of this cell failed
+        self.s_tflip = S(57)                                             # 0x80000000: this walk exponentiates A^T and stores transposed
+        self.s_karg = S(0, 2)                                            # kernel arguments (kept: the rare paths reload from them)
         self.s_hb, self.s_sb = S(46, 2), S(48, 2)                        # H0 / S base of the next cell
         self.s_t0, self.s_t1 = S(50, 2), S(52, 2)                        # tile bases (rotating)
         self.s_dt = S(54, 2)
-        self.s_pmask = S(56, 2)                                          # exec of the previous-result stores (0: no previous cell)
+        self.s_pm = S(56)                                                # previous-result stores: 0 no previous cell, 1 store
         self.s_tmp = [S(58 + i) for i in range(6)]                       # s58..s63
         self.s_dmask = [S(64 + 2 * r, 2) for r in range(4)]              # lanes holding a diagonal element in register r of slot 0
         self.s_c = {i: S(72 + 2 * (i - 1), 2) for i in range(1, 16)}     # c1..c15 at s72..s101
         self.s_k = S(3)                                                  # representative trajectory of the next cell
-        self.s_save = S(0, 2)                                            # saved exec (s0:1 free after the argument load)
+        self.s_save = S(40, 2)                                           # saved exec
         # ---- persistent vector registers ----
         self.v_tid, self.v_lane = V(0), V(1)
         self.v_AA = [[V(2 + 4 * so + sk) for sk in range(4)] for so in range(4)]
         self.v_SA = [V(18 + sl) for sl in range(4)]
-        self.v_EW1, self.v_EW2, self.v_ER, self.v_RD = V(22), V(23), V(24), V(25)
-        self.v_UO1, self.v_UO2 = V(26), V(27)
+        self.v_EW1, self.v_EW2, self.v_ER = V(22), V(23), V(24)
+        self.v_UO = [V(26), V(27), V(0), V(25)]                          # result stores: per-lane offset of register r (v0: free after the prologue)
         self.v_GO, self.v_GOI = V(28), V(29)
         self.v_CP, self.v_CM = V(30), V(31)
         self.vp = Pool("v", range(4, 32))      # tiles 4..31 = v32..v255
@@ -219,7 +249,7 @@ class Gen:
 
     def prologue(self):
         p = self.p
-        p.s_load(16, S(4, 16), S(0, 2), 0)
+        p.s_load(16, S(4, 16), self.s_karg, 0)
         p.valu("v_and_b32", self.v_tid, 0x3FF, V(0))
         p.valu("v_and_b32", self.v_lane, 63, self.v_tid)
         t = self.vp.alloc()                      # temporaries of the prologue
@@ -281,16 +311,7 @@ class Gen:
         p.valu("v_lshlrev_b32", vx, 5, self.v_lane)
         p.valu("v_lshl_add_u32", vx, vrg, 5, vx)                         # 32 lane + 32 (lane >> 4)
         p.valu("v_add_u32", self.v_ER, self.s_tmp[0], vx)                # E1 + EXW w + 32 lane + 32 (lane >> 4)
-        p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 3)
-        p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], RED)
-        p.valu("v_mov_b32", self.v_RD, self.s_tmp[0])
-        # result stores: element (16 tb + 4 r + rg, 16 w + c), 16 bytes each, rows of 1024 bytes
-        p.valu("v_lshlrev_b32", vx, 10, vrg)
-        p.valu("v_lshl_add_u32", vx, vc, 4, vx)
-        p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 8)
-        p.valu("v_add_u32", vx, self.s_tmp[0], vx)
-        p.valu("v_add_u32", self.v_UO1, 4096, vx)
-        p.valu("v_add_u32", self.v_UO2, 12288, vx)
+        # (result stores: their per-lane offsets depend on the orientation of this walk, see the end of the prologue)
         # operator tiles: element pair idx = tid & 127 of a tile: row idx & 15, columns 2 (idx >> 4), + 1
         p.valu("v_and_b32", vidx, 127, self.v_tid)
         # (16 consecutive lanes = the 16 rows of one column pair: a 16-lane store group then writes 16 consecutive positions
@@ -320,37 +341,50 @@ class Gen:
         for r in range(4):
             p.valu("v_add_u32", vx, 4 * r, vrg)
             p.v_cmp("v_cmp_eq_u32", self.s_dmask[r], vx, vc)
-        self.vp.free(t)
-        # tiles of this wave pair (waves 0, 1: tiles 2u; waves 2, 3: tiles 2u + 1)
-        p.s_cmp("s_cmp_eq_u32", self.s_hi, 0)
-        for u in range(5):
-            (i0, j0), (i1, j1) = TILES[2 * u], TILES[2 * u + 1]
-            self.ssel(self.s_toff[u], (16 * i0 * NP + 16 * j0) * 8, (16 * i1 * NP + 16 * j1) * 8)
         for i in range(1, 16):
             self.smov64(self.s_c[i], self.c[f"C{i}"])
         p.s_waitcnt(lgkm=0)
-        # cells of this workgroup: XCD x = wg & 7 walks [lo, hi) of the cells with stride nblk / 8 (expm_t18_kernel)
         wg = S(2)
         t0, t1, t2 = self.s_tmp[0], self.s_tmp[1], self.s_tmp[2]
         p.salu("s_mul_i32", t2, self.s_KC, self.s_NT)                    # ncell
         # the plan of this evaluation (t16_plan_kernel): more than a quarter of the cells predicted beyond the range of
         # the four-product route -> the route is not tried, the five-product launch behind this kernel walks all cells
-        p.s_load(2, self.s_t0, S(0, 2), 72)
+        p.s_load(2, self.s_t0, self.s_karg, 72)
         p.s_load(1, self.s_tmp[3], self.s_t0, 24)                        # flags[6]
         p.salu("s_lshl_b32", self.s_tmp[3], self.s_tmp[3], 2)
         p.s_cmp("s_cmp_gt_u32", self.s_tmp[3], t2)
         p.s_branch("s_cbranch_scc1", "L_end")
-        p.salu("s_and_b32", t0, wg, 7)
-        p.salu("s_mul_i32", t1, t0, t2)
-        p.salu("s_lshr_b32", t1, t1, 3)                                  # lo
-        p.salu("s_add_u32", t0, t0, 1)
-        p.salu("s_mul_i32", t0, t0, t2)
-        p.salu("s_lshr_b32", self.s_end, t0, 3)                          # hi
-        p.salu("s_lshr_b32", self.s_step, self.s_nblk, 3)
-        p.salu("s_lshr_b32", t0, wg, 3)
-        p.salu("s_add_u32", self.s_idx, t1, t0)
-        p.s_cmp("s_cmp_ge_u32", self.s_idx, self.s_end)
+        if self.diag:
+            p.s_load(2, self.s_diag, self.s_karg, 64)
+            p.salu("s_lshl_b32", t0, wg, 2)
+            p.salu("s_add_u32", t0, t0, self.s_wave)
+            p.salu("s_mul_i32", t0, t0, 8 * self.NSTAMP)
+            p.s_waitcnt(lgkm=0)
+            p.salu("s_add_u32", self.s_diag.sub(0), self.s_diag.sub(0), t0)
+            p.salu("s_addc_u32", self.s_diag.sub(1), self.s_diag.sub(1), 0)
+        # the cells of this workgroup: a contiguous range of the flattened index kc N_T + n, walked with step +1 or -1 from
+        # `first` (host table wgtab[wg] = {first, count, step, -}: grape_t18.hip t16_walks)
+        p.s_load(2, self.s_t1, self.s_karg, 80)
+        p.salu("s_lshl_b32", t0, wg, 4)
+        ent = S(60, 4)
+        p.s_load(4, ent, self.s_t1, t0)
+        p.s_load(1, t1, self.s_karg, 60)                                 # fuse: bit 0 ascending walks propagate, bit 1 descending ones
+        p.s_waitcnt(lgkm=0)
+        p.salu("s_mov_b32", self.s_cell, ent.sub(0))
+        p.salu("s_mov_b32", self.s_end, ent.sub(1))
+        p.salu("s_mov_b32", self.s_step, ent.sub(2))
+        p.salu("s_mov_b32", self.s_idx, 0)
+        p.s_cmp("s_cmp_eq_u32", self.s_end, 0)
         p.s_branch("s_cbranch_scc1", "L_end")
+        # an ascending walk that may propagate exponentiates A^T and stores its results transposed (see the module text)
+        p.salu("s_and_b32", t1, t1, 1)
+        p.s_cmp("s_cmp_eq_u32", self.s_step, 1)
+        p.salu("s_cselect_b32", t1, t1, 0)
+        p.salu("s_lshl_b32", self.s_tflip, t1, 31)
+        p.salu("s_mov_b32", self.s_prop, 0)
+        p.salu("s_mov_b32", self.s_prog, 0)
+        p.salu("s_mov_b32", self.s_xs, XS0)
+        p.salu("s_mov_b32", self.s_pm, 0)
         # (kc, n) of the first cell: restoring division, 32 steps
         q, r, i = self.s_kc, self.s_n, t0
         p.salu("s_mov_b32", q, 0)
@@ -358,7 +392,7 @@ class Gen:
         p.salu("s_mov_b32", i, 31)
         p.label("L_div")
         p.salu("s_lshl_b32", r, r, 1)
-        p.salu("s_lshr_b32", t1, self.s_idx, i)
+        p.salu("s_lshr_b32", t1, self.s_cell, i)
         p.salu("s_and_b32", t1, t1, 1)
         p.salu("s_or_b32", r, r, t1)
         p.s_cmp("s_cmp_ge_u32", r, self.s_NT)
@@ -370,16 +404,24 @@ class Gen:
         p.salu("s_sub_u32", i, i, 1)
         p.s_cmp("s_cmp_ge_i32", i, 0)
         p.s_branch("s_cbranch_scc1", "L_div")
-        p.salu("s_mov_b32", self.s_cell, self.s_idx)
-        p.salu("s_mov_b64", self.s_pmask, 0)
-        if self.diag:
-            p.s_load(2, self.s_diag, S(0, 2), 64)
-            p.salu("s_lshl_b32", t0, wg, 2)
-            p.salu("s_add_u32", t0, t0, self.s_wave)
-            p.salu("s_mul_i32", t0, t0, 8 * self.NSTAMP)
-            p.s_waitcnt(lgkm=0)
-            p.salu("s_add_u32", self.s_diag.sub(0), self.s_diag.sub(0), t0)
-            p.salu("s_addc_u32", self.s_diag.sub(1), self.s_diag.sub(1), 0)
+        # result stores, 16 bytes per lane and register r.  Plain walk: element (16 tb + 4 r + rg, 16 w + c) of U, rows of 1024
+        # bytes (tb 16384 in the slot's scalar base).  Transposed walk: the same register holds element (16 w + c, 16 tb + 4 r + rg)
+        # of U: row 16 w + c, 16-byte position tb 16 + 4 r + rg (tb 256 in the scalar base) -- the four lane rows of one
+        # instruction write 64 contiguous bytes, the four registers of a slot 256
+        p.valu("v_lshlrev_b32", vx, 10, vrg)
+        p.valu("v_lshl_add_u32", vx, vc, 4, vx)
+        p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 8)
+        p.valu("v_add_u32", vx, self.s_tmp[0], vx)                       # rg 1024 + c 16 + w 256
+        p.valu("v_lshl_add_u32", vy, vw, 4, vc)
+        p.valu("v_lshlrev_b32", vy, 10, vy)
+        p.valu("v_lshl_add_u32", vy, vrg, 4, vy)                         # (16 w + c) 1024 + rg 16
+        p.s_cmp("s_cmp_lg_u32", self.s_tflip, 0)
+        p.salu("s_cselect_b64", VCC, -1, 0)
+        for r_ in range(4):
+            p.valu("v_add_u32", vidx, 4096 * r_, vx)
+            p.valu("v_add_u32", vpc, 64 * r_, vy)
+            p.valu("v_cndmask_b32", self.v_UO[r_], vidx, vpc, VCC)
+        self.vp.free(t)
 
     # ---- scalars of a cell ----
     def cell_bases_issue(self, kc, n):
@@ -420,13 +462,19 @@ class Gen:
         """operator tiles u of the cell whose bases are in s_hb / s_sb: H0 re, H0 im (half 0), S re, S im (half 1),
         4 registers each"""
         p = self.p
+        # tiles of this wave pair (waves 0, 1: tiles 2u; waves 2, 3: tiles 2u + 1): byte offset selected here (scalar
+        # instructions are free in the shadow of the matrix instructions this is called between)
+        (i0, j0), (i1, j1) = TILES[2 * u], TILES[2 * u + 1]
+        toff = self.s_tmp[2]
+        p.s_cmp("s_cmp_eq_u32", self.s_hi, 0)
+        self.ssel(toff, (16 * i0 * NP + 16 * j0) * 8, (16 * i1 * NP + 16 * j1) * 8)
         if half in (None, 0):
-            p.salu("s_add_u32", self.s_t0.sub(0), self.s_hb.sub(0), self.s_toff[u])
+            p.salu("s_add_u32", self.s_t0.sub(0), self.s_hb.sub(0), toff)
             p.salu("s_addc_u32", self.s_t0.sub(1), self.s_hb.sub(1), 0)
             p.global_load(4, dst.sub(0, 4), self.v_GO, self.s_t0)
             p.global_load(4, dst.sub(4, 4), self.v_GOI, self.s_t0)
         if half in (None, 1):
-            p.salu("s_add_u32", self.s_t1.sub(0), self.s_sb.sub(0), self.s_toff[u])
+            p.salu("s_add_u32", self.s_t1.sub(0), self.s_sb.sub(0), toff)
             p.salu("s_addc_u32", self.s_t1.sub(1), self.s_sb.sub(1), 0)
             p.global_load(4, dst.sub(8, 4), self.v_GO, self.s_t1)
             p.global_load(4, dst.sub(12, 4), self.v_GOI, self.s_t1)
@@ -441,6 +489,10 @@ class Gen:
         both triangles (T18FormA::commit with the summed controls: xr = fma(1, s, h) = h + s)"""
         p = self.p
         ta, tb, tc = self.vp.alloc(), self.vp.alloc(), self.vp.alloc()
+        # A = -i dt H = dt H.im - i dt H.re; a transposed walk forms A^T = -conj(A): the real part changes its sign
+        dtT = S(self.s_tmp[4].idx, 2)
+        p.salu("s_mov_b32", dtT.sub(0), self.s_dt.sub(0))
+        p.salu("s_xor_b32", dtT.sub(1), self.s_dt.sub(1), self.s_tflip)
         for u in range(5):
             src = pf[u]
             hr, hi_, sr, si = ta.sub(0, 4), ta.sub(4, 4), tb.sub(0, 4), tb.sub(4, 4)
@@ -453,8 +505,8 @@ class Gen:
             p.valu("v_add_f64", xr1, hr.d(1), sr.d(1))
             p.valu("v_add_f64", xi0, hi_.d(0), si.d(0))
             p.valu("v_add_f64", xi1, hi_.d(1), si.d(1))
-            p.valu("v_mul_f64", ar.d(0), self.s_dt, xi0)
-            p.valu("v_mul_f64", ar.d(1), self.s_dt, xi1)
+            p.valu("v_mul_f64", ar.d(0), dtT, xi0)
+            p.valu("v_mul_f64", ar.d(1), dtT, xi1)
             p.valu("v_mul_f64", ai.d(0), Neg(self.s_dt), xr0)
             p.valu("v_mul_f64", ai.d(1), Neg(self.s_dt), xr1)
             p.valu("v_add_f64", sm.d(0), ar.d(0), ai.d(0))
@@ -666,9 +718,9 @@ class Gen:
         def hook_store(sk, r):
             # element r of slot sk of the previous result: one 16-byte store per lane and k-step (t18_store_u_slot)
             p.salu("s_mov_b64", self.s_save, EXEC)
-            p.salu("s_mov_b64", EXEC, self.s_pmask)
-            p.global_store(4, self.v_UO1 if r < 2 else self.v_UO2, Uprev.sub(16 * sk + 4 * r, 4), self.s_ub[sk],
-                           -4096 if r % 2 == 0 else 0)
+            p.s_cmp("s_cmp_lg_u32", self.s_pm, 0)
+            p.salu("s_cselect_b64", EXEC, -1, 0)
+            p.global_store(4, self.v_UO[r], Uprev.sub(16 * sk + 4 * r, 4), self.s_ub[sk])
             p.salu("s_mov_b64", EXEC, self.s_save)
 
         def bload_A(pl, sk, r):
@@ -812,11 +864,15 @@ class Gen:
             p.dpp_mov(tmp.sub(1), mx.sub(1), ctrl)
             p.valu("v_max_f64", mx, mx, tmp)
         # lane 63 publishes: red[w] = f, red[4 + w] = g, red[8 + w] = n2
+        vrd = ct.sub(2)                                 # RED + 8 w (ct's second double is free)
+        p.salu("s_lshl_b32", self.s_tmp[0], self.s_wave, 3)
+        p.salu("s_add_u32", self.s_tmp[0], self.s_tmp[0], RED)
+        p.valu("v_mov_b32", vrd, self.s_tmp[0])
         p.salu("s_mov_b64", self.s_save, EXEC)
         self.set_exec(0, 0x80000000)
-        p.ds_write(64, self.v_RD, f, 0)
-        p.ds_write(64, self.v_RD, g_, 32)
-        p.ds_write(64, self.v_RD, mx, 64)
+        p.ds_write(64, vrd, f, 0)
+        p.ds_write(64, vrd, g_, 32)
+        p.ds_write(64, vrd, mx, 64)
         p.salu("s_mov_b64", EXEC, self.s_save)
         for t in (ct, cacc, facc, gacc):
             vp.free(t)
@@ -851,6 +907,13 @@ class Gen:
         self.smov64(k2, th * th / (1.0 + 1e-9))
         p.v_cmp("v_cmp_le_f64", S(60, 2), N2, k2)                      # n2 (1 + 1e-9) <= theta^2
         p.salu("s_or_b64", S(58, 2), S(58, 2), S(60, 2))               # ok (per lane, all lanes alike)
+        # a cell beyond the bound will be redone by the five-product launch: what this walk propagates ends here
+        # (s_prop: bit 0 a state is being carried along, bit 1 the verdict of THIS cell failed -- also when nothing is carried
+        # yet: a trajectory must not be entered through a cell that is beyond the bound)
+        p.salu("s_and_b32", self.s_prop, self.s_prop, 1)
+        p.s_cmp("s_cmp_eq_u64", S(58, 2), 0)
+        p.salu("s_cselect_b32", self.s_tmp[4], 2, 0)
+        p.salu("s_or_b32", self.s_prop, self.s_prop, self.s_tmp[4])
         # verdict[cell] = !ok, lane 0 of wave 0
         p.valu("v_cndmask_b32", vz.sub(1), 1, 0, S(58, 2))
         p.salu("s_lshl_b32", self.s_tmp[2], self.s_cell, 2)
@@ -1016,7 +1079,210 @@ class Gen:
             self.interleave(streams[g:g + 4])
         p.s_barrier()                                   # everybody is done reading the planes
         self.stamp(10)
+        for t in self.QT:           # (the accumulators are dead: the result is in Un)
+            vp.free_tiles.append(t)
+        vp.free_tiles.sort()
+        self.propagate(Un)
         self.end_of_cell(pf, Qt, Un)
+
+    # ---- the state this walk carries along (module text, round 5) ----
+    def flush_progress(self, tag, at=None):
+        """prog[(descending ? K : 0) + kc] = s_prog (lane 0 of wave 0); the rare path: pointers come from the kernel arguments.
+        at: the tile of temporaries (between two cells the lowest free tiles still hold the result that is to be stored)"""
+        p = self.p
+        t = self.vp.alloc(at=at)
+        pp, tk = S(self.s_tmp[0].idx, 2), self.s_tmp[2]
+        p.s_load(2, pp, self.s_karg, 112)
+        p.s_load(1, tk, self.s_karg, 120)
+        p.s_waitcnt(lgkm=0)
+        p.s_cmp("s_cmp_eq_u32", self.s_step, 1)
+        p.salu("s_cselect_b32", tk, 0, tk)
+        p.salu("s_add_u32", tk, tk, self.s_kc)
+        p.salu("s_lshl_b32", tk, tk, 2)
+        p.salu("s_add_u32", pp.sub(0), pp.sub(0), tk)
+        p.salu("s_addc_u32", pp.sub(1), pp.sub(1), 0)
+        p.valu("v_mov_b32", t.sub(0), 0)
+        p.valu("v_mov_b32", t.sub(1), self.s_prog)
+        p.salu("s_mov_b64", self.s_save, EXEC)
+        p.s_cmp("s_cmp_eq_u32", self.s_wave, 0)
+        p.salu("s_cselect_b32", self.s_tmp[4], 1, 0)
+        p.salu("s_mov_b32", self.s_tmp[5], 0)
+        p.salu("s_mov_b64", EXEC, S(self.s_tmp[4].idx, 2))
+        p.global_store(1, t.sub(0), t.sub(1), pp)
+        p.salu("s_mov_b64", EXEC, self.s_save)
+        p.s_waitcnt(vm=0)
+        self.vp.free(t)
+
+    def propagate(self, Un):
+        """x <- M^T x with the cell's result M = Un still in registers (lane (c, rg), slot sl, register r: element
+        (16 ((w + sl) & 3) + 4 r + rg, 16 w + c)), the new state to fw / bw and to the other state buffer"""
+        p, vp = self.p, self.vp
+        uid = len(p.ins)
+        L_entry_done, L_noprop, L_stop = f"L_pr_entered_{uid}", f"L_pr_none_{uid}", f"L_pr_stop_{uid}"
+        t0, t1, t2 = self.s_tmp[0], self.s_tmp[1], self.s_tmp[2]
+        # ---- does this cell begin a trajectory at the end the walk starts from?  (n == 0 ascending, n == N_T - 1 descending) ----
+        p.salu("s_sub_u32", t1, self.s_NT, 1)
+        p.s_cmp("s_cmp_eq_u32", self.s_step, 1)
+        p.salu("s_cselect_b32", t1, 0, t1)
+        p.s_cmp("s_cmp_lg_u32", self.s_n, t1)
+        p.s_branch("s_cbranch_scc1", L_entry_done)
+        p.salu("s_and_b32", t0, self.s_prop, 2)           # (the very first cell of the trajectory is already beyond the bound)
+        p.s_cmp("s_cmp_lg_u32", t0, 0)
+        p.s_branch("s_cbranch_scc1", L_entry_done)
+        p.s_load(1, t0, self.s_karg, 60)                                 # fuse
+        p.s_load(1, t2, self.s_karg, 120)                                # K
+        p.s_load(2, self.s_t1, self.s_karg, 88)                          # xinit
+        p.s_load(4, S(48, 4), self.s_karg, 96)                           # fw, bw
+        p.s_waitcnt(lgkm=0)
+        # (s_sb = s48:49 and s_t0 = s50:51 -- the bases the fetches of the last product consumed -- are free until the next
+        # cell requests its own)
+        p.s_cmp("s_cmp_eq_u32", self.s_step, 1)
+        p.salu("s_cselect_b32", t1, 0, 1)                                # direction slot: 0 ascending, 1 descending
+        p.salu("s_lshr_b32", t0, t0, t1)
+        p.salu("s_and_b32", t0, t0, 1)
+        p.s_cmp("s_cmp_eq_u32", t0, 0)
+        p.s_branch("s_cbranch_scc1", L_entry_done)
+        # state pointer: (kc (N_T + 1) + (ascending ? 1 : N_T - 1)) 1024 behind fw / bw
+        p.s_cmp("s_cmp_eq_u32", self.s_step, 1)
+        p.salu("s_cselect_b32", self.s_stp.sub(0), S(48), S(50))
+        p.salu("s_cselect_b32", self.s_stp.sub(1), S(49), S(51))
+        p.salu("s_add_u32", self.s_tmp[3], self.s_NT, 1)
+        p.salu("s_mul_i32", self.s_tmp[3], self.s_tmp[3], self.s_kc)
+        p.salu("s_sub_u32", self.s_tmp[4], self.s_NT, 1)
+        p.s_cmp("s_cmp_eq_u32", self.s_step, 1)
+        p.salu("s_cselect_b32", self.s_tmp[4], 1, self.s_tmp[4])
+        p.salu("s_add_u32", self.s_tmp[3], self.s_tmp[3], self.s_tmp[4])
+        p.salu("s_lshr_b32", self.s_tmp[4], self.s_tmp[3], 22)
+        p.salu("s_lshl_b32", self.s_tmp[3], self.s_tmp[3], 10)
+        p.salu("s_add_u32", self.s_stp.sub(0), self.s_stp.sub(0), self.s_tmp[3])
+        p.salu("s_addc_u32", self.s_stp.sub(1), self.s_stp.sub(1), self.s_tmp[4])
+        # xinit[(slot K + kc) 64 + lane]: wave 0 loads the 64 elements and writes them planar, rows in the order qrow
+        p.salu("s_mul_i32", t2, t2, t1)
+        p.salu("s_add_u32", t2, t2, self.s_kc)
+        p.salu("s_lshr_b32", self.s_tmp[4], t2, 22)
+        p.salu("s_lshl_b32", t2, t2, 10)
+        p.salu("s_add_u32", self.s_t1.sub(0), self.s_t1.sub(0), t2)
+        p.salu("s_addc_u32", self.s_t1.sub(1), self.s_t1.sub(1), self.s_tmp[4])
+        p.salu("s_mov_b32", self.s_xs, XS0)
+        p.salu("s_mov_b32", self.s_prog, 0)
+        p.salu("s_mov_b32", self.s_prop, 1)
+        ti = vp.alloc()
+        vo, va, vb, xv = ti.sub(0), ti.sub(1), ti.sub(2), ti.sub(4, 4)
+        p.valu("v_lshlrev_b32", vo, 4, self.v_lane)
+        p.valu("v_and_b32", va, 3, self.v_lane)
+        p.valu("v_lshlrev_b32", va, 2, va)
+        p.valu("v_lshrrev_b32", vb, 2, self.v_lane)
+        p.valu("v_and_b32", vb, 3, vb)
+        p.valu("v_add_u32", va, va, vb)                                  # qrow(lane & 15)
+        p.valu("v_and_b32", vb, 48, self.v_lane)
+        p.valu("v_add_u32", va, va, vb)                                  # 16 (lane >> 4) + qrow(lane & 15)
+        p.valu("v_lshlrev_b32", va, 3, va)
+        p.valu("v_add_u32", va, XS0, va)
+        p.salu("s_mov_b64", self.s_save, EXEC)
+        p.s_cmp("s_cmp_eq_u32", self.s_wave, 0)
+        p.salu("s_cselect_b64", EXEC, -1, 0)
+        p.global_load(4, xv, vo, self.s_t1)
+        p.s_waitcnt(vm=0)
+        p.ds_write(64, va, xv.sub(0, 2), 0)
+        p.ds_write(64, va, xv.sub(2, 2), 512)
+        p.salu("s_mov_b64", EXEC, self.s_save)
+        p.s_waitcnt(lgkm=0)
+        p.s_barrier()
+        vp.free(ti)
+        p.label(L_entry_done)
+        p.s_cmp("s_cmp_eq_u32", self.s_prop, 0)
+        p.s_branch("s_cbranch_scc1", L_noprop)
+        p.s_cmp("s_cmp_lg_u32", self.s_prop, 1)
+        p.s_branch("s_cbranch_scc1", L_stop)
+        # ---- z_j = sum_i M_ij x_i over this lane's 16 rows ----
+        X = [vp.alloc() for _ in range(8)]                               # X[2 sl] = x.re of slot sl (4 doubles), X[2 sl + 1] = x.im
+        ta = vp.alloc()
+        vx0 = ta.sub(0)
+        p.valu("v_lshrrev_b32", vx0, 4, self.v_lane)
+        p.valu("v_lshlrev_b32", vx0, 5, vx0)                             # 32 rg
+        for sl in range(4):
+            p.salu("s_add_u32", t0, self.s_wave, sl)
+            p.salu("s_and_b32", t0, t0, 3)
+            p.salu("s_lshl_b32", t0, t0, 7)
+            p.salu("s_add_u32", t0, t0, self.s_xs)
+            p.valu("v_add_u32", ta.sub(1 + sl), t0, vx0)                 # xs + 128 tb + 32 rg
+        for sl in range(4):
+            for pl in range(2):
+                for h in range(2):
+                    p.ds_read(128, X[2 * sl + pl].sub(4 * h, 4), ta.sub(1 + sl), 512 * pl + 16 * h)
+        acc = vp.alloc()                                                 # four sums: M.re x.re, M.im x.im, M.re x.im, M.im x.re
+        first = True
+        for sl in range(4):
+            for r in range(4):
+                mr, mi = Un.sub(16 * sl + 4 * r, 2), Un.sub(16 * sl + 4 * r + 2, 2)
+                xr, xi = X[2 * sl].d(r), X[2 * sl + 1].d(r)
+                for q, (m_, x_) in enumerate(((mr, xr), (mi, xi), (mr, xi), (mi, xr))):
+                    if first:
+                        p.valu("v_mul_f64", acc.d(q), m_, x_)
+                    else:
+                        p.valu("v_fma_f64", acc.d(q), m_, x_, acc.d(q))
+                first = False
+        z = X[0]
+        p.valu("v_add_f64", z.d(0), acc.d(0), Neg(acc.d(1)))             # z.re = sum (M.re x.re - M.im x.im)
+        p.valu("v_add_f64", z.d(1), acc.d(2), acc.d(3))                  # z.im
+        # the four lane rows meet in the LDS (a wave's own LDS operations are ordered: no barrier)
+        vpa = ta.sub(5)
+        p.salu("s_lshl_b32", t0, self.s_wave, 10)
+        p.salu("s_add_u32", t0, t0, PART)
+        p.valu("v_lshl_add_u32", vpa, self.v_lane, 4, t0)                # PART + 1024 w + 16 lane
+        p.ds_write(128, vpa, z.sub(0, 4), 0)
+        p.salu("s_mov_b64", self.s_save, EXEC)
+        self.set_exec(0xFFFF, 0)                                         # lanes 0..15: column 16 w + c
+        P4 = [X[1], X[2]]
+        for g in range(4):
+            p.ds_read(128, P4[g // 2].sub(4 * (g % 2), 4), vpa, 256 * g)
+        # meanwhile: where the new state goes (rows in the order qrow) and the offset of its global copy
+        vq, vg, vt = ta.sub(6), ta.sub(7), X[3].sub(0)
+        p.valu("v_and_b32", vq, 3, self.v_lane)
+        p.valu("v_lshlrev_b32", vq, 2, vq)
+        p.valu("v_lshrrev_b32", vt, 2, self.v_lane)
+        p.valu("v_add_u32", vq, vq, vt)                                  # qrow(c)
+        p.salu("s_lshl_b32", t0, self.s_wave, 7)
+        p.salu("s_xor_b32", t1, self.s_xs, XS0 ^ XS1)
+        p.salu("s_add_u32", t0, t0, t1)
+        p.valu("v_lshl_add_u32", vq, vq, 3, t0)                          # other buffer + 8 (16 w + qrow(c))
+        p.salu("s_lshl_b32", t0, self.s_wave, 8)
+        p.valu("v_lshl_add_u32", vg, self.v_lane, 4, t0)                 # 16 (16 w + c)
+        zr, zi = z.d(2), z.d(3)
+        p.valu("v_add_f64", zr, P4[0].d(0), P4[0].d(2))
+        p.valu("v_add_f64", zi, P4[0].d(1), P4[0].d(3))
+        p.valu("v_add_f64", zr, zr, P4[1].d(0))
+        p.valu("v_add_f64", zi, zi, P4[1].d(1))
+        p.valu("v_add_f64", zr, zr, P4[1].d(2))
+        p.valu("v_add_f64", zi, zi, P4[1].d(3))
+        p.ds_write(64, vq, zr, 0)
+        p.ds_write(64, vq, zi, 512)
+        # the global copy: Psi as it is; the descending walk carries conj(chi)
+        out = X[3].sub(4, 4)
+        p.valu("v_mov_b64", out.sub(0, 2), zr)
+        p.valu("v_mov_b32", out.sub(2), zi.sub(0))
+        p.salu("s_and_b32", t0, self.s_step, 0x80000000)
+        p.valu("v_xor_b32", out.sub(3), t0, zi.sub(1))
+        p.global_store(4, vg, out, self.s_stp)
+        p.salu("s_mov_b64", EXEC, self.s_save)
+        for t in X + [ta, acc]:
+            vp.free(t)
+        # loop-carried scalars: the other buffer, the next row of fw / bw, one more step
+        p.salu("s_xor_b32", self.s_xs, self.s_xs, XS0 ^ XS1)
+        p.salu("s_lshl_b32", t0, self.s_step, 10)
+        p.salu("s_ashr_i32", t1, self.s_step, 31)
+        p.salu("s_add_u32", self.s_stp.sub(0), self.s_stp.sub(0), t0)
+        p.salu("s_addc_u32", self.s_stp.sub(1), self.s_stp.sub(1), t1)
+        p.salu("s_add_u32", self.s_prog, self.s_prog, 1)
+        p.s_branch("s_branch", L_noprop)
+        p.label(L_stop)                                   # the verdict of this cell failed
+        L_nf = f"L_pr_nf_{uid}"
+        p.s_cmp("s_cmp_lg_u32", self.s_prop, 3)
+        p.s_branch("s_cbranch_scc1", L_nf)
+        self.flush_progress("stop")                       # (a state was being carried: this is as far as it got)
+        p.label(L_nf)
+        p.salu("s_mov_b32", self.s_prop, 0)
+        p.label(L_noprop)
 
     def end_of_cell(self, pf, Qt, Un):
         p, vp, ap = self.p, self.vp, self.ap
@@ -1027,29 +1293,34 @@ class Gen:
         p.s_barrier()
         self.stamp(11)
         vp.free(Un)           # (the result stays where it is: the next cell's first product stores it)
-        for t in self.QT:
-            vp.free_tiles.append(t)
-        vp.free_tiles.sort()
 
     # -----------------------------------------------------------------------------------------------------------------
     def advance(self):
-        """(nkc, nn, ncell) = the cell after (kc, n, cell), clamped to the current one behind the last"""
+        """(nkc, nn, ncell) = the cell after (kc, n, cell) on this walk (step +1 or -1 over the flattened index kc N_T + n),
+        clamped to the current one behind the last"""
         p = self.p
-        p.salu("s_add_u32", self.s_tmp[2], self.s_idx, self.s_step)
+        uid = len(p.ins)
+        lab, lab_up = f"L_adv_{uid}", f"L_adv_up_{uid}"
+        p.salu("s_add_u32", self.s_tmp[2], self.s_idx, 1)
         p.salu("s_mov_b32", self.s_nkc, self.s_kc)
         p.salu("s_mov_b32", self.s_nn, self.s_n)
         p.salu("s_mov_b32", self.s_ncell, self.s_cell)
         p.s_cmp("s_cmp_ge_u32", self.s_tmp[2], self.s_end)
-        lab = f"L_adv_{len(p.ins)}"
         p.s_branch("s_cbranch_scc1", lab)
         p.salu("s_add_u32", self.s_ncell, self.s_cell, self.s_step)
         p.salu("s_add_u32", self.s_nn, self.s_n, self.s_step)
-        p.label(lab + "_w")
-        p.s_cmp("s_cmp_lt_u32", self.s_nn, self.s_NT)
+        p.s_cmp("s_cmp_eq_u32", self.s_step, 1)
+        p.s_branch("s_cbranch_scc1", lab_up)
+        p.s_cmp("s_cmp_ge_i32", self.s_nn, 0)               # descending: n = -1 -> the last step of the trajectory before
         p.s_branch("s_cbranch_scc1", lab)
-        p.salu("s_sub_u32", self.s_nn, self.s_nn, self.s_NT)
+        p.salu("s_sub_u32", self.s_nn, self.s_NT, 1)
+        p.salu("s_sub_u32", self.s_nkc, self.s_nkc, 1)
+        p.s_branch("s_branch", lab)
+        p.label(lab_up)
+        p.s_cmp("s_cmp_lt_u32", self.s_nn, self.s_NT)       # ascending: n = N_T -> the first step of the next trajectory
+        p.s_branch("s_cbranch_scc1", lab)
+        p.salu("s_mov_b32", self.s_nn, 0)
         p.salu("s_add_u32", self.s_nkc, self.s_nkc, 1)
-        p.s_branch("s_branch", lab + "_w")
         p.label(lab)
 
     def u_bases(self, cell):
@@ -1063,7 +1334,9 @@ class Gen:
             p.salu("s_addc_u32", self.s_ub[sl].sub(1), self.s_U.sub(1), t1)
             p.salu("s_add_u32", t0, self.s_wave, sl)
             p.salu("s_and_b32", t0, t0, 3)
-            p.salu("s_lshl_b32", t0, t0, 14)
+            p.s_cmp("s_cmp_lg_u32", self.s_tflip, 0)        # row tile tb: 16 rows of 1024 bytes, or (transposed walk) 16 positions of 16
+            p.salu("s_cselect_b32", t1, 8, 14)
+            p.salu("s_lshl_b32", t0, t0, t1)
             p.salu("s_add_u32", self.s_ub[sl].sub(0), self.s_ub[sl].sub(0), t0)
             p.salu("s_addc_u32", self.s_ub[sl].sub(1), self.s_ub[sl].sub(1), 0)
 
@@ -1084,19 +1357,29 @@ class Gen:
         self.cell()
         # loop-carried scalars
         self.u_bases(self.s_cell)
-        p.salu("s_mov_b64", self.s_pmask, -1)
+        p.salu("s_mov_b32", self.s_pm, 1)
+        p.salu("s_add_u32", self.s_idx, self.s_idx, 1)
+        # leaving a trajectory (or the walk): how far its propagation got
+        p.s_cmp("s_cmp_lg_u32", self.s_prop, 1)
+        p.s_branch("s_cbranch_scc1", "L_no_flush")
+        p.s_cmp("s_cmp_ge_u32", self.s_idx, self.s_end)
+        p.s_branch("s_cbranch_scc1", "L_flush")
+        p.s_cmp("s_cmp_eq_u32", self.s_nkc, self.s_kc)
+        p.s_branch("s_cbranch_scc1", "L_no_flush")
+        p.label("L_flush")
+        self.flush_progress("leave", at=self.QT[0])
+        p.salu("s_mov_b32", self.s_prop, 0)
+        p.label("L_no_flush")
         p.salu("s_mov_b32", self.s_kc, self.s_nkc)
         p.salu("s_mov_b32", self.s_n, self.s_nn)
         p.salu("s_mov_b32", self.s_cell, self.s_ncell)
-        p.salu("s_add_u32", self.s_idx, self.s_idx, self.s_step)
         p.s_cmp("s_cmp_lt_u32", self.s_idx, self.s_end)
         p.s_branch("s_cbranch_scc1", "L_cell")
         # the last result
         Uprev = V(8 * self.UT, 64)
         for sk in range(4):
             for rr in range(4):
-                p.global_store(4, self.v_UO1 if rr < 2 else self.v_UO2, Uprev.sub(16 * sk + 4 * rr, 4), self.s_ub[sk],
-                               -4096 if rr % 2 == 0 else 0)
+                p.global_store(4, self.v_UO[rr], Uprev.sub(16 * sk + 4 * rr, 4), self.s_ub[sk])
         p.label("L_end")
         p.s_endpgm()
         return p

@@ -126,6 +126,15 @@ struct grape_handle {
     // the four-product route as hand-allocated assembly (asm/gen_t16.py; GRAPE_EXPM_ASM=0: the C++ kernel): four tiles
     // per side, Hermitian generators, controls shared by the trajectories
     bool asm16 = false;
+    // round 5: the assembly kernel's workgroups walk contiguous ranges of cells (d_wgtab) and carry the state of their
+    // trajectory along while the cell's result is in registers -- Psi upwards from t = 0, conj(chi~) downwards from t = T
+    // (d_xinit: the two start vectors of every trajectory) -- and report how far each end got (d_prog[2][K]); the sweep
+    // kernel behind picks up from there.  GRAPE_EXPM_WALK=0: the kernel only exponentiates (A/B timing, parity twin).
+    int *d_wgtab = nullptr, *d_prog = nullptr;
+    double2 *d_xinit = nullptr;
+    int asm_blocks = 0;
+    int asm_walk = 0;            // bits of the walks that may carry a state: 1 ascending (Psi), 2 descending (conj(chi~)); GRAPE_EXPM_WALK
+                                 // = 0 / 1 / 2 narrows it (diagnostics, A/B timing)
     // the stream of the last device-pointer call: the getters that read device buffers wait for the device when it was
     // not the handle's own stream (a caller's non-blocking stream is not ordered against a blocking copy)
     bool foreign_stream = false;
@@ -294,7 +303,9 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
-extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks);
+extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
+                                    const void *const *walk, int fuse, int K);
+extern "C" void grape_t16_walks(int KC, int N_T, int nblk, int *tab);
 extern "C" int grape_t16_credit_launch(const void *args, size_t args_size, void *stream);
 // deriv3_kernel keeps the upper 16 x 16 tiles (re, im; stride 17) of H0_k and of the L control operators in LDS
 // (general drift: all NT x NT tiles of H0_k, three and four tiles per side and at most two controls)
@@ -1236,7 +1247,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -1757,6 +1768,36 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     h->asm16 = h->asm16 && h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT == 4 && !p->hc_per_traj && (long)K * N_T < (1L << 28);
     if (h->t18 && !h->large && !h->series && (L > 2 || h->asm16) && !p->hc_per_traj && (h->NT >= 3 || h->t18_small))
         CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * NP * NP));
+    if (h->asm16) {
+        // one workgroup per CU (512 registers, 139 KB of LDS), never more workgroups than cells
+        const long ncell = (long)h->KC * N_T;
+        h->asm_blocks = (int)std::max<long>(1, std::min<long>(h->num_cus, ncell));
+        std::vector<int> tab((size_t)4 * h->asm_blocks);
+        grape_t16_walks(h->KC, N_T, h->asm_blocks, tab.data());
+        CCHK(dmalloc(&h->d_wgtab, tab.size()));
+        CCHK(hipMemcpy(h->d_wgtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        const char *envw = getenv("GRAPE_EXPM_WALK");
+        // (generator classes: one propagator serves several trajectories -- nothing to carry along)
+        h->asm_walk = h->KC == K ? (envw ? atoi(envw) & 3 : 3) : 0;
+        if (h->asm_walk) {
+            std::vector<double> xi((size_t)2 * K * 64 * 2, 0.0);
+            for (int k = 0; k < K; ++k) {
+                double n2 = 0.0;
+                for (int i = 0; i < 2 * N; ++i) n2 += p->target[(size_t)k * 2 * N + i] * p->target[(size_t)k * 2 * N + i];
+                const double itn = n2 > 0.0 ? 1.0 / std::sqrt(n2) : 0.0;
+                for (int i = 0; i < N; ++i) {
+                    xi[2 * ((size_t)k * 64 + i)] = p->psi0[2 * ((size_t)k * N + i)];
+                    xi[2 * ((size_t)k * 64 + i) + 1] = p->psi0[2 * ((size_t)k * N + i) + 1];
+                    xi[2 * ((size_t)(K + k) * 64 + i)] = p->target[2 * ((size_t)k * N + i)] * itn;
+                    xi[2 * ((size_t)(K + k) * 64 + i) + 1] = -p->target[2 * ((size_t)k * N + i) + 1] * itn;   // conj
+                }
+            }
+            CCHK(dmalloc(&h->d_xinit, (size_t)2 * K * 64));
+            CCHK(hipMemcpy(h->d_xinit, xi.data(), xi.size() * 8, hipMemcpyHostToDevice));
+            CCHK(dmalloc(&h->d_prog, (size_t)2 * K));
+            CCHK(hipMemset(h->d_prog, 0, (size_t)2 * K * sizeof(int)));
+        }
+    }
     // (N <= 16 stays with five products: one tile per side is latency-bound -- the kernel gains nothing from the shorter
     // polynomial and the second launch costs 10 us of an evaluation of 0.4 ms; measured at C2: 0.079 -> 0.098 ms)
     if (h->t16 && h->t18 && h->herm && !h->large && !h->series && (h->NT >= 3 || (h->NT == 2 && h->t18_small))) {
@@ -1885,6 +1926,12 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         CCHK(dmalloc(&h->d_gb, (size_t)K * (N_T + 1)));
     }
     CCHK(hipHostMalloc((void **)&h->h_pin, h->h_pin_doubles * 8, hipHostMallocDefault));
+    // Everything above went through the NULL stream (hipMemset of device memory returns before the fill has run; a copy from
+    // pageable memory returns once the data is staged), the evaluations run on the handle's own NON-BLOCKING stream, which
+    // the NULL stream does not order: without this wait the fill of the stored-state arrays (1 GB at C4) can still be in
+    // flight when the first evaluation starts and zero rows it has already written.  (Found in round 5: the walks of the
+    // assembly kernel write fw / bw within microseconds of the first launch -- before, the first writer came 12 ms in.)
+    CCHK(hipDeviceSynchronize());
 #undef CCHK
     test_throw_point("late");
     *out = guard.release();
@@ -1922,6 +1969,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     grape_t18_set_stamps(d_stamps, (void *)s);
 #endif
     hipError_t e = hipSuccess;
+    int walk_fuse = 0;   // bits of the states the exponential kernel of THIS evaluation carried along (see grape_handle::d_prog)
     if (!h->series) {
         phase_begin(h, 0, s);
         if (h->large) {
@@ -1954,7 +2002,12 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                 const int blocks16 = (t16 && h->NT == 3) ? 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * 2, (ncell + 7) / 8)) : t18_blocks;
                 h->credit_pending = false;
                 if (t16 && h->asm16) {   // (the verdicts of the assembly kernel go through the flag array of the Pade path)
-                    e = (hipError_t)grape_t16_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, t18_blocks);
+                    // what the walks may carry along: Psi always (the forward sweep is the same whatever follows), conj(chi~)
+                    // when this evaluation runs the backward sweep from the unit targets (concurrent sweeps)
+                    walk_fuse = h->asm_walk & (1 | ((h->fuse && h->fuse_on && h->want_bw) ? 2 : 0));
+                    if (walk_fuse) HIPCHK(h, hipMemsetAsync(h->d_prog, 0, (size_t)2 * h->K * sizeof(int), s));
+                    const void *walk[5] = {h->d_wgtab, h->d_xinit, h->d_fw, h->d_bw, h->d_prog};
+                    e = (hipError_t)grape_t16_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, h->asm_blocks, walk, walk_fuse, h->K);
                     h->credit_pending = true;
                 }
                 else
@@ -2020,6 +2073,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     sa.store = h->d_fw; sa.tau = (double2 *)d_out; sa.f = nullptr; sa.rho = h->d_rho; sa.flags = h->d_flags;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
+    if (walk_fuse & 1) sa.resume = h->d_prog;
     if (h->test_hooks) {   // fault injection (test suite only, see grape_handle::test_hooks)
         const char *envd = getenv("GRAPE_TEST_DROP_SIBLING");
         sa.drop_sibling = envd ? atoi(envd) : 0;
@@ -2032,6 +2086,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         // backward sweep from the unit targets in the same launch: K more workgroups on the other CUs
         SweepArgs sb = sa;
         sb.store = h->d_bw; sb.tau = (double2 *)h->d_out; sb.f = nullptr; sb.unit_chi = 1; sb.inv_tnorm = h->d_inv_tnorm;
+        sb.resume = (walk_fuse & 2) ? h->d_prog + h->K : nullptr;
         if (h->series && h->large) {
             e = launch_cheby(h, &sa, &sb, s);
         } else if (h->series) {

@@ -2130,6 +2130,10 @@ struct SweepArgs {
     // of every trajectory exits at once, so that the others run into their spin limit -- the evaluation must fail
     // with GRAPE_ERR_HIP and the grid must drain; 0 in production
     int drop_sibling;
+    // round 5: the exponential kernel (asm/gen_t16.py) has already carried the state of trajectory k over its first
+    // resume[k] steps -- forward from t = 0 / backward from t = T -- and stored those states; the sweep picks up behind them
+    // (nullptr: from the boundary)
+    const int *resume;
 };
 
 // c_k of chi_k(T) = c_k target_k for the three functionals (docs/src/tutorial.md:349-356, 402)
@@ -2239,6 +2243,11 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
         }
     }
     __syncthreads();
+    const int step_start = a.resume ? min(max(a.resume[k], 0), a.N_T) : 0;
+    if (step_start > 0) {   // the state behind the steps the exponential kernel has done (it stored every one of them)
+        if (tid < NP) x[0][tid] = st[(size_t)(BACKWARD ? a.N_T - step_start : step_start) * NP + tid];
+        __syncthreads();
+    }
 
     int cur = 0;
     // software prefetch: the U tiles of the next steps are in flight while step n is reduced (the recurrence only
@@ -2263,8 +2272,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &a, const int k) {
     double2 un[D][RW];
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (d < a.N_T) load_tile(un[d], d);
-    for (int step0 = 0; step0 < a.N_T; step0 += D) {
+        if (step_start + d < a.N_T) load_tile(un[d], step_start + d);
+    for (int step0 = step_start; step0 < a.N_T; step0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int step = step0 + d;

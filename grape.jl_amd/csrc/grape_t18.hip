@@ -102,16 +102,22 @@ extern "C" int grape_deriv3_launch(int NT, const void *d2args, size_t d2size, co
 // C++ kernel books in its cell loop (credited work of Julia's exp!, executed matrix instructions).
 extern "C" const unsigned char grape_asm_co_start[], grape_asm_co_end[];
 namespace {
-struct T16AsmArgs {           // kernel argument block of expm_t16_asm (gen_t16.py: KERNARG = 80 bytes)
+struct T16AsmArgs {           // kernel argument block of expm_t16_asm (gen_t16.py: KERNARG = 128 bytes)
     const double *H0f, *Sf, *dts;
     double2 *U;
     int *verdict;
     const int *rep;
-    int KC, N_T, nblk, pad0;
+    int KC, N_T, nblk;
+    int fuse;                   // bit 0: ascending walks carry Psi along, bit 1: descending walks carry conj(chi) (round 5)
     unsigned long long *diag;   // diagnostic builds: stamp area
     const int *flags;           // flags[6]: cells predicted beyond the route's range (t16_plan_kernel)
+    const int *wgtab;           // [nblk][4]: first cell, number of cells, step (+1 / -1), - of every workgroup's walk
+    const double2 *xinit;       // [2][K][64]: Psi0_k; conj(target_k) / ||target_k||
+    double2 *fw, *bw;           // [K][N_T + 1][64] stored states
+    int *prog;                  // [2][K] steps each end of each trajectory was propagated by the walks
+    int K, pad0;
 };
-static_assert(sizeof(T16AsmArgs) == 80, "argument block of the assembly kernel");
+static_assert(sizeof(T16AsmArgs) == 128, "argument block of the assembly kernel");
 
 // ||A||_1 of A = -i dt (H0_k + S_n) from the operator planes (t18_norm1 on the same numbers), all 256 threads
 __device__ __forceinline__ double t16_post_norm1(const ExpmArgs &a, const int cell, double *red, const int tid) {
@@ -373,12 +379,32 @@ extern "C" int grape_lg_asm_launch(const void *k, size_t size, unsigned blocks, 
     return (int)hipModuleLaunchKernel(fn, blocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, cfg);
 }
 
-// args: ExpmArgs with Sf set (summed controls of every time step) and cell_list / flags / stats as for the C++ kernel
-extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks) {
+// The deal of the cells of expm_t16_asm (round 5): workgroup b walks the contiguous range [b ncell / nblk, (b + 1) ncell / nblk)
+// of the flattened index kc N_T + n -- ascending when the range begins with the first step of a trajectory (it can carry
+// Psi along from t = 0), descending from its last cell when it ends with the last step of one (conj(chi) from t = T), else
+// ascending.  At the headline shape (128 trajectories, 256 workgroups): one half of a trajectory each, both anchored.
+// tab: [nblk][4] = first cell, count, step, 0 (tests/test_asm_kernel.py t16_walks is the same rule)
+extern "C" void grape_t16_walks(int KC, int N_T, int nblk, int *tab) {
+    const long ncell = (long)KC * N_T;
+    for (int b = 0; b < nblk; ++b) {
+        const long lo = b * ncell / nblk, hi = (b + 1) * ncell / nblk;
+        int *e = tab + 4 * b;
+        e[3] = 0;
+        if (hi == lo) { e[0] = 0; e[1] = 0; e[2] = 1; }
+        else if (lo % N_T == 0 || hi % N_T != 0) { e[0] = (int)lo; e[1] = (int)(hi - lo); e[2] = 1; }
+        else { e[0] = (int)(hi - 1); e[1] = (int)(hi - lo); e[2] = -1; }
+    }
+}
+
+// args: ExpmArgs with Sf set (summed controls of every time step) and cell_list / flags / stats as for the C++ kernel;
+// walk: {wgtab, xinit, fw, bw, prog} device pointers, fuse / K as in T16AsmArgs
+extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
+                                    const void *const *walk, int fuse, int K) {
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
-    if (!a.Sf || a.hc_per_traj || !verdict || blocks < 8 || (blocks & 7)) return (int)hipErrorInvalidValue;
+    if (!a.Sf || a.hc_per_traj || !verdict || blocks < 1 || !walk || !walk[0]) return (int)hipErrorInvalidValue;
+    if (fuse && (!walk[1] || !walk[2] || !walk[3] || !walk[4] || a.rep || K != a.K)) return (int)hipErrorInvalidValue;
     const long ncell = (long)a.K * a.N_T;
     if (ncell <= 0 || ncell >= (1L << 28)) return (int)hipErrorInvalidValue;   // (32-bit cell arithmetic in the kernel)
     int dev = 0;
@@ -390,6 +416,8 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
     T16AsmArgs k{};
     k.H0f = a.H0f; k.Sf = a.Sf; k.dts = a.dts; k.U = a.U; k.verdict = verdict; k.rep = a.rep;
     k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks; k.flags = a.flags;
+    k.fuse = fuse; k.wgtab = (const int *)walk[0]; k.xinit = (const double2 *)walk[1]; k.fw = (double2 *)walk[2];
+    k.bw = (double2 *)walk[3]; k.prog = (int *)walk[4]; k.K = K;
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     hipStream_t s = (hipStream_t)stream;

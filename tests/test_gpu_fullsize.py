@@ -74,14 +74,17 @@ def test_baseline_config_c4_full_1024_trajectory_ensemble(g):
         tm = h.timings()
     # (b) 8 shards of 128 with the two all-reduces by hand (what 8 ranks do over RCCL)
     tau_s, sums, G_s = _sharded_by_hand(g, pr, 8, K)
-    assert np.array_equal(tau_s, tau)
+    # (round 5: with 1024 trajectories on 256 workgroups every walk of the exponential kernel carries whole trajectories
+    # forward, with 128 per shard a walk carries half of one and the sweep kernel does the rest -- the same products in
+    # another order of summation: equal to rounding, not bit for bit)
+    assert np.abs(tau_s - tau).max() <= 1e-13
     J_s = functional_value(0, sums, K)
     assert abs(J_s - J) <= 1e-14
     assert np.abs(G_s - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
     # (c) 8 device shards behind ONE handle (ndev = 8; here all on device 0)
     with g.GrapeHip(*args, devices=[0] * 8) as hm:
         Jm, Gm, taum = hm.eval(x)
-    assert abs(Jm - J) <= 1e-14 and np.array_equal(taum, tau)
+    assert abs(Jm - J) <= 1e-14 and np.abs(taum - tau).max() <= 1e-13
     assert np.abs(Gm - G).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
     print(f"C4 on one GPU: {tm}")
 

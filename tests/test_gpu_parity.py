@@ -431,6 +431,9 @@ def test_trajectories_with_identical_generators_share_propagators(g, ref, N, mon
     pr["H0"][3] = pr["H0"][0]
     pr["H0"][5] = pr["H0"][1]          # classes: {0,2,3}, {1,5}, {4}
     args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    # (bit-for-bit only with the same arithmetic on both sides: one propagator per trajectory lets the walks of the assembly
+    # kernel carry the states along -- round 5 -- which shared propagators cannot; that comparison follows, to rounding)
+    monkeypatch.setenv("GRAPE_EXPM_WALK", "0")
     with g.GrapeHip(*args) as h:
         J, G, tau = h.eval(pr["pulsevals"])
         w = h.work()
@@ -442,6 +445,10 @@ def test_trajectories_with_identical_generators_share_propagators(g, ref, N, mon
         J1, G1, tau1 = h.eval(pr["pulsevals"])
         assert h.work()["expm_cells"] == K * N_T
     assert J == J1 and np.array_equal(G, G1) and np.array_equal(tau, tau1)
+    monkeypatch.delenv("GRAPE_EXPM_WALK")
+    with g.GrapeHip(*args) as h:
+        J2, G2, tau2 = h.eval(pr["pulsevals"])
+    assert abs(J - J2) <= 1e-14 and np.abs(tau - tau2).max() <= 1e-14 and np.abs(G - G2).max() <= 1e-13 * max(np.abs(G).max(), 1e-3)
     Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
                                 gradient_method=ref.TAYLOR)
     assert abs(J - Jr) <= TOL_J and np.abs(tau - taur).max() <= TOL_TAU and np.abs(G - Gr).max() <= tol_G(Gr)
@@ -556,32 +563,33 @@ def test_bench_contract_two_rank_rehearsal(g):
     assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0
 
 
-def test_bench_contract_six_rank_rehearsal_of_config_c4(g):
+def test_bench_contract_four_rank_rehearsal_of_config_c4(g):
     """BASELINE config 4 (128 trajectories per GPU, one rank per GPU) rehearsed with as many ranks as this pool lets one
-    box run against its one GPU -- SIX processes may use the card together, so the driver's 8-rank launch is rehearsed
-    with 6 (768 trajectories instead of 1024; `bench.py --gpus 6 --config C4` under torch.distributed.run, gloo
-    collectives, every rank on device 0).  One JSON line with n_gpus = 6, and the functional value the ranks agree on --
-    formed from the all-reduced sums of six shard handles in six processes -- equals the value ONE handle with all 768
-    trajectories returns, to 1e-14."""
+    box run against its one GPU: SIX processes may have the card open at once, and this test process and the launcher
+    are two of them (a six-rank attempt was killed by the box's process guard: eight processes on the GPU) -- so the
+    driver's 8-rank launch is rehearsed with FOUR (`bench.py --gpus 4 --config C4` under torch.distributed.run, 512
+    trajectories, gloo collectives, every rank on device 0).  One JSON line with n_gpus = 4, and the functional value the
+    ranks agree on -- formed from the all-reduced sums of four shard handles in four processes -- equals the value ONE
+    handle with all 512 trajectories returns, to 1e-14."""
     import json
     import subprocess
     import sys
     from grape_jl_amd import synth
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GRAPE_BENCH_REHEARSAL="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "6", "--master-addr",
-           "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "6", "--config", "C4",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "4", "--config", "C4",
            "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout[:2000]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 6 and d["scaling"] == "weak" and "768 total" in d["config"]["workload"]
-    assert abs(d["value"] - 6 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and "512 total" in d["config"]["workload"]
+    assert abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
     assert d["gradient_allreduce_latency_us"] > 0.0
-    # the same 768 trajectories (rank r owns [128 r, 128 (r + 1)), synth.make_config(k_offset = 128 r)) behind ONE handle
-    prs = [synth.make_config("C4", K=128, k_offset=128 * r) for r in range(6)]
+    # the same 512 trajectories (rank r owns [128 r, 128 (r + 1)), synth.make_config(k_offset = 128 r)) behind ONE handle
+    prs = [synth.make_config("C4", K=128, k_offset=128 * r) for r in range(4)]
     cat = lambda key: np.concatenate([p[key] for p in prs])      # noqa: E731
     with g.GrapeHip(cat("H0"), prs[0]["Hc"], prs[0]["tlist"], cat("psi0"), cat("target"), cat("weights")) as h:
         J1, _, _ = h.eval(prs[0]["pulsevals"])
