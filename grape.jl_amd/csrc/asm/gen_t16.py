@@ -73,12 +73,10 @@ EXW = 2 * EXH                   # bytes per wave of an exchange area
 E2 = E1 + 4 * EXW               # exchange area of the mirrored tiles
 RED = E2 + 4 * EXW              # 16 doubles of reduction scratch
 # state of the trajectory this workgroup walks (round 5): two buffers of 64 complex numbers, planar (re[64] | im[64]) with
-# the rows of a 16-row tile in the order qrow (the four rows 4 r + rg of a lane are contiguous), and the partial sums of
-# the mat-vec, (re, im) per lane
+# the rows of a 16-row tile in the order qrow (the four rows 4 r + rg of a lane are contiguous)
 XS0 = RED + 16 * 8
 XS1 = XS0 + 1024
-PART = XS1 + 1024
-LDS_BYTES = PART + 4 * 1024
+LDS_BYTES = XS1 + 1024
 KERNARG = 128
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -479,12 +477,12 @@ class Gen:
             p.global_load(4, dst.sub(8, 4), self.v_GO, self.s_t1)
             p.global_load(4, dst.sub(12, 4), self.v_GOI, self.s_t1)
 
-    def commit(self, pf):
+    def commit(self, pf, fill=None):
         self.p.tag = "commit"
-        self._commit(pf)
+        self._commit(pf, fill)
         self.p.tag = ""
 
-    def _commit(self, pf):
+    def _commit(self, pf, fill=None):
         """A = -i dt (H0 + S) of the fetched tiles (pf[u]: 16 registers, either half of the file) into the three planes,
         both triangles (T18FormA::commit with the summed controls: xr = fma(1, s, h) = h + s)"""
         p = self.p
@@ -544,6 +542,8 @@ class Gen:
                     p.ds_write(64, vm, ms.d(e), 32 * e + 2 * PLB)
                 if d0 or d1:
                     p.label(lab)
+            if fill:        # (vector work that needs no LDS rides while the stores of this tile drain: the store path is what a commit waits for)
+                fill(u)
         for t in (ta, tb, tc):
             self.vp.free(t)
 
@@ -1190,13 +1190,27 @@ class Gen:
         p.s_barrier()
         vp.free(ti)
         p.label(L_entry_done)
-        p.s_cmp("s_cmp_eq_u32", self.s_prop, 0)
+        # a failed verdict ends what this walk carries (bit 1 of s_prop); afterwards s_prop is 0 or 1
+        p.salu("s_and_b32", t0, self.s_prop, 2)
+        p.s_cmp("s_cmp_eq_u32", t0, 0)
         p.s_branch("s_cbranch_scc1", L_noprop)
+        L_nf = f"L_pr_nf_{uid}"
+        p.s_cmp("s_cmp_lg_u32", self.s_prop, 3)
+        p.s_branch("s_cbranch_scc1", L_nf)
+        self.flush_progress("stop")                       # (a state was being carried: this is as far as it got)
+        p.label(L_nf)
+        p.salu("s_mov_b32", self.s_prop, 0)
+        p.label(L_noprop)
+        # ---- z_j = sum_i M_ij x_i over this lane's 16 rows (walks that carry a state only).  Measured (round 5): a branch-free
+        # form whose arithmetic always runs, spread over the LDS stores of the commit, costs the same 0.25 ms per C3 launch --
+        # what a cell pays is the 64 KB that x takes from the LDS into the registers of all lanes, not latency -- and it
+        # costs that also when nothing is carried (generator classes); so: one branch ----
+        L_mv_end = f"L_pr_mv_end_{uid}"
         p.s_cmp("s_cmp_lg_u32", self.s_prop, 1)
-        p.s_branch("s_cbranch_scc1", L_stop)
-        # ---- z_j = sum_i M_ij x_i over this lane's 16 rows ----
+        p.s_branch("s_cbranch_scc1", L_mv_end)
         X = [vp.alloc() for _ in range(8)]                               # X[2 sl] = x.re of slot sl (4 doubles), X[2 sl + 1] = x.im
         ta = vp.alloc()
+        acc = vp.alloc()                                                 # four sums: M.re x.re, M.im x.im, M.re x.im, M.im x.re
         vx0 = ta.sub(0)
         p.valu("v_lshrrev_b32", vx0, 4, self.v_lane)
         p.valu("v_lshlrev_b32", vx0, 5, vx0)                             # 32 rg
@@ -1210,7 +1224,6 @@ class Gen:
             for pl in range(2):
                 for h in range(2):
                     p.ds_read(128, X[2 * sl + pl].sub(4 * h, 4), ta.sub(1 + sl), 512 * pl + 16 * h)
-        acc = vp.alloc()                                                 # four sums: M.re x.re, M.im x.im, M.re x.im, M.im x.re
         first = True
         for sl in range(4):
             for r in range(4):
@@ -1225,36 +1238,32 @@ class Gen:
         z = X[0]
         p.valu("v_add_f64", z.d(0), acc.d(0), Neg(acc.d(1)))             # z.re = sum (M.re x.re - M.im x.im)
         p.valu("v_add_f64", z.d(1), acc.d(2), acc.d(3))                  # z.im
-        # the four lane rows meet in the LDS (a wave's own LDS operations are ordered: no barrier)
-        vpa = ta.sub(5)
-        p.salu("s_lshl_b32", t0, self.s_wave, 10)
-        p.salu("s_add_u32", t0, t0, PART)
-        p.valu("v_lshl_add_u32", vpa, self.v_lane, 4, t0)                # PART + 1024 w + 16 lane
-        p.ds_write(128, vpa, z.sub(0, 4), 0)
-        p.salu("s_mov_b64", self.s_save, EXEC)
-        self.set_exec(0xFFFF, 0)                                         # lanes 0..15: column 16 w + c
-        P4 = [X[1], X[2]]
-        for g in range(4):
-            p.ds_read(128, P4[g // 2].sub(4 * (g % 2), 4), vpa, 256 * g)
+        # the four lane rows meet in TWO matrix instructions: ones(16 x 4) times the 4 x 16 block of the per-lane sums puts
+        # sum_rg z(c, rg) into every row of column c (the trick of the column sums of the spectral bound) -- no LDS round trip
+        ones = z.d(2)
+        lo, hi = dbits(1.0)
+        p.valu("v_mov_b32", ones.sub(0), lo)
+        p.valu("v_mov_b32", ones.sub(1), hi)
+        ctr, cti = X[1], X[2]
+        p.mfma(ctr, ones, z.d(0), 0)
+        p.mfma(cti, ones, z.d(1), 0)
         # meanwhile: where the new state goes (rows in the order qrow) and the offset of its global copy
         vq, vg, vt = ta.sub(6), ta.sub(7), X[3].sub(0)
         p.valu("v_and_b32", vq, 3, self.v_lane)
         p.valu("v_lshlrev_b32", vq, 2, vq)
         p.valu("v_lshrrev_b32", vt, 2, self.v_lane)
+        p.valu("v_and_b32", vt, 3, vt)
         p.valu("v_add_u32", vq, vq, vt)                                  # qrow(c)
         p.salu("s_lshl_b32", t0, self.s_wave, 7)
         p.salu("s_xor_b32", t1, self.s_xs, XS0 ^ XS1)
         p.salu("s_add_u32", t0, t0, t1)
         p.valu("v_lshl_add_u32", vq, vq, 3, t0)                          # other buffer + 8 (16 w + qrow(c))
         p.salu("s_lshl_b32", t0, self.s_wave, 8)
-        p.valu("v_lshl_add_u32", vg, self.v_lane, 4, t0)                 # 16 (16 w + c)
-        zr, zi = z.d(2), z.d(3)
-        p.valu("v_add_f64", zr, P4[0].d(0), P4[0].d(2))
-        p.valu("v_add_f64", zi, P4[0].d(1), P4[0].d(3))
-        p.valu("v_add_f64", zr, zr, P4[1].d(0))
-        p.valu("v_add_f64", zi, zi, P4[1].d(1))
-        p.valu("v_add_f64", zr, zr, P4[1].d(2))
-        p.valu("v_add_f64", zi, zi, P4[1].d(3))
+        p.valu("v_and_b32", vt, 15, self.v_lane)
+        p.valu("v_lshl_add_u32", vg, vt, 4, t0)                          # 16 (16 w + c)
+        zr, zi = ctr.d(0), cti.d(0)
+        p.salu("s_mov_b64", self.s_save, EXEC)
+        self.set_exec(0xFFFF, 0)                                         # lanes 0..15: column 16 w + c
         p.ds_write(64, vq, zr, 0)
         p.ds_write(64, vq, zi, 512)
         # the global copy: Psi as it is; the descending walk carries conj(chi)
@@ -1274,15 +1283,7 @@ class Gen:
         p.salu("s_add_u32", self.s_stp.sub(0), self.s_stp.sub(0), t0)
         p.salu("s_addc_u32", self.s_stp.sub(1), self.s_stp.sub(1), t1)
         p.salu("s_add_u32", self.s_prog, self.s_prog, 1)
-        p.s_branch("s_branch", L_noprop)
-        p.label(L_stop)                                   # the verdict of this cell failed
-        L_nf = f"L_pr_nf_{uid}"
-        p.s_cmp("s_cmp_lg_u32", self.s_prop, 3)
-        p.s_branch("s_cbranch_scc1", L_nf)
-        self.flush_progress("stop")                       # (a state was being carried: this is as far as it got)
-        p.label(L_nf)
-        p.salu("s_mov_b32", self.s_prop, 0)
-        p.label(L_noprop)
+        p.label(L_mv_end)
 
     def end_of_cell(self, pf, Qt, Un):
         p, vp, ap = self.p, self.vp, self.ap

@@ -234,6 +234,18 @@ struct grape_handle {
                                    // one after the other from the calling thread)
     double host_enqueue_ms = 0.0;  // composite: wall time of the enqueue halves since the last grape_reset_timings
     long host_enqueue_calls = 0;
+    // Small systems are launch-bound (C2: ~14 launches, copies and fills for 0.25 ms of kernels): grape_eval with a gradient
+    // replays the whole evaluation -- H2D of the pulses, every kernel, D2H of the result slab -- as ONE captured HIP graph
+    // (N <= 64, one device).  Nothing in that sequence is decided on the host from device data, so the graph of a handle
+    // never changes (it is rebuilt when grape_set_fused_sweeps changes the sweeps).  The first two evaluations and every
+    // 16th run uncaptured: they warm the lazy parts of the runtime (module loads, LDS limits) and keep the per-phase HIP-event
+    // timings alive (events recorded inside a capture cannot be read).  GRAPE_GRAPH=0: off.
+    bool graph_ok = false, capturing = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_fuse_on = true;     // the setting the graph was captured with
+    bool graph_bw_unit = false, graph_z_valid = false, graph_credit = false;   // host-side state the captured calls leave behind
+    long n_eval = 0;               // grape_eval calls on the single-wait path
 };
 
 namespace {
@@ -764,8 +776,12 @@ hipError_t launch_deriv_sub(int NP, const DerivSubArgs &a, int nblocks, hipStrea
 
 // phases 0,1 belong to the forward call, 2,3,4 to the backward call, 5 to grape_eval
 long phase_slot(grape_handle *h, int i) { return (i <= 1 ? h->n_fwd : (i <= 4 ? h->n_bwd : h->n_fwd)) % kRing; }
-void phase_begin(grape_handle *h, int i, hipStream_t s) { hipEventRecord(h->ph[phase_slot(h, i)][i].e0, s); }
+void phase_begin(grape_handle *h, int i, hipStream_t s) {
+    if (h->capturing) return;   // (events recorded inside a stream capture cannot be read: the uncaptured evaluations time the phases)
+    hipEventRecord(h->ph[phase_slot(h, i)][i].e0, s);
+}
 void phase_end(grape_handle *h, int i, hipStream_t s) {
+    if (h->capturing) return;
     Phase &p = h->ph[phase_slot(h, i)][i];
     hipEventRecord(p.e1, s);
     p.used = true;
@@ -1260,6 +1276,8 @@ void grape_destroy(grape_handle *h) {
             if (p.e0) hipEventDestroy(p.e0);
             if (p.e1) hipEventDestroy(p.e1);
         }
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) hipGraphDestroy(h->graph);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1440,6 +1458,8 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
             h->expm_lds_pad_kb = envl ? std::max(0, atoi(envl)) : 0;
             h->cheby_xmode = envx ? atoi(envx) & 1 : 1;
             h->test_hooks = envk && atoi(envk) == 1;
+            const char *envgr = getenv("GRAPE_GRAPH");
+            h->graph_ok = !(envgr && atoi(envgr) == 0) && !h->test_hooks;
             const char *envlg = getenv("GRAPE_LG_ASM"), *envd3 = getenv("GRAPE_DERIV3_ASM");
             h->lg_asm = !(envlg && atoi(envlg) == 0);
             h->deriv3_asm = !(envd3 && atoi(envd3) == 0);
@@ -2326,7 +2346,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
                        unit ? (const double2 *)h->d_z : (const double2 *)nullptr);
     HIPCHK(h, hipGetLastError());
     phase_end(h, 4, s);
-    h->n_bwd++;
+    if (!h->capturing) h->n_bwd++;
     return GRAPE_OK;
 }
 }  // namespace
@@ -2773,20 +2793,62 @@ int grape_eval(grape_handle *h, const double *pulsevals, double *J, double *G, d
         // the backward half takes f = sum_k w_k tau_k straight from the device-side sums of the forward half (this handle
         // owns all trajectories), and ONE wait at the end reads J's sums, tau, G and the error flags.  (A small system is
         // launch- and latency-bound: at C2 the wait between the halves was a tenth of the evaluation.)
-        phase_begin(h, 5, h->stream);
-        h->in_eval = true;
-        h->want_bw = true;
-        int rc = forward_enqueue(h, pulsevals, false);
-        h->in_eval = false;
-        if (rc) { h->n_fwd++; return rc; }
-        rc = backward_device_impl(h, h->d_out + 2 * (size_t)h->K, h->d_G, h->stream, nullptr);
-        if (rc) { h->n_fwd++; return rc; }
-        // forward outputs | G | flags: contiguous in the result slab and in the staging area -- ONE copy
         const size_t nl_ = (size_t)h->L * h->N_T;
         double *gpin = h->h_pin + nl_ + 2 * (size_t)h->K + 8;
-        HIPCHK(h, hipMemcpyAsync(h->h_pin + nl_, h->d_ret, ((size_t)2 * h->K + 8 + nl_ + 4) * 8, hipMemcpyDeviceToHost, h->stream));
-        phase_end(h, 5, h->stream);
-        h->n_fwd++;
+        int rc;
+        const long ne = h->n_eval++;
+        bool replayed = false;
+        if (h->graph_ok && ne >= 2 && (ne & 15) != 0) {   // (see grape_handle::graph)
+            if (h->graph_exec && h->graph_fuse_on != h->fuse_on) {
+                hipGraphExecDestroy(h->graph_exec); hipGraphDestroy(h->graph);
+                h->graph_exec = nullptr; h->graph = nullptr;
+            }
+            if (!h->graph_exec) {
+                HIPCHK(h, hipSetDevice(h->device));
+                (void)hipGetLastError();
+                bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    h->capturing = true; h->in_eval = true; h->want_bw = true;
+                    rc = forward_enqueue(h, pulsevals, false);
+                    if (!rc) rc = backward_device_impl(h, h->d_out + 2 * (size_t)h->K, h->d_G, h->stream, nullptr);
+                    if (!rc && hipMemcpyAsync(h->h_pin + nl_, h->d_ret, ((size_t)2 * h->K + 8 + nl_ + 4) * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = GRAPE_ERR_HIP;
+                    h->capturing = false; h->in_eval = false;
+                    hipGraph_t gph = nullptr;
+                    ok = hipStreamEndCapture(h->stream, &gph) == hipSuccess && gph && !rc;
+                    if (ok) ok = hipGraphInstantiate(&h->graph_exec, gph, nullptr, nullptr, 0) == hipSuccess;
+                    if (ok) {
+                        h->graph = gph; h->graph_fuse_on = h->fuse_on;
+                        h->graph_bw_unit = h->bw_unit; h->graph_z_valid = h->z_valid; h->graph_credit = h->credit_pending;
+                    } else {
+                        if (gph) hipGraphDestroy(gph);
+                        h->graph_exec = nullptr;
+                    }
+                }
+                if (!ok) { h->graph_ok = false; (void)hipGetLastError(); }   // this runtime cannot capture the sequence: launches as before
+            }
+            if (h->graph_exec) {
+                memcpy(h->h_pin, pulsevals, nl_ * 8);
+                HIPCHK(h, hipSetDevice(h->device));
+                HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+                h->foreign_stream = false; h->have_forward = true; h->bw_done = false;
+                h->bw_unit = h->graph_bw_unit; h->z_valid = h->graph_z_valid; h->credit_pending = h->graph_credit;
+                replayed = true;
+            }
+        }
+        if (!replayed) {
+            phase_begin(h, 5, h->stream);
+            h->in_eval = true;
+            h->want_bw = true;
+            rc = forward_enqueue(h, pulsevals, false);
+            h->in_eval = false;
+            if (rc) { h->n_fwd++; return rc; }
+            rc = backward_device_impl(h, h->d_out + 2 * (size_t)h->K, h->d_G, h->stream, nullptr);
+            if (rc) { h->n_fwd++; return rc; }
+            // forward outputs | G | flags: contiguous in the result slab and in the staging area -- ONE copy
+            HIPCHK(h, hipMemcpyAsync(h->h_pin + nl_, h->d_ret, ((size_t)2 * h->K + 8 + nl_ + 4) * 8, hipMemcpyDeviceToHost, h->stream));
+            phase_end(h, 5, h->stream);
+            h->n_fwd++;
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         rc = digest_flags(h, pinned_flags(h));
         if (rc) return rc;
@@ -2974,6 +3036,7 @@ int grape_reset_timings(grape_handle *h) try {
     for (auto &ring : h->ph)
         for (auto &p : ring) p.used = false;
     h->n_fwd = h->n_bwd = 0;
+    h->n_eval = 0;   // (the next two evaluations run uncaptured: fresh phase timings behind every reset, see grape_handle::graph)
     return GRAPE_OK;
 }
 GRAPE_BARRIER(h ? &h->err : &g_create_error)

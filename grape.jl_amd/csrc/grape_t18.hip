@@ -146,9 +146,15 @@ __device__ __forceinline__ double t16_post_norm1(const ExpmArgs &a, const int ce
 }
 
 // behind the assembly kernel, every evaluation: the cells beyond the bound go to the hand-over list; executed work
-__global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *verdict) {
+__global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *verdict, const int *prog, int nprog) {
     const int tid = threadIdx.x, lane = tid & 63, ncell = a.K * a.N_T;
     if (t16_skipped(a.flags, ncell)) return;   // the route was not tried: the five-product launch books all cells
+    if (prog && blockIdx.x == 0) {   // two matrix instructions per wave for every step a walk carried its state over (round 5)
+        unsigned long long steps = 0;
+        for (int i = tid; i < nprog; i += 256) steps += (unsigned long long)prog[i];
+        for (int off = 32; off >= 1; off >>= 1) steps += __shfl_xor(steps, off, 64);
+        if (lane == 0 && steps) stat_add(a.stats, 12, steps * 4ull * 2ull);
+    }
     const int cell = blockIdx.x * 256 + tid;
     const bool valid = cell < ncell;
     const bool ok = valid && verdict[cell] == 0;
@@ -423,7 +429,8 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
     hipStream_t s = (hipStream_t)stream;
     e = hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(t16_post_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, (const int *)verdict);
+    hipLaunchKernelGGL(t16_post_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, (const int *)verdict,
+                       fuse ? (const int *)walk[4] : (const int *)nullptr, 2 * K);
     return (int)hipGetLastError();
 }
 

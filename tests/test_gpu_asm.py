@@ -50,9 +50,10 @@ def test_assembly_kernel_against_its_twin(g, N, L, N_T, K):
     assert abs(a[0] - b[0]) <= 1e-13 and np.abs(a[2] - b[2]).max() <= 1e-13
     assert np.abs(a[1] - b[1]).max() <= 1e-12 * max(np.abs(b[1]).max(), 1e-3)
     # every cell inside the bound of the four-product route (spectral radius ~ 1), on both paths; the assembly kernel
-    # executes one matrix instruction more per wave and cell (the column sums of the bound)
+    # executes one matrix instruction more per wave and cell (the column sums of the bound), and two more for every step over
+    # which a walk carried its state (at most every cell)
     assert a[4]["t16_cells"] == b[4]["t16_cells"] == K * N_T
-    assert a[4]["t18_mfma_flop"] == pytest.approx(b[4]["t18_mfma_flop"] * 697.0 / 696.0, rel=1e-12)
+    assert b[4]["t18_mfma_flop"] * 697.0 / 696.0 * (1 - 1e-12) <= a[4]["t18_mfma_flop"] <= b[4]["t18_mfma_flop"] * 699.0 / 696.0 * (1 + 1e-12)
     assert a[4]["flop_expm"] == b[4]["flop_expm"] and a[4]["squarings"] == b[4]["squarings"]     # credited work: Julia's exp!
     # against scipy on a few cells
     for k, n in [(0, 0), (K - 1, N_T - 1)]:

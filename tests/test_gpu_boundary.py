@@ -516,3 +516,41 @@ def test_composite_handle_validates_its_first_collective(g, monkeypatch):
         pytest.skip("RCCL could not be loaded / initialised on this box")
     assert J1 == J2 and np.array_equal(G1, G2)
     assert (t2 - t1) < (t1 - t0)                         # no second communicator initialisation
+
+
+@pytest.mark.parametrize("N,L,N_T,K,kw", [(16, 1, 50, 8, {}), (64, 2, 30, 128, {}), (40, 2, 20, 3, {"functional": 1}),
+                                          (24, 2, 16, 4, {"prop_method": 1}), (64, 2, 12, 5, {"gradient_method": 1})])
+def test_captured_graph_replays_the_evaluation_bit_for_bit(g, monkeypatch, N, L, N_T, K, kw):
+    """grape_eval with a gradient replays the whole evaluation as one captured HIP graph from its third call on (N <= 64, one
+    device; every 16th call and the two behind a grape_reset_timings run uncaptured).  Twenty evaluations with fresh pulses
+    each: identical, bit for bit, to the same calls with GRAPE_GRAPH=0; switching the concurrent sweeps off rebuilds the
+    graph; the error flags of a replayed evaluation still surface; the phase timings stay alive."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=17 + N)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    rng = np.random.default_rng(0)
+    xs = [pr["pulsevals"] + 1e-2 * rng.standard_normal(L * N_T) for _ in range(20)]
+    out = {}
+    for graph in ("1", "0"):
+        monkeypatch.setenv("GRAPE_GRAPH", graph)
+        with g.GrapeHip(*args, **kw) as h:
+            res = [h.eval(x) for x in xs[:12]]
+            assert h.set_fused_sweeps(False) is False
+            res += [h.eval(x) for x in xs[12:16]]
+            h.set_fused_sweeps(True)
+            h.reset_timings()
+            res += [h.eval(x) for x in xs[16:]]
+            tm = h.timings()
+            assert tm["expm"] > 0 or kw.get("prop_method") == 1
+            assert tm["total"] > 0
+            fw = h.storage(0)
+            out[graph] = (res, fw)
+    for (Ja, Ga, ta), (Jb, Gb, tb) in zip(out["1"][0], out["0"][0]):
+        assert Ja == Jb and np.array_equal(Ga, Gb) and np.array_equal(ta, tb)
+    assert np.array_equal(out["1"][1], out["0"][1])
+    monkeypatch.setenv("GRAPE_GRAPH", "1")
+    with g.GrapeHip(*args, chi_min_norm=1e3, **kw) as h:      # the chi-norm guard fires in every evaluation, replayed or not
+        for x in xs[:6]:
+            with pytest.raises(g.GrapeHipError) as ei:
+                h.eval(x)
+            assert ei.value.code == -3
