@@ -77,7 +77,7 @@ RED = E2 + 4 * EXW              # 16 doubles of reduction scratch
 XS0 = RED + 16 * 8
 XS1 = XS0 + 1024
 LDS_BYTES = XS1 + 1024
-KERNARG = 128
+KERNARG = 136
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -171,11 +171,16 @@ class Gen:
         # ---- scalar registers ----
         self.s_H0, self.s_Sf, self.s_dts, self.s_U = S(4, 2), S(6, 2), S(8, 2), S(10, 2)
         self.s_verdict, self.s_rep = S(12, 2), S(14, 2)
-        self.s_KC, self.s_NT, self.s_nblk = S(16), S(17), S(18)
+        self.s_KC, self.s_NT = S(16), S(17)
+        # scaling and squaring around the four products (round 5): the cell exponentiates A / 2^s and squares the result s
+        # times; s comes per cell from the plan of the evaluation (t16_plan_kernel -> splan[cell]).  s18 / s19 held nblk and
+        # wave >> 1 (prologue only / recomputed where it is used)
+        self.s_scur, self.s_snext = S(18), S(19)
+        self.s_splan = S(30, 2)                                          # (diagnostic builds: their stamp area lives there -- they run unscaled)
+        self.s_sqc = S(3)                                                # squarings left (s_k is dead behind cell_bases_finish)
         self.s_wave, self.s_idx, self.s_end, self.s_step = S(20), S(21), S(22), S(23)
         self.s_kc, self.s_n, self.s_cell = S(24), S(25), S(26)          # current cell
         self.s_nkc, self.s_nn, self.s_ncell = S(27), S(28), S(29)       # next cell (clamped to the current one at the end)
-        self.s_hi = S(19)                                                # wave >> 1
         self.s_diag = S(30, 2)                                           # diagnostic builds: stamp area of this wave
         self.s_ub = [S(32 + 2 * i, 2) for i in range(4)]                 # U bases of the previous cell, per slot
         # (the byte offsets of this wave pair's operator tiles are selected in fetch(): round 5 needs their registers)
@@ -254,7 +259,6 @@ class Gen:
         vc, vrg, vw, vx, vy, vidx = (t.sub(i) for i in range(6))
         p.valu("v_lshrrev_b32", vw, 6, self.v_tid)
         p.v_readfirstlane(self.s_wave, vw)
-        p.salu("s_lshr_b32", self.s_hi, self.s_wave, 1)
         p.valu("v_and_b32", vc, 15, self.v_lane)
         p.valu("v_lshrrev_b32", vrg, 4, self.v_lane)
         # left-operand fragments: lane (i = c, kq = rg) reads row 16 tr + c, column 16 tk + 4 r + kq:
@@ -383,6 +387,8 @@ class Gen:
         p.salu("s_mov_b32", self.s_prog, 0)
         p.salu("s_mov_b32", self.s_xs, XS0)
         p.salu("s_mov_b32", self.s_pm, 0)
+        if not self.diag:
+            p.s_load(2, self.s_splan, self.s_karg, 128)
         # (kc, n) of the first cell: restoring division, 32 steps
         q, r, i = self.s_kc, self.s_n, t0
         p.salu("s_mov_b32", q, 0)
@@ -422,11 +428,16 @@ class Gen:
         self.vp.free(t)
 
     # ---- scalars of a cell ----
-    def cell_bases_issue(self, kc, n):
-        """scalars of cell (kc, n), first half: k = rep ? rep[kc] : kc and dt are requested (no branch: without the class
-        table the load reads dts[0] and its result is discarded); S base"""
+    def cell_bases_issue(self, kc, n, cell):
+        """scalars of cell (kc, n) = flattened index `cell`, first half: k = rep ? rep[kc] : kc, dt and the planned number of
+        squarings are requested (no branch: without the class table the load reads dts[0] and its result is discarded); S base"""
         p = self.p
         t0, t1 = self.s_tmp[0], self.s_tmp[1]
+        if self.diag:
+            p.salu("s_mov_b32", self.s_snext, 0)
+        else:
+            p.salu("s_lshl_b32", t0, cell, 2)
+            p.s_load(1, self.s_snext, self.s_splan, t0)
         p.s_cmp("s_cmp_lg_u64", self.s_rep, 0)
         p.salu("s_cselect_b32", self.s_t0.sub(0), self.s_rep.sub(0), self.s_dts.sub(0))
         p.salu("s_cselect_b32", self.s_t0.sub(1), self.s_rep.sub(1), self.s_dts.sub(1))
@@ -451,9 +462,12 @@ class Gen:
         p.salu("s_lshr_b32", t1, self.s_k, 16)
         p.salu("s_add_u32", self.s_hb.sub(0), self.s_H0.sub(0), t0)
         p.salu("s_addc_u32", self.s_hb.sub(1), self.s_H0.sub(1), t1)
+        # the cell exponentiates A / 2^s: dt / 2^s (exact: the exponent field)
+        p.salu("s_lshl_b32", t0, self.s_snext, 20)
+        p.salu("s_sub_u32", self.s_dt.sub(1), self.s_dt.sub(1), t0)
 
-    def cell_bases(self, kc, n):
-        self.cell_bases_issue(kc, n)
+    def cell_bases(self, kc, n, cell):
+        self.cell_bases_issue(kc, n, cell)
         self.cell_bases_finish(kc)
 
     def fetch(self, u, dst, half=None):
@@ -464,7 +478,7 @@ class Gen:
         # instructions are free in the shadow of the matrix instructions this is called between)
         (i0, j0), (i1, j1) = TILES[2 * u], TILES[2 * u + 1]
         toff = self.s_tmp[2]
-        p.s_cmp("s_cmp_eq_u32", self.s_hi, 0)
+        p.s_cmp("s_cmp_lt_u32", self.s_wave, 2)
         self.ssel(toff, (16 * i0 * NP + 16 * j0) * 8, (16 * i1 * NP + 16 * j1) * 8)
         if half in (None, 0):
             p.salu("s_add_u32", self.s_t0.sub(0), self.s_hb.sub(0), toff)
@@ -512,7 +526,7 @@ class Gen:
             # addresses of this tile: scalar part by wave pair
             (i0, j0), (i1, j1) = TILES[2 * u], TILES[2 * u + 1]
             va, vm = tc.sub(4), tc.sub(5)
-            p.s_cmp("s_cmp_eq_u32", self.s_hi, 0)
+            p.s_cmp("s_cmp_lt_u32", self.s_wave, 2)
             self.ssel(self.s_tmp[0], 16 * j0 * LDB + 16 * i0 * 8, 16 * j1 * LDB + 16 * i1 * 8)      # direct: column block tj, rows ti
             self.ssel(self.s_tmp[1], 16 * i0 * LDB + 16 * j0 * 8, 16 * i1 * LDB + 16 * j1 * 8)      # mirrored: column block ti, rows tj
             p.valu("v_add_u32", va, self.s_tmp[0], self.v_CP)
@@ -533,9 +547,9 @@ class Gen:
                 if d0 or d1:
                     # one of the two wave pairs holds a diagonal tile: its lanes sit this out
                     p.salu("s_mov_b64", self.s_save, EXEC)
-                    p.s_cmp("s_cmp_eq_u32", self.s_hi, 0 if d0 else 1)
+                    p.s_cmp("s_cmp_lt_u32", self.s_wave, 2)       # scc: waves 0, 1 (the wave pair of the first tile of the two)
                     lab = f"L_mirror_{u}_{len(p.ins)}"
-                    p.s_branch("s_cbranch_scc1", lab)
+                    p.s_branch("s_cbranch_scc1" if d0 else "s_cbranch_scc0", lab)
                 for e in range(2):
                     p.ds_write(64, vm, nar.d(e), 32 * e)
                     p.ds_write(64, vm, ai.d(e), 32 * e + PLB)
@@ -776,7 +790,7 @@ class Gen:
         p.s_barrier()                                   # (also: everybody is done reading A)
         # scalars of the NEXT cell (its operator bases, dt): requested here, needed by the last product
         self.advance()
-        self.cell_bases_issue(self.s_nkc, self.s_nn)
+        self.cell_bases_issue(self.s_nkc, self.s_nn, self.s_ncell)
         txr, txi = vp.alloc(), vp.alloc()
         for h in range(2):
             p.ds_read(128, txr.sub(4 * h, 4), self.v_ER, 16 * h)
@@ -1067,6 +1081,10 @@ class Gen:
         ap.free(self.As_im)
         # ---- result, interleaved (re, im) per element: the layout of the 16-byte stores ----
         Un = vp.alloc(8, at=self.UT)
+        uid = len(p.ins)
+        L_sq, L_sq_loop, L_res = f"L_sq_{uid}", f"L_sq_loop_{uid}", f"L_res_{uid}"
+        p.s_cmp("s_cmp_lg_u32", self.s_scur, 0)
+        p.s_branch("s_cbranch_scc1", L_sq)
         streams = []
         for sl in range(4):
             for r in range(4):
@@ -1078,6 +1096,49 @@ class Gen:
         for g in range(0, 16, 4):
             self.interleave(streams[g:g + 4])
         p.s_barrier()                                   # everybody is done reading the planes
+        p.s_branch("s_branch", L_res)
+        # ---- s squarings (scaling and squaring around the four products: the cell exponentiated A / 2^s).  The result stays
+        # planar in the accumulators (p1 <- re, p3 <- im, p2 <- re + im): it is the right operand of its own square, and its
+        # column strip goes to the planes inside that product's first k-block, like every left operand of this kernel ----
+        p.label(L_sq)
+        vp.free(Un)                                     # (generator bookkeeping: on this path the result tiles are taken at the end)
+        in_place_y(range(4))
+        p.s_barrier()                                   # everybody is done reading the planes
+        p.salu("s_mov_b32", self.s_sqc, self.s_scur)
+        p.label(L_sq_loop)
+        Q2 = [[vp.alloc() for _ in range(3)] for _ in range(4)]
+
+        def valu_sq(sl):
+            for r in range(4):
+                p.valu("v_add_f64", Qt[sl][1].d(r), Qt[sl][0].d(r), Qt[sl][2].d(r))
+
+        self.product(Q2, [[Qt[sl][0] for sl in range(4)], [Qt[sl][2] for sl in range(4)], [Qt[sl][1] for sl in range(4)]],
+                     fused={"valu": valu_sq, "stores": lambda sl: self.plane_stores(sl, Qt[sl][0], Qt[sl][2], Qt[sl][1])})
+        streams = []
+        for sl in range(4):
+            for r in range(4):
+                q1, q2, q3 = (Q2[sl][j].d(r) for j in range(3))
+                tr, ti = Qt[sl][0].d(r), Qt[sl][2].d(r)
+                streams.append([lambda tr=tr, q1=q1, q2=q2: p.valu("v_add_f64", tr, q1, Neg(q2)),
+                                lambda ti=ti, q3=q3, q1=q1: p.valu("v_add_f64", ti, q3, Neg(q1)),
+                                lambda ti=ti, q2=q2: p.valu("v_add_f64", ti, ti, Neg(q2))])
+        # (the right operand Qt is overwritten: the matrix instructions that read it have all been issued; the hazard tracker
+        # spaces the first writes)
+        for g in range(0, 16, 4):
+            self.interleave(streams[g:g + 4])
+        for row in Q2:
+            for t in row:
+                vp.free(t)
+        p.s_barrier()                                   # everybody is done reading the planes
+        p.salu("s_sub_u32", self.s_sqc, self.s_sqc, 1)
+        p.s_cmp("s_cmp_gt_u32", self.s_sqc, 0)
+        p.s_branch("s_cbranch_scc1", L_sq_loop)
+        Un = vp.alloc(8, at=self.UT)
+        for sl in range(4):
+            for r in range(4):
+                p.valu("v_mov_b64", Un.sub(16 * sl + 4 * r, 2), Qt[sl][0].d(r))
+                p.valu("v_mov_b64", Un.sub(16 * sl + 4 * r + 2, 2), Qt[sl][2].d(r))
+        p.label(L_res)
         self.stamp(10)
         for t in self.QT:           # (the accumulators are dead: the result is in Un)
             vp.free_tiles.append(t)
@@ -1345,7 +1406,8 @@ class Gen:
         p = self.p
         self.prologue()
         # first cell: fetch and commit its A
-        self.cell_bases(self.s_kc, self.s_n)
+        self.cell_bases(self.s_kc, self.s_n, self.s_cell)
+        p.salu("s_mov_b32", self.s_scur, self.s_snext)
         pf = [self.ap.alloc(2) for _ in range(5)]
         for u in range(5):
             self.fetch(u, pf[u])
@@ -1374,6 +1436,7 @@ class Gen:
         p.salu("s_mov_b32", self.s_kc, self.s_nkc)
         p.salu("s_mov_b32", self.s_n, self.s_nn)
         p.salu("s_mov_b32", self.s_cell, self.s_ncell)
+        p.salu("s_mov_b32", self.s_scur, self.s_snext)
         p.s_cmp("s_cmp_lt_u32", self.s_idx, self.s_end)
         p.s_branch("s_cbranch_scc1", "L_cell")
         # the last result

@@ -130,9 +130,11 @@ struct grape_handle {
     // trajectory along while the cell's result is in registers -- Psi upwards from t = 0, conj(chi~) downwards from t = T
     // (d_xinit: the two start vectors of every trajectory) -- and report how far each end got (d_prog[2][K]); the sweep
     // kernel behind picks up from there.  GRAPE_EXPM_WALK=0: the kernel only exponentiates (A/B timing, parity twin).
-    int *d_wgtab = nullptr, *d_prog = nullptr;
+    int *d_wgtab = nullptr, *d_prog = nullptr, *d_splan = nullptr;   // d_splan: squarings planned per cell (scaling and squaring around the four products)
     double2 *d_xinit = nullptr;
     int asm_blocks = 0;
+    bool asm_sq = true;          // GRAPE_EXPM_SQ=0: no scaling and squaring around the four products (cells beyond the bound go to
+                                 // the five-product launch, as before round 5)
     int asm_walk = 0;            // bits of the walks that may carry a state: 1 ascending (Psi), 2 descending (conj(chi~)); GRAPE_EXPM_WALK
                                  // = 0 / 1 / 2 narrows it (diagnostics, A/B timing)
     // the stream of the last device-pointer call: the getters that read device buffers wait for the device when it was
@@ -1263,7 +1265,7 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -1795,8 +1797,11 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         std::vector<int> tab((size_t)4 * h->asm_blocks);
         grape_t16_walks(h->KC, N_T, h->asm_blocks, tab.data());
         CCHK(dmalloc(&h->d_wgtab, tab.size()));
+        CCHK(dmalloc(&h->d_splan, (size_t)ncell));
+        CCHK(hipMemset(h->d_splan, 0, (size_t)ncell * sizeof(int)));
         CCHK(hipMemcpy(h->d_wgtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-        const char *envw = getenv("GRAPE_EXPM_WALK");
+        const char *envw = getenv("GRAPE_EXPM_WALK"), *envq = getenv("GRAPE_EXPM_SQ");
+        h->asm_sq = !(envq && atoi(envq) == 0);
         // (generator classes: one propagator serves several trajectories -- nothing to carry along)
         h->asm_walk = h->KC == K ? (envw ? atoi(envw) & 3 : 3) : 0;
         if (h->asm_walk) {
@@ -2015,6 +2020,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                     T16PlanArgs pa{};
                     pa.gram = h->d_gram; pa.eps = h->d_eps; pa.shape = h->d_shape; pa.dts = h->d_dts; pa.flags = h->d_flags;
                     pa.KC = h->KC; pa.L = h->L; pa.N_T = h->N_T; pa.N = h->N;
+                    pa.splan = (h->asm16 && h->asm_sq) ? h->d_splan : nullptr;
                     hipLaunchKernelGGL(t16_plan_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, pa);
                     HIPCHK(h, hipGetLastError());
                 }
@@ -2026,7 +2032,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                     // when this evaluation runs the backward sweep from the unit targets (concurrent sweeps)
                     walk_fuse = h->asm_walk & (1 | ((h->fuse && h->fuse_on && h->want_bw) ? 2 : 0));
                     if (walk_fuse) HIPCHK(h, hipMemsetAsync(h->d_prog, 0, (size_t)2 * h->K * sizeof(int), s));
-                    const void *walk[5] = {h->d_wgtab, h->d_xinit, h->d_fw, h->d_bw, h->d_prog};
+                    const void *walk[6] = {h->d_wgtab, h->d_xinit, h->d_fw, h->d_bw, h->d_prog, h->d_splan};
                     e = (hipError_t)grape_t16_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, h->asm_blocks, walk, walk_fuse, h->K);
                     h->credit_pending = true;
                 }

@@ -94,11 +94,20 @@ struct ExpmArgs {
 // a hand-over list (t16_skipped()).
 // The estimate decides speed only: a cell it lets through is still certified (or handed over) by the kernel's own bound.
 #define T16_PLAN_R 1.15   // the kernel's bound m8^(1/8) is 3.5^(1/8) = 1.17 R for a semicircle: 1.17 * 1.15 * 1.01 < 1.36
+// Round 5 -- scaling and squaring around the four products (assembly kernel only, splan != nullptr): a cell whose estimate
+// is beyond T16_PLAN_R is not given up: it exponentiates A / 2^s and squares the result s times (asm/gen_t16.py), with the
+// smallest s <= T16_PLAN_SMAX that brings the estimate to T16_PLAN_RS (a little below T16_PLAN_R: a cell whose rigorous
+// bound fails after all has wasted 4 + s products).  4 + s products in the assembly kernel, with the walk's state riding
+// on the result, against five (+ squarings beyond a radius of 2) in the compiled kernel and a full-length sweep:
+// C3 shape at dt = 1.5: 26.8 -> 22.9 ms, dt = 2: 30.7 -> 23.6 ms.  Only cells beyond 2^SMAX count as out of range.
+#define T16_PLAN_RS 1.11
+#define T16_PLAN_SMAX 3
 struct T16PlanArgs {
     const double *gram;   // [KC][(L + 1)^2 + (L + 1)]: Gram matrix | shape factors
     const double *eps, *shape, *dts;
     int *flags;
     int KC, L, N_T, N;
+    int *splan;           // nullptr or [KC * N_T]: squarings planned for every cell (0 where the cell is left to its own bound)
 };
 __global__ void __launch_bounds__(256) t16_plan_kernel(T16PlanArgs a) {
     const int cell = blockIdx.x * 256 + threadIdx.x;
@@ -118,6 +127,16 @@ __global__ void __launch_bounds__(256) t16_plan_kernel(T16PlanArgs a) {
         const double dt = a.dts[n];
         const double r = 2.0 * fabs(dt) * sqrt(fmax(m2, 0.0) / (double)a.N) * (w > 0.0 ? wk / w : 1.0);
         out = !(r <= T16_PLAN_R);
+        if (a.splan) {
+            int sq = 0;
+            if (out) {
+                double rs = r;
+                while (sq < T16_PLAN_SMAX && !(rs <= T16_PLAN_RS)) { rs *= 0.5; ++sq; }
+                out = !(rs <= T16_PLAN_RS);      // (NaN included)
+                if (out) sq = 0;
+            }
+            a.splan[cell] = sq;
+        }
     }
     const unsigned long long m = __ballot(out);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[6], (int)__popcll(m));

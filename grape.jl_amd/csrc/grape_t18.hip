@@ -116,8 +116,9 @@ struct T16AsmArgs {           // kernel argument block of expm_t16_asm (gen_t16.
     double2 *fw, *bw;           // [K][N_T + 1][64] stored states
     int *prog;                  // [2][K] steps each end of each trajectory was propagated by the walks
     int K, pad0;
+    const int *splan;           // [KC * N_T] squarings planned per cell (t16_plan_kernel): the cell exponentiates A / 2^s
 };
-static_assert(sizeof(T16AsmArgs) == 128, "argument block of the assembly kernel");
+static_assert(sizeof(T16AsmArgs) == 136, "argument block of the assembly kernel");
 
 // ||A||_1 of A = -i dt (H0_k + S_n) from the operator planes (t18_norm1 on the same numbers), all 256 threads
 __device__ __forceinline__ double t16_post_norm1(const ExpmArgs &a, const int cell, double *red, const int tid) {
@@ -146,7 +147,7 @@ __device__ __forceinline__ double t16_post_norm1(const ExpmArgs &a, const int ce
 }
 
 // behind the assembly kernel, every evaluation: the cells beyond the bound go to the hand-over list; executed work
-__global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *verdict, const int *prog, int nprog) {
+__global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *verdict, const int *prog, int nprog, const int *splan) {
     const int tid = threadIdx.x, lane = tid & 63, ncell = a.K * a.N_T;
     if (t16_skipped(a.flags, ncell)) return;   // the route was not tried: the five-product launch books all cells
     if (prog && blockIdx.x == 0) {   // two matrix instructions per wave for every step a walk carried its state over (round 5)
@@ -160,6 +161,13 @@ __global__ void __launch_bounds__(256) t16_post_kernel(ExpmArgs a, const int *ve
     const bool ok = valid && verdict[cell] == 0;
     if (valid && !ok) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
     const unsigned long long m_ok = __ballot(ok), m_valid = __ballot(valid);
+    {   // the squarings the kernel executed (whatever the verdict): 192 matrix instructions per wave each
+        unsigned long long sq = valid ? (unsigned long long)splan[cell] : 0ull;
+        unsigned long long sq_ok = ok ? sq : 0ull;
+        for (int off = 32; off >= 1; off >>= 1) { sq += __shfl_xor(sq, off, 64); sq_ok += __shfl_xor(sq_ok, off, 64); }
+        if (lane == 0 && sq) stat_add(a.stats, 12, sq * 4ull * 192ull);
+        if (lane == 0 && sq_ok) stat_add(a.stats, 13, sq_ok);   // squarings of cells this route finished
+    }
     if (lane == 0 && m_valid) {
         // executed matrix instructions of the assembly kernel: four waves x (120 + 3 * 192 + 1 for the column sums) per cell
         stat_add(a.stats, 12, (unsigned long long)__popcll(m_valid) * 4ull * (unsigned long long)(T16Count<4>::CELL + 1));
@@ -403,13 +411,13 @@ extern "C" void grape_t16_walks(int KC, int N_T, int nblk, int *tab) {
 }
 
 // args: ExpmArgs with Sf set (summed controls of every time step) and cell_list / flags / stats as for the C++ kernel;
-// walk: {wgtab, xinit, fw, bw, prog} device pointers, fuse / K as in T16AsmArgs
+// walk: {wgtab, xinit, fw, bw, prog, splan} device pointers, fuse / K as in T16AsmArgs
 extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
                                     const void *const *walk, int fuse, int K) {
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
-    if (!a.Sf || a.hc_per_traj || !verdict || blocks < 1 || !walk || !walk[0]) return (int)hipErrorInvalidValue;
+    if (!a.Sf || a.hc_per_traj || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
     if (fuse && (!walk[1] || !walk[2] || !walk[3] || !walk[4] || a.rep || K != a.K)) return (int)hipErrorInvalidValue;
     const long ncell = (long)a.K * a.N_T;
     if (ncell <= 0 || ncell >= (1L << 28)) return (int)hipErrorInvalidValue;   // (32-bit cell arithmetic in the kernel)
@@ -423,14 +431,14 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
     k.H0f = a.H0f; k.Sf = a.Sf; k.dts = a.dts; k.U = a.U; k.verdict = verdict; k.rep = a.rep;
     k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks; k.flags = a.flags;
     k.fuse = fuse; k.wgtab = (const int *)walk[0]; k.xinit = (const double2 *)walk[1]; k.fw = (double2 *)walk[2];
-    k.bw = (double2 *)walk[3]; k.prog = (int *)walk[4]; k.K = K;
+    k.bw = (double2 *)walk[3]; k.prog = (int *)walk[4]; k.K = K; k.splan = (const int *)walk[5];
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     hipStream_t s = (hipStream_t)stream;
     e = hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(t16_post_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, (const int *)verdict,
-                       fuse ? (const int *)walk[4] : (const int *)nullptr, 2 * K);
+                       fuse ? (const int *)walk[4] : (const int *)nullptr, 2 * K, (const int *)walk[5]);
     return (int)hipGetLastError();
 }
 

@@ -55,7 +55,8 @@ def t16_walks(KC, N_T, nblk):
     return tab
 
 
-def run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, rep=None, skipped_cells=0, fuse=0, psi0=None, chiT=None, want_state=False):
+def run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, rep=None, skipped_cells=0, fuse=0, psi0=None, chiT=None, want_state=False,
+               splan=None):
     g = gcn.GlobalMem()
     a_H0, _ = g.add("H0f", H0f)
     a_Sf, _ = g.add("Sf", Sf)
@@ -75,8 +76,9 @@ def run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, rep=None, skipped_cells=0, fus
     a_fw, fw = g.add("fw", np.full((KC, N_T + 1, 64, 2), np.nan))
     a_bw, bw = g.add("bw", np.full((KC, N_T + 1, 64, 2), np.nan))
     a_pg, prog_ = g.add("prog", np.zeros((2, KC), np.int32))
-    karg = struct.pack("<QQQQQQiiiiQQQQQQQii", a_H0, a_Sf, a_dt, a_U, a_v, a_rep, KC, N_T, nblk, fuse, 0, a_f,
-                       a_tab, a_xi, a_fw, a_bw, a_pg, KC, 0)
+    a_sp, _ = g.add("splan", np.zeros(KC * N_T, np.int32) if splan is None else np.asarray(splan, np.int32))
+    karg = struct.pack("<QQQQQQiiiiQQQQQQQiiQ", a_H0, a_Sf, a_dt, a_U, a_v, a_rep, KC, N_T, nblk, fuse, 0, a_f,
+                       a_tab, a_xi, a_fw, a_bw, a_pg, KC, 0, a_sp)
     assert len(karg) == gen_t16.KERNARG
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     stats = {"instr": 0, "mfma": 0}
@@ -100,8 +102,8 @@ def test_generated_program_has_no_missing_wait_states(program):
     _, prog, _ = program
     assert gcn.check_hazards(prog) == 0
     # the k loops: matrix instructions per cell and wave (120 + 3 * 192 products, one for the column sums of the bound; two
-    # more, executed only by a walk that carries a state, add the four lane rows of that state)
-    assert prog.count("mfma") == 120 + 3 * 192 + 3
+    # more, executed only by a walk that carries a state, add the four lane rows of that state; 192 for the squaring loop)
+    assert prog.count("mfma") == 120 + 3 * 192 + 3 + 192
 
 
 @pytest.mark.parametrize("N,KC,N_T,nblk", [(64, 2, 5, 8), (50, 1, 3, 8)])
@@ -257,3 +259,31 @@ def test_without_the_fuse_bits_nothing_is_propagated_and_nothing_transposed(prog
     assert np.isnan(fw).all() and np.isnan(bw).all() and not prog_.any()
     for n in range(4):
         assert np.abs(U[n] - scipy.linalg.expm(-1j * 0.7 * dts[n] * (H0[0] + Sn[n]))).max() < 2e-15
+
+
+def test_scaling_and_squaring_around_the_four_products(program):
+    """Round 5: cells the plan of the evaluation expects beyond the range of the four products (spectral bound 1.36) are
+    exponentiated as (p16(A / 2^s))^(2^s): dt / 2^s in the commit, s squarings behind the fourth product -- same kernel, the
+    state of the walk rides on the squared result.  Steps of 0.6 (s = 0), 1.9 (s = 1), 3.4 (s = 2) and one cell whose plan
+    is too optimistic (s = 0 at dt = 1.9): its verdict fails, everything else agrees with scipy and the walks stop there."""
+    _, prog, _ = program
+    KC, N_T = 1, 6
+    H0, Sn, dts, H0f, Sf = make_inputs(64, KC, N_T, seed=21)
+    dts[:] = [0.6, 1.9, 3.4, 0.6, 1.9, 1.9]
+    splan = [0, 1, 2, 0, 0, 1]
+    rng = np.random.default_rng(4)
+    psi0 = rng.normal(size=(KC, 64)) + 1j * rng.normal(size=(KC, 64))
+    U, verdict, stats, fw, bw, prog_ = run_kernel(prog, H0f, Sf, dts, KC, N_T, 2, fuse=3, psi0=psi0, chiT=psi0, want_state=True,
+                                                  splan=splan)
+    assert list(verdict) == [0, 0, 0, 0, 1, 0]
+    for n in (0, 1, 2, 3, 5):
+        ref = scipy.linalg.expm(-1j * dts[n] * (H0[0] + Sn[n]))
+        assert np.abs(U[n] - ref).max() < 4e-15 * 2 ** splan[n], (n, np.abs(U[n] - ref).max())
+    # the ascending walk covers cells 0, 1, 2 (all fine), the descending one 5, 4, 3: it stops at cell 4
+    assert list(prog_[0]) == [3] and list(prog_[1]) == [1]
+    x = psi0[0]
+    for n in range(3):
+        x = scipy.linalg.expm(-1j * dts[n] * (H0[0] + Sn[n])) @ x
+        assert np.abs(fw[0, n + 1] - x).max() < 2e-14 * np.abs(x).max()
+    # executed matrix instructions: 697 per cell and wave, 192 per squaring, 2 per carried step
+    assert stats["mfma"] == 4 * (697 * 6 + 192 * (1 + 2 + 1) + 2 * (3 + 1))

@@ -73,8 +73,11 @@ def test_cells_beyond_the_bound_are_handed_to_the_five_product_route(g):
     a = run(g, pr, True)
     b = run(g, pr, False)
     n_long = int((steps > 1.5).sum()) * 3
-    assert a[4]["t16_cells"] == b[4]["t16_cells"] == 3 * 24 - n_long
-    assert np.abs(a[3] - b[3]).max() < 5e-15
+    # the compiled kernel hands its long cells to the five-product launch; the assembly kernel (round 5) keeps them: the plan
+    # of the evaluation gives them two halvings, and the four products are followed by two squarings
+    assert b[4]["t16_cells"] == 3 * 24 - n_long and a[4]["t16_cells"] == 3 * 24
+    assert n_long <= a[4]["t18_squarings"] <= 2 * n_long          # (steps of 2.0 .. 2.4: one or two halvings each)
+    assert np.abs(a[3] - b[3]).max() < 2e-14
     assert abs(a[0] - b[0]) <= 1e-12 and np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
     uni = max(np.abs(u.conj().T @ u - np.eye(64)).max() for u in a[3])
     assert uni < 1e-14
@@ -392,3 +395,35 @@ def test_walks_leave_the_custom_chi_route_alone(g, ref):
     Gc, _, psiTc, _ = ref.evaluate_chi(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], chi)
     assert np.abs(psiT - psiTc).max() <= 1e-12
     assert np.abs(G - Gc).max() <= 1e-10 * max(np.abs(Gc).max(), 1e-3)
+
+
+@pytest.mark.parametrize("dt,s_expected", [(1.5, 1), (2.0, 1), (3.0, 2), (5.0, 3)])
+def test_scaled_four_product_route_against_the_five_product_route(g, dt, s_expected):
+    """round 5: steps beyond the range of the four products (spectral radius ~ dt here) are exponentiated by the SAME
+    assembly kernel as (p16(A / 2^s))^(2^s) instead of being handed to the compiled five-product kernel
+    (GRAPE_EXPM_SQ=0: the behaviour before).  Both against scipy and against each other; the walks ride along."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 2, 12, 128, seed=40, dt=dt)
+    res = {}
+    for sq in ("1", "0"):
+        old = os.environ.get("GRAPE_EXPM_SQ")
+        os.environ["GRAPE_EXPM_SQ"] = sq
+        try:
+            res[sq] = run(g, pr, True, props=False)
+            with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+                h.eval(pr["pulsevals"])
+                res[sq] += (np.stack([h.propagator(k, n) for k, n in ((0, 0), (5, 3), (127, 11))]),)
+        finally:
+            if old is None:
+                os.environ.pop("GRAPE_EXPM_SQ", None)
+            else:
+                os.environ["GRAPE_EXPM_SQ"] = old
+    a, b = res["1"], res["0"]
+    assert a[4]["t16_cells"] == 128 * 12 and b[4]["t16_cells"] == 0
+    assert a[4]["t18_squarings"] == s_expected * 128 * 12
+    assert abs(a[0] - b[0]) <= 1e-12 and np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
+    e = pr["pulsevals"].reshape(2, 12)
+    for i, (k, n) in enumerate(((0, 0), (5, 3), (127, 11))):
+        H = pr["H0"][k] + e[0, n] * pr["Hc"][0] + e[1, n] * pr["Hc"][1]
+        ref = expm(-1j * dt * H)
+        assert np.abs(a[5][i] - ref).max() < 2e-14 * max(1.0, dt) and np.abs(b[5][i] - ref).max() < 2e-14 * max(1.0, dt)
