@@ -9,7 +9,7 @@ recursion of taylor_grad_step!, :604-653, term by term); C++ twin with the same 
     <chi'_l | Psi> = -i dt s_l sum_a < mu_l^dagger w_a | u_a > / (a + 1),
     u_a = A^a Psi / a!  (ascending, parked),    w_a = chi + B w_{a+1} / (a + 2)  (Horner, descending),   A = -i dt H = B^dagger.
 
-Why assembly: the compiled kernel keeps 55 registers in scratch and spends 23 % of its wave cycles outside
+Why assembly (docs/LAB_NOTEBOOK.md 4.3b): the compiled kernel keeps 55 registers in scratch and spends 23 % of its wave cycles outside
 the matrix pipe; with the register file laid out by hand nothing spills, the k loops hold matrix instructions, LDS reads
 and the one vector addition per left-operand fragment the 3M scheme needs (a third LDS plane does not fit beside three
 operators), and the loads / stores of the parked terms ride in the shadow of matrix instructions.

@@ -7,7 +7,7 @@ evaluation; C++ twin with the same arithmetic: expm_t18_kernel<4, true, true, tr
     A2 = A A,  y0 = (c1 A2 + c2 A) A2,  y1 = (y0 + c3 A2 + c4 A)(y0 + c5 A2) + c6 y0 + c7 A2
     p  = (y1 + c8 A2 + c9 A)(y1 + c10 y0 + c11 A) + c12 y1 + c13 y0 + c14 A2 + c15 A + c16 I        (grape_t18_coeffs.h)
 
-Why assembly: a v_mfma_f64_16x16x4 holds the vector ALU for its 64 cycles and nothing a wave issues to
+Why assembly (docs/LAB_NOTEBOOK.md 4.1c): a v_mfma_f64_16x16x4 holds the vector ALU for its 64 cycles and nothing a wave issues to
 the VALU hides under it, so every compiler-inserted register move between the two halves of the 512-register file and
 every address computation is paid in full; the C++ kernel carries ~2000 of them per cell and wave.  Here the register
 file is laid out once:
