@@ -97,6 +97,15 @@ struct grape_handle {
     int *d_scell = nullptr;
     double *d_colpart = nullptr;   // [chunk][2][LG_PARTS][NP] partial column sums of two powers (lg_t18_operands2_kernel)
     bool lg_spec = true;           // GRAPE_LG_SPEC=0: the separate norm pass (lg_t18_scale_kernel) in front of the combinations
+    // second lane of the polynomial route (round 5): the chunks of an evaluation are independent, so odd chunks run on a
+    // second stream with their own scratch -- the HBM-bound passes of one chunk (formation, combinations) share the chip with
+    // the matrix-bound products of the other instead of standing between them.  GRAPE_LG_LANES=1: one lane
+    int lg_lanes = 1;
+    double *d_lg2[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *d_dinv2 = nullptr, *d_colpart2 = nullptr;
+    int *d_scell2 = nullptr, *d_smax2 = nullptr;
+    hipStream_t lg_stream2 = nullptr;
+    hipEvent_t lg_ev_fork = nullptr, lg_ev_join = nullptr;
     double *d_dts = nullptr, *d_shape = nullptr, *d_weights = nullptr;
     double2 *d_psi0 = nullptr, *d_target = nullptr;
     // per-evaluation
@@ -920,10 +929,8 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
     const long ncell = (long)h->KC * h->N_T;
     // nine chunk buffers: the four powers, then the five combinations; the powers are dead once those are formed and
     // their buffers take A9, B3 + A9 and the result
-    double *A = h->d_lg[0], *A2 = h->d_lg[1], *A3 = h->d_lg[2], *A6 = h->d_lg[3], *B1 = h->d_lg[4], *B5 = h->d_lg[5],
-           *B4 = h->d_lg[6], *B3 = h->d_lg[7], *B2 = h->d_lg[8];
-    double *A9 = A, *Lm = A2, *T = A3;
     const bool hm = h->herm;
+    hipStream_t const s_main = s;
     // executed matrix instructions per cell (all waves of all workgroups; a 64-block product of one output block is 4 waves
     // x 192 instructions): full products NB^3 blocks, triangular ones NB^2 (NB + 1) / 2
     const unsigned long long blk = 4ull * 192ull;
@@ -935,14 +942,28 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         hipLaunchKernelGGL(ctrl_sum_kernel, dim3(h->N_T, std::max(1, ca.pp2 / 2 / 2048)), dim3(256), 0, s, ca);
         LGCHK(hipGetLastError());
     }
-    for (long c0_ = 0; c0_ < ncell; c0_ += h->chunk) {
+    if (h->lg_lanes == 2) {   // the second lane starts behind what this stream has enqueued so far (pulses, S_n, cleared flags)
+        LGCHK(hipMemsetAsync(h->d_smax2, 0, sizeof(int), s_main));
+        LGCHK(hipEventRecord(h->lg_ev_fork, s_main));
+        LGCHK(hipStreamWaitEvent(h->lg_stream2, h->lg_ev_fork, 0));
+    }
+    long ichunk = 0;
+    for (long c0_ = 0; c0_ < ncell; c0_ += h->chunk, ++ichunk) {
         const int nc = (int)std::min<long>(h->chunk, ncell - c0_);
+        const bool lane2 = h->lg_lanes == 2 && (ichunk & 1);
+        double *const *lg = lane2 ? h->d_lg2 : h->d_lg;
+        double *A = lg[0], *A2 = lg[1], *A3 = lg[2], *A6 = lg[3], *B1 = lg[4], *B5 = lg[5], *B4 = lg[6], *B3 = lg[7], *B2 = lg[8];
+        double *A9 = A, *Lm = A2, *T = A3;
+        int *const d_scell = lane2 ? h->d_scell2 : h->d_scell;
+        double *const d_dinv = lane2 ? h->d_dinv2 : h->d_dinv, *const d_colpart = lane2 ? h->d_colpart2 : h->d_colpart;
+        int *const d_smax = lane2 ? h->d_smax2 : h->d_flags + 1;
+        s = lane2 ? h->lg_stream2 : s_main;
         const size_t nel = (size_t)nc * 2 * pp;
         LgFormArgs fa{};
         fa.H0f = h->d_H0f; fa.Hcf = h->d_Hcf; fa.eps = h->d_eps; fa.shape = h->d_shape; fa.dts = h->d_dts;
-        fa.A = A; fa.s_cell = h->d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
+        fa.A = A; fa.s_cell = d_scell; fa.stats = h->d_stats; fa.flags = h->d_flags;
         fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0_; fa.rep = h->d_rep;
-        fa.norm1 = h->d_dinv;   // (the inverse slots of the Pade route are idle here: ||A||_1 per cell)
+        fa.norm1 = d_dinv;   // (the inverse slots of the Pade route are idle here: ||A||_1 per cell)
         fa.Sf = h->d_Sf;
         hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(1024), 0, s, fa);
         LGCHK(hipGetLastError());
@@ -952,8 +973,8 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         LGCHK(lg_gemm(h, s, nc, NB, NB, vA2, vA, vA3, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? -1 : 0));   // A3 = A2 A
         LGCHK(lg_gemm(h, s, nc, NB, NB, vA3, vA3, vA6, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? 1 : 0));   // A6 = A3 A3
         LgT18ScaleArgs sa{};
-        sa.P = A2; sa.Q = hm ? A6 : A3; sa.qpow = hm ? 6 : 3; sa.norm1 = hm ? nullptr : h->d_dinv;
-        sa.s_cell = h->d_scell; sa.flags = h->d_flags; sa.stats = h->d_stats; sa.NP = NP;
+        sa.P = A2; sa.Q = hm ? A6 : A3; sa.qpow = hm ? 6 : 3; sa.norm1 = hm ? nullptr : d_dinv;
+        sa.s_cell = d_scell; sa.flags = h->d_flags; sa.smax = d_smax; sa.stats = h->d_stats; sa.NP = NP;
         sa.theta = hm ? T18_THETA : T18T_THETA;
         sa.mfma_per_cell = (hm ? 3 * tri : 3 * gen) + 2 * gen; sa.mfma_per_sq = gen;
         if (!h->lg_spec) {
@@ -962,7 +983,7 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         }
         LgT18OperandsArgs oa{};
         oa.A = A; oa.A2 = A2; oa.A3 = A3; oa.A6 = A6; oa.B1 = B1; oa.B5 = B5; oa.B4 = B4; oa.B3 = B3; oa.B2 = B2;
-        oa.s_cell = h->d_scell; oa.NP = NP; oa.per_cell = 2 * pp; oa.n = nel;
+        oa.s_cell = d_scell; oa.NP = NP; oa.per_cell = 2 * pp; oa.n = nel;
         if (hm) {
             const double a_[3] = {T18_A1, T18_A2, T18_A3}, e_[3] = {T18_E2, T18_E3, T18_E6}, b_[5] = {T18_B0, T18_B1, T18_B2, T18_B3, T18_B6};
             const double c_[5] = {T18_C0, T18_C1, T18_C2, T18_C3, T18_C6}, d_[5] = {T18_D0, T18_D1, T18_D2, T18_D3, T18_D6};
@@ -978,11 +999,11 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
             // combinations for s = 0 with the column sums of A2 and A6 / A3 on the way, the decision, and the combinations once
             // more for the cells that need a scaling (none at the benchmark's norms: that launch leaves at once)
             LgT18Operands2Args o2{};
-            o2.o = oa; o2.colpart = h->d_colpart; o2.q_is_a6 = hm ? 1 : 0; o2.redo = 0;
+            o2.o = oa; o2.colpart = d_colpart; o2.q_is_a6 = hm ? 1 : 0; o2.redo = 0;
             hipLaunchKernelGGL(lg_t18_operands2_kernel, dim3((unsigned)nc * LG_PARTS), dim3(256), 0, s, o2);
             LGCHK(hipGetLastError());
             LgT18DecideArgs da{};
-            da.colpart = h->d_colpart; da.s = sa;
+            da.colpart = d_colpart; da.s = sa;
             hipLaunchKernelGGL(lg_t18_decide_kernel, dim3(nc), dim3(256), 0, s, da);
             LGCHK(hipGetLastError());
             o2.redo = 1;
@@ -993,7 +1014,7 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
             LGCHK(hipGetLastError());
         }
         const LgView vB4 = lg_full(B4, NP), vB3 = lg_full(B3, NP), vB2 = lg_full(B2, NP);
-        const int *smax_ptr = h->d_flags + 1;
+        const int *smax_ptr = d_smax;
         {   // A9 = B1 B5 + B4 and, from the same launch, B3 + A9 (the left operand of the last product)
             const LgView add[2] = {vB4, vB3};
             const double c1[2] = {1.0, 0.0}, c2[2] = {0.0, 1.0};
@@ -1012,11 +1033,16 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         double *X = T, *Y = B1;
         for (int it = 0; it < h->sq_plan; ++it) {
             LGCHK(lg_gemm(h, s, nc, NB, NB, lg_full(X, NP), lg_full(X, NP), lg_full(Y, NP), NB, 1.0, 0.0, 0, nullptr, nullptr,
-                          0.0, h->d_scell, it, 0, nullptr, 0, h->d_U + (size_t)c0_ * pp, NP, -1, smax_ptr));
+                          0.0, d_scell, it, 0, nullptr, 0, h->d_U + (size_t)c0_ * pp, NP, -1, smax_ptr));
             std::swap(X, Y);
         }
     }
-    hipLaunchKernelGGL(lg_plan_check_kernel, dim3(1), dim3(1), 0, s, h->d_flags, h->sq_plan);
+    s = s_main;
+    if (h->lg_lanes == 2) {
+        LGCHK(hipEventRecord(h->lg_ev_join, h->lg_stream2));
+        LGCHK(hipStreamWaitEvent(s, h->lg_ev_join, 0));
+    }
+    hipLaunchKernelGGL(lg_plan_check_kernel, dim3(1), dim3(1), 0, s, h->d_flags, h->sq_plan, h->lg_lanes == 2 ? h->d_smax2 : nullptr);
     LGCHK(hipGetLastError());
     return hipSuccess;
 }
@@ -1110,7 +1136,7 @@ hipError_t expm_large(grape_handle *h, hipStream_t s) {
                            h->d_U + (size_t)c0 * pp, NP, (size_t)nc * pp, smax_ptr);
         LGCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(lg_plan_check_kernel, dim3(1), dim3(1), 0, s, h->d_flags, h->sq_plan);
+    hipLaunchKernelGGL(lg_plan_check_kernel, dim3(1), dim3(1), 0, s, h->d_flags, h->sq_plan, (const int *)nullptr);
     LGCHK(hipGetLastError());
     return hipSuccess;
 }
@@ -1265,7 +1291,12 @@ void grape_destroy(grape_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (double *b : h->d_lg)
         if (b) hipFree(b);
-    void *bufs[] = {h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    for (double *b : h->d_lg2)
+        if (b) hipFree(b);
+    if (h->lg_stream2) { hipStreamSynchronize(h->lg_stream2); hipStreamDestroy(h->lg_stream2); }
+    if (h->lg_ev_fork) hipEventDestroy(h->lg_ev_fork);
+    if (h->lg_ev_join) hipEventDestroy(h->lg_ev_join);
+    void *bufs[] = {h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -1661,7 +1692,13 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     }
     if (h->large && !h->series) {
         const long ncell = (long)h->KC * N_T;
-        double scratch_bytes = 6.0e9;
+        // chunk scratch: 6 GB for one lane of chunks (a launch of 635 cells at N = 256 has tails of ~1 % of its length), 1 GB
+        // per lane when two lanes alternate (each covers the other's tails, and the finer the chunks, the more often an
+        // HBM-bound pass of one lane meets a product of the other: phase A of the C5 shard 143.4 ms with one lane, 142.3 / 139.7 /
+        // 138.6 / 145.9 ms with two lanes of 6 / 2 / 1 / 0.5 GB, same box)
+        const char *envl = getenv("GRAPE_LG_LANES"), *envsp0 = getenv("GRAPE_LG_SPEC");
+        const bool want_lanes = h->t18 && !(envsp0 && atoi(envsp0) == 0) && !(envl && atoi(envl) <= 1);
+        double scratch_bytes = want_lanes ? 1.0e9 : 6.0e9;
         if (const char *envg = getenv("GRAPE_LG_SCRATCH_GB")) scratch_bytes = std::max(0.1, atof(envg)) * 1e9;   // (experiments: launch tails against scratch)
         const long cap = std::max<long>(1, (long)(scratch_bytes / (9.0 * 2.0 * pp * 8.0)));
         h->chunk = (int)std::min<long>(ncell, std::min<long>(cap, 16384));
@@ -1678,6 +1715,25 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
             const double sn_bytes = (double)N_T * 2.0 * (double)pp * 8.0;
             if (h->t18 && !p->hc_per_traj && !(envsn && atoi(envsn) == 0) && sn_bytes <= 0.25 * (double)h->KC * N_T * (double)pp * 16.0 + 1e9)
                 CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * pp));
+            // second lane: only when there is more than one chunk to overlap and the second scratch set is small against the
+            // device (the propagators themselves take K N_T pp 16 bytes)
+            size_t free_b = 0, total_b = 0;
+            CCHK(hipMemGetInfo(&free_b, &total_b));
+            const double lane_bytes = 9.0 * (double)h->chunk * 2.0 * (double)pp * 8.0;
+            if (want_lanes && h->lg_spec && ncell > h->chunk &&
+                lane_bytes + (double)h->KC * N_T * (double)pp * 16.0 + 4e9 < (double)free_b) {
+                h->lg_lanes = 2;
+                for (auto &b : h->d_lg2) CCHK(dmalloc(&b, (size_t)h->chunk * 2 * pp));
+                CCHK(dmalloc(&h->d_dinv2, (size_t)h->chunk * 2 * 4096));
+                CCHK(dmalloc(&h->d_scell2, (size_t)h->chunk + 1));
+                CCHK(dmalloc(&h->d_colpart2, (size_t)h->chunk * 2 * LG_PARTS * NP));
+                CCHK(dmalloc(&h->d_smax2, 1));
+                if (!h->lg_stream2) {
+                    CCHK(hipStreamCreateWithFlags(&h->lg_stream2, hipStreamNonBlocking));
+                    CCHK(hipEventCreateWithFlags(&h->lg_ev_fork, hipEventDisableTiming));
+                    CCHK(hipEventCreateWithFlags(&h->lg_ev_join, hipEventDisableTiming));
+                }
+            }
         }
     }
 

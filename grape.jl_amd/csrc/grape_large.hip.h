@@ -342,6 +342,7 @@ struct LgT18ScaleArgs {
     const double *norm1;   // ||A||_1 per cell (general matrices), nullptr for Hermitian generators
     int *s_cell;
     int *flags;
+    int *smax;             // the largest squaring count of the evaluation so far, per lane of chunks (flags + 1 for the first lane)
     unsigned long long *stats;
     int NP, qpow;          // Q = A^qpow (6 or 3)
     double theta;
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(256) lg_t18_scale_kernel(LgT18ScaleArgs a) {
         }
         if (bad) { s = 0; atomicOr(&a.flags[0], 64); }   // NaN / overflow in the generator
         a.s_cell[blockIdx.x] = s;
-        atomicMax(&a.flags[1], s);
+        atomicMax(a.smax, s);
         stat_add(a.stats, 12, a.mfma_per_cell + (unsigned long long)s * a.mfma_per_sq);
         stat_add(a.stats, 13, (unsigned long long)s);
         stat_add(a.stats, 14, 1ull);
@@ -508,7 +509,7 @@ __global__ void __launch_bounds__(256) lg_t18_decide_kernel(LgT18DecideArgs g) {
         }
         if (bad) { s = 0; atomicOr(&a.flags[0], 64); }   // NaN / overflow in the generator
         a.s_cell[blockIdx.x] = s;
-        atomicMax(&a.flags[1], s);
+        atomicMax(a.smax, s);
         stat_add(a.stats, 12, a.mfma_per_cell + (unsigned long long)s * a.mfma_per_sq);
         stat_add(a.stats, 13, (unsigned long long)s);
         stat_add(a.stats, 14, 1ull);
@@ -690,7 +691,8 @@ __global__ void lg_store_u_kernel(const double *X, double2 *U, int NP, size_t nc
 
 // the squaring plan of the launch sequence was too short for the counts found on the device: flag the evaluation
 // (bit 5) so that the host repeats it with a longer plan
-__global__ void lg_plan_check_kernel(int *flags, int cap) {
+__global__ void lg_plan_check_kernel(int *flags, int cap, const int *smax2) {
+    if (smax2 && *smax2 > flags[1]) flags[1] = *smax2;   // (second lane of chunks: the host sizes its next plan from flags[1])
     if (flags[1] > cap) atomicOr(&flags[0], 32);
 }
 

@@ -128,6 +128,35 @@ def test_blocked_path_vs_c_oracle(g, ref, case):
     assert np.abs(psiT - parts["psiT"]).max() <= 1e-12
 
 
+@pytest.mark.parametrize("herm", [True, False], ids=["herm", "general"])
+def test_blocked_path_two_lanes_of_chunks(g, ref, herm, monkeypatch):
+    """Round 5: the chunks of the blocked path alternate between two streams with their own scratch (the HBM-bound passes of
+    one chunk share the chip with the products of the other).  Forced here by chunks of two cells; the time grid makes the
+    cells need 0, 1 and 2 squarings, so that one lane's chunk is squared while the other's goes straight to U.  Bit for
+    bit the one-lane result (no floating-point sum crosses a chunk), and the oracle's."""
+    from grape_jl_amd import synth
+    N, L, N_T, K = 100, 2, 7, 2
+    pr = synth.make_problem(N, L, N_T, K, seed=4100, dt=1.0, hermitian=herm)
+    dts = np.array([0.6, 0.6, 2.4, 0.6, 4.9, 0.6, 0.6]) * (1.0 if herm else 0.4)
+    pr["tlist"] = np.concatenate([[0.0], np.cumsum(dts)])
+    monkeypatch.setenv("GRAPE_LG_CHUNK", "2")
+    out = {}
+    for lanes in ("2", "1"):
+        monkeypatch.setenv("GRAPE_LG_LANES", lanes)
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], weights=pr["weights"]) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            J2, G2, tau2 = h.eval(pr["pulsevals"])          # (a second evaluation: the lanes' flags are cleared per evaluation)
+            assert J == J2 and np.array_equal(G, G2)
+            w = h.work()
+            out[lanes] = (J, G.copy(), tau.copy(), h.propagator(1, 4), w["t18_squarings"])
+    assert out["2"][0] == out["1"][0] and np.array_equal(out["2"][1], out["1"][1]) and np.array_equal(out["2"][2], out["1"][2])
+    assert np.array_equal(out["2"][3], out["1"][3])
+    assert out["2"][4] == out["1"][4] and out["2"][4] > 0          # squarings happened, the same number
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                functional=0, gradient_method=ref.TAYLOR)[:3]
+    assert abs(out["2"][0] - Jr) <= TOL_J and np.abs(out["2"][1] - Gr).max() <= tol_G(Gr)
+
+
 def test_expm_kernel_vs_scipy(g):
     """The ExpProp step itself (optimize.jl:732): U_kn = exp(-i H_kn dt_n), every Pade branch."""
     from grape_jl_amd import synth
