@@ -20,14 +20,27 @@ Why assembly: the compiled kernel loads a 64-wide k-block, synchronises, multipl
   * two workgroups per CU (128 + 128 registers per lane, 64 KB of LDS each) cover each other's prologue and epilogue.
 
 Matrices are whole planar arrays ([cell][re | im][NP][NP], NP = 128 or 256), as the polynomial route passes them.
+
+Round 5 -- the launch that writes the LAST power also forms the five combinations (`comb`, the third part of the argument
+block).  lg_t18_operands2_kernel read A, A2, A3, A6 of every cell again and wrote B1 .. B5: nine array passes at the HBM rate
+(27.8 ms per C5-shard evaluation) between two matrix-bound launches.  Here a workgroup that has A6(bi, bj) in its
+accumulators loads the same block of A, A2, A3 (48 loads per lane and plane in flight at once; the registers of the
+finished block and of the operand buffers hold them), forms and stores
+    B1 = a1 A + a2 A2 + a3 A3        B5 = e2 A2 + e3 A3 + e6 A6        B4, B3, B2 = x0 I + x1 A + x2 A2 + x3 A3 + x6 A6
+for s = 0 (the speculative pass of the round-5 host code: the decision follows from the column sums taken on the way, and
+cells that need a scaling are redone from the intact powers), and the column sums of |A2| and |A6| (|A3|: general
+matrices) over its 64 rows -- while the other workgroup of the CU multiplies.  Hermitian products compute the upper block
+triangle only: a workgroup with an off-diagonal block has the mirrored block in its registers after the mirrored store, and
+forms the combinations of that one as well (from the lower blocks of A, A2, A3, which ARE in memory).
 """
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gcn import Prog, V, A, S, M0, Neg, kernel_text  # noqa: E402
+from gcn import Prog, V, A, S, M0, VCC, EXEC, Neg, Abs, kernel_text  # noqa: E402
 
-KERNARG = 168
+KERNARG = 416                    # 168: the product; 8: comb mode; 72: nine pointers; 168: 21 coefficients
+LG_PARTS = 16                    # row parts of the column-sum scratch (grape_large.hip.h); the fused epilogue writes part bi
 STAGE_B = 32768                  # one k-block of the left operand: [re | im][64 rows][32 columns]
 LDS_BYTES = 2 * STAGE_B
 KSTEPS = 8                       # k-steps (of 4) per k-block
@@ -429,10 +442,17 @@ class GenLG:
         # ---- plain product (Hermitian / skew-Hermitian results also store the mirrored block) ----
         p.label("L_epi_plain")
         self.store_block("plain", True)
+        # round 5: the combinations of this block (comb mode; the registers of E are its staging area: E is formed again for
+        # the mirrored store)
+        self.comb_body(False)
         p.s_cmp("s_cmp_eq_u32", self.s_herm, 0)
         p.s_branch("s_cbranch_scc1", "L_end")
         p.s_cmp("s_cmp_eq_u32", self.s_bi, self.s_bj)
         p.s_branch("s_cbranch_scc1", "L_end")
+        p.s_cmp("s_cmp_eq_u32", S(34), 0)                 # (s_mode of comb_body)
+        p.s_branch("s_cbranch_scc1", "L_have_e")
+        self.combine_all()
+        p.label("L_have_e")
         # block (bj, bi) = sgn conj(transpose): one plane at a time through the idle LDS
         lo1, hi1 = 0, 0x3FF00000
         p.s_cmp("s_cmp_gt_i32", self.s_herm, 0)
@@ -463,6 +483,174 @@ class GenLG:
                 p.valu("v_mul_f64", e.sub(2, 2), e.sub(2, 2), self.s_nsg)
                 p.global_store(2, self.v_o[r], e.sub(0, 2), self.s_Cb)
                 p.global_store(2, self.v_o[r], e.sub(2, 2), self.s_b)
+        # ... and the combinations of the mirrored block (bj, bi): its elements go to the accumulators of p1 / p2 (the partial
+        # products are dead), the block coordinates are swapped
+        p.s_load(1, S(34), S(0, 2), 168)
+        p.s_waitcnt(lgkm=0)
+        p.s_cmp("s_cmp_eq_u32", S(34), 0)
+        p.s_branch("s_cbranch_scc1", "L_end")
+        for t in range(4):
+            for r in range(4):
+                e = self.elem(t, r)
+                for pl in range(2):
+                    for hw in range(2):
+                        p.valu("v_accvgpr_write_b32", self.P[pl][t].d(r).sub(hw), e.sub(2 * pl + hw))
+        p.salu("s_mov_b32", self.s_boff, self.s_boffT)
+        p.salu("s_mov_b32", self.s_t[0], self.s_bi)
+        p.salu("s_mov_b32", self.s_bi, self.s_bj)
+        p.salu("s_mov_b32", self.s_bj, self.s_t[0])
+        self.comb_body(True)
+
+    # ---- round 5: the combinations of the polynomial route from the block that is still in the accumulators --------------
+    def comb_body(self, second):
+        """B1 .. B5 of the block at s_boff (block row s_bi, block column s_bj) and its column sums.  First pass (behind the
+        plain store): the 3M partial products are still in the accumulation half -- the elements of the block are formed
+        from them again, four at a time, and the 64 registers of E (with the operand buffers: 96) hold one plane of A, A2,
+        A3.  Second pass (Hermitian products, behind the mirrored store): the block (bj, bi), whose elements the caller has
+        put into the accumulators of p1 (real parts) and p2 (imaginary parts)."""
+        p = self.p
+        tag = "2" if second else "1"
+        s_mode = S(34)
+        ptr = [S(4 + 2 * q, 2) for q in range(8)]           # A, A2, A3, B1, B5, B4, B3, B2 (+ cell, + plane)
+        s_cp = S(20, 2)
+        slots = [S(i, 2) for i in (22, 24, 26, 28, 30, 36, 38, 44, 46, 48, 50, 52, 54, 74, 76, 78, 80, 84, 86, 88, 90, 92, 94)]
+        ca, ce, cd, cc, cb = slots[0:3], slots[3:6], slots[6:11], slots[11:16], slots[16:21]   # (d, c, b: index 0 = identity)
+        s_dd, s_dc, s_db = S(60, 2), S(62, 2), S(64, 2)     # identity coefficients of THIS wave's tile row, or zero (s_t[2..7])
+        p.s_load(1, s_mode, S(0, 2), 168)
+        p.s_waitcnt(lgkm=0)
+        p.s_cmp("s_cmp_eq_u32", s_mode, 0)
+        p.s_branch("s_cbranch_scc1", f"L_comb_end_{tag}")
+        p.s_load(16, S(4, 16), S(0, 2), 176)
+        p.s_load(2, s_cp, S(0, 2), 240)
+        for i in range(21):
+            p.s_load(2, slots[i], S(0, 2), 248 + 8 * i)
+        p.s_waitcnt(lgkm=0)
+        for q in range(8):
+            self.add64(ptr[q], ptr[q], self.s_cellb.sub(0), self.s_cellb.sub(1))
+        # registers: one plane of the three inputs (48 elements), temporaries
+        inp = [V(46 + 2 * i, 2) for i in range(32)] + [V(22 + 2 * i, 2) for i in range(12)] + [V(2 + 2 * i, 2) for i in range(4)]
+        X = [[[inp[16 * a + 4 * t + r] for r in range(4)] for t in range(4)] for a in range(3)]      # X[array][t][r]
+        T = self.T
+        acc6 = [T.sub(0, 2), T.sub(2, 2), T.sub(4, 2)]       # p1, p2, p3 of one element
+        x6 = T.sub(6, 2)
+        outs = [T.sub(8, 2), V(110, 2)]                      # results alternate: a store still reads the one before
+        v_one_hi = T.sub(13)
+        cs2, cs3, cs6 = V(10, 2), V(12, 2), T.sub(10, 2)
+        vd, wdiag = T.sub(12), T.sub(14, 2)
+        for c_ in (cs2, cs3, cs6):
+            p.valu("v_mov_b32", c_.sub(0), 0)
+            p.valu("v_mov_b32", c_.sub(1), 0)
+        # lanes of the diagonal of a 16 x 16 tile in register r: column c == row 4 r + rg  <=>  c - rg == 4 r
+        p.valu("v_and_b32", vd, 15, self.v_lane)
+        p.valu("v_lshrrev_b32", wdiag.sub(0), 4, self.v_lane)
+        p.valu("v_sub_u32", vd, vd, wdiag.sub(0))
+        p.valu("v_mov_b32", wdiag.sub(0), 0)
+        p.valu("v_mov_b32", v_one_hi, 0x3FF00000)
+        n_out = 0
+        for pl in range(2):
+            if pl == 1:
+                for q in range(8):
+                    self.add64(ptr[q], ptr[q], self.s_planeb)
+            for t in range(4):
+                self.offsets(t, self.s_boff)
+                for a in range(3):
+                    for r in range(4):
+                        p.global_load(2, X[a][t][r], self.v_o[r], ptr[a])
+            for t in range(4):
+                self.offsets(t, self.s_boff)
+                if pl == 0:
+                    # identity terms: only the diagonal block's tile row t == wave has diagonal elements
+                    p.s_cmp("s_cmp_eq_u32", self.s_bi, self.s_bj)
+                    p.salu("s_cselect_b32", self.s_t[0], 1, 0)
+                    p.s_cmp("s_cmp_eq_u32", self.s_wave, t)
+                    p.salu("s_cselect_b32", self.s_t[0], self.s_t[0], 0)
+                    p.s_cmp("s_cmp_lg_u32", self.s_t[0], 0)
+                    for dst, src in ((s_dd, cd[0]), (s_dc, cc[0]), (s_db, cb[0])):
+                        p.salu("s_cselect_b32", dst.sub(0), src.sub(0), 0)
+                        p.salu("s_cselect_b32", dst.sub(1), src.sub(1), 0)
+                for r in range(4):
+                    x1, x2, x3 = X[0][t][r], X[1][t][r], X[2][t][r]
+                    # the element of the product from its 3M partial sums: re = p1 - p2, im = p3 - p1 - p2
+                    if second:
+                        for hw in range(2):
+                            p.valu("v_accvgpr_read_b32", x6.sub(hw), self.P[pl][t].d(r).sub(hw))
+                    else:
+                        n_acc = 2 if pl == 0 else 3
+                        for j in range(n_acc):
+                            for hw in range(2):
+                                p.valu("v_accvgpr_read_b32", acc6[j].sub(hw), self.P[j][t].d(r).sub(hw))
+                        if pl == 0:
+                            p.valu("v_add_f64", x6, acc6[0], Neg(acc6[1]))
+                        else:
+                            p.valu("v_add_f64", x6, acc6[2], Neg(acc6[0]))
+                            p.valu("v_add_f64", x6, x6, Neg(acc6[1]))
+                    p.valu("v_add_f64", cs2, cs2, Abs(x2))
+                    p.valu("v_add_f64", cs3, cs3, Abs(x3))
+                    p.valu("v_add_f64", cs6, cs6, Abs(x6))
+                    if pl == 0:
+                        p.v_cmp("v_cmp_eq_u32", VCC, vd, 4 * r)
+                        p.valu("v_cndmask_b32", wdiag.sub(1), 0, v_one_hi, VCC)            # 1.0 on the diagonal lanes
+                    # B1
+                    out = outs[n_out & 1]
+                    n_out += 1
+                    p.valu("v_mul_f64", out, ca[0], x1)
+                    p.valu("v_fma_f64", out, ca[1], x2, out)
+                    p.valu("v_fma_f64", out, ca[2], x3, out)
+                    p.global_store(2, self.v_o[r], out, ptr[3])
+                    # B5
+                    out = outs[n_out & 1]
+                    n_out += 1
+                    p.valu("v_mul_f64", out, ce[0], x2)
+                    p.valu("v_fma_f64", out, ce[1], x3, out)
+                    p.valu("v_fma_f64", out, ce[2], x6, out)
+                    p.global_store(2, self.v_o[r], out, ptr[4])
+                    # B4, B3, B2
+                    for cf, sdiag, dstp in ((cd, s_dd, ptr[5]), (cc, s_dc, ptr[6]), (cb, s_db, ptr[7])):
+                        out = outs[n_out & 1]
+                        n_out += 1
+                        p.valu("v_mul_f64", out, cf[1], x1)
+                        p.valu("v_fma_f64", out, cf[2], x2, out)
+                        p.valu("v_fma_f64", out, cf[3], x3, out)
+                        p.valu("v_fma_f64", out, cf[4], x6, out)
+                        if pl == 0:
+                            p.valu("v_fma_f64", out, sdiag, wdiag, out)
+                        p.global_store(2, self.v_o[r], out, dstp)
+        # ---- column sums over this block's 64 rows: ones(16 x 4) times the 4 x 16 block of the per-lane sums adds the four
+        # lane rows; lanes 0..15 store column bj 64 + 16 w + c of row part bi ----
+        p.salu("s_and_b32", self.s_t[0], s_mode, 2)
+        p.s_cmp("s_cmp_lg_u32", self.s_t[0], 0)
+        p.salu("s_cselect_b64", VCC, -1, 0)
+        p.valu("v_cndmask_b32", cs3.sub(0), cs3.sub(0), cs6.sub(0), VCC)                  # second sum: |A6| or |A3|
+        p.valu("v_cndmask_b32", cs3.sub(1), cs3.sub(1), cs6.sub(1), VCC)
+        ones = T.sub(0, 2)
+        p.valu("v_mov_b32", ones.sub(0), 0)
+        p.valu("v_mov_b32", ones.sub(1), 0x3FF00000)
+        ct2, ct3 = V(46, 8), V(54, 8)
+        p.mfma(ct2, ones, cs2, 0)
+        p.mfma(ct3, ones, cs3, 0)
+        # colpart + (((cell 2 + which) LG_PARTS + bi) NP + bj 64 + 16 w + c) 8
+        va = T.sub(2)
+        p.salu("s_lshl_b32", self.s_t[0], self.s_cell, 1)
+        p.salu("s_mul_i32", self.s_t[0], self.s_t[0], LG_PARTS)
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.s_bi)
+        p.salu("s_mul_i32", self.s_t[0], self.s_t[0], self.s_NP)
+        p.salu("s_lshl_b32", self.s_t[1], self.s_bj, 6)
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.s_t[1])
+        p.salu("s_lshl_b32", self.s_t[1], self.s_wave, 4)
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.s_t[1])
+        p.valu("v_and_b32", va, 15, self.v_lane)
+        p.valu("v_add_u32", va, self.s_t[0], va)
+        p.valu("v_lshlrev_b32", va, 3, va)
+        p.salu("s_mul_i32", self.s_t[1], self.s_NP, LG_PARTS * 8)                        # the second sum: LG_PARTS NP doubles on
+        self.add64(S(36, 2), s_cp, self.s_t[1])
+        p.salu("s_mov_b64", self.s_save, EXEC)
+        p.salu("s_mov_b32", S(38), 0xFFFF)
+        p.salu("s_mov_b32", S(39), 0)
+        p.salu("s_mov_b64", EXEC, S(38, 2))
+        p.global_store(2, va, ct2.sub(0, 2), s_cp)
+        p.global_store(2, va, ct3.sub(0, 2), S(36, 2))
+        p.salu("s_mov_b64", EXEC, self.s_save)
+        p.label(f"L_comb_end_{tag}")
 
     # ---------------------------------------------------------------------------------------------------------------
     def build(self):

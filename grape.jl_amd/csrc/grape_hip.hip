@@ -96,6 +96,8 @@ struct grape_handle {
     double *d_dinv = nullptr;
     int *d_scell = nullptr;
     double *d_colpart = nullptr;   // [chunk][2][LG_PARTS][NP] partial column sums of two powers (lg_t18_operands2_kernel)
+    bool lg_fuse = true;           // GRAPE_LG_FUSE=0: the combinations in a pass of their own (lg_t18_operands2_kernel) instead of
+                                   // the epilogue of the launch that writes the last power
     bool lg_spec = true;           // GRAPE_LG_SPEC=0: the separate norm pass (lg_t18_scale_kernel) in front of the combinations
     // second lane of the polynomial route (round 5): the chunks of an evaluation are independent, so odd chunks run on a
     // second stream with their own scratch -- the HBM-bound passes of one chunk (formation, combinations) share the chip with
@@ -818,13 +820,28 @@ struct LgAsmArgs {
     int pad;
     const int *s_cell;             // squaring launches: cells with s_cell[cell] <= sq_iter are copied through
     int sq_iter, sq_mode;          // sq_mode: leave at once when sq_iter >= *smax_ptr, write U when sq_iter == *smax_ptr - 1
+    // the combinations of the polynomial route from the epilogue of the launch that writes the last power (asm/gen_lg.py, comb)
+    int comb_mode, pad2;           // bit 0: on; bit 1: the second column sum is |this product| (A6), else |P3| (A3)
+    const double *P1, *P2, *P3;    // A, A2, A3
+    double *B1, *B5, *B4, *B3, *B2;
+    double *colpart;
+    double ca[3], ce[3], cd[5], cc[5], cb[5];
 };
-static_assert(sizeof(LgAsmArgs) == 168, "argument block of lg_gemm_asm");
+static_assert(sizeof(LgAsmArgs) == 416, "argument block of lg_gemm_asm");
+// what the launch of the last power needs to form B1 .. B5 (expm_large_t18)
+struct LgComb {
+    const LgT18OperandsArgs *o;
+    double *colpart;
+    int q_is_a6;
+};
+bool lg_asm_eligible(const grape_handle *h, int NP, int nc, int per_cell) {
+    return h->lg_asm && (NP == 128 || NP == 256) && (long)((nc + 7) / 8) * 8 * per_cell < (1L << 24);
+}
 bool lg_full_view(const LgView &v, int NP) {
     return v.p && v.rb == 0 && v.cb == 0 && v.ld == NP && v.plane == (size_t)NP * NP && v.cell_stride == (size_t)2 * NP * NP;
 }
 // true: launched (err holds the status); false: not eligible
-bool lg_try_asm(const grape_handle *h, hipStream_t s, const LgGemmArgs &a, hipError_t *err) {
+bool lg_try_asm(const grape_handle *h, hipStream_t s, const LgGemmArgs &a, hipError_t *err, const LgComb *comb = nullptr) {
     if (!h->lg_asm) return false;   // (GRAPE_LG_ASM, read once in grape_create: the route of a handle never changes)
     const int NP = a.C.ld, NB = a.nbi;
     if ((NP != 128 && NP != 256) || a.nbj != NB || a.kblocks != NB || NB * 64 != NP) return false;
@@ -848,6 +865,15 @@ bool lg_try_asm(const grape_handle *h, hipStream_t s, const LgGemmArgs &a, hipEr
     k.s_cell = a.s_cell; k.sq_iter = a.sq_iter; k.sq_mode = (squaring && a.smax_ptr) ? 1 : 0;
     k.magic_pc = (unsigned)((1ull << 32) / (unsigned)k.per_cell + 1);
     k.magic_nb = (unsigned)((1ull << 32) / (unsigned)NB + 1);
+    if (comb) {
+        if (a.nadd || a.Uout || a.C2.p || squaring) return false;
+        const LgT18OperandsArgs &o = *comb->o;
+        k.comb_mode = 1 | (comb->q_is_a6 ? 2 : 0);
+        k.P1 = o.A; k.P2 = o.A2; k.P3 = o.A3; k.B1 = o.B1; k.B5 = o.B5; k.B4 = o.B4; k.B3 = o.B3; k.B2 = o.B2;
+        k.colpart = comb->colpart;
+        memcpy(k.ca, o.a, sizeof(k.ca)); memcpy(k.ce, o.e, sizeof(k.ce)); memcpy(k.cd, o.d, sizeof(k.cd));
+        memcpy(k.cc, o.c, sizeof(k.cc)); memcpy(k.cb, o.b, sizeof(k.cb));
+    }
     const int groups = (a.ncell + 7) / 8;
     if ((long)groups * 8 * k.per_cell >= (1L << 24)) return false;
     *err = (hipError_t)grape_lg_asm_launch(&k, sizeof(k), (unsigned)(groups * 8 * k.per_cell), (void *)s);
@@ -858,7 +884,7 @@ hipError_t lg_gemm(const grape_handle *h, hipStream_t s, int nc, int nbi, int nb
                    double beta, int nadd = 0, const LgView *add = nullptr, const double *coef = nullptr,
                    double cI = 0.0, const int *s_cell = nullptr, int sq_iter = 0, int herm = 0,
                    const int *scale_s = nullptr, int scale_pow = 0, double2 *Uout = nullptr, int u_np = 0,
-                   int skip_bi = -1, const int *smax_ptr = nullptr) {
+                   int skip_bi = -1, const int *smax_ptr = nullptr, const LgComb *comb = nullptr) {
     if (nbi <= 0 || nbj <= 0) return hipSuccess;
     LgGemmArgs a{};
     a.X = X; a.Y = Y; a.C = C; a.kblocks = kblocks; a.alpha = alpha; a.beta = beta; a.cI = cI;
@@ -871,7 +897,8 @@ hipError_t lg_gemm(const grape_handle *h, hipStream_t s, int nc, int nbi, int nb
     const int groups = (nc + 7) / 8;   // cells are dealt to the 8 XCDs in groups
     const int per_cell = a.herm ? nbi * (nbi + 1) / 2 : nbi * nbj;
     hipError_t easm;
-    if (lg_try_asm(h, s, a, &easm)) return easm;
+    if (lg_try_asm(h, s, a, &easm, comb)) return easm;
+    if (comb) return hipErrorInvalidValue;   // (only the assembly kernel has that epilogue: the caller asks lg_asm_eligible first)
     hipLaunchKernelGGL(lg_gemm_kernel, dim3(groups * 8 * per_cell), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -971,16 +998,11 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
                      vB1 = lg_full(B1, NP), vB5 = lg_full(B5, NP), vA9 = lg_full(A9, NP), vL = lg_full(Lm, NP), vT = lg_full(T, NP);
         LGCHK(lg_gemm(h, s, nc, NB, NB, vA, vA, vA2, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? 1 : 0));     // A2 = A A
         LGCHK(lg_gemm(h, s, nc, NB, NB, vA2, vA, vA3, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? -1 : 0));   // A3 = A2 A
-        LGCHK(lg_gemm(h, s, nc, NB, NB, vA3, vA3, vA6, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? 1 : 0));   // A6 = A3 A3
         LgT18ScaleArgs sa{};
         sa.P = A2; sa.Q = hm ? A6 : A3; sa.qpow = hm ? 6 : 3; sa.norm1 = hm ? nullptr : d_dinv;
         sa.s_cell = d_scell; sa.flags = h->d_flags; sa.smax = d_smax; sa.stats = h->d_stats; sa.NP = NP;
         sa.theta = hm ? T18_THETA : T18T_THETA;
         sa.mfma_per_cell = (hm ? 3 * tri : 3 * gen) + 2 * gen; sa.mfma_per_sq = gen;
-        if (!h->lg_spec) {
-            hipLaunchKernelGGL(lg_t18_scale_kernel, dim3(nc), dim3(256), 0, s, sa);
-            LGCHK(hipGetLastError());
-        }
         LgT18OperandsArgs oa{};
         oa.A = A; oa.A2 = A2; oa.A3 = A3; oa.A6 = A6; oa.B1 = B1; oa.B5 = B5; oa.B4 = B4; oa.B3 = B3; oa.B2 = B2;
         oa.s_cell = d_scell; oa.NP = NP; oa.per_cell = 2 * pp; oa.n = nel;
@@ -995,15 +1017,29 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
             memcpy(oa.a, a_, sizeof(a_)); memcpy(oa.e, e_, sizeof(e_)); memcpy(oa.b, b_, sizeof(b_));
             memcpy(oa.c, c_, sizeof(c_)); memcpy(oa.d, d_, sizeof(d_));
         }
+        // round 5: the launch of A6 forms the combinations in its epilogue, for s = 0, with the column sums of the decision
+        // (Hermitian generators: a workgroup of the upper block triangle also forms those of the mirrored block)
+        const bool fused = h->lg_spec && h->lg_fuse && lg_asm_eligible(h, NP, nc, hm ? NB * (NB + 1) / 2 : NB * NB);
+        {
+            const LgComb cb{&oa, d_colpart, hm ? 1 : 0};
+            LGCHK(lg_gemm(h, s, nc, NB, NB, vA3, vA3, vA6, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? 1 : 0,    // A6 = A3 A3
+                          nullptr, 0, nullptr, 0, -1, nullptr, fused ? &cb : nullptr));
+        }
+        if (!h->lg_spec) {
+            hipLaunchKernelGGL(lg_t18_scale_kernel, dim3(nc), dim3(256), 0, s, sa);
+            LGCHK(hipGetLastError());
+        }
         if (h->lg_spec) {
             // combinations for s = 0 with the column sums of A2 and A6 / A3 on the way, the decision, and the combinations once
             // more for the cells that need a scaling (none at the benchmark's norms: that launch leaves at once)
             LgT18Operands2Args o2{};
             o2.o = oa; o2.colpart = d_colpart; o2.q_is_a6 = hm ? 1 : 0; o2.redo = 0;
-            hipLaunchKernelGGL(lg_t18_operands2_kernel, dim3((unsigned)nc * LG_PARTS), dim3(256), 0, s, o2);
-            LGCHK(hipGetLastError());
+            if (!fused) {
+                hipLaunchKernelGGL(lg_t18_operands2_kernel, dim3((unsigned)nc * LG_PARTS), dim3(256), 0, s, o2);
+                LGCHK(hipGetLastError());
+            }
             LgT18DecideArgs da{};
-            da.colpart = d_colpart; da.s = sa;
+            da.colpart = d_colpart; da.s = sa; da.nparts = fused ? NB : LG_PARTS;
             hipLaunchKernelGGL(lg_t18_decide_kernel, dim3(nc), dim3(256), 0, s, da);
             LGCHK(hipGetLastError());
             o2.redo = 1;
@@ -1709,6 +1745,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         {
             const char *envsp = getenv("GRAPE_LG_SPEC"), *envsn = getenv("GRAPE_LG_SN");
             h->lg_spec = h->t18 && !(envsp && atoi(envsp) == 0);
+            if (const char *envf = getenv("GRAPE_LG_FUSE")) h->lg_fuse = atoi(envf) != 0;
             if (h->lg_spec) CCHK(dmalloc(&h->d_colpart, (size_t)h->chunk * 2 * LG_PARTS * NP));
             // summed controls of every time step for the generator formation (polynomial route, shared control operators):
             // N_T 2 NP^2 doubles -- 2.1 GB at C5 -- when that is a small part of what the propagators take anyway

@@ -469,10 +469,14 @@ __global__ void __launch_bounds__(256) lg_t18_operands2_kernel(LgT18Operands2Arg
         cp[(size_t)LG_PARTS * NP + tid] = sq;
     }
 }
+// Round 5 (second half): the launch that writes the last power forms the combinations in its epilogue (lg_gemm_asm `comb`,
+// asm/gen_lg.py: every block, with the column sums of its 64 rows in row part bi of the column-sum scratch); the pass above
+// is then only launched for the cells that need a scaling (redo = 1) and as the twin (GRAPE_LG_FUSE=0).
 // the decision of lg_t18_scale_kernel from the partial column sums (one workgroup per cell, thread j owns column j)
 struct LgT18DecideArgs {
     const double *colpart;
     LgT18ScaleArgs s;      // P, Q unused
+    int nparts;            // row parts that were written: LG_PARTS (lg_t18_operands2_kernel) or NP / 64 (fused epilogue)
 };
 __global__ void __launch_bounds__(256) lg_t18_decide_kernel(LgT18DecideArgs g) {
     const LgT18ScaleArgs &a = g.s;
@@ -481,7 +485,7 @@ __global__ void __launch_bounds__(256) lg_t18_decide_kernel(LgT18DecideArgs g) {
     double sp = 0., sq = 0.;
     if (tid < NP) {
         const double *cp = g.colpart + (size_t)blockIdx.x * 2 * LG_PARTS * NP;
-        for (int part = 0; part < LG_PARTS; ++part) {   // fixed order
+        for (int part = 0; part < g.nparts; ++part) {   // fixed order
             sp += cp[(size_t)part * NP + tid];
             sq += cp[(size_t)(LG_PARTS + part) * NP + tid];
         }

@@ -376,17 +376,17 @@ extern "C" int grape_deriv4_launch(int NP, const void *d2args, size_t d2size, co
     return (int)hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, cfg);
 }
 
-// batched complex block product of the blocked path (asm/gen_lg.py): `k` is the 168-byte argument block of lg_gemm_asm,
+// batched complex block product of the blocked path (asm/gen_lg.py): `k` is the 416-byte argument block of lg_gemm_asm,
 // filled by the caller (grape_hip.hip: lg_asm_args), one workgroup per 64 x 64 output block
 extern "C" int grape_lg_asm_launch(const void *k, size_t size, unsigned blocks, void *stream) {
-    if (size != 168 || blocks == 0) return (int)hipErrorInvalidValue;
+    if (size != 416 || blocks == 0) return (int)hipErrorInvalidValue;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     hipFunction_t fn;
     e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, &fn);
     if (e != hipSuccess) return (int)e;
-    unsigned char buf[168];
+    unsigned char buf[416];
     memcpy(buf, k, sizeof(buf));
     size_t sz = sizeof(buf);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

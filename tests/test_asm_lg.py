@@ -27,7 +27,12 @@ def unplanar(P):
     return P[:, 0] + 1j * P[:, 1]
 
 
-def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False, uif=0, smax=0, s_cell=None, sq_iter=0):
+COMB_NONE = struct.pack("<ii9Q21d", 0, 0, *([0] * 9), *([0.0] * 21))
+
+
+def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False, uif=0, smax=0, s_cell=None, sq_iter=0, comb=None):
+    """comb = (mode, [A, A2, A3], coefficients a[3] e[3] d[5] c[5] b[5]): the fused combinations; returns them and the column
+    sums as a sixth and seventh value"""
     ncell, NB = X.shape[0], NP // 64
     g = gcn.GlobalMem()
     a_X, _ = g.add("X", planar(X))
@@ -48,6 +53,16 @@ def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False
     karg = struct.pack("<8Q6d8iIiQii", a_X, a_Y, a_C, a_C2, a_add[0], a_add[1], a_U, a_s, cf[0], cf[1], cf2[0], cf2[1], 0.0, 0.0,
                        NP, NB, ncell, herm, len(adds), uif, per_cell, (1 << 32) // per_cell + 1, ((1 << 32) // NB + 1) & 0xFFFFFFFF, 0,
                        a_sc, sq_iter, 1 if s_cell is not None else 0)
+    Bs = colpart = None
+    if comb is None:
+        karg += COMB_NONE
+    else:
+        mode, powers, cf21 = comb
+        a_in = [g.add(f"P{i}", planar(m))[0] for i, m in enumerate(powers)]
+        outs = [g.add(f"B{i}", np.full((ncell, 2, NP, NP), np.nan)) for i in range(5)]
+        a_cp, colpart = g.add("colpart", np.full((ncell, 2, gen_lg.LG_PARTS, NP), np.nan))
+        Bs = [o[1] for o in outs]
+        karg += struct.pack("<ii9Q21d", mode, 0, *a_in, *[o[0] for o in outs], a_cp, *cf21)
     assert len(karg) == gen_lg.KERNARG
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     groups = (ncell + 7) // 8
@@ -58,6 +73,8 @@ def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False
         e = gcn.Emu(prog, g, a_k, wg_id=wg, lds_bytes=gen_lg.LDS_BYTES)
         e.run()
         mf += e.mfma_count
+    if comb is not None:
+        return unplanar(C), [unplanar(b) for b in Bs], colpart, mf
     return unplanar(C), (unplanar(C2) if c2 else None), (U[..., 0] + 1j * U[..., 1] if uout else None), mf
 
 
@@ -76,7 +93,7 @@ def program():
 def test_program_has_no_missing_wait_states_and_assembles(program, tmp_path):
     _, prog, text = program
     assert gcn.check_hazards(prog) == 0
-    assert prog.count("mfma") == 2 * 8 * 12          # two k-blocks per loop iteration, 8 k-steps, 12 matrix instructions each
+    assert prog.count("mfma") == 2 * 8 * 12 + 4      # two k-blocks per loop iteration, 8 k-steps, 12 matrix instructions each; 2 x 2 column sums
     if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
         src = tmp_path / "lg.s"
         src.write_text(text)
@@ -111,7 +128,7 @@ def test_epilogue_terms_second_output_and_grid_mapping(program):
     assert np.abs(C - ref).max() < 4e-15 and np.abs(C2 - (ref + B3)).max() < 4e-15
     # a workgroup whose cell does not exist
     g = gcn.GlobalMem()
-    karg = struct.pack("<8Q6d8iIiQii", *([0] * 8), *([0.0] * 6), NP, 2, 2, 0, 0, 0, 4, (1 << 32) // 4 + 1, (1 << 32) // 2 + 1, 0, 0, 0, 0)
+    karg = struct.pack("<8Q6d8iIiQii", *([0] * 8), *([0.0] * 6), NP, 2, 2, 0, 0, 0, 4, (1 << 32) // 4 + 1, (1 << 32) // 2 + 1, 0, 0, 0, 0) + COMB_NONE
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     e = gcn.Emu(prog, g, a_k, wg_id=5, lds_bytes=gen_lg.LDS_BYTES)
     assert e.run() < 10000 and e.mfma_count == 0
@@ -145,3 +162,48 @@ def test_squaring_launches_copy_finished_cells_through_and_follow_the_device_sid
     assert np.abs(U[0] - X[0]).max() == 0.0 and np.abs(U[1] - X[1] @ X[1]).max() < 4e-15 and np.isnan(C.real).all()
     C, _, U, mf = run(prog, NP, X, X, uout=True, smax=2, s_cell=[0, 2], sq_iter=2)
     assert np.isnan(C.real).all() and np.isnan(U.real).all() and mf == 0
+
+
+@pytest.mark.parametrize("herm", [1, 0], ids=["hermitian", "general"])
+def test_last_power_forms_the_combinations_in_its_epilogue(program, herm):
+    """round 5: A6 = A3 A3 with `comb`: B1 .. B5 of the polynomial route for s = 0 from the block in the accumulators and the
+    same block of A, A2, A3, identity terms on the diagonal, column sums of |A2| and |A6| (general matrices: |A3|) over the
+    block's 64 rows.  Hermitian products compute the upper block triangle: the workgroup of an off-diagonal block forms the
+    combinations of the mirrored block too, from the transposed elements it has just stored."""
+    _, prog, _ = program
+    rng = np.random.default_rng(7)
+    NP, NB = 128, 2
+    A = rnd(rng, 2, NP, "skew" if herm else None) * 0.7
+    A2 = A @ A
+    A3 = A2 @ A
+    cf = [0.11, -0.23, 0.31,  0.41, 0.53, -0.61,  0.7, 0.13, -0.17, 0.19, 0.23,  -0.9, 0.29, 0.31, -0.37, 0.41,  1.0, 0.43, 0.47, 0.53, -0.59]
+    a, e, d, c, b = cf[0:3], cf[3:6], cf[6:11], cf[11:16], cf[16:21]
+    A6, Bs, colpart, mf = run(prog, NP, A3, A3, herm=herm, comb=(1 | (2 if herm else 0), [A, A2, A3], cf))
+    r6 = A3 @ A3
+    assert np.abs(A6 - r6).max() < 4e-15 * max(1.0, np.abs(r6).max())
+    I = np.eye(NP)
+    ref = [a[0] * A + a[1] * A2 + a[2] * A3, e[0] * A2 + e[1] * A3 + e[2] * r6,
+           d[0] * I + d[1] * A + d[2] * A2 + d[3] * A3 + d[4] * r6, c[0] * I + c[1] * A + c[2] * A2 + c[3] * A3 + c[4] * r6,
+           b[0] * I + b[1] * A + b[2] * A2 + b[3] * A3 + b[4] * r6]
+    blocks = [(bi, bj) for bi in range(NB) for bj in range(NB)]
+    for got, want in zip(Bs, ref):
+        for bi in range(NB):
+            for bj in range(NB):
+                blk = got[:, 64 * bi:64 * bi + 64, 64 * bj:64 * bj + 64]
+                if (bi, bj) in blocks:
+                    assert np.abs(blk - want[:, 64 * bi:64 * bi + 64, 64 * bj:64 * bj + 64]).max() < 1e-14
+                else:
+                    assert np.isnan(blk.real).all()
+    absum = lambda M: np.abs(M.real) + np.abs(M.imag)
+    P, Q = absum(A2), absum(r6 if herm else A3)
+    for cell in range(2):
+        for bi in range(NB):
+            for bj in range(NB):
+                got_p = colpart[cell, 0, bi, 64 * bj:64 * bj + 64]
+                got_q = colpart[cell, 1, bi, 64 * bj:64 * bj + 64]
+                if (bi, bj) in blocks:
+                    assert np.abs(got_p - P[cell, 64 * bi:64 * bi + 64, 64 * bj:64 * bj + 64].sum(axis=0)).max() < 1e-13
+                    assert np.abs(got_q - Q[cell, 64 * bi:64 * bi + 64, 64 * bj:64 * bj + 64].sum(axis=0)).max() < 1e-13
+                else:
+                    assert np.isnan(got_p).all() and np.isnan(got_q).all()
+    assert np.isnan(colpart[:, :, NB:]).all()
