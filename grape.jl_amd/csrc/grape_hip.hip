@@ -96,6 +96,8 @@ struct grape_handle {
     double *d_dinv = nullptr;
     int *d_scell = nullptr;
     double *d_colpart = nullptr;   // [chunk][2][LG_PARTS][NP] partial column sums of two powers (lg_t18_operands2_kernel)
+    bool lg_form2 = false;         // formation with the operators in registers (lg_form2_kernel; GRAPE_LG_FORM2=0: lg_form_kernel)
+    double *d_normpart = nullptr, *d_normpart2 = nullptr;   // [chunk][NP / 8][NP] partial column sums of |A| (per lane of chunks)
     bool lg_fuse = true;           // GRAPE_LG_FUSE=0: the combinations in a pass of their own (lg_t18_operands2_kernel) instead of
                                    // the epilogue of the launch that writes the last power
     bool lg_spec = true;           // GRAPE_LG_SPEC=0: the separate norm pass (lg_t18_scale_kernel) in front of the combinations
@@ -992,7 +994,16 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         fa.NP = NP; fa.L = h->L; fa.N_T = h->N_T; fa.hc_per_traj = h->p.hc_per_traj; fa.cell0 = (int)c0_; fa.rep = h->d_rep;
         fa.norm1 = d_dinv;   // (the inverse slots of the Pade route are idle here: ||A||_1 per cell)
         fa.Sf = h->d_Sf;
-        hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(1024), 0, s, fa);
+        if (h->lg_form2) {
+            double *np_ = lane2 ? h->d_normpart2 : h->d_normpart;
+            const dim3 grid(NP / LG_FORM_ROWS, (nc + 15) / 16);
+            if (h->L <= 2) hipLaunchKernelGGL(lg_form2_kernel<2>, grid, dim3(256), 0, s, fa, nc, np_);
+            else hipLaunchKernelGGL(lg_form2_kernel<4>, grid, dim3(256), 0, s, fa, nc, np_);
+            LGCHK(hipGetLastError());
+            hipLaunchKernelGGL(lg_norm1_kernel, dim3(nc), dim3(256), 0, s, fa, (const double *)np_);
+        } else {
+            hipLaunchKernelGGL(lg_form_kernel, dim3(nc), dim3(1024), 0, s, fa);
+        }
         LGCHK(hipGetLastError());
         const LgView vA = lg_full(A, NP), vA2 = lg_full(A2, NP), vA3 = lg_full(A3, NP), vA6 = lg_full(A6, NP),
                      vB1 = lg_full(B1, NP), vB5 = lg_full(B5, NP), vA9 = lg_full(A9, NP), vL = lg_full(Lm, NP), vT = lg_full(T, NP);
@@ -1332,7 +1343,7 @@ void grape_destroy(grape_handle *h) {
     if (h->lg_stream2) { hipStreamSynchronize(h->lg_stream2); hipStreamDestroy(h->lg_stream2); }
     if (h->lg_ev_fork) hipEventDestroy(h->lg_ev_fork);
     if (h->lg_ev_join) hipEventDestroy(h->lg_ev_join);
-    void *bufs[] = {h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_normpart, h->d_normpart2, h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -1749,8 +1760,13 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
             if (h->lg_spec) CCHK(dmalloc(&h->d_colpart, (size_t)h->chunk * 2 * LG_PARTS * NP));
             // summed controls of every time step for the generator formation (polynomial route, shared control operators):
             // N_T 2 NP^2 doubles -- 2.1 GB at C5 -- when that is a small part of what the propagators take anyway
+            {
+                const char *envf2 = getenv("GRAPE_LG_FORM2");
+                h->lg_form2 = h->t18 && !p->hc_per_traj && L <= 4 && NP % LG_FORM_ROWS == 0 && !(envf2 && atoi(envf2) == 0);
+                if (h->lg_form2) CCHK(dmalloc(&h->d_normpart, (size_t)h->chunk * (NP / LG_FORM_ROWS) * NP));
+            }
             const double sn_bytes = (double)N_T * 2.0 * (double)pp * 8.0;
-            if (h->t18 && !p->hc_per_traj && !(envsn && atoi(envsn) == 0) && sn_bytes <= 0.25 * (double)h->KC * N_T * (double)pp * 16.0 + 1e9)
+            if (!h->lg_form2 && h->t18 && !p->hc_per_traj && !(envsn && atoi(envsn) == 0) && sn_bytes <= 0.25 * (double)h->KC * N_T * (double)pp * 16.0 + 1e9)
                 CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * pp));
             // second lane: only when there is more than one chunk to overlap and the second scratch set is small against the
             // device (the propagators themselves take K N_T pp 16 bytes)
@@ -1765,6 +1781,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
                 CCHK(dmalloc(&h->d_scell2, (size_t)h->chunk + 1));
                 CCHK(dmalloc(&h->d_colpart2, (size_t)h->chunk * 2 * LG_PARTS * NP));
                 CCHK(dmalloc(&h->d_smax2, 1));
+                if (h->lg_form2) CCHK(dmalloc(&h->d_normpart2, (size_t)h->chunk * (NP / LG_FORM_ROWS) * NP));
                 if (!h->lg_stream2) {
                     CCHK(hipStreamCreateWithFlags(&h->lg_stream2, hipStreamNonBlocking));
                     CCHK(hipEventCreateWithFlags(&h->lg_ev_fork, hipEventDisableTiming));

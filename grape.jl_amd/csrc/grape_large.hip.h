@@ -331,6 +331,92 @@ __global__ void __launch_bounds__(1024) lg_form_kernel(LgFormArgs a) {
     }
 }
 
+// Round 5: formation with the operators in registers.  lg_form_kernel (one workgroup per cell) reads H0_k and S_n for every
+// cell and writes A: 33.6 GB per C5-shard evaluation at 4.5 TB/s, 7.4 ms (+ 0.7 ms for the S_n).  Here a workgroup owns
+// LG_FORM_ROWS rows of the matrix for a SLICE OF CELLS: thread j keeps its column's elements of H0_k and of the (at most
+// four, shared) control operators in registers and only writes -- 16.8 GB, plus the partial column sums of |a_ij| (1/16 of
+// that), which lg_norm1_kernel turns into ||A||_1 per cell (same sums, same order for every launch geometry).
+constexpr int LG_FORM_ROWS = 8;
+template <int LMAX>
+__global__ void __launch_bounds__(256) lg_form2_kernel(LgFormArgs a, int ncell, double *normpart) {
+    const int NP = a.NP, j = threadIdx.x, rg = blockIdx.x, i0 = rg * LG_FORM_ROWS, ngroups = NP / LG_FORM_ROWS;
+    if (j >= NP) return;
+    const size_t pp = (size_t)NP * NP;
+    const int per = (ncell + gridDim.y - 1) / gridDim.y, c_lo = blockIdx.y * per, c_hi = min(ncell, c_lo + per);
+    double hr[LG_FORM_ROWS], hi[LG_FORM_ROWS], cr[LMAX][LG_FORM_ROWS], ci[LMAX][LG_FORM_ROWS];
+    int k_have = -1;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int cell = a.cell0 + c, kc = cell / a.N_T, n = cell - kc * a.N_T;
+        const int k = a.rep ? a.rep[kc] : kc;
+        if (k != k_have) {   // (a chunk holds the cells of one trajectory, rarely of two)
+            const double *h0 = a.H0f + (size_t)k * 2 * pp;
+#pragma unroll
+            for (int r = 0; r < LG_FORM_ROWS; ++r) {
+                const size_t o = (size_t)(i0 + r) * NP + j;
+                hr[r] = h0[o]; hi[r] = h0[pp + o];
+            }
+            if (k_have < 0) {
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l)
+#pragma unroll
+                    for (int r = 0; r < LG_FORM_ROWS; ++r) {
+                        const size_t o = (size_t)l * 2 * pp + (size_t)(i0 + r) * NP + j;
+                        cr[l][r] = l < a.L ? a.Hcf[o] : 0.0; ci[l][r] = l < a.L ? a.Hcf[pp + o] : 0.0;
+                    }
+            }
+            k_have = k;
+        }
+        const double dt = a.dts[n];
+        double e[LMAX];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            e[l] = l < a.L ? a.eps[(size_t)l * a.N_T + n] : 0.0;
+            if (a.shape && l < a.L) e[l] *= a.shape[(size_t)l * a.N_T + n];
+        }
+        double *A = a.A + (size_t)c * 2 * pp;
+        double cs = 0.;
+#pragma unroll
+        for (int r = 0; r < LG_FORM_ROWS; ++r) {
+            double xr = hr[r], xi = hi[r];
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) { xr = fma(e[l], cr[l][r], xr); xi = fma(e[l], ci[l][r], xi); }
+            const double ar = dt * xi, ai = -dt * xr;
+            cs += sqrt(ar * ar + ai * ai);
+            const size_t o = (size_t)(i0 + r) * NP + j;
+            __builtin_nontemporal_store(ar, A + o);
+            __builtin_nontemporal_store(ai, A + pp + o);
+        }
+        normpart[((size_t)c * ngroups + rg) * NP + j] = cs;
+    }
+}
+// ||A||_1 per cell from the partial column sums of lg_form2_kernel (one workgroup per cell, thread j owns column j): what the
+// tail of lg_form_kernel does
+__global__ void __launch_bounds__(256) lg_norm1_kernel(LgFormArgs a, const double *normpart) {
+    __shared__ double wmax[4];
+    const int NP = a.NP, tid = threadIdx.x, ngroups = NP / LG_FORM_ROWS;
+    double m = 0.;
+    if (tid < NP) {
+        const double *np_ = normpart + (size_t)blockIdx.x * ngroups * NP + tid;
+        for (int g = 0; g < ngroups; ++g) m += np_[(size_t)g * NP];   // fixed order
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        const double nA = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+        int s = 0;
+        if (nA > 5.4) {
+            const double r = nA / 5.4;
+            const int ex = ilogb(r);
+            s = (r == ldexp(1.0, ex)) ? ex : ex + 1;
+        }
+        stat_add(a.stats, 0, (unsigned long long)s);
+        stat_add(a.stats, 7, 1ull);
+        a.norm1[blockIdx.x] = nA;
+    }
+}
+
 // ---- polynomial route of the blocked path (five products, no solve; scheme and coefficients: grape_t18_coeffs.h) ----
 // Scaling of one cell from the powers: Hermitian generators beta = min(||A2||_1^(1/2), ||A6||_1^(1/6)) against theta = 2
 // (spectral bound, see grape_t18.hip.h); general matrices alpha = min(||A||_1, max(||A2||_1^(1/2), ||A3||_1^(1/3))) against
