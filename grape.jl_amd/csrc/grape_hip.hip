@@ -101,9 +101,8 @@ struct grape_handle {
     bool lg_fuse = true;           // GRAPE_LG_FUSE=0: the combinations in a pass of their own (lg_t18_operands2_kernel) instead of
                                    // the epilogue of the launch that writes the last power
     bool lg_spec = true;           // GRAPE_LG_SPEC=0: the separate norm pass (lg_t18_scale_kernel) in front of the combinations
-    // second lane of the polynomial route (round 5): the chunks of an evaluation are independent, so odd chunks run on a
-    // second stream with their own scratch -- the HBM-bound passes of one chunk (formation, combinations) share the chip with
-    // the matrix-bound products of the other instead of standing between them.  GRAPE_LG_LANES=1: one lane
+    // second lane of the polynomial route (round 5, GRAPE_LG_LANES=2; off by default): the chunks of an evaluation are
+    // independent, so odd chunks run on a second stream with their own scratch and fill the launch tails of the even ones
     int lg_lanes = 1;
     double *d_lg2[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     double *d_dinv2 = nullptr, *d_colpart2 = nullptr;
@@ -1739,12 +1738,12 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     }
     if (h->large && !h->series) {
         const long ncell = (long)h->KC * N_T;
-        // chunk scratch: 6 GB for one lane of chunks (a launch of 635 cells at N = 256 has tails of ~1 % of its length), 1 GB
-        // per lane when two lanes alternate (each covers the other's tails, and the finer the chunks, the more often an
-        // HBM-bound pass of one lane meets a product of the other: phase A of the C5 shard 143.4 ms with one lane, 142.3 / 139.7 /
-        // 138.6 / 145.9 ms with two lanes of 6 / 2 / 1 / 0.5 GB, same box)
+        // chunk scratch: 6 GB (a launch of 635 cells at N = 256 has tails of ~1 % of its length).  GRAPE_LG_LANES=2: two lanes of
+        // chunks of 1 GB on two streams, each covering the other's launch tails -- phase A of the C5 shard 143.4 -> 138.6 ms before
+        // the combinations moved into the epilogue of the products, 128.8 -> 127.5 ms since; off by default (1 % for a second
+        // scratch set, and kernel statistics in which the launches of the two lanes overlap)
         const char *envl = getenv("GRAPE_LG_LANES"), *envsp0 = getenv("GRAPE_LG_SPEC");
-        const bool want_lanes = h->t18 && !(envsp0 && atoi(envsp0) == 0) && !(envl && atoi(envl) <= 1);
+        const bool want_lanes = h->t18 && !(envsp0 && atoi(envsp0) == 0) && envl && atoi(envl) >= 2;
         double scratch_bytes = want_lanes ? 1.0e9 : 6.0e9;
         if (const char *envg = getenv("GRAPE_LG_SCRATCH_GB")) scratch_bytes = std::max(0.1, atof(envg)) * 1e9;   // (experiments: launch tails against scratch)
         const long cap = std::max<long>(1, (long)(scratch_bytes / (9.0 * 2.0 * pp * 8.0)));

@@ -13,8 +13,8 @@ d=json.load(open('gpurun_out/${tag}_${name}.json')); print('${name}', round(d['m
 }
 for rep in a b; do
 run default_$rep X=1 &&
+run lanes2_$rep GRAPE_LG_LANES=2 &&
 run form1_$rep GRAPE_LG_FORM2=0 &&
 run nofuse_$rep GRAPE_LG_FUSE=0 &&
-run lanes1_$rep GRAPE_LG_LANES=1 &&
-run r05start_$rep GRAPE_LG_LANES=1 GRAPE_LG_FUSE=0 GRAPE_LG_FORM2=0 || exit 1
+run r05start_$rep GRAPE_LG_FUSE=0 GRAPE_LG_FORM2=0 || exit 1
 done
