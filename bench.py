@@ -269,6 +269,13 @@ def main():
                     traffic = d.get("hbm_bytes_per_launch")
                     hw_util = d.get("MfmaUtil_percent")
                     pmc_mops = d.get("SQ_INSTS_VALU_MFMA_MOPS_F64")
+            if N > 64:   # blocked path: phase A is a chain of launches -- all of them, per evaluation of the profiled run
+                n_eval = max([d.get("dispatches", 0) for k_, d in pmc["kernels"].items() if "grad_reduce_kernel" in k_] or [0])
+                phase_a = [d for k_, d in pmc["kernels"].items()
+                           if any(t in k_ for t in ("lg_gemm_asm", "lg_gemm_kernel", "lg_form", "lg_norm1", "lg_t18", "ctrl_sum_kernel"))]
+                if n_eval and phase_a:
+                    traffic = sum(d.get("hbm_bytes_per_launch", 0.0) * d.get("dispatches", 0) for d in phase_a) / n_eval
+                    hw_util = max(d.get("MfmaUtil_percent", 0.0) for d in phase_a)
         except Exception:
             pass
         expm_ms = tm["expm"]
@@ -352,7 +359,9 @@ def main():
                                            "issue: padding to 16-row tiles and redone cells included)",
                          "flop_per_launch": work["flop_expm"], "avg_launch_ms": expm_ms,
                          "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE + WRITE_SIZE); algorithmic bytes per launch = "
+                         "traffic_unit": ("HBM bytes of ALL launches of phase A per evaluation (blocked path: formation, products with "
+                                          "their fused epilogue, decision)" if N > 64 else "HBM bytes per launch") +
+                                         " (PMC FETCH_SIZE + WRITE_SIZE); algorithmic bytes per launch = "
                                          f"K*N_T*N^2*16 (U store) = {16.0 * work['expm_cells'] * N * N:.3e}",
                          "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc passes of tools/pmc.sh; NOT "
                                            "measured in this run)" if pmc_file else None,
