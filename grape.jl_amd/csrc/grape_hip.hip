@@ -1455,8 +1455,14 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     if (p->chi_min_norm > 0) h->chi_min_norm = p->chi_min_norm;
     if (p->taylor_tolerance > 0) h->taylor_tol = p->taylor_tolerance;
     if (p->taylor_max_order > 0) h->taylor_max_order = p->taylor_max_order;
-    // the gradient-generator route sums the same series until it has converged to rounding
-    if (p->gradient_method == GRAPE_GRAD_GRADGEN) { h->taylor_max_order = 200; h->taylor_tol = 1e-17; }
+    // the gradient-generator route sums the same series until it has converged to rounding: a term below 1e-16 of the state
+    // norm.  (The tail behind it is geometric with ratio rho / m -- 0.07 at the headline shape -- so what is cut is below
+    // 1e-17; until round 5 the bound was 1e-17 itself: one more order per cell for a gradient that differs by 4e-16 RELATIVE,
+    // the rounding of the sums the terms are added to.  tools/tol_ab.py)
+    if (p->gradient_method == GRAPE_GRAD_GRADGEN) {
+        h->taylor_max_order = 200; h->taylor_tol = 1e-16;
+        if (const char *envt = getenv("GRAPE_GRADGEN_TOL")) h->taylor_tol = atof(envt);   // (tools/tol_ab.py)
+    }
     h->series = p->prop_method == GRAPE_PROP_SERIES;
     if (p->prop_tolerance > 0) h->series_tol = p->prop_tolerance;
 
