@@ -343,8 +343,7 @@ class Gen:
         for r in range(4):
             p.valu("v_add_u32", vx, 4 * r, vrg)
             p.v_cmp("v_cmp_eq_u32", self.s_dmask[r], vx, vc)
-        for i in range(1, 16):
-            self.smov64(self.s_c[i], self.c[f"C{i}"])
+        self.load_constants()
         p.s_waitcnt(lgkm=0)
         wg = S(2)
         t0, t1, t2 = self.s_tmp[0], self.s_tmp[1], self.s_tmp[2]
@@ -426,6 +425,10 @@ class Gen:
             p.valu("v_add_u32", vpc, 64 * r_, vy)
             p.valu("v_cndmask_b32", self.v_UO[r_], vidx, vpc, VCC)
         self.vp.free(t)
+
+    def load_constants(self):
+        for i in range(1, 16):
+            self.smov64(self.s_c[i], self.c[f"C{i}"])
 
     # ---- scalars of a cell ----
     def cell_bases_issue(self, kc, n, cell):
