@@ -305,7 +305,9 @@ def main():
             expm_kernel = (name + " (inverse-free degree-16 polynomial, four products; %d of %d cells beyond "
                            "its spectral bound redone by the five-product launch)" % (redone, work["t18_cells"]))
         elif work.get("t18_cells", 0.0) > 0.0:
-            expm_kernel = "expm_t18_kernel<%d> (inverse-free degree-18 polynomial, five products)" % ((N + 15) // 16)
+            expm_kernel = ("expm_t18g_asm (hand-allocated gfx950 assembly, csrc/asm/gen_t18g.py; general matrices, scaling decided in "
+                           "the cell)" if work.get("asm_kernel", 0.0) == 2.0 else
+                           "expm_t18_kernel<%d>" % ((N + 15) // 16)) + " (inverse-free degree-18 polynomial, five products)"
         else:
             expm_kernel = ("expm_persistent_kernel<4,...>" if N > 48 else "expm_pade_kernel<%d,...>" % ((N + 15) // 16)) + " (order-13 Pade)"
         # minimal matrix-instruction work of the CHOSEN algorithm (not of Julia's): a complex product by the 3M scheme is three

@@ -138,6 +138,7 @@ struct grape_handle {
     // the four-product route as hand-allocated assembly (asm/gen_t16.py; GRAPE_EXPM_ASM=0: the C++ kernel): four tiles
     // per side, Hermitian generators, controls shared by the trajectories
     bool asm16 = false;
+    bool asm18g = false;         // general matrices at four tiles per side: the five-product cell as assembly (GRAPE_EXPM_ASM18G=0: compiled)
     // round 5: the assembly kernel's workgroups walk contiguous ranges of cells (d_wgtab) and carry the state of their
     // trajectory along while the cell's result is in registers -- Psi upwards from t = 0, conj(chi~) downwards from t = T
     // (d_xinit: the two start vectors of every trajectory) -- and report how far each end got (d_prog[2][K]); the sweep
@@ -329,6 +330,8 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
+extern "C" int grape_t18g_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
+                                     const void *const *walk, int fuse, int K);
 extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
                                     const void *const *walk, int fuse, int K);
 extern "C" void grape_t16_walks(int KC, int N_T, int nblk, int *tab);
@@ -1535,6 +1538,8 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
             h->t16 = !(env16 && !atoi(env16));
             const char *enva = getenv("GRAPE_EXPM_ASM");
             h->asm16 = !(enva && !atoi(enva));
+            const char *envg = getenv("GRAPE_EXPM_ASM18G");
+            h->asm18g = !(envg && !atoi(envg));
         }
         {
             const char *envp = getenv("GRAPE_EXPM_PERSIST"), *envl = getenv("GRAPE_EXPM_LDS_PAD"), *envx = getenv("GRAPE_CHEBY_XMODE");
@@ -1903,9 +1908,10 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
     // more than two controls shared by all trajectories: the cell fetches H0_k and ONE summed operator S_n (ctrl_sum_kernel)
     h->asm16 = h->asm16 && h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT == 4 && !p->hc_per_traj && (long)K * N_T < (1L << 28);
-    if (h->t18 && !h->large && !h->series && (L > 2 || h->asm16) && !p->hc_per_traj && (h->NT >= 3 || h->t18_small))
+    h->asm18g = h->asm18g && h->t18 && !h->herm && !h->large && !h->series && h->NT == 4 && !p->hc_per_traj && (long)K * N_T < (1L << 28);
+    if (h->t18 && !h->large && !h->series && (L > 2 || h->asm16 || h->asm18g) && !p->hc_per_traj && (h->NT >= 3 || h->t18_small))
         CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * NP * NP));
-    if (h->asm16) {
+    if (h->asm16 || h->asm18g) {
         // one workgroup per CU (512 registers, 139 KB of LDS), never more workgroups than cells
         const long ncell = (long)h->KC * N_T;
         h->asm_blocks = (int)std::max<long>(1, std::min<long>(h->num_cus, ncell));
@@ -2142,7 +2148,14 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                 // (three tiles per side, four-product variant: 256 registers and 72 KB -- two workgroups per CU)
                 const int blocks16 = (t16 && h->NT == 3) ? 8 * (int)std::max<long>(1, std::min<long>((long)(h->num_cus / 8) * 2, (ncell + 7) / 8)) : t18_blocks;
                 h->credit_pending = false;
-                if (t16 && h->asm16) {   // (the verdicts of the assembly kernel go through the flag array of the Pade path)
+                if (h->asm18g) {   // general matrices: the assembly cell decides its squarings itself, nothing is handed over
+                    walk_fuse = h->asm_walk & (1 | ((h->fuse && h->fuse_on && h->want_bw) ? 2 : 0));
+                    if (walk_fuse) HIPCHK(h, hipMemsetAsync(h->d_prog, 0, (size_t)2 * h->K * sizeof(int), s));
+                    const void *walk[6] = {h->d_wgtab, h->d_xinit, h->d_fw, h->d_bw, h->d_prog, h->d_splan};
+                    e = (hipError_t)grape_t18g_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, h->asm_blocks, walk, walk_fuse, h->K);
+                    h->credit_pending = true;
+                }
+                else if (t16 && h->asm16) {   // (the verdicts of the assembly kernel go through the flag array of the Pade path)
                     // what the walks may carry along: Psi always (the forward sweep is the same whatever follows), conj(chi~)
                     // when this evaluation runs the backward sweep from the unit targets (concurrent sweeps)
                     walk_fuse = h->asm_walk & (1 | ((h->fuse && h->fuse_on && h->want_bw) ? 2 : 0));
@@ -3173,7 +3186,7 @@ int grape_get_work(grape_handle *h, double *out, int n) try {
             if (rc < 0) return multi_fail(h, c, rc);
             for (int i = 0; i < m; ++i) out[i] = (i == 15 || i == 16) ? cw[i] : out[i] + cw[i];   // ([15], [16]: kernel ids, the same in every shard)
         }
-        if (m > 14 && out[14] > 0.0) out[14] = 1.0;   // (a flag, not a count)
+        if (m > 14 && out[14] > 0.0) out[14] = h->shards[0]->asm18g ? 2.0 : 1.0;   // (an id, not a count)
         return 4;
     }
     HIPCHK(h, hipSetDevice(h->device));
@@ -3215,7 +3228,7 @@ int grape_get_work(grape_handle *h, double *out, int n) try {
     // runs matrix-free (see grape_create)
     if (n > 12) out[12] = h->u_fallback ? 1.0 : 0.0;
     if (n > 13) out[13] = (double)st[15];   // cells of [11] that took the four-product degree-16 route
-    if (n > 14) out[14] = h->asm16 ? 1.0 : 0.0;   // the four-product route of this handle is the hand-allocated assembly kernel
+    if (n > 14) out[14] = h->asm16 ? 1.0 : h->asm18g ? 2.0 : 0.0;   // 1: the four-product route of this handle is the hand-allocated assembly kernel; 2: general matrices, expm_t18g_asm
     // which derivative kernel the ExpProp route of this handle launches: 0 a compiled one, 1 deriv3_asm, 2 deriv3s_asm (streamed
     // controls), 3 deriv3g_asm (general operators), 4 deriv4_asm (blocked path); [16]: the products of the blocked polynomial
     // route are lg_gemm_asm

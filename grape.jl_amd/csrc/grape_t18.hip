@@ -231,11 +231,12 @@ constexpr int D3_INV_TABLE = 2048;
 struct AsmModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr, fn_d3g = nullptr, fn_d4[2] = {nullptr, nullptr};
+    hipFunction_t fn_t18g = nullptr;
     double *inv = nullptr;      // 1 / m, m < D3_INV_TABLE
 };
 hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr,
                         hipFunction_t *fn_d3s = nullptr, hipFunction_t *fn_lg = nullptr, hipFunction_t *fn_d3g = nullptr,
-                        hipFunction_t *fn_d4 = nullptr, int d4_index = 0) {
+                        hipFunction_t *fn_d4 = nullptr, int d4_index = 0, hipFunction_t *fn_t18g = nullptr) {
     static AsmModule mods[64];
     static std::mutex mtx;
     std::lock_guard<std::mutex> lock(mtx);
@@ -254,6 +255,8 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         e = hipModuleGetFunction(&m.fn_d4[0], m.mod, "deriv4_asm_128");
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn_d4[1], m.mod, "deriv4_asm_256");
+        if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn_t18g, m.mod, "expm_t18g_asm");
         if (e != hipSuccess) return e;
         // 1 / m for the series orders (the kernels read them with scalar loads; gfx9 has no scalar floating point); behind
         // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
@@ -279,6 +282,7 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
     if (fn_lg) *fn_lg = m.fn_lg;
     if (fn_d3g) *fn_d3g = m.fn_d3g;
     if (fn_d4) *fn_d4 = m.fn_d4[d4_index & 1];
+    if (fn_t18g) *fn_t18g = m.fn_t18g;
     if (inv) *inv = m.inv;
     return hipSuccess;
 }
@@ -438,6 +442,65 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
     e = hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(t16_post_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, (const int *)verdict,
+                       fuse ? (const int *)walk[4] : (const int *)nullptr, 2 * K, (const int *)walk[5]);
+    return (int)hipGetLastError();
+}
+
+// ---- general matrices: the five-product cell with its own scaling decision (asm/gen_t18g.py -> expm_t18g_asm) ----
+// Same argument block and walk tables as expm_t16_asm; the kernel writes verdict[cell] (2: norms not finite) and the number
+// of squarings it chose into splan[cell].  Behind it: executed work (960 products + 3 column sums + 192 per squaring matrix
+// instructions per wave and cell, two per carried state), squarings, cells; a cell that is not finite raises bit 6.
+namespace {
+__global__ void __launch_bounds__(256) t18g_post_kernel(ExpmArgs a, const int *verdict, const int *prog, int nprog, const int *splan) {
+    const int tid = threadIdx.x, lane = tid & 63, ncell = a.K * a.N_T;
+    if (prog && blockIdx.x == 0) {
+        unsigned long long steps = 0;
+        for (int i = tid; i < nprog; i += 256) steps += (unsigned long long)prog[i];
+        for (int off = 32; off >= 1; off >>= 1) steps += __shfl_xor(steps, off, 64);
+        if (lane == 0 && steps) stat_add(a.stats, 12, steps * 4ull * 2ull);
+    }
+    const int cell = blockIdx.x * 256 + tid;
+    const bool valid = cell < ncell;
+    const bool bad = valid && verdict[cell] != 0;
+    unsigned long long sq = valid ? (unsigned long long)splan[cell] : 0ull;
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const unsigned long long m_valid = __ballot(valid), m_bad = __ballot(bad);
+    if (lane == 0 && m_valid) {
+        const unsigned long long nc = (unsigned long long)__popcll(m_valid);
+        stat_add(a.stats, 12, 4ull * (nc * (5ull * 192ull + 3ull) + sq * 192ull));
+        if (sq) stat_add(a.stats, 13, sq);
+        stat_add(a.stats, 14, nc);
+        if (m_bad) atomicOr(&a.flags[0], 64);
+    }
+}
+}  // namespace
+
+extern "C" int grape_t18g_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
+                                     const void *const *walk, int fuse, int K) {
+    if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
+    ExpmArgs a;
+    memcpy(&a, args, sizeof(a));
+    if (!a.Sf || a.hc_per_traj || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
+    if (fuse && (!walk[1] || !walk[2] || !walk[3] || !walk[4] || a.rep || K != a.K)) return (int)hipErrorInvalidValue;
+    const long ncell = (long)a.K * a.N_T;
+    if (ncell <= 0 || ncell >= (1L << 28)) return (int)hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipFunction_t fn;
+    e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &fn);
+    if (e != hipSuccess) return (int)e;
+    T16AsmArgs k{};
+    k.H0f = a.H0f; k.Sf = a.Sf; k.dts = a.dts; k.U = a.U; k.verdict = verdict; k.rep = a.rep;
+    k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks; k.flags = a.flags;
+    k.fuse = fuse; k.wgtab = (const int *)walk[0]; k.xinit = (const double2 *)walk[1]; k.fw = (double2 *)walk[2];
+    k.bw = (double2 *)walk[3]; k.prog = (int *)walk[4]; k.K = K; k.splan = (const int *)walk[5];
+    size_t size = sizeof(k);
+    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    hipStream_t s = (hipStream_t)stream;
+    e = hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, s, nullptr, cfg);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(t18g_post_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, s, a, (const int *)verdict,
                        fuse ? (const int *)walk[4] : (const int *)nullptr, 2 * K, (const int *)walk[5]);
     return (int)hipGetLastError();
 }
