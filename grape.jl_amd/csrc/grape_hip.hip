@@ -511,6 +511,9 @@ std::vector<double> gebal_scaling(int N, std::vector<double> M) {
             }
             c = std::sqrt(c); r = std::sqrt(r);
             if (c == 0.0 || r == 0.0) continue;
+            // (LAPACK's xGEBAL leaves with an error on a NaN; here: no balancing -- the evaluation reports the generator that is
+            // not finite.  Without this exit the loop below never converges: every comparison with a NaN is false.  Round 5.)
+            if (!(c + r + ca + ra <= 1.7976931348623157e308)) return std::vector<double>((size_t)N, 1.0);
             double g = r / radix, f = 1.0;
             const double s0 = c + r;
             while (c < g && std::max(f, std::max(c, ca)) < sfmax2 && std::min(r, std::min(g, ra)) > sfmin2) {

@@ -427,3 +427,74 @@ def test_scaled_four_product_route_against_the_five_product_route(g, dt, s_expec
         H = pr["H0"][k] + e[0, n] * pr["Hc"][0] + e[1, n] * pr["Hc"][1]
         ref = expm(-1j * dt * H)
         assert np.abs(a[5][i] - ref).max() < 2e-14 * max(1.0, dt) and np.abs(b[5][i] - ref).max() < 2e-14 * max(1.0, dt)
+
+
+# ---- general matrices: expm_t18g_asm (csrc/asm/gen_t18g.py) against expm_t18_kernel<4, false, false> ----
+def run_general(g, pr, asm, walk="3", **kw):
+    old = {k: os.environ.get(k) for k in ("GRAPE_EXPM_ASM18G", "GRAPE_EXPM_WALK")}
+    os.environ["GRAPE_EXPM_ASM18G"] = "1" if asm else "0"
+    os.environ["GRAPE_EXPM_WALK"] = walk
+    try:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            J2, G2, _ = h.eval(pr["pulsevals"])
+            assert J2 == J and np.array_equal(G, G2)
+            K, N_T = pr["H0"].shape[0], len(pr["tlist"]) - 1
+            U = np.stack([h.propagator(k, n) for k in range(K) for n in range(N_T)])
+            return J, G, tau, U, h.work(), h.storage(0), h.storage(1)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("N,L,N_T,K,dt,ctrl", [(64, 2, 9, 3, 1.0, False), (53, 1, 6, 2, 0.2, False), (64, 3, 12, 2, 2.6, True), (60, 2, 33, 5, 1.0, True)])
+def test_general_matrix_assembly_cell_against_its_twin(g, N, L, N_T, K, dt, ctrl):
+    """Round 5: non-Hermitian generators at four tiles per side take the five-product cell as assembly, with the squarings
+    decided in the cell (none at dt = 0.2, one at the headline norm, several at dt = 2.6), the walks carrying the states of
+    the trajectories through it (ascending walks through the transposed exponential), and non-Hermitian control operators
+    through the all-tiles derivative kernel behind it.  Same propagators, squaring counts, J, G, tau as the compiled kernel."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=900 + N, dt=dt, hermitian=False)
+    if ctrl:
+        rng = np.random.default_rng(N)
+        pr["Hc"] = pr["Hc"] + 0.2 * (rng.normal(size=pr["Hc"].shape) + 1j * rng.normal(size=pr["Hc"].shape)) / np.sqrt(N)
+    a = run_general(g, pr, True)
+    b = run_general(g, pr, False)
+    assert a[4]["asm_kernel"] == 2.0 and b[4]["asm_kernel"] == 0.0
+    scale = max(1.0, np.abs(b[3]).max())
+    assert np.abs(a[3] - b[3]).max() < 2e-14 * scale
+    assert a[4]["t18_squarings"] == b[4]["t18_squarings"] and a[4]["t18_cells"] == b[4]["t18_cells"] == K * N_T
+    if dt <= 0.2:
+        assert a[4]["t18_squarings"] == 0
+    if dt >= 2.6:
+        assert a[4]["t18_squarings"] >= 2 * K * N_T
+    jscale = max(1.0, abs(b[0]))
+    assert abs(a[0] - b[0]) <= 1e-12 * jscale and np.abs(a[2] - b[2]).max() <= 1e-12 * max(1.0, np.abs(b[2]).max())
+    assert np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
+    # the stored states: carried by the walks on one side, by the sweep kernel on the other
+    assert np.abs(a[5] - b[5]).max() <= 1e-12 * max(1.0, np.abs(b[5]).max())
+    assert np.abs(a[6] - b[6]).max() <= 1e-12 * max(1.0, np.abs(b[6]).max())
+    # executed matrix instructions: (960 + 3 column sums + 192 per squaring) per wave and cell, two per carried state
+    mi = 4.0 * ((963.0 * K * N_T) + 192.0 * a[4]["t18_squarings"])
+    assert mi * 2048.0 <= a[4]["t18_mfma_flop"] <= (mi + 8.0 * K * N_T) * 2048.0
+    # the walks change nothing but rounding
+    c = run_general(g, pr, True, walk="0")
+    assert abs(a[0] - c[0]) <= 1e-12 * jscale and np.abs(a[1] - c[1]).max() <= 1e-10 * max(np.abs(c[1]).max(), 1e-3)
+    for k, n in [(0, 0), (K - 1, N_T - 1)]:
+        e = pr["pulsevals"].reshape(L, N_T)[:, n]
+        H = pr["H0"][k] + sum(e[l] * pr["Hc"][l] for l in range(L))
+        ref = expm(-1j * (pr["tlist"][n + 1] - pr["tlist"][n]) * H)
+        assert np.abs(a[3][k * N_T + n] - ref).max() < 1e-13 * max(1.0, np.abs(ref).max())
+
+
+def test_general_matrix_assembly_cell_flags_a_generator_that_is_not_finite(g):
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 2, 5, 2, seed=3, hermitian=False)
+    pr["H0"] = pr["H0"].copy()
+    pr["H0"][1, 3, 4] = np.nan
+    with pytest.raises(g.GrapeHipError):
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+            h.eval(pr["pulsevals"])
