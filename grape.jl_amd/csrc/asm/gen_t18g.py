@@ -17,7 +17,7 @@ last product, the trajectory-resident walk that carries a state along.  What dif
 
   * no tile symmetry: all sixteen operator tiles are fetched and committed (a transposed walk writes tile (i, j) to the
     transposed position of block (j, i): A^T, no conjugation), every product has four slots (5 x 192 matrix instructions);
-  * the scaling is decided in the cell from the column sums of |A|, |A2|, |A3| (one matrix instruction each adds the four
+  * the scaling is decided in the cell from the column sums of |A2|, |A3| (one matrix instruction each adds the four
     lane rows, the four waves meet through the reduction scratch) and applied to the COEFFICIENTS: x_p 2^(-p s) is an
     exponent subtraction on a scalar pair, the powers stay as they are;
   * register plan of the combinations (the vector half is full: accumulators 12 tiles, A3 / B5 12, temporaries 4):
@@ -26,7 +26,7 @@ last product, the trajectory-resident walk that carries a state along.  What dif
     the idle p2 accumulator of the slot); B4 becomes the start value of A9 in place of A6; B1 goes to the planes.
 
 Executed by the emulator of gcn.py against scipy (tests/test_asm_t18g.py); verdict[cell] = 2 marks a cell whose norms are not
-finite, splan[cell] receives s (the post kernel books 960 + 192 s matrix instructions per wave and cell from it).
+finite, splan[cell] receives s (the post kernel books 960 + 2 + 192 s matrix instructions per wave and cell from it).
 """
 import os
 import re
@@ -264,41 +264,12 @@ class GenG(g16.Gen):
         A2p_re, A2p_im = ap.alloc(4), ap.alloc(4)
         for sl in range(4):
             A2re[sl], A2im[sl], A2sm[sl] = vp.alloc(), vp.alloc(), vp.alloc()
-        # ---- ||A||_1 (strip in the accumulation half) and ||A2||_1 ----
-        nt0, nt1, nv = vp.alloc(), vp.alloc(), vp.alloc()       # temporaries; nv: n1, n2, n3 of this wave, published values
-        xa = vp.alloc()
-        elems = []
-        streams = []
-        # (A is read through one tile of temporaries, four elements at a time)
-        accn = [nt0.d(k) for k in range(4)]
-        for k in range(4):
-            p.valu("v_mov_b32", accn[k].sub(0), 0)
-            p.valu("v_mov_b32", accn[k].sub(1), 0)
-        for sl in range(4):
-            for r in range(4):
-                xr, xi = xa.d(0 if r % 2 == 0 else 2), xa.d(1 if r % 2 == 0 else 3)
-                self.acc_read(xr, As_re.sub(8 * sl, 8).d(r))
-                self.acc_read(xi, As_im.sub(8 * sl, 8).d(r))
-                p.valu("v_add_f64", accn[r], accn[r], Abs(xr))
-                p.valu("v_add_f64", accn[(r + 2) % 4], accn[(r + 2) % 4], Abs(xi))
-        p.valu("v_add_f64", accn[0], accn[0], accn[1])
-        p.valu("v_add_f64", accn[2], accn[2], accn[3])
-        p.valu("v_add_f64", accn[0], accn[0], accn[2])
-        ones = accn[1]
-        lo, hi = dbits(1.0)
-        p.valu("v_mov_b32", ones.sub(0), lo)
-        p.valu("v_mov_b32", ones.sub(1), hi)
-        p.mfma(nt1, ones, accn[0], 0)
-        n1 = nv.d(0)
-        p.valu("v_mov_b64", n1, nt1.d(0))
-        tmp = accn[2]
-        for ctrl in ("quad_perm:[1,0,3,2]", "quad_perm:[2,3,0,1]", "row_half_mirror", "row_mirror"):
-            p.dpp_mov(tmp.sub(0), n1.sub(0), ctrl)
-            p.dpp_mov(tmp.sub(1), n1.sub(1), ctrl)
-            p.valu("v_max_f64", n1, n1, tmp)
-        vp.free(xa)
+        # ---- ||A2||_1.  (||A||_1 is not needed: the column sums of |re| + |im| are the 1-norm of the real representation of the
+        # matrix, which is submultiplicative, so ||A2||^(1/2) <= ||A|| and ||A3||^(1/3) <= ||A|| -- alpha = min(||A||, max(d2, d3))
+        # is max(d2, d3).  The compiled kernel computes it all the same; its decision can differ only through the factor
+        # 1 + 1e-9 on the two power norms.) ----
+        nt0, nt1, nv = vp.alloc(), vp.alloc(), vp.alloc()       # temporaries; nv: n2, n3 of this wave
         self.colsum_max([(Qt[sl][0].d(r), Qt[sl][2].d(r)) for sl in range(4) for r in range(4)], nv.d(1), (nt0, nt1))
-        self.publish(n1, 0, nv.sub(6))
         self.publish(nv.d(1), 1, nv.sub(6))
         p.s_waitcnt(lgkm=0)
         p.s_barrier()                                 # everybody is done reading A from the planes
@@ -352,19 +323,9 @@ class GenG(g16.Gen):
         vz = vtn[1].sub(6)
         p.valu("v_mov_b32", vz, RED)
         va, vb = vtn[0], vtn[1]
-        for h in range(2):                            # red[0..3] = n1, red[4..7] = n2, red[8..11] = n3 of the four waves
-            p.ds_read(128, va.sub(4 * h, 4), vz, 16 * h)
-        q1 = va.d(0)
-        for k in range(1, 4):
-            p.valu("v_max_f64", q1, q1, va.d(k))
         k0 = S(72, 2)                                 # (a coefficient pair: set behind the decision)
-        self.smov64(k0, 1.0 / THETA)
-        p.valu("v_mul_f64", q1, q1, k0)
         s1, s2, s3 = self.s_tmp[0], self.s_tmp[1], self.s_tmp[2]
         hi_, lo_ = self.s_tmp[4], self.s_tmp[5]
-        p.v_readfirstlane(hi_, q1.sub(1))
-        p.v_readfirstlane(lo_, q1.sub(0))
-        self.ceil_log2_scaled(s1, hi_, lo_, 0, 1)
         for h in range(2):
             p.ds_read(128, va.sub(4 * h, 4), vz, 32 + 16 * h)
         q2 = va.d(0)
@@ -385,8 +346,7 @@ class GenG(g16.Gen):
         p.v_readfirstlane(hi_, q3.sub(1))
         p.v_readfirstlane(lo_, q3.sub(0))
         self.ceil_log2_scaled(s3, hi_, lo_, 0, 3)
-        p.salu("s_max_i32", s2, s2, s3)
-        p.salu("s_min_i32", self.s_scur, s1, s2)
+        p.salu("s_max_i32", self.s_scur, s2, s3)
         # not finite (or absurd): s = 0, verdict 2
         p.s_cmp("s_cmp_gt_i32", self.s_scur, 30)
         p.salu("s_cselect_b32", self.s_tmp[3], 2, 0)

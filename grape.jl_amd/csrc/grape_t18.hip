@@ -448,7 +448,7 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
 
 // ---- general matrices: the five-product cell with its own scaling decision (asm/gen_t18g.py -> expm_t18g_asm) ----
 // Same argument block and walk tables as expm_t16_asm; the kernel writes verdict[cell] (2: norms not finite) and the number
-// of squarings it chose into splan[cell].  Behind it: executed work (960 products + 3 column sums + 192 per squaring matrix
+// of squarings it chose into splan[cell].  Behind it: executed work (960 products + 2 column sums + 192 per squaring matrix
 // instructions per wave and cell, two per carried state), squarings, cells; a cell that is not finite raises bit 6.
 namespace {
 __global__ void __launch_bounds__(256) t18g_post_kernel(ExpmArgs a, const int *verdict, const int *prog, int nprog, const int *splan) {
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(256) t18g_post_kernel(ExpmArgs a, const int *v
     const unsigned long long m_valid = __ballot(valid), m_bad = __ballot(bad);
     if (lane == 0 && m_valid) {
         const unsigned long long nc = (unsigned long long)__popcll(m_valid);
-        stat_add(a.stats, 12, 4ull * (nc * (5ull * 192ull + 3ull) + sq * 192ull));
+        stat_add(a.stats, 12, 4ull * (nc * (5ull * 192ull + 2ull) + sq * 192ull));
         if (sq) stat_add(a.stats, 13, sq);
         stat_add(a.stats, 14, nc);
         if (m_bad) atomicOr(&a.flags[0], 64);

@@ -74,9 +74,9 @@ def run(prog, H0f, Sf, dts, KC, N_T, nblk, fuse=0, psi0=None, chiT=None):
 def s_rule(A):
     n = lambda M: (np.abs(M.real) + np.abs(M.imag)).sum(axis=0).max()
     A2 = A @ A
-    n1, n2, n3 = n(A), n(A2) * (1 + 1e-9), n(A2 @ A) * (1 + 1e-9)
+    n2, n3 = n(A2) * (1 + 1e-9), n(A2 @ A) * (1 + 1e-9)       # (||A||_1 >= both roots: it never decides)
     s, t1 = 0, 1.09
-    while not (n1 <= t1 or (n2 <= t1 ** 2 and n3 <= t1 ** 3)):
+    while not (n2 <= t1 ** 2 and n3 <= t1 ** 3):
         s += 1
         t1 *= 2.0
     return s
@@ -90,7 +90,7 @@ def program():
 def test_program_has_no_missing_wait_states_and_assembles(program, tmp_path):
     _, prog, text = program
     assert gcn.check_hazards(prog) == 0
-    assert prog.count("mfma") == 5 * 192 + 3 + 2 + 192      # five products, three column sums, the carried state, the squaring loop
+    assert prog.count("mfma") == 5 * 192 + 2 + 2 + 192      # five products, two column sums, the carried state, the squaring loop
     if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
         src = tmp_path / "t18g.s"
         src.write_text(text)
@@ -113,7 +113,7 @@ def test_emulated_kernel_matches_expm_for_general_matrices(program, N, KC, N_T, 
             want_s.append(s_rule(A))
     assert (verdict == 0).all()
     assert np.array_equal(splan, want_s), (splan, want_s)
-    assert mf == 4 * (963 * KC * N_T + 192 * int(np.sum(want_s)))
+    assert mf == 4 * (962 * KC * N_T + 192 * int(np.sum(want_s)))
     if scale >= 4.0:
         assert max(want_s) >= 2
     if scale <= 0.25:
