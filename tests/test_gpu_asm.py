@@ -498,3 +498,19 @@ def test_general_matrix_assembly_cell_flags_a_generator_that_is_not_finite(g):
     with pytest.raises(g.GrapeHipError):
         with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
             h.eval(pr["pulsevals"])
+
+
+def test_general_matrix_assembly_cell_follows_generator_classes(g):
+    """trajectories with bit-identical non-Hermitian generators share one set of propagators (KC < K): the assembly cell
+    reads the representative of its class, nothing is carried along (one propagator serves several trajectories)"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(64, 2, 7, 4, seed=61, hermitian=False)
+    pr["H0"] = pr["H0"].copy()
+    pr["H0"][2] = pr["H0"][0]
+    pr["H0"][3] = pr["H0"][1]
+    a = run_general(g, pr, True)
+    b = run_general(g, pr, False)
+    assert a[4]["asm_kernel"] == 2.0 and a[4]["expm_cells"] == 2 * 7 == b[4]["expm_cells"]
+    assert np.abs(a[3] - b[3]).max() < 2e-14 * max(1.0, np.abs(b[3]).max())
+    assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(b[0])) and np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
+    assert a[4]["t18_mfma_flop"] == 4.0 * (962.0 * 14 + 192.0 * a[4]["t18_squarings"]) * 2048.0      # no carried states
