@@ -56,8 +56,12 @@ def cpu_baseline(pr, handle_eval, target_seconds=15.0):
 
     def timed(K_s, budget, method=None):
         t1, _, _ = sample(K_s, 1, method)
-        n_s = min(int(max(2, min(pr["N_T"], budget / max(t1, 1e-3)))), 64)
+        n_s = min(int(max(2, min(pr["N_T"], budget / max(t1, 1e-3)))), 256)
         t, ref, inp = sample(K_s, n_s, method)
+        cap = min(pr["N_T"], 256)
+        if t < 0.5 * budget and n_s < cap:   # (the one-step probe carries the start-up of the threads: it overestimates a step)
+            n_s = min(cap, int(n_s * budget / max(t, 1e-3)))
+            t, ref, inp = sample(K_s, n_s, method)
         return t, n_s, ref, inp
 
     def gate(ref, inp):   # parity gate on the sample problem
