@@ -182,6 +182,7 @@ struct grape_handle {
     unsigned *d_coop = nullptr;  // [2][K] step counters of the cooperative sweeps (forward, backward)
     int coop_S = 0;              // workgroups per trajectory in the cooperative sweeps (0: one-workgroup kernel)
     int coop_rpw = 0, coop_nw = 0;  // rows per wave and waves of a cooperative workgroup (R = nw * rpw state rows)
+    int coop_S_fw = 0, coop_rpw_fw = 0, coop_nw_fw = 0;   // the forward sweep's own split (GRAPE_COOP_S_FW; default: fewer siblings, see grape_create)
     // state running cost (g_b = <Psi|D|Psi>): transposed D, trapezoid weights, xi and g per stored state
     double2 *d_Dt = nullptr, *d_xi = nullptr;
     double *d_wq = nullptr, *d_gb = nullptr;
@@ -2044,6 +2045,17 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
             h->coop_S = S;
             h->coop_nw = R >= 16 ? 16 : R;
             h->coop_rpw = R / h->coop_nw;
+            // the two directions have different optima (round 5, C5 shard, forward / backward ms by siblings: 32: 8.5 / 9.6,
+            // 16: 7.3 / 11.1, 8: 10.2 / 11.0, 4: 15.3 / -): a step is a latency chain whose length grows with the siblings that
+            // have to meet; the forward slice is whole rows (a wave sum per row), the backward one columns (tools/coop_s.sh)
+            int Sf = S == 32 ? 16 : S, Sb = S;
+            if (const char *e_ = getenv("GRAPE_COOP_S_FW")) Sf = atoi(e_);
+            if (const char *e_ = getenv("GRAPE_COOP_S_BW")) Sb = atoi(e_);
+            auto valid = [&](int s_) { return s_ >= 2 && s_ <= S && (s_ & (s_ - 1)) == 0 && h->NP / s_ <= 64; };
+            if (!valid(Sf)) Sf = S;
+            if (!valid(Sb)) Sb = S;
+            h->coop_S = Sb; h->coop_nw = h->NP / Sb >= 16 ? 16 : h->NP / Sb; h->coop_rpw = (h->NP / Sb) / h->coop_nw;
+            h->coop_S_fw = Sf; h->coop_nw_fw = h->NP / Sf >= 16 ? 16 : h->NP / Sf; h->coop_rpw_fw = (h->NP / Sf) / h->coop_nw_fw;
             CCHK(dmalloc(&h->d_coop, (size_t)2 * K));
         }
     }
@@ -2269,8 +2281,8 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         case 64: e = launch_sweep<64>(sa, false, s); break;
         default:
             if (h->coop_S)
-                e = h->NP == 128 ? launch_coop<2>(sa, false, h->coop_S, h->coop_rpw, h->coop_nw, h->d_coop, s)
-                                 : launch_coop<4>(sa, false, h->coop_S, h->coop_rpw, h->coop_nw, h->d_coop, s);
+                e = h->NP == 128 ? launch_coop<2>(sa, false, h->coop_S_fw, h->coop_rpw_fw, h->coop_nw_fw, h->d_coop, s)
+                                 : launch_coop<4>(sa, false, h->coop_S_fw, h->coop_rpw_fw, h->coop_nw_fw, h->d_coop, s);
             else {
                 hipLaunchKernelGGL((sweep_lg_kernel<false>), dim3(sa.K), dim3(1024), 0, s, sa, h->NP);
                 e = hipGetLastError();
