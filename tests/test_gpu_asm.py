@@ -514,3 +514,16 @@ def test_general_matrix_assembly_cell_follows_generator_classes(g):
     assert np.abs(a[3] - b[3]).max() < 2e-14 * max(1.0, np.abs(b[3]).max())
     assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(b[0])) and np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
     assert a[4]["t18_mfma_flop"] == 4.0 * (962.0 * 14 + 192.0 * a[4]["t18_squarings"]) * 2048.0      # no carried states
+
+
+@pytest.mark.parametrize("N", [64, 40, 100])
+def test_a_hermitian_generator_that_is_not_finite_is_an_error_not_a_hang(g, N):
+    """(round 5: the host-side balancing used to spin forever on a NaN -- every comparison false)"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, 2, 5, 2, seed=4)
+    pr["H0"] = pr["H0"].copy()
+    pr["H0"][1, 3, 4] = np.nan
+    pr["H0"][1, 4, 3] = np.nan
+    with pytest.raises(g.GrapeHipError):
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+            h.eval(pr["pulsevals"])
