@@ -172,6 +172,7 @@ class Gen:
         self.s_H0, self.s_Sf, self.s_dts, self.s_U = S(4, 2), S(6, 2), S(8, 2), S(10, 2)
         self.s_verdict, self.s_rep = S(12, 2), S(14, 2)
         self.s_KC, self.s_NT = S(16), S(17)
+        self.s_scell = S(16)                                             # (behind the prologue: 1 = the summed controls are per CELL -- control operators per trajectory)
         # scaling and squaring around the four products (round 5): the cell exponentiates A / 2^s and squares the result s
         # times; s comes per cell from the plan of the evaluation (t16_plan_kernel -> splan[cell]).  s18 / s19 held nblk and
         # wave >> 1 (prologue only / recomputed where it is used)
@@ -388,6 +389,7 @@ class Gen:
         p.salu("s_mov_b32", self.s_pm, 0)
         if not self.diag:
             p.s_load(2, self.s_splan, self.s_karg, 128)
+        p.s_load(1, self.s_scell, self.s_karg, 124)                      # (s_KC is dead: ncell has been formed)
         # (kc, n) of the first cell: restoring division, 32 steps
         q, r, i = self.s_kc, self.s_n, t0
         p.salu("s_mov_b32", q, 0)
@@ -449,8 +451,16 @@ class Gen:
         p.s_load(1, self.s_k, self.s_t0, t0)
         p.salu("s_lshl_b32", t0, n, 3)
         p.s_load(2, self.s_dt, self.s_dts, t0)
-        p.salu("s_lshl_b32", t0, n, 16)                                  # n * 2 NP^2 * 8 = n << 16
-        p.salu("s_lshr_b32", t1, n, 16)
+        self.s_base(n, cell)
+
+    def s_base(self, n, cell):
+        """s_sb = Sf + (summed controls per cell ? cell : n) * 2 NP^2 * 8 (<< 16)"""
+        p = self.p
+        t0, t1 = self.s_tmp[0], self.s_tmp[1]
+        p.s_cmp("s_cmp_lg_u32", self.s_scell, 0)
+        p.salu("s_cselect_b32", t1, cell, n)
+        p.salu("s_lshl_b32", t0, t1, 16)
+        p.salu("s_lshr_b32", t1, t1, 16)
         p.salu("s_add_u32", self.s_sb.sub(0), self.s_Sf.sub(0), t0)
         p.salu("s_addc_u32", self.s_sb.sub(1), self.s_Sf.sub(1), t1)
 

@@ -77,10 +77,7 @@ class GenG(g16.Gen):
         p.s_load(1, self.s_k, self.s_t0, t0)
         p.salu("s_lshl_b32", t0, n, 3)
         p.s_load(2, self.s_dt, self.s_dts, t0)
-        p.salu("s_lshl_b32", t0, n, 16)
-        p.salu("s_lshr_b32", t1, n, 16)
-        p.salu("s_add_u32", self.s_sb.sub(0), self.s_Sf.sub(0), t0)
-        p.salu("s_addc_u32", self.s_sb.sub(1), self.s_Sf.sub(1), t1)
+        self.s_base(n, cell)
 
     def cell_bases_finish(self, kc):
         p = self.p

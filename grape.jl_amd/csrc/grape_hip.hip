@@ -1911,10 +1911,20 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     CCHK(dmalloc(&h->d_f, 2)); CCHK(dmalloc(&h->d_rho, (size_t)K));
     CCHK(dmalloc(&h->d_cellflag, (size_t)K * N_T));
     // more than two controls shared by all trajectories: the cell fetches H0_k and ONE summed operator S_n (ctrl_sum_kernel)
-    h->asm16 = h->asm16 && h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT == 4 && !p->hc_per_traj && (long)K * N_T < (1L << 28);
-    h->asm18g = h->asm18g && h->t18 && !h->herm && !h->large && !h->series && h->NT == 4 && !p->hc_per_traj && (long)K * N_T < (1L << 28);
-    if (h->t18 && !h->large && !h->series && (L > 2 || h->asm16 || h->asm18g) && !p->hc_per_traj && (h->NT >= 3 || h->t18_small))
-        CCHK(dmalloc(&h->d_Sf, (size_t)N_T * 2 * NP * NP));
+    // control operators per trajectory (the ensemble of robustness problems): the summed controls are an array per CELL of the
+    // generator classes -- as large as the propagators themselves -- when that fits; the assembly cells then apply as they are
+    bool sf_per_cell_ok = false;
+    if (p->hc_per_traj && h->t18 && !h->large && !h->series && h->NT == 4) {
+        size_t free_b = 0, total_b = 0;
+        CCHK(hipMemGetInfo(&free_b, &total_b));
+        const char *envs = getenv("GRAPE_SF_PER_CELL");
+        sf_per_cell_ok = !(envs && atoi(envs) == 0) && 2.0 * (double)h->KC * N_T * NP * NP * 16.0 + 8e9 < (double)free_b;
+    }
+    const bool sf_shape_ok = !p->hc_per_traj || sf_per_cell_ok;
+    h->asm16 = h->asm16 && h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT == 4 && sf_shape_ok && (long)K * N_T < (1L << 28);
+    h->asm18g = h->asm18g && h->t18 && !h->herm && !h->large && !h->series && h->NT == 4 && sf_shape_ok && (long)K * N_T < (1L << 28);
+    if (h->t18 && !h->large && !h->series && ((L > 2 && !p->hc_per_traj) || h->asm16 || h->asm18g) && (h->NT >= 3 || h->t18_small))
+        CCHK(dmalloc(&h->d_Sf, (size_t)(p->hc_per_traj ? (size_t)h->KC * N_T : (size_t)N_T) * 2 * NP * NP));
     if (h->asm16 || h->asm18g) {
         // one workgroup per CU (512 registers, 139 KB of LDS), never more workgroups than cells
         const long ncell = (long)h->KC * N_T;
@@ -2146,7 +2156,8 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                     CtrlSumArgs ca{};
                     ca.Hcf = h->d_Hcf; ca.eps = h->d_eps; ca.shape = h->d_shape; ca.Sf = h->d_Sf;
                     ca.L = h->L; ca.N_T = h->N_T; ca.pp2 = 2 * h->NP * h->NP;
-                    hipLaunchKernelGGL(ctrl_sum_kernel, dim3(h->N_T, std::max(1, ca.pp2 / 2 / 2048)), dim3(256), 0, s, ca);
+                    ca.per_traj = h->p.hc_per_traj ? 1 : 0; ca.rep = h->d_rep;
+                    hipLaunchKernelGGL(ctrl_sum_kernel, dim3((unsigned)((ca.per_traj ? h->KC : 1) * h->N_T), std::max(1, ca.pp2 / 2 / 2048)), dim3(256), 0, s, ca);
                     HIPCHK(h, hipGetLastError());
                     ea.Sf = h->d_Sf;
                 }

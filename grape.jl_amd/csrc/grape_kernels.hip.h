@@ -148,14 +148,19 @@ struct CtrlSumArgs {
     const double *Hcf, *eps, *shape;
     double *Sf;
     int L, N_T, pp2;   // pp2 = 2 NP^2 doubles per operator
+    // control operators per trajectory (round 5): one block per CELL of the generator classes, grid.x = KC N_T; block kc N_T + n
+    // sums the operators of the representative trajectory of class kc
+    int per_traj;
+    const int *rep;
 };
 // (grid: N_T x parts -- a workgroup per step walked 256 dependent-latency iterations per thread at NP = 256: 0.86 ms per
 // evaluation of a C5 shard; with one part per 2048 element pairs the launch is bound by what it writes)
 __global__ void __launch_bounds__(256) ctrl_sum_kernel(CtrlSumArgs a) {
-    const int n = blockIdx.x;
+    const int blk = blockIdx.x, kc = a.per_traj ? blk / a.N_T : 0, n = blk - kc * a.N_T;
+    if (a.per_traj) a.Hcf += (size_t)(a.rep ? a.rep[kc] : kc) * a.L * a.pp2;
     double e[8];
     for (int l = 0; l < a.L; ++l) e[l] = a.eps[(size_t)l * a.N_T + n] * (a.shape ? a.shape[(size_t)l * a.N_T + n] : 1.0);
-    double2 *dst = (double2 *)(a.Sf + (size_t)n * a.pp2);
+    double2 *dst = (double2 *)(a.Sf + (size_t)blk * a.pp2);
 #pragma unroll 4
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < a.pp2 / 2; i += gridDim.y * blockDim.x) {
         double2 acc = make_double2(0., 0.);

@@ -115,7 +115,7 @@ struct T16AsmArgs {           // kernel argument block of expm_t16_asm (gen_t16.
     const double2 *xinit;       // [2][K][64]: Psi0_k; conj(target_k) / ||target_k||
     double2 *fw, *bw;           // [K][N_T + 1][64] stored states
     int *prog;                  // [2][K] steps each end of each trajectory was propagated by the walks
-    int K, pad0;
+    int K, s_per_cell;          // s_per_cell: Sf is [KC][N_T] (control operators per trajectory) instead of [N_T]
     const int *splan;           // [KC * N_T] squarings planned per cell (t16_plan_kernel): the cell exponentiates A / 2^s
 };
 static_assert(sizeof(T16AsmArgs) == 136, "argument block of the assembly kernel");
@@ -124,7 +124,7 @@ static_assert(sizeof(T16AsmArgs) == 136, "argument block of the assembly kernel"
 __device__ __forceinline__ double t16_post_norm1(const ExpmArgs &a, const int cell, double *red, const int tid) {
     constexpr int NP = 64;
     const int kc = cell / a.N_T, n = cell - kc * a.N_T, k = a.rep ? a.rep[kc] : kc;
-    const double *h0 = a.H0f + (size_t)k * 2 * NP * NP, *sn = a.Sf + (size_t)n * 2 * NP * NP;
+    const double *h0 = a.H0f + (size_t)k * 2 * NP * NP, *sn = a.Sf + (size_t)(a.hc_per_traj ? cell : n) * 2 * NP * NP;
     const double dt = a.dts[n];
     const int j = tid & 63, part = tid >> 6;
     double sum = 0.;
@@ -421,7 +421,7 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
-    if (!a.Sf || a.hc_per_traj || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
+    if (!a.Sf || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
     if (fuse && (!walk[1] || !walk[2] || !walk[3] || !walk[4] || a.rep || K != a.K)) return (int)hipErrorInvalidValue;
     const long ncell = (long)a.K * a.N_T;
     if (ncell <= 0 || ncell >= (1L << 28)) return (int)hipErrorInvalidValue;   // (32-bit cell arithmetic in the kernel)
@@ -436,6 +436,7 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
     k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks; k.flags = a.flags;
     k.fuse = fuse; k.wgtab = (const int *)walk[0]; k.xinit = (const double2 *)walk[1]; k.fw = (double2 *)walk[2];
     k.bw = (double2 *)walk[3]; k.prog = (int *)walk[4]; k.K = K; k.splan = (const int *)walk[5];
+    k.s_per_cell = a.hc_per_traj ? 1 : 0;
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     hipStream_t s = (hipStream_t)stream;
@@ -480,7 +481,7 @@ extern "C" int grape_t18g_asm_launch(const void *args, size_t args_size, int *ve
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
-    if (!a.Sf || a.hc_per_traj || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
+    if (!a.Sf || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
     if (fuse && (!walk[1] || !walk[2] || !walk[3] || !walk[4] || a.rep || K != a.K)) return (int)hipErrorInvalidValue;
     const long ncell = (long)a.K * a.N_T;
     if (ncell <= 0 || ncell >= (1L << 28)) return (int)hipErrorInvalidValue;
@@ -495,6 +496,7 @@ extern "C" int grape_t18g_asm_launch(const void *args, size_t args_size, int *ve
     k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks; k.flags = a.flags;
     k.fuse = fuse; k.wgtab = (const int *)walk[0]; k.xinit = (const double2 *)walk[1]; k.fw = (double2 *)walk[2];
     k.bw = (double2 *)walk[3]; k.prog = (int *)walk[4]; k.K = K; k.splan = (const int *)walk[5];
+    k.s_per_cell = a.hc_per_traj ? 1 : 0;
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     hipStream_t s = (hipStream_t)stream;

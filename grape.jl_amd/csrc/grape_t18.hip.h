@@ -322,7 +322,7 @@ struct T18FormA {
         const int k = a.rep ? a.rep[kc] : kc;
         const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
         // (a.Sf: the controls of this time step are already summed -- ONE "control" with coefficient 1, see ExpmArgs)
-        const double2 *hc = a.Sf ? (const double2 *)(a.Sf + (size_t)(cell - kc * a.N_T) * 2 * NP * NP)
+        const double2 *hc = a.Sf ? (const double2 *)(a.Sf + (size_t)(a.hc_per_traj ? cell : cell - kc * a.N_T) * 2 * NP * NP)   // (per-trajectory control operators: summed per CELL)
                                  : (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
         const size_t o1 = (a.L > 1 && !a.Sf) ? (size_t)2 * HALF : 0;   // (one control: the same tile again, unused)
 #pragma unroll
@@ -389,7 +389,7 @@ __device__ __forceinline__ void t18_form_a_general(const ExpmArgs &a, double *R,
     const int kc = cell / a.N_T, n = cell - kc * a.N_T;
     const int k = a.rep ? a.rep[kc] : kc;
     const double2 *h0 = (const double2 *)(a.H0f + (size_t)k * 2 * NP * NP);
-    const double2 *hc = a.Sf ? (const double2 *)(a.Sf + (size_t)n * 2 * NP * NP)
+    const double2 *hc = a.Sf ? (const double2 *)(a.Sf + (size_t)(a.hc_per_traj ? cell : n) * 2 * NP * NP)
                              : (const double2 *)(a.Hcf + (size_t)(a.hc_per_traj ? k : 0) * a.L * 2 * NP * NP);
     const int L = a.Sf ? 1 : a.L;   // (summed controls: one "control" with coefficient 1)
     const size_t o1 = L > 1 ? (size_t)2 * HALF : 0;

@@ -56,7 +56,7 @@ def t16_walks(KC, N_T, nblk):
 
 
 def run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, rep=None, skipped_cells=0, fuse=0, psi0=None, chiT=None, want_state=False,
-               splan=None):
+               splan=None, s_per_cell=0):
     g = gcn.GlobalMem()
     a_H0, _ = g.add("H0f", H0f)
     a_Sf, _ = g.add("Sf", Sf)
@@ -78,7 +78,7 @@ def run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, rep=None, skipped_cells=0, fus
     a_pg, prog_ = g.add("prog", np.zeros((2, KC), np.int32))
     a_sp, _ = g.add("splan", np.zeros(KC * N_T, np.int32) if splan is None else np.asarray(splan, np.int32))
     karg = struct.pack("<QQQQQQiiiiQQQQQQQiiQ", a_H0, a_Sf, a_dt, a_U, a_v, a_rep, KC, N_T, nblk, fuse, 0, a_f,
-                       a_tab, a_xi, a_fw, a_bw, a_pg, KC, 0, a_sp)
+                       a_tab, a_xi, a_fw, a_bw, a_pg, KC, s_per_cell, a_sp)
     assert len(karg) == gen_t16.KERNARG
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     stats = {"instr": 0, "mfma": 0}
@@ -287,3 +287,17 @@ def test_scaling_and_squaring_around_the_four_products(program):
         assert np.abs(fw[0, n + 1] - x).max() < 2e-14 * np.abs(x).max()
     # executed matrix instructions: 697 per cell and wave, 192 per squaring, 2 per carried step
     assert stats["mfma"] == 4 * (697 * 6 + 192 * (1 + 2 + 1) + 2 * (3 + 1))
+
+
+def test_summed_controls_per_cell(program):
+    """control operators per trajectory: the summed controls are an array per CELL ([KC][N_T], flag in the argument block) --
+    the cell reads block kc N_T + n instead of block n"""
+    _, prog, _ = program
+    N, KC, N_T, nblk = 64, 2, 3, 3
+    H0, Sn, dts, H0f, Sf = make_inputs(N, KC, KC * N_T, seed=77)            # KC N_T different summed controls
+    dts = dts[:N_T]
+    U, verdict, stats = run_kernel(prog, H0f, Sf, dts, KC, N_T, nblk, s_per_cell=1)
+    for kc in range(KC):
+        for n in range(N_T):
+            ref = scipy.linalg.expm(-1j * dts[n] * (H0[kc] + Sn[kc * N_T + n]))
+            assert np.abs(U[kc * N_T + n] - ref).max() < 2e-15, (kc, n)

@@ -41,7 +41,7 @@ def make_general(N, KC, N_T, seed, scale=1.0):
     return H0, Sn, dts, H0f, Sf
 
 
-def run(prog, H0f, Sf, dts, KC, N_T, nblk, fuse=0, psi0=None, chiT=None):
+def run(prog, H0f, Sf, dts, KC, N_T, nblk, fuse=0, psi0=None, chiT=None, s_per_cell=0):
     g = gcn.GlobalMem()
     a_H0, _ = g.add("H0f", H0f)
     a_Sf, _ = g.add("Sf", Sf)
@@ -60,7 +60,7 @@ def run(prog, H0f, Sf, dts, KC, N_T, nblk, fuse=0, psi0=None, chiT=None):
     a_pg, prog_ = g.add("prog", np.zeros((2, KC), np.int32))
     a_sp, splan = g.add("splan", np.full(KC * N_T, -1, np.int32))
     karg = struct.pack("<QQQQQQiiiiQQQQQQQiiQ", a_H0, a_Sf, a_dt, a_U, a_v, 0, KC, N_T, nblk, fuse, 0, a_f,
-                       a_tab, a_xi, a_fw, a_bw, a_pg, KC, 0, a_sp)
+                       a_tab, a_xi, a_fw, a_bw, a_pg, KC, s_per_cell, a_sp)
     assert len(karg) == gen_t16.KERNARG
     a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
     mf = 0
@@ -168,3 +168,16 @@ def test_a_generator_that_is_not_finite_is_flagged(program):
     H0f[0, 0, 3, 5] = np.inf
     U, verdict, splan, mf, _, _, _ = run(prog, H0f, Sf, dts, 1, 2, 1)
     assert (verdict == 2).all() and (splan == 0).all()
+
+
+def test_summed_controls_per_cell(program):
+    """control operators per trajectory: the cell reads block kc N_T + n of the summed controls"""
+    _, prog, _ = program
+    N, KC, N_T = 64, 2, 2
+    H0, Sn, dts, H0f, Sf = make_general(N, KC, KC * N_T, seed=5, scale=0.6)
+    dts = dts[:N_T]
+    U = run(prog, H0f, Sf, dts, KC, N_T, 2, s_per_cell=1)[0]
+    for kc in range(KC):
+        for n in range(N_T):
+            ref = scipy.linalg.expm(-1j * dts[n] * (H0[kc] + Sn[kc * N_T + n]))
+            assert np.abs(U[kc * N_T + n] - ref).max() < 5e-15 * max(1.0, np.abs(ref).max()), (kc, n)
