@@ -428,6 +428,20 @@ class Gen:
             p.valu("v_cndmask_b32", self.v_UO[r_], vidx, vpc, VCC)
         self.vp.free(t)
 
+    # ---- the operator tiles of the next cell (hooks of the variant with control operators per trajectory, gen_t16p.py) ----
+    early_free = False      # True: A and the parked A2 are released behind the first k-block of the last product (pf_late)
+
+    def pf_alloc(self):
+        return [self.ap.alloc(2) for _ in range(5)]
+
+    def pf_late(self, pf):
+        pass
+
+    def fetch_plan(self, pf, ki):
+        # two 16-byte loads per lane and k-step, k-steps 4..13: operator tiles u of the next cell
+        if 0 <= ki < 10:
+            self.fetch(ki // 2, pf[ki // 2], half=ki % 2)
+
     def load_constants(self):
         for i in range(1, 16):
             self.smov64(self.s_c[i], self.c[f"C{i}"])
@@ -1072,26 +1086,30 @@ class Gen:
                 for r in range(4):
                     p.valu("v_add_f64", Bsm[sl].d(r), Bre[sl].d(r), Bim[sl].d(r))
 
-        pf = [ap.alloc(2) for _ in range(5)]
+        pf = self.pf_alloc()
 
         def hook_fetch(sk, r):
-            # two 16-byte loads per lane and k-step, k-steps 4..13: operator tiles u of the next cell
-            ki = 4 * sk + r - 4
-            if 0 <= ki < 10:
-                self.fetch(ki // 2, pf[ki // 2], half=ki % 2)
+            # operator tiles of the next cell, from k-step 4 on (behind the first k-block: see pf_late)
+            self.fetch_plan(pf, 4 * sk + r - 4)
+
+        def post4():
+            bsm([1, 2, 3])
+            self.pf_late(pf)
 
         self.product(Qt, [Bre, Bim, Bsm], init=init13, hook=hook_fetch,
                      fused={"valu": valu4, "stores": lambda sl: self.plane_stores(sl, Bsm[sl], Qt[sl][1], tt[0]),
-                            "after_first": lambda: bsm([0]), "post": lambda: bsm([1, 2, 3])})
+                            "after_first": lambda: bsm([0]), "post": post4})
         for t in tt:
             vp.free(t)
-        ap.free(self.A2p_re)
-        ap.free(self.A2p_im)
+        if not self.early_free:
+            ap.free(self.A2p_re)
+            ap.free(self.A2p_im)
         for t in Bre + Bim + Bsm:
             vp.free(t)
         self.stamp(9)
-        ap.free(self.As_re)
-        ap.free(self.As_im)
+        if not self.early_free:
+            ap.free(self.As_re)
+            ap.free(self.As_im)
         # ---- result, interleaved (re, im) per element: the layout of the 16-byte stores ----
         Un = vp.alloc(8, at=self.UT)
         uid = len(p.ins)
