@@ -172,6 +172,16 @@ __global__ void __launch_bounds__(256) ctrl_sum_kernel(CtrlSumArgs a) {
     }
 }
 
+// table of expm_t16p_asm (control operators per trajectory, asm/gen_t16p.py): row n = dt_n, e1_n, e2_n, 0 with e_l = eps_ln shape_ln
+__global__ void __launch_bounds__(256) dte_kernel(const double *eps, const double *shape, const double *dts, int L, int N_T, double *out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N_T) return;
+    out[4 * n] = dts[n];
+    out[4 * n + 1] = eps[n] * (shape ? shape[n] : 1.0);
+    out[4 * n + 2] = L > 1 ? eps[(size_t)N_T + n] * (shape ? shape[(size_t)N_T + n] : 1.0) : 0.0;
+    out[4 * n + 3] = 0.0;
+}
+
 // A column strip of an NP x NP complex matrix held by one wave in MFMA C/D layout:
 // lane l holds rows 16*t + 4*r + (l>>4) (t = row tile, r = register) of column 16*w + (l&15).
 // Register r of tile t is also exactly the B operand of k-step k0 = 16*t + 4*r.

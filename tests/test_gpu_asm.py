@@ -529,41 +529,50 @@ def test_a_hermitian_generator_that_is_not_finite_is_an_error_not_a_hang(g, N):
             h.eval(pr["pulsevals"])
 
 
-@pytest.mark.parametrize("herm", [True, False], ids=["hermitian", "general"])
-def test_control_operators_per_trajectory_take_the_assembly_cells(g, herm):
-    """Round 5: with control operators per trajectory (the ensemble of a robustness problem) the controls of every CELL are
-    summed once per evaluation ([KC][N_T] blocks) and the assembly cells read block kc N_T + n: same results as the compiled
-    kernels (GRAPE_SF_PER_CELL=0), which read the L operators of the trajectory; generator classes share their blocks."""
+@pytest.mark.parametrize("herm,L", [(True, 2), (True, 1), (True, 3), (False, 2)], ids=["hermitian_L2", "hermitian_L1", "hermitian_L3", "general"])
+def test_control_operators_per_trajectory_take_the_assembly_cells(g, herm, L):
+    """Round 5: control operators per trajectory (the ensemble of a robustness problem).  Hermitian generators with one or two
+    controls: expm_t16p_asm fetches the operators of its trajectory itself (work[14] = 3).  More controls, or general
+    matrices: the controls of every CELL are summed once per evaluation ([KC][N_T] blocks) and the assembly cells read block
+    kc N_T + n.  Same results as the compiled kernels on the L operators of the trajectory (all switches off); generator
+    classes share propagators (and blocks)."""
     from grape_jl_amd import synth
-    N, L, N_T, K = 64, 2, 11, 4
-    pr = synth.make_problem(N, L, N_T, K, seed=71, hermitian=herm)
+    N, N_T, K = 64, 11, 4
+    pr = synth.make_problem(N, L, N_T, K, seed=71 + L, hermitian=herm)
     rng = np.random.default_rng(2)
     Hc = np.stack([pr["Hc"] * (1.0 + 0.1 * rng.standard_normal()) for _ in range(K)])
     Hc[3] = Hc[1]
     H0 = pr["H0"].copy()
     H0[3] = H0[1]                                     # trajectories 1 and 3: one generator class
+    modes = {"default": {}, "summed": {"GRAPE_EXPM_ASM16P": "0"}, "compiled": {"GRAPE_EXPM_ASM16P": "0", "GRAPE_SF_PER_CELL": "0"}}
     out = {}
-    old = os.environ.get("GRAPE_SF_PER_CELL")
-    try:
-        for flag in ("1", "0"):
-            os.environ["GRAPE_SF_PER_CELL"] = flag
+    for name, env in modes.items():
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
             with g.GrapeHip(H0, Hc, pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
                 J, G, tau = h.eval(pr["pulsevals"])
                 J2, G2, _ = h.eval(pr["pulsevals"])
                 assert J == J2 and np.array_equal(G, G2)
                 U = np.stack([h.propagator(k, n) for k in range(K) for n in range(N_T)])
-                out[flag] = (J, G.copy(), tau.copy(), U, h.work())
-    finally:
-        if old is None:
-            os.environ.pop("GRAPE_SF_PER_CELL", None)
-        else:
-            os.environ["GRAPE_SF_PER_CELL"] = old
-    a, b = out["1"], out["0"]
-    assert a[4]["asm_kernel"] == (1.0 if herm else 2.0) and b[4]["asm_kernel"] == 0.0
-    assert a[4]["expm_cells"] == 3 * N_T == b[4]["expm_cells"]
-    assert np.abs(a[3] - b[3]).max() < 2e-14 * max(1.0, np.abs(b[3]).max())
-    assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(b[0])) and np.abs(a[2] - b[2]).max() <= 1e-12 * max(1.0, np.abs(b[2]).max())
-    assert np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
+                out[name] = (J, G.copy(), tau.copy(), U, h.work())
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    want = 3.0 if (herm and L <= 2) else (1.0 if herm else 2.0)
+    assert out["default"][4]["asm_kernel"] == want
+    assert out["summed"][4]["asm_kernel"] == (1.0 if herm else 2.0) and out["compiled"][4]["asm_kernel"] == 0.0
+    b = out["compiled"]
+    for name in ("default", "summed"):
+        a = out[name]
+        assert a[4]["expm_cells"] == 3 * N_T == b[4]["expm_cells"]
+        assert np.abs(a[3] - b[3]).max() < 2e-14 * max(1.0, np.abs(b[3]).max()), name
+        assert abs(a[0] - b[0]) <= 1e-12 * max(1.0, abs(b[0])) and np.abs(a[2] - b[2]).max() <= 1e-12 * max(1.0, np.abs(b[2]).max())
+        assert np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
+    a = out["default"]
     for k, n in [(0, 0), (3, N_T - 1)]:
         e = pr["pulsevals"].reshape(L, N_T)[:, n]
         H = H0[k] + sum(e[l] * Hc[k, l] for l in range(L))

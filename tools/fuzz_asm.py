@@ -8,7 +8,7 @@ import grape_jl_amd as g
 from grape_jl_amd import synth
 
 OFF = {"GRAPE_EXPM_ASM": "0", "GRAPE_DERIV3_ASM": "0", "GRAPE_DERIV3S": "0", "GRAPE_DERIV3G": "0", "GRAPE_LG_ASM": "0", "GRAPE_DERIV4": "0",
-       "GRAPE_LG_FORM2": "0", "GRAPE_GRAPH": "0", "GRAPE_EXPM_ASM18G": "0"}   # (walks, in-cell squarings and the fused combinations exist in the assembly kernels only)
+       "GRAPE_LG_FORM2": "0", "GRAPE_GRAPH": "0", "GRAPE_EXPM_ASM18G": "0", "GRAPE_EXPM_ASM16P": "0", "GRAPE_SF_PER_CELL": "0"}   # (walks, in-cell squarings and the fused combinations exist in the assembly kernels only)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 worst = 0.0
