@@ -147,6 +147,23 @@ class Trajectory:
     generator: Generator
     target_state: Optional[np.ndarray] = None
     weight: float = 1.0
+    # per-step propagation callbacks (the `callback` / `observables` propagation keyword arguments of a trajectory, called at
+    # src/optimize.jl:733-737 forward, :882-887 and :973-978 backward): `prop_callback(propagator, observables)` is called
+    # once per time step with a PropagatorView.  On the HIP path the steps do not run on the host: the calls are synthesised
+    # AFTER the sweep from the stored states (grape_get_storage), in the reference's order
+    prop_callback: Optional[Callable] = None
+    prop_observables: object = None
+
+
+@dataclass
+class PropagatorView:
+    """what a propagation callback sees of the propagator (QuantumPropagators' `propagator.state`, `.t`, `.tlist`, `.backward`)"""
+    state: np.ndarray
+    t: float
+    tlist: np.ndarray
+    n: int                 # index into tlist of the time point just reached
+    k: int                 # trajectory
+    backward: bool = False
 
 
 def get_controls(trajectories):
@@ -275,6 +292,8 @@ class GrapeWrk:
             self.pulsevals_guess = self.pulsevals.copy()
             prev.start_local_time = prev.end_local_time = time.time()
             self.backend = backend if backend is not None else self._make_hip_backend()
+            if any(t.prop_callback is not None for t in self.trajectories) and hasattr(self.backend, "set_fused_sweeps"):
+                self.backend.set_fused_sweeps(False)
             return
         self.result = GrapeResult(tlist=self.tlist.copy(), iter_start=self.kwargs.get("iter_start", 0),
                                   iter_stop=self.kwargs.get("iter_stop", 5000))
@@ -285,6 +304,8 @@ class GrapeWrk:
         self.result.states = [np.zeros_like(t.initial_state, dtype=np.complex128) for t in self.trajectories]
         self.result.start_local_time = self.result.end_local_time = time.time()
         self.backend = backend if backend is not None else self._make_hip_backend()
+        if any(t.prop_callback is not None for t in self.trajectories) and hasattr(self.backend, "set_fused_sweeps"):
+            self.backend.set_fused_sweeps(False)     # (the callbacks see the backward states of the reference: see _propagation_callbacks)
 
     def _make_hip_backend(self):
         J_T = self.kwargs["J_T"]
@@ -458,6 +479,23 @@ def _split_functional(wrk, J, tau):
     wrk.J_parts[2] = float(J - J_T) if on else 0.0
 
 
+def _propagation_callbacks(wrk, backward):
+    """the per-step callbacks of the trajectories (src/optimize.jl:733-737; :882-887 / :973-978), from the stored states: forward
+    after every step n = 1 .. N_T with Psi_k(t_n); backward after every step n = N_T .. 1 with chi_k(t_(n-1)) (normalised as the
+    backward propagator holds it, src/optimize.jl:867-868).  The backend runs its sweeps one after the other while callbacks
+    are registered (the concurrent backward sweep starts from unit targets: other states)."""
+    if not any(t.prop_callback is not None for t in wrk.trajectories):
+        return
+    st = wrk.backend.storage(1 if backward else 0)
+    N_T = wrk.N_T
+    for k, traj in enumerate(wrk.trajectories):
+        if traj.prop_callback is None:
+            continue
+        steps = range(N_T - 1, -1, -1) if backward else range(1, N_T + 1)
+        for n in steps:
+            traj.prop_callback(PropagatorView(np.array(st[k, n]), float(wrk.tlist[n]), wrk.tlist, n, k, backward), traj.prop_observables)
+
+
 def evaluate_functional(pulsevals, wrk: GrapeWrk, count_call=True):
     """src/optimize.jl:696-768 (side effects on wrk as documented there)."""
     if pulsevals is not wrk.pulsevals:
@@ -466,6 +504,7 @@ def evaluate_functional(pulsevals, wrk: GrapeWrk, count_call=True):
         wrk.result.f_calls += 1
         wrk.fg_count[1] += 1
     J, _, tau, psiT = wrk.backend.eval(wrk.pulsevals, gradient=False, want_psiT=True)
+    _propagation_callbacks(wrk, backward=False)
     wrk.result.tau_vals[:] = tau
     wrk._states = psiT
     _split_functional(wrk, J, tau)
@@ -482,6 +521,8 @@ def evaluate_gradient_b(G, pulsevals, wrk: GrapeWrk):
     wrk.result.fg_calls += 1
     wrk.fg_count[0] += 1
     J, g, tau, psiT = wrk.backend.eval(wrk.pulsevals, gradient=True, want_psiT=True)
+    _propagation_callbacks(wrk, backward=False)
+    _propagation_callbacks(wrk, backward=True)
     wrk.result.tau_vals[:] = tau
     wrk._states = psiT
     _split_functional(wrk, J, tau)

@@ -272,3 +272,35 @@ def test_pulse_optimization_does_not_mutate_the_guess_and_convergence_checks():
     assert res.records[-1][0] == res.iter and abs(res.records[-1][1] - res.J_T) < 1e-15
     res = G.optimize(trajs, tlist, J_T=G.J_T_ss, iter_stop=2, check_convergence=lambda r: "never" if r.J_T < -1 else "")
     assert res.converged and res.iter == 2 and res.message == "Reached maximum number of iterations"
+
+
+def test_propagation_callbacks_on_the_hip_backend():
+    """per-step propagation callbacks (/root/reference/src/optimize.jl:733-737, 882-887, 973-978) through the HIP backend: synthesised
+    from the stored states after the sweeps; the states they see are the oracle's forward states and (normalised) backward
+    states, in the reference's order"""
+    import grape_oracle as go
+    from grape_jl_amd import grape as G
+    rng = np.random.default_rng(5)
+    N, N_T = 6, 12
+    X = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    H0 = (X + X.conj().T) / 4
+    Y = rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))
+    H1 = (Y + Y.conj().T) / 4
+    tlist = np.linspace(0, 3, N_T + 1)
+    psi0 = np.zeros(N, complex); psi0[0] = 1.0
+    tgt = np.zeros(N, complex); tgt[2] = 1.0
+    seen = []
+    traj = G.Trajectory(psi0, G.hamiltonian(H0, (H1, lambda t: 0.4 * np.cos(t))), target_state=tgt,
+                        prop_callback=lambda prop, obs: seen.append((prop.backward, prop.n, prop.state.copy())))
+    wrk = G.GrapeWrk([traj], tlist, J_T=G.J_T_sm)
+    Gout = np.zeros_like(wrk.pulsevals)
+    G.evaluate_gradient_b(Gout, wrk.pulsevals, wrk)
+    Jr, Gr, taur, parts = go.evaluate_gradient(H0[None], H1[None], tlist, wrk.pulsevals, psi0[None], tgt[None], return_parts=True)
+    assert np.abs(Gout - Gr).max() < 1e-12
+    fwd = [s for s in seen if not s[0]]
+    bwd = [s for s in seen if s[0]]
+    assert [s[1] for s in fwd] == list(range(1, N_T + 1)) and [s[1] for s in bwd] == list(range(N_T - 1, -1, -1))
+    for _, n, st in fwd:
+        assert np.abs(st - parts["storage"][0, n]).max() < 1e-13
+    for _, n, st in bwd:
+        assert np.abs(st - parts["chi"][0, n]).max() < 1e-13

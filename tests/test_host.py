@@ -184,3 +184,55 @@ def test_continue_from_previous_result():
     # intervals -> points -> midpoints is not the identity, so J_T is close to, not equal to, the last value
     assert abs(r2.records[n_rec][1] - J_mid) < 0.05 * J_mid and r2.records[n_rec][0] == 0
     assert [r[0] for r in r2.records[n_rec + 1:]] == [3, 4, 5]
+
+
+class OracleBackendWithStorage(OracleBackend):
+    """... that also keeps the stored states, as GrapeHip.storage hands them out"""
+
+    def eval(self, pulsevals, gradient=True, want_psiT=False):
+        H0, Hc, tl, p0, tg = self.a
+        if gradient:
+            J, g, tau, parts = go.evaluate_gradient(H0, Hc, tl, pulsevals, p0, tg, return_parts=True)
+            self.fw, self.bw = parts["storage"], np.concatenate([parts["chi"], parts["chi"][:, -1:]], axis=1)
+            psiT = parts["storage"][:, -1]
+        else:
+            J, tau, st = go.evaluate_functional(H0, Hc, tl, pulsevals, p0, tg)
+            self.fw, self.bw = st, None
+            g, psiT = None, st[:, -1]
+        return (J, g, tau, psiT) if want_psiT else (J, g, tau)
+
+    def storage(self, which=0):
+        return self.fw if which == 0 else self.bw
+
+    def set_fused_sweeps(self, on):
+        self.fused = on
+        return False
+
+
+def test_propagation_callbacks_are_synthesised_from_the_stored_states():
+    """per-step propagation callbacks (/root/reference/src/optimize.jl:733-737 forward, :882-887 / :973-978 backward): on the HIP path
+    the steps do not run on the host, the mirror calls `prop_callback(propagator, observables)` afterwards from the stored
+    states -- once per time step, in time order forward and in reverse order backward, with the state just reached"""
+    trajs, tl, _ = tls(lambda t: 0.3, nt=21)
+    seen = []
+    trajs[0].prop_callback = lambda prop, obs: seen.append((prop.backward, prop.n, prop.t, prop.state.copy(), obs))
+    trajs[0].prop_observables = "obs"
+    sz = np.array([[-0.5, 0], [0, 0.5]], complex)
+    sx = np.array([[0, 1], [1, 0]], complex)
+    be = OracleBackendWithStorage((sz[None], sx[None], tl, np.array([[1, 0]], complex), np.array([[0, 1]], complex)))
+    wrk = G.GrapeWrk(trajs, tl, backend=be, J_T=G.J_T_sm)
+    assert be.fused is False                                   # sequential sweeps while callbacks are registered
+    G.evaluate_functional(wrk.pulsevals, wrk)
+    N_T = len(tl) - 1
+    assert [s[1] for s in seen] == list(range(1, N_T + 1)) and not any(s[0] for s in seen) and all(s[4] == "obs" for s in seen)
+    assert all(abs(s[2] - tl[s[1]]) < 1e-15 for s in seen)
+    assert np.allclose(seen[-1][3], wrk._states[0]) and np.allclose(seen[3][3], be.fw[0, 4])
+    assert all(abs(np.linalg.norm(s[3]) - 1.0) < 1e-12 for s in seen)
+    seen.clear()
+    Gout = np.zeros_like(wrk.pulsevals)
+    G.evaluate_gradient_b(Gout, wrk.pulsevals, wrk)
+    fwd = [s for s in seen if not s[0]]
+    bwd = [s for s in seen if s[0]]
+    assert [s[1] for s in fwd] == list(range(1, N_T + 1)) and [s[1] for s in bwd] == list(range(N_T - 1, -1, -1))
+    assert seen.index(bwd[0]) > seen.index(fwd[-1])            # the backward calls follow the forward ones
+    assert np.allclose(bwd[0][3], be.bw[0, N_T - 1]) and np.allclose(bwd[-1][3], be.bw[0, 0])
