@@ -23,7 +23,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gcn import V, A, S, VCC, EXEC, Neg, kernel_text  # noqa: E402
+from gcn import V, S, EXEC, Neg, kernel_text  # noqa: E402
 import gen_t16 as g16  # noqa: E402
 from gen_t16 import NP, LDB, PLB, TILES, LDS_BYTES, KERNARG  # noqa: E402
 

@@ -33,9 +33,9 @@ import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gcn import Reg, V, A, S, VCC, EXEC, Neg, Abs, kernel_text  # noqa: E402
+from gcn import V, S, EXEC, Neg, Abs, kernel_text  # noqa: E402
 import gen_t16 as g16  # noqa: E402
-from gen_t16 import NP, LDB, PLB, RED, XS0, XS1, LDS_BYTES, KERNARG, dbits  # noqa: E402
+from gen_t16 import NP, LDB, PLB, RED, LDS_BYTES, KERNARG, dbits  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TILES16 = [(q // 4, q % 4) for q in range(16)]
