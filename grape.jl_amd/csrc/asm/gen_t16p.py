@@ -33,10 +33,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 class GenP(g16.Gen):
     early_free = True
 
-    def __init__(self, name="expm_t16p_asm", opts=None):
+    def __init__(self, name="expm_t16p_asm", nc=2, opts=None):
+        """nc: control slots of this variant -- 2 (expm_t16p_asm: table rows of 4 doubles dt, e1, e2, -) or 4 (expm_t16p4_asm:
+        rows of 8 doubles dt, e1 .. e4, -, -, -); a problem with fewer controls than slots fetches its last operator again
+        with coefficient zero"""
         super().__init__(name=name, opts=opts)
+        assert nc in (2, 4)
+        self.NC = nc
+        self.ROW = 5 if nc == 2 else 6           # log2 of the bytes of a table row
         self.s_L = self.s_scell                  # (argument `s_per_cell`: the number of controls)
-        self.s_e = [S(50, 2), S(52, 2)]          # e1, e2 of the cell that is committed (s_t0 / s_t1: idle between the fetches and the next cell's)
+        # e_l of the cell that is committed: the base registers of the fetches, idle between those and the next cell's
+        self.s_e = [S(50, 2), S(52, 2), S(46, 2), S(48, 2)][:nc]
 
     # ---- scalars of a cell ----
     def cell_bases_issue(self, kc, n, cell):
@@ -53,7 +60,7 @@ class GenP(g16.Gen):
         p.salu("s_lshl_b32", t0, kc, 2)
         p.salu("s_cselect_b32", t0, t0, 0)
         p.s_load(1, self.s_k, self.s_t0, t0)
-        p.salu("s_lshl_b32", t0, n, 5)                                   # table row n: dt | e1 | e2 | -
+        p.salu("s_lshl_b32", t0, n, self.ROW)                            # table row n: dt | e1 | e2 | ...
         p.s_load(2, self.s_dt, self.s_dts, t0)
 
     def cell_bases_finish(self, kc):
@@ -71,20 +78,19 @@ class GenP(g16.Gen):
         """e1, e2 of time step n (behind the fetches of that cell: their base registers are idle)"""
         p = self.p
         t0 = self.s_tmp[0]
-        p.salu("s_lshl_b32", t0, n, 5)
-        p.salu("s_add_u32", t0, t0, 8)
-        p.s_load(2, self.s_e[0], self.s_dts, t0)
-        p.salu("s_add_u32", t0, t0, 8)
-        p.s_load(2, self.s_e[1], self.s_dts, t0)
+        p.salu("s_lshl_b32", t0, n, self.ROW)
+        for l in range(self.NC):
+            p.salu("s_add_u32", t0, t0, 8)
+            p.s_load(2, self.s_e[l], self.s_dts, t0)
 
-    # ---- operator tiles: H0 (half 0), control 1 (half 1), control 2 (half 2; one control: control 1 again) ----
+    # ---- operator tiles: H0 (half 0), control l (half l; beyond the problem's controls: its last one again) ----
     def fetch(self, u, dst, half=None):
         p = self.p
         (i0, j0), (i1, j1) = TILES[2 * u], TILES[2 * u + 1]
         toff = self.s_tmp[2]
         p.s_cmp("s_cmp_lt_u32", self.s_wave, 2)
         self.ssel(toff, (16 * i0 * NP + 16 * j0) * 8, (16 * i1 * NP + 16 * j1) * 8)
-        for h in ((0, 1, 2) if half is None else (half,)):
+        for h in (range(1 + self.NC) if half is None else (half,)):
             base = self.s_t0 if h == 0 else self.s_t1
             if h == 0:
                 p.salu("s_add_u32", base.sub(0), self.s_hb.sub(0), toff)
@@ -92,8 +98,9 @@ class GenP(g16.Gen):
             else:
                 p.salu("s_add_u32", base.sub(0), self.s_sb.sub(0), toff)
                 p.salu("s_addc_u32", base.sub(1), self.s_sb.sub(1), 0)
-                if h == 2:      # the second operator: (L - 1) 2 NP^2 8 bytes on
+                if h >= 2:      # operator min(h, L) - 1: that many times 2 NP^2 8 bytes on
                     p.salu("s_sub_u32", self.s_tmp[3], self.s_L, 1)
+                    p.salu("s_min_u32", self.s_tmp[3], self.s_tmp[3], h - 1)
                     p.salu("s_lshl_b32", self.s_tmp[3], self.s_tmp[3], 16)
                     p.salu("s_add_u32", base.sub(0), base.sub(0), self.s_tmp[3])
                     p.salu("s_addc_u32", base.sub(1), base.sub(1), 0)
@@ -106,34 +113,41 @@ class GenP(g16.Gen):
     def pf_late(self, pf):
         ap = self.ap
         ap.free(self.A2p_re); ap.free(self.A2p_im); ap.free(self.As_re); ap.free(self.As_im)
-        pf.extend(ap.alloc(3) for _ in range(5))
+        pf.extend(ap.alloc(1 + self.NC) for _ in range(5))
 
     def fetch_plan(self, pf, ki):
-        # fifteen (tile group, operator) fetches over the k-steps 4 .. 11, two per k-step
-        for ev in (2 * ki, 2 * ki + 1):
-            if 0 <= ki and ev < 15:
-                self.fetch(ev // 3, pf[ev // 3], half=ev % 3)
+        # 5 (1 + NC) (tile group, operator) fetches from k-step 4 on, two (NC = 2) or three per k-step
+        nop, per = 1 + self.NC, (2 if self.NC == 2 else 3)
+        for ev in range(per * ki, per * ki + per):
+            if 0 <= ki and ev < 5 * nop:
+                self.fetch(ev // nop, pf[ev // nop], half=ev % nop)
 
     def _commit(self, pf, fill=None):
         """A = -i dt (H0 + e1 C1 + e2 C2) of the fetched tiles into the three planes, both triangles (base-class commit with
         the sum formed here)"""
         p = self.p
-        ta, tb, tc, td = self.vp.alloc(), self.vp.alloc(), self.vp.alloc(), self.vp.alloc()
+        NC = self.NC
+        ta, tb, tc = self.vp.alloc(), self.vp.alloc(), self.vp.alloc()
+        tcs = [self.vp.alloc() for _ in range(NC - 1)]                   # controls 2 .. NC
         dtT = S(self.s_tmp[4].idx, 2)
         p.salu("s_mov_b32", dtT.sub(0), self.s_dt.sub(0))
         p.salu("s_xor_b32", dtT.sub(1), self.s_dt.sub(1), self.s_tflip)
         for u in range(5):
             src = pf[u]
-            hr, hi_, c1r, c1i, c2r, c2i = ta.sub(0, 4), ta.sub(4, 4), tb.sub(0, 4), tb.sub(4, 4), td.sub(0, 4), td.sub(4, 4)
-            for j, dst in enumerate((hr, hi_, c1r, c1i, c2r, c2i)):
+            hr, hi_, c1r, c1i = ta.sub(0, 4), ta.sub(4, 4), tb.sub(0, 4), tb.sub(4, 4)
+            parts = [hr, hi_, c1r, c1i] + [t.sub(4 * q, 4) for t in tcs for q in range(2)]
+            for j, dst in enumerate(parts):
                 for e in range(4):
                     p.valu("v_accvgpr_read_b32" if src.cls == "a" else "v_mov_b32", dst.sub(e), src.sub(4 * j + e))
+            c2r, c2i = tcs[0].sub(0, 4), tcs[0].sub(4, 4)
             ar, ai, sm = tc.sub(0, 4), hr, hi_
             xr0, xr1, xi0, xi1 = c1r.d(0), c1r.d(1), c1i.d(0), c1i.d(1)
             for x_, h_ in ((xr0, hr.d(0)), (xr1, hr.d(1)), (xi0, hi_.d(0)), (xi1, hi_.d(1))):
                 p.valu("v_fma_f64", x_, self.s_e[0], x_, h_)                  # h + e1 c1
-            for x_, c_ in ((xr0, c2r.d(0)), (xr1, c2r.d(1)), (xi0, c2i.d(0)), (xi1, c2i.d(1))):
-                p.valu("v_fma_f64", x_, self.s_e[1], c_, x_)                  # ... + e2 c2
+            for l in range(1, NC):
+                cr, ci = tcs[l - 1].sub(0, 4), tcs[l - 1].sub(4, 4)
+                for x_, c_ in ((xr0, cr.d(0)), (xr1, cr.d(1)), (xi0, ci.d(0)), (xi1, ci.d(1))):
+                    p.valu("v_fma_f64", x_, self.s_e[l], c_, x_)              # ... + e_l c_l
             p.valu("v_mul_f64", ar.d(0), dtT, xi0)
             p.valu("v_mul_f64", ar.d(1), dtT, xi1)
             p.valu("v_mul_f64", ai.d(0), Neg(self.s_dt), xr0)
@@ -170,7 +184,7 @@ class GenP(g16.Gen):
                     p.ds_write(64, vm, ms.d(e), 32 * e + 2 * PLB)
                 if d0 or d1:
                     p.label(lab)
-        for t in (ta, tb, tc, td):
+        for t in [ta, tb, tc] + tcs:
             self.vp.free(t)
 
     def end_of_cell(self, pf, Qt, Un):
@@ -182,7 +196,7 @@ class GenP(g16.Gen):
         self.prologue()
         self.cell_bases(self.s_kc, self.s_n, self.s_cell)
         p.salu("s_mov_b32", self.s_scur, self.s_snext)
-        pf = [self.ap.alloc(3) for _ in range(5)]
+        pf = [self.ap.alloc(1 + self.NC) for _ in range(5)]
         for u in range(5):
             self.fetch(u, pf[u])
         self.load_e(self.s_n)
@@ -222,6 +236,9 @@ class GenP(g16.Gen):
 
 
 def generate(path=None, **kw):
+    if path and "p4" in os.path.basename(path):      # (build_asm names the variant by its output file)
+        kw.setdefault("name", "expm_t16p4_asm")
+        kw.setdefault("nc", 4)
     g = GenP(**kw)
     prog = g.build()
     text = kernel_text(prog, KERNARG, LDS_BYTES)

@@ -1920,8 +1920,8 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     // generator classes -- as large as the propagators themselves -- when that fits; the assembly cells then apply as they are
     bool sf_per_cell_ok = false;
     const char *envp16 = getenv("GRAPE_EXPM_ASM16P");
-    // (Hermitian generators with one or two controls: the assembly cell fetches the operators of its trajectory itself)
-    const bool p_direct = p->hc_per_traj && h->herm && L <= 2 && !(envp16 && atoi(envp16) == 0);
+    // (Hermitian generators with up to four controls: the assembly cell fetches the operators of its trajectory itself)
+    const bool p_direct = p->hc_per_traj && h->herm && L <= 4 && !(envp16 && atoi(envp16) == 0);
     if (p->hc_per_traj && !p_direct && h->t18 && !h->large && !h->series && h->NT == 4) {
         size_t free_b = 0, total_b = 0;
         CCHK(hipMemGetInfo(&free_b, &total_b));
@@ -1932,7 +1932,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     h->asm16 = h->asm16 && h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT == 4 && sf_shape_ok && (long)K * N_T < (1L << 28);
     h->asm18g = h->asm18g && h->t18 && !h->herm && !h->large && !h->series && h->NT == 4 && sf_shape_ok && (long)K * N_T < (1L << 28);
     h->asm16p = h->asm16 && p_direct;
-    if (h->asm16p) CCHK(dmalloc(&h->d_dte, (size_t)4 * N_T));
+    if (h->asm16p) CCHK(dmalloc(&h->d_dte, (size_t)(L <= 2 ? 4 : 8) * N_T));
     if (h->t18 && !h->large && !h->series && ((L > 2 && !p->hc_per_traj) || (h->asm16 && !h->asm16p) || h->asm18g) && (h->NT >= 3 || h->t18_small))
         CCHK(dmalloc(&h->d_Sf, (size_t)(p->hc_per_traj ? (size_t)h->KC * N_T : (size_t)N_T) * 2 * NP * NP));
     if (h->asm16 || h->asm18g) {
@@ -2195,7 +2195,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                     walk_fuse = h->asm_walk & (1 | ((h->fuse && h->fuse_on && h->want_bw) ? 2 : 0));
                     if (walk_fuse) HIPCHK(h, hipMemsetAsync(h->d_prog, 0, (size_t)2 * h->K * sizeof(int), s));
                     hipLaunchKernelGGL(dte_kernel, dim3((unsigned)((h->N_T + 255) / 256)), dim3(256), 0, s, (const double *)h->d_eps,
-                                       (const double *)h->d_shape, (const double *)h->d_dts, h->L, h->N_T, h->d_dte);
+                                       (const double *)h->d_shape, (const double *)h->d_dts, h->L, h->N_T, h->L <= 2 ? 2 : 4, h->d_dte);
                     HIPCHK(h, hipGetLastError());
                     const void *walk[6] = {h->d_wgtab, h->d_xinit, h->d_fw, h->d_bw, h->d_prog, h->d_splan};
                     e = (hipError_t)grape_t16p_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, h->asm_blocks, walk, walk_fuse, h->K, h->d_dte);

@@ -172,14 +172,15 @@ __global__ void __launch_bounds__(256) ctrl_sum_kernel(CtrlSumArgs a) {
     }
 }
 
-// table of expm_t16p_asm (control operators per trajectory, asm/gen_t16p.py): row n = dt_n, e1_n, e2_n, 0 with e_l = eps_ln shape_ln
-__global__ void __launch_bounds__(256) dte_kernel(const double *eps, const double *shape, const double *dts, int L, int N_T, double *out) {
+// table of expm_t16p_asm / expm_t16p4_asm (control operators per trajectory, asm/gen_t16p.py): row n = dt_n, e_1n .. e_(slots)n,
+// zeros up to 2 * slots doubles, with e_l = eps_ln shape_ln (0 beyond the problem's controls)
+__global__ void __launch_bounds__(256) dte_kernel(const double *eps, const double *shape, const double *dts, int L, int N_T, int slots, double *out) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N_T) return;
-    out[4 * n] = dts[n];
-    out[4 * n + 1] = eps[n] * (shape ? shape[n] : 1.0);
-    out[4 * n + 2] = L > 1 ? eps[(size_t)N_T + n] * (shape ? shape[(size_t)N_T + n] : 1.0) : 0.0;
-    out[4 * n + 3] = 0.0;
+    double *row = out + (size_t)2 * slots * n;
+    row[0] = dts[n];
+    for (int l = 0; l < 2 * slots - 1; ++l)
+        row[1 + l] = l < L ? eps[(size_t)l * N_T + n] * (shape ? shape[(size_t)l * N_T + n] : 1.0) : 0.0;
 }
 
 // A column strip of an NP x NP complex matrix held by one wave in MFMA C/D layout:

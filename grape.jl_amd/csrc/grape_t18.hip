@@ -231,13 +231,13 @@ constexpr int D3_INV_TABLE = 2048;
 struct AsmModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr, fn_d3g = nullptr, fn_d4[2] = {nullptr, nullptr};
-    hipFunction_t fn_t18g = nullptr, fn_t16p = nullptr;
+    hipFunction_t fn_t18g = nullptr, fn_t16p = nullptr, fn_t16p4 = nullptr;
     double *inv = nullptr;      // 1 / m, m < D3_INV_TABLE
 };
 hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr,
                         hipFunction_t *fn_d3s = nullptr, hipFunction_t *fn_lg = nullptr, hipFunction_t *fn_d3g = nullptr,
                         hipFunction_t *fn_d4 = nullptr, int d4_index = 0, hipFunction_t *fn_t18g = nullptr,
-                        hipFunction_t *fn_t16p = nullptr) {
+                        hipFunction_t *fn_t16p = nullptr, int t16p_slots = 2) {
     static AsmModule mods[64];
     static std::mutex mtx;
     std::lock_guard<std::mutex> lock(mtx);
@@ -260,6 +260,8 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         e = hipModuleGetFunction(&m.fn_t18g, m.mod, "expm_t18g_asm");
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn_t16p, m.mod, "expm_t16p_asm");
+        if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn_t16p4, m.mod, "expm_t16p4_asm");
         if (e != hipSuccess) return e;
         // 1 / m for the series orders (the kernels read them with scalar loads; gfx9 has no scalar floating point); behind
         // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
@@ -286,7 +288,7 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
     if (fn_d3g) *fn_d3g = m.fn_d3g;
     if (fn_d4) *fn_d4 = m.fn_d4[d4_index & 1];
     if (fn_t18g) *fn_t18g = m.fn_t18g;
-    if (fn_t16p) *fn_t16p = m.fn_t16p;
+    if (fn_t16p) *fn_t16p = t16p_slots == 4 ? m.fn_t16p4 : m.fn_t16p;
     if (inv) *inv = m.inv;
     return hipSuccess;
 }
@@ -453,13 +455,14 @@ extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *ver
 
 // ---- control operators per trajectory, Hermitian generators, one or two controls (asm/gen_t16p.py -> expm_t16p_asm): the
 // cell fetches H0_k and the control operators of its trajectory; `dte`: [N_T][4] = dt, e1, e2, - of every time step (built per
-// evaluation by the caller).  Same verdicts, hand-over list and statistics as expm_t16_asm (t16_post_kernel).
+// evaluation by the caller); three or four controls: expm_t16p4_asm with rows of 8 (dt, e1 .. e4, -, -, -).  Same verdicts,
+// hand-over list and statistics as expm_t16_asm (t16_post_kernel).
 extern "C" int grape_t16p_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
                                      const void *const *walk, int fuse, int K, const double *dte) {
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
-    if (!a.hc_per_traj || a.L < 1 || a.L > 2 || !dte || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
+    if (!a.hc_per_traj || a.L < 1 || a.L > 4 || !dte || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
     if (fuse && (!walk[1] || !walk[2] || !walk[3] || !walk[4] || a.rep || K != a.K)) return (int)hipErrorInvalidValue;
     const long ncell = (long)a.K * a.N_T;
     if (ncell <= 0 || ncell >= (1L << 28)) return (int)hipErrorInvalidValue;
@@ -467,7 +470,7 @@ extern "C" int grape_t16p_asm_launch(const void *args, size_t args_size, int *ve
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     hipFunction_t fn;
-    e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &fn);
+    e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &fn, a.L <= 2 ? 2 : 4);
     if (e != hipSuccess) return (int)e;
     T16AsmArgs k{};
     k.H0f = a.H0f; k.Sf = a.Hcf; k.dts = dte; k.U = a.U; k.verdict = verdict; k.rep = a.rep;

@@ -31,16 +31,16 @@ def planar(M):
     return np.stack([M.real, M.imag]).astype(np.float64)
 
 
-def run(prog, H0, C, dts, e, KC, N_T, nblk, fuse=0, psi0=None, chiT=None):
-    """H0[kc], C[kc][l] complex 64 x 64; e[l][n]"""
+def run(prog, H0, C, dts, e, KC, N_T, nblk, fuse=0, psi0=None, chiT=None, nc=2):
+    """H0[kc], C[kc][l] complex 64 x 64; e[l][n]; nc: control slots of the kernel variant (table rows of 2 nc doubles)"""
     L = C.shape[1]
     g = gcn.GlobalMem()
     a_H0, _ = g.add("H0f", np.stack([planar(h) for h in H0]))
     a_C, _ = g.add("Hcf", np.stack([np.stack([planar(c) for c in ck]) for ck in C]))
-    tab = np.zeros((N_T, 4))
+    tab = np.zeros((N_T, 2 * nc))
     tab[:, 0] = dts
-    tab[:, 1] = e[0]
-    tab[:, 2] = e[1] if L > 1 else 0.0
+    for l in range(L):
+        tab[:, 1 + l] = e[l]
     a_t, _ = g.add("dte", tab)
     a_U, U = g.add("U", np.full((KC * N_T, 64, 64, 2), np.nan))
     a_v, verdict = g.add("verdict", np.full(KC * N_T, -1, np.int32))
@@ -72,8 +72,14 @@ def program():
     return gen_t16p.generate()
 
 
-def test_program_has_no_missing_wait_states_and_assembles(program, tmp_path):
-    _, prog, text = program
+@pytest.fixture(scope="module")
+def program4():
+    return gen_t16p.generate(name="expm_t16p4_asm", nc=4)
+
+
+@pytest.mark.parametrize("which", [2, 4])
+def test_program_has_no_missing_wait_states_and_assembles(program, program4, tmp_path, which):
+    _, prog, text = program if which == 2 else program4
     assert gcn.check_hazards(prog) == 0
     assert prog.count("mfma") == 120 + 3 * 192 + 3 + 192
     if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
@@ -83,17 +89,18 @@ def test_program_has_no_missing_wait_states_and_assembles(program, tmp_path):
                         "-o", str(tmp_path / "t16p.o")], check=True)
 
 
-@pytest.mark.parametrize("N,KC,N_T,nblk,L", [(64, 2, 4, 4, 2), (52, 3, 3, 2, 1)])
-def test_cells_and_walks_with_control_operators_per_trajectory(program, N, KC, N_T, nblk, L):
-    _, prog, _ = program
+@pytest.mark.parametrize("N,KC,N_T,nblk,L", [(64, 2, 4, 4, 2), (52, 3, 3, 2, 1), (64, 2, 3, 2, 4), (60, 1, 4, 2, 3)])
+def test_cells_and_walks_with_control_operators_per_trajectory(program, program4, N, KC, N_T, nblk, L):
+    _, prog, _ = program if L <= 2 else program4
+    nc = 2 if L <= 2 else 4
     rng = np.random.default_rng(10 * N + L)
     H0 = np.stack([herm(rng, N, 0.8) for _ in range(KC)])
     C = np.stack([np.stack([herm(rng, N, 0.5) for _ in range(L)]) for _ in range(KC)])
     dts = 0.5 + 0.5 * rng.random(N_T)
-    e = rng.normal(size=(L, N_T)) * 0.6
+    e = rng.normal(size=(L, N_T)) * (0.6 if L <= 2 else 0.35)
     psi0 = rng.normal(size=(KC, N)) + 1j * rng.normal(size=(KC, N))
     chiT = rng.normal(size=(KC, N)) + 1j * rng.normal(size=(KC, N))
-    U, verdict, mf, fw, bw, prog_ = run(prog, H0, C, dts, e, KC, N_T, nblk, fuse=3, psi0=psi0, chiT=chiT)
+    U, verdict, mf, fw, bw, prog_ = run(prog, H0, C, dts, e, KC, N_T, nblk, fuse=3, psi0=psi0, chiT=chiT, nc=nc)
     Uref = np.stack([scipy.linalg.expm(-1j * dts[n] * (H0[kc] + sum(e[l, n] * C[kc, l] for l in range(L))))
                      for kc in range(KC) for n in range(N_T)])
     assert (verdict == 0).all()
