@@ -64,7 +64,7 @@ def build_asm(verbose: bool = False, workdir: str | None = None) -> str:
     intermediates are written to ``workdir`` (default: csrc/asm, the layout tools/ expect); returns the object's path."""
     asm_dir = os.path.join(_CSRC, "asm")
     work = workdir or asm_dir
-    kernels = (("gen_t16.py", "expm_t16_asm"), ("gen_t16p.py", "expm_t16p_asm"), ("gen_t16p.py", "expm_t16p4_asm"), ("gen_t18g.py", "expm_t18g_asm"), ("gen_d3.py", "deriv3_asm"), ("gen_d3s.py", "deriv3s_asm"), ("gen_d3s.py", "deriv3g_asm"),
+    kernels = (("gen_t16.py", "expm_t16_asm"), ("gen_t16p.py", "expm_t16p_asm"), ("gen_t16p.py", "expm_t16p4_asm"), ("gen_t18g.py", "expm_t18g_asm"), ("gen_t18gp.py", "expm_t18gp_asm"), ("gen_d3.py", "deriv3_asm"), ("gen_d3s.py", "deriv3s_asm"), ("gen_d3s.py", "deriv3g_asm"),
                ("gen_lg.py", "lg_gemm_asm"), ("gen_d4.py", "deriv4_asm_128"), ("gen_d4.py", "deriv4_asm_256"))
     co_path, emb_s, emb_o = os.path.join(work, "grape_asm.co"), os.path.join(work, "asm_embed.S"), os.path.join(work, "asm_embed.o")
     llvm = "/opt/rocm/lib/llvm/bin"
@@ -96,7 +96,7 @@ def build_asm(verbose: bool = False, workdir: str | None = None) -> str:
 def _sources():
     srcs = [os.path.join(_CSRC, f) for f in ("grape_hip.hip", "grape_t18.hip", "grape_kernels.hip.h", "grape_large.hip.h",
                                              "grape_series.hip.h", "grape_cheby.hip.h", "grape_t18.hip.h", "grape_t18_coeffs.h",
-                                             "grape_deriv3.hip.h", os.path.join("asm", "gen_t16.py"), os.path.join("asm", "gen_t16p.py"), os.path.join("asm", "gen_t18g.py"), os.path.join("asm", "gen_d3.py"), os.path.join("asm", "gen_d3s.py"), os.path.join("asm", "gen_lg.py"), os.path.join("asm", "gen_d4.py"), os.path.join("asm", "gcn.py"))]
+                                             "grape_deriv3.hip.h", os.path.join("asm", "gen_t16.py"), os.path.join("asm", "gen_t16p.py"), os.path.join("asm", "gen_t18g.py"), os.path.join("asm", "gen_t18gp.py"), os.path.join("asm", "gen_d3.py"), os.path.join("asm", "gen_d3s.py"), os.path.join("asm", "gen_lg.py"), os.path.join("asm", "gen_d4.py"), os.path.join("asm", "gcn.py"))]
     return srcs, os.path.join(_HERE, "..", "include", "grape_hip.h")
 
 

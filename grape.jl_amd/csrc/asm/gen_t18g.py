@@ -65,6 +65,17 @@ class GenG(g16.Gen):
     def load_constants(self):
         pass                                     # (set per cell, behind the scaling decision)
 
+    PF_TILES = 2            # tiles of 8 accumulation registers per fetched tile group (H0 re, im | S re, im)
+
+    def fetch_plan(self, pf, ki):
+        # operator tiles of the next cell: sixteen half-groups over the k-steps 4 .. 11, two per k-step
+        if 0 <= ki < 8:
+            self.fetch(ki, pf[ki], half=0)
+            self.fetch(ki, pf[ki], half=1)
+
+    def first_commit_scalars(self):
+        pass
+
     # ---- scalars of a cell: no plan of squarings, no scaling of dt ----
     def cell_bases_issue(self, kc, n, cell):
         p = self.p
@@ -474,14 +485,10 @@ class GenG(g16.Gen):
 
         def post_p5():
             ap.free(As_re); ap.free(As_im); ap.free(A2p_re); ap.free(A2p_im)
-            pf.extend(ap.alloc(2) for _ in range(8))
+            pf.extend(ap.alloc(self.PF_TILES) for _ in range(8))
 
         def hook_fetch(sk, r):
-            # operator tiles of the next cell: sixteen half-groups over the k-steps 4 .. 11, two per k-step
-            ki = 4 * sk + r - 4
-            if 0 <= ki < 8:
-                self.fetch(ki, pf[ki], half=0)
-                self.fetch(ki, pf[ki], half=1)
+            self.fetch_plan(pf, 4 * sk + r - 4)
 
         self.product(Qt, [R9re, R9im, R9sm], init=init13, hook=hook_fetch,
                      fused={"valu": valu_p5, "stores": lambda sl: self.plane_stores(sl, tt[0], tt[1], Qt[sl][1]), "post": post_p5})
@@ -554,9 +561,10 @@ class GenG(g16.Gen):
         p = self.p
         self.prologue()
         self.cell_bases(self.s_kc, self.s_n, self.s_cell)
-        pf = [self.ap.alloc(2) for _ in range(8)]
+        pf = [self.ap.alloc(self.PF_TILES) for _ in range(8)]
         for u in range(8):
             self.fetch(u, pf[u])
+        self.first_commit_scalars()
         self.commit(pf)
         for x in pf:
             self.ap.free(x)

@@ -140,7 +140,8 @@ struct grape_handle {
     bool asm16 = false;
     bool asm16p = false;         // ... its variant for control operators per trajectory (one or two controls): expm_t16p_asm fetches the
                                  // operators of the trajectory itself (GRAPE_EXPM_ASM16P=0: controls summed per cell, or the compiled kernel)
-    double *d_dte = nullptr;     // [N_T][4] dt, e1, e2, - of every time step (expm_t16p_asm)
+    double *d_dte = nullptr;     // [N_T][4] dt, e1, e2, - of every time step (expm_t16p_asm, expm_t18gp_asm; [N_T][8] with four slots)
+    bool asm18gp = false;        // general matrices, control operators per trajectory, one or two controls: expm_t18gp_asm
     bool asm18g = false;         // general matrices at four tiles per side: the five-product cell as assembly (GRAPE_EXPM_ASM18G=0: compiled)
     // round 5: the assembly kernel's workgroups walk contiguous ranges of cells (d_wgtab) and carry the state of their
     // trajectory along while the cell's result is in registers -- Psi upwards from t = 0, conj(chi~) downwards from t = T
@@ -337,7 +338,7 @@ extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, siz
 extern "C" int grape_t16p_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
                                      const void *const *walk, int fuse, int K, const double *dte);
 extern "C" int grape_t18g_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
-                                     const void *const *walk, int fuse, int K);
+                                     const void *const *walk, int fuse, int K, const double *dte);
 extern "C" int grape_t16_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
                                     const void *const *walk, int fuse, int K);
 extern "C" void grape_t16_walks(int KC, int N_T, int nblk, int *tab);
@@ -1920,8 +1921,9 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     // generator classes -- as large as the propagators themselves -- when that fits; the assembly cells then apply as they are
     bool sf_per_cell_ok = false;
     const char *envp16 = getenv("GRAPE_EXPM_ASM16P");
-    // (Hermitian generators with up to four controls: the assembly cell fetches the operators of its trajectory itself)
-    const bool p_direct = p->hc_per_traj && h->herm && L <= 4 && !(envp16 && atoi(envp16) == 0);
+    // (Hermitian generators with up to four controls, general ones with up to two: the assembly cell fetches the operators of its
+    // trajectory itself)
+    const bool p_direct = p->hc_per_traj && (h->herm ? L <= 4 : L <= 2) && !(envp16 && atoi(envp16) == 0);
     if (p->hc_per_traj && !p_direct && h->t18 && !h->large && !h->series && h->NT == 4) {
         size_t free_b = 0, total_b = 0;
         CCHK(hipMemGetInfo(&free_b, &total_b));
@@ -1932,8 +1934,9 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     h->asm16 = h->asm16 && h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT == 4 && sf_shape_ok && (long)K * N_T < (1L << 28);
     h->asm18g = h->asm18g && h->t18 && !h->herm && !h->large && !h->series && h->NT == 4 && sf_shape_ok && (long)K * N_T < (1L << 28);
     h->asm16p = h->asm16 && p_direct;
-    if (h->asm16p) CCHK(dmalloc(&h->d_dte, (size_t)(L <= 2 ? 4 : 8) * N_T));
-    if (h->t18 && !h->large && !h->series && ((L > 2 && !p->hc_per_traj) || (h->asm16 && !h->asm16p) || h->asm18g) && (h->NT >= 3 || h->t18_small))
+    h->asm18gp = h->asm18g && p_direct;
+    if (h->asm16p || h->asm18gp) CCHK(dmalloc(&h->d_dte, (size_t)(L <= 2 ? 4 : 8) * N_T));
+    if (h->t18 && !h->large && !h->series && ((L > 2 && !p->hc_per_traj) || (h->asm16 && !h->asm16p) || (h->asm18g && !h->asm18gp)) && (h->NT >= 3 || h->t18_small))
         CCHK(dmalloc(&h->d_Sf, (size_t)(p->hc_per_traj ? (size_t)h->KC * N_T : (size_t)N_T) * 2 * NP * NP));
     if (h->asm16 || h->asm18g) {
         // one workgroup per CU (512 registers, 139 KB of LDS), never more workgroups than cells
@@ -2188,8 +2191,14 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
                     walk_fuse = h->asm_walk & (1 | ((h->fuse && h->fuse_on && h->want_bw) ? 2 : 0));
                     if (walk_fuse) HIPCHK(h, hipMemsetAsync(h->d_prog, 0, (size_t)2 * h->K * sizeof(int), s));
                     const void *walk[6] = {h->d_wgtab, h->d_xinit, h->d_fw, h->d_bw, h->d_prog, h->d_splan};
-                    e = (hipError_t)grape_t18g_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, h->asm_blocks, walk, walk_fuse, h->K);
-                    h->credit_pending = true;
+                    if (h->asm18gp) {
+                        hipLaunchKernelGGL(dte_kernel, dim3((unsigned)((h->N_T + 255) / 256)), dim3(256), 0, s, (const double *)h->d_eps,
+                                           (const double *)h->d_shape, (const double *)h->d_dts, h->L, h->N_T, 2, h->d_dte);
+                        HIPCHK(h, hipGetLastError());
+                    }
+                    e = (hipError_t)grape_t18g_asm_launch(&ea, sizeof(ea), h->d_cellflag, (void *)s, h->asm_blocks, walk, walk_fuse, h->K,
+                                                          h->asm18gp ? h->d_dte : nullptr);
+                    h->credit_pending = !h->asm18gp;
                 }
                 else if (t16 && h->asm16p) {   // control operators per trajectory: the cell fetches them itself
                     walk_fuse = h->asm_walk & (1 | ((h->fuse && h->fuse_on && h->want_bw) ? 2 : 0));
@@ -3231,7 +3240,7 @@ int grape_get_work(grape_handle *h, double *out, int n) try {
             if (rc < 0) return multi_fail(h, c, rc);
             for (int i = 0; i < m; ++i) out[i] = (i == 15 || i == 16) ? cw[i] : out[i] + cw[i];   // ([15], [16]: kernel ids, the same in every shard)
         }
-        if (m > 14 && out[14] > 0.0) out[14] = h->shards[0]->asm16p ? 3.0 : h->shards[0]->asm18g ? 2.0 : 1.0;   // (an id, not a count)
+        if (m > 14 && out[14] > 0.0) out[14] = h->shards[0]->asm16p ? 3.0 : h->shards[0]->asm18gp ? 4.0 : h->shards[0]->asm18g ? 2.0 : 1.0;   // (an id, not a count)
         return 4;
     }
     HIPCHK(h, hipSetDevice(h->device));
@@ -3273,7 +3282,7 @@ int grape_get_work(grape_handle *h, double *out, int n) try {
     // runs matrix-free (see grape_create)
     if (n > 12) out[12] = h->u_fallback ? 1.0 : 0.0;
     if (n > 13) out[13] = (double)st[15];   // cells of [11] that took the four-product degree-16 route
-    if (n > 14) out[14] = h->asm16p ? 3.0 : h->asm16 ? 1.0 : h->asm18g ? 2.0 : 0.0;   // 1: the four-product route of this handle is the hand-allocated assembly kernel; 2: general matrices, expm_t18g_asm
+    if (n > 14) out[14] = h->asm16p ? 3.0 : h->asm16 ? 1.0 : h->asm18gp ? 4.0 : h->asm18g ? 2.0 : 0.0;   // 1: the four-product route of this handle is the hand-allocated assembly kernel; 2: general matrices, expm_t18g_asm
     // which derivative kernel the ExpProp route of this handle launches: 0 a compiled one, 1 deriv3_asm, 2 deriv3s_asm (streamed
     // controls), 3 deriv3g_asm (general operators), 4 deriv4_asm (blocked path); [16]: the products of the blocked polynomial
     // route are lg_gemm_asm

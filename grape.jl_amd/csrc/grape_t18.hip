@@ -231,7 +231,7 @@ constexpr int D3_INV_TABLE = 2048;
 struct AsmModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr, fn_d3g = nullptr, fn_d4[2] = {nullptr, nullptr};
-    hipFunction_t fn_t18g = nullptr, fn_t16p = nullptr, fn_t16p4 = nullptr;
+    hipFunction_t fn_t18g = nullptr, fn_t16p = nullptr, fn_t16p4 = nullptr, fn_t18gp = nullptr;
     double *inv = nullptr;      // 1 / m, m < D3_INV_TABLE
 };
 hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullptr, const double **inv = nullptr,
@@ -263,6 +263,8 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn_t16p4, m.mod, "expm_t16p4_asm");
         if (e != hipSuccess) return e;
+        e = hipModuleGetFunction(&m.fn_t18gp, m.mod, "expm_t18gp_asm");
+        if (e != hipSuccess) return e;
         // 1 / m for the series orders (the kernels read them with scalar loads; gfx9 has no scalar floating point); behind
         // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
         std::vector<double> tab(D3_INV_TABLE + 20);
@@ -288,7 +290,7 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
     if (fn_d3g) *fn_d3g = m.fn_d3g;
     if (fn_d4) *fn_d4 = m.fn_d4[d4_index & 1];
     if (fn_t18g) *fn_t18g = m.fn_t18g;
-    if (fn_t16p) *fn_t16p = t16p_slots == 4 ? m.fn_t16p4 : m.fn_t16p;
+    if (fn_t16p) *fn_t16p = t16p_slots == 4 ? m.fn_t16p4 : t16p_slots == 0 ? m.fn_t18gp : m.fn_t16p;   // (0: the general-matrix variant)
     if (inv) *inv = m.inv;
     return hipSuccess;
 }
@@ -517,12 +519,15 @@ __global__ void __launch_bounds__(256) t18g_post_kernel(ExpmArgs a, const int *v
 }
 }  // namespace
 
+// dte != nullptr: control operators per trajectory, one or two controls -- expm_t18gp_asm fetches them itself (asm/gen_t18gp.py;
+// table as for expm_t16p_asm); otherwise the summed controls a.Sf (per time step, or per cell with operators per trajectory)
 extern "C" int grape_t18g_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
-                                     const void *const *walk, int fuse, int K) {
+                                     const void *const *walk, int fuse, int K, const double *dte) {
     if (args_size != sizeof(ExpmArgs)) return (int)hipErrorInvalidValue;
     ExpmArgs a;
     memcpy(&a, args, sizeof(a));
-    if (!a.Sf || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
+    if ((!a.Sf && !dte) || !verdict || blocks < 1 || !walk || !walk[0] || !walk[5]) return (int)hipErrorInvalidValue;
+    if (dte && (!a.hc_per_traj || a.L < 1 || a.L > 2)) return (int)hipErrorInvalidValue;
     if (fuse && (!walk[1] || !walk[2] || !walk[3] || !walk[4] || a.rep || K != a.K)) return (int)hipErrorInvalidValue;
     const long ncell = (long)a.K * a.N_T;
     if (ncell <= 0 || ncell >= (1L << 28)) return (int)hipErrorInvalidValue;
@@ -530,14 +535,15 @@ extern "C" int grape_t18g_asm_launch(const void *args, size_t args_size, int *ve
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     hipFunction_t fn;
-    e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &fn);
+    if (dte) e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &fn, 0);
+    else e = asm_function(dev, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &fn);
     if (e != hipSuccess) return (int)e;
     T16AsmArgs k{};
-    k.H0f = a.H0f; k.Sf = a.Sf; k.dts = a.dts; k.U = a.U; k.verdict = verdict; k.rep = a.rep;
+    k.H0f = a.H0f; k.Sf = dte ? a.Hcf : a.Sf; k.dts = dte ? dte : a.dts; k.U = a.U; k.verdict = verdict; k.rep = a.rep;
     k.KC = a.K; k.N_T = a.N_T; k.nblk = blocks; k.flags = a.flags;
     k.fuse = fuse; k.wgtab = (const int *)walk[0]; k.xinit = (const double2 *)walk[1]; k.fw = (double2 *)walk[2];
     k.bw = (double2 *)walk[3]; k.prog = (int *)walk[4]; k.K = K; k.splan = (const int *)walk[5];
-    k.s_per_cell = a.hc_per_traj ? 1 : 0;
+    k.s_per_cell = dte ? a.L : (a.hc_per_traj ? 1 : 0);
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     hipStream_t s = (hipStream_t)stream;

@@ -260,7 +260,7 @@ int grape_reset_timings(grape_handle *h);
  * Hermitian generators, 49 <= N <= 64, control operators shared by the trajectories; GRAPE_EXPM_ASM=0: the C++ kernel), 2 if
  * the exponential of this handle is the assembly cell for GENERAL matrices (csrc/asm/gen_t18g.py: non-Hermitian drift or
  * controls, same sizes; GRAPE_EXPM_ASM18G=0: the C++ kernel), 3 if it is the four-product assembly cell for control operators
- * per trajectory (csrc/asm/gen_t16p.py: Hermitian generators, up to four controls; GRAPE_EXPM_ASM16P=0),
+ * per trajectory (csrc/asm/gen_t16p.py: Hermitian generators, up to four controls; GRAPE_EXPM_ASM16P=0), 4 the same for general matrices (gen_t18gp.py: one or two controls),
  * [15] the derivative kernel of the ExpProp route: 0 a compiled kernel, 1 deriv3_asm (49 <= N <= 64, Hermitian, L <= 2),
  * 2 deriv3s_asm (3 <= L <= 8, controls streamed through the LDS), 3 deriv3g_asm (general drift / controls), 4 deriv4_asm
  * (64 < N <= 256), [16] 1 if the products of the blocked polynomial route are the assembly kernel lg_gemm_asm

@@ -181,3 +181,68 @@ def test_summed_controls_per_cell(program):
         for n in range(N_T):
             ref = scipy.linalg.expm(-1j * dts[n] * (H0[kc] + Sn[kc * N_T + n]))
             assert np.abs(U[kc * N_T + n] - ref).max() < 5e-15 * max(1.0, np.abs(ref).max()), (kc, n)
+
+
+def test_control_operators_per_trajectory_variant():
+    """expm_t18gp_asm (gen_t18gp.py): the cell fetches H0_k and the one or two control operators of its trajectory; dt, e1, e2 from
+    one table row; walks through transposed cells as in the base kernel"""
+    import gen_t18gp
+    _, prog, text = gen_t18gp.generate()
+    assert gcn.check_hazards(prog) == 0
+    rng = np.random.default_rng(8)
+    for N, KC, N_T, nblk, L in [(64, 2, 3, 3, 2), (58, 1, 3, 1, 1)]:
+        def gen(s):
+            X = (rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))) / (2.8 * np.sqrt(N)) * s
+            P = np.zeros((64, 64), complex)
+            P[:N, :N] = X
+            return P
+        H0 = np.stack([gen(0.8) for _ in range(KC)])
+        C = np.stack([np.stack([gen(0.5) for _ in range(L)]) for _ in range(KC)])
+        dts = 0.5 + 0.5 * rng.random(N_T)
+        e = rng.normal(size=(L, N_T)) * 0.6
+        psi0 = rng.normal(size=(KC, N)) + 1j * rng.normal(size=(KC, N))
+        chiT = rng.normal(size=(KC, N)) + 1j * rng.normal(size=(KC, N))
+        g = gcn.GlobalMem()
+        pl = lambda M: np.stack([M.real, M.imag]).astype(np.float64)
+        a_H0, _ = g.add("H0f", np.stack([pl(h) for h in H0]))
+        a_C, _ = g.add("Hcf", np.stack([np.stack([pl(c) for c in ck]) for ck in C]))
+        tab = np.zeros((N_T, 4))
+        tab[:, 0] = dts
+        for l in range(L):
+            tab[:, 1 + l] = e[l]
+        a_t, _ = g.add("dte", tab)
+        a_U, U = g.add("U", np.full((KC * N_T, 64, 64, 2), np.nan))
+        a_v, verdict = g.add("verdict", np.full(KC * N_T, -1, np.int32))
+        a_f, _ = g.add("flags", np.zeros(8, np.int32))
+        a_tab, _ = g.add("wgtab", t16_walks(KC, N_T, nblk))
+        xinit = np.zeros((2, KC, 64, 2))
+        xinit[0, :, :N, 0], xinit[0, :, :N, 1] = psi0.real, psi0.imag
+        xinit[1, :, :N, 0], xinit[1, :, :N, 1] = chiT.real, -chiT.imag
+        a_xi, _ = g.add("xinit", xinit)
+        a_fw, fw = g.add("fw", np.full((KC, N_T + 1, 64, 2), np.nan))
+        a_bw, bw = g.add("bw", np.full((KC, N_T + 1, 64, 2), np.nan))
+        a_pg, prog_ = g.add("prog", np.zeros((2, KC), np.int32))
+        a_sp, splan = g.add("splan", np.full(KC * N_T, -1, np.int32))
+        karg = struct.pack("<QQQQQQiiiiQQQQQQQiiQ", a_H0, a_C, a_t, a_U, a_v, 0, KC, N_T, nblk, 3, 0, a_f,
+                           a_tab, a_xi, a_fw, a_bw, a_pg, KC, L, a_sp)
+        a_k, _ = g.add("kernarg", np.frombuffer(karg, np.uint8).copy())
+        for wg in range(nblk):
+            gcn.Emu(prog, g, a_k, wg_id=wg, lds_bytes=gen_t16.LDS_BYTES).run()
+        Uc = U[..., 0] + 1j * U[..., 1]
+        Uref = np.stack([scipy.linalg.expm(-1j * dts[n] * (H0[kc] + sum(e[l, n] * C[kc, l] for l in range(L))))
+                         for kc in range(KC) for n in range(N_T)])
+        assert (verdict == 0).all() and np.abs(Uc - Uref).max() < 5e-15 * max(1.0, np.abs(Uref).max())
+        fwc, bwc = fw[..., 0] + 1j * fw[..., 1], bw[..., 0] + 1j * bw[..., 1]
+        assert prog_.sum() > 0
+        for kc in range(KC):
+            x = np.zeros(64, complex)
+            x[:N] = psi0[kc]
+            for n in range(prog_[0, kc]):
+                x = Uref[kc * N_T + n] @ x
+                assert np.abs(fwc[kc, n + 1] - x).max() < 1e-14 * max(1.0, np.abs(x).max())
+            y = np.zeros(64, complex)
+            y[:N] = chiT[kc]
+            for i in range(prog_[1, kc]):
+                n = N_T - 1 - i
+                y = Uref[kc * N_T + n].conj().T @ y
+                assert np.abs(bwc[kc, n] - y).max() < 1e-14 * max(1.0, np.abs(y).max())

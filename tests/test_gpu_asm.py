@@ -529,12 +529,12 @@ def test_a_hermitian_generator_that_is_not_finite_is_an_error_not_a_hang(g, N):
             h.eval(pr["pulsevals"])
 
 
-@pytest.mark.parametrize("herm,L", [(True, 2), (True, 1), (True, 3), (True, 4), (True, 5), (False, 2)],
-                         ids=["hermitian_L2", "hermitian_L1", "hermitian_L3", "hermitian_L4", "hermitian_L5", "general"])
+@pytest.mark.parametrize("herm,L", [(True, 2), (True, 1), (True, 3), (True, 4), (True, 5), (False, 2), (False, 1), (False, 3)],
+                         ids=["hermitian_L2", "hermitian_L1", "hermitian_L3", "hermitian_L4", "hermitian_L5", "general_L2", "general_L1", "general_L3"])
 def test_control_operators_per_trajectory_take_the_assembly_cells(g, herm, L):
     """Round 5: control operators per trajectory (the ensemble of a robustness problem).  Hermitian generators with up to four
-    controls: expm_t16p_asm / expm_t16p4_asm fetch the operators of their trajectory themselves (work[14] = 3).  More controls, or general
-    matrices: the controls of every CELL are summed once per evaluation ([KC][N_T] blocks) and the assembly cells read block
+    controls (general ones with up to two): expm_t16p_asm / expm_t16p4_asm (expm_t18gp_asm) fetch the operators of their
+    trajectory themselves (work[14] = 3 (4)).  More controls: the controls of every CELL are summed once per evaluation ([KC][N_T] blocks) and the assembly cells read block
     kc N_T + n.  Same results as the compiled kernels on the L operators of the trajectory (all switches off); generator
     classes share propagators (and blocks)."""
     from grape_jl_amd import synth
@@ -563,7 +563,7 @@ def test_control_operators_per_trajectory_take_the_assembly_cells(g, herm, L):
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-    want = 3.0 if (herm and L <= 4) else (1.0 if herm else 2.0)
+    want = (3.0 if L <= 4 else 1.0) if herm else (4.0 if L <= 2 else 2.0)
     assert out["default"][4]["asm_kernel"] == want
     assert out["summed"][4]["asm_kernel"] == (1.0 if herm else 2.0) and out["compiled"][4]["asm_kernel"] == 0.0
     b = out["compiled"]
