@@ -126,6 +126,9 @@ def main():
                     help="the same shape with non-Hermitian generators (Liouvillian-like; secondary lines in profiles/)")
     ap.add_argument("--nonhermitian-controls", action="store_true",
                     help="with --nonhermitian: the control operators are general matrices as well (secondary line)")
+    ap.add_argument("--per-trajectory-controls", action="store_true",
+                    help="control operators per trajectory (the ensemble of a robustness problem: 5 %% amplitude errors of the "
+                         "shared operators; secondary lines in profiles/)")
     ap.add_argument("--dt", type=float, default=None,
                     help="time step of the synthetic grid instead of 1.0 (secondary lines: the cells leave the range of the "
                          "four-product exponential at dt ~ 1.2 and need a squaring beyond dt ~ 1.7)")
@@ -180,6 +183,10 @@ def main():
         import numpy as _np
         _rng = _np.random.default_rng(synth.BASE_SEED + 77)
         pr["Hc"] = pr["Hc"] + 0.1 * (_rng.normal(size=pr["Hc"].shape) + 1j * _rng.normal(size=pr["Hc"].shape)) / _np.sqrt(N)
+    if args.per_trajectory_controls:
+        import numpy as _np
+        _rng = _np.random.default_rng(synth.BASE_SEED + 78 + rank)
+        pr["Hc"] = _np.stack([pr["Hc"] * (1.0 + 0.05 * _rng.standard_normal()) for _ in range(K_local)])
     if args.dt is not None:
         pr["tlist"] = pr["tlist"] * args.dt
     h = g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"],
@@ -304,13 +311,17 @@ def main():
                           " chain (blocked path: one launch per product of the five-product polynomial)"
         elif work.get("t16_cells", 0.0) > 0.0:
             redone = work["t18_cells"] - work["t16_cells"]
-            name = ("expm_t16_asm (hand-allocated gfx950 assembly, csrc/asm/gen_t16.py)" if work.get("asm_kernel", 0.0) > 0.0
+            name = ("expm_t16p_asm (hand-allocated gfx950 assembly, csrc/asm/gen_t16p.py: control operators fetched per trajectory)"
+                    if work.get("asm_kernel", 0.0) == 3.0 else
+                    "expm_t16_asm (hand-allocated gfx950 assembly, csrc/asm/gen_t16.py)" if work.get("asm_kernel", 0.0) > 0.0
                     else "expm_t18_kernel<%d,...,T16>" % ((N + 15) // 16))
             expm_kernel = (name + " (inverse-free degree-16 polynomial, four products; %d of %d cells beyond "
                            "its spectral bound redone by the five-product launch)" % (redone, work["t18_cells"]))
         elif work.get("t18_cells", 0.0) > 0.0:
             expm_kernel = ("expm_t18g_asm (hand-allocated gfx950 assembly, csrc/asm/gen_t18g.py; general matrices, scaling decided in "
                            "the cell)" if work.get("asm_kernel", 0.0) == 2.0 else
+                           "expm_t18gp_asm (hand-allocated gfx950 assembly, csrc/asm/gen_t18gp.py; general matrices, control operators "
+                           "fetched per trajectory)" if work.get("asm_kernel", 0.0) == 4.0 else
                            "expm_t18_kernel<%d>" % ((N + 15) // 16)) + " (inverse-free degree-18 polynomial, five products)"
         else:
             expm_kernel = ("expm_persistent_kernel<4,...>" if N > 48 else "expm_pade_kernel<%d,...>" % ((N + 15) // 16)) + " (order-13 Pade)"
@@ -345,7 +356,8 @@ def main():
             "config": {"workload": f"{args.config}: N={N}, L={L} controls, N_T={N_T} time steps, "
                                    f"{K_local} trajectories per GPU ({K_total} total), J_T_sm, ExpProp"
                                    + (", NON-HERMITIAN generators" if args.nonhermitian else "")
-                                   + (" (general control operators too)" if args.nonhermitian_controls else ""),
+                                   + (" (general control operators too)" if args.nonhermitian_controls else "")
+                                   + (", CONTROL OPERATORS PER TRAJECTORY" if args.per_trajectory_controls else ""),
                        "gradient_method": "gradgen (exact derivative via the series of the gradient-generator "
                                           "propagator on the extended state)",
                        "one_eval": f"one shard evaluation = functional + full gradient of {K_local} trajectories; "

@@ -26,4 +26,7 @@ GRAPE_DERIV3G=0 python3 bench.py --config C3 --nonhermitian --nonhermitian-contr
 # the cliff of the four-product route: every cell beyond its range (dt = 1.5: five products) and with one squaring (dt = 2)
 python3 bench.py --config C3 --dt 1.5 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_dt1p5.json 2> gpurun_out/${tag}_bench_C3_dt1p5.err
 python3 bench.py --config C3 --dt 2.0 --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_dt2.json 2> gpurun_out/${tag}_bench_C3_dt2.err
+# control operators per trajectory (the ensemble of a robustness problem), Hermitian and general
+python3 bench.py --config C3 --per-trajectory-controls --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_pertraj.json 2> gpurun_out/${tag}_bench_C3_pertraj.err
+python3 bench.py --config C3 --per-trajectory-controls --nonhermitian --steps 8 --warmup 2 --no-cpu-baseline --no-matrix-free > gpurun_out/${tag}_bench_C3_pertraj_nonherm.json 2> gpurun_out/${tag}_bench_C3_pertraj_nonherm.err
 exit $rc
