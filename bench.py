@@ -107,6 +107,45 @@ def cpu_baseline(pr, handle_eval, target_seconds=15.0):
                 blas_free_variant=dict(plain, structured_variant=structured))
 
 
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks OURSELVES, as a child process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`), relay the one JSON
+    line of rank 0 and return the child's exit status.  Runs before torch or the HIP library is imported: this process
+    never touches a GPU (and never replaces itself with another program).  Returns None when this process is a rank
+    itself (WORLD_SIZE set by a launcher, or --gpus 1).  A launcher whose WORLD_SIZE disagrees with --gpus is an error:
+    the line would carry an `n_gpus` the caller did not ask for.
+    The ranks replace the loops over the trajectories of /root/reference/src/optimize.jl:720, 876 and the sum of :579."""
+    import subprocess
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world_env}; refusing to "
+                             "report a line whose n_gpus differs from the request\n")
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:   # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")]
+    for ln in res.stdout.splitlines():      # anything else the ranks wrote to stdout belongs on stderr: ONE line here
+        if ln.strip() and not ln.strip().startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if lines:
+        print(lines[-1])
+    if res.returncode == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, got {len(lines)}\n")
+        return 3
+    return res.returncode
+
+
 def g_eval_host(h, x):
     """One host-pointer evaluation of an (unsharded) handle: (J, G, tau)."""
     return h.eval(x)
@@ -133,6 +172,10 @@ def main():
                     help="time step of the synthetic grid instead of 1.0 (secondary lines: the cells leave the range of the "
                          "four-product exponential at dt ~ 1.2 and need a squaring beyond dt ~ 1.7)")
     args = ap.parse_args()
+
+    rc = launch_ranks_if_needed(args)
+    if rc is not None:
+        sys.exit(rc)
 
     import torch
     import grape_jl_amd as g
@@ -269,17 +312,31 @@ def main():
     if rank == 0:
         # HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes of tools/pmc.sh
         # (separate run: counters cannot be collected inside the timed bench), see profiles/.
-        traffic, hw_util, pmc_file, pmc_mops = None, None, None, None
+        traffic, hw_util, pmc_file, pmc_mops, pmc_kernel = None, None, None, None, None
+        # the kernel of phase A that RAN (grape_get_work[14], [11], [13]): its own PMC entry or none
+        asm_id = int(work.get("asm_kernel", 0))
+        if N > 64:
+            ran = None
+        elif asm_id:
+            ran = {1: "expm_t16_asm", 2: "expm_t18g_asm", 3: "expm_t16p", 4: "expm_t18gp_asm"}[asm_id]
+        elif work.get("t18_cells", 0.0) > 0.0:
+            ran = "expm_t18_kernel"
+        else:
+            ran = "expm_persistent_kernel" if N > 48 else "expm_pade_kernel"
+        variant = ("_nonherm_ctrl" if args.nonhermitian_controls else "_nonherm" if args.nonhermitian else "") + \
+                  ("_pertraj" if args.per_trajectory_controls else "") + \
+                  ("_dt%s" % str(args.dt).replace(".", "p") if args.dt is not None else "")
         try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"_pmc_summary_{args.config}.json"))
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                           if f.endswith(f"_pmc_summary_{args.config}{variant}.json"))
             pmc_file = cands[-1] if cands else None
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file))) if pmc_file else {"kernels": {}}
-            for kname, d in pmc["kernels"].items():   # the dominant kernel of phase A of THIS configuration
-                if any(t in kname for t in ("expm_t16_asm", "expm_t18_kernel", "expm_pade_kernel", "expm_persistent_kernel", "lg_gemm_kernel")) \
-                        and d.get("MfmaUtil_percent", 0) > 1:
+            for kname, d in pmc["kernels"].items():
+                if ran and ran in kname and d.get("MfmaUtil_percent", 0) > 1:
                     traffic = d.get("hbm_bytes_per_launch")
                     hw_util = d.get("MfmaUtil_percent")
                     pmc_mops = d.get("SQ_INSTS_VALU_MFMA_MOPS_F64")
+                    pmc_kernel = kname
             if N > 64:   # blocked path: phase A is a chain of launches -- all of them, per evaluation of the profiled run
                 n_eval = max([d.get("dispatches", 0) for k_, d in pmc["kernels"].items() if "grad_reduce_kernel" in k_] or [0])
                 phase_a = [d for k_, d in pmc["kernels"].items()
@@ -287,8 +344,11 @@ def main():
                 if n_eval and phase_a:
                     traffic = sum(d.get("hbm_bytes_per_launch", 0.0) * d.get("dispatches", 0) for d in phase_a) / n_eval
                     hw_util = max(d.get("MfmaUtil_percent", 0.0) for d in phase_a)
+                    pmc_kernel = "all launches of phase A"
         except Exception:
             pass
+        if traffic is None and hw_util is None:
+            pmc_file = None   # no committed counters for the kernel that ran: the line says null, not another kernel's figures
         expm_ms = tm["expm"]
         algorithmic = work["flop_expm"] / (expm_ms * 1e-3) * 1e-12
         # EXECUTED matrix-instruction flop per launch: counted by the kernel itself on the inverse-free path (2048 flop per
@@ -333,6 +393,19 @@ def main():
         per16 = (10.0 / 16.0 + 3.0) * 6.0 * float(N) ** 3
         per18 = ((2 * 10.0 / 16.0 + 12.0 / 16.0 + 2.0) if herm else 5.0) * 6.0 * float(N) ** 3
         min_flop = (n16 * per16 + n18 * per18 + work.get("t18_squarings", 0.0) * 6.0 * float(N) ** 3) if n18 + n16 > 0 and N <= 64 else None
+        # phase B: the sweep launch is charged with the steps it DID -- the walks of the exponential kernel carried
+        # grape_get_work[17] of the 2 K N_T steps (their U never comes back from HBM); per step one read of U and the state
+        # traffic.  The sequential order (no concurrent sweeps) runs the backward sweep in a launch of its own.
+        steps_total = 2.0 * K_local * N_T
+        steps_walked = float(work.get("walk_steps", 0.0))
+        per_step_bytes = N * N * 16 + 3 * N * 16
+        sweep_ms = tm.get("forward", -1.0) + max(tm.get("backward", 0.0), 0.0)
+        pb_bytes = (steps_total - steps_walked) * per_step_bytes
+        phase_b = {"kernel": sweep_kernel, "steps_total": steps_total, "steps_carried_by_the_walks_of_phase_A": steps_walked,
+                   "algorithmic_bytes": pb_bytes,
+                   "GB_per_s": pb_bytes / (sweep_ms * 1e-3) * 1e-9 if sweep_ms > 0 else None, "bound": "hbm",
+                   "peak_GB_per_s": 8000.0,
+                   "note": "bytes = (2 K N_T - steps carried by the walks) x (N^2 16 + 3 N 16); time = forward + backward phase"}
         res = {
             "metric": "GRAPE gradient evals/sec (N=64, 1000 steps, 128 traj)" if args.config == "C3"
                       else f"GRAPE gradient evals/sec ({args.config})",
@@ -381,6 +454,7 @@ def main():
                                           "their fused epilogue, decision)" if N > 64 else "HBM bytes per launch") +
                                          " (PMC FETCH_SIZE + WRITE_SIZE); algorithmic bytes per launch = "
                                          f"K*N_T*N^2*16 (U store) = {16.0 * work['expm_cells'] * N * N:.3e}",
+                         "traffic_kernel": pmc_kernel,
                          "traffic_source": f"profiles/{pmc_file} (separate rocprofv3 --pmc passes of tools/pmc.sh; NOT "
                                            "measured in this run)" if pmc_file else None,
                          "hw_mfma_busy_percent": hw_util,
@@ -394,10 +468,7 @@ def main():
                                  "Hermitian generators take a four- or five-product polynomial without the Pade solve",
                          "flop_model": "SURVEY 8d F_exp = (g+s)*8N^3 + (32/3)N^3 per cell, g = 6 for Pade order 13"},
             "phases_ms": {k: round(v, 4) for k, v in tm.items() if v >= 0},
-            "phase_b": {"kernel": sweep_kernel,
-                        "algorithmic_bytes": 2.0 * K_local * N_T * (N * N * 16 + 3 * N * 16),
-                        "GB_per_s": 2.0 * K_local * N_T * (N * N * 16 + 3 * N * 16) / (tm["forward"] * 1e-3) * 1e-9
-                        if tm.get("forward", -1) > 0 else None, "bound": "hbm"},
+            "phase_b": phase_b,
             "gradient_allreduce_latency_us": allreduce_us,
             "w_eval_model": {"flop_per_eval": (170.0 + 2.0 / 3.0 + 24.0 * work["squarings"] / max(work["cells"], 1.0))
                                               * float(N) ** 3 * work["cells"],

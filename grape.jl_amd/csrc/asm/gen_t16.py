@@ -30,7 +30,11 @@ the four elements a lane holds of a 16 x 16 tile are four rows of ONE column: wi
 instruction outside the shadow of a matrix instruction costs ~28 cycles of a lone wave, whatever its width: measured).
 The columns of a 16-column block are stored in the order (j >> 1) + 8 (j & 1): a 16-lane store group (16 columns) covers
 16 distinct 4-bank groups, and the two columns a half-wave of a left-operand read covers (k, k + 1) lie 8 records =
-32 banks apart -- both access patterns are free of bank conflicts.
+32 banks apart.  That was the design intent; the hardware counters say otherwise: SQ_LDS_BANK_CONFLICT is 10.8 % of
+the LDS-active cycles and WAIT_INST_LDS 5.8 % of the wave cycles (profiles/r05_asm_kernels_sq_wave_cycles.txt).  The
+residue is structural for this layout -- a conflict-free fragment read wants adjacent columns 32 banks apart, a
+conflict-free 16-byte strip store wants 8 consecutive columns on distinct 4-bank granules, and (c, c + 1) sit in the same
+store group; a padded-record variant measured worse in the bank model (docs/LAB_NOTEBOOK.md section 10.3).  It stays.
 
 The instruction list is executed by the emulator of gcn.py against numpy (tests/test_asm_kernel.py) -- this container
 has no GPU -- and the same list is printed as the .s file the library embeds.

@@ -150,6 +150,7 @@ struct grape_handle {
     int *d_wgtab = nullptr, *d_prog = nullptr, *d_splan = nullptr;   // d_splan: squarings planned per cell (scaling and squaring around the four products)
     double2 *d_xinit = nullptr;
     int asm_blocks = 0;
+    int last_walk_fuse = 0;      // which ends the walks of the LAST evaluation carried (grape_get_work[17] counts their steps from d_prog)
     bool asm_sq = true;          // GRAPE_EXPM_SQ=0: no scaling and squaring around the four products (cells beyond the bound go to
                                  // the five-product launch, as before round 5)
     int asm_walk = 0;            // bits of the walks that may carry a state: 1 ascending (Psi), 2 descending (conj(chi~)); GRAPE_EXPM_WALK
@@ -544,7 +545,9 @@ std::vector<double> gebal_scaling(int N, std::vector<double> M) {
 
 // fn(q) for q in [0, n) over the host cores.  A std::thread that cannot be created (std::system_error) is not an error:
 // its share runs on the calling thread; threads that did start are always joined (a joinable std::thread that is
-// destroyed ends the process).
+// destroyed ends the process).  An exception that fn throws INSIDE a worker (std::bad_alloc of a scratch vector) must not
+// leave the thread function -- that is std::terminate, past every barrier of the C boundary (round-5 advisor finding):
+// the worker keeps the first one and the calling thread rethrows it after the join, where GRAPE_BARRIER sees it.
 template <class F>
 void parallel_for(int n, F fn, unsigned max_threads = 32u) {
     const int nth = (int)std::max(1u, std::min<unsigned>(std::min<unsigned>(std::thread::hardware_concurrency(), max_threads), (unsigned)std::max(n, 1)));
@@ -552,14 +555,22 @@ void parallel_for(int n, F fn, unsigned max_threads = 32u) {
     std::vector<std::thread> pool;
     pool.reserve((size_t)nth);
     std::vector<char> covered((size_t)nth, 0);
+    std::vector<std::exception_ptr> thrown((size_t)nth);
     try {
         for (int t = 0; t < nth; ++t) {
-            pool.emplace_back([&, t]() { for (int q = t; q < n; q += nth) fn(q); });
+            pool.emplace_back([&, t]() {
+                try {
+                    if (t == nth - 1) test_throw_point("worker");
+                    for (int q = t; q < n; q += nth) fn(q);
+                } catch (...) { thrown[(size_t)t] = std::current_exception(); }
+            });
             covered[t] = 1;
         }
     } catch (const std::system_error &) {
     }
     for (auto &th : pool) th.join();
+    for (auto &ep : thrown)
+        if (ep) std::rethrow_exception(ep);
     for (int t = 0; t < nth; ++t)
         if (!covered[t]) for (int q = t; q < n; q += nth) fn(q);
 }
@@ -1455,7 +1466,10 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     h->p = *p;
     h->bal = bal;
     h->no_target = no_target;
-    h->taylor_check = p->taylor_no_check == 0;
+    // (taylor_grad_check_convergence belongs to gradient_method = :taylor, optimize.jl:917-918; :gradgen shares the series
+    // kernels and their non-convergence flag, and a series of ITS 200 terms that has not converged is always an error --
+    // round-5 advisor finding: the switch used to silence it)
+    h->taylor_check = p->gradient_method != GRAPE_GRAD_TAYLOR || p->taylor_no_check == 0;
     h->N = p->N; h->L = p->L; h->K = p->K; h->N_T = p->N_T;
     h->K_total = p->K_total > 0 ? p->K_total : p->K;
     h->NT = (p->N + 15) / 16; h->NP = 16 * h->NT;
@@ -2275,6 +2289,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         }
     }
 #endif
+    h->last_walk_fuse = walk_fuse;
     // ---- phase 1: forward sweep + tau ----
     SweepArgs sa{};
     sa.U = h->d_U; sa.cls = h->d_cls; sa.psi0 = h->d_psi0; sa.target = h->d_target; sa.weights = h->d_weights;
@@ -2687,7 +2702,17 @@ int multi_enqueue(grape_handle *h, F fn) {
         pool.reserve(G);
         try {   // (std::thread's constructor may throw std::system_error: nothing may cross the extern "C" boundary)
             for (size_t g = 0; g < G; ++g) {
-                pool.emplace_back([&, g]() { rcs[g] = fn(h->shards[g], g); });
+                // (an exception may not leave a thread function -- std::terminate, whatever the entry point's barrier says:
+                // the shard reports it as its own GRAPE_ERR_HOST and the other shards are waited for below)
+                pool.emplace_back([&, g]() {
+                    try {
+                        if (h->test_hooks && g + 1 == G) test_throw_point("shard");
+                        rcs[g] = fn(h->shards[g], g);
+                    }
+                    catch (const std::bad_alloc &) { rcs[g] = barrier_fail(&h->shards[g]->err, "std::bad_alloc (out of host memory) in a shard thread"); }
+                    catch (const std::exception &e) { rcs[g] = barrier_fail(&h->shards[g]->err, e.what()); }
+                    catch (...) { rcs[g] = barrier_fail(&h->shards[g]->err, "unknown exception in a shard thread"); }
+                });
                 started[g] = 1;
             }
         } catch (...) {
@@ -3232,10 +3257,10 @@ GRAPE_BARRIER(h ? &h->err : &g_create_error)
 int grape_get_work(grape_handle *h, double *out, int n) try {
     if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
     if (!h->shards.empty()) {   // every entry is a count: the shards add up
-        const int m = n < 17 ? n : 17;
+        const int m = n < 18 ? n : 18;
         std::fill(out, out + m, 0.0);
         for (grape_handle *c : h->shards) {
-            double cw[17] = {0.};
+            double cw[18] = {0.};
             const int rc = grape_get_work(c, cw, m);
             if (rc < 0) return multi_fail(h, c, rc);
             for (int i = 0; i < m; ++i) out[i] = (i == 15 || i == 16) ? cw[i] : out[i] + cw[i];   // ([15], [16]: kernel ids, the same in every shard)
@@ -3296,6 +3321,20 @@ int grape_get_work(grape_handle *h, double *out, int n) try {
         out[15] = kind;
     }
     if (n > 16) out[16] = (h->large && !h->series && h->t18 && h->lg_asm) ? 1.0 : 0.0;
+    // steps of the two sweeps the walks of the exponential kernel carried in the last evaluation (the sweep launch did
+    // the other 2 K N_T - [17]; bench.py prices its HBM rate with that)
+    if (n > 17) {
+        double carried = 0.0;
+        if (h->last_walk_fuse && h->d_prog) {
+            std::vector<int> prog((size_t)2 * h->K);
+            HIPCHK(h, hipMemcpy(prog.data(), h->d_prog, prog.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int k = 0; k < h->K; ++k) {
+                if (h->last_walk_fuse & 1) carried += prog[(size_t)k];
+                if (h->last_walk_fuse & 2) carried += prog[(size_t)h->K + k];
+            }
+        }
+        out[17] = carried;
+    }
     return 4;
 }
 GRAPE_BARRIER(h ? &h->err : &g_create_error)
@@ -3324,6 +3363,8 @@ int multi_create(grape_handle **out, const grape_problem *p) {
     {
         const char *envm = getenv("GRAPE_MULTI_THREADS");
         h->multi_threads = !(envm && atoi(envm) == 0);
+        const char *envk = getenv("GRAPE_TEST_HOOKS");
+        h->test_hooks = envk && atoi(envk) == 1;
     }
     const size_t nn2 = (size_t)2 * p->N * p->N;
     const int base = p->K / G, rem = p->K % G;

@@ -86,6 +86,57 @@ class NonlinearAmplitude:
         self.shape = shape
 
 
+class FixedAmplitude:
+    """A time-dependent coefficient that is NOT an optimisable control: an amplitude type whose ``get_controls`` is empty
+    and whose value the reference obtains per interval from ``evaluate(ampl, tlist, n)`` (the generator is re-evaluated on
+    every step, /root/reference/src/optimize.jl:732, 881, 937-945; ExpProp's ``evaluate!``).  ``values``: a callable a(t)
+    or an array on ``tlist`` / on its midpoints.  ``grape_problem`` knows one constant drift per trajectory, so the term
+    crosses the boundary as a PSEUDO-CONTROL: an extra control operator whose pulse values are fixed on the host and whose
+    rows of the gradient are dropped."""
+
+    def __init__(self, values):
+        self.values = values
+
+
+class _PseudoControlBackend:
+    """Innermost wrapper of a handle that carries P pseudo-controls behind the L optimised ones (see FixedAmplitude): the
+    fixed pulse values are appended to every pulse vector on the way in, the gradient rows of the pseudo-controls are cut on
+    the way out.  The handle itself works on L + P controls."""
+
+    def __init__(self, inner, fixed_vals, L, N_T):
+        self.inner, self.L_opt, self.N_T = inner, L, N_T
+        self.fixed = np.ascontiguousarray(fixed_vals, dtype=np.float64).reshape(-1)
+
+    def _x(self, x):
+        return np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1), self.fixed])
+
+    def _g(self, G):
+        return None if G is None else G[: self.L_opt * self.N_T].copy()
+
+    def eval(self, x, gradient=True, want_psiT=False):
+        res = list(self.inner.eval(self._x(x), gradient=gradient, want_psiT=want_psiT))
+        res[1] = self._g(res[1])
+        return tuple(res)
+
+    def forward(self, x):
+        return self.inner.forward(self._x(x))
+
+    def backward(self, f_total):
+        return self._g(self.inner.backward(f_total))
+
+    def backward_chi(self, chi):
+        return self._g(self.inner.backward_chi(chi))
+
+    def backward_xi(self, xi, lambda_b, f_total=None, chi=None):
+        return self._g(self.inner.backward_xi(xi, lambda_b, f_total=f_total, chi=chi))
+
+    def tau_grads(self):
+        return self.inner.tau_grads()[:, : self.L_opt]
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+
 class _AmplitudeBackend:
     """Wraps a backend whose pulse values are the amplitudes f_l(eps): maps eps -> f(eps) on the way in and applies
     the chain rule to the gradient on the way out."""
@@ -118,8 +169,11 @@ class _AmplitudeBackend:
 def hamiltonian(H0, *terms):
     """``hamiltonian(H0, (H1, eps1), (H2, eps2), ...)``: H(t) = H0 + sum_l a_l(t) H_l, a_l a control or a
     ``ShapedAmplitude`` of one."""
-    ops, ctrls, shapes, nonlinear = [], [], [], {}
+    ops, ctrls, shapes, nonlinear, fixed = [], [], [], {}, []
     for op, ctrl in terms:
+        if isinstance(ctrl, FixedAmplitude):      # time-dependent, but not a control (get_controls(ampl) == ())
+            fixed.append((np.asarray(op, dtype=np.complex128), ctrl))
+            continue
         ops.append(np.asarray(op, dtype=np.complex128))
         if isinstance(ctrl, (ShapedAmplitude, NonlinearAmplitude)):
             ctrls.append(ctrl.control)
@@ -129,7 +183,7 @@ def hamiltonian(H0, *terms):
         else:
             ctrls.append(ctrl)
             shapes.append(None)
-    return Generator(np.asarray(H0, dtype=np.complex128), ops, ctrls, shapes, nonlinear)
+    return Generator(np.asarray(H0, dtype=np.complex128), ops, ctrls, shapes, nonlinear, fixed)
 
 
 @dataclass
@@ -139,6 +193,7 @@ class Generator:
     controls: list
     shapes: list = None   # per term: None or the static shape S(t) of a ShapedAmplitude
     nonlinear: dict = None  # id(control) -> (f, f') for controls that enter through a NonlinearAmplitude
+    fixed: list = None      # [(operator, FixedAmplitude)]: time-dependent terms that are not controls
 
 
 @dataclass
@@ -247,6 +302,13 @@ class GrapeWrk:
             raise ValueError("no controls in trajectories: cannot optimize")  # workspace.jl:155-157
         if "J_T" not in self.kwargs:
             raise ValueError("`optimize` for `method=GRAPE` must be passed the functional `J_T`.")  # :298-303
+        if any(t.prop_callback is not None for t in self.trajectories) and self.kwargs.get("lambda_b", 1.0) != 0.0 and \
+                (self.kwargs.get("g_b") is not None or self.kwargs.get("state_penalty") is not None):
+            # the reference calls a backward callback right after prop_step!, BEFORE the xi term of the running cost is added to
+            # the state (src/optimize.jl:973-985); the stored backward states the callbacks are synthesised from already hold
+            # that term (round-5 advisor finding): refused rather than handed different states than upstream
+            raise ValueError("per-step propagation callbacks cannot be combined with a state running cost (g_b / state_penalty) "
+                             "on the HIP path: the stored backward states already include the xi term")
         L, N_T, K = len(self.controls), len(self.tlist) - 1, len(self.trajectories)
         self.L, self.N_T, self.K = L, N_T, K
         # pulsevals = vcat(discretize_on_midpoints(ctrl, tlist)...)   (workspace.jl:159-162)
@@ -323,6 +385,21 @@ class GrapeWrk:
                 op = [o for o, cc in zip(t.generator.ops, t.generator.controls) if cc is c]
                 ops.append(sum(op) if op else np.zeros_like(t.generator.drift))
             per_traj.append(np.stack(ops))
+        # time-dependent terms that are not controls (FixedAmplitude): one pseudo-control per amplitude object, behind the
+        # optimised ones; its operator per trajectory, its pulse values fixed here
+        fixed_amps = []
+        for t in trajs:
+            for _, a in (t.generator.fixed or []):
+                if not any(a is b for b in fixed_amps):
+                    fixed_amps.append(a)
+        if fixed_amps:
+            for i, t in enumerate(trajs):
+                extra = []
+                for a in fixed_amps:
+                    op = [o for o, aa in (t.generator.fixed or []) if aa is a]
+                    extra.append(sum(op) if op else np.zeros_like(t.generator.drift))
+                per_traj[i] = np.concatenate([per_traj[i], np.stack(extra)])
+            fixed_vals = np.stack([discretize_on_midpoints(a.values, self.tlist) for a in fixed_amps])
         Hc = np.stack(per_traj)
         if all(np.array_equal(Hc[0], h) for h in Hc[1:]):
             Hc = Hc[0]
@@ -339,7 +416,7 @@ class GrapeWrk:
                 if len(shaped) != len(found) or any(not np.array_equal(vals[0], v) for v in vals[1:]):
                     raise ValueError("a control must enter every term with the same shape")
                 if shape is None:
-                    shape = np.ones((self.L, self.N_T))
+                    shape = np.ones((self.L + len(fixed_amps), self.N_T))
                 shape[l] = vals[0]
         method = {"gradgen": api.GRAD_GRADGEN, "taylor": api.GRAD_TAYLOR}.get(
             self.kwargs.get("gradient_method", "gradgen"))
@@ -377,6 +454,9 @@ class GrapeWrk:
             wrap = lambda b: inner_wrap(_CustomChiBackend(b, J_T, self.kwargs["chi"], trajs))  # noqa: E731
         # trajectories without a target_state (optimize.jl:753: tau = NaN; legal with a user-defined J_T / chi): no target
         # array crosses the boundary.  A mix of trajectories with and without one keeps zeros in the gaps.
+        if fixed_amps:       # innermost (directly on the handle): every other wrapper sees a backend of the L optimised controls
+            outer_wrap_pc = wrap
+            wrap = lambda b: outer_wrap_pc(_PseudoControlBackend(b, fixed_vals, self.L, self.N_T))  # noqa: E731
         if custom and all(t.target_state is None for t in trajs):
             targets = None
         else:

@@ -91,7 +91,7 @@ typedef enum {
                               (grape_get_work[12]).                                                                */
     GRAPE_PROP_SERIES = 1  /* matrix-free polynomial propagator on the state vector (the role of the reference's
                               Cheby / Newton methods, README.md:55), no U: N <= 64 power series of exp(-i H_n dt_n) Psi
-                              summed to prop_tolerance, O(N^2) per term; 64 < N <= 256 cooperative Chebyshev sweeps
+                              summed to prop_tolerance, O(N^2) per term; 64 < N <= 512 cooperative Chebyshev sweeps
                               (Hermitian generators, guaranteed spectral interval) or Taylor sub-steps              */
 } grape_prop_method;
 
@@ -263,7 +263,9 @@ int grape_reset_timings(grape_handle *h);
  * per trajectory (csrc/asm/gen_t16p.py: Hermitian generators, up to four controls; GRAPE_EXPM_ASM16P=0), 4 the same for general matrices (gen_t18gp.py: one or two controls),
  * [15] the derivative kernel of the ExpProp route: 0 a compiled kernel, 1 deriv3_asm (49 <= N <= 64, Hermitian, L <= 2),
  * 2 deriv3s_asm (3 <= L <= 8, controls streamed through the LDS), 3 deriv3g_asm (general drift / controls), 4 deriv4_asm
- * (64 < N <= 256), [16] 1 if the products of the blocked polynomial route are the assembly kernel lg_gemm_asm
+ * (64 < N <= 256), [16] 1 if the products of the blocked polynomial route are the assembly kernel lg_gemm_asm,
+ * [17] the steps of the two sweeps that the walks of the exponential kernel carried in the last evaluation (the sweep
+ * launch did the remaining 2 K N_T - [17])
  * (entries beyond n are not written). */
 int grape_get_work(grape_handle *h, double *out, int n);
 

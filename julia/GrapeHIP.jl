@@ -1,4 +1,4 @@
-# GrapeHIP.jl -- thin `ccall` glue between GRAPE.jl and libgrape_hip.so (include/grape_hip.h, ABI v5).
+# GrapeHIP.jl -- thin `ccall` glue between GRAPE.jl and libgrape_hip.so (include/grape_hip.h, ABI v6).
 #
 # NOT EXECUTED in this repository's CI: the build image has no Julia toolchain.  It is written
 # against the C ABI and the reference's own interfaces and shows exactly what a GRAPE.jl maintainer
@@ -10,7 +10,7 @@ module GrapeHIP
 using LinearAlgebra
 import QuantumControl
 import QuantumControl.QuantumPropagators
-using QuantumControl.QuantumPropagators.Controls: discretize_on_midpoints
+using QuantumControl.QuantumPropagators.Controls: discretize_on_midpoints, evaluate, get_controls
 using QuantumControl.QuantumPropagators.Amplitudes: ShapedAmplitude
 using QuantumControl.Functionals: J_T_sm, J_T_ss, J_T_re
 
@@ -56,6 +56,12 @@ mutable struct Handle
     K::Int
     N::Int
     functional::Int          # -1: user-supplied J_T / chi (split-phase calls + grape_backward_chi)
+    no_target::Vector{Int}   # trajectories without a target_state: tau_vals[k] = NaN on the host (optimize.jl:753)
+    L::Int                   # optimised controls (length(wrk.controls))
+    N_T::Int
+    fixed::Vector{Float64}   # pulse values of the pseudo-controls ([P*N_T], control-major; empty: none), see problem_arrays
+    x_full::Vector{Float64}  # [(L+P)*N_T] staging: wrk.pulsevals followed by `fixed`
+    G_full::Vector{Float64}  # [(L+P)*N_T] staging of the gradient (the first L*N_T entries are the caller's)
 end
 
 last_error(ptr) = unsafe_string(ccall((:grape_last_error, libgrape), Cstring, (Ptr{Cvoid},), ptr))
@@ -89,28 +95,48 @@ control_of(a) = a
 control_of(a::ShapedAmplitude) = a.control
 
 """
-    H0, Hc, hc_per_traj, shape = problem_arrays(wrk)
+    H0, Hc, hc_per_traj, shape, fixed = problem_arrays(wrk)
 
 Drift `H0[k]` of every trajectory, the operator `Hc[k][l]` = ∂H_k/∂ϵ_l multiplying control `l` of `wrk.controls`
 (src/workspace.jl:152-157; a control that enters a generator through several amplitudes gets the sum of their
 operators), and the static shapes `S_l(t_n)` of `ShapedAmplitude`s discretised on the midpoints of the time grid
 (docs/src/tutorial.md:75-107) -- `nothing` if no amplitude is shaped.  Control amplitudes that depend non-linearly on
 their control are not expressible in `grape_problem` (INTEGRATION.md: host-side chain rule).
+
+A time-dependent amplitude that is NOT a control (`get_controls(a) == ()`: the reference re-evaluates the generator on
+every interval, `evaluate(a, tlist, n)`, src/optimize.jl:732, 881, 937-945) becomes a PSEUDO-CONTROL: an extra operator
+slot `L + j` in every `Hc[k]` and a row of fixed pulse values in `fixed` ([N_T, P]); `make_fg!` appends those values to
+every pulse vector and drops the pseudo-controls' rows of the gradient.  (`grape_problem.H0` is one constant matrix per
+trajectory; the library limits L + P to 8.)
 """
 function problem_arrays(wrk)
     tlist, controls = wrk.result.tlist, wrk.controls
     K, L, N_T = length(wrk.trajectories), length(controls), length(tlist) - 1
+    # pass 1: the amplitudes without a control, by identity, in order of first appearance
+    fixed_amps = Any[]
+    for traj in wrk.trajectories
+        for a in split_generator(traj.generator)[3]
+            isempty(get_controls(a)) && !any(b -> b === a, fixed_amps) && push!(fixed_amps, a)
+        end
+    end
+    P = length(fixed_amps)
+    fixed = Float64[real(evaluate(a, tlist, n)) for n = 1:N_T, a in fixed_amps]   # [N_T, P]
     H0 = Matrix{ComplexF64}[]
     Hc = Vector{Matrix{ComplexF64}}[]
-    shape = ones(Float64, N_T, L)
+    shape = ones(Float64, N_T, L + P)
     shaped = false
     for traj in wrk.trajectories
         drift, ops, amps = split_generator(traj.generator)
         n = size(drift, 1)
-        per_l = [zeros(ComplexF64, n, n) for _ = 1:L]
+        per_l = [zeros(ComplexF64, n, n) for _ = 1:(L + P)]
         for (op, a) in zip(ops, amps)
+            j = findfirst(b -> b === a, fixed_amps)
+            if !isnothing(j)
+                per_l[L + j] .+= op
+                continue
+            end
             l = findfirst(c -> c === control_of(a), controls)
-            isnothing(l) && error("GrapeHIP: amplitude of type $(typeof(a)) is not a (shaped) control of the problem")
+            isnothing(l) && error("GrapeHIP: amplitude of type $(typeof(a)) is neither a (shaped) control of the problem nor control-free")
             per_l[l] .+= op
             if a isa ShapedAmplitude
                 shape[:, l] .= discretize_on_midpoints(a.shape, tlist)
@@ -121,7 +147,7 @@ function problem_arrays(wrk)
         push!(Hc, per_l)
     end
     hc_per_traj = any(Hc[k] != Hc[1] for k = 2:K)
-    return H0, Hc, hc_per_traj, (shaped ? shape : nothing)
+    return H0, Hc, hc_per_traj, (shaped ? shape : nothing), fixed
 end
 
 """J_T_sm / J_T_ss / J_T_re have a device-side χ (fast path); any other functional goes through `grape_backward_chi`."""
@@ -147,14 +173,17 @@ one handle -- the analogue of `use_threads` (optimize.jl:720, 876).
 function Handle(wrk; device = 0, devices = nothing, prop_method = 0, D = nothing)
     tlist = Vector{Float64}(wrk.result.tlist)
     kw = wrk.kwargs
-    H0, Hc, hc_per_traj, shape = problem_arrays(wrk)
+    H0, Hc, hc_per_traj, shape, fixed = problem_arrays(wrk)
     K, N, L, N_T = length(H0), size(H0[1], 1), length(wrk.controls), length(tlist) - 1
+    P = size(fixed, 2)                                                      # pseudo-controls behind the L optimised ones
     H0f = reduce(hcat, vec.(H0))                                            # [N*N, K]: K column-major matrices
     Hcf = hc_per_traj ? reduce(hcat, [reduce(hcat, vec.(Hc[k])) for k = 1:K]) : reduce(hcat, vec.(Hc[1]))
     p0 = reduce(hcat, [Vector{ComplexF64}(t.initial_state) for t in wrk.trajectories])
-    # trajectories without a target_state (optimize.jl:753: tau = NaN, legal with a user J_T): no target array at all
-    has_tgt = all(t -> !isnothing(t.target_state), wrk.trajectories)
-    tg = has_tgt ? reduce(hcat, [Vector{ComplexF64}(t.target_state) for t in wrk.trajectories]) : nothing
+    # trajectories without a target_state (optimize.jl:753: tau_k = NaN for THOSE k only, legal with a user J_T): no target
+    # array at all when no trajectory has one; otherwise zeros in the gaps and tau_vals[k] = NaN set on the host (make_fg!)
+    no_target = findall(t -> isnothing(t.target_state), wrk.trajectories)
+    tg = length(no_target) == K ? nothing :
+         reduce(hcat, [isnothing(t.target_state) ? zeros(ComplexF64, N) : Vector{ComplexF64}(t.target_state) for t in wrk.trajectories])
     weights = Float64[hasproperty(t, :weight) ? t.weight : 1.0 for t in wrk.trajectories]
     shp = isnothing(shape) ? nothing : Matrix{Float64}(shape)               # [N_T, L] column-major == [l][n]
     Df = isnothing(D) ? nothing : (D isa AbstractMatrix ? Matrix{ComplexF64}(D) : reduce(hcat, vec.(Matrix{ComplexF64}.(D))))
@@ -162,7 +191,7 @@ function Handle(wrk; device = 0, devices = nothing, prop_method = 0, D = nothing
     functional = functional_code(kw[:J_T])
     keep = Any[H0f, Hcf, p0, tg, tlist, weights, shp, Df, devs]
     prob = Ref(GrapeProblem(
-        ABI_VERSION, N, L, K, 0, N_T, max(functional, 0),
+        ABI_VERSION, N, L + P, K, 0, N_T, max(functional, 0),
         get(kw, :gradient_method, :gradgen) == :taylor ? 1 : 0, hc_per_traj ? 1 : 0, device,
         pointer(tlist), pointer(H0f), pointer(Hcf), isnothing(shp) ? C_NULL : pointer(shp), pointer(p0), isnothing(tg) ? C_NULL : pointer(tg),
         pointer(weights), get(kw, :chi_min_norm, 0.0), get(kw, :taylor_grad_max_order, 0),
@@ -173,7 +202,8 @@ function Handle(wrk; device = 0, devices = nothing, prop_method = 0, D = nothing
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = GC.@preserve keep ccall((:grape_create, libgrape), Cint, (Ref{Ptr{Cvoid}}, Ref{GrapeProblem}), out, prob)
     rc == 0 || error(last_error(C_NULL))
-    h = Handle(out[], keep, K, N, functional)
+    h = Handle(out[], keep, K, N, functional, no_target, L, N_T, vec(fixed), zeros(Float64, (L + P) * N_T), zeros(Float64, (L + P) * N_T))
+    h.x_full[(L * N_T + 1):end] .= h.fixed
     finalizer(x -> ccall((:grape_destroy, libgrape), Cvoid, (Ptr{Cvoid},), x.ptr), h)
     # caller-supplied chi (functional == -1) or xi (a g_b that is not given as the operator D): the backward sweep runs
     # when that data arrives -- the forward call must not run a (unit-target) backward sweep in the same launch
@@ -236,10 +266,16 @@ function make_fg!(h::Handle, wrk)
         else
             wrk.result.fg_calls += 1; wrk.fg_count[1] += 1                 # :838-839
         end
-        x, tau = wrk.pulsevals, wrk.result.tau_vals
+        tau = wrk.result.tau_vals
+        # pseudo-controls (problem_arrays): the library sees L + P controls -- the fixed pulse values ride behind the caller's,
+        # and the gradient lands in a staging vector whose first L*N_T entries are the caller's rows
+        pseudo = !isempty(h.fixed)
+        pseudo && copyto!(h.x_full, 1, wrk.pulsevals, 1, h.L * h.N_T)
+        x = pseudo ? h.x_full : wrk.pulsevals
+        Gbuf = pseudo ? h.G_full : wrk.grad_J_Tb
         if h.functional >= 0 && xi_route
             # built-in J_T with a g_b given as callbacks: split-phase calls, xi on the host
-            check(h, GC.@preserve x tau ccall((:grape_forward, libgrape), Cint,
+            check(h, GC.@preserve x tau h ccall((:grape_forward, libgrape), Cint,
                 (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}), h.ptr, pointer(x), pointer(tau)))
             check(h, ccall((:grape_get_final_states, libgrape), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), h.ptr, psiT))
             check(h, ccall((:grape_get_sums, libgrape), Cint, (Ptr{Cvoid}, Ptr{Float64}), h.ptr, sums))
@@ -248,15 +284,15 @@ function make_fg!(h::Handle, wrk)
             wrk.J_parts[3] = λ_b * J_b_and_xi!(!isnothing(G))
             if !isnothing(G)
                 f_total = Float64[sums[1], sums[2]]                        # Σ_k w_k τ_k of this (unsharded) handle
-                check(h, GC.@preserve f_total xi_arr wrk ccall((:grape_backward_xi, libgrape), Cint,
+                check(h, GC.@preserve f_total xi_arr wrk h ccall((:grape_backward_xi, libgrape), Cint,
                     (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Cdouble, Ptr{Float64}),
-                    h.ptr, pointer(f_total), C_NULL, pointer(xi_arr), λ_b, pointer(wrk.grad_J_Tb)))
+                    h.ptr, pointer(f_total), C_NULL, pointer(xi_arr), λ_b, pointer(Gbuf)))
             end
         elseif h.functional >= 0
             # built-in functional: one call, χ is formed on the device
             J = Ref{Float64}(0.0)
-            Gp = isnothing(G) ? Ptr{Float64}(C_NULL) : pointer(wrk.grad_J_Tb)
-            rc = GC.@preserve x tau psiT wrk ccall((:grape_eval, libgrape), Cint,
+            Gp = isnothing(G) ? Ptr{Float64}(C_NULL) : pointer(Gbuf)
+            rc = GC.@preserve x tau psiT wrk h ccall((:grape_eval, libgrape), Cint,
                 (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}),
                 h.ptr, pointer(x), J, Gp, pointer(tau), pointer(psiT))
             check(h, rc)
@@ -270,7 +306,7 @@ function make_fg!(h::Handle, wrk)
         else
             # user-supplied J_T / chi (optimize.jl:757-760, 845-855): forward on the device, J_T and χ(T) on the host,
             # backward sweep and gradient on the device from the χ the user's function returns
-            check(h, GC.@preserve x tau ccall((:grape_forward, libgrape), Cint,
+            check(h, GC.@preserve x tau h ccall((:grape_forward, libgrape), Cint,
                 (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}), h.ptr, pointer(x), pointer(tau)))
             check(h, ccall((:grape_get_final_states, libgrape), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), h.ptr, psiT))
             Ψ = states()
@@ -286,15 +322,19 @@ function make_fg!(h::Handle, wrk)
                     chiT[:, k] .= χ[k]
                 end
                 if xi_route
-                    check(h, GC.@preserve chiT xi_arr wrk ccall((:grape_backward_xi, libgrape), Cint,
+                    check(h, GC.@preserve chiT xi_arr wrk h ccall((:grape_backward_xi, libgrape), Cint,
                         (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Cdouble, Ptr{Float64}),
-                        h.ptr, C_NULL, pointer(chiT), pointer(xi_arr), λ_b, pointer(wrk.grad_J_Tb)))
+                        h.ptr, C_NULL, pointer(chiT), pointer(xi_arr), λ_b, pointer(Gbuf)))
                 else
-                    check(h, GC.@preserve chiT wrk ccall((:grape_backward_chi, libgrape), Cint,
-                        (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}), h.ptr, pointer(chiT), pointer(wrk.grad_J_Tb)))
+                    check(h, GC.@preserve chiT wrk h ccall((:grape_backward_chi, libgrape), Cint,
+                        (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}), h.ptr, pointer(chiT), pointer(Gbuf)))
                 end
             end
         end
+        for k in h.no_target                                               # :753 -- only the trajectories without a target
+            tau[k] = NaN
+        end
+        (pseudo && !isnothing(G)) && copyto!(wrk.grad_J_Tb, 1, h.G_full, 1, h.L * h.N_T)
         if !isnothing(J_a)
             wrk.J_parts[2] = λₐ * J_a(wrk.pulsevals, tlist)                # :761-763
         end

@@ -19,7 +19,9 @@ const FUNCTIONALS = (J_T_sm, J_T_ss, J_T_re)          # codes 0, 1, 2 of include
 function reference_outputs(path; gradient_method = :gradgen)
     z = npzread(path)
     H0, Hc, tlist = z["H0"], z["Hc"], Vector{Float64}(z["tlist"])       # H0[k, i, j], Hc[l, i, j] (row, column)
-    K, N, L, N_T = size(H0, 1), size(H0, 2), size(Hc, 1), length(tlist) - 1
+    per_traj = ndims(Hc) == 4                                            # Hc[k, l, i, j]: control operators per trajectory
+    hc(k, l) = Matrix{ComplexF64}(per_traj ? Hc[k, l, :, :] : Hc[l, :, :])
+    K, N, L, N_T = size(H0, 1), size(H0, 2), size(Hc, per_traj ? 2 : 1), length(tlist) - 1
     pulses = reshape(Vector{Float64}(z["pulsevals"]), N_T, L)            # control-major: column l = control l
     # one control per l, given by its values on the N_T intervals (discretize_on_midpoints keeps such a vector as it is,
     # src/workspace.jl:162); the SAME vector object in every trajectory, so that get_controls finds L controls
@@ -28,7 +30,7 @@ function reference_outputs(path; gradient_method = :gradgen)
     trajectories = [
         Trajectory(
             Vector{ComplexF64}(z["psi0"][k, :]),
-            hamiltonian(Matrix{ComplexF64}(H0[k, :, :]), [(Matrix{ComplexF64}(Hc[l, :, :]), controls[l]) for l = 1:L]...);
+            hamiltonian(Matrix{ComplexF64}(H0[k, :, :]), [(hc(k, l), controls[l]) for l = 1:L]...);
             target_state = Vector{ComplexF64}(z["target"][k, :]), weight = weights[k]
         ) for k = 1:K
     ]

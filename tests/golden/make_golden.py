@@ -31,7 +31,39 @@ def save(name, pr, functional=0, **extra):
     print(name, J, np.abs(G).max())
 
 
+def compact(pr, bits=10):
+    """Round the operators to multiples of 2^-bits (Hermitian structure kept: the rounding is elementwise and odd): the
+    doubles of a fixture then carry a few significant bits and the archive compresses to about a quarter -- what keeps
+    the N = 64 / N = 100 fixtures near 100 KB.  Inputs are exact dyadic rationals, so every consumer (numpy, C, Julia)
+    reads the same numbers."""
+    q = float(2 ** bits)
+    for key in ("H0", "Hc"):
+        a = pr[key]
+        pr[key] = (np.round(a.real * q) + 1j * np.round(a.imag * q)) / q
+    return pr
+
+
+def headline_kernel_fixtures():
+    """Round 6: fixtures that REACH the hand-written kernels (the fixtures above all have N <= 20, i.e. compiled kernels
+    only): N = 64 Hermitian -> expm_t16_asm + deriv3_asm, N = 64 general -> expm_t18g_asm + deriv3g_asm, N = 64 with
+    control operators per trajectory -> expm_t16p_asm, N = 100 -> the blocked path (lg_gemm_asm, deriv4_asm_128).
+    tests/test_gpu_parity.py::test_golden_fixtures_reach_the_assembly_kernels asserts which kernel ran;
+    julia/make_reference_fixtures.jl would pin exactly these kernels to GRAPE.jl the day someone runs it."""
+    save("n64_l2_k2_sm_herm", compact(synth.make_problem(64, 2, 8, 2, seed=601)), 0)
+    pr = compact(synth.make_problem(64, 2, 6, 2, seed=602, hermitian=False))
+    pr["weights"] = np.array([0.75, 1.25])
+    save("n64_l2_k2_re_nonherm", pr, 2)
+    pr = synth.make_problem(64, 2, 5, 3, seed=603)
+    rng = np.random.default_rng(603)
+    pr["Hc"] = np.stack([pr["Hc"] * (1.0 + 0.05 * rng.standard_normal()) for _ in range(3)])   # [K, L, N, N]
+    save("n64_l2_k3_sm_pertraj", compact(pr, bits=7), 0)
+    save("n100_l2_k2_ss", compact(synth.make_problem(100, 2, 4, 2, seed=604), bits=8), 1)
+
+
 if __name__ == "__main__":
+    if "--headline" in sys.argv:     # only the round-6 fixtures (the older ones are left as committed)
+        headline_kernel_fixtures()
+        sys.exit(0)
     # C1: the README problem at the guess pulse; closed form J_T = 1 - (0.04/1.04) sin^2(5 sqrt(1.04))
     save("c1_readme_tls", synth.readme_tls(), J_closed_form=1.0 - (0.04 / 1.04) * np.sin(5.0 * np.sqrt(1.04)) ** 2)
     # small dense ensembles, all three functionals, ragged N (padding), non-Hermitian, non-uniform grid
@@ -42,3 +74,4 @@ if __name__ == "__main__":
     pr["weights"] = np.array([0.7, 1.3])
     save("n16_l2_k2_re_nonherm_nonuniform", pr, 2)
     save("n20_l3_k2_sm_dt3", synth.make_problem(20, 3, 4, 2, seed=104, dt=3.0), 0)
+    headline_kernel_fixtures()

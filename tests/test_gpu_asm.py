@@ -367,6 +367,51 @@ def test_walks_against_the_sweeps(g, N, L, N_T, K, kw):
     assert np.abs(a[3] - b[3]).max() <= 1e-13 and np.abs(a[4] - b[4]).max() <= 1e-13
 
 
+_ORACLE_CACHE = {}
+
+
+@pytest.mark.parametrize("N,L,N_T,K,herm,kw", [
+    (64, 2, 11, 4, True, {}),                       # the review's size: the literal oracle well under a second
+    (64, 2, 3, 300, True, {}),                      # more trajectories than workgroups: walks cross into the next trajectory
+    (57, 1, 9, 130, True, {"functional": 1}),
+    (64, 2, 4, 128, True, {"functional": 2}),       # the headline deal (two anchored walks per trajectory)
+    (64, 2, 9, 5, False, {}),                       # general matrices: the walks of expm_t18g_asm (transposed cells)
+    (60, 2, 4, 140, False, {"functional": 2}),
+])
+@pytest.mark.parametrize("walk", [3, 1, 2, 0], ids=["both", "ascending", "descending", "sweeps_only"])
+def test_walks_against_the_c_oracle(g, ref, N, L, N_T, K, herm, kw, walk):
+    """every walk mode of the assembly exponentials -- states carried from both ends, from one end, not at all -- against the
+    ORACLE (oracle/grape_ref.c, the reference's literal :gradgen route): J, tau, G and the per-cell overlaps tau_grads at
+    SURVEY 8c's tolerances.  (Round-5 review: the walks had only been compared with the sweeps of the same library.)"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=11 + N + K, hermitian=herm)
+    pr["weights"] = 0.5 + np.random.default_rng(3).random(K)
+    f = kw.get("functional", 0)
+    old = os.environ.get("GRAPE_EXPM_WALK")
+    os.environ["GRAPE_EXPM_WALK"] = str(walk)
+    try:
+        with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], functional=f) as h:
+            J, G, tau = h.eval(pr["pulsevals"])
+            tg, w = h.tau_grads(), h.work()
+    finally:
+        if old is None:
+            os.environ.pop("GRAPE_EXPM_WALK", None)
+        else:
+            os.environ["GRAPE_EXPM_WALK"] = old
+    assert int(w["asm_kernel"]) == (1 if herm else 2)
+    # grape_get_work[17]: the steps the walks carried -- none without walks, at most one sweep's worth per enabled direction
+    n_dir = (walk & 1) + ((walk >> 1) & 1)
+    assert (w["walk_steps"] == 0) if walk == 0 else (0 < w["walk_steps"] <= n_dir * K * N_T)
+    key = (N, L, N_T, K, herm, f)
+    if key not in _ORACLE_CACHE:      # (the literal route costs ~60 ms per cell and core: once per problem, not per walk mode)
+        _ORACLE_CACHE[key] = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"],
+                                          pr["weights"], functional=f, gradient_method=ref.GRADGEN, want_parts=True)
+    Jr, Gr, taur, parts = _ORACLE_CACHE[key]
+    assert abs(J - Jr) <= 1e-12 and np.abs(tau - taur).max() <= 1e-12
+    assert np.abs(G - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)
+    assert np.abs(tg - parts["tau_grads"]).max() <= 1e-10 * max(np.abs(parts["tau_grads"]).max(), 1e-3)
+
+
 def test_walks_stop_at_cells_the_four_product_route_hands_over(g):
     """a sixth of the steps beyond the spectral bound: the walk of a trajectory ends at the first such cell, the
     five-product launch redoes the cell, the sweep picks up in front of it"""
@@ -531,7 +576,7 @@ def test_a_hermitian_generator_that_is_not_finite_is_an_error_not_a_hang(g, N):
 
 @pytest.mark.parametrize("herm,L", [(True, 2), (True, 1), (True, 3), (True, 4), (True, 5), (False, 2), (False, 1), (False, 3)],
                          ids=["hermitian_L2", "hermitian_L1", "hermitian_L3", "hermitian_L4", "hermitian_L5", "general_L2", "general_L1", "general_L3"])
-def test_control_operators_per_trajectory_take_the_assembly_cells(g, herm, L):
+def test_control_operators_per_trajectory_take_the_assembly_cells(g, ref, herm, L):
     """Round 5: control operators per trajectory (the ensemble of a robustness problem).  Hermitian generators with up to four
     controls (general ones with up to two): expm_t16p_asm / expm_t16p4_asm (expm_t18gp_asm) fetch the operators of their
     trajectory themselves (work[14] = 3 (4)).  More controls: the controls of every CELL are summed once per evaluation ([KC][N_T] blocks) and the assembly cells read block
@@ -577,5 +622,13 @@ def test_control_operators_per_trajectory_take_the_assembly_cells(g, herm, L):
     for k, n in [(0, 0), (3, N_T - 1)]:
         e = pr["pulsevals"].reshape(L, N_T)[:, n]
         H = H0[k] + sum(e[l] * Hc[k, l] for l in range(L))
-        ref = expm(-1j * (pr["tlist"][n + 1] - pr["tlist"][n]) * H)
-        assert np.abs(a[3][k * N_T + n] - ref).max() < 1e-13 * max(1.0, np.abs(ref).max())
+        Uref = expm(-1j * (pr["tlist"][n + 1] - pr["tlist"][n]) * H)
+        assert np.abs(a[3][k * N_T + n] - Uref).max() < 1e-13 * max(1.0, np.abs(Uref).max())
+    # ... and EVERY mode against the oracle (round-5 review: a twin test finds divergence, not a shared mistake): the
+    # literal route of the reference, dense (L+1)N block exponential per backward step, at SURVEY 8c's tolerances
+    Jr, Gr, taur = ref.evaluate(H0, Hc, pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                gradient_method=ref.GRADGEN)
+    for name, o in out.items():
+        assert abs(o[0] - Jr) <= 1e-12, name
+        assert np.abs(o[2] - taur).max() <= 1e-12, name
+        assert np.abs(o[1] - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3), name

@@ -554,3 +554,99 @@ def test_captured_graph_replays_the_evaluation_bit_for_bit(g, monkeypatch, N, L,
             with pytest.raises(g.GrapeHipError) as ei:
                 h.eval(x)
             assert ei.value.code == -3
+
+
+def test_exception_inside_a_shard_thread_stops_at_the_barrier(g, monkeypatch):
+    """round-5 advisor finding: the exception barrier of the entry points did not cover WORKER threads -- a std::bad_alloc
+    inside a shard's enqueue thread (or inside a parallel_for worker of grape_create) left the thread function and ended
+    the process in std::terminate.  Injected here in the last shard's thread of a composite handle's evaluation and in a
+    worker of grape_create: both come back as GRAPE_ERR_HOST with a message, the process lives, the next call works."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(24, 2, 12, 6, seed=19)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    monkeypatch.setenv("GRAPE_TEST_HOOKS", "1")
+    monkeypatch.setenv("GRAPE_TEST_THROW_AT", "none")
+    monkeypatch.setenv("GRAPE_TEST_THROW", "bad_alloc")
+    with g.GrapeHip(*args, devices=[0, 0, 0]) as h:           # three shards on this box's one GPU, one host thread each
+        J0, G0, _ = h.eval(pr["pulsevals"])
+        monkeypatch.setenv("GRAPE_TEST_THROW_AT", "shard")
+        with pytest.raises(g.GrapeHipError) as ei:
+            h.eval(pr["pulsevals"])
+        assert ei.value.code == -8 and "bad_alloc" in str(ei.value)
+        monkeypatch.setenv("GRAPE_TEST_THROW_AT", "none")
+        J1, G1, _ = h.eval(pr["pulsevals"])                   # the handle is still usable
+        assert J1 == J0 and np.array_equal(G1, G0)
+    # a worker thread of grape_create's host-side set-up (operator norms of a general problem: parallel_for)
+    prn = synth.make_problem(40, 2, 6, 8, seed=20, hermitian=False)
+    monkeypatch.setenv("GRAPE_TEST_THROW_AT", "worker")
+    monkeypatch.setenv("GRAPE_TEST_THROW", "a worker failed")
+    with pytest.raises(g.GrapeHipError) as ei:
+        g.GrapeHip(prn["H0"], prn["Hc"], prn["tlist"], prn["psi0"], prn["target"], prn["weights"])
+    assert ei.value.code == -8 and "a worker failed" in str(ei.value)
+    monkeypatch.delenv("GRAPE_TEST_HOOKS")
+    with g.GrapeHip(prn["H0"], prn["Hc"], prn["tlist"], prn["psi0"], prn["target"], prn["weights"]) as h:
+        assert np.isfinite(h.eval(prn["pulsevals"])[0])
+
+
+@pytest.mark.parametrize("N", [16, 40, 64])
+def test_gradgen_never_accepts_an_unconverged_series(g, monkeypatch, N):
+    """round-5 advisor finding: taylor_grad_check_convergence = false belongs to gradient_method = :taylor
+    (optimize.jl:917-918); :gradgen shares the series kernels and their non-convergence flag, and the switch used to
+    silence a :gradgen series that had not converged -- a wrong gradient with GRAPE_OK.  A tolerance no term can reach
+    forces the non-convergence: :gradgen reports it whatever the switch says."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, 2, 6, 3, seed=5)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    monkeypatch.setenv("GRAPE_GRADGEN_TOL", "-1")
+    for check in (True, False):
+        with g.GrapeHip(*args, gradient_method=g.GRAD_GRADGEN, taylor_check_convergence=check) as h:
+            with pytest.raises(g.GrapeHipError) as ei:
+                h.eval(pr["pulsevals"])
+            assert ei.value.code == -5
+    monkeypatch.delenv("GRAPE_GRADGEN_TOL")
+    with g.GrapeHip(*args, gradient_method=g.GRAD_GRADGEN, taylor_check_convergence=False) as h:
+        assert np.isfinite(h.eval(pr["pulsevals"])[1]).all()
+
+
+@pytest.mark.parametrize("N,L,K,herm,custom", [(8, 1, 2, True, False), (64, 2, 3, True, False), (20, 2, 2, False, True)])
+def test_time_dependent_term_that_is_not_a_control_rides_as_a_pseudo_control(g, ref, N, L, K, herm, custom):
+    """A generator term with a time-dependent coefficient that is NOT optimised (an amplitude whose get_controls is empty;
+    the reference re-evaluates the generator on every interval, optimize.jl:732, 881, 937-945) crosses the boundary as a
+    pseudo-control: extra operator, fixed pulse values, its gradient rows dropped (FixedAmplitude).
+    Against the oracle with the drive written out as an (L+1)-th control: J, tau and the L optimised rows of G."""
+    from grape_jl_amd import grape as G_, synth
+    N_T = 9
+    pr = synth.make_problem(N, L + 1, N_T, K, seed=77 + N, hermitian=herm)
+    tl = pr["tlist"]
+    drive = lambda t: 0.3 * np.cos(0.7 * t) - 0.1                                     # noqa: E731
+    x_opt = pr["pulsevals"][:L * N_T].copy()
+    ctrls = [x_opt[l * N_T:(l + 1) * N_T].copy() for l in range(L)]
+    amp = G_.FixedAmplitude(drive)
+    trajs = [G_.Trajectory(pr["psi0"][k], G_.hamiltonian(pr["H0"][k], *[(pr["Hc"][l], ctrls[l]) for l in range(L)],
+                                                         (pr["Hc"][L], amp)), target_state=pr["target"][k]) for k in range(K)]
+    kw = {}
+    if custom:
+        J_T, chi = observable_functional(N, K, seed=3)
+        kw = dict(J_T=J_T, chi=chi)
+    else:
+        kw = dict(J_T=G_.J_T_sm)
+    wrk = G_.GrapeWrk(trajs, tl, **kw)
+    assert wrk.L == L and len(wrk.pulsevals) == L * N_T          # the optimiser sees the L controls only
+    Gout = np.zeros(L * N_T)
+    J = G_.evaluate_gradient_b(Gout, wrk.pulsevals, wrk)
+    x_full = np.concatenate([x_opt, G_.discretize_on_midpoints(drive, tl)])
+    if custom:
+        psiT = _final_states(ref, pr, tl, x_full)
+        Gr, taur, _, _ = ref.evaluate_chi(pr["H0"], pr["Hc"], tl, x_full, pr["psi0"], pr["target"], np.stack(chi(list(psiT))))
+        Jr = J_T(list(psiT))
+    else:
+        Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], tl, x_full, pr["psi0"], pr["target"], None)
+    assert abs(J - Jr) <= 1e-12
+    assert np.abs(wrk.result.tau_vals - taur).max() <= 1e-12
+    assert np.abs(Gout - Gr[:L * N_T]).max() <= tol_G(Gr)
+    assert len(Gout) == L * N_T
+
+
+def _final_states(ref, pr, tl, x):
+    _, _, _, parts = ref.evaluate(pr["H0"], pr["Hc"], tl, x, pr["psi0"], pr["target"], None, want_parts=True)
+    return parts["psiT"]

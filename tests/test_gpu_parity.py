@@ -51,6 +51,34 @@ def test_golden_fixtures(g, path, method):
     assert np.abs(tg - z["tau_grads"]).max() <= 1e-12
 
 
+# which hand-written kernels a fixture must reach (grape_get_work[14..16]: exponential cell, derivative kernel, blocked products)
+REACHES = {"n64_l2_k2_sm_herm.npz": dict(asm_kernel=1, asm_deriv_kernel=1),          # expm_t16_asm, deriv3_asm
+           "n64_l2_k2_re_nonherm.npz": dict(asm_kernel=2, asm_deriv_kernel=3),       # expm_t18g_asm, deriv3g_asm
+           "n64_l2_k3_sm_pertraj.npz": dict(asm_kernel=3),                           # expm_t16p_asm
+           "n100_l2_k2_ss.npz": dict(asm_blocked_products=1, asm_deriv_kernel=4)}    # lg_gemm_asm, deriv4_asm_128
+
+
+@pytest.mark.parametrize("name", sorted(REACHES))
+def test_golden_fixtures_reach_the_assembly_kernels(g, name):
+    """the round-6 fixtures exist to pin the HEADLINE kernels (every older fixture has N <= 20 and runs compiled kernels only):
+    each of them must take the hand-written kernel it was made for -- and agree with the fixture's numbers, which
+    julia/make_reference_fixtures.jl would replace by GRAPE.jl's own the day someone runs it"""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    pr = {k: z[k] for k in ("H0", "Hc", "tlist", "pulsevals", "psi0", "target", "weights")}
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"],
+                    functional=int(z["functional"])) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        w = h.work()
+        tg = h.tau_grads()
+    for key, want in REACHES[name].items():
+        assert int(w[key]) == want, (key, w[key], want)
+    if REACHES[name].get("asm_kernel") in (1, 3):
+        assert w["t16_cells"] == w["t18_cells"] > 0        # every cell took the four-product assembly route
+    assert abs(J - z["J"]) <= TOL_J and np.abs(tau - z["tau"]).max() <= TOL_TAU
+    assert np.abs(G - z["G"]).max() <= tol_G(z["G"])
+    assert np.abs(tg - z["tau_grads"]).max() <= 1e-12
+
+
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 def test_reference_outputs_when_present_gpu(g, path):
     """the HIP path against outputs of GRAPE.jl itself (tests/golden/ref_<name>.json, julia/make_reference_fixtures.jl);
@@ -568,17 +596,18 @@ def test_baseline_config_c5_shard_properties(g):
 
 
 def test_bench_contract_two_rank_rehearsal(g):
-    """bench.py under torch.distributed.run with two ranks (rehearsal mode: both ranks on this box's one GPU, gloo
-    collectives; the driver's N > 1 runs use RCCL on one GPU per rank): stdout carries exactly ONE line, a JSON object
-    with the contract's keys, the whole-job value counts both shards, and the roofline block is present."""
+    """PLAIN `python bench.py --gpus 2` -- no launcher in the test (round-5 review: `--gpus` used to be parsed and ignored, so
+    this form ran one rank and printed n_gpus = 1): bench.py starts the two ranks itself, as a child
+    `python -m torch.distributed.run`, before it touches torch or the GPU.  Rehearsal mode: both ranks on this box's one
+    GPU, gloo collectives (the driver's N > 1 runs use RCCL on one GPU per rank).  stdout carries exactly ONE line, a JSON
+    object with the contract's keys; the whole-job value counts both shards; the all-reduce latency is reported."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GRAPE_BENCH_REHEARSAL="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29543", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["GRAPE_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
@@ -590,6 +619,12 @@ def test_bench_contract_two_rank_rehearsal(g):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
     assert d["roofline"]["bound"] == "mfma" and 0.0 < d["roofline"]["frac"] < 1.0
+    assert d["gradient_allreduce_latency_us"] > 0.0
+    assert d["phase_b"]["GB_per_s"] is None or d["phase_b"]["GB_per_s"] <= 8000.0      # never above the HBM peak
+    # a launcher whose WORLD_SIZE disagrees with --gpus: refused before anything is measured
+    env_bad = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=root, env=env_bad)
+    assert bad.returncode != 0 and not bad.stdout.strip() and "WORLD_SIZE" in bad.stderr
 
 
 def test_bench_contract_four_rank_rehearsal_of_config_c4(g):

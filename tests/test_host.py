@@ -1,6 +1,8 @@
 """Host-side mirror of the reference interface (grape.jl_amd/grape.py), CPU only.  The evaluator
 behind fg! is injected: here the oracle stands in for the HIP library so that the optimizer loop,
 result bookkeeping and error behaviour can be checked without a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -236,3 +238,15 @@ def test_propagation_callbacks_are_synthesised_from_the_stored_states():
     assert [s[1] for s in fwd] == list(range(1, N_T + 1)) and [s[1] for s in bwd] == list(range(N_T - 1, -1, -1))
     assert seen.index(bwd[0]) > seen.index(fwd[-1])            # the backward calls follow the forward ones
     assert np.allclose(bwd[0][3], be.bw[0, N_T - 1]) and np.allclose(bwd[-1][3], be.bw[0, 0])
+
+
+def test_bench_gpus_flag_and_world_size_must_agree(tmp_path):
+    """bench.py --gpus N under a launcher that set another WORLD_SIZE is refused before torch is imported (no GPU needed):
+    the JSON line may never carry an n_gpus the caller did not ask for"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], capture_output=True,
+                         text=True, timeout=60, env=env)
+    assert res.returncode == 2 and not res.stdout.strip() and "WORLD_SIZE=4" in res.stderr
