@@ -227,6 +227,18 @@ class Prog:
             self.state += k
             n -= k
 
+    def s_sleep(self, n):
+        """s_sleep n: the wave sleeps ~64 n cycles (1 <= n <= 127); the emulator treats it as a no-op"""
+        assert 1 <= n <= 127
+        self.ins.append(Ins("s_sleep", None, [n], {}, "nop", f"s_sleep {n}", [], []))
+        self.state += 1
+
+    def s_setprio(self, n):
+        """s_setprio n: issue priority of this wave among the waves of its SIMD (0 .. 3); a no-op for the emulator"""
+        assert 0 <= n <= 3
+        self.ins.append(Ins("s_setprio", None, [n], {}, "nop", f"s_setprio {n}", [], []))
+        self.state += 1
+
     def _waits_needed(self, ins):
         """(vmcnt, lgkmcnt) this instruction needs before it may issue, or None"""
         touched = set(ins.reads) | set(ins.writes)

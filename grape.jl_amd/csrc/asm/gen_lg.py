@@ -12,12 +12,20 @@ kernel, which is also the differential twin (GRAPE_LG_ASM=0).
 Why assembly: the compiled kernel loads a 64-wide k-block, synchronises, multiplies, synchronises -- its matrix pipe is
 56.7 % busy (profiles/r03_pmc_summary_C5.json) because nothing is in flight while it multiplies.  Here
 
-  * the left operand's k-blocks (64 rows x 32 columns, re and im) arrive by LDS-DMA into a two-stage ring, one k-block
-    ahead, written lane-linear with the bank swizzle on the SOURCE address (16-byte granule g of row i sits at g ^ (i & 15):
-    the fragment reads of 16 rows x 4 columns are conflict-free);
-  * the right operand's strip (32 rows x this wave's 16 columns) is loaded one k-block ahead into a second register set;
-  * a k-step is 12 matrix instructions, 8 LDS reads and 5 vector additions (the operand sums of the 3M scheme);
+  * BOTH operands' k-blocks (left: 64 rows x 16 columns, right: 16 rows x 64 columns, re and im: 32 KB) arrive by LDS-DMA
+    into a two-stage ring, one k-block ahead, written lane-linear with the bank swizzle on the SOURCE address (left: two
+    matrix rows share a 256-byte LDS row R, granule g at g ^ (R & 15); right: the 128-byte windows of the four waves swap
+    in pairs on odd rows) -- every fragment read is free of bank conflicts;
+  * a k-step is 12 matrix instructions, 10 LDS reads and 5 vector additions (the operand sums of the 3M scheme);
   * two workgroups per CU (128 + 128 registers per lane, 64 KB of LDS each) cover each other's prologue and epilogue.
+
+Round 6 -- the right operand goes through the LDS as well.  Until round 5 every wave loaded its 32 x 16 strip of the right
+operand straight into registers (16 global_load_dwordx2 per k-block).  Measured by duplication (tools/lg_ablate.sh, results
+unchanged, C5 shard, phase A 127.7 ms): the operand sums twice +0.9 ms, the fragment reads twice +1.5, the LDS-DMA requests
+twice +1.4, the barrier twice 0 -- and those sixteen register loads twice +17.3 ms: a global load that RETURNS INTO VECTOR
+REGISTERS stalls the matrix pipe for ~100 cycles (its write-back competes with the operand reads of the running matrix
+instruction), an LDS-DMA request for ~17 and an LDS read for ~2.  So nothing returns into registers from global memory
+inside the k loop any more.
 
 Matrices are whole planar arrays ([cell][re | im][NP][NP], NP = 128 or 256), as the polynomial route passes them.
 
@@ -41,14 +49,28 @@ from gcn import Prog, V, A, S, M0, VCC, EXEC, Neg, Abs, kernel_text  # noqa: E40
 
 KERNARG = 416                    # 168: the product; 8: comb mode; 72: nine pointers; 168: 21 coefficients
 LG_PARTS = 16                    # row parts of the column-sum scratch (grape_large.hip.h); the fused epilogue writes part bi
-STAGE_B = 32768                  # one k-block of the left operand: [re | im][64 rows][32 columns]
+STAGE_B = 32768                  # one k-block: left operand [re | im][32 LDS rows][256 B], right operand [re | im][16 rows][512 B]
+A_PLANE = 8192                   # bytes of a plane of the left operand's k-block (64 rows x 16 columns)
+B_OFF = 2 * A_PLANE              # the right operand's k-block behind it
+B_PLANE = 8192                   # 16 rows x 64 columns
 LDS_BYTES = 2 * STAGE_B
-KSTEPS = 8                       # k-steps (of 4) per k-block
+KSTEPS = 4                       # k-steps (of 4) per k-block of 16
+STAGGER = 0                      # see prologue (set from the measurement of tools/lg_bench.py)
 TLD = 65                         # row stride (doubles) of the transposition plane of the mirrored block
 
 
 class GenLG:
-    def __init__(self, name="lg_gemm_asm"):
+    def __init__(self, name="lg_gemm_asm", ablate=()):
+        # ablate: timing-only variants (tools/lg_ablate.sh).  Removing work changes the numbers, and the route decides its
+        # squarings from them -- so the variants that are measured DUPLICATE an item instead (idempotent: same results, the
+        # slope is the item's cost): "sums2", "lds2", "sync2", "dma2" (left-operand requests), "bload2" (right-operand loads).
+        # ("sums" / "prefetch" / "sync" / "lds" drop the item: results are wrong, kept for stand-alone timing only.)
+        self.ablate = set(a for a in ablate if not a.startswith("stagger"))
+        # s_sleep 127 (~8100 cycles each) in front of the second workgroup of every CU (prologue); "staggerN" overrides
+        self.stagger = STAGGER
+        for a in ablate:
+            if a.startswith("stagger"):
+                self.stagger = int(a[7:])
         self.p = Prog(name)
         self.p.soft_vm_flush = True
         # ---- scalars ----
@@ -61,8 +83,9 @@ class GenLG:
         # sq_iter >= *smax_ptr and writes U when it is the last one needed
         self.s_scell, self.s_sqiter, self.s_sqmode = S(92, 2), S(94), S(95)
         self.s_cell, self.s_bi, self.s_bj, self.s_useu = S(40), S(41), S(42), S(43)
-        self.s_xp, self.s_yp, self.s_yq = S(44, 2), S(46, 2), S(48, 2)
-        self.s_ldsw, self.s_rowstep, self.s_kb, self.s_nkb = S(50), S(51), S(52), S(53)
+        self.s_xp, self.s_yp = S(44, 2), S(46, 2)
+        self.s_bstep, self.s_byadv = S(48), S(49)         # right operand: 2 rows (one piece) / 16 rows (one k-block) in bytes
+        self.s_ldsw, self.s_rowstep, self.s_kb, self.s_nkb = S(50), S(51), S(52), S(53)   # s_rowstep: 8 rows (one piece of the left operand)
         self.s_a, self.s_b = S(54, 2), S(56, 2)
         self.s_t = [S(58 + i) for i in range(8)]
         self.s_save = S(66, 2)
@@ -75,19 +98,21 @@ class GenLG:
         self.s_smaxv = S(88)
         # ---- per-lane ----
         self.v_tid, self.v_lane = V(0), V(1)
-        self.v_AB = [V(2 + r) for r in range(KSTEPS)]
+        self.v_AB = [[V(2 + 2 * r + par) for par in range(2)] for r in range(KSTEPS)]   # [k-step][row tile & 1]
         self.v_GP = [V(10 + k) for k in range(4)]
+        self.v_GPB = V(21)
         self.v_voff = V(14)
         self.v_tw, self.v_tr = V(15), V(16)           # transposition plane: write / read address of this lane
         self.v_o = [V(17 + r) for r in range(4)]
         self.f_re = [V(22 + 2 * rt, 2) for rt in range(4)]
         self.f_im = [V(30 + 2 * rt, 2) for rt in range(4)]
         self.f_sm = [V(38 + 2 * rt, 2) for rt in range(4)]
-        self.B = [[[V(46 + 32 * b + 4 * r + 2 * pl, 2) for pl in range(2)] for r in range(KSTEPS)] for b in range(2)]   # B[buf][r][re|im]
+        self.f_bre, self.f_bim = V(46, 2), V(48, 2)    # right-operand fragment of the current k-step
+        self.v_BB = V(50)                              # ... and where this lane reads it
         self.v_bsm = V(110, 2)
         self.T = V(112, 16)                            # temporaries (prologue, epilogue)
         self.P = [[A(8 * (4 * j + rt), 8) for rt in range(4)] for j in range(3)]
-        self.E = V(46, 64)                             # epilogue: the block's elements [t][r] (vr, vi), over the B buffers
+        self.E = V(46, 64)                             # epilogue: the block's elements [t][r] (vr, vi)
 
     # ---------------------------------------------------------------------------------------------------------------
     def add64(self, dst, base, lo, hi=0):
@@ -130,6 +155,19 @@ class GenLG:
         p.s_waitcnt(lgkm=0)
         # ---- which block: the blocks of a cell share blockIdx % 8 (one XCD, one L2) ----
         wg = S(2)
+        # Two workgroups share a CU, every workgroup of a launch takes the same time, and the first 512 start together: left
+        # alone the pair of a CU runs in LOCKSTEP for the whole launch -- both in their prologue (argument loads, first
+        # k-block in flight), both in their epilogue (stores draining) at the same moments, the matrix pipe idle in between.
+        # The workgroups that take the SECOND slot of the CUs in the first round (ids 256 .. 511) therefore start half a
+        # workgroup's time late; from then on one of the pair multiplies while the other changes blocks.
+        nst = self.stagger
+        if nst:
+            p.salu("s_lshr_b32", self.s_t[0], wg, 8)
+            p.s_cmp("s_cmp_eq_u32", self.s_t[0], 1)
+            p.s_branch("s_cbranch_scc0", "L_no_stagger")
+            for _ in range(nst):
+                p.s_sleep(127)
+            p.label("L_no_stagger")
         p.salu("s_and_b32", self.s_t[0], wg, 7)
         p.salu("s_lshr_b32", self.s_t[1], wg, 3)
         self.udiv(self.s_t[2], self.s_t[3], self.s_t[1], self.s_percell, self.s_mpc)
@@ -175,21 +213,52 @@ class GenLG:
         p.salu("s_cselect_b32", self.s_useu, 0, self.s_useu)
         p.label("L_not_sq")
         # ---- per-lane constants ----
-        for r in range(KSTEPS):     # fragment (row 16 rt + c, k-step r): c 256 + (((2 r | h) ^ c) << 4) + (rg & 1) 8
-            p.valu("v_or_b32", vx, 2 * r, vh)
-            p.valu("v_xor_b32", vx, vx, vc)
-            p.valu("v_lshlrev_b32", vx, 4, vx)
-            p.valu("v_and_b32", vy, 1, vrg)
-            p.valu("v_lshl_add_u32", vx, vy, 3, vx)
-            p.valu("v_lshl_add_u32", self.v_AB[r], vc, 8, vx)
-        p.valu("v_lshrrev_b32", vx, 4, self.v_lane)                  # row of the lane inside a piece (0 .. 3)
-        p.valu("v_mul_lo_u32", vy, vx, self.s_NP)
-        p.valu("v_lshlrev_b32", vy, 3, vy)                            # (i >> 4) NP 8
-        for k in range(4):          # piece pattern k = q & 3: granule (i & 15) ^ (4 k + (i >> 4))
-            p.valu("v_add_u32", t.sub(6), 4 * k, vx)
-            p.valu("v_and_b32", t.sub(7), 15, self.v_lane)
-            p.valu("v_xor_b32", t.sub(6), t.sub(6), t.sub(7))
-            p.valu("v_lshl_add_u32", self.v_GP[k], t.sub(6), 4, vy)
+        # left-operand fragment (row 16 rt + c, column 4 r + rg of the k-block): LDS row R = 8 rt + (c >> 1) holds the matrix
+        # rows 2 R and 2 R + 1 (8 granules of 16 bytes each); granule g = 8 (c & 1) + 2 r + (rg >> 1) sits at g ^ (R & 15):
+        # v_AB[r][rt & 1] = Rl 256 + ((8 (c & 1) + 2 r + (rg >> 1)) ^ Rl) 16 + (rg & 1) 8, Rl = 8 (rt & 1) + (c >> 1)
+        # (+ (rt >> 1) 4096 in the instruction offset)
+        vc1, vc0, vrl, vg = t.sub(6), t.sub(7), t.sub(8), t.sub(9)
+        p.valu("v_lshrrev_b32", vc1, 1, vc)
+        p.valu("v_and_b32", vc0, 1, vc)
+        for r in range(KSTEPS):
+            for par in range(2):
+                p.valu("v_add_u32", vrl, 8 * par, vc1)
+                p.valu("v_lshl_add_u32", vg, vc0, 3, vh)                  # 8 (c & 1) + (rg >> 1)
+                p.valu("v_add_u32", vg, 2 * r, vg)
+                p.valu("v_xor_b32", vg, vg, vrl)
+                p.valu("v_lshlrev_b32", vg, 4, vg)
+                p.valu("v_and_b32", vy, 1, vrg)
+                p.valu("v_lshl_add_u32", vg, vy, 3, vg)
+                p.valu("v_lshl_add_u32", self.v_AB[r][par], vrl, 8, vg)
+        # LDS-DMA pieces of the left operand: piece q of a wave = 4 LDS rows (1 KB); lane l writes granule P = l & 15 of
+        # LDS row 4 q + (l >> 4), which holds source granule g = P ^ (4 q + (l >> 4)): matrix row 2 (l >> 4) + (g >> 3) of
+        # the piece's 8 rows, columns 2 (g & 7), + 1:  v_GP[q] = (2 (l >> 4) + (g >> 3)) NP 8 + (g & 7) 16
+        for q in range(4):
+            p.valu("v_add_u32", vg, 4 * q, vrg)
+            p.valu("v_xor_b32", vg, vg, vc)                               # g
+            p.valu("v_lshrrev_b32", vx, 3, vg)
+            p.valu("v_lshl_add_u32", vx, vrg, 1, vx)                      # 2 (l >> 4) + (g >> 3)
+            p.valu("v_mul_lo_u32", vx, vx, self.s_NP)
+            p.valu("v_and_b32", vy, 7, vg)
+            p.valu("v_lshlrev_b32", vy, 4, vy)
+            p.valu("v_lshl_add_u32", self.v_GP[q], vx, 3, vy)
+        # ... of the right operand: piece = 2 rows of 512 bytes; lane l writes granule l & 31 of row l >> 5, which holds
+        # source granule (l & 31) ^ (8 (l >> 5)) (odd rows: the 128-byte windows of the waves swap in pairs)
+        p.valu("v_lshrrev_b32", vx, 5, self.v_lane)
+        p.valu("v_lshlrev_b32", vy, 3, vx)
+        p.valu("v_and_b32", vg, 31, self.v_lane)
+        p.valu("v_xor_b32", vg, vg, vy)
+        p.valu("v_lshlrev_b32", vg, 4, vg)
+        p.valu("v_mul_lo_u32", vx, vx, self.s_NP)
+        p.valu("v_lshl_add_u32", self.v_GPB, vx, 3, vg)
+        # right-operand fragment (row 4 r + rg of the k-block, column 16 w + c): rg 512 + (8 (w ^ (rg & 1)) + (c >> 1)) 16
+        # + (c & 1) 8  (+ r 2048 in the instruction offset)
+        p.valu("v_and_b32", vx, 1, vrg)
+        p.valu("v_xor_b32", vx, vx, vw)
+        p.valu("v_lshl_add_u32", vx, vx, 3, vc1)
+        p.valu("v_lshlrev_b32", vx, 4, vx)
+        p.valu("v_lshl_add_u32", vx, vc0, 3, vx)
+        p.valu("v_lshl_add_u32", self.v_BB, vrg, 9, vx)
         # element (row 4 r + rg [+ 16 t], column 16 w + c) of a 64 x 64 block: (rg NP + 16 w + c) 8
         p.valu("v_lshl_add_u32", vx, vw, 4, vc)                       # 16 w + c
         p.valu("v_mul_lo_u32", vy, vrg, self.s_NP)
@@ -206,28 +275,33 @@ class GenLG:
         p.salu("s_lshl_b32", self.s_planeb, self.s_planeb, 3)         # bytes of a plane
         p.salu("s_lshl_b32", self.s_t[0], self.s_planeb, 1)
         self.mul64(self.s_cellb, self.s_cell, self.s_t[0])
-        p.salu("s_lshl_b32", self.s_rowstep, self.s_NP, 5)            # 4 rows: 4 NP 8 bytes
-        # X: this wave's pieces: plane w >> 1, rows 4 j, j = (w & 1) 8 + q
+        p.salu("s_lshl_b32", self.s_rowstep, self.s_NP, 6)            # 8 rows of the left operand: one piece
+        p.salu("s_lshl_b32", self.s_bstep, self.s_NP, 4)              # 2 rows of the right operand: one piece
+        p.salu("s_lshl_b32", self.s_byadv, self.s_NP, 7)              # 16 rows: one k-block
+        # X: this wave's pieces: plane w & 1, rows 32 (w >> 1) + 8 q ...
         self.add64(self.s_xp, self.s_X, self.s_cellb.sub(0), self.s_cellb.sub(1))
         p.salu("s_mul_i32", self.s_t[0], self.s_bi, self.s_NP)
         p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 9)             # bi 64 NP 8
         self.add64(self.s_xp, self.s_xp, self.s_t[0])
-        p.salu("s_lshr_b32", self.s_t[1], self.s_wave, 1)
+        p.salu("s_and_b32", self.s_t[1], self.s_wave, 1)
         p.salu("s_mul_i32", self.s_t[0], self.s_t[1], self.s_planeb)
         self.add64(self.s_xp, self.s_xp, self.s_t[0])
-        p.salu("s_and_b32", self.s_t[2], self.s_wave, 1)
-        p.salu("s_lshl_b32", self.s_t[0], self.s_rowstep, 3)
-        p.salu("s_mul_i32", self.s_t[0], self.s_t[0], self.s_t[2])
-        self.add64(self.s_xp, self.s_xp, self.s_t[0])
-        p.salu("s_lshl_b32", self.s_ldsw, self.s_t[1], 14)
-        p.salu("s_lshl_b32", self.s_t[2], self.s_t[2], 13)
-        p.salu("s_add_u32", self.s_ldsw, self.s_ldsw, self.s_t[2])
-        # Y: rows k, columns bj 64 + ...
+        p.salu("s_lshr_b32", self.s_t[2], self.s_wave, 1)
+        p.salu("s_lshl_b32", self.s_t[3], self.s_rowstep, 2)          # 32 rows
+        p.salu("s_mul_i32", self.s_t[3], self.s_t[3], self.s_t[2])
+        self.add64(self.s_xp, self.s_xp, self.s_t[3])
+        p.salu("s_lshl_b32", self.s_ldsw, self.s_t[1], 13)            # plane (w & 1) 8192 + half (w >> 1) 4096
+        p.salu("s_lshl_b32", self.s_t[3], self.s_t[2], 12)
+        p.salu("s_add_u32", self.s_ldsw, self.s_ldsw, self.s_t[3])
+        # Y: plane w & 1, rows 8 (w >> 1) + 2 q ..., columns bj 64 + ...
         self.add64(self.s_yp, self.s_Y, self.s_cellb.sub(0), self.s_cellb.sub(1))
-        p.salu("s_lshl_b32", self.s_t[0], self.s_bj, 9)
+        p.salu("s_lshl_b32", self.s_t[3], self.s_bj, 9)
+        self.add64(self.s_yp, self.s_yp, self.s_t[3])
         self.add64(self.s_yp, self.s_yp, self.s_t[0])
-        self.add64(self.s_yq, self.s_yp, self.s_planeb)
-        p.salu("s_lshl_b32", self.s_nkb, self.s_NB, 1)
+        p.salu("s_lshl_b32", self.s_t[3], self.s_bstep, 2)            # 8 rows
+        p.salu("s_mul_i32", self.s_t[3], self.s_t[3], self.s_t[2])
+        self.add64(self.s_yp, self.s_yp, self.s_t[3])
+        p.salu("s_lshl_b32", self.s_nkb, self.s_NB, 2)
         # a cell that needs no (further) squaring: its block of X is the result
         p.s_cmp("s_cmp_eq_u64", self.s_scell, 0)
         p.s_branch("s_cbranch_scc1", "L_no_copy")
@@ -243,71 +317,92 @@ class GenLG:
                     p.valu("v_accvgpr_write_b32", self.P[j][rt].sub(i), 0)
 
     # ---- loads of a k-block, in pieces ------------------------------------------------------------------------------
-    def dma_piece(self, q, stage):
+    def dma_a(self, q, stage):
         p = self.p
         if q == 0:
             p.salu("s_mov_b64", self.s_a, self.s_xp)
         else:
             self.add64(self.s_a, self.s_a, self.s_rowstep)
         p.salu("s_add_u32", M0, self.s_ldsw, stage * STAGE_B + q * 1024)
-        p.global_load_lds(self.v_GP[q & 3], self.s_a)
+        p.global_load_lds(self.v_GP[q], self.s_a)
 
-    def b_loads(self, r, buf):
+    def dma_b(self, q, stage):
         p = self.p
-        p.global_load(2, self.B[buf][r][0], self.v_voff, self.s_yp)
-        p.global_load(2, self.B[buf][r][1], self.v_voff, self.s_yq)
-        self.add64(self.s_yp, self.s_yp, self.s_rowstep)
-        self.add64(self.s_yq, self.s_yq, self.s_rowstep)
+        if q == 0:
+            p.salu("s_mov_b64", self.s_b, self.s_yp)
+        else:
+            self.add64(self.s_b, self.s_b, self.s_bstep)
+        p.salu("s_add_u32", M0, self.s_ldsw, stage * STAGE_B + B_OFF + q * 1024)
+        p.global_load_lds(self.v_GPB, self.s_b)
 
     def frag_read(self, pl, rt, r, stage):
         dst = (self.f_re if pl == 0 else self.f_im)[rt]
-        self.p.ds_read(64, dst, self.v_AB[r], stage * STAGE_B + pl * 16384 + rt * 4096)
+        self.p.ds_read(64, dst, self.v_AB[r][rt & 1], stage * STAGE_B + pl * A_PLANE + (rt >> 1) * 4096)
+
+    def bfrag_read(self, pl, r, stage):
+        self.p.ds_read(64, self.f_bre if pl == 0 else self.f_bim, self.v_BB, stage * STAGE_B + B_OFF + pl * B_PLANE + r * 2048)
 
     def kblock(self, par, prefetch=True):
-        """the 8 k-steps of a k-block (stage and B set `par`); requests of the next k-block in its first steps"""
+        """the 4 k-steps of a k-block (stage `par`); the requests of the next k-block in its first two steps"""
         p = self.p
+        ab = self.ablate
+        prefetch = prefetch and "prefetch" not in ab
         for rt in range(4):
             self.frag_read(0, rt, 0, par)
+        self.bfrag_read(0, 0, par)
         for rt in range(4):
             self.frag_read(1, rt, 0, par)
+        self.bfrag_read(1, 0, par)
         for r in range(KSTEPS):
-            more = r < KSTEPS - 1
+            more = r < KSTEPS - 1 and "lds" not in ab
+            if "sums" not in ab:
+                for rep in range(2 if "sums2" in ab else 1):
+                    for rt in range(4):
+                        p.valu("v_add_f64", self.f_sm[rt], self.f_re[rt], self.f_im[rt])
+                    p.valu("v_add_f64", self.v_bsm, self.f_bre, self.f_bim)
             for rt in range(4):
-                p.valu("v_add_f64", self.f_sm[rt], self.f_re[rt], self.f_im[rt])
-            p.valu("v_add_f64", self.v_bsm, self.B[par][r][0], self.B[par][r][1])
-            for rt in range(4):
-                p.mfma(self.P[0][rt], self.f_re[rt], self.B[par][r][0], self.P[0][rt])
-                if prefetch and rt == 0 and r < 4:
-                    self.dma_piece(2 * r, par ^ 1)
-                    self.dma_piece(2 * r + 1, par ^ 1)
+                p.mfma(self.P[0][rt], self.f_re[rt], self.f_bre, self.P[0][rt])
+                if prefetch and r < 2 and rt in (0, 2):
+                    self.dma_a(2 * r + (rt >> 1), par ^ 1)
+                    if "dma2" in ab:
+                        p.global_load_lds(self.v_GP[2 * r + (rt >> 1)], self.s_a)       # (the same piece again)
             if more:
-                for rt in range(4):
-                    self.frag_read(0, rt, r + 1, par)
+                for rep in range(2 if "lds2" in ab else 1):
+                    for rt in range(4):
+                        self.frag_read(0, rt, r + 1, par)
+                    self.bfrag_read(0, r + 1, par)
             for rt in range(4):
-                p.mfma(self.P[1][rt], self.f_im[rt], self.B[par][r][1], self.P[1][rt])
-                if prefetch and rt == 0 and r < 4:
-                    self.b_loads(2 * r, par ^ 1)
-                    self.b_loads(2 * r + 1, par ^ 1)
+                p.mfma(self.P[1][rt], self.f_im[rt], self.f_bim, self.P[1][rt])
+                if prefetch and r < 2 and rt in (0, 2):
+                    self.dma_b(2 * r + (rt >> 1), par ^ 1)
+                    if "dma2" in ab:
+                        p.global_load_lds(self.v_GPB, self.s_b)
             if more:
-                for rt in range(4):
-                    self.frag_read(1, rt, r + 1, par)
+                for rep in range(2 if "lds2" in ab else 1):
+                    for rt in range(4):
+                        self.frag_read(1, rt, r + 1, par)
+                    self.bfrag_read(1, r + 1, par)
             for rt in range(4):
-                p.mfma(self.P[2][rt], self.f_sm[rt], self.v_bsm, self.P[2][rt])
+                if "sums" in ab:    # (finite stand-ins: the third product reads the real planes again)
+                    p.mfma(self.P[2][rt], self.f_re[rt], self.f_bre, self.P[2][rt])
+                else:
+                    p.mfma(self.P[2][rt], self.f_sm[rt], self.v_bsm, self.P[2][rt])
 
     def block_top(self, par):
         """the k-block at s_kb + par: its operands have landed; where the next one comes from (the last k-block asks for
         itself again: its prefetch is never used, and stays inside the arrays)"""
         p = self.p
-        p.s_waitcnt(vm=0, lgkm=0)
-        p.s_barrier()
+        if "sync" not in self.ablate:
+            p.s_waitcnt(vm=0, lgkm=0)
+            p.s_barrier()
+            if "sync2" in self.ablate:
+                p.s_barrier()
         p.salu("s_add_u32", self.s_t[0], self.s_kb, par + 1)
-        p.salu("s_lshl_b32", self.s_t[2], self.s_rowstep, 3)
         p.s_cmp("s_cmp_lt_u32", self.s_t[0], self.s_nkb)
-        p.salu("s_cselect_b32", self.s_t[1], 256, 0)                 # next k-block: 32 columns on
-        p.salu("s_cselect_b32", self.s_t[2], 0, self.s_t[2])         # last: back over the 32 rows just requested
+        p.salu("s_cselect_b32", self.s_t[1], 128, 0)                 # next k-block: 16 columns on
+        p.salu("s_cselect_b32", self.s_t[2], self.s_byadv, 0)        # ... 16 rows down
         self.add64(self.s_xp, self.s_xp, self.s_t[1])
-        self.sub64(self.s_yp, self.s_yp, self.s_t[2])
-        self.sub64(self.s_yq, self.s_yq, self.s_t[2])
+        self.add64(self.s_yp, self.s_yp, self.s_t[2])
 
     # ---- epilogue ----------------------------------------------------------------------------------------------------
     def elem(self, t, r):
@@ -657,11 +752,13 @@ class GenLG:
         p = self.p
         self.prologue()
         # k-block 0 into stage 0 / B set 0
-        for q in range(8):
-            self.dma_piece(q, 0)
-        for r in range(KSTEPS):
-            self.b_loads(r, 0)
+        for q in range(4):
+            self.dma_a(q, 0)
+        for q in range(4):
+            self.dma_b(q, 0)
         p.salu("s_mov_b32", self.s_kb, 0)
+        if "loopprio" in self.ablate:
+            p.s_setprio(2)
         p.label("L_loop")
         for par in range(2):
             self.block_top(par)
@@ -669,6 +766,13 @@ class GenLG:
         p.salu("s_add_u32", self.s_kb, self.s_kb, 2)
         p.s_cmp("s_cmp_lt_u32", self.s_kb, self.s_nkb)
         p.s_branch("s_cbranch_scc1", "L_loop")
+        # (the last k-block asked for itself again: those LDS-DMA writes must have landed before the epilogue's barrier lets
+        # any wave use the LDS as a transposition plane -- nothing else retires them now that no load returns into registers)
+        p.s_waitcnt(vm=0)
+        if "prio" in self.ablate:
+            p.s_setprio(3)
+        if "loopprio" in self.ablate:
+            p.s_setprio(0)
         self.epilogue()
         p.s_branch("s_branch", "L_end")
         self.copy_through()
@@ -691,6 +795,6 @@ def generate(path=None, **kw):
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "lg_gemm_asm.s")
-    g, prog, _ = generate(out)
+    g, prog, _ = generate(out, ablate=tuple(a for a in os.environ.get("GRAPE_LG_ABLATE", "").split(",") if a))
     print(f"{out}: {len(prog.ins)} lines, {prog.count('mfma')} matrix instructions, {prog.count('valu')} vector, "
           f"{prog.count('lds')} LDS, {prog.count('vmem')} global, {prog.auto_nops} wait states inserted")

@@ -1501,6 +1501,14 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     } while (0)
 
     CCHK(hipSetDevice(h->device));
+    if (const char *envcu = getenv("GRAPE_STREAM_CUS")) {
+        // diagnostic (tools/cu_curve.sh): the handle's stream on the first n CUs of the mask (the bits are dealt round-robin to
+        // the XCDs) -- how the phases scale with the CUs they get, i.e. what running two of them side by side could gain
+        const int ncu = std::max(8, std::min(256, atoi(envcu)));
+        uint32_t mask[8] = {0};
+        for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+        CCHK(hipExtStreamCreateWithCUMask(&h->stream, 8, mask));
+    } else
     CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     {
         int ncu = 0;

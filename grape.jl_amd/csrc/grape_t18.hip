@@ -13,6 +13,7 @@
 #include <mutex>
 #include <vector>
 #include <stdlib.h>
+#include <stdio.h>
 namespace {
 #include "grape_t18.hip.h"
 #include "grape_deriv3.hip.h"
@@ -243,7 +244,27 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
     std::lock_guard<std::mutex> lock(mtx);
     AsmModule &m = mods[dev & 63];
     if (!m.fn) {
-        hipError_t e = hipModuleLoadData(&m.mod, (const void *)grape_asm_co_start);
+        // GRAPE_ASM_CO=<file>: a code object from a file instead of the embedded one (tools/lg_ablate.sh: timing variants of
+        // the generators without rebuilding the library; read once, when the module of a device is first loaded)
+        static std::vector<char> override_co;
+        const void *image = (const void *)grape_asm_co_start;
+        if (const char *path = getenv("GRAPE_ASM_CO")) {
+            if (override_co.empty()) {
+                if (FILE *f = fopen(path, "rb")) {
+                    fseek(f, 0, SEEK_END);
+                    const long n = ftell(f);
+                    fseek(f, 0, SEEK_SET);
+                    if (n > 0) {
+                        override_co.resize((size_t)n);
+                        if (fread(override_co.data(), 1, (size_t)n, f) != (size_t)n) override_co.clear();
+                    }
+                    fclose(f);
+                }
+            }
+            if (override_co.empty()) return hipErrorFileNotFound;
+            image = override_co.data();
+        }
+        hipError_t e = hipModuleLoadData(&m.mod, image);
         if (e != hipSuccess) return e;
         e = hipModuleGetFunction(&m.fn_d3, m.mod, "deriv3_asm");
         if (e != hipSuccess) return e;

@@ -93,7 +93,7 @@ def program():
 def test_program_has_no_missing_wait_states_and_assembles(program, tmp_path):
     _, prog, text = program
     assert gcn.check_hazards(prog) == 0
-    assert prog.count("mfma") == 2 * 8 * 12 + 4      # two k-blocks per loop iteration, 8 k-steps, 12 matrix instructions each; 2 x 2 column sums
+    assert prog.count("mfma") == 2 * 4 * 12 + 4      # two k-blocks per loop iteration, 4 k-steps (round 6: k-blocks of 16), 12 matrix instructions each; 2 x 2 column sums
     if os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
         src = tmp_path / "lg.s"
         src.write_text(text)

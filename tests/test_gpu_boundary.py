@@ -576,8 +576,9 @@ def test_exception_inside_a_shard_thread_stops_at_the_barrier(g, monkeypatch):
         monkeypatch.setenv("GRAPE_TEST_THROW_AT", "none")
         J1, G1, _ = h.eval(pr["pulsevals"])                   # the handle is still usable
         assert J1 == J0 and np.array_equal(G1, G0)
-    # a worker thread of grape_create's host-side set-up (operator norms of a general problem: parallel_for)
-    prn = synth.make_problem(40, 2, 6, 8, seed=20, hermitian=False)
+    # a worker thread of grape_create's host-side set-up (shape factors of the four-product route's plan: parallel_for over
+    # the generator classes of a Hermitian problem with 16 < N <= 64)
+    prn = synth.make_problem(40, 2, 6, 8, seed=20)
     monkeypatch.setenv("GRAPE_TEST_THROW_AT", "worker")
     monkeypatch.setenv("GRAPE_TEST_THROW", "a worker failed")
     with pytest.raises(g.GrapeHipError) as ei:
