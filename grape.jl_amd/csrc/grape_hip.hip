@@ -214,6 +214,11 @@ struct grape_handle {
     bool z_valid = false;        // d_z belongs to the states in d_bw (grape_backward ran after the fused forward)
     double *d_inv_tnorm = nullptr, *d_ones = nullptr;
     double2 *d_z = nullptr;
+    // round 6: the sweeps of N <= 16 as a parallel scan over the time axis (scan16_* kernels, grape_kernels.hip.h): block
+    // propagators, boundary states of the coarse sweeps.  On for small ensembles (GRAPE_SCAN16=0: off, =1: always)
+    bool scan16 = false;
+    int scan_Bk = 0, scan_NB = 0;
+    double2 *d_scanF = nullptr, *d_scan_fw = nullptr, *d_scan_bw = nullptr;
     int num_cus = 256;
     bool series = false;
     bool u_fallback = false;     // prop_method = ExpProp was asked for, but the propagators do not fit the device: matrix-free
@@ -374,6 +379,29 @@ hipError_t launch_coop(const SweepArgs &a, bool backward, int S, int rpw, int nw
     COOP_CASE(4, 1) COOP_CASE(8, 1) COOP_CASE(16, 1) COOP_CASE(16, 2) COOP_CASE(16, 4)
 #undef COOP_CASE
     return hipErrorInvalidValue;
+}
+
+// N <= 16, parallel scan (scan16_* kernels): block propagators (once per set of propagators: `blocks`), coarse sweeps over
+// them, then all blocks filled at once.  af / ab: the arguments of the fine sweeps (nullptr: that direction is not wanted)
+hipError_t launch_scan16(grape_handle *h, const SweepArgs *af, const SweepArgs *ab, bool blocks, hipStream_t s) {
+    const int NB = h->scan_NB, Bk = h->scan_Bk;
+    const SweepArgs &any = af ? *af : *ab;
+    if (blocks) {
+        Scan16Args sa{};
+        sa.U = any.U; sa.F = h->d_scanF; sa.KC = h->KC; sa.N_T = any.N_T; sa.Bk = Bk; sa.NB = NB;
+        hipLaunchKernelGGL(scan16_block_kernel, dim3((unsigned)(h->KC * NB)), dim3(64), 0, s, sa);
+    }
+    SweepArgs cf{}, cb{};
+    if (af) { cf = *af; cf.U = h->d_scanF; cf.N_T = NB; cf.store = h->d_scan_fw; }
+    if (ab) { cb = *ab; cb.U = h->d_scanF; cb.N_T = NB; cb.store = h->d_scan_bw; }
+    if (af && ab) hipLaunchKernelGGL(sweep16_pair_kernel, dim3(2 * any.K), dim3(64), 0, s, cf, cb);
+    else if (af) hipLaunchKernelGGL((sweep16_kernel<false>), dim3(any.K), dim3(64), 0, s, cf);
+    else hipLaunchKernelGGL((sweep16_kernel<true>), dim3(any.K), dim3(64), 0, s, cb);
+    Scan16FillArgs fa{};
+    fa.cfw = h->d_scan_fw; fa.cbw = h->d_scan_bw; fa.Bk = Bk; fa.NB = NB; fa.both = (af && ab) ? 1 : 0;
+    const unsigned nblk = (unsigned)(any.K * NB * ((af && ab) ? 2 : 1));
+    hipLaunchKernelGGL(scan16_fill_kernel, dim3(nblk), dim3(64), 0, s, af ? *af : *ab, ab ? *ab : *af, fa, af ? 0 : 1);
+    return hipGetLastError();
 }
 
 template <int NP>
@@ -1366,7 +1394,7 @@ void grape_destroy(grape_handle *h) {
     if (h->lg_stream2) { hipStreamSynchronize(h->lg_stream2); hipStreamDestroy(h->lg_stream2); }
     if (h->lg_ev_fork) hipEventDestroy(h->lg_ev_fork);
     if (h->lg_ev_join) hipEventDestroy(h->lg_ev_join);
-    void *bufs[] = {h->d_dte, h->d_normpart, h->d_normpart2, h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_scanF, h->d_scan_fw, h->d_scan_bw, h->d_dte, h->d_normpart, h->d_normpart2, h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -1927,6 +1955,22 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     }
     CCHK(dmalloc(&h->d_fw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_bw, (size_t)K * (N_T + 1) * NP));
+    {   // parallel scan of the sweeps (N <= 16): a latency chain of N_T steps becomes Bk + NB + Bk; pays while the chains
+        // alone leave the chip idle (phase 1 does 16 x the flops of the sweep it replaces)
+        const char *envs = getenv("GRAPE_SCAN16");
+        const bool want = envs ? atoi(envs) != 0 : (2L * K <= (long)h->num_cus && N_T >= 64);
+        if (NP == 16 && !h->series && want && !(envs && atoi(envs) == 0)) {
+            int Bk = 8;
+            while ((long)Bk * Bk * 2 < (long)N_T && Bk < 64) Bk += 4;     // Bk ~ sqrt(N_T / 2) (tools/scan_bk.sh: 16 at 500 steps: C2 0.273 -> 0.214 ms, the README problem 0.184 -> 0.101 ms)
+            if (const char *envb = getenv("GRAPE_SCAN16_BK")) Bk = std::max(2, atoi(envb));
+            h->scan_Bk = Bk;
+            h->scan_NB = (N_T + Bk - 1) / Bk;
+            CCHK(dmalloc(&h->d_scanF, (size_t)h->KC * h->scan_NB * 256));
+            CCHK(dmalloc(&h->d_scan_fw, (size_t)K * (h->scan_NB + 1) * 16));
+            CCHK(dmalloc(&h->d_scan_bw, (size_t)K * (h->scan_NB + 1) * 16));
+            h->scan16 = true;
+        }
+    }
     CCHK(dmalloc(&h->d_tg, (size_t)K * L * N_T));
     // ONE slab for everything an evaluation hands back or resets: [tau + sums (2K + 8) | G (L N_T) | flags (8 ints) | statistics]
     // -- the single-wait grape_eval reads the first three with one copy and resets the last two with one memset (every copy or
@@ -2325,6 +2369,8 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             const bool sc = 2 * h->K > h->num_cus;
             e = h->NP == 16 ? launch_series_pair<16>(rf, rb, sc, s) : h->NP == 32 ? launch_series_pair<32>(rf, rb, sc, s)
                                                                                  : launch_series_pair<64>(rf, rb, sc, s);
+        } else if (h->scan16) {
+            e = launch_scan16(h, &sa, &sb, true, s);
         } else {
             e = h->NP == 16 ? launch_sweep_pair<16>(sa, sb, s) : h->NP == 32 ? launch_sweep_pair<32>(sa, sb, s)
                 : h->NP == 48 ? launch_sweep_pair<48>(sa, sb, s) : launch_sweep_pair<64>(sa, sb, s);
@@ -2335,6 +2381,8 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         const SeriesArgs ra = series_args(h, sa, false);
         e = h->NP == 16 ? launch_series<16>(ra, false, s) : h->NP == 32 ? launch_series<32>(ra, false, s)
                                                                        : launch_series<64>(ra, false, s);
+    } else if (h->scan16) {
+        e = launch_scan16(h, &sa, nullptr, true, s);
     } else
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, false, s); break;
@@ -2420,6 +2468,10 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
         const SeriesArgs ra = series_args(h, sa, true);
         e = h->NP == 16 ? launch_series<16>(ra, true, s) : h->NP == 32 ? launch_series<32>(ra, true, s)
                                                                       : launch_series<64>(ra, true, s);
+    } else if (h->scan16 && !sa.xi) {
+        // (the block propagators of the forward call belong to the same propagators; the running-cost inhomogeneity enters
+        // every fine step: the sequential sweep keeps that case)
+        e = launch_scan16(h, nullptr, &sa, false, s);
     } else
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, true, s); break;

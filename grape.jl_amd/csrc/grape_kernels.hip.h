@@ -2614,6 +2614,145 @@ __global__ void __launch_bounds__(64) sweep16_pair_kernel(SweepArgs af, SweepArg
 }
 
 
+// ---------------------------------------------------------------------------------------
+// Round 6 -- sweeps for N <= 16 as a PARALLEL SCAN over the time axis.  The recurrences Psi_n = U_n Psi_(n-1)
+// (/root/reference/src/optimize.jl:731-738) and chi_(n-1) = U_n^dagger chi_n (:880-881) are latency chains: at C2 (32
+// trajectories, 500 steps) sweep16_pair_kernel keeps 64 waves of a 256-CU chip busy for 500 x 0.22 us = 0.11 ms, 40 % of
+// the evaluation.  Matrix products are associative, so the chain is cut into NB blocks of Bk steps:
+//   1. scan16_block_kernel   F_b = U_(e-1) ... U_s of every block, all blocks at once (one wave each: a 16 x 16 x 16
+//                            complex product per step on the matrix pipe, the result tile IS the next right operand);
+//   2. the ordinary one-wave sweeps over the NB block propagators: Psi(t_e) = F_b Psi(t_s), chi(t_s) = F_b^dagger chi(t_e)
+//      -- the backward block operator is the adjoint of the forward one, nothing else is formed; boundary states, rho_k
+//      and tau_k come out of this pass exactly as from the fine sweep;
+//   3. scan16_fill_kernel    the states inside every block from its boundary state, all blocks and both directions at
+//                            once, into the storage arrays the derivative kernels read (workspace.jl:215).
+// Chain length Bk + NB + Bk instead of N_T (16 + 32 + 16 at C2).  Results agree with the sequential order to rounding
+// (a product of Bk unitary factors is formed before it is applied).  Not used with the running-cost inhomogeneity xi
+// (it enters every fine step) and not for ensembles that fill the chip by themselves (phase 1 does 16 x the flops).
+// ---------------------------------------------------------------------------------------
+struct Scan16Args {
+    const double2 *U;   // [KC][N_T][256]
+    double2 *F;         // [KC][NB][256] block propagators, same layout
+    int KC, N_T, Bk, NB;
+};
+__global__ void __launch_bounds__(64) scan16_block_kernel(Scan16Args a) {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int kc = blockIdx.x / a.NB, b = blockIdx.x - kc * a.NB;
+    const int s = b * a.Bk, e = min(a.N_T, s + a.Bk);
+    const double2 *Un = a.U + ((size_t)kc * a.N_T + s) * 256 + j * 16 + g;   // lane (i = j, g): U[i][g], U[i][4 + g], U[i][8 + g], U[i][12 + g]
+    // P = 1 in the result layout of the matrix instruction: register r of lane (j, g) is P[4r + g][j] -- which is exactly
+    // the right operand of k-step r (k = 4r + g), so the result of a step feeds the next one without a move (Strip, above)
+    d4 pr, pi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pr[r] = (4 * r + g == j) ? 1.0 : 0.0; pi[r] = 0.0; }
+    constexpr int DEPTH = 4;
+    double2 un[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (s + d < e) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) un[d][m] = Un[(size_t)d * 256 + 4 * m];
+        }
+    for (int n0 = s; n0 < e; n0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int n = n0 + d;
+            if (n < e) {
+                // k-step m covers k = 4m + g: left operand U[i][4m + g] (this lane's m-th loaded element), right operand
+                // P[4m + g][j] = register m of the previous result
+                d4 cr = {0., 0., 0., 0.}, ci = {0., 0., 0., 0.};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double ur = un[d][m].x, ui = un[d][m].y;
+                    cr = MFMA64(ur, pr[m], cr);
+                    ci = MFMA64(ur, pi[m], ci);
+                    cr = MFMA64(-ui, pi[m], cr);
+                    ci = MFMA64(ui, pr[m], ci);
+                }
+                pr = cr; pi = ci;
+                if (n + DEPTH < e) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) un[d][m] = Un[(size_t)(n - s + DEPTH) * 256 + 4 * m];
+                }
+            }
+        }
+    }
+    double2 *Fb = a.F + ((size_t)kc * a.NB + b) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Fb[(4 * r + g) * 16 + j] = make_double2(pr[r], pi[r]);
+}
+
+// phase 3: the fine steps of block b of trajectory k from the boundary state the coarse sweep left in cs[k][b] (forward:
+// Psi(t_s)) / cs[k][b + 1] (backward: chi(t_e)); same lane layout and arithmetic as sweep16_body
+struct Scan16FillArgs {
+    const double2 *cfw, *cbw;   // [K][NB + 1][16] boundary states of the coarse sweeps (forward / backward)
+    int Bk, NB, both;           // both: blocks [K NB, 2 K NB) of the grid are the backward blocks
+};
+template <bool BACKWARD>
+__device__ __forceinline__ void scan16_fill_body(const SweepArgs &a, const Scan16FillArgs &f, const int k, const int b, double2 *xs) {
+    constexpr int NP = 16;
+    const int lane = threadIdx.x & 63;
+    const int r = lane >> 2, c = lane & 3;
+    const int s = b * f.Bk, e = min(a.N_T, s + f.Bk);
+    const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
+    double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
+    if (lane < NP) {
+        const double2 v = BACKWARD ? f.cbw[((size_t)k * (f.NB + 1) + b + 1) * NP + lane] : f.cfw[((size_t)k * (f.NB + 1) + b) * NP + lane];
+        xs[lane] = v;
+        if (BACKWARD ? e == a.N_T : s == 0) st[(size_t)(BACKWARD ? a.N_T : 0) * NP + lane] = v;   // the boundary state of the trajectory itself
+    }
+    const int nsteps = e - s;
+    auto load_tile = [&](double2 (&dst)[4], int t) __attribute__((always_inline)) {
+        const int nn = BACKWARD ? e - 1 - t : s + t;
+        const double2 *Un = Uk + (size_t)nn * NP * NP;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dst[m] = BACKWARD ? Un[(4 * c + m) * NP + r] : Un[r * NP + 4 * c + m];
+    };
+    constexpr int DEPTH = 8;
+    double2 un[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nsteps) load_tile(un[d], d);
+    for (int t0 = 0; t0 < nsteps; t0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int t = t0 + d;
+            if (t < nsteps) {
+                const int n = BACKWARD ? e - 1 - t : s + t;
+                double pr = 0., pi = 0.;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double2 x = xs[4 * c + m];
+                    const double2 u = un[d][m];
+                    if (!BACKWARD) {
+                        pr = fma(u.x, x.x, pr); pr = fma(-u.y, x.y, pr);
+                        pi = fma(u.x, x.y, pi); pi = fma(u.y, x.x, pi);
+                    } else {
+                        pr = fma(u.x, x.x, pr); pr = fma(u.y, x.y, pr);
+                        pi = fma(u.x, x.y, pi); pi = fma(-u.y, x.x, pi);
+                    }
+                }
+                if (t + DEPTH < nsteps) load_tile(un[d], t + DEPTH);
+                pr = group_sum<4>(pr);
+                pi = group_sum<4>(pi);
+                if (c == 0) {
+                    const double2 y = make_double2(pr, pi);
+                    xs[r] = y;
+                    st[(size_t)(BACKWARD ? n : n + 1) * NP + r] = y;
+                }
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(64) scan16_fill_kernel(SweepArgs af, SweepArgs ab, Scan16FillArgs f, int backward_only) {
+    __shared__ double2 xs[16];
+    const int nfw = backward_only ? 0 : af.K * f.NB;
+    const int id = blockIdx.x;
+    if (id < nfw) scan16_fill_body<false>(af, f, id / f.NB, id % f.NB, xs);
+    else { const int q = id - nfw; scan16_fill_body<true>(ab, f, q / f.NB, q % f.NB, xs); }
+}
+
+
 template <int NP, int LMAX, int NTH>
 __global__ void __launch_bounds__(NTH) deriv_kernel(DerivArgs a) {
     constexpr int NCH = NTH / NP;      // column chunks per row = adjacent lanes (<= 16)
