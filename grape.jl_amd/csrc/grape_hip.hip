@@ -186,6 +186,8 @@ struct grape_handle {
     int *d_cls = nullptr, *d_rep = nullptr;
     unsigned *d_coop = nullptr;  // [2][K] step counters of the cooperative sweeps (forward, backward)
     int coop_S = 0;              // workgroups per trajectory in the cooperative sweeps (0: one-workgroup kernel)
+    int *d_xcc_sw = nullptr;     // [2][K][32] XCC ids of the siblings of the cooperative sweeps (forward, backward)
+    int coop_xmode = 1;          // GRAPE_COOP_XMODE=0: step counters instead of armed storage rows (SweepArgs::xmode)
     int coop_rpw = 0, coop_nw = 0;  // rows per wave and waves of a cooperative workgroup (R = nw * rpw state rows)
     int coop_S_fw = 0, coop_rpw_fw = 0, coop_nw_fw = 0;   // the forward sweep's own split (GRAPE_COOP_S_FW; default: fewer siblings, see grape_create)
     // state running cost (g_b = <Psi|D|Psi>): transposed D, trapezoid weights, xi and g per stored state
@@ -369,6 +371,14 @@ template <int CPL>
 hipError_t launch_coop(const SweepArgs &a, bool backward, int S, int rpw, int nw, unsigned *cnt, hipStream_t s) {
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)a.K * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
+    if (a.xcc) {
+        e = hipMemsetAsync(a.xcc, 0xFF, (size_t)a.K * 32 * sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
+    if (a.xmode) {   // arm every row of the storage (the boundary row of a trajectory is written by sibling 0 inside the kernel and polled by nobody)
+        e = hipMemsetAsync((void *)a.store, 0xFF, (size_t)a.K * (a.N_T + 1) * 64 * CPL * sizeof(double2), s);
+        if (e != hipSuccess) return e;
+    }
     const dim3 grid(8 * ((a.K + 7) / 8) * S), block(64 * nw);
 #define COOP_CASE(NW_, RPW_)                                                                                          \
     if (nw == NW_ && rpw == RPW_) {                                                                                   \
@@ -1394,7 +1404,7 @@ void grape_destroy(grape_handle *h) {
     if (h->lg_stream2) { hipStreamSynchronize(h->lg_stream2); hipStreamDestroy(h->lg_stream2); }
     if (h->lg_ev_fork) hipEventDestroy(h->lg_ev_fork);
     if (h->lg_ev_join) hipEventDestroy(h->lg_ev_join);
-    void *bufs[] = {h->d_scanF, h->d_scan_fw, h->d_scan_bw, h->d_dte, h->d_normpart, h->d_normpart2, h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_xcc_sw, h->d_scanF, h->d_scan_fw, h->d_scan_bw, h->d_dte, h->d_normpart, h->d_normpart2, h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -2132,12 +2142,15 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         const char *env = getenv("GRAPE_SWEEP_COOP");
         if (S >= 2 && R <= 64 && !(env && atoi(env) == 0)) {
             h->coop_S = S;
+            if (const char *envx = getenv("GRAPE_COOP_XMODE")) h->coop_xmode = atoi(envx) != 0;
             h->coop_nw = R >= 16 ? 16 : R;
             h->coop_rpw = R / h->coop_nw;
             // the two directions have different optima (round 5, C5 shard, forward / backward ms by siblings: 32: 8.5 / 9.6,
             // 16: 7.3 / 11.1, 8: 10.2 / 11.0, 4: 15.3 / -): a step is a latency chain whose length grows with the siblings that
             // have to meet; the forward slice is whole rows (a wave sum per row), the backward one columns (tools/coop_s.sh)
-            int Sf = S == 32 ? 16 : S, Sb = S;
+            // round 6 (armed storage rows instead of step counters, stores into the XCD's L2): forward 32 / 16 / 8 siblings
+            // 3.5 / 4.3 / 6.9 ms, backward 32 / 16 / 8: 5.4 / 5.7 / 7.1 ms (round 5: 7.1 + 9.6 ms)
+            int Sf = h->coop_xmode ? S : (S == 32 ? 16 : S), Sb = S;
             if (const char *e_ = getenv("GRAPE_COOP_S_FW")) Sf = atoi(e_);
             if (const char *e_ = getenv("GRAPE_COOP_S_BW")) Sb = atoi(e_);
             auto valid = [&](int s_) { return s_ >= 2 && s_ <= S && (s_ & (s_ - 1)) == 0 && h->NP / s_ <= 64; };
@@ -2146,6 +2159,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
             h->coop_S = Sb; h->coop_nw = h->NP / Sb >= 16 ? 16 : h->NP / Sb; h->coop_rpw = (h->NP / Sb) / h->coop_nw;
             h->coop_S_fw = Sf; h->coop_nw_fw = h->NP / Sf >= 16 ? 16 : h->NP / Sf; h->coop_rpw_fw = (h->NP / Sf) / h->coop_nw_fw;
             CCHK(dmalloc(&h->d_coop, (size_t)2 * K));
+            CCHK(dmalloc(&h->d_xcc_sw, (size_t)2 * K * 32));
         }
     }
     CCHK(hipMemset(h->d_flags, 0, 8 * sizeof(int)));
@@ -2348,6 +2362,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
     sa.store = h->d_fw; sa.tau = (double2 *)d_out; sa.f = nullptr; sa.rho = h->d_rho; sa.flags = h->d_flags;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
+    sa.xmode = h->coop_xmode; sa.xcc = h->d_xcc_sw;
     if (walk_fuse & 1) sa.resume = h->d_prog;
     if (h->test_hooks) {   // fault injection (test suite only, see grape_handle::test_hooks)
         const char *envd = getenv("GRAPE_TEST_DROP_SIBLING");
@@ -2449,6 +2464,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
     sa.lambda_b = h->xi_user ? h->lambda_user : h->p.lambda_b;
     sa.chi_min_norm = h->chi_min_norm;
     sa.K = h->K; sa.K_total = h->K_total; sa.N = h->N; sa.N_T = h->N_T; sa.functional = h->p.functional;
+    sa.xmode = h->coop_xmode; sa.xcc = h->d_xcc_sw ? h->d_xcc_sw + (size_t)h->K * 32 : nullptr;
     sa.chi_in = d_chi;
     phase_begin(h, 2, s);
     // (a caller-supplied chi or xi breaks the linearity the concurrent sweeps rely on: the backward sweep runs here)

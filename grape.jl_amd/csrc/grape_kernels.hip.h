@@ -2169,6 +2169,13 @@ struct SweepArgs {
     // resume[k] steps -- forward from t = 0 / backward from t = T -- and stored those states; the sweep picks up behind them
     // (nullptr: from the boundary)
     const int *resume;
+    // round 6, cooperative sweeps: 1 = the published slices ARE the signal -- the storage rows a sweep will write are armed
+    // with an all-ones bit pattern before the launch, a reader polls the elements it needs until none shows the pattern;
+    // the step counter, the wait for the store acknowledgements and one barrier per step disappear (0: step counter)
+    int xmode;
+    // ... and where the siblings of a trajectory check that they share an XCD ([K][32] XCC ids, -1 at launch; nullptr: not
+    // checked): then the stores of the exchange only have to reach that XCD's L2 (sc0) instead of the memory fabric
+    int *xcc;
 };
 
 // c_k of chi_k(T) = c_k target_k for the three functionals (docs/src/tutorial.md:349-356, 402)

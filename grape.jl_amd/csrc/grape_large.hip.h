@@ -939,12 +939,36 @@ __device__ __forceinline__ bool coop_wait(unsigned *cnt, unsigned target, int *f
     return false;
 }
 
+// round 6 (SweepArgs::xmode = 1): poll ONE element of the state until it no longer shows the arming pattern (all ones in
+// either half: a 16-byte element is published as two 8-byte stores).  Bounded: a sibling that never publishes raises bit 3.
+#define COOP_SENTINEL 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ double2 coop_poll(const double2 *p, int *flags, bool &gone) {
+    double2 v = make_double2(0., 0.);
+    if (gone) return v;
+    for (int spin = 0; spin < (1 << 21); ++spin) {
+        v = coop_load(p);
+        if ((unsigned long long)__double_as_longlong(v.x) != COOP_SENTINEL && (unsigned long long)__double_as_longlong(v.y) != COOP_SENTINEL) return v;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    atomicOr(&flags[0], 8);
+    gone = true;
+    return make_double2(0., 0.);
+}
+
+// a slice element published for siblings on the SAME XCD: past the per-CU vector cache into that XCD's L2 (sc0); the polls
+// stay device-scope loads, which that L2 serves while the line is there (grape_cheby.hip.h has the measurement)
+__device__ __forceinline__ void coop_store_l2(double2 *p, double2 v) {
+    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int CPL, int RPW, int NW, bool BACKWARD>
 __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S, unsigned *cnt) {
     constexpr int NP = 64 * CPL, T = 64 * NW, R = NW * RPW, E = CPL * RPW, NG = T / R;
     __shared__ double2 x[NP];
     __shared__ double2 part[T > NP ? T : NP];
     __shared__ double sc[2];
+    __shared__ int xl;
     bool gone = false;   // (thread 0) a sibling did not arrive within the spin limit
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -956,6 +980,27 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
     const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
     double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
     unsigned *ck = cnt + k;
+    // ---- do all siblings of this trajectory share an XCD (and with it an L2)?  Checked, not assumed. ----
+    if (tid == 0) {
+        int same = 0;
+        if (a.xcc && a.xmode) {
+            int *xc = a.xcc + (size_t)k * 32;
+            const int mine = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);   // HW_REG_XCC_ID[3:0]
+            __hip_atomic_store(&xc[s], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            same = 1;
+            for (int j = 0; j < S; ++j) {
+                int v = -1, spin = 0;
+                while ((v = __hip_atomic_load(&xc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+                    if (++spin > (1 << 22)) { atomicOr(&a.flags[0], 8); break; }   // a sibling never started
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                same &= (v == mine);
+            }
+        }
+        xl = same;
+    }
+    __syncthreads();
+    const bool l2 = xl != 0;
 
     // ---- initial state: every sibling forms it redundantly (N elements), sibling 0 stores it ----
     double rho = 1.0;
@@ -1001,8 +1046,10 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
     // r0 + w*RPW + r, lane covers columns c*64 + lane; backward: thread (ig = tid / R, jj = tid % R) owns
     // column r0 + jj over rows ig + NG * m
     const int jj = tid % R, ig = tid / R;
-    double2 u[E];
-    auto load_u = [&](int n) {
+    // the U slices of the next TWO steps are in flight (a ring of two register sets with static indices: the step loop is
+    // unrolled twice) -- with one the HBM latency of the slice was on the critical path of every step
+    double2 u2[2][E];
+    auto load_u = [&](double2 (&u)[E], int n) __attribute__((always_inline)) {
         const double2 *Un = Uk + (size_t)n * NP * NP;
         if (!BACKWARD) {
 #pragma unroll
@@ -1014,18 +1061,32 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
             for (int m = 0; m < E; ++m) u[m] = Un[(size_t)(ig + NG * m) * NP + r0 + jj];
         }
     };
-    load_u(BACKWARD ? a.N_T - 1 : 0);
+    load_u(u2[0], BACKWARD ? a.N_T - 1 : 0);
+    if (a.N_T > 1) load_u(u2[1], BACKWARD ? a.N_T - 2 : 1);
+    const bool sentinel = a.xmode != 0;
+    bool lost = false;   // (any thread, sentinel mode) an element never arrived
 
-    for (int step = 0; step < a.N_T; ++step) {
+    for (int step0 = 0; step0 < a.N_T; step0 += 2) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int step = step0 + d;
+        if (step >= a.N_T) break;
+        double2 (&u)[E] = u2[d];
         const int n = BACKWARD ? a.N_T - 1 - step : step;
         const int nout = BACKWARD ? n : n + 1;       // storage row of the new state
         if (step > 0) {
-            // wait until all S siblings have published step - 1, then fetch the full state
-            if (tid == 0 && !gone) gone = !coop_wait(ck, (unsigned)(S * step), a.flags);   // a time-out is final: no further waits
-            __syncthreads();
             const int nin = BACKWARD ? n + 1 : n;
-            if (tid < NP) x[tid] = coop_load(&st[(size_t)nin * NP + tid]);
-            __syncthreads();
+            if (sentinel) {
+                // the state of the previous step: every element is polled by the thread that needs it in the LDS copy
+                if (tid < NP) x[tid] = coop_poll(&st[(size_t)nin * NP + tid], a.flags, lost);
+                __syncthreads();
+            } else {
+                // wait until all S siblings have published step - 1, then fetch the full state
+                if (tid == 0 && !gone) gone = !coop_wait(ck, (unsigned)(S * step), a.flags);   // a time-out is final: no further waits
+                __syncthreads();
+                if (tid < NP) x[tid] = coop_load(&st[(size_t)nin * NP + tid]);
+                __syncthreads();
+            }
         }
         double2 y = make_double2(0., 0.);
         if (!BACKWARD) {
@@ -1040,7 +1101,10 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
                 }
                 pr = wave_sum_dpp(pr);
                 pi = wave_sum_dpp(pi);
-                if (lane == 0) coop_store(&st[(size_t)nout * NP + r0 + wave * RPW + r], make_double2(pr, pi));
+                if (lane == 0) {
+                    if (l2) coop_store_l2(&st[(size_t)nout * NP + r0 + wave * RPW + r], make_double2(pr, pi));
+                    else coop_store(&st[(size_t)nout * NP + r0 + wave * RPW + r], make_double2(pr, pi));
+                }
             }
         } else {
             double ar = 0., ai = 0.;
@@ -1060,24 +1124,32 @@ __global__ void __launch_bounds__(64 * NW) sweep_coop_kernel(SweepArgs a, int S,
                     const double c = a.lambda_b * a.wq[n] / rho;
                     sum.x += c * x_.x; sum.y += c * x_.y;
                 }
-                coop_store(&st[(size_t)nout * NP + r0 + tid], sum);
+                if (l2) coop_store_l2(&st[(size_t)nout * NP + r0 + tid], sum);
+                else coop_store(&st[(size_t)nout * NP + r0 + tid], sum);
             }
             (void)y;
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this thread's slice elements are acknowledged ...
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the count
-        // request the next U slice now: it does not depend on the state and streams in during the exchange
-        if (step + 1 < a.N_T) load_u(BACKWARD ? n - 1 : n + 1);
+        if (!sentinel) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this thread's slice elements are acknowledged ...
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(ck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the count
+        } else {
+            __syncthreads();                      // (x is rewritten by the next step's poll)
+        }
+        // request the U slice of the step after next now: it does not depend on the state and streams in during the exchanges
+        if (step + 2 < a.N_T) load_u(u2[d], BACKWARD ? n - 2 : n + 2);
+      }
     }
 
     if (!BACKWARD && s == 0) {   // tau_k = <target_k | Psi_k(T)>
-        if (tid == 0 && !gone) coop_wait(ck, (unsigned)(S * a.N_T), a.flags);
-        __syncthreads();
+        if (!sentinel) {
+            if (tid == 0 && !gone) coop_wait(ck, (unsigned)(S * a.N_T), a.flags);
+            __syncthreads();
+        }
         double pr = 0., pi = 0.;
         if (tid < a.N) {
             const double2 t = a.target[(size_t)k * a.N + tid];
-            const double2 p = coop_load(&st[(size_t)a.N_T * NP + tid]);
+            const double2 p = sentinel ? coop_poll(&st[(size_t)a.N_T * NP + tid], a.flags, lost) : coop_load(&st[(size_t)a.N_T * NP + tid]);
             pr = t.x * p.x + t.y * p.y;
             pi = t.x * p.y - t.y * p.x;
         }
