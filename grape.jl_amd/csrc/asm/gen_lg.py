@@ -65,8 +65,13 @@ class GenLG:
         # squarings from them -- so the variants that are measured DUPLICATE an item instead (idempotent: same results, the
         # slope is the item's cost): "sums2", "lds2", "sync2", "dma2" (left-operand requests), "bload2" (right-operand loads).
         # ("sums" / "prefetch" / "sync" / "lds" drop the item: results are wrong, kept for stand-alone timing only.)
-        self.ablate = set(a for a in ablate if not a.startswith("stagger"))
+        self.ablate = set(a for a in ablate if not a.startswith("stagger") and a not in ("nont", "nontl"))
         # s_sleep 127 (~8100 cycles each) in front of the second workgroup of every CU (prologue); "staggerN" overrides
+        # non-temporal result / combination stores (round 6: every array of a chunk is 640 MB and is read again one launch
+        # later at the earliest -- nothing of it survives in a cache; in-situ, C5 shard, A/B/A/B on one box: Hermitian launches
+        # 856.5 -> 838 us, general ones 566 -> 550 us, products 120.9 -> 117.9 ms per evaluation); "nont": off
+        self.nt = "nont" not in ablate
+        self.ntl = "nontl" not in ablate  # ... and the epilogue's streamed loads (combination inputs, epilogue terms)
         self.stagger = STAGGER
         for a in ablate:
             if a.startswith("stagger"):
@@ -441,8 +446,8 @@ class GenLG:
             self.offsets(t, self.s_boff)
             for r in range(4):
                 e = self.elem(t, r)
-                p.global_store(2, self.v_o[r], e.sub(0, 2), self.s_Cb)
-                p.global_store(2, self.v_o[r], e.sub(2, 2), self.s_b)          # im plane: s_b = Cb + plane
+                p.global_store(2, self.v_o[r], e.sub(0, 2), self.s_Cb, nt=self.nt)
+                p.global_store(2, self.v_o[r], e.sub(2, 2), self.s_b, nt=self.nt)          # im plane: s_b = Cb + plane
         if to_u_allowed:
             p.s_branch("s_branch", f"L_store_done_{tag}")
             p.label(f"L_store_u_{tag}")
@@ -450,7 +455,7 @@ class GenLG:
                 self.offsets(t, self.s_boff)
                 for r in range(4):
                     p.valu("v_lshlrev_b32", self.v_o[r], 1, self.v_o[r])
-                    p.global_store(4, self.v_o[r], self.elem(t, r), self.s_Ub)
+                    p.global_store(4, self.v_o[r], self.elem(t, r), self.s_Ub, nt=self.nt)
             p.label(f"L_store_done_{tag}")
 
     def epilogue(self):
@@ -497,10 +502,10 @@ class GenLG:
             self.offsets(t, self.s_boff)
             x0 = [self.T.sub(4 * r, 4) for r in range(4)]               # Add_0 (re, im) of the four elements
             for r in range(4):
-                p.global_load(2, x0[r].sub(0, 2), self.v_o[r], self.s_A0b)
+                p.global_load(2, x0[r].sub(0, 2), self.v_o[r], self.s_A0b, nt=self.ntl)
             self.add64(self.s_a, self.s_A0b, self.s_planeb)
             for r in range(4):
-                p.global_load(2, x0[r].sub(2, 2), self.v_o[r], self.s_a)
+                p.global_load(2, x0[r].sub(2, 2), self.v_o[r], self.s_a, nt=self.ntl)
             lab1 = f"L_one_add_{t}"
             # second output starts from E (before its own terms are added): W = E + coef2_0 x0 [+ coef2_1 x1]
             w = [V(22 + 4 * r, 4) for r in range(4)]                    # over the (idle) fragment registers
@@ -512,10 +517,10 @@ class GenLG:
             p.s_cmp("s_cmp_lt_u32", self.s_nadd, 2)
             p.s_branch("s_cbranch_scc1", lab1)
             for r in range(4):
-                p.global_load(2, x0[r].sub(0, 2), self.v_o[r], self.s_A1b)
+                p.global_load(2, x0[r].sub(0, 2), self.v_o[r], self.s_A1b, nt=self.ntl)
             self.add64(self.s_a, self.s_A1b, self.s_planeb)
             for r in range(4):
-                p.global_load(2, x0[r].sub(2, 2), self.v_o[r], self.s_a)
+                p.global_load(2, x0[r].sub(2, 2), self.v_o[r], self.s_a, nt=self.ntl)
             for r in range(4):
                 e = self.elem(t, r)
                 for pl in range(2):
@@ -529,8 +534,8 @@ class GenLG:
             p.s_branch("s_cbranch_scc1", lab2)
             self.add64(self.s_a, self.s_C2b, self.s_planeb)
             for r in range(4):
-                p.global_store(2, self.v_o[r], w[r].sub(0, 2), self.s_C2b)
-                p.global_store(2, self.v_o[r], w[r].sub(2, 2), self.s_a)
+                p.global_store(2, self.v_o[r], w[r].sub(0, 2), self.s_C2b, nt=self.nt)
+                p.global_store(2, self.v_o[r], w[r].sub(2, 2), self.s_a, nt=self.nt)
             p.label(lab2)
         self.store_block("adds", True)
         p.s_branch("s_branch", "L_end")
@@ -576,8 +581,8 @@ class GenLG:
                 e = self.elem(t, r)
                 p.valu("v_mul_f64", e.sub(0, 2), e.sub(0, 2), self.s_sg)
                 p.valu("v_mul_f64", e.sub(2, 2), e.sub(2, 2), self.s_nsg)
-                p.global_store(2, self.v_o[r], e.sub(0, 2), self.s_Cb)
-                p.global_store(2, self.v_o[r], e.sub(2, 2), self.s_b)
+                p.global_store(2, self.v_o[r], e.sub(0, 2), self.s_Cb, nt=self.nt)
+                p.global_store(2, self.v_o[r], e.sub(2, 2), self.s_b, nt=self.nt)
         # ... and the combinations of the mirrored block (bj, bi): its elements go to the accumulators of p1 / p2 (the partial
         # products are dead), the block coordinates are swapped
         p.s_load(1, S(34), S(0, 2), 168)
@@ -650,7 +655,7 @@ class GenLG:
                 self.offsets(t, self.s_boff)
                 for a in range(3):
                     for r in range(4):
-                        p.global_load(2, X[a][t][r], self.v_o[r], ptr[a])
+                        p.global_load(2, X[a][t][r], self.v_o[r], ptr[a], nt=self.ntl)
             for t in range(4):
                 self.offsets(t, self.s_boff)
                 if pl == 0:
@@ -691,14 +696,14 @@ class GenLG:
                     p.valu("v_mul_f64", out, ca[0], x1)
                     p.valu("v_fma_f64", out, ca[1], x2, out)
                     p.valu("v_fma_f64", out, ca[2], x3, out)
-                    p.global_store(2, self.v_o[r], out, ptr[3])
+                    p.global_store(2, self.v_o[r], out, ptr[3], nt=self.nt)
                     # B5
                     out = outs[n_out & 1]
                     n_out += 1
                     p.valu("v_mul_f64", out, ce[0], x2)
                     p.valu("v_fma_f64", out, ce[1], x3, out)
                     p.valu("v_fma_f64", out, ce[2], x6, out)
-                    p.global_store(2, self.v_o[r], out, ptr[4])
+                    p.global_store(2, self.v_o[r], out, ptr[4], nt=self.nt)
                     # B4, B3, B2
                     for cf, sdiag, dstp in ((cd, s_dd, ptr[5]), (cc, s_dc, ptr[6]), (cb, s_db, ptr[7])):
                         out = outs[n_out & 1]
@@ -709,7 +714,7 @@ class GenLG:
                         p.valu("v_fma_f64", out, cf[4], x6, out)
                         if pl == 0:
                             p.valu("v_fma_f64", out, sdiag, wdiag, out)
-                        p.global_store(2, self.v_o[r], out, dstp)
+                        p.global_store(2, self.v_o[r], out, dstp, nt=self.nt)
         # ---- column sums over this block's 64 rows: ones(16 x 4) times the 4 x 16 block of the per-lane sums adds the four
         # lane rows; lanes 0..15 store column bj 64 + 16 w + c of row part bi ----
         p.salu("s_and_b32", self.s_t[0], s_mode, 2)

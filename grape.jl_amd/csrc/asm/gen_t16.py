@@ -172,6 +172,10 @@ class Gen:
         self.stop_after = stop_after     # diagnostic builds: leave the cell after phase n (timing by truncation)
         self.diag = diag                 # diagnostic builds: s_memtime stamps at the phase boundaries of every cell
         self.opts = dict(opts or {})
+        for o in os.environ.get("GRAPE_T16_OPTS", "").split(","):      # (variants of a whole code object: tools, A/B timing)
+            if o:
+                self.opts.setdefault(o, True)
+        self.nt_u = bool(self.opts.get("ntu"))       # non-temporal stores of the propagators
         # ---- scalar registers ----
         self.s_H0, self.s_Sf, self.s_dts, self.s_U = S(4, 2), S(6, 2), S(8, 2), S(10, 2)
         self.s_verdict, self.s_rep = S(12, 2), S(14, 2)
@@ -765,7 +769,7 @@ class Gen:
             p.salu("s_mov_b64", self.s_save, EXEC)
             p.s_cmp("s_cmp_lg_u32", self.s_pm, 0)
             p.salu("s_cselect_b64", EXEC, -1, 0)
-            p.global_store(4, self.v_UO[r], Uprev.sub(16 * sk + 4 * r, 4), self.s_ub[sk])
+            p.global_store(4, self.v_UO[r], Uprev.sub(16 * sk + 4 * r, 4), self.s_ub[sk], nt=self.nt_u)
             p.salu("s_mov_b64", EXEC, self.s_save)
 
         def bload_A(pl, sk, r):
@@ -1478,7 +1482,7 @@ class Gen:
         Uprev = V(8 * self.UT, 64)
         for sk in range(4):
             for rr in range(4):
-                p.global_store(4, self.v_UO[rr], Uprev.sub(16 * sk + 4 * rr, 4), self.s_ub[sk])
+                p.global_store(4, self.v_UO[rr], Uprev.sub(16 * sk + 4 * rr, 4), self.s_ub[sk], nt=self.nt_u)
         p.label("L_end")
         p.s_endpgm()
         return p
