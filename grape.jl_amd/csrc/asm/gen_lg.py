@@ -490,6 +490,76 @@ class GenLG:
         p.salu("s_add_u32", self.s_boff, self.s_boff, self.s_bj)
         p.salu("s_lshl_b32", self.s_boff, self.s_boff, 9)            # (bi 64 NP + bj 64) 8
 
+    def power_adds(self):
+        """E += c1 . (1, A, A2, A3, A6) and, when there is a second output, C2 = E + c2 . (1, A, A2, A3, A6): the coefficient
+        sets sit in the cd / cc slots of the argument block, the pointers in P1 .. P3 and the B1 slot (A6).  One plane and one
+        tile row at a time: 16 loads in flight, their registers are the idle fragment and address registers of the k loop."""
+        p = self.p
+        T = self.T
+        ptr = [S(4, 2), S(6, 2), S(8, 2), S(12, 2)]
+        c1 = [S(20 + 2 * i, 2) for i in range(5)]
+        c2 = [S(84 + 2 * i, 2) for i in range(5)]
+        s_d1, s_d2, s_c2im = S(60, 2), S(62, 2), S(76, 2)
+        p.s_load(4, S(4, 4), S(0, 2), 176)
+        p.s_load(2, S(8, 2), S(0, 2), 192)
+        p.s_load(2, S(12, 2), S(0, 2), 200)
+        p.s_load(8, S(20, 8), S(0, 2), 296)
+        p.s_load(2, S(28, 2), S(0, 2), 328)
+        p.s_load(4, S(84, 4), S(0, 2), 336)
+        p.s_load(4, S(88, 4), S(0, 2), 352)
+        p.s_load(2, S(92, 2), S(0, 2), 368)
+        p.s_waitcnt(lgkm=0)
+        for q in ptr:
+            self.add64(q, q, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        self.add64(s_c2im, self.s_C2b, self.s_planeb)
+        regs = [V(22 + 2 * i, 2) for i in range(12)] + [V(2 + 2 * i, 2) for i in range(4)]
+        X = [[regs[4 * a + r] for r in range(4)] for a in range(4)]
+        vd, v_one_hi, wdiag = T.sub(12), T.sub(13), T.sub(14, 2)
+        p.valu("v_and_b32", vd, 15, self.v_lane)
+        p.valu("v_lshrrev_b32", wdiag.sub(0), 4, self.v_lane)
+        p.valu("v_sub_u32", vd, vd, wdiag.sub(0))
+        p.valu("v_mov_b32", wdiag.sub(0), 0)
+        p.valu("v_mov_b32", v_one_hi, 0x3FF00000)
+        for pl in range(2):
+            if pl == 1:
+                for q in ptr:
+                    self.add64(q, q, self.s_planeb)
+            for t in range(4):
+                self.offsets(t, self.s_boff)
+                for a in range(4):
+                    for r in range(4):
+                        p.global_load(2, X[a][r], self.v_o[r], ptr[a], nt=self.ntl)
+                if pl == 0:      # identity terms: the diagonal block's tile row t == wave only
+                    p.s_cmp("s_cmp_eq_u32", self.s_bi, self.s_bj)
+                    p.salu("s_cselect_b32", self.s_t[0], 1, 0)
+                    p.s_cmp("s_cmp_eq_u32", self.s_wave, t)
+                    p.salu("s_cselect_b32", self.s_t[0], self.s_t[0], 0)
+                    p.s_cmp("s_cmp_lg_u32", self.s_t[0], 0)
+                    for dst, src in ((s_d1, c1[0]), (s_d2, c2[0])):
+                        p.salu("s_cselect_b32", dst.sub(0), src.sub(0), 0)
+                        p.salu("s_cselect_b32", dst.sub(1), src.sub(1), 0)
+                for r in range(4):
+                    e = self.elem(t, r).sub(2 * pl, 2)
+                    if pl == 0:
+                        p.v_cmp("v_cmp_eq_u32", VCC, vd, 4 * r)
+                        p.valu("v_cndmask_b32", wdiag.sub(1), 0, v_one_hi, VCC)            # 1.0 on the diagonal lanes
+                    for a in range(4):
+                        p.valu("v_fma_f64", e, c1[1 + a], X[a][r], e)
+                    if pl == 0:
+                        p.valu("v_fma_f64", e, s_d1, wdiag, e)
+                    w = T.sub(2 * r, 2)
+                    p.valu("v_fma_f64", w, c2[1], X[0][r], e)
+                    for a in range(1, 4):
+                        p.valu("v_fma_f64", w, c2[1 + a], X[a][r], w)
+                    if pl == 0:
+                        p.valu("v_fma_f64", w, s_d2, wdiag, w)
+                lab = f"L_pow_no_c2_{pl}_{t}"
+                p.s_cmp("s_cmp_eq_u64", self.s_C2, 0)
+                p.s_branch("s_cbranch_scc1", lab)
+                for r in range(4):
+                    p.global_store(2, self.v_o[r], T.sub(2 * r, 2), self.s_C2b if pl == 0 else s_c2im, nt=self.nt)
+                p.label(lab)
+
     def epilogue_rest(self):
         p = self.p
         p.s_cmp("s_cmp_eq_u32", self.s_nadd, 0)
@@ -498,6 +568,26 @@ class GenLG:
         self.add64(self.s_A0b, self.s_A0, self.s_cellb.sub(0), self.s_cellb.sub(1))
         self.add64(self.s_A1b, self.s_A1, self.s_cellb.sub(0), self.s_cellb.sub(1))
         self.add64(self.s_C2b, self.s_C2, self.s_cellb.sub(0), self.s_cellb.sub(1))
+        # round 6 (comb mode bit 2): the epilogue terms of this launch are combinations of the POWERS A, A2, A3, A6 -- formed
+        # here, from the block this workgroup owns, instead of being read from arrays B4 / B3 / B2 that the launch of the last
+        # power had to write (that launch is HBM-bound; this one has bandwidth to spare).  Cells that need a scaling
+        # (s_cell > 0: their combinations were redone from the powers with scaled coefficients) keep the arrays.
+        s_mode = S(34)
+        p.s_load(1, s_mode, S(0, 2), 168)
+        p.s_waitcnt(lgkm=0)
+        p.salu("s_and_b32", self.s_t[0], s_mode, 4)
+        p.s_cmp("s_cmp_eq_u32", self.s_t[0], 0)
+        p.s_branch("s_cbranch_scc1", "L_adds_classic")
+        p.s_load(2, S(44, 2), S(0, 2), 208)                  # (the B5 slot of the argument block: s_cell of this chunk)
+        p.s_waitcnt(lgkm=0)
+        p.salu("s_lshl_b32", self.s_t[0], self.s_cell, 2)
+        p.s_load(1, self.s_t[1], S(44, 2), self.s_t[0])
+        p.s_waitcnt(lgkm=0)
+        p.s_cmp("s_cmp_gt_i32", self.s_t[1], 0)
+        p.s_branch("s_cbranch_scc1", "L_adds_classic")
+        self.power_adds()
+        p.s_branch("s_branch", "L_adds_store")
+        p.label("L_adds_classic")
         for t in range(4):
             self.offsets(t, self.s_boff)
             x0 = [self.T.sub(4 * r, 4) for r in range(4)]               # Add_0 (re, im) of the four elements
@@ -537,6 +627,7 @@ class GenLG:
                 p.global_store(2, self.v_o[r], w[r].sub(0, 2), self.s_C2b, nt=self.nt)
                 p.global_store(2, self.v_o[r], w[r].sub(2, 2), self.s_a, nt=self.nt)
             p.label(lab2)
+        p.label("L_adds_store")
         self.store_block("adds", True)
         p.s_branch("s_branch", "L_end")
         # ---- plain product (Hermitian / skew-Hermitian results also store the mirrored block) ----
@@ -620,6 +711,10 @@ class GenLG:
         p.s_waitcnt(lgkm=0)
         p.s_cmp("s_cmp_eq_u32", s_mode, 0)
         p.s_branch("s_cbranch_scc1", f"L_comb_end_{tag}")
+        # round 6 (mode bit 3): B4, B3, B2 are NOT formed here -- the launches that add them form them from the powers
+        # (power_adds); this launch, which is HBM-bound, then writes three arrays instead of six
+        s_lite = S(83)
+        p.salu("s_and_b32", s_lite, s_mode, 8)
         p.s_load(16, S(4, 16), S(0, 2), 176)
         p.s_load(2, s_cp, S(0, 2), 240)
         for i in range(21):
@@ -705,6 +800,9 @@ class GenLG:
                     p.valu("v_fma_f64", out, ce[2], x6, out)
                     p.global_store(2, self.v_o[r], out, ptr[4], nt=self.nt)
                     # B4, B3, B2
+                    skip = f"L_comb_lite_{tag}_{pl}_{t}_{r}"
+                    p.s_cmp("s_cmp_lg_u32", s_lite, 0)
+                    p.s_branch("s_cbranch_scc1", skip)
                     for cf, sdiag, dstp in ((cd, s_dd, ptr[5]), (cc, s_dc, ptr[6]), (cb, s_db, ptr[7])):
                         out = outs[n_out & 1]
                         n_out += 1
@@ -715,6 +813,7 @@ class GenLG:
                         if pl == 0:
                             p.valu("v_fma_f64", out, sdiag, wdiag, out)
                         p.global_store(2, self.v_o[r], out, dstp, nt=self.nt)
+                    p.label(skip)
         # ---- column sums over this block's 64 rows: ones(16 x 4) times the 4 x 16 block of the per-lane sums adds the four
         # lane rows; lanes 0..15 store column bj 64 + 16 w + c of row part bi ----
         p.salu("s_and_b32", self.s_t[0], s_mode, 2)

@@ -100,6 +100,7 @@ struct grape_handle {
     double *d_normpart = nullptr, *d_normpart2 = nullptr;   // [chunk][NP / 8][NP] partial column sums of |A| (per lane of chunks)
     bool lg_fuse = true;           // GRAPE_LG_FUSE=0: the combinations in a pass of their own (lg_t18_operands2_kernel) instead of
                                    // the epilogue of the launch that writes the last power
+    bool lg_pow = false;           // GRAPE_LG_POW=1 (round 6, measured, off): B4, B3, B2 formed from the powers by the launches that add them
     bool lg_spec = true;           // GRAPE_LG_SPEC=0: the separate norm pass (lg_t18_scale_kernel) in front of the combinations
     // second lane of the polynomial route (round 5, GRAPE_LG_LANES=2; off by default): the chunks of an evaluation are
     // independent, so odd chunks run on a second stream with their own scratch and fill the launch tails of the even ones
@@ -896,6 +897,14 @@ struct LgComb {
     const LgT18OperandsArgs *o;
     double *colpart;
     int q_is_a6;
+    int lite;                      // round 6: B4, B3, B2 are left to the launches that add them (LgPow)
+};
+// round 6: the epilogue terms of a launch as combinations of the powers, formed in its epilogue (asm/gen_lg.py power_adds):
+// C += c1 . (1, A, A2, A3, A6); second output C2 = C + c2 . (...).  Cells with s_cell > 0 read the launch's Add arrays.
+struct LgPow {
+    const double *A, *A2, *A3, *A6;
+    const int *s_cell;
+    double c1[5], c2[5];
 };
 bool lg_asm_eligible(const grape_handle *h, int NP, int nc, int per_cell) {
     return h->lg_asm && (NP == 128 || NP == 256) && (long)((nc + 7) / 8) * 8 * per_cell < (1L << 24);
@@ -904,7 +913,8 @@ bool lg_full_view(const LgView &v, int NP) {
     return v.p && v.rb == 0 && v.cb == 0 && v.ld == NP && v.plane == (size_t)NP * NP && v.cell_stride == (size_t)2 * NP * NP;
 }
 // true: launched (err holds the status); false: not eligible
-bool lg_try_asm(const grape_handle *h, hipStream_t s, const LgGemmArgs &a, hipError_t *err, const LgComb *comb = nullptr) {
+bool lg_try_asm(const grape_handle *h, hipStream_t s, const LgGemmArgs &a, hipError_t *err, const LgComb *comb = nullptr,
+                const LgPow *pow = nullptr) {
     if (!h->lg_asm) return false;   // (GRAPE_LG_ASM, read once in grape_create: the route of a handle never changes)
     const int NP = a.C.ld, NB = a.nbi;
     if ((NP != 128 && NP != 256) || a.nbj != NB || a.kblocks != NB || NB * 64 != NP) return false;
@@ -931,11 +941,19 @@ bool lg_try_asm(const grape_handle *h, hipStream_t s, const LgGemmArgs &a, hipEr
     if (comb) {
         if (a.nadd || a.Uout || a.C2.p || squaring) return false;
         const LgT18OperandsArgs &o = *comb->o;
-        k.comb_mode = 1 | (comb->q_is_a6 ? 2 : 0);
+        k.comb_mode = 1 | (comb->q_is_a6 ? 2 : 0) | (comb->lite ? 8 : 0);
         k.P1 = o.A; k.P2 = o.A2; k.P3 = o.A3; k.B1 = o.B1; k.B5 = o.B5; k.B4 = o.B4; k.B3 = o.B3; k.B2 = o.B2;
         k.colpart = comb->colpart;
         memcpy(k.ca, o.a, sizeof(k.ca)); memcpy(k.ce, o.e, sizeof(k.ce)); memcpy(k.cd, o.d, sizeof(k.cd));
         memcpy(k.cc, o.c, sizeof(k.cc)); memcpy(k.cb, o.b, sizeof(k.cb));
+    }
+    if (pow) {
+        if (comb || !a.nadd || squaring || a.herm) return false;
+        k.comb_mode = 4;
+        k.P1 = pow->A; k.P2 = pow->A2; k.P3 = pow->A3;
+        k.B1 = const_cast<double *>(pow->A6);                       // (slots of the argument block: gen_lg.py power_adds)
+        k.B5 = reinterpret_cast<double *>(const_cast<int *>(pow->s_cell));
+        memcpy(k.cd, pow->c1, sizeof(k.cd)); memcpy(k.cc, pow->c2, sizeof(k.cc));
     }
     const int groups = (a.ncell + 7) / 8;
     if ((long)groups * 8 * k.per_cell >= (1L << 24)) return false;
@@ -970,7 +988,7 @@ hipError_t lg_gemm(const grape_handle *h, hipStream_t s, int nc, int nbi, int nb
 hipError_t lg_gemm_poly(const grape_handle *h, hipStream_t s, int nc, int NB, LgView X, LgView Y, LgView C, int herm, int nadd, const LgView *add,
                         const double *coef, const int *add_pow, double cI, const int *scale_s,
                         const LgView *C2 = nullptr, const double *coef2 = nullptr, double cI2 = 0.0,
-                        double2 *Uout = nullptr, int u_np = 0, const int *smax_ptr = nullptr) {
+                        double2 *Uout = nullptr, int u_np = 0, const int *smax_ptr = nullptr, const LgPow *pow = nullptr) {
     LgGemmArgs a{};
     a.X = X; a.Y = Y; a.C = C; a.kblocks = NB; a.alpha = 1.0; a.beta = 0.0; a.cI = cI;
     a.nadd = nadd;
@@ -985,7 +1003,8 @@ hipError_t lg_gemm_poly(const grape_handle *h, hipStream_t s, int nc, int NB, Lg
     const int groups = (nc + 7) / 8;
     const int per_cell = a.herm ? NB * (NB + 1) / 2 : NB * NB;
     hipError_t easm;
-    if (lg_try_asm(h, s, a, &easm)) return easm;
+    if (lg_try_asm(h, s, a, &easm, nullptr, pow)) return easm;
+    if (pow) return hipErrorInvalidValue;   // (only the assembly kernel forms its terms from the powers: the caller asks lg_asm_eligible first)
     hipLaunchKernelGGL(lg_gemm_kernel, dim3(groups * 8 * per_cell), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -1043,7 +1062,16 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         const bool lane2 = h->lg_lanes == 2 && (ichunk & 1);
         double *const *lg = lane2 ? h->d_lg2 : h->d_lg;
         double *A = lg[0], *A2 = lg[1], *A3 = lg[2], *A6 = lg[3], *B1 = lg[4], *B5 = lg[5], *B4 = lg[6], *B3 = lg[7], *B2 = lg[8];
-        double *A9 = A, *Lm = A2, *T = A3;
+        const int nc_ = (int)std::min<long>(h->chunk, ncell - c0_);
+        // round 6: B4, B3, B2 are formed by the launches that add them, from the powers (the launch of A6 then writes three
+        // arrays instead of six: it is HBM-bound, the two general products have bandwidth to spare).  The powers have to
+        // survive until the last product: A9 and B3 + A9 take the buffers of B4 and B3 (a cell that needed a scaling reads
+        // its B4 / B3 block and then overwrites it, in the same workgroup).  Measured at the C5 shard (GRAPE_LG_POW=1, same
+        // box): the launch of A6 1.33 -> 1.13 ms per chunk, the two general products 1.09 -> 1.22 ms each -- the epilogue's eight
+        // serial load groups cost what the HBM-bound launch saves (phase A 124.5 / 126.4 -> 126.4 / 126.3 ms).  Off by default.
+        const bool power = h->lg_pow && h->lg_spec && h->lg_fuse && lg_asm_eligible(h, NP, nc_, hm ? NB * (NB + 1) / 2 : NB * NB) &&
+                           lg_asm_eligible(h, NP, nc_, NB * NB);
+        double *A9 = power ? B4 : A, *Lm = power ? B3 : A2, *T = A3;
         int *const d_scell = lane2 ? h->d_scell2 : h->d_scell;
         double *const d_dinv = lane2 ? h->d_dinv2 : h->d_dinv, *const d_colpart = lane2 ? h->d_colpart2 : h->d_colpart;
         int *const d_smax = lane2 ? h->d_smax2 : h->d_flags + 1;
@@ -1093,7 +1121,7 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
         // (Hermitian generators: a workgroup of the upper block triangle also forms those of the mirrored block)
         const bool fused = h->lg_spec && h->lg_fuse && lg_asm_eligible(h, NP, nc, hm ? NB * (NB + 1) / 2 : NB * NB);
         {
-            const LgComb cb{&oa, d_colpart, hm ? 1 : 0};
+            const LgComb cb{&oa, d_colpart, hm ? 1 : 0, (fused && power) ? 1 : 0};
             LGCHK(lg_gemm(h, s, nc, NB, NB, vA3, vA3, vA6, NB, 1.0, 0.0, 0, nullptr, nullptr, 0.0, nullptr, 0, hm ? 1 : 0,    // A6 = A3 A3
                           nullptr, 0, nullptr, 0, -1, nullptr, fused ? &cb : nullptr));
         }
@@ -1127,14 +1155,19 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
             const LgView add[2] = {vB4, vB3};
             const double c1[2] = {1.0, 0.0}, c2[2] = {0.0, 1.0};
             const int pw0[2] = {0, 0};
-            LGCHK(lg_gemm_poly(h, s, nc, NB, vB1, vB5, vA9, 0, 2, add, c1, pw0, 0.0, nullptr, &vL, c2, 0.0));
+            LgPow pw{A, A2, A3, A6, d_scell, {0}, {0}};
+            memcpy(pw.c1, oa.d, sizeof(pw.c1)); memcpy(pw.c2, oa.c, sizeof(pw.c2));
+            LGCHK(lg_gemm_poly(h, s, nc, NB, vB1, vB5, vA9, 0, 2, add, c1, pw0, 0.0, nullptr, &vL, c2, 0.0, nullptr, 0, nullptr,
+                               (fused && power) ? &pw : nullptr));
         }
         {   // p = B2 + (B3 + A9) A9: straight into U_kn unless a cell of this evaluation needs a squaring
             const LgView add[1] = {vB2};
             const double c1[1] = {1.0};
             const int pw0[1] = {0};
+            LgPow pw{A, A2, A3, A6, d_scell, {0}, {0}};
+            memcpy(pw.c1, oa.b, sizeof(pw.c1));
             LGCHK(lg_gemm_poly(h, s, nc, NB, vL, vA9, vT, 0, 1, add, c1, pw0, 0.0, nullptr, nullptr, nullptr, 0.0,
-                               h->d_U + (size_t)c0_ * pp, NP, smax_ptr));
+                               h->d_U + (size_t)c0_ * pp, NP, smax_ptr, (fused && power) ? &pw : nullptr));
         }
         // squarings by the launch plan (see expm_large): every launch exits at once when it is not needed, the last
         // needed one writes U_kn for all cells of the chunk (cells that are done are copied through)
@@ -1837,6 +1870,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
             const char *envsp = getenv("GRAPE_LG_SPEC"), *envsn = getenv("GRAPE_LG_SN");
             h->lg_spec = h->t18 && !(envsp && atoi(envsp) == 0);
             if (const char *envf = getenv("GRAPE_LG_FUSE")) h->lg_fuse = atoi(envf) != 0;
+            if (const char *envp = getenv("GRAPE_LG_POW")) h->lg_pow = atoi(envp) != 0;
             if (h->lg_spec) CCHK(dmalloc(&h->d_colpart, (size_t)h->chunk * 2 * LG_PARTS * NP));
             // summed controls of every time step for the generator formation (polynomial route, shared control operators):
             // N_T 2 NP^2 doubles -- 2.1 GB at C5 -- when that is a small part of what the propagators take anyway

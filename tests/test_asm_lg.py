@@ -30,7 +30,7 @@ def unplanar(P):
 COMB_NONE = struct.pack("<ii9Q21d", 0, 0, *([0] * 9), *([0.0] * 21))
 
 
-def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False, uif=0, smax=0, s_cell=None, sq_iter=0, comb=None):
+def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False, uif=0, smax=0, s_cell=None, sq_iter=0, comb=None, power=None):
     """comb = (mode, [A, A2, A3], coefficients a[3] e[3] d[5] c[5] b[5]): the fused combinations; returns them and the column
     sums as a sixth and seventh value"""
     ncell, NB = X.shape[0], NP // 64
@@ -54,7 +54,14 @@ def run(prog, NP, X, Y, herm=0, adds=(), coef=(), coef2=(), c2=False, uout=False
                        NP, NB, ncell, herm, len(adds), uif, per_cell, (1 << 32) // per_cell + 1, ((1 << 32) // NB + 1) & 0xFFFFFFFF, 0,
                        a_sc, sq_iter, 1 if s_cell is not None else 0)
     Bs = colpart = None
-    if comb is None:
+    if power is not None:
+        # round 6: the epilogue terms of this launch are combinations of the powers (A, A2, A3, A6), per cell unless s_of_cell > 0
+        powers, s_of_cell, c1, c2_ = power
+        a_in = [g.add(f"P{i}", planar(m))[0] for i, m in enumerate(powers)]
+        a_sc2, _ = g.add("s_of_cell", np.asarray(s_of_cell, np.int32))
+        karg += struct.pack("<ii9Q21d", 4, 0, a_in[0], a_in[1], a_in[2], a_in[3], a_sc2, 0, 0, 0, 0,
+                            *([0.0] * 6), *c1, *(list(c2_) if c2_ is not None else [0.0] * 5), *([0.0] * 5))
+    elif comb is None:
         karg += COMB_NONE
     else:
         mode, powers, cf21 = comb
@@ -207,3 +214,46 @@ def test_last_power_forms_the_combinations_in_its_epilogue(program, herm):
                 else:
                     assert np.isnan(got_p).all() and np.isnan(got_q).all()
     assert np.isnan(colpart[:, :, NB:]).all()
+
+
+def test_epilogue_terms_formed_from_the_powers(program):
+    """round 6: A9 = B1 B5 + d . (1, A, A2, A3, A6) with the second output A9 + c . (1, A, A2, A3, A6), formed in the epilogue
+    from the block of the four powers (identity terms on the diagonal of diagonal blocks only) -- except for a cell whose
+    s_cell > 0, which reads the arrays B4, B3 as before; and the one-output form p = L A9 + b . (...) that goes to U"""
+    _, prog, _ = program
+    rng = np.random.default_rng(11)
+    NP = 128
+    B1, B5, B4, B3 = (rnd(rng, 2, NP) for _ in range(4))
+    A, A2, A3, A6 = (rnd(rng, 2, NP) for _ in range(4))
+    d, c = [0.7, 0.13, -0.17, 0.19, 0.23], [-0.9, 0.29, 0.31, -0.37, 0.41]
+    C, C2, _, _ = run(prog, NP, B1, B5, adds=(B4, B3), coef=(1.0, 0.0), coef2=(0.0, 1.0), c2=True, power=([A, A2, A3, A6], [0, 1], d, c))
+    I = np.eye(NP)
+    comb = lambda q, k: q[0] * I + q[1] * A[k] + q[2] * A2[k] + q[3] * A3[k] + q[4] * A6[k]      # noqa: E731
+    ref0 = B1[0] @ B5[0] + comb(d, 0)
+    assert np.abs(C[0] - ref0).max() < 4e-15 and np.abs(C2[0] - (ref0 + comb(c, 0))).max() < 4e-15
+    ref1 = B1[1] @ B5[1] + B4[1]                                                                    # the cell that keeps its arrays
+    assert np.abs(C[1] - ref1).max() < 4e-15 and np.abs(C2[1] - (ref1 + B3[1])).max() < 4e-15
+    L_, A9, B2 = (rnd(rng, 1, NP) for _ in range(3))
+    b = [1.0, 0.43, 0.47, 0.53, -0.59]
+    Cp, _, U, _ = run(prog, NP, L_, A9, adds=(B2,), coef=(1.0,), uout=True, uif=1, smax=0,
+                      power=([A[:1], A2[:1], A3[:1], A6[:1]], [0], b, None))
+    refp = L_[0] @ A9[0] + comb(b, 0)
+    assert np.abs(U[0] - refp).max() < 4e-15 and np.isnan(Cp.real).all()
+
+
+def test_last_power_leaves_the_epilogue_combinations_to_their_consumers(program):
+    """round 6 (comb mode bit 3): the launch of A6 forms B1, B5 and the column sums only; B4, B3, B2 stay untouched"""
+    _, prog, _ = program
+    rng = np.random.default_rng(12)
+    NP = 128
+    A = rnd(rng, 1, NP, "skew") * 0.7
+    A2 = A @ A
+    A3 = A2 @ A
+    cf = [0.11, -0.23, 0.31,  0.41, 0.53, -0.61] + [0.5] * 15
+    A6, Bs, colpart, _ = run(prog, NP, A3, A3, herm=1, comb=(1 | 2 | 8, [A, A2, A3], cf))
+    r6 = A3 @ A3
+    assert np.abs(A6 - r6).max() < 4e-15 * max(1.0, np.abs(r6).max())
+    assert np.abs(Bs[0] - (cf[0] * A + cf[1] * A2 + cf[2] * A3)).max() < 1e-14
+    assert np.abs(Bs[1] - (cf[3] * A2 + cf[4] * A3 + cf[5] * r6)).max() < 1e-14
+    assert all(np.isnan(b_.real).all() for b_ in Bs[2:])
+    assert not np.isnan(colpart[:, :, :2]).any()
