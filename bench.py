@@ -360,7 +360,11 @@ def main():
         elif pmc_mops and N <= 64:
             executed_flop, executed_src = pmc_mops * 512.0, f"profiles/{pmc_file} (PMC SQ_INSTS_VALU_MFMA_MOPS_F64 x 512; NOT measured in this run)"
         achieved = executed_flop / (expm_ms * 1e-3) * 1e-12 if executed_flop else None
-        if N <= 16:
+        scan_bk = int(work.get("scan_block", 0))
+        if N <= 16 and scan_bk:
+            sweep_kernel = (f"parallel scan over the time axis: scan16_block_kernel (block propagators of {scan_bk} steps on the matrix "
+                            "pipe) + sweep16_pair_kernel over the blocks + scan16_fill_kernel (all blocks at once)")
+        elif N <= 16:
             sweep_kernel = "sweep16_pair_kernel (one wave per trajectory and direction)"
         elif N <= 64:
             sweep_kernel = "sweep_pair_kernel (forward and backward sweep in one launch)"
@@ -401,11 +405,14 @@ def main():
         per_step_bytes = N * N * 16 + 3 * N * 16
         sweep_ms = tm.get("forward", -1.0) + max(tm.get("backward", 0.0), 0.0)
         pb_bytes = (steps_total - steps_walked) * per_step_bytes
+        if N <= 16 and scan_bk:   # the block products read every propagator once more
+            pb_bytes += K_local * N_T * N * N * 16.0
         phase_b = {"kernel": sweep_kernel, "steps_total": steps_total, "steps_carried_by_the_walks_of_phase_A": steps_walked,
                    "algorithmic_bytes": pb_bytes,
                    "GB_per_s": pb_bytes / (sweep_ms * 1e-3) * 1e-9 if sweep_ms > 0 else None, "bound": "hbm",
                    "peak_GB_per_s": 8000.0,
-                   "note": "bytes = (2 K N_T - steps carried by the walks) x (N^2 16 + 3 N 16); time = forward + backward phase"}
+                   "note": "bytes = (2 K N_T - steps carried by the walks) x (N^2 16 + 3 N 16) (+ K N_T N^2 16 for the block "
+                           "products of the scanned sweeps); time = forward + backward phase"}
         res = {
             "metric": "GRAPE gradient evals/sec (N=64, 1000 steps, 128 traj)" if args.config == "C3"
                       else f"GRAPE gradient evals/sec ({args.config})",

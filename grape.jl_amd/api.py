@@ -432,10 +432,10 @@ class GrapeHip:
         self._chk(self._lib.grape_reset_timings(self._h))
 
     def work(self):
-        w = np.zeros(18)
-        self._lib.grape_get_work(self._h, w.ctypes.data, 18)
+        w = np.zeros(19)
+        self._lib.grape_get_work(self._h, w.ctypes.data, 19)
         return dict(cells=w[0], squarings=w[1], flop_expm=w[2], flop_deriv=w[3], deriv_orders=w[4],
                     pivoted_cells=w[5], expm_cells=w[6], series_terms=w[7], series_steps=w[8],
                     t18_mfma_flop=w[9], t18_squarings=w[10], t18_cells=w[11], matrix_free_fallback=w[12], t16_cells=w[13],
                     asm_kernel=w[14], asm_deriv_kernel=w[15], asm_blocked_products=w[16],
-                    walk_steps=w[17])
+                    walk_steps=w[17], scan_block=w[18])

@@ -1361,7 +1361,10 @@ int status_from_flags(grape_handle *h, int flags) {
         // error.  The series kernels of N > 32 hold 64 terms: a larger taylor_max_order that was actually needed there is
         // still reported -- the reference would have summed the further terms
         const bool cut_at_the_limit = h->NP < 48 || h->taylor_max_order <= 64;
-        if (h->taylor_check || !cut_at_the_limit) {
+        // (taylor_grad_step! raises only `if check_convergence && max_order > 1`, optimize.jl:644: a series of ONE term is
+        // returned as it is -- round-5 advisor finding)
+        const bool one_term = h->p.gradient_method == GRAPE_GRAD_TAYLOR && h->taylor_max_order <= 1;
+        if ((h->taylor_check || !cut_at_the_limit) && !one_term) {
             h->err = h->taylor_check ? "taylor_grad_step! did not converge within max_order iterations (optimize.jl:644-648)"
                                      : "taylor_grad_check_convergence = false with taylor_max_order > 64: a series of this evaluation was "
                                        "still unconverged at the 64 terms the series kernels of N > 32 hold";
@@ -3367,13 +3370,13 @@ GRAPE_BARRIER(h ? &h->err : &g_create_error)
 int grape_get_work(grape_handle *h, double *out, int n) try {
     if (!h || !out || n < 4) return GRAPE_ERR_INVALID;
     if (!h->shards.empty()) {   // every entry is a count: the shards add up
-        const int m = n < 18 ? n : 18;
+        const int m = n < 19 ? n : 19;
         std::fill(out, out + m, 0.0);
         for (grape_handle *c : h->shards) {
-            double cw[18] = {0.};
+            double cw[19] = {0.};
             const int rc = grape_get_work(c, cw, m);
             if (rc < 0) return multi_fail(h, c, rc);
-            for (int i = 0; i < m; ++i) out[i] = (i == 15 || i == 16) ? cw[i] : out[i] + cw[i];   // ([15], [16]: kernel ids, the same in every shard)
+            for (int i = 0; i < m; ++i) out[i] = (i == 15 || i == 16 || i == 18) ? cw[i] : out[i] + cw[i];   // ([15], [16]: kernel ids, the same in every shard)
         }
         if (m > 14 && out[14] > 0.0) out[14] = h->shards[0]->asm16p ? 3.0 : h->shards[0]->asm18gp ? 4.0 : h->shards[0]->asm18g ? 2.0 : 1.0;   // (an id, not a count)
         return 4;
@@ -3445,6 +3448,7 @@ int grape_get_work(grape_handle *h, double *out, int n) try {
         }
         out[17] = carried;
     }
+    if (n > 18) out[18] = h->scan16 ? (double)h->scan_Bk : 0.0;   // block length of the scanned sweeps (N <= 16), 0: sequential sweeps
     return 4;
 }
 GRAPE_BARRIER(h ? &h->err : &g_create_error)

@@ -265,7 +265,8 @@ int grape_reset_timings(grape_handle *h);
  * 2 deriv3s_asm (3 <= L <= 8, controls streamed through the LDS), 3 deriv3g_asm (general drift / controls), 4 deriv4_asm
  * (64 < N <= 256), [16] 1 if the products of the blocked polynomial route are the assembly kernel lg_gemm_asm,
  * [17] the steps of the two sweeps that the walks of the exponential kernel carried in the last evaluation (the sweep
- * launch did the remaining 2 K N_T - [17])
+ * launch did the remaining 2 K N_T - [17]), [18] the block length of the scanned sweeps of N <= 16 (round 6: the time axis is
+ * cut into blocks whose propagators are formed first; 0: sequential sweeps; GRAPE_SCAN16=0 / 1 forces)
  * (entries beyond n are not written). */
 int grape_get_work(grape_handle *h, double *out, int n);
 

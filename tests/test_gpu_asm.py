@@ -632,3 +632,36 @@ def test_control_operators_per_trajectory_take_the_assembly_cells(g, ref, herm, 
         assert abs(o[0] - Jr) <= 1e-12, name
         assert np.abs(o[2] - taur).max() <= 1e-12, name
         assert np.abs(o[1] - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3), name
+
+
+@pytest.mark.parametrize("N,L,N_T,K,dt,herm", [(128, 2, 3, 2, 1.0, True), (128, 2, 3, 2, 3.0, True), (100, 1, 4, 2, 1.0, False),
+                                              (256, 2, 2, 1, 2.5, True)])
+def test_blocked_path_epilogue_terms_from_the_powers(g, ref, N, L, N_T, K, dt, herm):
+    """round 6, GRAPE_LG_POW=1 (off by default: measured, no gain): B4, B3, B2 of the five-product polynomial are not written by
+    the launch of the last power but formed from A, A2, A3, A6 in the epilogues of the two launches that add them
+    (gen_lg.py power_adds); cells that need a scaling (dt = 2.5, 3) keep their arrays.  Same results as the default route
+    to rounding, and the oracle's."""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=77 + N, dt=dt, hermitian=herm)
+    out = {}
+    for pow_ in ("1", "0"):
+        old = os.environ.get("GRAPE_LG_POW")
+        os.environ["GRAPE_LG_POW"] = pow_
+        try:
+            with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+                J, G, tau = h.eval(pr["pulsevals"])
+                U = np.stack([h.propagator(k, n) for k in range(K) for n in range(N_T)])
+                out[pow_] = (J, G, tau, U, h.work())
+        finally:
+            if old is None:
+                os.environ.pop("GRAPE_LG_POW", None)
+            else:
+                os.environ["GRAPE_LG_POW"] = old
+    a, b = out["1"], out["0"]
+    assert a[4]["asm_blocked_products"] == 1.0
+    assert np.abs(a[3] - b[3]).max() < 2e-14 * max(1.0, np.abs(b[3]).max())
+    assert abs(a[0] - b[0]) <= 1e-12 and np.abs(a[1] - b[1]).max() <= 1e-10 * max(np.abs(b[1]).max(), 1e-3)
+    Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                gradient_method=ref.TAYLOR)
+    assert abs(a[0] - Jr) <= 1e-12 and np.abs(a[2] - taur).max() <= 1e-12
+    assert np.abs(a[1] - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)

@@ -651,3 +651,21 @@ def test_time_dependent_term_that_is_not_a_control_rides_as_a_pseudo_control(g, 
 def _final_states(ref, pr, tl, x):
     _, _, _, parts = ref.evaluate(pr["H0"], pr["Hc"], tl, x, pr["psi0"], pr["target"], None, want_parts=True)
     return parts["psiT"]
+
+
+@pytest.mark.parametrize("N", [12, 40, 64])
+def test_taylor_series_of_one_term_is_returned_as_it_is(g, ref, N):
+    """taylor_grad_step! raises only `if check_convergence && max_order > 1` (optimize.jl:644): with taylor_grad_max_order = 1
+    the loop `for n = 2:max_order` is empty and the first-order term is the result, whatever check_convergence says
+    (round-5 advisor finding: the HIP path raised GRAPE_ERR_TAYLOR)"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, 2, 5, 2, seed=31 + N, dt=0.05)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"])
+    ref.set_taylor(1, 1e-16, True)
+    try:
+        Jr, Gr, _ = ref.evaluate(*args[:3], pr["pulsevals"], *args[3:], gradient_method=ref.TAYLOR)
+    finally:
+        ref.set_taylor()
+    with g.GrapeHip(*args, gradient_method=g.GRAD_TAYLOR, taylor_max_order=1) as h:
+        J, G, _ = h.eval(pr["pulsevals"])
+    assert abs(J - Jr) <= 1e-12 and np.abs(G - Gr).max() <= tol_G(Gr)
