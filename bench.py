@@ -366,6 +366,9 @@ def main():
                             "pipe) + sweep16_pair_kernel over the blocks + scan16_fill_kernel (all blocks at once)")
         elif N <= 16:
             sweep_kernel = "sweep16_pair_kernel (one wave per trajectory and direction)"
+        elif N <= 64 and scan_bk:
+            sweep_kernel = (f"parallel scan over the time axis: scan_block_kernel (block propagators of {scan_bk} steps, one workgroup per "
+                            "block on the tile engine) + sweep_pair_kernel over the blocks + scan_fill_kernel (all blocks at once)")
         elif N <= 64:
             sweep_kernel = "sweep_pair_kernel (forward and backward sweep in one launch)"
         else:
@@ -405,7 +408,7 @@ def main():
         per_step_bytes = N * N * 16 + 3 * N * 16
         sweep_ms = tm.get("forward", -1.0) + max(tm.get("backward", 0.0), 0.0)
         pb_bytes = (steps_total - steps_walked) * per_step_bytes
-        if N <= 16 and scan_bk:   # the block products read every propagator once more
+        if N <= 64 and scan_bk:   # the block products read every propagator once more
             pb_bytes += K_local * N_T * N * N * 16.0
         phase_b = {"kernel": sweep_kernel, "steps_total": steps_total, "steps_carried_by_the_walks_of_phase_A": steps_walked,
                    "algorithmic_bytes": pb_bytes,

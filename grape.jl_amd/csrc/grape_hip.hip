@@ -392,26 +392,70 @@ hipError_t launch_coop(const SweepArgs &a, bool backward, int S, int rpw, int nw
     return hipErrorInvalidValue;
 }
 
-// N <= 16, parallel scan (scan16_* kernels): block propagators (once per set of propagators: `blocks`), coarse sweeps over
-// them, then all blocks filled at once.  af / ab: the arguments of the fine sweeps (nullptr: that direction is not wanted)
-hipError_t launch_scan16(grape_handle *h, const SweepArgs *af, const SweepArgs *ab, bool blocks, hipStream_t s) {
-    const int NB = h->scan_NB, Bk = h->scan_Bk;
+template <int NP>
+hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s);
+template <int NP>
+hipError_t launch_sweep_pair(const SweepArgs &af, const SweepArgs &ab, hipStream_t s);
+
+// phases 1 and 3 of the scanned sweeps for 17 <= N <= 64 (scan_block_kernel / scan_fill_kernel)
+template <int NT>
+hipError_t launch_scan_block(const ScanArgs &sa, hipStream_t s) {
+    static LdsLimit lim;
+    constexpr int NP = 16 * NT;
+    const size_t lds = (size_t)2 * 2 * NP * (NP + 2) * sizeof(double);
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipError_t e = lim.ensure((const void *)scan_block_kernel<NT>, dev, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((scan_block_kernel<NT>), dim3((unsigned)(sa.KC * sa.NB)), dim3(64 * NT), lds, s, sa);
+    return hipGetLastError();
+}
+
+// Parallel scan of the sweeps over the time axis (grape_kernels.hip.h: scan16_* for N <= 16, scan_* for 17 <= N <= 64): block
+// propagators (once per set of propagators: `blocks`), the ordinary sweeps over them, then all blocks filled at once.
+// af / ab: the arguments of the fine sweeps (nullptr: that direction is not wanted)
+hipError_t launch_scan(grape_handle *h, const SweepArgs *af, const SweepArgs *ab, bool blocks, hipStream_t s) {
+    const int NB = h->scan_NB, Bk = h->scan_Bk, NP = h->NP;
     const SweepArgs &any = af ? *af : *ab;
+    hipError_t e = hipSuccess;
     if (blocks) {
-        Scan16Args sa{};
-        sa.U = any.U; sa.F = h->d_scanF; sa.KC = h->KC; sa.N_T = any.N_T; sa.Bk = Bk; sa.NB = NB;
-        hipLaunchKernelGGL(scan16_block_kernel, dim3((unsigned)(h->KC * NB)), dim3(64), 0, s, sa);
+        if (NP == 16) {
+            Scan16Args sa{};
+            sa.U = any.U; sa.F = h->d_scanF; sa.KC = h->KC; sa.N_T = any.N_T; sa.Bk = Bk; sa.NB = NB;
+            hipLaunchKernelGGL(scan16_block_kernel, dim3((unsigned)(h->KC * NB)), dim3(64), 0, s, sa);
+            e = hipGetLastError();
+        } else {
+            ScanArgs sa{};
+            sa.U = any.U; sa.F = h->d_scanF; sa.KC = h->KC; sa.N_T = any.N_T; sa.Bk = Bk; sa.NB = NB;
+            e = NP == 32 ? launch_scan_block<2>(sa, s) : NP == 48 ? launch_scan_block<3>(sa, s) : launch_scan_block<4>(sa, s);
+        }
+        if (e != hipSuccess) return e;
     }
     SweepArgs cf{}, cb{};
-    if (af) { cf = *af; cf.U = h->d_scanF; cf.N_T = NB; cf.store = h->d_scan_fw; }
-    if (ab) { cb = *ab; cb.U = h->d_scanF; cb.N_T = NB; cb.store = h->d_scan_bw; }
-    if (af && ab) hipLaunchKernelGGL(sweep16_pair_kernel, dim3(2 * any.K), dim3(64), 0, s, cf, cb);
-    else if (af) hipLaunchKernelGGL((sweep16_kernel<false>), dim3(any.K), dim3(64), 0, s, cf);
-    else hipLaunchKernelGGL((sweep16_kernel<true>), dim3(any.K), dim3(64), 0, s, cb);
-    Scan16FillArgs fa{};
-    fa.cfw = h->d_scan_fw; fa.cbw = h->d_scan_bw; fa.Bk = Bk; fa.NB = NB; fa.both = (af && ab) ? 1 : 0;
+    if (af) { cf = *af; cf.U = h->d_scanF; cf.N_T = NB; cf.store = h->d_scan_fw; cf.resume = nullptr; }
+    if (ab) { cb = *ab; cb.U = h->d_scanF; cb.N_T = NB; cb.store = h->d_scan_bw; cb.resume = nullptr; }
+    if (af && ab) e = NP == 16 ? launch_sweep_pair<16>(cf, cb, s) : NP == 32 ? launch_sweep_pair<32>(cf, cb, s)
+                      : NP == 48 ? launch_sweep_pair<48>(cf, cb, s) : launch_sweep_pair<64>(cf, cb, s);
+    else {
+        const SweepArgs &c1 = af ? cf : cb;
+        const bool bw = !af;
+        e = NP == 16 ? launch_sweep<16>(c1, bw, s) : NP == 32 ? launch_sweep<32>(c1, bw, s)
+            : NP == 48 ? launch_sweep<48>(c1, bw, s) : launch_sweep<64>(c1, bw, s);
+    }
+    if (e != hipSuccess) return e;
     const unsigned nblk = (unsigned)(any.K * NB * ((af && ab) ? 2 : 1));
-    hipLaunchKernelGGL(scan16_fill_kernel, dim3(nblk), dim3(64), 0, s, af ? *af : *ab, ab ? *ab : *af, fa, af ? 0 : 1);
+    const SweepArgs &a1 = af ? *af : *ab, &a2 = ab ? *ab : *af;
+    if (NP == 16) {
+        Scan16FillArgs fa{};
+        fa.cfw = h->d_scan_fw; fa.cbw = h->d_scan_bw; fa.Bk = Bk; fa.NB = NB; fa.both = (af && ab) ? 1 : 0;
+        hipLaunchKernelGGL(scan16_fill_kernel, dim3(nblk), dim3(64), 0, s, a1, a2, fa, af ? 0 : 1);
+    } else {
+        ScanFillArgs fa{};
+        fa.cfw = h->d_scan_fw; fa.cbw = h->d_scan_bw; fa.Bk = Bk; fa.NB = NB;
+        if (NP == 32) hipLaunchKernelGGL((scan_fill_kernel<32>), dim3(nblk), dim3(256), 0, s, a1, a2, fa, af ? 0 : 1);
+        else if (NP == 48) hipLaunchKernelGGL((scan_fill_kernel<48>), dim3(nblk), dim3(192), 0, s, a1, a2, fa, af ? 0 : 1);
+        else hipLaunchKernelGGL((scan_fill_kernel<64>), dim3(nblk), dim3(256), 0, s, a1, a2, fa, af ? 0 : 1);
+    }
     return hipGetLastError();
 }
 
@@ -2002,19 +2046,34 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     }
     CCHK(dmalloc(&h->d_fw, (size_t)K * (N_T + 1) * NP));
     CCHK(dmalloc(&h->d_bw, (size_t)K * (N_T + 1) * NP));
-    {   // parallel scan of the sweeps (N <= 16): a latency chain of N_T steps becomes Bk + NB + Bk; pays while the chains
-        // alone leave the chip idle (phase 1 does 16 x the flops of the sweep it replaces)
+    {   // parallel scan of the sweeps over the time axis (N <= 64): a latency chain of N_T steps becomes Bk + NB + Bk steps.  It
+        // pays while the chains alone leave the chip idle: phase 1 does NP times the flops of the sweep it replaces, so its
+        // throughput term grows with the number of trajectories while the sequential sweeps do not.  Measured crossovers at
+        // 1000 steps (forward + backward phase, ms; sequential 1.08 / 1.8 / 1.8 at NP = 32 / 48 / 64): NP = 32: K = 4 / 16 / 64 /
+        // 128 -> 0.14 / 0.27 / 0.93 / 1.76; NP = 48: 0.24 / 0.57 / 1.93 / -; NP = 64: 0.32 / 0.92 / 3.44 / -; NP = 16 (500 steps,
+        // sequential 0.11): K = 32 / 64 / 128 -> 0.049 / 0.090 / 0.145.  Both sides scale with N_T: the rule is a bound on K.
         const char *envs = getenv("GRAPE_SCAN16");
-        const bool want = envs ? atoi(envs) != 0 : (2L * K <= (long)h->num_cus && N_T >= 64);
-        if (NP == 16 && !h->series && want && !(envs && atoi(envs) == 0)) {
-            int Bk = 8;
-            while ((long)Bk * Bk * 2 < (long)N_T && Bk < 64) Bk += 4;     // Bk ~ sqrt(N_T / 2) (tools/scan_bk.sh: 16 at 500 steps: C2 0.273 -> 0.214 ms, the README problem 0.184 -> 0.101 ms)
-            if (const char *envb = getenv("GRAPE_SCAN16_BK")) Bk = std::max(2, atoi(envb));
-            h->scan_Bk = Bk;
-            h->scan_NB = (N_T + Bk - 1) / Bk;
-            CCHK(dmalloc(&h->d_scanF, (size_t)h->KC * h->scan_NB * 256));
-            CCHK(dmalloc(&h->d_scan_fw, (size_t)K * (h->scan_NB + 1) * 16));
-            CCHK(dmalloc(&h->d_scan_bw, (size_t)K * (h->scan_NB + 1) * 16));
+        if (const char *envs2 = getenv("GRAPE_SCAN")) envs = envs2;
+        const bool forced = envs && atoi(envs) != 0;
+        const int kmax = NP == 16 ? 96 : NP == 32 ? 64 : NP == 48 ? 48 : 24;
+        if (NP <= 64 && !h->series && !h->large && !(envs && atoi(envs) == 0) && N_T >= 8 && (forced || (h->KC <= kmax && N_T >= 64))) {
+            // block length: Bk matrix steps (t1 each, a block of phase 1 holds a CU -- NP = 16: a wave -- for its whole chain)
+            // + NB + Bk vector steps (t2 each)
+            const double t2 = NP == 16 ? 0.22 : NP == 32 ? 1.1 : 1.8, t1 = NP == 16 ? 0.45 : NP == 32 ? 3.3 : NP == 48 ? 7.3 : 13.5;
+            const double slots = NP == 16 ? 16.0 * h->num_cus : (double)h->num_cus;
+            int best = 4;
+            double best_t = 1e300;
+            for (int Bk = 4; Bk <= 64 && Bk < std::max(N_T, 5); Bk += (Bk < 16 ? 2 : 4)) {
+                const int NBq = (N_T + Bk - 1) / Bk;
+                const double t = std::ceil((double)h->KC * NBq / slots) * Bk * t1 + (NBq + Bk) * t2;
+                if (t < best_t) { best_t = t; best = Bk; }
+            }
+            if (const char *envb = getenv("GRAPE_SCAN16_BK")) best = std::max(2, atoi(envb));
+            h->scan_Bk = std::min(best, N_T);
+            h->scan_NB = (N_T + h->scan_Bk - 1) / h->scan_Bk;
+            CCHK(dmalloc(&h->d_scanF, (size_t)h->KC * h->scan_NB * NP * NP));
+            CCHK(dmalloc(&h->d_scan_fw, (size_t)K * (h->scan_NB + 1) * NP));
+            CCHK(dmalloc(&h->d_scan_bw, (size_t)K * (h->scan_NB + 1) * NP));
             h->scan16 = true;
         }
     }
@@ -2065,6 +2124,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         h->asm_sq = !(envq && atoi(envq) == 0);
         // (generator classes: one propagator serves several trajectories -- nothing to carry along)
         h->asm_walk = h->KC == K ? (envw ? atoi(envw) & 3 : 3) : 0;
+        if (h->scan16) h->asm_walk = 0;   // (few trajectories: the sweeps are scanned, there is nothing for a walk to carry)
         if (h->asm_walk) {
             std::vector<double> xi((size_t)2 * K * 64 * 2, 0.0);
             for (int k = 0; k < K; ++k) {
@@ -2422,7 +2482,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             e = h->NP == 16 ? launch_series_pair<16>(rf, rb, sc, s) : h->NP == 32 ? launch_series_pair<32>(rf, rb, sc, s)
                                                                                  : launch_series_pair<64>(rf, rb, sc, s);
         } else if (h->scan16) {
-            e = launch_scan16(h, &sa, &sb, true, s);
+            e = launch_scan(h, &sa, &sb, true, s);
         } else {
             e = h->NP == 16 ? launch_sweep_pair<16>(sa, sb, s) : h->NP == 32 ? launch_sweep_pair<32>(sa, sb, s)
                 : h->NP == 48 ? launch_sweep_pair<48>(sa, sb, s) : launch_sweep_pair<64>(sa, sb, s);
@@ -2434,7 +2494,7 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         e = h->NP == 16 ? launch_series<16>(ra, false, s) : h->NP == 32 ? launch_series<32>(ra, false, s)
                                                                        : launch_series<64>(ra, false, s);
     } else if (h->scan16) {
-        e = launch_scan16(h, &sa, nullptr, true, s);
+        e = launch_scan(h, &sa, nullptr, true, s);
     } else
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, false, s); break;
@@ -2524,7 +2584,7 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
     } else if (h->scan16 && !sa.xi) {
         // (the block propagators of the forward call belong to the same propagators; the running-cost inhomogeneity enters
         // every fine step: the sequential sweep keeps that case)
-        e = launch_scan16(h, nullptr, &sa, false, s);
+        e = launch_scan(h, nullptr, &sa, false, s);
     } else
     switch (h->NP) {
         case 16: e = launch_sweep<16>(sa, true, s); break;

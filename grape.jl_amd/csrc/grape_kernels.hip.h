@@ -2760,6 +2760,178 @@ __global__ void __launch_bounds__(64) scan16_fill_kernel(SweepArgs af, SweepArgs
 }
 
 
+// ---------------------------------------------------------------------------------------
+// Round 6 -- the same scan for 17 <= N <= 64 (NT = 2 .. 4 tiles per side), for the problems the reference itself is used
+// on: FEW trajectories.  There the sweeps are one latency chain per trajectory and direction (1.1 us per step at N = 32,
+// 1.8 us at N = 48 / 64, whatever the size: two barriers and an LDS round trip) on a chip that is otherwise idle -- 60-76 %
+// of an evaluation at K = 4, N_T = 1000.  Phase 1: one workgroup of NT waves per block multiplies the block propagator
+// from the left by U_n, step by step (wave w owns column strip w of F: in the C/D layout that strip is exactly the right
+// operand of the product, U_n is staged through the LDS as the left operand of the tile engine gemm_xb3: 3M arithmetic,
+// 12 NT^2 matrix instructions per wave and step); phase 2: the ordinary sweeps over the block propagators; phase 3:
+// scan_fill_kernel, all blocks and both directions at once.
+// ---------------------------------------------------------------------------------------
+struct ScanArgs {
+    const double2 *U;   // [KC][N_T][NP*NP] row-major interleaved
+    double2 *F;         // [KC][NB][NP*NP] block propagators, same layout
+    int KC, N_T, Bk, NB;
+};
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) scan_block_kernel(ScanArgs a) {
+    constexpr int NP = 16 * NT, LD = NP + 2, NTH = 64 * NT, EPT = NP * NP / NTH;   // elements (double2) per thread of a matrix
+    extern __shared__ double scan_lds[];   // two stages of [re | im][NP][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int kc = blockIdx.x / a.NB, b = blockIdx.x - kc * a.NB;
+    const int s = b * a.Bk, e = min(a.N_T, s + a.Bk);
+    const double2 *Un = a.U + ((size_t)kc * a.N_T + s) * NP * NP;
+    // F = 1: register r of tile t of lane (j, g) is F[16 t + 4 r + g][16 wave + j]
+    Strip<NT> F;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            F.re[t][r] = (16 * t + 4 * r + g == 16 * wave + j) ? 1.0 : 0.0;
+            F.im[t][r] = 0.0;
+        }
+    auto stage = [&](int st) { return scan_lds + (size_t)st * 2 * NP * LD; };
+    double2 pre[EPT];
+    auto fetch = [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) pre[q] = Un[(size_t)(n - s) * NP * NP + q * NTH + tid];
+    };
+    auto commit = [&](int st) __attribute__((always_inline)) {
+        double *xr = stage(st), *xi = xr + NP * LD;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int idx = q * NTH + tid, row = idx / NP, col = idx - row * NP;
+            xr[row * LD + col] = pre[q].x;
+            xi[row * LD + col] = pre[q].y;
+        }
+    };
+    fetch(s);
+    commit(0);
+    __syncthreads();
+    for (int n = s; n < e; ++n) {
+        const int cur = (n - s) & 1;
+        if (n + 1 < e) fetch(n + 1);                  // (in flight under the product)
+        Strip3<NT> q;
+        strip3_zero(q);
+        const double *xr = stage(cur);
+        gemm_xb3<NT, LD>(q, xr, xr + NP * LD, F, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            F.re[t] = q.p1[t] - q.p2[t];
+            F.im[t] = q.p3[t] - q.p1[t] - q.p2[t];
+        }
+        if (n + 1 < e) commit(cur ^ 1);               // (the other stage: nobody reads it during this step)
+        __syncthreads();
+    }
+    double2 *Fb = a.F + ((size_t)kc * a.NB + b) * NP * NP;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            Fb[(size_t)(16 * t + 4 * r + g) * NP + 16 * wave + j] = make_double2(F.re[t][r], F.im[t][r]);
+}
+
+// phase 3 for 17 <= N <= 64: block b of trajectory k from the boundary state of the coarse sweep; thread map and arithmetic of
+// sweep_body (one workgroup per block and direction)
+struct ScanFillArgs {
+    const double2 *cfw, *cbw;   // [K][NB + 1][NP]
+    int Bk, NB;
+};
+template <int NP, bool BACKWARD>
+__device__ __forceinline__ void scan_fill_body(const SweepArgs &a, const ScanFillArgs &f, const int k, const int b) {
+    constexpr int NW = NP == 48 ? 3 : 4, RW = NP / NW;
+    __shared__ double2 x[2][NP];
+    __shared__ double2 part[NW][NP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = b * f.Bk, e = min(a.N_T, s + f.Bk), nsteps = e - s;
+    const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
+    double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
+    if (tid < NP) {
+        const double2 v = BACKWARD ? f.cbw[((size_t)k * (f.NB + 1) + b + 1) * NP + tid] : f.cfw[((size_t)k * (f.NB + 1) + b) * NP + tid];
+        x[0][tid] = v;
+        if (BACKWARD ? e == a.N_T : s == 0) st[(size_t)(BACKWARD ? a.N_T : 0) * NP + tid] = v;
+    }
+    __syncthreads();
+    int cur = 0;
+    auto load_tile = [&](double2 (&dst)[RW], int t) __attribute__((always_inline)) {
+        const int nn = BACKWARD ? e - 1 - t : s + t;
+        const double2 *Un = Uk + (size_t)nn * NP * NP;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) dst[r] = lane < NP ? Un[(size_t)(wave * RW + r) * NP + lane] : make_double2(0., 0.);
+    };
+    constexpr int D = NP == 64 ? 2 : NP == 48 ? 4 : 6;
+    double2 un[D][RW];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < nsteps) load_tile(un[d], d);
+    for (int t0 = 0; t0 < nsteps; t0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int t = t0 + d;
+        if (t >= nsteps) break;
+        const int n = BACKWARD ? e - 1 - t : s + t;
+        double2 (&ucur)[RW] = un[d];
+        if (!BACKWARD) {
+            const double2 xv = lane < NP ? x[cur][lane] : make_double2(0., 0.);
+            double pr[RW], pi[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const double2 u = ucur[r];
+                pr[r] = u.x * xv.x - u.y * xv.y;
+                pi[r] = u.x * xv.y + u.y * xv.x;
+            }
+            if (t + D < nsteps) load_tile(un[d], t + D);
+            int row = 0;
+            rs_step<RW / 2, 32>(pr, pi, lane, row);
+            if constexpr (RW >= 4) rs_step<RW / 4, 16>(pr, pi, lane, row);
+            if constexpr (RW >= 8) rs_step<RW / 8, 8>(pr, pi, lane, row);
+            if constexpr (RW >= 16) rs_step<RW / 16, 4>(pr, pi, lane, row);
+#pragma unroll
+            for (int off = 32 / RW; off >= 1; off >>= 1) {
+                pr[0] += __shfl_xor(pr[0], off, 64);
+                pi[0] += __shfl_xor(pi[0], off, 64);
+            }
+            if ((lane & (64 / RW - 1)) == 0) x[cur ^ 1][wave * RW + row] = make_double2(pr[0], pi[0]);
+            __syncthreads();
+            if (tid < NP) st[(size_t)(n + 1) * NP + tid] = x[cur ^ 1][tid];
+        } else {
+            double ar = 0., ai = 0.;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int i = wave * RW + r;
+                const double2 u = ucur[r];
+                const double2 xi = x[cur][i];
+                ar += u.x * xi.x + u.y * xi.y;
+                ai += u.x * xi.y - u.y * xi.x;
+            }
+            if (t + D < nsteps) load_tile(un[d], t + D);
+            if (lane < NP) part[wave][lane] = make_double2(ar, ai);
+            __syncthreads();
+            if (tid < NP) {
+                double2 sum = part[0][tid];
+#pragma unroll
+                for (int q = 1; q < NW; ++q) { sum.x += part[q][tid].x; sum.y += part[q][tid].y; }
+                x[cur ^ 1][tid] = sum;
+                st[(size_t)n * NP + tid] = sum;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
+}
+template <int NP>
+__global__ void __launch_bounds__(NP == 48 ? 192 : 256) scan_fill_kernel(SweepArgs af, SweepArgs ab, ScanFillArgs f, int backward_only) {
+    const int nfw = backward_only ? 0 : af.K * f.NB;
+    const int id = blockIdx.x;
+    if (id < nfw) scan_fill_body<NP, false>(af, f, id / f.NB, id % f.NB);
+    else { const int q = id - nfw; scan_fill_body<NP, true>(ab, f, q / f.NB, q % f.NB); }
+}
+
+
 template <int NP, int LMAX, int NTH>
 __global__ void __launch_bounds__(NTH) deriv_kernel(DerivArgs a) {
     constexpr int NCH = NTH / NP;      // column chunks per row = adjacent lanes (<= 16)

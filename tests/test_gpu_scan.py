@@ -49,6 +49,14 @@ def run(g, pr, scan, bk=None, **kw):
     (7, 1, 64, 2, 0, True, 5),            # 13 blocks, the last one of 4 steps
     (16, 3, 90, 4, 0, True, 90),          # ONE block: phase 2 is a single step
     (12, 1, 67, 2, 1, False, 2),          # blocks of two steps
+    # round 6, 17 <= N <= 64: block propagators by one workgroup per block on the tile engine, the 256-thread sweeps over them
+    (32, 2, 100, 3, 0, True, None),
+    (20, 1, 61, 2, 1, False, 7),          # NP = 32 with padding, a short last block
+    (48, 2, 90, 2, 2, True, None),
+    (40, 1, 50, 3, 0, False, 8),
+    (64, 2, 120, 4, 0, True, None),       # the headline size with few trajectories (the assembly cells without their walks)
+    (64, 2, 45, 2, 1, False, 6),          # general matrices: expm_t18g_asm
+    (57, 3, 40, 2, 2, True, 40),          # one block
 ])
 def test_scan_against_the_sequential_sweeps_and_the_oracle(g, ref, N, L, N_T, K, f, herm, bk):
     from grape_jl_amd import synth
