@@ -1863,6 +1863,13 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
                 }
                 CCHK(dmalloc(&h->d_park2, std::max((size_t)h->deriv_blocks * h->deriv2_maxm, (size_t)h->deriv4_blocks * (h->deriv2_maxm + 1)) * 2 * NP * 16));
                 const char *env3 = getenv("GRAPE_DERIV3");
+                // round 6: FEW batches (few trajectories): one wave per batch leaves the chip idle for a whole batch latency
+                // (0.41 / 0.65 ms at NP = 48 / 64) while a workgroup per batch (deriv2_kernel) takes 0.17 / 0.21 ms per round of
+                // #CUs batches -- measured crossovers ~650 / ~800 batches (K = 4, 1000 steps: 0.41 -> 0.18, 0.65 -> 0.23 ms)
+                const long nbatch = (long)K * ((N_T + 15) / 16);
+                const double t_wave = (NP == 48 ? 0.41 : 0.65) * std::ceil((double)nbatch / (4.0 * h->num_cus));
+                const double t_wg = (NP == 48 ? 0.17 : 0.21) * std::ceil((double)nbatch / (double)h->num_cus);
+                const bool few = !(env3 && atoi(env3) != 0) && NP <= 64 && t_wg < t_wave;
                 const char *envnh = getenv("GRAPE_NO_HERM");
                 h->deriv3_h0g = !h->herm && h->herm_ctrl && !(envnh && atoi(envnh));
                 // four tiles per side and more than two controls: the operators do not fit the LDS; the assembly kernel
@@ -1875,7 +1882,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
                 const char *env3g = getenv("GRAPE_DERIV3G");
                 h->deriv3_general = !h->herm && h->NT == 4 && L <= 7 && !(env3g && atoi(env3g) == 0);
                 if ((h->herm || h->deriv3_h0g || h->deriv3_general) && !h->large && !h->series
-                    && (deriv3_fits(h->NT, L, h->deriv3_h0g) || streamed || h->deriv3_general) && !(env3 && atoi(env3) == 0)) {
+                    && (deriv3_fits(h->NT, L, h->deriv3_h0g) || streamed || h->deriv3_general) && !(env3 && atoi(env3) == 0) && !few) {
                     // workgroups per trajectory: as many as it takes to put a workgroup on every CU, at most one per four batches
                     const int bpk = (N_T + 15) / 16;
                     h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));
@@ -1889,7 +1896,11 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     if (NP < 48 && h->herm && deriv3_fits(h->NT, L)) {   // one wave per batch also at one and two tiles per side (grape_deriv3.hip.h); the matrix-free
                                           // mode as well: at these sizes the derivative kernel never used the parked forward terms
         const char *env3 = getenv("GRAPE_DERIV3");
-        if (!(env3 && atoi(env3) == 0)) {
+        // (few batches at two tiles per side: 0.20 ms per batch latency against 0.14 ms per round of #CUs batches, see above)
+        const long nbatch = (long)K * ((N_T + 15) / 16);
+        const bool few = NP == 32 && !(env3 && atoi(env3) != 0) &&
+                         0.14 * std::ceil((double)nbatch / (double)h->num_cus) < 0.20 * std::ceil((double)nbatch / (4.0 * h->num_cus));
+        if (!(env3 && atoi(env3) == 0) && !few) {
             const int bpk = (N_T + 15) / 16;
             h->deriv2_maxm = 64;
             h->deriv3_wpt = (int)std::max<long>(1, std::min<long>((bpk + 3) / 4, h->num_cus / std::max(1, K)));

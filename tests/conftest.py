@@ -9,6 +9,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+# The suite's problems are tiny (a few trajectories, a few time steps).  Since round 6 grape_create gives such problems the
+# kernels that are fastest for FEW batches -- a workgroup per derivative batch instead of the one-wave assembly kernels -- which
+# would leave the assembly kernels, the subject of most GPU tests, unexercised.  GRAPE_DERIV3=1 pins the one-wave route as the
+# default of the test session; tests/test_gpu_scan.py::test_few_batches_take_the_workgroup_per_batch_kernel removes it.
+os.environ.setdefault("GRAPE_DERIV3", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

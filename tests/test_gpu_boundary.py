@@ -515,7 +515,8 @@ def test_composite_handle_validates_its_first_collective(g, monkeypatch):
     if not rccl:
         pytest.skip("RCCL could not be loaded / initialised on this box")
     assert J1 == J2 and np.array_equal(G1, G2)
-    assert (t2 - t1) < (t1 - t0)                         # no second communicator initialisation
+    if (t1 - t0) > 0.05:                                 # (the first handle really initialised a communicator set: tens of ms; an
+        assert (t2 - t1) < (t1 - t0)                     #  earlier test of this process may have left it in the cache) -- no second one
 
 
 @pytest.mark.parametrize("N,L,N_T,K,kw", [(16, 1, 50, 8, {}), (64, 2, 30, 128, {}), (40, 2, 20, 3, {"functional": 1}),

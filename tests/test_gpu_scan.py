@@ -107,3 +107,22 @@ def test_scan_with_generator_classes_custom_chi_and_running_cost(g, ref):
         assert abs(J - Jr) <= 1e-12 and np.abs(G - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)
     finally:
         os.environ.pop("GRAPE_SCAN16", None)
+
+
+@pytest.mark.parametrize("N,K,N_T,few", [(64, 3, 40, True), (48, 2, 64, True), (32, 2, 50, True), (64, 300, 160, False)])
+def test_few_batches_take_the_workgroup_per_batch_kernel(g, ref, monkeypatch, N, K, N_T, few):
+    """round 6: with few derivative batches (few trajectories) one wave per batch leaves the chip idle for a whole batch
+    latency; grape_create then selects the workgroup-per-batch kernel (grape_get_work[15] == 0) -- and the one-wave assembly
+    kernel when there are many.  Either way the oracle's numbers."""
+    from grape_jl_amd import synth
+    monkeypatch.delenv("GRAPE_DERIV3", raising=False)        # (the suite pins the one-wave route: tests/conftest.py)
+    pr = synth.make_problem(N, 2, N_T, K, seed=5 + N + K)
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"]) as h:
+        J, G, tau = h.eval(pr["pulsevals"])
+        w = h.work()
+    assert (int(w["asm_deriv_kernel"]) == 0) == (few or N < 49)
+    if K * N_T <= 400:
+        Jr, Gr, taur = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                    gradient_method=ref.TAYLOR)
+        assert abs(J - Jr) <= 1e-12 and np.abs(tau - taur).max() <= 1e-12
+        assert np.abs(G - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)
