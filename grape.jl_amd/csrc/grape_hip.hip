@@ -1898,8 +1898,11 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         const char *env3 = getenv("GRAPE_DERIV3");
         // (few batches at two tiles per side: 0.20 ms per batch latency against 0.14 ms per round of #CUs batches, see above)
         const long nbatch = (long)K * ((N_T + 15) / 16);
-        const bool few = NP == 32 && !(env3 && atoi(env3) != 0) &&
-                         0.14 * std::ceil((double)nbatch / (double)h->num_cus) < 0.20 * std::ceil((double)nbatch / (4.0 * h->num_cus));
+        // (one tile per side: deriv_kernel<16> 0.010 ms per ~100 batches against 0.033 ms of batch latency -- the README problem, 32
+        // batches: derivatives 0.033 -> 0.010 ms, evaluation 0.102 -> 0.081 ms; C2, 1024 batches: 0.065 against 0.106)
+        const bool few = !(env3 && atoi(env3) != 0) &&
+                         (NP == 32 ? 0.14 * std::ceil((double)nbatch / (double)h->num_cus) < 0.20 * std::ceil((double)nbatch / (4.0 * h->num_cus))
+                                   : NP == 16 && nbatch <= 256);
         if (!(env3 && atoi(env3) == 0) && !few) {
             const int bpk = (N_T + 15) / 16;
             h->deriv2_maxm = 64;
