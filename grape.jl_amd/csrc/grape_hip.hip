@@ -392,6 +392,8 @@ hipError_t launch_coop(const SweepArgs &a, bool backward, int S, int rpw, int nw
     return hipErrorInvalidValue;
 }
 
+// GRAPE_SWEEP1W=0 (read in grape_create, process-wide: a diagnostic): the 256-thread sweeps at two tiles per side
+static bool g_sweep_wg32 = false;
 template <int NP>
 hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s);
 template <int NP>
@@ -445,15 +447,15 @@ hipError_t launch_scan(grape_handle *h, const SweepArgs *af, const SweepArgs *ab
     if (e != hipSuccess) return e;
     const unsigned nblk = (unsigned)(any.K * NB * ((af && ab) ? 2 : 1));
     const SweepArgs &a1 = af ? *af : *ab, &a2 = ab ? *ab : *af;
-    if (NP == 16) {
+    if (NP <= 32) {
         Scan16FillArgs fa{};
         fa.cfw = h->d_scan_fw; fa.cbw = h->d_scan_bw; fa.Bk = Bk; fa.NB = NB; fa.both = (af && ab) ? 1 : 0;
-        hipLaunchKernelGGL(scan16_fill_kernel, dim3(nblk), dim3(64), 0, s, a1, a2, fa, af ? 0 : 1);
+        if (NP == 16) hipLaunchKernelGGL((scan1w_fill_kernel<16>), dim3(nblk), dim3(64), 0, s, a1, a2, fa, af ? 0 : 1);
+        else hipLaunchKernelGGL((scan1w_fill_kernel<32>), dim3(nblk), dim3(64), 0, s, a1, a2, fa, af ? 0 : 1);
     } else {
         ScanFillArgs fa{};
         fa.cfw = h->d_scan_fw; fa.cbw = h->d_scan_bw; fa.Bk = Bk; fa.NB = NB;
-        if (NP == 32) hipLaunchKernelGGL((scan_fill_kernel<32>), dim3(nblk), dim3(256), 0, s, a1, a2, fa, af ? 0 : 1);
-        else if (NP == 48) hipLaunchKernelGGL((scan_fill_kernel<48>), dim3(nblk), dim3(192), 0, s, a1, a2, fa, af ? 0 : 1);
+        if (NP == 48) hipLaunchKernelGGL((scan_fill_kernel<48>), dim3(nblk), dim3(192), 0, s, a1, a2, fa, af ? 0 : 1);
         else hipLaunchKernelGGL((scan_fill_kernel<64>), dim3(nblk), dim3(256), 0, s, a1, a2, fa, af ? 0 : 1);
     }
     return hipGetLastError();
@@ -461,11 +463,13 @@ hipError_t launch_scan(grape_handle *h, const SweepArgs *af, const SweepArgs *ab
 
 template <int NP>
 hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s) {
-    if (NP == 16) {   // one wave per trajectory, no barriers in the time loop
-        if (backward) hipLaunchKernelGGL((sweep16_kernel<true>), dim3(a.K), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((sweep16_kernel<false>), dim3(a.K), dim3(64), 0, s, a);
+    if (NP == 16 || (NP == 32 && !g_sweep_wg32)) {   // one wave per trajectory, no barriers in the time loop (NP = 32: round 6; GRAPE_SWEEP1W=0: the workgroup kernel)
+        constexpr int P = NP <= 16 ? 16 : 32;
+        if (backward) hipLaunchKernelGGL((sweep1w_kernel<P, true>), dim3(a.K), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((sweep1w_kernel<P, false>), dim3(a.K), dim3(64), 0, s, a);
         return hipGetLastError();
     }
+    if constexpr (NP == 16) return hipErrorInvalidValue;
     constexpr int NTH = NP == 48 ? 192 : 256;   // NP = 48: three waves of 16 rows
     if (backward) hipLaunchKernelGGL((sweep_kernel<NP, true>), dim3(a.K), dim3(NTH), 0, s, a);
     else hipLaunchKernelGGL((sweep_kernel<NP, false>), dim3(a.K), dim3(NTH), 0, s, a);
@@ -474,7 +478,8 @@ hipError_t launch_sweep(const SweepArgs &a, bool backward, hipStream_t s) {
 
 template <int NP>
 hipError_t launch_sweep_pair(const SweepArgs &af, const SweepArgs &ab, hipStream_t s) {
-    if (NP == 16) hipLaunchKernelGGL(sweep16_pair_kernel, dim3(2 * af.K), dim3(64), 0, s, af, ab);
+    if (NP == 16 || (NP == 32 && !g_sweep_wg32)) hipLaunchKernelGGL((sweep1w_pair_kernel<(NP <= 16 ? 16 : 32)>), dim3(2 * af.K), dim3(64), 0, s, af, ab);
+    else if constexpr (NP == 16) return hipErrorInvalidValue;
     else hipLaunchKernelGGL((sweep_pair_kernel<NP>), dim3(2 * af.K), dim3(NP == 48 ? 192 : 256), 0, s, af, ab);
     return hipGetLastError();
 }
@@ -2068,6 +2073,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         // sequential 0.11): K = 32 / 64 / 128 -> 0.049 / 0.090 / 0.145.  Both sides scale with N_T: the rule is a bound on K.
         const char *envs = getenv("GRAPE_SCAN16");
         if (const char *envs2 = getenv("GRAPE_SCAN")) envs = envs2;
+        { const char *env1w = getenv("GRAPE_SWEEP1W"); g_sweep_wg32 = env1w && atoi(env1w) == 0; }
         const bool forced = envs && atoi(envs) != 0;
         const int kmax = NP == 16 ? 96 : NP == 32 ? 64 : NP == 48 ? 48 : 24;
         if (NP <= 64 && !h->series && !h->large && !(envs && atoi(envs) == 0) && N_T >= 8 && (forced || (h->KC <= kmax && N_T >= 64))) {

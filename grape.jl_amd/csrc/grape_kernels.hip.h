@@ -2508,11 +2508,17 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
 // of LDS that only this wave touches (a wave's LDS operations are ordered: no barrier).  The tile of step n+1 and
 // n+2 is requested while step n is reduced.
 // ---------------------------------------------------------------------------------------
-template <bool BACKWARD>
-__device__ __forceinline__ void sweep16_body(const SweepArgs &a, const int k, double2 *xs /* [16] LDS, this wave's */) {
-    constexpr int NP = 16;
+#ifndef SWEEP1W32_DEPTH
+#define SWEEP1W32_DEPTH 5   /* (X32 shape, forward + backward in one launch: 3 -> 1.012 ms, 4 -> 0.992, 5 -> 0.973; the 256-thread kernel 1.148) */
+#endif
+// Round 6: the same design at two tiles per side (NP = 32: lane (row r = lane >> 1, half c = lane & 1) holds SIXTEEN entries,
+// a pair sum instead of a quad sum, three tiles in flight): the 256-thread kernel costs 1.1 us per step whatever the size.
+template <int NP, bool BACKWARD>
+__device__ __forceinline__ void sweep1w_body(const SweepArgs &a, const int k, double2 *xs /* [NP] LDS, this wave's */) {
+    static_assert(NP == 16 || NP == 32, "one wave per trajectory: one or two tiles per side");
+    constexpr int LPR = 64 / NP, EPL = NP / LPR;      // lanes per row, entries per lane
     const int lane = threadIdx.x & 63;
-    const int r = lane >> 2, c = lane & 3;
+    const int r = lane / LPR, c = lane % LPR;
     const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
     double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
     // ---- boundary state: lanes 0..15 hold element `lane` ----
@@ -2544,17 +2550,17 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs &a, const int k, do
         }
     }
     // tile loads: forward row r, columns 4c..4c+3 (64 contiguous bytes); backward rows 4c..4c+3 of column r
-    auto load_tile = [&](double2 (&dst)[4], int step) __attribute__((always_inline)) {
+    auto load_tile = [&](double2 (&dst)[EPL], int step) __attribute__((always_inline)) {
         const int nn = BACKWARD ? a.N_T - 1 - step : step;
         const double2 *Un = Uk + (size_t)nn * NP * NP;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) dst[m] = BACKWARD ? Un[(4 * c + m) * NP + r] : Un[r * NP + 4 * c + m];
+        for (int m = 0; m < EPL; ++m) dst[m] = BACKWARD ? Un[(EPL * c + m) * NP + r] : Un[r * NP + EPL * c + m];
     };
     // The tiles of the next DEPTH steps are in flight, in a ring of registers with STATIC indices (the time loop is
     // unrolled DEPTH times): shifting the ring with register moves makes every step wait for the newest load
     // (s_waitcnt vmcnt(0)), and the loop then runs at one memory latency per step whatever the depth.
-    constexpr int DEPTH = 12;   // (C2 forward + backward: 8 -> 0.114 ms, 12 -> 0.108, 16 -> 0.111, 24 -> 0.120)
-    double2 un[DEPTH][4];
+    constexpr int DEPTH = NP == 16 ? 12 : SWEEP1W32_DEPTH;   // (C2 forward + backward: 8 -> 0.114 ms, 12 -> 0.108, 16 -> 0.111, 24 -> 0.120)
+    double2 un[DEPTH][EPL];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (d < a.N_T) load_tile(un[d], d);
@@ -2567,8 +2573,8 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs &a, const int k, do
                 const int n = BACKWARD ? a.N_T - 1 - step : step;
                 double pr = 0., pi = 0.;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const double2 x = xs[4 * c + m];
+                for (int m = 0; m < EPL; ++m) {
+                    const double2 x = xs[EPL * c + m];
                     const double2 u = un[d][m];
                     if (!BACKWARD) {   // U x
                         pr = fma(u.x, x.x, pr); pr = fma(-u.y, x.y, pr);
@@ -2579,8 +2585,8 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs &a, const int k, do
                     }
                 }
                 if (step + DEPTH < a.N_T) load_tile(un[d], step + DEPTH);
-                pr = group_sum<4>(pr);
-                pi = group_sum<4>(pi);
+                pr = group_sum<LPR>(pr);
+                pi = group_sum<LPR>(pi);
                 if (BACKWARD && a.xi && n > 0) {   // chi(t_n) += lambda_b Dt_n / rho_k xi_k(t_n)   (optimize.jl:897-908)
                     const double2 x_ = a.xi[((size_t)k * (a.N_T + 1) + n) * NP + r];
                     const double cc = a.lambda_b * a.wq[n] / rho;
@@ -2609,15 +2615,16 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs &a, const int k, do
     }
 }
 
-template <bool BACKWARD>
-__global__ void __launch_bounds__(64) sweep16_kernel(SweepArgs a) {
-    __shared__ double2 xs[16];
-    sweep16_body<BACKWARD>(a, blockIdx.x, xs);
+template <int NP, bool BACKWARD>
+__global__ void __launch_bounds__(64) sweep1w_kernel(SweepArgs a) {
+    __shared__ double2 xs[NP];
+    sweep1w_body<NP, BACKWARD>(a, blockIdx.x, xs);
 }
-__global__ void __launch_bounds__(64) sweep16_pair_kernel(SweepArgs af, SweepArgs ab) {
-    __shared__ double2 xs[16];
-    if ((int)blockIdx.x < af.K) sweep16_body<false>(af, blockIdx.x, xs);
-    else sweep16_body<true>(ab, blockIdx.x - af.K, xs);
+template <int NP>
+__global__ void __launch_bounds__(64) sweep1w_pair_kernel(SweepArgs af, SweepArgs ab) {
+    __shared__ double2 xs[NP];
+    if ((int)blockIdx.x < af.K) sweep1w_body<NP, false>(af, blockIdx.x, xs);
+    else sweep1w_body<NP, true>(ab, blockIdx.x - af.K, xs);
 }
 
 
@@ -2695,11 +2702,11 @@ struct Scan16FillArgs {
     const double2 *cfw, *cbw;   // [K][NB + 1][16] boundary states of the coarse sweeps (forward / backward)
     int Bk, NB, both;           // both: blocks [K NB, 2 K NB) of the grid are the backward blocks
 };
-template <bool BACKWARD>
-__device__ __forceinline__ void scan16_fill_body(const SweepArgs &a, const Scan16FillArgs &f, const int k, const int b, double2 *xs) {
-    constexpr int NP = 16;
+template <int NP, bool BACKWARD>
+__device__ __forceinline__ void scan1w_fill_body(const SweepArgs &a, const Scan16FillArgs &f, const int k, const int b, double2 *xs) {
+    constexpr int LPR = 64 / NP, EPL = NP / LPR;
     const int lane = threadIdx.x & 63;
-    const int r = lane >> 2, c = lane & 3;
+    const int r = lane / LPR, c = lane % LPR;
     const int s = b * f.Bk, e = min(a.N_T, s + f.Bk);
     const double2 *Uk = a.U + (size_t)(a.cls ? a.cls[k] : k) * a.N_T * NP * NP;
     double2 *st = a.store + (size_t)k * (a.N_T + 1) * NP;
@@ -2709,14 +2716,14 @@ __device__ __forceinline__ void scan16_fill_body(const SweepArgs &a, const Scan1
         if (BACKWARD ? e == a.N_T : s == 0) st[(size_t)(BACKWARD ? a.N_T : 0) * NP + lane] = v;   // the boundary state of the trajectory itself
     }
     const int nsteps = e - s;
-    auto load_tile = [&](double2 (&dst)[4], int t) __attribute__((always_inline)) {
+    auto load_tile = [&](double2 (&dst)[EPL], int t) __attribute__((always_inline)) {
         const int nn = BACKWARD ? e - 1 - t : s + t;
         const double2 *Un = Uk + (size_t)nn * NP * NP;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) dst[m] = BACKWARD ? Un[(4 * c + m) * NP + r] : Un[r * NP + 4 * c + m];
+        for (int m = 0; m < EPL; ++m) dst[m] = BACKWARD ? Un[(EPL * c + m) * NP + r] : Un[r * NP + EPL * c + m];
     };
-    constexpr int DEPTH = 8;
-    double2 un[DEPTH][4];
+    constexpr int DEPTH = NP == 16 ? 8 : 3;
+    double2 un[DEPTH][EPL];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (d < nsteps) load_tile(un[d], d);
@@ -2728,8 +2735,8 @@ __device__ __forceinline__ void scan16_fill_body(const SweepArgs &a, const Scan1
                 const int n = BACKWARD ? e - 1 - t : s + t;
                 double pr = 0., pi = 0.;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const double2 x = xs[4 * c + m];
+                for (int m = 0; m < EPL; ++m) {
+                    const double2 x = xs[EPL * c + m];
                     const double2 u = un[d][m];
                     if (!BACKWARD) {
                         pr = fma(u.x, x.x, pr); pr = fma(-u.y, x.y, pr);
@@ -2740,8 +2747,8 @@ __device__ __forceinline__ void scan16_fill_body(const SweepArgs &a, const Scan1
                     }
                 }
                 if (t + DEPTH < nsteps) load_tile(un[d], t + DEPTH);
-                pr = group_sum<4>(pr);
-                pi = group_sum<4>(pi);
+                pr = group_sum<LPR>(pr);
+                pi = group_sum<LPR>(pi);
                 if (c == 0) {
                     const double2 y = make_double2(pr, pi);
                     xs[r] = y;
@@ -2751,12 +2758,13 @@ __device__ __forceinline__ void scan16_fill_body(const SweepArgs &a, const Scan1
         }
     }
 }
-__global__ void __launch_bounds__(64) scan16_fill_kernel(SweepArgs af, SweepArgs ab, Scan16FillArgs f, int backward_only) {
-    __shared__ double2 xs[16];
+template <int NP>
+__global__ void __launch_bounds__(64) scan1w_fill_kernel(SweepArgs af, SweepArgs ab, Scan16FillArgs f, int backward_only) {
+    __shared__ double2 xs[NP];
     const int nfw = backward_only ? 0 : af.K * f.NB;
     const int id = blockIdx.x;
-    if (id < nfw) scan16_fill_body<false>(af, f, id / f.NB, id % f.NB, xs);
-    else { const int q = id - nfw; scan16_fill_body<true>(ab, f, q / f.NB, q % f.NB, xs); }
+    if (id < nfw) scan1w_fill_body<NP, false>(af, f, id / f.NB, id % f.NB, xs);
+    else { const int q = id - nfw; scan1w_fill_body<NP, true>(ab, f, q / f.NB, q % f.NB, xs); }
 }
 
 
