@@ -203,3 +203,25 @@ def test_absolute_pin_against_a_60_digit_evaluation_gpu(g, name, functional, met
     assert np.abs(G - w["G"]).max() <= 1e-13 * sG, np.abs(G - w["G"]).max() / sG
     assert np.abs(psiT - w["psiT"]).max() <= 1e-13 * sT
     assert np.abs(tg - w["tau_grads"]).max() <= 1e-13 * np.abs(w["tau_grads"]).max()
+
+
+@pytest.mark.parametrize("name,kernels", [("herm64", dict(asm_kernel=1, asm_deriv_kernel=1)),
+                                          ("herm100", dict(asm_blocked_products=1, asm_deriv_kernel=4))])
+@pytest.mark.parametrize("functional", [0, 1, 2])
+def test_absolute_pins_reach_the_headline_kernels(g, name, kernels, functional):
+    """Round 6: the HIP path against 50-digit values at N = 64 (expm_t16_asm + deriv3_asm, asserted) and N = 100 (lg_gemm_asm +
+    deriv4_asm_128) -- tests/golden/make_mpmath_pin64.py: Hermitian eigendecomposition + Daleckii-Krein in mpmath, inputs from
+    a written-out LCG.  The round-5 review's "missing" 1: no pin reached an assembly kernel.  1e-13 of the scale."""
+    from conftest import load_mpmath_pin64
+    pr, want = load_mpmath_pin64(name)
+    w = want[functional]
+    with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], functional=functional) as h:
+        J, G, tau, psiT = h.eval(pr["pulsevals"], want_psiT=True)
+        tg, work = h.tau_grads(), h.work()
+    for key, v in kernels.items():
+        assert int(work[key]) == v, (key, work[key])
+    sJ, sG, sT = max(1.0, abs(w["J"])), np.abs(w["G"]).max(), max(1.0, np.abs(w["tau"]).max())
+    assert abs(J - w["J"]) <= 1e-13 * sJ and np.abs(tau - w["tau"]).max() <= 1e-13 * sT
+    assert np.abs(G - w["G"]).max() <= 2e-13 * sG, np.abs(G - w["G"]).max() / sG
+    assert np.abs(psiT - w["psiT"]).max() <= 1e-13 * sT
+    assert np.abs(tg - w["tau_grads"]).max() <= 2e-13 * np.abs(w["tau_grads"]).max()

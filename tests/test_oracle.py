@@ -185,6 +185,32 @@ def test_golden_vs_c_oracle(ref, path):
         assert abs(z["J"] - z["J_closed_form"]) < 1e-14
 
 
+@pytest.mark.parametrize("name", ["herm64", "herm100"])
+def test_absolute_pins_at_the_sizes_of_the_headline_kernels(ref, name):
+    """Round 6: 50-digit values at N = 64 and N = 100 (tests/golden/make_mpmath_pin64.py: Hermitian eigendecomposition +
+    Daleckii-Krein in mpmath -- another exact formula for the same quantities, no scipy, no LAPACK).  Both restatements, both
+    gradient routes, all three functionals, to 1e-13 of the scale: the oracle that checks the assembly kernels is itself
+    pinned at their sizes."""
+    from conftest import load_mpmath_pin64
+    pr, want = load_mpmath_pin64(name)
+    args = (pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"])
+    for functional in (0, 1, 2):
+        w = want[functional]
+        sJ, sG, sT = max(1.0, abs(w["J"])), np.abs(w["G"]).max(), max(1.0, np.abs(w["tau"]).max())
+        sg = np.abs(w["tau_grads"]).max()
+        for method in (ref.GRADGEN, ref.TAYLOR):
+            J, G, tau, parts = ref.evaluate(*args, functional, gradient_method=method, want_parts=True)
+            assert abs(J - w["J"]) <= 1e-13 * sJ and np.abs(tau - w["tau"]).max() <= 1e-13 * sT
+            assert np.abs(G - w["G"]).max() <= 1e-13 * sG, (name, functional, method, np.abs(G - w["G"]).max() / sG)
+            assert np.abs(parts["psiT"] - w["psiT"]).max() <= 1e-13 * sT
+            assert np.abs(parts["tau_grads"] - w["tau_grads"]).max() <= 1e-13 * sg
+    if name == "herm64":      # the numpy restatement too (scipy's expm of the dense 192 x 192 block matrix per backward cell)
+        w = want[0]
+        J, G, tau = go.evaluate_gradient(*args, 0)
+        assert abs(J - w["J"]) <= 1e-13 and np.abs(tau - w["tau"]).max() <= 1e-13
+        assert np.abs(G - w["G"]).max() <= 1e-13 * np.abs(w["G"]).max()
+
+
 def test_chi_norm_guard(ref):
     # target orthogonal to everything reachable: tau = 0 -> chi_sm = 0 -> error (optimize.jl:1021-1025)
     H0 = np.zeros((1, 2, 2), complex)
