@@ -41,7 +41,9 @@ def vdot(x, y):
     return sum(mp.conj(x[i]) * y[i] for i in range(len(x)))
 
 
-def evaluate_all(pr):
+def evaluate_all(pr, general=False):
+    """general: H = V diag(lam) V^-1 by mpmath's general eigensolver; the backward quantities then live in the eigenbasis of
+    H^dagger = W diag(conj(lam)) W^-1 with W = (V^-1)^dagger, W^-1 = V^dagger"""
     N, L, N_T, K = pr["N"], pr["L"], pr["N_T"], pr["K"]
     tl = [mp.mpf(float(t)) for t in pr["tlist"]]
     eps = [[mp.mpf(float(pr["pulsevals"][l * N_T + n])) for n in range(N_T)] for l in range(L)]
@@ -57,11 +59,18 @@ def evaluate_all(pr):
             H = H0[k].copy()
             for l in range(L):
                 H = H + eps[l][n] * Hc[l]
-            lam, V = mp.eighe(H)
-            Vh = V.transpose_conj()
-            D = Vh * H * V
-            resid = max(resid, max(abs(D[i, j] - (lam[i] if i == j else 0)) for i in range(N) for j in range(N)))
-            cells[(k, n)] = (lam, V, Vh)
+            if general:
+                lam, V = mp.eig(H, left=False, right=True)
+                Vi = V ** -1
+                D = Vi * H * V
+                resid = max(resid, max(abs(D[i, j] - (lam[i] if i == j else 0)) for i in range(N) for j in range(N)))
+                cells[(k, n)] = (lam, V, Vi)
+            else:
+                lam, V = mp.eighe(H)
+                Vh = V.transpose_conj()
+                D = Vh * H * V
+                resid = max(resid, max(abs(D[i, j] - (lam[i] if i == j else 0)) for i in range(N) for j in range(N)))
+                cells[(k, n)] = (lam, V, Vh)
             print(f"  cell ({k}, {n}) decomposed, residual so far {mp.nstr(resid, 3)}", flush=True)
     # forward sweep (evaluate_functional, optimize.jl:696-768)
     storage = []
@@ -99,11 +108,14 @@ def evaluate_all(pr):
             for n in range(N_T - 1, -1, -1):
                 dt = tl[n + 1] - tl[n]
                 lam, V, Vh = cells[(k, n)]
-                ex = [mp.exp(I * lam[i] * dt) for i in range(N)]          # exp(+i H dt) = U_n^dagger (H Hermitian)
+                if general:       # eigenbasis of H^dagger: W = (V^-1)^dagger, W^-1 = V^dagger, eigenvalues conj(lam)
+                    lam = [mp.conj(x) for x in lam]
+                    V, Vh = Vh.transpose_conj(), V.transpose_conj()
+                ex = [mp.exp(I * lam[i] * dt) for i in range(N)]          # exp(+i H^dagger dt) = U_n^dagger
                 c = Vh * chik
                 psi = storage[k][n]
                 for l in range(L):
-                    Et = Vh * (I * dt * Hc[l]) * V                          # direction i dt mu_l^dagger in the eigenbasis
+                    Et = Vh * (I * dt * Hc[l].transpose_conj()) * V         # direction i dt mu_l^dagger in the eigenbasis
                     d = mp.zeros(N, 1)
                     for i in range(N):
                         acc = mp.mpc(0)
@@ -130,7 +142,9 @@ def main():
     for name in SHAPES:
         pr = make_inputs(name)
         print(name, flush=True)
-        res, resid = evaluate_all(pr)
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
+        res, resid = evaluate_all(pr, general=bool(SHAPES[name].get("general")))
         out = dict(note="inputs: tests/golden/pin64_inputs.py (dyadic rationals from a written-out LCG); outputs: 50-digit mpmath "
                         "evaluation by Hermitian eigendecomposition + Daleckii-Krein (tests/golden/make_mpmath_pin64.py), printed to 40 digits",
                    name=name, N=pr["N"], L=pr["L"], N_T=pr["N_T"], K=pr["K"], eig_residual=mp.nstr(resid, 5), functionals={})

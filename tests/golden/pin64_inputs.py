@@ -4,7 +4,9 @@ linear congruential generator written out here -- no library random stream enter
 and to the GPU ARE the numbers mpmath worked with, on every machine and numpy version."""
 import numpy as np
 
-SHAPES = {"herm64": dict(N=64, L=2, N_T=4, K=2, seed=0x6772617065_64), "herm100": dict(N=100, L=2, N_T=2, K=1, seed=0x6772617065_100)}
+SHAPES = {"herm64": dict(N=64, L=2, N_T=4, K=2, seed=0x6772617065_64), "herm100": dict(N=100, L=2, N_T=2, K=1, seed=0x6772617065_100),
+          # general (non-Hermitian) generators: expm_t18g_asm + deriv3g_asm
+          "gen64": dict(N=64, L=2, N_T=3, K=1, seed=0x6772617065_65, general=True)}
 
 
 class Lcg:
@@ -31,6 +33,8 @@ def make_inputs(name):
         a = g.ints(N * N, -int(scale * q), int(scale * q)).reshape(N, N)
         b = g.ints(N * N, -int(scale * q), int(scale * q)).reshape(N, N)
         X = (a + 1j * b) / q
+        if sh.get("general"):
+            return X * 1.5                   # (spectral radius ~ 0.45 ... 0.9; an exact factor)
         return (X + X.conj().T) / 2
 
     s0 = 1.0 / (2.0 * np.sqrt(N))                  # spectral radius of the drift ~ 1, of a control ~ 0.5

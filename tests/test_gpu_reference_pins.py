@@ -206,7 +206,8 @@ def test_absolute_pin_against_a_60_digit_evaluation_gpu(g, name, functional, met
 
 
 @pytest.mark.parametrize("name,kernels", [("herm64", dict(asm_kernel=1, asm_deriv_kernel=1)),
-                                          ("herm100", dict(asm_blocked_products=1, asm_deriv_kernel=4))])
+                                          ("herm100", dict(asm_blocked_products=1, asm_deriv_kernel=4)),
+                                          ("gen64", dict(asm_kernel=2, asm_deriv_kernel=3))])
 @pytest.mark.parametrize("functional", [0, 1, 2])
 def test_absolute_pins_reach_the_headline_kernels(g, name, kernels, functional):
     """Round 6: the HIP path against 50-digit values at N = 64 (expm_t16_asm + deriv3_asm, asserted) and N = 100 (lg_gemm_asm +

@@ -185,10 +185,10 @@ def test_golden_vs_c_oracle(ref, path):
         assert abs(z["J"] - z["J_closed_form"]) < 1e-14
 
 
-@pytest.mark.parametrize("name", ["herm64", "herm100"])
+@pytest.mark.parametrize("name", ["herm64", "herm100", "gen64"])
 def test_absolute_pins_at_the_sizes_of_the_headline_kernels(ref, name):
-    """Round 6: 50-digit values at N = 64 and N = 100 (tests/golden/make_mpmath_pin64.py: Hermitian eigendecomposition +
-    Daleckii-Krein in mpmath -- another exact formula for the same quantities, no scipy, no LAPACK).  Both restatements, both
+    """Round 6: 50-digit values at N = 64 and N = 100 (tests/golden/make_mpmath_pin64.py: eigendecomposition -- Hermitian, and
+    general for gen64 -- + Daleckii-Krein in mpmath: another exact formula for the same quantities, no scipy, no LAPACK).  Both restatements, both
     gradient routes, all three functionals, to 1e-13 of the scale: the oracle that checks the assembly kernels is itself
     pinned at their sizes."""
     from conftest import load_mpmath_pin64
