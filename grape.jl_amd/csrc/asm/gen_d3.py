@@ -23,7 +23,13 @@ Register map (512 per lane, one wave per SIMD):
   a0..a95     the vector block (re, im, re + im): right operand of every product of an order
   a96..a159   chi(t_{n+1}) (pass 2)
   a160..a223  landing area of the parked term u_a (pass 2)
-"""
+
+Round 6 -- the economized series (tools/econ_coeffs.py, grape_econ_coeffs.h).  A batch whose 16 cells the four-product
+exponential kernel has certified (spectral radius <= 1.36: bit 1 of the kernel argument `deep` says that a second array of
+batch flags lies behind `batch_flag`) stops pass 1 after ECON_M - 1 orders if the Taylor terms are not below the tolerance
+by then, and pass 2 runs the SAME recursion with the scalars (omega_a, sigma_a) of a degree-16 polynomial whose derivative
+is within 2e-16 of exp's on the certified segment -- 31 applications of H where the Taylor sum takes 2 x 19.  Pass 2 reads
+its two scalars per order from a table of pairs behind 1 / m (Taylor: both 1 / (a + 1), the same bits as before)."""
 import os
 import struct
 import sys
@@ -39,6 +45,9 @@ NTILE = NT * (NT + 1) // 2
 MAT_B = NTILE * 2 * TILE_B       # bytes of an operator in LDS (43520)
 KERNARG = 160
 VPLANE_B = NP * 16 * 16          # bytes of one parked term (64 x 16 complex, interleaved)
+ECON_M = 16                      # degree of the economized polynomial (grape_econ_coeffs.h: ECON_M)
+PAIRS_OFF = 32768                # the buffer behind `inv`: 1 / m (2048 doubles) | piece table of deriv3s_asm | at PAIRS_OFF the pairs
+ECON_OFF = 32768                 # (omega_a, sigma_a) of the Taylor series, a < 2048 | ECON_OFF further those of the economized one
 
 
 def tile_index(ti, tj):
@@ -77,6 +86,8 @@ class GenD3:
         self.s_save = S(84, 2)
         self.s_rhov = S(86, 2)
         self.s_lo16 = S(88, 2)                            # exec of lanes 0..15
+        self.s_capb, self.s_econ = S(90), S(91)           # orders pass 1 may form for this batch; the economized scalars apply
+        self.s_sig = S(92, 2)                             # sigma_a (pass 2; s_invm holds omega_a)
         # ---- per-lane ----
         self.v_tid, self.v_lane = V(0), V(1)
         self.v_BD = [V(2 + 2 * op) for op in range(3)]
@@ -340,10 +351,59 @@ class GenD3:
         for t in range(4):
             self.add64(self.s_pb[t], self.s_b, t * 4096)
 
+    def econ_setup(self, nb=1, first=None):
+        """s_econ = every one of the nb batches from `first` (s_bq) on (clamped to the trajectory's last) is certified for the economized
+        series: batch_flag[(K + k) batches_per_k + b], present when bit 1 of `deep` is set; s_capb = the orders pass 1 may form"""
+        p = self.p
+        p.salu("s_mov_b32", self.s_econ, 0)
+        lab = f"L_noecon_{len(p.ins)}"
+        p.salu("s_and_b32", self.s_t[0], self.s_deep, 2)
+        p.s_cmp("s_cmp_eq_u32", self.s_t[0], 0)
+        p.s_branch("s_cbranch_scc1", lab)
+        p.salu("s_add_u32", self.s_t[0], self.s_K, self.s_k)
+        p.salu("s_mul_i32", self.s_t[0], self.s_t[0], self.s_bpk)
+        p.salu("s_sub_u32", self.s_t[5], self.s_bpk, 1)
+        for i in range(nb):
+            p.salu("s_add_u32", self.s_t[6], first if first is not None else self.s_bq, i)
+            p.salu("s_min_u32", self.s_t[6], self.s_t[6], self.s_t[5])
+            p.salu("s_add_u32", self.s_t[6], self.s_t[6], self.s_t[0])
+            p.salu("s_lshl_b32", self.s_t[6], self.s_t[6], 2)
+            p.s_load(1, self.s_t[1 + i], self.s_bflag, self.s_t[6])
+        p.s_waitcnt(lgkm=0)
+        p.salu("s_and_b32", self.s_econ, self.s_t[1], 1)
+        for i in range(1, nb):
+            p.salu("s_and_b32", self.s_econ, self.s_econ, self.s_t[1 + i])
+        p.label(lab)
+        p.s_cmp("s_cmp_lg_u32", self.s_econ, 0)
+        p.salu("s_cselect_b32", self.s_capb, ECON_M - 1, self.s_mcap)
+
+    def econ_after_pass1(self, conv):
+        """behind pass 1: a converged Taylor sum keeps its own scalars; else, for a certified batch, the ECON_M - 1 orders
+        formed are all the economized polynomial needs: M = ECON_M, converged by construction"""
+        p = self.p
+        p.s_cmp("s_cmp_lg_u32", conv, 0)
+        p.salu("s_cselect_b32", self.s_econ, 0, self.s_econ)
+        p.s_cmp("s_cmp_lg_u32", self.s_econ, 0)
+        p.salu("s_cselect_b32", self.s_M, ECON_M, self.s_M)
+        p.salu("s_cselect_b32", conv, 1, conv)
+
+    def load_pair(self):
+        """(omega_a, sigma_a) of order a = s_m -> s_invm, s_sig: the table of pairs behind 1 / m"""
+        p = self.p
+        p.salu("s_lshl_b32", self.s_t[0], self.s_m, 4)
+        p.salu("s_lshl_b32", self.s_t[1], self.s_econ, 15)
+        assert ECON_OFF == 1 << 15
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.s_t[1])
+        p.salu("s_add_u32", self.s_t[0], self.s_t[0], PAIRS_OFF)
+        p.s_load(2, self.s_invm, self.s_inv, self.s_t[0])
+        p.salu("s_add_u32", self.s_t[1], self.s_t[0], 8)
+        p.s_load(2, self.s_sig, self.s_inv, self.s_t[1])
+
     # ---------------------------------------------------------------------------------------------------------------
     def batch(self):
         p = self.p
         L = self.LMAX
+        self.econ_setup()
         t0 = self.TMP[0]
         vc, vrg, vn, vnc = t0.sub(0), t0.sub(1), t0.sub(2), t0.sub(3)
         p.salu("s_lshl_b32", self.s_n0, self.s_bq, 4)
@@ -478,9 +538,10 @@ class GenD3:
         p.s_branch("s_branch", "L_pass1_done")
         p.label("L_p1_next")
         p.salu("s_add_u32", self.s_m, self.s_m, 1)
-        p.s_cmp("s_cmp_le_u32", self.s_m, self.s_mcap)
+        p.s_cmp("s_cmp_le_u32", self.s_m, self.s_capb)
         p.s_branch("s_cbranch_scc1", "L_pass1")
         p.label("L_pass1_done")
+        self.econ_after_pass1(self.s_conv)
 
         # ================= pass 2: w_{M-1} = chi(t_{n+1}), w_{a-1} = chi + (i dt / (a + 1)) H w_a ========================
         load_block(self.v_bwoff, self.s_bwb, self.CHI, False)
@@ -491,9 +552,7 @@ class GenD3:
         p.salu("s_sub_u32", self.s_m, self.s_M, 1)           # aa
         self.prefetch(0)
         p.label("L_pass2")
-        p.salu("s_add_u32", self.s_t[0], self.s_m, 1)
-        p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 3)
-        p.s_load(2, self.s_invm, self.s_inv, self.s_t[0])    # 1 / (aa + 1)
+        self.load_pair()                                     # omega_aa, sigma_aa (Taylor: both 1 / (aa + 1))
         self.park_bases(self.s_m)
 
         def hook_uload(ks):
@@ -530,9 +589,9 @@ class GenD3:
         self.apply_H(overlap_of=overlap_of, hook=hook_uload)
         p.s_cmp("s_cmp_eq_u32", self.s_m, 0)
         p.s_branch("s_cbranch_scc1", "L_pass2_done")
-        # w <- chi + (i s)(x + i y) = chi - s y + i s x,  s = dt / (aa + 1)
+        # w <- chi + (i s)(x + i y) = chi - s y + i s x,  s = dt sigma_aa   (Taylor: dt / (aa + 1))
         self.prefetch(0)
-        p.valu("v_mul_f64", self.v_sfac, self.v_dt, self.s_invm)
+        p.valu("v_mul_f64", self.v_sfac, self.v_dt, self.s_sig)
         for t in range(4):
             for r in range(4):
                 cr, ci, ws = self.TMP[r % 2].d(0), self.TMP[r % 2].d(1), self.TMP[r % 2].d(2)

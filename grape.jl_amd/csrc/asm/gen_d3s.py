@@ -66,6 +66,9 @@ class GenD3S(GenD3):
         self.s_poffs = [S(92 + q) for q in range(10)]
         self.s_bq0 = S(90)
         self.s_wb = S(91)                        # wave * 10240
+        # (the two halves of a tile plane come from the same source offset: the odd entries of s_poffs are free after the load)
+        self.s_capb, self.s_econ = S(93), S(95)  # round 6, the economized series (gen_d3.py): orders of pass 1; its scalars apply
+        self.s_sig = S(86, 2)                    # sigma_a of pass 2 (GenD3: rho of the trajectory, loaded behind pass 2)
         # per-lane
         self.v_BDs = [V(2 + r) for r in range(4)]
         self.v_BMs = [V(6 + r) for r in range(4)]
@@ -178,7 +181,7 @@ class GenD3S(GenD3):
     def piece(self, q):
         """request this wave's q-th piece of the operator at s_src into the slot at s_sd"""
         p = self.p
-        self.add64(self.s_a, self.s_src, self.s_poffs[q])
+        self.add64(self.s_a, self.s_src, self.s_poffs[q & ~1])
         p.salu("s_add_u32", self.s_t[4], self.s_sd, self.s_wb)
         p.salu("s_add_u32", M0, self.s_t[4], q * 1024)
         p.global_load_lds(self.v_goff[q & 1], self.s_a)
@@ -329,6 +332,7 @@ class GenD3S(GenD3):
         p.salu("s_cselect_b32", self.s_live, 1, 0)
         p.salu("s_sub_u32", self.s_t[0], self.s_bpk, 1)
         p.salu("s_min_u32", self.s_bq, self.s_bq, self.s_t[0])
+        self.econ_setup(4, self.s_bq0)                       # (the four batches of the workgroup stop together: all four certified)
         p.salu("s_lshl_b32", self.s_n0, self.s_bq, 4)
         p.valu("v_and_b32", vc, 15, self.v_lane)
         p.valu("v_lshrrev_b32", vrg, 4, self.v_lane)
@@ -407,8 +411,8 @@ class GenD3S(GenD3):
         p.s_cmp("s_cmp_lg_u32", self.s_t[0], 0)
         p.s_branch("s_cbranch_scc1", "L_pass1_done")
         p.label("L_p1_nocheck")
-        p.s_cmp("s_cmp_gt_u32", self.s_m, self.s_mcap)
-        p.s_branch("s_cbranch_scc1", "L_pass1_done")
+        p.s_cmp("s_cmp_gt_u32", self.s_m, self.s_capb)
+        p.s_branch("s_cbranch_scc1", "L_pass1_cap")
         self.apply_H_s(entry_label="L_p1_h0", tag="p1")
         # u_m = (-i dt / m) H u_{m-1}: parked, new vector block, its norm
         p.salu("s_lshl_b32", self.s_t[0], self.s_m, 3)
@@ -453,8 +457,16 @@ class GenD3S(GenD3):
         p.salu("s_mov_b64", EXEC, self.s_save)
         p.salu("s_add_u32", self.s_m, self.s_m, 1)
         p.s_branch("s_branch", "L_pass1")
+        p.label("L_pass1_cap")                               # every order the batch may form is formed, the workgroup not converged
+        p.salu("s_sub_u32", self.s_M, self.s_m, 1)
+        p.salu("s_mov_b32", self.s_t[0], 0)
+        self.econ_after_pass1(self.s_t[0])                   # certified: M = ECON_M ...
+        p.salu("s_or_b32", self.s_myconv, self.s_myconv, self.s_t[0])      # ... and converged by construction
+        p.s_branch("s_branch", "L_pass1_after")
         p.label("L_pass1_done")
         p.salu("s_sub_u32", self.s_M, self.s_m, 1)
+        p.salu("s_mov_b32", self.s_econ, 0)                  # (a converged Taylor sum keeps its own scalars)
+        p.label("L_pass1_after")
 
         # ================= pass 2 =====================================================================================
         self.adjoint = True
@@ -469,9 +481,7 @@ class GenD3S(GenD3):
         p.label("L_pass2")
         self.step_top()
         p.label("L_pass2_entry")
-        p.salu("s_add_u32", self.s_t[0], self.s_m, 1)
-        p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 3)
-        p.s_load(2, self.s_invm, self.s_inv, self.s_t[0])    # 1 / (aa + 1)
+        self.load_pair()                                     # omega_aa, sigma_aa (Taylor: both 1 / (aa + 1))
         self.park_bases(self.s_m)
 
         def overlap():
@@ -508,7 +518,7 @@ class GenD3S(GenD3):
         self.apply_H_s(entry_label="L_p2_h0", overlap=overlap, uload=True, tag="p2")
         p.s_cmp("s_cmp_eq_u32", self.s_m, 0)
         p.s_branch("s_cbranch_scc1", "L_pass2_done")
-        p.valu("v_mul_f64", self.v_sfac, self.v_dt, self.s_invm)
+        p.valu("v_mul_f64", self.v_sfac, self.v_dt, self.s_sig)
         for t in range(4):
             for r in range(4):
                 cr, ci, ws = self.TMP[r % 2].d(0), self.TMP[r % 2].d(1), self.TMP[r % 2].d(2)

@@ -231,7 +231,13 @@ struct grape_handle {
     double2 *d_gpark = nullptr;  // [K][N_T][maxp][NP] terms of the forward series, consumed by deriv2_kernel
     int *d_morder = nullptr;     // [K][N_T]
     int maxp = 0;
-    int *d_batchflag = nullptr;  // [K * ceil(N_T / 16)] derivative batches left to deriv_sub_kernel (sub-stepped series)
+    int *d_batchflag = nullptr;  // [2][K * ceil(N_T / 16)] derivative batches left to deriv_sub_kernel (sub-stepped series) | certified for the economized series
+    // Round 6: the economized derivative series (tools/econ_coeffs.py, asm/gen_d3.py).  Batches of 16 cells that the
+    // four-product exponential kernel of THIS evaluation has certified (verdict 0 without scaling: spectral radius <= 1.36)
+    // take a degree-16 polynomial whose derivative is within 2e-16 of exp's on that segment where the Taylor sum needs
+    // 19-21 terms.  Exact-derivative route only (:taylor is the reference's recursion, term by term), default tolerance
+    // or looser... a tighter one keeps the Taylor sum.  GRAPE_DERIV_ECON=0: off.
+    bool deriv_econ = false;
     double sub_theta = 0.0;      // threshold of deriv_substeps (0: off, gradient_method = :taylor mirrors the reference)
     int sq_plan = 2;             // blocked path: squaring launches issued per chunk (adapted by grape_check, see expm_large)
     // matrix-free propagator for 64 < N <= 256 (grape_cheby.hip.h): exchange slots, counters, launch plan
@@ -2043,7 +2049,9 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         // the exact-derivative route sub-steps its series for ||H|| dt > theta; :taylor is the reference's plain recursion
         const char *envd = getenv("GRAPE_DERIV_THETA");
         h->sub_theta = p->gradient_method == GRAPE_GRAD_GRADGEN ? (envd ? atof(envd) : 4.0) : 0.0;
-        CCHK(dmalloc(&h->d_batchflag, (size_t)K * ((N_T + 15) / 16)));
+        // (behind the batch flags, round 6: the flags of the economized derivative series, deriv_econ_kernel)
+        CCHK(dmalloc(&h->d_batchflag, (size_t)2 * K * ((N_T + 15) / 16)));
+        CCHK(hipMemset(h->d_batchflag, 0, (size_t)2 * K * ((N_T + 15) / 16) * sizeof(int)));
     }
     if (h->series) {
         const char *env = getenv("GRAPE_SERIES_THETA");
@@ -2127,6 +2135,11 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     h->asm18g = h->asm18g && h->t18 && !h->herm && !h->large && !h->series && h->NT == 4 && sf_shape_ok && (long)K * N_T < (1L << 28);
     h->asm16p = h->asm16 && p_direct;
     h->asm18gp = h->asm18g && p_direct;
+    {
+        const char *enve = getenv("GRAPE_DERIV_ECON");
+        h->deriv_econ = h->asm16 && p->gradient_method == GRAPE_GRAD_GRADGEN && h->taylor_tol >= 1e-16 && h->d_batchflag &&
+                        !(enve && atoi(enve) == 0);
+    }
     if (h->asm16p || h->asm18gp) CCHK(dmalloc(&h->d_dte, (size_t)(L <= 2 ? 4 : 8) * N_T));
     if (h->t18 && !h->large && !h->series && ((L > 2 && !p->hc_per_traj) || (h->asm16 && !h->asm16p) || (h->asm18g && !h->asm18gp)) && (h->NT >= 3 || h->t18_small))
         CCHK(dmalloc(&h->d_Sf, (size_t)(p->hc_per_traj ? (size_t)h->KC * N_T : (size_t)N_T) * 2 * NP * NP));
@@ -2436,6 +2449,14 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
             }
         }
         HIPCHK(h, e);
+        if (h->deriv_econ) {   // which derivative batches this evaluation's verdicts certify for the economized series
+            DerivEconArgs ec{};
+            ec.verdict = h->d_cellflag; ec.splan = h->d_splan; ec.cls = h->d_cls; ec.flags = h->d_flags;
+            ec.K = h->K; ec.KC = h->KC; ec.N_T = h->N_T; ec.batches_per_k = (h->N_T + 15) / 16;
+            ec.nbatch_total = h->K * ec.batches_per_k; ec.batch_econ = h->d_batchflag + ec.nbatch_total;
+            hipLaunchKernelGGL(deriv_econ_kernel, dim3((unsigned)((ec.nbatch_total + 255) / 256)), dim3(256), 0, s, ec);
+            HIPCHK(h, hipGetLastError());
+        }
         phase_end(h, 0, s);
     }
 #ifdef GRAPE_DIAG
@@ -2662,6 +2683,10 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
 #endif
         if (h->d_park3 && !d2.gpark) {
             d2.park = h->d_park3;
+            if (h->deriv_econ && !h->deriv3_general && !h->deriv3_h0g) {   // (without sub-steps the batch flags stay zero, from grape_create)
+                d2.batch_flag = h->d_batchflag;
+                d2.batch_econ = 1;
+            }
             e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, h->deriv3_general ? 2 : (h->deriv3_h0g ? 1 : 0), h->deriv3_asm ? 1 : 0, (void *)s, h->deriv3_blocks);
         } else if (h->deriv4_blocks && !d2.gpark) {
             e = (hipError_t)grape_deriv4_launch(h->NP, &d2, sizeof(d2), h->d_H0q3, h->d_Hcq3, h->d_H0p3, h->d_Hcp3, (void *)s, h->deriv4_blocks);

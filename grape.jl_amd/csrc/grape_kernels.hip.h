@@ -3425,6 +3425,28 @@ __global__ void deriv_flag_kernel(DerivFlagArgs a) {
     if (ns > 1) atomicAdd(&a.flags[3], 1);
 }
 
+// Round 6 -- one thread per batch: has the four-product exponential kernel of this evaluation CERTIFIED every cell of the
+// batch (verdict 0: spectral radius of H dt <= T16_THETA = ECON_THETA, asm/gen_t16.py) without scaling (a cell that was
+// exponentiated as A / 2^s is certified for A / 2^s)?  Those batches may take the economized derivative series
+// (asm/gen_d3.py, tools/econ_coeffs.py).  A route that was not tried in this evaluation has written no verdicts.
+struct DerivEconArgs {
+    const int *verdict, *splan, *cls, *flags;   // [KC * N_T] each; cls: generator class of trajectory k (nullptr: k)
+    int K, KC, N_T, batches_per_k, nbatch_total;
+    int *batch_econ;                            // [nbatch_total]
+};
+__global__ void deriv_econ_kernel(DerivEconArgs a) {
+    const int batch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (batch >= a.nbatch_total) return;
+    const int k = batch / a.batches_per_k, n0 = (batch - k * a.batches_per_k) * 16;
+    const int kc = a.cls ? a.cls[k] : k;
+    bool ok = !t16_skipped(a.flags, a.KC * a.N_T);
+    for (int n = n0; ok && n < min(n0 + 16, a.N_T); ++n) {
+        const int cell = kc * a.N_T + n;
+        ok = a.verdict[cell] == 0 && a.splan[cell] == 0;
+    }
+    a.batch_econ[batch] = ok ? 1 : 0;
+}
+
 struct DerivSubArgs {
     DerivMfmaArgs m;          // operators, states, scratch, tolerances (deriv_mfma_kernel's)
     const double *rb;         // 2-norm estimates, see deriv_substeps
@@ -3699,6 +3721,9 @@ struct Deriv2Args {
     // deriv3_kernel at one and two tiles per side: a series that is not converged within the terms the kernel parks, while
     // max_order allows more, raises flags[7] instead of the non-convergence error -- deriv_kernel redoes the derivatives
     int deep_redo;
+    // round 6: flags of the economized series lie behind the batch flags, batch_flag[nbatch_total + batch] (deriv_econ_kernel;
+    // read by the Hermitian assembly kernels of four tiles per side only)
+    int batch_econ;
 #ifdef GRAPE_DIAG
     int ablate;                // diagnostic builds only: bit0 no parking traffic (results wrong)
 #endif

@@ -17,6 +17,7 @@
 namespace {
 #include "grape_t18.hip.h"
 #include "grape_deriv3.hip.h"
+#include "grape_econ_coeffs.h"
 
 template <int NT, bool SYM, bool CHEB, bool T16 = false>
 hipError_t launch(const ExpmArgs &a, hipStream_t s, int blocks) {
@@ -229,6 +230,7 @@ __global__ void __launch_bounds__(256) t16_credit_kernel(ExpmArgs a) {
 }
 
 constexpr int D3_INV_TABLE = 2048;
+constexpr int D3_PAIRS_OFF = 32768, D3_ECON_OFF = 32768;   // (gen_d3.py: PAIRS_OFF, ECON_OFF)
 struct AsmModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr, fn_d3g = nullptr, fn_d4[2] = {nullptr, nullptr};
@@ -288,9 +290,15 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         if (e != hipSuccess) return e;
         // 1 / m for the series orders (the kernels read them with scalar loads; gfx9 has no scalar floating point); behind
         // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
-        std::vector<double> tab(D3_INV_TABLE + 20);
+        // round 6: at D3_PAIRS_OFF bytes the scalars (omega_a, sigma_a) of pass 2, a < D3_INV_TABLE, of the Taylor series (both
+        // 1 / (a + 1)); D3_ECON_OFF bytes further those of the economized series (grape_econ_coeffs.h, tools/econ_coeffs.py)
+        static_assert(D3_PAIRS_OFF >= (D3_INV_TABLE + 20) * 8 && D3_ECON_OFF == D3_INV_TABLE * 16, "layout of gen_d3.py");
+        std::vector<double> tab((D3_PAIRS_OFF + D3_ECON_OFF) / 8 + 2 * ECON_M);
         tab[0] = 0.0;
         for (int i = 1; i < D3_INV_TABLE; ++i) tab[i] = 1.0 / (double)i;
+        for (int a = 0; a < D3_INV_TABLE; ++a) tab[D3_PAIRS_OFF / 8 + 2 * a] = tab[D3_PAIRS_OFF / 8 + 2 * a + 1] = 1.0 / (double)(a + 1);
+        for (int a = 0; a < ECON_M; ++a)
+            for (int j = 0; j < 2; ++j) tab[(D3_PAIRS_OFF + D3_ECON_OFF) / 8 + 2 * a + j] = ECON_TAB[a][j];
         int *pt = (int *)(tab.data() + D3_INV_TABLE);
         int np_ = 0;
         for (int ti = 0; ti < 4; ++ti)
@@ -356,6 +364,8 @@ hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks, bool ge
     k.slots = a.maxm + 1;
     k.tol2 = a.tol * a.tol;
     k.deep = (a.deep_redo && a.max_order > k.mcap) ? 1 : 0;
+    // bit 1: flags of the economized series behind the batch flags (Hermitian kernels; the orders pass 1 forms must fit)
+    if (a.batch_econ && !general && a.batch_flag && k.mcap >= ECON_M) k.deep |= 2;
     k.nblocks = blocks;
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};

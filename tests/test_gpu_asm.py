@@ -107,9 +107,10 @@ def test_six_controls_and_per_trajectory_controls(g):
 
 
 # ---- the derivative overlaps as assembly (asm/gen_d3.py) against deriv3_kernel<4, L> (GRAPE_DERIV3_ASM=0) ----
-def run_d3(g, pr, asm, **kw):
-    old = os.environ.get("GRAPE_DERIV3_ASM")
+def run_d3(g, pr, asm, econ=False, **kw):
+    old, old_e = os.environ.get("GRAPE_DERIV3_ASM"), os.environ.get("GRAPE_DERIV_ECON")
     os.environ["GRAPE_DERIV3_ASM"] = "1" if asm else "0"     # (read at every launch)
+    os.environ["GRAPE_DERIV_ECON"] = "1" if econ else "0"    # (grape_create; the compiled twin has the Taylor sum only)
     try:
         with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
             J, G, tau = h.eval(pr["pulsevals"])
@@ -117,10 +118,47 @@ def run_d3(g, pr, asm, **kw):
             assert J2 == J and np.array_equal(G, G2)         # repeatable bit for bit
             return J, G, tau, h.work()
     finally:
-        if old is None:
-            os.environ.pop("GRAPE_DERIV3_ASM", None)
-        else:
-            os.environ["GRAPE_DERIV3_ASM"] = old
+        for name, val in (("GRAPE_DERIV3_ASM", old), ("GRAPE_DERIV_ECON", old_e)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
+
+
+@pytest.mark.parametrize("N,L,N_T,K,kw", [
+    (64, 2, 37, 3, {}), (57, 2, 100, 5, {}), (64, 1, 40, 16, {}), (64, 2, 33, 2, {"shape": True}), (60, 2, 18, 3, {"per_traj": True}),
+    (64, 6, 70, 3, {}), (64, 3, 40, 2, {"per_traj": True}), (64, 2, 40, 3, {"dt": 0.6}), (64, 2, 40, 3, {"dt": 1.4})])
+def test_economized_derivative_series_against_the_taylor_sum(g, ref, N, L, N_T, K, kw):
+    """round 6: batches the four-product exponential kernel certifies (spectral radius <= 1.36) take the degree-16
+    polynomial of tools/econ_coeffs.py in the derivative kernels (gen_d3.py, gen_d3s.py): fewer orders, the Taylor sum's
+    numbers to 1e-13 and the oracle's at SURVEY 8c's tolerance; short steps converge before ECON_M orders and change nothing;
+    long steps (scaled cells: not certified) keep the Taylor sum"""
+    from grape_jl_amd import synth
+    pr = synth.make_problem(N, L, N_T, K, seed=17 + N + L)
+    args = {}
+    if kw.get("shape"):
+        args["shape"] = 0.5 + np.random.default_rng(3).random((L, N_T))
+    if kw.get("per_traj"):
+        rng = np.random.default_rng(4)
+        pr["Hc"] = np.stack([pr["Hc"] * (1.0 + 0.1 * rng.random()) for _ in range(K)])
+    if kw.get("dt"):
+        pr["tlist"] = pr["tlist"] * kw["dt"]
+    a = run_d3(g, pr, True, econ=True, **args)
+    b = run_d3(g, pr, True, econ=False, **args)
+    assert a[0] == b[0] and np.array_equal(a[2], b[2])
+    gs = max(np.abs(b[1]).max(), 1e-3)
+    assert np.abs(a[1] - b[1]).max() <= 1e-13 * gs, np.abs(a[1] - b[1]).max() / gs
+    cells = K * N_T
+    if kw.get("dt"):
+        assert a[3]["deriv_orders"] == b[3]["deriv_orders"]      # nothing to economize / nothing certified
+        if kw["dt"] < 1:
+            assert a[3]["deriv_orders"] < 16 * cells
+    else:
+        assert a[3]["deriv_orders"] < b[3]["deriv_orders"] and a[3]["deriv_orders"] <= 16.5 * cells, (a[3]["deriv_orders"], b[3]["deriv_orders"])
+    if K * N_T <= 400 and "shape" not in args:
+        Jr, Gr, _ = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
+                                 gradient_method=ref.GRADGEN)
+        assert abs(a[0] - Jr) <= 1e-12 and np.abs(a[1] - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)
 
 
 @pytest.mark.parametrize("N,L,N_T,K,kw", [
@@ -161,8 +199,9 @@ def test_derivative_kernel_taylor_route_and_its_order_limit(g):
 # ---- more than two controls at four tiles per side: the streamed-controls assembly kernel (asm/gen_d3s.py) against
 # deriv2_kernel's STREAM_L form (GRAPE_DERIV3S=0, read in grape_create) ----
 def run_d3s(g, pr, asm, **kw):
-    old = os.environ.get("GRAPE_DERIV3S")
+    old, old_e = os.environ.get("GRAPE_DERIV3S"), os.environ.get("GRAPE_DERIV_ECON")
     os.environ["GRAPE_DERIV3S"] = "1" if asm else "0"
+    os.environ["GRAPE_DERIV_ECON"] = "0"                     # (the compiled twin has the Taylor sum only)
     try:
         with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
             J, G, tau = h.eval(pr["pulsevals"])
@@ -170,10 +209,11 @@ def run_d3s(g, pr, asm, **kw):
             assert J2 == J and np.array_equal(G, G2)         # repeatable bit for bit
             return J, G, tau, h.work()
     finally:
-        if old is None:
-            os.environ.pop("GRAPE_DERIV3S", None)
-        else:
-            os.environ["GRAPE_DERIV3S"] = old
+        for name, val in (("GRAPE_DERIV3S", old), ("GRAPE_DERIV_ECON", old_e)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
 
 
 @pytest.mark.parametrize("N,L,N_T,K,kw", [

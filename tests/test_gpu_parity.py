@@ -949,6 +949,7 @@ def test_derivative_kernel_with_one_wave_per_batch_matches_the_shared_batch_kern
     to rounding; and both against the C restatement on the first steps.  Shapes: a last batch with unused columns, padded
     sizes (60 -> 64, 40 -> 48), more trajectories than workgroups, several workgroups per trajectory, shaped amplitudes."""
     from grape_jl_amd import synth
+    monkeypatch.setenv("GRAPE_DERIV_ECON", "0")     # (twins of the Taylor sum; the economized series: tests/test_gpu_asm.py)
     pr = synth.make_problem(N, L, N_T, K, seed=3300 + N + L)
     rng = np.random.default_rng(N * 7 + L)
     tl = np.concatenate([[0.0], np.cumsum(0.6 + 0.8 * rng.random(N_T))])
