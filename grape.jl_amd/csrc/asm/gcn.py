@@ -908,15 +908,15 @@ class Emu:
             self.wr_s32(w, d, (self.rd_s32(w, s[0]) * self.rd_s32(w, s[1])) & M)
         elif op == "s_mul_hi_u32":
             self.wr_s32(w, d, (self.rd_s32(w, s[0]) * self.rd_s32(w, s[1])) >> 32)
-        elif op in ("s_lshl_b32", "s_lshr_b32", "s_and_b32", "s_or_b32", "s_xor_b32", "s_ashr_i32", "s_min_i32", "s_min_u32", "s_max_i32"):
+        elif op in ("s_lshl_b32", "s_lshr_b32", "s_and_b32", "s_or_b32", "s_xor_b32", "s_ashr_i32", "s_min_i32", "s_min_u32", "s_max_i32", "s_max_u32"):
             a, b = self.rd_s32(w, s[0]), self.rd_s32(w, s[1])
             sa = a - (1 << 32) if a >> 31 else a
             sb = b - (1 << 32) if b >> 31 else b
             r = {"s_lshl_b32": (a << (b & 31)) & M, "s_lshr_b32": a >> (b & 31), "s_and_b32": a & b, "s_or_b32": a | b,
                  "s_xor_b32": a ^ b, "s_ashr_i32": (sa >> (b & 31)) & M, "s_min_i32": min(sa, sb) & M, "s_min_u32": min(a, b),
-                 "s_max_i32": max(sa, sb) & M}[op]
+                 "s_max_i32": max(sa, sb) & M, "s_max_u32": max(a, b)}[op]
             self.wr_s32(w, d, r)
-            if op in ("s_min_i32", "s_min_u32", "s_max_i32"):
+            if op in ("s_min_i32", "s_min_u32", "s_max_i32", "s_max_u32"):
                 w.scc = int(r == (a if op != "s_max_i32" else a) )
             else:
                 w.scc = int(r != 0)

@@ -26,10 +26,11 @@ Register map (512 per lane, one wave per SIMD):
 
 Round 6 -- the economized series (tools/econ_coeffs.py, grape_econ_coeffs.h).  A batch whose 16 cells the four-product
 exponential kernel has certified (spectral radius <= 1.36: bit 1 of the kernel argument `deep` says that a second array of
-batch flags lies behind `batch_flag`) stops pass 1 after ECON_M - 1 orders if the Taylor terms are not below the tolerance
-by then, and pass 2 runs the SAME recursion with the scalars (omega_a, sigma_a) of a degree-16 polynomial whose derivative
-is within 2e-16 of exp's on the certified segment -- 31 applications of H where the Taylor sum takes 2 x 19.  Pass 2 reads
-its two scalars per order from a table of pairs behind 1 / m (Taylor: both 1 / (a + 1), the same bits as before)."""
+batch flags lies behind `batch_flag`: the degree M every cell of the batch is certified for, 0: none) stops pass 1 after
+M - 1 orders if the Taylor terms are not below the tolerance by then, and pass 2 runs the SAME recursion with the scalars
+(omega_a, sigma_a) of a degree-M polynomial whose derivative is within 2e-16 of exp's on the certified segment (M = 16 for
+1.36: 31 applications of H where the Taylor sum takes 2 x 18..21).  Pass 2 reads its two scalars per order from a table of
+pairs behind 1 / m (Taylor: both 1 / (a + 1), the same bits as before)."""
 import os
 import struct
 import sys
@@ -45,9 +46,10 @@ NTILE = NT * (NT + 1) // 2
 MAT_B = NTILE * 2 * TILE_B       # bytes of an operator in LDS (43520)
 KERNARG = 160
 VPLANE_B = NP * 16 * 16          # bytes of one parked term (64 x 16 complex, interleaved)
-ECON_M = 16                      # degree of the economized polynomial (grape_econ_coeffs.h: ECON_M)
+ECON_MIN = 16                    # smallest degree of an economized polynomial (grape_econ_coeffs.h: ECON_DEG; at most 31)
 PAIRS_OFF = 32768                # the buffer behind `inv`: 1 / m (2048 doubles) | piece table of deriv3s_asm | at PAIRS_OFF the pairs
-ECON_OFF = 32768                 # (omega_a, sigma_a) of the Taylor series, a < 2048 | ECON_OFF further those of the economized one
+ECON_OFF = 32768                 # (omega_a, sigma_a) of the Taylor series, a < 2048 | ECON_OFF further those of the economized
+ECON_TAB_B = 512                 # polynomial of degree M at (M - ECON_MIN) ECON_TAB_B (32 pairs each)
 
 
 def tile_index(ti, tj):
@@ -352,8 +354,10 @@ class GenD3:
             self.add64(self.s_pb[t], self.s_b, t * 4096)
 
     def econ_setup(self, nb=1, first=None):
-        """s_econ = every one of the nb batches from `first` (s_bq) on (clamped to the trajectory's last) is certified for the economized
-        series: batch_flag[(K + k) batches_per_k + b], present when bit 1 of `deep` is set; s_capb = the orders pass 1 may form"""
+        """s_econ = degree M of the economized polynomial the nb batches from `first` (s_bq) on (clamped to the trajectory's
+        last) may take, 0: none -- batch_flag[(K + k) batches_per_k + b] holds the degree every cell of batch b is certified
+        for (present when bit 1 of `deep` is set); of several batches the largest degree (the widest segment), none if one
+        has none.  s_capb = the orders pass 1 may form: M - 1, or mcap."""
         p = self.p
         p.salu("s_mov_b32", self.s_econ, 0)
         lab = f"L_noecon_{len(p.ins)}"
@@ -370,29 +374,48 @@ class GenD3:
             p.salu("s_lshl_b32", self.s_t[6], self.s_t[6], 2)
             p.s_load(1, self.s_t[1 + i], self.s_bflag, self.s_t[6])
         p.s_waitcnt(lgkm=0)
-        p.salu("s_and_b32", self.s_econ, self.s_t[1], 1)
-        for i in range(1, nb):
-            p.salu("s_and_b32", self.s_econ, self.s_econ, self.s_t[1 + i])
+        self.econ_combine([self.s_t[1 + i] for i in range(nb)])
         p.label(lab)
+        self.econ_cap()
+
+    def econ_combine(self, flags):
+        p = self.p
+        p.salu("s_mov_b32", self.s_econ, flags[0])
+        if len(flags) > 1:
+            p.salu("s_mov_b32", self.s_t[0], flags[0])
+            for f in flags[1:]:
+                p.salu("s_max_u32", self.s_econ, self.s_econ, f)
+                p.salu("s_min_u32", self.s_t[0], self.s_t[0], f)
+            p.s_cmp("s_cmp_eq_u32", self.s_t[0], 0)
+            p.salu("s_cselect_b32", self.s_econ, 0, self.s_econ)
+
+    def econ_cap(self):
+        p = self.p
+        p.salu("s_sub_u32", self.s_t[0], self.s_econ, 1)
         p.s_cmp("s_cmp_lg_u32", self.s_econ, 0)
-        p.salu("s_cselect_b32", self.s_capb, ECON_M - 1, self.s_mcap)
+        p.salu("s_cselect_b32", self.s_capb, self.s_t[0], self.s_mcap)
 
     def econ_after_pass1(self, conv):
-        """behind pass 1: a converged Taylor sum keeps its own scalars; else, for a certified batch, the ECON_M - 1 orders
-        formed are all the economized polynomial needs: M = ECON_M, converged by construction"""
+        """behind pass 1: a converged Taylor sum keeps its own scalars; else, for a certified batch, the M - 1 orders
+        formed are all the economized polynomial needs: M orders in pass 2, converged by construction"""
         p = self.p
         p.s_cmp("s_cmp_lg_u32", conv, 0)
         p.salu("s_cselect_b32", self.s_econ, 0, self.s_econ)
         p.s_cmp("s_cmp_lg_u32", self.s_econ, 0)
-        p.salu("s_cselect_b32", self.s_M, ECON_M, self.s_M)
+        p.salu("s_cselect_b32", self.s_M, self.s_econ, self.s_M)
         p.salu("s_cselect_b32", conv, 1, conv)
 
     def load_pair(self):
-        """(omega_a, sigma_a) of order a = s_m -> s_invm, s_sig: the table of pairs behind 1 / m"""
+        """(omega_a, sigma_a) of order a = s_m -> s_invm, s_sig: the table of pairs behind 1 / m -- the Taylor series' or that
+        of the economized polynomial of degree s_econ"""
         p = self.p
+        p.salu("s_sub_u32", self.s_t[1], self.s_econ, ECON_MIN)
+        p.salu("s_lshl_b32", self.s_t[1], self.s_t[1], 9)
+        assert ECON_TAB_B == 1 << 9
+        p.salu("s_add_u32", self.s_t[1], self.s_t[1], ECON_OFF)
+        p.s_cmp("s_cmp_lg_u32", self.s_econ, 0)
+        p.salu("s_cselect_b32", self.s_t[1], self.s_t[1], 0)
         p.salu("s_lshl_b32", self.s_t[0], self.s_m, 4)
-        p.salu("s_lshl_b32", self.s_t[1], self.s_econ, 15)
-        assert ECON_OFF == 1 << 15
         p.salu("s_add_u32", self.s_t[0], self.s_t[0], self.s_t[1])
         p.salu("s_add_u32", self.s_t[0], self.s_t[0], PAIRS_OFF)
         p.s_load(2, self.s_invm, self.s_inv, self.s_t[0])

@@ -460,7 +460,7 @@ class GenD3S(GenD3):
         p.label("L_pass1_cap")                               # every order the batch may form is formed, the workgroup not converged
         p.salu("s_sub_u32", self.s_M, self.s_m, 1)
         p.salu("s_mov_b32", self.s_t[0], 0)
-        self.econ_after_pass1(self.s_t[0])                   # certified: M = ECON_M ...
+        self.econ_after_pass1(self.s_t[0])                   # certified: M = the polynomial's degree ...
         p.salu("s_or_b32", self.s_myconv, self.s_myconv, self.s_t[0])      # ... and converged by construction
         p.s_branch("s_branch", "L_pass1_after")
         p.label("L_pass1_done")

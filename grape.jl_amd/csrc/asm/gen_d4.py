@@ -26,7 +26,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gcn import Prog, Reg, V, A, S, VCC, EXEC, Neg, kernel_text  # noqa: E402
-from gen_d3 import dbits  # noqa: E402
+from gen_d3 import dbits, GenD3  # noqa: E402
 
 KERNARG = 176
 FRAG_B = 3 * 512                 # bytes of one (row tile, k-step) fragment: 64 lanes x (re, im), then 64 lanes x (re + im)
@@ -63,6 +63,9 @@ class GenD4:
         self.s_c, self.s_it = S(94), S(95)
         self.s_h0, self.s_hc = S(96, 2), S(98, 2)        # operator arrays of the current pass, this wave's rows of trajectory k
         self.s_bq = S(100)
+        # round 6, the economized series (gen_d3.py's header; same flags behind the batch flags, same tables behind 1 / m)
+        self.s_capb, self.s_econ = S(0), S(1)            # (the kernel argument pointer is dead behind the prologue)
+        self.s_sig = self.s_rhov                         # sigma_a of pass 2 (rho of the trajectory is loaded behind pass 2)
         # ---- per-lane ----
         self.v_tid, self.v_lane = V(0), V(1)
         self.v_b, self.v_b2 = V(2), V(3)
@@ -392,6 +395,23 @@ class GenD4:
         p.ds_write(64, self.v_w, im_, self.PL + off)
         p.ds_write(64, self.v_w2, sm_, off)
 
+    econ_combine, econ_cap, econ_after_pass1, load_pair = GenD3.econ_combine, GenD3.econ_cap, GenD3.econ_after_pass1, GenD3.load_pair
+
+    def econ_setup(self):
+        """s_econ = the degree of the economized polynomial this batch is certified for (batch_flag[nbatch_total + batch],
+        present when bit 1 of `deep` is set), 0: none; s_capb = the orders pass 1 may form"""
+        p = self.p
+        p.salu("s_mov_b32", self.s_econ, 0)
+        p.salu("s_and_b32", self.s_t[0], self.s_deep, 2)
+        p.s_cmp("s_cmp_eq_u32", self.s_t[0], 0)
+        p.s_branch("s_cbranch_scc1", "L_noecon")
+        p.salu("s_add_u32", self.s_t[0], self.s_nbatch, self.s_batch)
+        p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 2)
+        p.s_load(1, self.s_econ, self.s_bflag, self.s_t[0])
+        p.s_waitcnt(lgkm=0)
+        p.label("L_noecon")
+        self.econ_cap()
+
     # ---------------------------------------------------------------------------------------------------------------
     def batch(self):
         p = self.p
@@ -399,6 +419,7 @@ class GenD4:
         t0 = self.TMP[0]
         vc, vrg, vn, vnc = t0.sub(0), t0.sub(1), t0.sub(2), t0.sub(3)
         self.udiv(self.s_k, self.s_bq, self.s_batch, self.s_bpk, "bk")
+        self.econ_setup()
         p.salu("s_lshl_b32", self.s_n0, self.s_bq, 4)
         p.valu("v_and_b32", vc, 15, self.v_lane)
         p.valu("v_lshrrev_b32", vrg, 4, self.v_lane)
@@ -508,9 +529,10 @@ class GenD4:
         p.s_branch("s_branch", "L_pass1_done")
         p.label("L_p1_next")
         p.salu("s_add_u32", self.s_m, self.s_m, 1)
-        p.s_cmp("s_cmp_le_u32", self.s_m, self.s_mcap)
+        p.s_cmp("s_cmp_le_u32", self.s_m, self.s_capb)
         p.s_branch("s_cbranch_scc1", "L_pass1")
         p.label("L_pass1_done")
+        self.econ_after_pass1(self.s_conv)
 
         # ================= pass 2 =====================================================================================
         self.set_pass(True)
@@ -527,9 +549,7 @@ class GenD4:
         p.s_barrier()
         p.salu("s_sub_u32", self.s_m, self.s_M, 1)          # aa
         p.label("L_pass2")
-        p.salu("s_add_u32", self.s_t[0], self.s_m, 1)
-        p.salu("s_lshl_b32", self.s_t[0], self.s_t[0], 3)
-        p.s_load(2, self.s_invm, self.s_inv, self.s_t[0])    # 1 / (aa + 1)
+        self.load_pair()                                     # omega_aa, sigma_aa (Taylor: both 1 / (aa + 1))
         self.park_bases(self.s_m)
 
         def overlap():
@@ -574,7 +594,7 @@ class GenD4:
         p.salu("s_mov_b64", EXEC, self.s_save)
         p.s_waitcnt(lgkm=0)
         p.s_barrier()                                       # every wave is done reading the old block
-        p.valu("v_mul_f64", self.v_sfac, self.v_dt, self.s_invm)
+        p.valu("v_mul_f64", self.v_sfac, self.v_dt, self.s_sig)
         for t in range(TPW):
             for r in range(4):
                 e = 4 * t + r

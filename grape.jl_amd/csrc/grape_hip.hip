@@ -9,6 +9,7 @@
 #include "../../include/grape_hip.h"
 #include "grape_kernels.hip.h"
 #include "grape_t18_coeffs.h"
+#include "grape_econ_coeffs.h"
 #include "grape_large.hip.h"
 #include "grape_series.hip.h"
 #include "grape_cheby.hip.h"
@@ -238,6 +239,7 @@ struct grape_handle {
     // 19-21 terms.  Exact-derivative route only (:taylor is the reference's recursion, term by term), default tolerance
     // or looser... a tighter one keeps the Taylor sum.  GRAPE_DERIV_ECON=0: off.
     bool deriv_econ = false;
+    int *d_celldeg = nullptr;    // blocked path: [KC * N_T] degree named by lg_t18_decide_kernel for every cell
     double sub_theta = 0.0;      // threshold of deriv_substeps (0: off, gradient_method = :taylor mirrors the reference)
     int sq_plan = 2;             // blocked path: squaring launches issued per chunk (adapted by grape_check, see expm_large)
     // matrix-free propagator for 64 < N <= 256 (grape_cheby.hip.h): exchange slots, counters, launch plan
@@ -1195,6 +1197,11 @@ hipError_t expm_large_t18(grape_handle *h, hipStream_t s) {
             }
             LgT18DecideArgs da{};
             da.colpart = d_colpart; da.s = sa; da.nparts = fused ? NB : LG_PARTS;
+            if (h->deriv_econ && h->d_celldeg && hm) {
+                da.cell_deg = h->d_celldeg; da.cell0 = (int)c0_; da.econ_n = 0;
+                for (int i = 0; i < ECON_NSETS && da.econ_n < 4; ++i)
+                    if (ECON_THETAS[i] <= T18_THETA) { da.econ_theta[da.econ_n] = ECON_THETAS[i]; da.econ_deg[da.econ_n++] = ECON_DEG[i]; }
+            }
             hipLaunchKernelGGL(lg_t18_decide_kernel, dim3(nc), dim3(256), 0, s, da);
             LGCHK(hipGetLastError());
             o2.redo = 1;
@@ -1495,7 +1502,7 @@ void grape_destroy(grape_handle *h) {
     if (h->lg_stream2) { hipStreamSynchronize(h->lg_stream2); hipStreamDestroy(h->lg_stream2); }
     if (h->lg_ev_fork) hipEventDestroy(h->lg_ev_fork);
     if (h->lg_ev_join) hipEventDestroy(h->lg_ev_join);
-    void *bufs[] = {h->d_xcc_sw, h->d_scanF, h->d_scan_fw, h->d_scan_bw, h->d_dte, h->d_normpart, h->d_normpart2, h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
+    void *bufs[] = {h->d_celldeg, h->d_xcc_sw, h->d_scanF, h->d_scan_fw, h->d_scan_bw, h->d_dte, h->d_normpart, h->d_normpart2, h->d_dinv2, h->d_scell2, h->d_colpart2, h->d_smax2, h->d_xch, h->d_xcc, h->d_batchflag, h->d_chi_in, h->d_n1, h->d_gpark, h->d_morder, h->d_inv_tnorm, h->d_ones, h->d_z, h->d_rb, h->d_cls, h->d_rep, h->d_coop, h->d_Dt, h->d_xi, h->d_wq, h->d_gb, h->d_cellflag, h->d_celllist, h->d_gram, h->d_Sf, h->d_dinv, h->d_scell, h->d_colpart, h->d_wgtab, h->d_prog, h->d_splan, h->d_xinit, h->d_H0p, h->d_Hcp, h->d_vecs, h->d_H0q, h->d_Hcq, h->d_H0q3, h->d_Hcq3, h->d_park2, h->d_park3, h->d_H0f, h->d_Hcf, h->d_H0t, h->d_Hct, h->d_dts, h->d_shape, h->d_weights, h->d_psi0,
                     h->d_target, h->d_eps, h->d_U, h->d_fw, h->d_bw, h->d_tg, h->d_ret, h->d_f,
                     h->d_rho};
     for (void *b : bufs)
@@ -2137,8 +2144,13 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     h->asm18gp = h->asm18g && p_direct;
     {
         const char *enve = getenv("GRAPE_DERIV_ECON");
-        h->deriv_econ = h->asm16 && p->gradient_method == GRAPE_GRAD_GRADGEN && h->taylor_tol >= 1e-16 && h->d_batchflag &&
+        const bool lg_ok = h->large && h->t18 && h->herm && h->lg_spec && !h->series;
+        h->deriv_econ = (h->asm16 || lg_ok) && p->gradient_method == GRAPE_GRAD_GRADGEN && h->taylor_tol >= 1e-16 && h->d_batchflag &&
                         !(enve && atoi(enve) == 0);
+        if (h->deriv_econ && lg_ok) {
+            CCHK(dmalloc(&h->d_celldeg, (size_t)h->KC * N_T));
+            CCHK(hipMemset(h->d_celldeg, 0, (size_t)h->KC * N_T * sizeof(int)));
+        }
     }
     if (h->asm16p || h->asm18gp) CCHK(dmalloc(&h->d_dte, (size_t)(L <= 2 ? 4 : 8) * N_T));
     if (h->t18 && !h->large && !h->series && ((L > 2 && !p->hc_per_traj) || (h->asm16 && !h->asm16p) || (h->asm18g && !h->asm18gp)) && (h->NT >= 3 || h->t18_small))
@@ -2452,6 +2464,9 @@ int grape_forward_device(grape_handle *h, const double *d_pulsevals, double *d_o
         if (h->deriv_econ) {   // which derivative batches this evaluation's verdicts certify for the economized series
             DerivEconArgs ec{};
             ec.verdict = h->d_cellflag; ec.splan = h->d_splan; ec.cls = h->d_cls; ec.flags = h->d_flags;
+            ec.cell_deg = h->large ? h->d_celldeg : nullptr;
+            ec.deg0 = ECON_DEG[0]; ec.deg1 = ECON_DEG[ECON_NSETS - 1];
+            static_assert(ECON_NSETS == 4, "segments 1.36 (verdict), 1.6, 2.0 (blocked path), 2.72 (one planned squaring)");
             ec.K = h->K; ec.KC = h->KC; ec.N_T = h->N_T; ec.batches_per_k = (h->N_T + 15) / 16;
             ec.nbatch_total = h->K * ec.batches_per_k; ec.batch_econ = h->d_batchflag + ec.nbatch_total;
             hipLaunchKernelGGL(deriv_econ_kernel, dim3((unsigned)((ec.nbatch_total + 255) / 256)), dim3(256), 0, s, ec);
@@ -2689,6 +2704,10 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
             }
             e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, h->deriv3_general ? 2 : (h->deriv3_h0g ? 1 : 0), h->deriv3_asm ? 1 : 0, (void *)s, h->deriv3_blocks);
         } else if (h->deriv4_blocks && !d2.gpark) {
+            if (h->deriv_econ && h->d_celldeg) {
+                d2.batch_flag = h->d_batchflag;
+                d2.batch_econ = 1;
+            }
             e = (hipError_t)grape_deriv4_launch(h->NP, &d2, sizeof(d2), h->d_H0q3, h->d_Hcq3, h->d_H0p3, h->d_Hcp3, (void *)s, h->deriv4_blocks);
         } else
         e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);

@@ -3425,13 +3425,18 @@ __global__ void deriv_flag_kernel(DerivFlagArgs a) {
     if (ns > 1) atomicAdd(&a.flags[3], 1);
 }
 
-// Round 6 -- one thread per batch: has the four-product exponential kernel of this evaluation CERTIFIED every cell of the
-// batch (verdict 0: spectral radius of H dt <= T16_THETA = ECON_THETA, asm/gen_t16.py) without scaling (a cell that was
-// exponentiated as A / 2^s is certified for A / 2^s)?  Those batches may take the economized derivative series
-// (asm/gen_d3.py, tools/econ_coeffs.py).  A route that was not tried in this evaluation has written no verdicts.
+// Round 6 -- one thread per batch: the degree of the economized derivative series (asm/gen_d3.py, tools/econ_coeffs.py)
+// EVERY cell of the batch is certified for, 0: none.  Certificates of this evaluation's exponential kernels:
+//   * four-product assembly kernels (asm/gen_t16.py): verdict 0 = spectral radius of the exponentiated matrix <= T16_THETA
+//     = 1.36; a cell exponentiated as A / 2 (one planned squaring) is certified for 2.72; more squarings: none.  A route
+//     that was not tried in this evaluation has written no verdicts.
+//   * blocked path, Hermitian generators (lg_t18_decide_kernel): cell_deg, from the norms of A^2 and A^6.
+// Of the degrees of a batch's cells the largest (its segment holds the others).
 struct DerivEconArgs {
     const int *verdict, *splan, *cls, *flags;   // [KC * N_T] each; cls: generator class of trajectory k (nullptr: k)
+    const int *cell_deg;                        // nullptr or [KC * N_T]: degrees named by the blocked path
     int K, KC, N_T, batches_per_k, nbatch_total;
+    int deg0, deg1;                             // degrees of the segments 1.36 and 2.72 (grape_econ_coeffs.h)
     int *batch_econ;                            // [nbatch_total]
 };
 __global__ void deriv_econ_kernel(DerivEconArgs a) {
@@ -3439,12 +3444,17 @@ __global__ void deriv_econ_kernel(DerivEconArgs a) {
     if (batch >= a.nbatch_total) return;
     const int k = batch / a.batches_per_k, n0 = (batch - k * a.batches_per_k) * 16;
     const int kc = a.cls ? a.cls[k] : k;
-    bool ok = !t16_skipped(a.flags, a.KC * a.N_T);
+    bool ok = a.cell_deg || !t16_skipped(a.flags, a.KC * a.N_T);
+    int deg = 0;
     for (int n = n0; ok && n < min(n0 + 16, a.N_T); ++n) {
         const int cell = kc * a.N_T + n;
-        ok = a.verdict[cell] == 0 && a.splan[cell] == 0;
+        int d;
+        if (a.cell_deg) d = a.cell_deg[cell];
+        else d = a.verdict[cell] != 0 ? 0 : a.splan[cell] == 0 ? a.deg0 : a.splan[cell] == 1 ? a.deg1 : 0;
+        ok = d > 0;
+        deg = max(deg, d);
     }
-    a.batch_econ[batch] = ok ? 1 : 0;
+    a.batch_econ[batch] = ok ? deg : 0;
 }
 
 struct DerivSubArgs {
@@ -3721,8 +3731,8 @@ struct Deriv2Args {
     // deriv3_kernel at one and two tiles per side: a series that is not converged within the terms the kernel parks, while
     // max_order allows more, raises flags[7] instead of the non-convergence error -- deriv_kernel redoes the derivatives
     int deep_redo;
-    // round 6: flags of the economized series lie behind the batch flags, batch_flag[nbatch_total + batch] (deriv_econ_kernel;
-    // read by the Hermitian assembly kernels of four tiles per side only)
+    // round 6: the degrees of the economized series lie behind the batch flags, batch_flag[nbatch_total + batch]
+    // (deriv_econ_kernel; read by the assembly kernels, Hermitian operators only)
     int batch_econ;
 #ifdef GRAPE_DIAG
     int ablate;                // diagnostic builds only: bit0 no parking traffic (results wrong)

@@ -563,6 +563,13 @@ struct LgT18DecideArgs {
     const double *colpart;
     LgT18ScaleArgs s;      // P, Q unused
     int nparts;            // row parts that were written: LG_PARTS (lg_t18_operands2_kernel) or NP / 64 (fused epilogue)
+    // round 6 -- the economized derivative series (deriv_econ_kernel): for a Hermitian cell without scaling the smallest
+    // segment theta_i with ||A^2|| <= theta_i^2 or ||A^6|| <= theta_i^6 (the spectral radius of a normal matrix is at most
+    // ||A^k||^(1/k)) names the degree of its polynomial; cell_deg[cell0 + cell] = that degree, 0: none
+    int *cell_deg;         // nullptr: not asked for
+    int cell0, econ_n;
+    double econ_theta[4];
+    int econ_deg[4];
 };
 __global__ void __launch_bounds__(256) lg_t18_decide_kernel(LgT18DecideArgs g) {
     const LgT18ScaleArgs &a = g.s;
@@ -596,6 +603,15 @@ __global__ void __launch_bounds__(256) lg_t18_decide_kernel(LgT18DecideArgs g) {
             double t1 = a.theta, t2 = t1 * t1, t3 = t2 * t1;
             while (!(n1 <= t1 || (np_ <= t2 && nq <= t3)) && s < 64) { ++s; t1 *= 2.0; t2 *= 4.0; t3 *= 8.0; }
             bad = bad || s >= 64;
+        }
+        if (g.cell_deg) {
+            int deg = 0;
+            if (!a.norm1 && s == 0 && !bad)
+                for (int i = 0; i < g.econ_n && !deg; ++i) {
+                    const double t2 = g.econ_theta[i] * g.econ_theta[i];
+                    if (np_ <= t2 || nq <= t2 * t2 * t2) deg = g.econ_deg[i];
+                }
+            g.cell_deg[g.cell0 + blockIdx.x] = deg;
         }
         if (bad) { s = 0; atomicOr(&a.flags[0], 64); }   // NaN / overflow in the generator
         a.s_cell[blockIdx.x] = s;

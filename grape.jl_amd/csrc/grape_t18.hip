@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) t16_credit_kernel(ExpmArgs a) {
 }
 
 constexpr int D3_INV_TABLE = 2048;
-constexpr int D3_PAIRS_OFF = 32768, D3_ECON_OFF = 32768;   // (gen_d3.py: PAIRS_OFF, ECON_OFF)
+constexpr int D3_PAIRS_OFF = 32768, D3_ECON_OFF = 32768, D3_ECON_TAB_B = 512;   // (gen_d3.py: PAIRS_OFF, ECON_OFF, ECON_TAB_B)
 struct AsmModule {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr, fn_d3 = nullptr, fn_d3s = nullptr, fn_lg = nullptr, fn_d3g = nullptr, fn_d4[2] = {nullptr, nullptr};
@@ -292,13 +292,15 @@ hipError_t asm_function(int dev, hipFunction_t *fn, hipFunction_t *fn_d3 = nullp
         // them the piece table of the streamed kernel (gen_d3s.py piece_table: source offset of piece 4 tile + 2 plane + half)
         // round 6: at D3_PAIRS_OFF bytes the scalars (omega_a, sigma_a) of pass 2, a < D3_INV_TABLE, of the Taylor series (both
         // 1 / (a + 1)); D3_ECON_OFF bytes further those of the economized series (grape_econ_coeffs.h, tools/econ_coeffs.py)
-        static_assert(D3_PAIRS_OFF >= (D3_INV_TABLE + 20) * 8 && D3_ECON_OFF == D3_INV_TABLE * 16, "layout of gen_d3.py");
-        std::vector<double> tab((D3_PAIRS_OFF + D3_ECON_OFF) / 8 + 2 * ECON_M);
+        static_assert(D3_PAIRS_OFF >= (D3_INV_TABLE + 20) * 8 && D3_ECON_OFF == D3_INV_TABLE * 16 && ECON_MAXDEG <= 31, "layout of gen_d3.py");
+        std::vector<double> tab((D3_PAIRS_OFF + D3_ECON_OFF + 16 * D3_ECON_TAB_B) / 8);
         tab[0] = 0.0;
         for (int i = 1; i < D3_INV_TABLE; ++i) tab[i] = 1.0 / (double)i;
         for (int a = 0; a < D3_INV_TABLE; ++a) tab[D3_PAIRS_OFF / 8 + 2 * a] = tab[D3_PAIRS_OFF / 8 + 2 * a + 1] = 1.0 / (double)(a + 1);
-        for (int a = 0; a < ECON_M; ++a)
-            for (int j = 0; j < 2; ++j) tab[(D3_PAIRS_OFF + D3_ECON_OFF) / 8 + 2 * a + j] = ECON_TAB[a][j];
+        for (int i = 0; i < ECON_NSETS; ++i)   // the polynomial of degree M at (M - 16) D3_ECON_TAB_B
+            for (int a = 0; a < ECON_DEG[i]; ++a)
+                for (int j = 0; j < 2; ++j)
+                    tab[(D3_PAIRS_OFF + D3_ECON_OFF + (ECON_DEG[i] - 16) * D3_ECON_TAB_B) / 8 + 2 * a + j] = ECON_TABS[i][a][j];
         int *pt = (int *)(tab.data() + D3_INV_TABLE);
         int np_ = 0;
         for (int ti = 0; ti < 4; ++ti)
@@ -365,7 +367,7 @@ hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks, bool ge
     k.tol2 = a.tol * a.tol;
     k.deep = (a.deep_redo && a.max_order > k.mcap) ? 1 : 0;
     // bit 1: flags of the economized series behind the batch flags (Hermitian kernels; the orders pass 1 forms must fit)
-    if (a.batch_econ && !general && a.batch_flag && k.mcap >= ECON_M) k.deep |= 2;
+    if (a.batch_econ && !general && a.batch_flag && k.mcap >= ECON_MAXDEG) k.deep |= 2;
     k.nblocks = blocks;
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -412,7 +414,7 @@ extern "C" int grape_deriv4_launch(int NP, const void *d2args, size_t d2size, co
     k.mcap = a.max_order < a.maxm ? a.max_order : a.maxm;
     k.slots = a.maxm + 1;
     k.tol2 = a.tol * a.tol;
-    k.deep = 0;
+    k.deep = (a.batch_econ && a.batch_flag && k.mcap >= ECON_MAXDEG) ? 2 : 0;   // bit 1: degrees of the economized series behind the batch flags
     k.nblocks = blocks;
     size_t size = sizeof(k);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &k, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};

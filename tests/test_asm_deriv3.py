@@ -57,25 +57,33 @@ def make_inputs(N, K, L, N_T, seed, hc_per_traj=False, shape=False, dt_scale=1.0
     return d
 
 
-def econ_table():
-    """(omega_a, sigma_a) of the economized series: the numbers of grape_econ_coeffs.h (generated by tools/econ_coeffs.py)"""
+def econ_tables():
+    """{degree M: (theta_M, [(omega_a, sigma_a)])} of the economized series: the numbers of grape_econ_coeffs.h (generated
+    by tools/econ_coeffs.py)"""
     import re
     text = open(os.path.join(ROOT, "grape.jl_amd", "csrc", "grape_econ_coeffs.h")).read()
+    degs = [int(x) for x in re.search(r"ECON_DEG\[\d+\] = \{([^}]*)\}", text).group(1).split(",")]
+    thetas = [float(x) for x in re.search(r"ECON_THETAS\[\d+\] = \{([^}]*)\}", text).group(1).split(",")]
     rows = re.findall(r"^\s*\{([-0-9.e]+), ([-0-9.e]+)\},", text, re.M)
-    tab = np.array([[float(a), float(b)] for a, b in rows])
-    assert tab.shape == (gen_d3.ECON_M, 2) and int(re.search(r"#define ECON_M (\d+)", text).group(1)) == gen_d3.ECON_M
-    return tab
+    out, at = {}, 0
+    for M, th in zip(degs, thetas):
+        out[M] = (th, np.array([[float(a), float(b)] for a, b in rows[at:at + M]]))
+        at += M
+    assert at == len(rows) and min(degs) == gen_d3.ECON_MIN and max(degs) < gen_d3.ECON_MIN + 16
+    return out
 
 
 def inv_buffer():
-    """1 / m | piece table of the streamed kernel | (omega, sigma) pairs of the Taylor series | of the economized series
-    (grape_t18.hip lays the same buffer out)"""
-    tab = np.zeros(gen_d3.PAIRS_OFF + gen_d3.ECON_OFF + gen_d3.ECON_M * 16, np.uint8)
+    """1 / m | piece table of the streamed kernel | (omega, sigma) pairs of the Taylor series | of the economized polynomials
+    by degree (grape_t18.hip lays the same buffer out)"""
+    tab = np.zeros(gen_d3.PAIRS_OFF + gen_d3.ECON_OFF + 16 * gen_d3.ECON_TAB_B, np.uint8)
     tab[:gen_d3s.INV_TABLE * 8].view(np.float64)[1:] = 1.0 / np.arange(1, gen_d3s.INV_TABLE)
     tab[gen_d3s.INV_TABLE * 8:gen_d3s.INV_TABLE * 8 + 160].view(np.int32)[:] = gen_d3s.piece_table()
     pairs = tab[gen_d3.PAIRS_OFF:gen_d3.PAIRS_OFF + gen_d3.ECON_OFF].view(np.float64).reshape(-1, 2)
     pairs[:] = (1.0 / np.arange(1, len(pairs) + 1))[:, None]
-    tab[gen_d3.PAIRS_OFF + gen_d3.ECON_OFF:].view(np.float64)[:] = econ_table().ravel()
+    for M, (_, t) in econ_tables().items():
+        o = gen_d3.PAIRS_OFF + gen_d3.ECON_OFF + (M - gen_d3.ECON_MIN) * gen_d3.ECON_TAB_B
+        tab[o:o + 16 * M].view(np.float64)[:] = t.ravel()
     return tab
 
 
@@ -124,9 +132,10 @@ def run_kernel(prog, d, nblk, wpt, mcap=40, tol=1e-16, deep=0, batch_flag=None, 
 def series_reference(d, mcap=40, tol=1e-16, group_wpt=None, econ=None):
     """the two-pass series of the kernel, cell by cell; the stopping rule is a batch's (16 cells stop together) -- or, for
     the streamed kernel (group_wpt = workgroups per trajectory), that of the four batches a workgroup walks in lockstep.
-    econ: [K][batches] flags of the economized series (a certified group stops pass 1 after ECON_M - 1 orders and takes the
-    scalars of grape_econ_coeffs.h when its Taylor terms are not below the tolerance by then)"""
-    etab = econ_table()
+    econ: [K][batches] degree M of the economized polynomial every cell of the batch is certified for, 0: none (a certified
+    group stops pass 1 after M - 1 orders and takes the scalars of grape_econ_coeffs.h when its Taylor terms are not below
+    the tolerance by then; of several batches the largest degree)"""
+    etabs = econ_tables()
     K, L, N_T = d["K"], d["L"], d["N_T"]
     tg = np.zeros((K, L, N_T), complex)
     bpk = (N_T + 15) // 16
@@ -145,9 +154,10 @@ def series_reference(d, mcap=40, tol=1e-16, group_wpt=None, econ=None):
                 Hs[n] = d["H0"][k] + sum(d["eps"][l, n] * sh[l] * mu[l] for l in range(L))
                 us[n] = [d["fw"][k, n]]
             M = 0
-            certified = econ is not None and all(econ[k][min(bb, bpk - 1)] for bb in range(grp[0], grp[0] + (4 if group_wpt else 1)))
+            degs = [econ[k][min(bb, bpk - 1)] for bb in range(grp[0], grp[0] + (4 if group_wpt else 1))] if econ is not None else [0]
+            certified = 0 if min(degs) == 0 else int(max(degs))
             converged = False
-            for m in range(1, (gen_d3.ECON_M - 1 if certified else mcap) + 1):
+            for m in range(1, (certified - 1 if certified else mcap) + 1):
                 for n in cells:
                     us[n].append(-1j * d["dts"][n] / m * (Hs[n] @ us[n][-1]))
                 M = m
@@ -156,7 +166,7 @@ def series_reference(d, mcap=40, tol=1e-16, group_wpt=None, econ=None):
                     break
             pairs = [(1.0 / (a + 1), 1.0 / (a + 1)) for a in range(M)]
             if certified and not converged:
-                M, pairs = gen_d3.ECON_M, etab
+                M, pairs = certified, etabs[certified][1]
             orders[k, b] = M
             for n in cells:
                 mu = d["Hc"][k if d["hc_per_traj"] else 0]
@@ -217,35 +227,40 @@ def test_emulated_kernel_matches_the_series_and_the_frechet_derivative(program, 
     assert int(stats[:, 8].sum()) == int((orders * np.array(cells)).sum())
 
 
-def certified_batches(d, theta=1.36):
-    """[K][batches]: every cell of the batch has a spectral radius of H_n dt_n within theta -- what the verdict of the
-    four-product exponential kernel certifies (asm/gen_t16.py)"""
+def certified_batches(d, only=None):
+    """[K][batches]: the smallest degree of grape_econ_coeffs.h whose segment holds the spectral radius of H_n dt_n of every
+    cell of the batch, 0: none -- what the exponential kernels certify (asm/gen_t16.py: 1.36; scaled cells and the blocked
+    path: the wider segments).  only: the degrees the certifying kernel can name"""
     K, L, N_T = d["K"], d["L"], d["N_T"]
     bpk = (N_T + 15) // 16
-    ok = np.ones((K, bpk), np.int32)
+    rad = np.zeros((K, bpk))
     for k in range(K):
         mu = d["Hc"][k if d["hc_per_traj"] else 0]
         for n in range(N_T):
             sh = d["shape"][:, n] if d["shape"] is not None else np.ones(L)
             H = d["H0"][k] + sum(d["eps"][l, n] * sh[l] * mu[l] for l in range(L))
-            if np.abs(np.linalg.eigvalsh(H)).max() * d["dts"][n] > theta:
-                ok[k, n // 16] = 0
+            rad[k, n // 16] = max(rad[k, n // 16], np.abs(np.linalg.eigvalsh(H)).max() * d["dts"][n])
+    ok = np.zeros((K, bpk), np.int32)
+    for M, (theta, _) in sorted(econ_tables().items(), reverse=True):
+        if only is None or M in only:
+            ok[rad <= theta] = M
     return ok
 
 
-@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape,dts", [(64, 2, 2, 40, 2, 1, False, False, 0.72), (50, 1, 1, 37, 1, 1, True, True, 0.62)])
-def test_economized_series_of_certified_batches(program, N, K, L, N_T, nblk, wpt, hcpt, shape, dts):
-    """round 6: certified batches whose Taylor terms are not below the tolerance after ECON_M - 1 orders take the scalars
-    of the degree-16 polynomial (tools/econ_coeffs.py): the restatement with the same scalars to rounding, the Frechet
-    derivative as closely as the Taylor sum, ECON_M booked orders; the other batches exactly as before"""
+@pytest.mark.parametrize("N,K,L,N_T,nblk,wpt,hcpt,shape,dts,only", [
+    (64, 2, 2, 40, 2, 1, False, False, 0.72, (16,)), (50, 1, 1, 37, 1, 1, True, True, 0.62, (16,)), (64, 1, 2, 40, 1, 1, False, False, 1.15, (16, 21))])
+def test_economized_series_of_certified_batches(program, N, K, L, N_T, nblk, wpt, hcpt, shape, dts, only):
+    """round 6: certified batches whose Taylor terms are not below the tolerance after M - 1 orders take the scalars
+    of the degree-M polynomial of their segment (tools/econ_coeffs.py): the restatement with the same scalars to rounding,
+    the Frechet derivative as closely as the Taylor sum, M booked orders; the other batches exactly as before"""
     _, prog, _ = program
     d = make_inputs(N, K, L, N_T, seed=N + L + 1, hc_per_traj=hcpt, shape=shape, dt_scale=dts)
-    econ = certified_batches(d)
+    econ = certified_batches(d, only)
     assert econ.any() and not econ.all()
     tg, flags, stats, info = run_kernel(prog, d, nblk, wpt, econ=econ)
     ref, orders = series_reference(d, econ=econ)
     ref_t, orders_t = series_reference(d)
-    assert (orders[econ == 1] <= gen_d3.ECON_M).all() and (orders == gen_d3.ECON_M).any() and (orders <= orders_t).all()
+    assert (orders[econ > 0] <= econ[econ > 0]).all() and (orders == econ).any() and (orders <= orders_t).all()
     assert (orders[econ == 0] == orders_t[econ == 0]).all() and (orders < orders_t).any()
     assert np.abs(tg - ref).max() < 2e-15 * max(1.0, np.abs(ref).max()) * 8, np.abs(tg - ref).max()
     fre = frechet_reference(d)
@@ -313,12 +328,12 @@ def test_streamed_kernel_economized_series(program_s):
     """the four batches of a workgroup stop together: the economized scalars apply when all four are certified"""
     _, prog, _ = program_s
     d = make_inputs(64, 1, 3, 100, seed=11, dt_scale=0.5)
-    econ = certified_batches(d)
+    econ = certified_batches(d, (16,))
     wpt = 1
     tg, flags, stats, info = run_kernel(prog, d, 1, wpt, lds_bytes=gen_d3s.LDS_BYTES, econ=econ)
     ref, orders = series_reference(d, group_wpt=wpt, econ=econ)
     _, orders_t = series_reference(d, group_wpt=wpt)
-    assert (orders == gen_d3.ECON_M).any() and (orders < orders_t).any() and (orders <= orders_t).all(), (econ, orders, orders_t)
+    assert (orders == 16).any() and (orders < orders_t).any() and (orders <= orders_t).all(), (econ, orders, orders_t)
     assert np.abs(tg - ref).max() < 2e-15 * max(1.0, np.abs(ref).max()) * 8, np.abs(tg - ref).max()
     fre = frechet_reference(d)
     assert np.abs(tg - fre).max() < 1e-13, np.abs(tg - fre).max()

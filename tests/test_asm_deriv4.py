@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "grape.jl_amd", "csrc", "asm"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gcn  # noqa: E402
 import gen_d4  # noqa: E402
-from test_asm_deriv3 import series_reference, frechet_reference  # noqa: E402
+from test_asm_deriv3 import series_reference, frechet_reference, inv_buffer, certified_batches  # noqa: E402
 
 
 def pack3(mats, NP, dagger):
@@ -61,7 +61,7 @@ def make_inputs(N, NP, K, L, N_T, seed, hc_per_traj=False, shape=False, dt_scale
     return d
 
 
-def run_kernel(gen, prog, d, nblk, mcap=40, tol=1e-16, deep=0, batch_flag=None):
+def run_kernel(gen, prog, d, nblk, mcap=40, tol=1e-16, deep=0, batch_flag=None, econ=None):
     NP, K, L, N_T = gen.NP, d["K"], d["L"], d["N_T"]
     g = gcn.GlobalMem()
     hcs = d["Hc"].reshape(-1, NP, NP)
@@ -87,11 +87,13 @@ def run_kernel(gen, prog, d, nblk, mcap=40, tol=1e-16, deep=0, batch_flag=None):
     a_stats, stats = g.add("stats", np.zeros(64 * 16, np.uint64))
     bpk = (N_T + 15) // 16
     a_bf = 0
+    if econ is not None:     # degrees of the economized series behind the batch flags (bit 1 of `deep`)
+        batch_flag = np.concatenate([np.zeros(K * bpk, np.int32) if batch_flag is None else np.asarray(batch_flag, np.int32),
+                                     np.asarray(econ, np.int32).ravel()])
+        deep |= 2
     if batch_flag is not None:
         a_bf, _ = g.add("batch_flag", np.asarray(batch_flag, np.int32))
-    tab = np.zeros(2048)
-    tab[1:] = 1.0 / np.arange(1, 2048)
-    a_inv, _ = g.add("inv", tab)
+    a_inv, _ = g.add("inv", inv_buffer())
     karg = struct.pack("<16Q8idii", a_H0q, a_Hcq, a_H0p, a_Hcp, a_eps, a_shape, a_dts, a_fw, a_bw, a_rho, a_tg, a_park, a_flags, a_stats,
                        a_bf, a_inv, K, L, N_T, d["hc_per_traj"], K * bpk, bpk, mcap, slots, tol * tol, deep, nblk)
     assert len(karg) == gen_d4.KERNARG
@@ -129,6 +131,25 @@ def test_emulated_kernel_matches_the_series_and_the_frechet_derivative(program12
     assert np.abs(tg - fre).max() < 1e-13, np.abs(tg - fre).max()
     assert flags[0] == 0 and flags[7] == 0
     cells = [[min(16, N_T - 16 * b) for b in range((N_T + 15) // 16)] for _ in range(K)]
+    assert int(stats[:, 8].sum()) == int((orders * np.array(cells)).sum())
+
+
+def test_economized_series_of_certified_batches(program128):
+    """round 6 (gen_d3.py's header): Hermitian operators whose batches the blocked path's bound certifies for a segment take
+    the polynomial of that segment's degree"""
+    gen, prog, _ = program128
+    d = make_inputs(128, 128, 1, 2, 40, seed=21, general=False, dt_scale=1.0)
+    econ = certified_batches(d, (16, 17, 19))
+    assert len(set(econ.ravel().tolist()) - {0}) >= 1
+    tg, flags, stats = run_kernel(gen, prog, d, 2, econ=econ)
+    ref, orders = series_reference(d, econ=econ)
+    _, orders_t = series_reference(d)
+    assert (orders == econ)[econ > 0].any() and (orders < orders_t).any() and (orders <= orders_t).all(), (econ, orders, orders_t)
+    assert np.abs(tg - ref).max() < 2e-15 * max(1.0, np.abs(ref).max()) * 8, np.abs(tg - ref).max()
+    fre = frechet_reference(d)
+    assert np.abs(tg - fre).max() < 1e-13, np.abs(tg - fre).max()
+    assert flags[0] == 0 and flags[7] == 0
+    cells = [[min(16, 40 - 16 * b) for b in range(3)]]
     assert int(stats[:, 8].sum()) == int((orders * np.array(cells)).sum())
 
 

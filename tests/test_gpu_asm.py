@@ -127,12 +127,16 @@ def run_d3(g, pr, asm, econ=False, **kw):
 
 @pytest.mark.parametrize("N,L,N_T,K,kw", [
     (64, 2, 37, 3, {}), (57, 2, 100, 5, {}), (64, 1, 40, 16, {}), (64, 2, 33, 2, {"shape": True}), (60, 2, 18, 3, {"per_traj": True}),
-    (64, 6, 70, 3, {}), (64, 3, 40, 2, {"per_traj": True}), (64, 2, 40, 3, {"dt": 0.6}), (64, 2, 40, 3, {"dt": 1.4})])
+    (64, 6, 70, 3, {}), (64, 3, 40, 2, {"per_traj": True}), (64, 2, 40, 3, {"dt": 0.6}), (64, 2, 40, 3, {"dt": 1.4}),
+    (64, 4, 40, 2, {"dt": 1.5}), (64, 2, 40, 2, {"dt": 4.0}),
+    (128, 2, 40, 2, {}), (100, 3, 33, 2, {"shape": True}), (256, 4, 20, 1, {}), (200, 2, 20, 1, {"dt": 1.5}), (128, 2, 20, 2, {"dt": 3.0})])
 def test_economized_derivative_series_against_the_taylor_sum(g, ref, N, L, N_T, K, kw):
-    """round 6: batches the four-product exponential kernel certifies (spectral radius <= 1.36) take the degree-16
-    polynomial of tools/econ_coeffs.py in the derivative kernels (gen_d3.py, gen_d3s.py): fewer orders, the Taylor sum's
-    numbers to 1e-13 and the oracle's at SURVEY 8c's tolerance; short steps converge before ECON_M orders and change nothing;
-    long steps (scaled cells: not certified) keep the Taylor sum"""
+    """round 6: batches the exponential kernels certify for a segment of the imaginary axis take the polynomial of that
+    segment (tools/econ_coeffs.py) in the derivative kernels (gen_d3.py, gen_d3s.py, gen_d4.py): the four-product kernel's
+    verdict (spectral radius <= 1.36: degree 16; a cell exponentiated as A / 2: 2.72, degree 21), the blocked path's bounds
+    from ||A^2|| and ||A^6|| (1.36, 1.6, 2.0).  Fewer orders, the Taylor sum's numbers to 1e-13 and the oracle's at SURVEY
+    8c's tolerance; short steps converge before any polynomial's degree and change nothing; long steps (several squarings:
+    nothing certified) keep the Taylor sum"""
     from grape_jl_amd import synth
     pr = synth.make_problem(N, L, N_T, K, seed=17 + N + L)
     args = {}
@@ -149,15 +153,19 @@ def test_economized_derivative_series_against_the_taylor_sum(g, ref, N, L, N_T, 
     gs = max(np.abs(b[1]).max(), 1e-3)
     assert np.abs(a[1] - b[1]).max() <= 1e-13 * gs, np.abs(a[1] - b[1]).max() / gs
     cells = K * N_T
-    if kw.get("dt"):
+    if kw.get("dt", 1.0) < 1 or kw.get("dt", 1.0) >= 3:
         assert a[3]["deriv_orders"] == b[3]["deriv_orders"]      # nothing to economize / nothing certified
         if kw["dt"] < 1:
             assert a[3]["deriv_orders"] < 16 * cells
+    elif kw.get("dt"):       # (the degree of a wide segment pays only near its end: the Taylor sum may get there first)
+        assert a[3]["deriv_orders"] <= b[3]["deriv_orders"], (a[3]["deriv_orders"], b[3]["deriv_orders"])
     else:
-        assert a[3]["deriv_orders"] < b[3]["deriv_orders"] and a[3]["deriv_orders"] <= 16.5 * cells, (a[3]["deriv_orders"], b[3]["deriv_orders"])
-    if K * N_T <= 400 and "shape" not in args:
+        assert a[3]["deriv_orders"] < b[3]["deriv_orders"], (a[3]["deriv_orders"], b[3]["deriv_orders"])
+        if N <= 64:
+            assert a[3]["deriv_orders"] <= 16.5 * cells
+    if K * N_T * (N / 64.0) ** 3 <= 400 and "shape" not in args:
         Jr, Gr, _ = ref.evaluate(pr["H0"], pr["Hc"], pr["tlist"], pr["pulsevals"], pr["psi0"], pr["target"], pr["weights"],
-                                 gradient_method=ref.GRADGEN)
+                                 gradient_method=ref.GRADGEN if N <= 64 else ref.TAYLOR)
         assert abs(a[0] - Jr) <= 1e-12 and np.abs(a[1] - Gr).max() <= 1e-10 * max(np.abs(Gr).max(), 1e-3)
 
 
@@ -326,8 +334,9 @@ def test_general_operator_derivative_kernel_against_the_compiled_kernels(g, N, L
 # ---- blocked path: the derivative kernel as assembly (asm/gen_d4.py) against deriv2_kernel (GRAPE_DERIV4=0, read in
 # grape_create) ----
 def run_d4(g, pr, asm, **kw):
-    old = os.environ.get("GRAPE_DERIV4")
+    old, old_e = os.environ.get("GRAPE_DERIV4"), os.environ.get("GRAPE_DERIV_ECON")
     os.environ["GRAPE_DERIV4"] = "1" if asm else "0"
+    os.environ["GRAPE_DERIV_ECON"] = "0"                     # (the compiled twin has the Taylor sum only)
     try:
         with g.GrapeHip(pr["H0"], pr["Hc"], pr["tlist"], pr["psi0"], pr["target"], pr["weights"], **kw) as h:
             J, G, tau = h.eval(pr["pulsevals"])
@@ -335,10 +344,11 @@ def run_d4(g, pr, asm, **kw):
             assert J2 == J and np.array_equal(G, G2)
             return J, G, tau, h.work()
     finally:
-        if old is None:
-            os.environ.pop("GRAPE_DERIV4", None)
-        else:
-            os.environ["GRAPE_DERIV4"] = old
+        for name, val in (("GRAPE_DERIV4", old), ("GRAPE_DERIV_ECON", old_e)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
 
 
 @pytest.mark.parametrize("N,L,N_T,K,herm,kw", [

@@ -31,8 +31,12 @@ import mpmath as mp
 import numpy as np
 
 mp.mp.dps = 60
-THETA = mp.mpf("1.36")
-M = 16
+# (degree M, radius theta_M of the segment): the smallest degree whose derivative error 2 J_M(theta) stays below 2.5e-16.
+#   1.36  the verdict of the four-product exponential kernel (T16_THETA)        1.6, 2.0  bounds of the blocked path
+#   2.72  a cell of the four-product kernel that was exponentiated as A / 2 (one planned squaring)
+SETS = [(16, "1.36"), (17, "1.6"), (19, "2.0"), (21, "2.72")]
+THETA = mp.mpf(SETS[0][1])
+M = SETS[0][0]
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "grape.jl_amd", "csrc", "grape_econ_coeffs.h")
 
@@ -133,30 +137,43 @@ def check(tab_d, radius, seed=0, n=10):
     return abs(got - ex) / np.linalg.norm(E, 2)
 
 
+def taylor_degree(theta):
+    """terms the Taylor sum needs for the same derivative error on the segment"""
+    m = 2
+    while theta ** m / mp.factorial(m) > mp.mpf("2.5e-16"):
+        m += 1
+    return m + 1
+
+
 def main():
-    c = polynomial()
-    tab = table(c)
-    ev, ed = segment_errors(c, THETA)
-    print(f"degree {M} on i[-{THETA}, {THETA}]: |p - exp| <= {ev:.2e}, |p' - exp| <= {ed:.2e}")
-    for deg in (19, 20, 21):
-        t = [1 / mp.factorial(m) for m in range(deg + 1)]
-        print(f"   Taylor, degree {deg}: |p' - exp| <= {segment_errors(t, THETA)[1]:.2e} at {THETA}, {segment_errors(t, mp.mpf('1.2'))[1]:.2e} at 1.2")
-    tab_d = [(float(a), float(b)) for a, b in tab]
-    for radius in (0.4, 1.0, 1.2, 1.36):
-        errs = [check(tab_d, radius, seed) for seed in range(3)]
-        tay = [(1.0 / (a + 1), 1.0 / (a + 1)) for a in range(21)]
-        errt = [check(tay, radius, seed) for seed in range(3)]
-        print(f"   two-pass contraction, rho = {radius}: economized {max(errs):.2e}, Taylor (21 terms) {max(errt):.2e}   (relative to ||E||)")
     lines = ["// GENERATED by tools/econ_coeffs.py -- scalars of the economized derivative series (see its header).",
-             f"// p(x) = 1 + int_0^x q, q the degree-{M - 1} Chebyshev truncation of exp on i [-{THETA}, {THETA}]:",
-             f"// |p - exp| <= {ev:.1e}, |p' - exp| <= {ed:.1e} on the segment.",
+             "// p_M(x) = 1 + int_0^x q, q the degree-(M - 1) Chebyshev truncation of exp on i [-theta_M, theta_M]; one polynomial per",
+             "// degree, the smallest degree whose derivative stays within 2.5e-16 of exp's on its segment.",
              "#pragma once",
-             f"#define ECON_M {M}",
-             f"#define ECON_THETA {THETA}",
-             "// {omega_a, sigma_a}, a = 0 .. ECON_M - 1   (Taylor: both 1 / (a + 1))",
-             f"static const double ECON_TAB[{M}][2] = {{"]
-    for a, (om, sg) in enumerate(tab):
-        lines.append(f"    {{{mp.nstr(om, 20)}, {mp.nstr(sg, 20)}}},   // {a}: 1 / (a + 1) = {1.0 / (a + 1):.17g}")
+             f"#define ECON_NSETS {len(SETS)}",
+             f"#define ECON_MAXDEG {max(m for m, _ in SETS)}",
+             f"static const int ECON_DEG[{len(SETS)}] = {{{', '.join(str(m) for m, _ in SETS)}}};",
+             f"static const double ECON_THETAS[{len(SETS)}] = {{{', '.join(t for _, t in SETS)}}};",
+             "// [set][a] = {omega_a, sigma_a}, a = 0 .. ECON_DEG[set] - 1   (Taylor: both 1 / (a + 1))",
+             f"static const double ECON_TABS[{len(SETS)}][{max(m for m, _ in SETS)}][2] = {{"]
+    for deg, th in SETS:
+        theta = mp.mpf(th)
+        c = polynomial(theta, deg)
+        tab = table(c)
+        ev, ed = segment_errors(c, theta)
+        print(f"degree {deg} on i[-{th}, {th}]: |p - exp| <= {ev:.2e}, |p' - exp| <= {ed:.2e};  degree {deg - 1}: "
+              f"{segment_errors(polynomial(theta, deg - 1), theta)[1]:.2e};  the Taylor sum needs {taylor_degree(theta)} terms")
+        assert ed < 2.5e-16
+        tab_d = [(float(a), float(b)) for a, b in tab]
+        for radius in (0.5 * float(theta), 0.9 * float(theta), float(theta)):
+            errs = [check(tab_d, radius, seed) for seed in range(2)]
+            tay = [(1.0 / (a + 1), 1.0 / (a + 1)) for a in range(taylor_degree(theta) + 2)]
+            errt = [check(tay, radius, seed) for seed in range(2)]
+            print(f"   two-pass contraction, rho = {radius:.3f}: economized {max(errs):.2e}, Taylor ({len(tay)} terms) {max(errt):.2e}   (relative to ||E||)")
+        lines.append(f"    {{   // degree {deg}, |lambda| <= {th}: |p - exp| <= {ev:.1e}, |p' - exp| <= {ed:.1e}")
+        for a, (om, sg) in enumerate(tab):
+            lines.append(f"        {{{mp.nstr(om, 20)}, {mp.nstr(sg, 20)}}},   // {a}: 1 / (a + 1) = {1.0 / (a + 1):.17g}")
+        lines.append("    },")
     lines.append("};")
     text = "\n".join(lines) + "\n"
     print(text)
