@@ -73,7 +73,12 @@ typedef enum {
     GRAPE_J_T_RE = 2   /* 1 - Re sum_k w_k tau_k / K    ; chi_k = w_k / (2K) * tgt_k                  */
 } grape_functional;
 
-/* gradient_method keyword of the reference (workspace.jl:150, optimize.jl:871-998) */
+/* gradient_method keyword of the reference (workspace.jl:150, optimize.jl:871-998).
+ * GRAPE_GRAD_GRADGEN: the contraction <chi| D exp(-i H dt)[-i dt mu_l] |Psi> to rounding (what the exponential of the gradient
+ * generator delivers in the reference), by a two-pass polynomial series on the stored states: the Taylor sum cut at 1e-16,
+ * sub-stepped for long steps -- and, for Hermitian cells whose spectrum this evaluation's exponential kernel has certified
+ * to lie in a segment of the imaginary axis, the economized polynomial of that segment (same accuracy, fewer orders;
+ * DESIGN.md 4.3, tools/econ_coeffs.py; environment GRAPE_DERIV_ECON=0 keeps the Taylor sum everywhere). */
 typedef enum {
     GRAPE_GRAD_GRADGEN = 0, /* exact derivative of exp (what the gradient generator yields)  */
     GRAPE_GRAD_TAYLOR = 1   /* Kuprov-Rodgers recursion, taylor_grad_step! (optimize.jl:604) */
