@@ -698,13 +698,14 @@ class GenD3:
         p.s_branch("s_cbranch_scc1", lab3)
         # not converged: flags[7] += 1 when deriv_kernel may redo it (deep_redo and max_order > mcap is decided by the host:
         # deep_redo is only set then), else flags[0] |= 4
-        p.s_cmp("s_cmp_lg_u32", self.s_deep, 0)
+        p.salu("s_and_b32", self.s_t[5], self.s_deep, 1)           # (bit 1 of `deep`: the economized series)
+        p.s_cmp("s_cmp_lg_u32", self.s_t[5], 0)
         p.salu("s_cselect_b32", self.s_t[1], 28, 0)
         p.salu("s_cselect_b32", self.s_t[2], 1, 4)
         p.valu("v_mov_b32", bk.sub(3), self.s_t[1])
         p.valu("v_mov_b32", bk.sub(4), self.s_t[2])
         lab4 = f"L_deep_{len(p.ins)}"
-        p.s_cmp("s_cmp_lg_u32", self.s_deep, 0)
+        p.s_cmp("s_cmp_lg_u32", self.s_t[5], 0)
         p.s_branch("s_cbranch_scc1", lab4)
         p.global_atomic("global_atomic_or", bk.sub(3), bk.sub(4), self.s_flags)
         p.s_branch("s_branch", lab3)

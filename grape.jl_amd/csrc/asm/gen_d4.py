@@ -691,12 +691,13 @@ class GenD4:
         p.global_atomic("global_atomic_add_x2", bk.sub(2), bk.sub(0, 2), self.s_stats)
         p.s_cmp("s_cmp_lg_u32", self.s_conv, 0)
         p.s_branch("s_cbranch_scc1", "L_bk_done")
-        p.s_cmp("s_cmp_lg_u32", self.s_deep, 0)
+        p.salu("s_and_b32", self.s_t[5], self.s_deep, 1)           # (bit 1 of `deep`: the economized series)
+        p.s_cmp("s_cmp_lg_u32", self.s_t[5], 0)
         p.salu("s_cselect_b32", self.s_t[1], 28, 0)
         p.salu("s_cselect_b32", self.s_t[2], 1, 4)
         p.valu("v_mov_b32", bk.sub(3), self.s_t[1])
         p.valu("v_mov_b32", bk.sub(4), self.s_t[2])
-        p.s_cmp("s_cmp_lg_u32", self.s_deep, 0)
+        p.s_cmp("s_cmp_lg_u32", self.s_t[5], 0)
         p.s_branch("s_cbranch_scc1", "L_bk_deep")
         p.global_atomic("global_atomic_or", bk.sub(3), bk.sub(4), self.s_flags)
         p.s_branch("s_branch", "L_bk_done")

@@ -202,7 +202,11 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
                 }
             d3_finish<NT>(v);
             int M = 0, converged = 0;
-            for (int m = 1; m <= mcap; ++m) {   // forms u_m
+            // round 6: degree of the economized polynomial this batch is certified for (asm/gen_d3.py's header), 0: none
+            const int deg = (a.batch_econ && a.batch_flag && a.econ_pairs) ? a.batch_flag[a.nbatch_total + batch] : 0;
+            const int capb = (deg && deg - 1 <= mcap) ? deg - 1 : mcap;
+            const double *pairs = nullptr;
+            for (int m = 1; m <= capb; ++m) {   // forms u_m
                 Strip<NT> sum;
                 apply(v, sum, [](int, const Strip<NT> &) {}, std::false_type());
                 const double sfac = dt / (double)m;
@@ -225,6 +229,10 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
                 M = m;
                 if (m >= 2 && __all(nn < a.tol * a.tol)) { converged = 1; break; }   // ||u_m|| < tol for every cell of the batch
             }
+            if (!converged && capb != mcap) {   // certified: the deg - 1 orders formed are all the polynomial needs
+                M = deg; converged = 1;
+                pairs = a.econ_pairs + (size_t)(deg - 16) * 64;
+            }
             // ---- pass 2: w_{M-1} = chi(t_{n+1}), w_{a-1} = chi + (i dt / (a+1)) H^dagger w_a ----
             Strip<NT> chi;
 #pragma unroll
@@ -241,7 +249,7 @@ __global__ void __launch_bounds__(256) deriv3_kernel(Deriv3Args g) {
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) { dr[l] = 0.; di[l] = 0.; }
             for (int aa = M - 1; aa >= 0; --aa) {
-                const double inv = 1.0 / (double)(aa + 1), sfac = dt * inv;
+                const double inv = pairs ? pairs[2 * aa] : 1.0 / (double)(aa + 1), sfac = dt * (pairs ? pairs[2 * aa + 1] : inv);
                 Strip<NT> u;   // u_aa (requested before the products)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)

@@ -239,6 +239,7 @@ struct grape_handle {
     // 19-21 terms.  Exact-derivative route only (:taylor is the reference's recursion, term by term), default tolerance
     // or looser... a tighter one keeps the Taylor sum.  GRAPE_DERIV_ECON=0: off.
     bool deriv_econ = false;
+    const double *d_econ_pairs = nullptr;   // device: (omega, sigma) of the economized polynomials, degree M at 64 (M - 16) doubles
     int *d_celldeg = nullptr;    // blocked path: [KC * N_T] degree named by lg_t18_decide_kernel for every cell
     double sub_theta = 0.0;      // threshold of deriv_substeps (0: off, gradient_method = :taylor mirrors the reference)
     int sq_plan = 2;             // blocked path: squaring launches issued per chunk (adapted by grape_check, see expm_large)
@@ -352,6 +353,7 @@ hipError_t launch_expm(const ExpmArgs &a, bool herm, hipStream_t s, int persiste
 // Hermitian generators, N in (32, 64]: inverse-free degree-18 polynomial kernel (grape_t18.hip.h, its own translation
 // unit grape_t18.hip), persistent grid
 extern "C" int grape_t18_launch(int NT, int herm, int t16, const void *args, size_t args_size, void *stream, int blocks);
+extern "C" const double *grape_econ_pairs(void);   // grape_t18.hip: the tables of the economized series on the current device
 extern "C" int grape_t16p_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
                                      const void *const *walk, int fuse, int K, const double *dte);
 extern "C" int grape_t18g_asm_launch(const void *args, size_t args_size, int *verdict, void *stream, int blocks,
@@ -2145,8 +2147,12 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
     {
         const char *enve = getenv("GRAPE_DERIV_ECON");
         const bool lg_ok = h->large && h->t18 && h->herm && h->lg_spec && !h->series;
-        h->deriv_econ = (h->asm16 || lg_ok) && p->gradient_method == GRAPE_GRAD_GRADGEN && h->taylor_tol >= 1e-16 && h->d_batchflag &&
+        // (the compiled four-product kernel of three and four tiles per side writes the same verdicts: expm_t18_kernel<.., T16>)
+        const bool t16c_ok = h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT >= 3;
+        h->deriv_econ = (h->asm16 || lg_ok || t16c_ok) && p->gradient_method == GRAPE_GRAD_GRADGEN && h->taylor_tol >= 1e-16 && h->d_batchflag &&
                         !(enve && atoi(enve) == 0);
+        if (h->deriv_econ) h->d_econ_pairs = grape_econ_pairs();   // (the compiled derivative kernels read the tables through a pointer)
+        if (h->deriv_econ && !h->d_econ_pairs) h->deriv_econ = false;
         if (h->deriv_econ && lg_ok) {
             CCHK(dmalloc(&h->d_celldeg, (size_t)h->KC * N_T));
             CCHK(hipMemset(h->d_celldeg, 0, (size_t)h->KC * N_T * sizeof(int)));
@@ -2700,17 +2706,24 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
             d2.park = h->d_park3;
             if (h->deriv_econ && !h->deriv3_general && !h->deriv3_h0g) {   // (without sub-steps the batch flags stay zero, from grape_create)
                 d2.batch_flag = h->d_batchflag;
-                d2.batch_econ = 1;
+                d2.batch_econ = 1; d2.econ_pairs = h->d_econ_pairs;
             }
             e = (hipError_t)grape_deriv3_launch(h->NT, &d2, sizeof(d2), h->d_H0f, h->d_Hcf, h->deriv3_wpt, 0, h->deriv3_general ? 2 : (h->deriv3_h0g ? 1 : 0), h->deriv3_asm ? 1 : 0, (void *)s, h->deriv3_blocks);
         } else if (h->deriv4_blocks && !d2.gpark) {
             if (h->deriv_econ && h->d_celldeg) {
                 d2.batch_flag = h->d_batchflag;
-                d2.batch_econ = 1;
+                d2.batch_econ = 1; d2.econ_pairs = h->d_econ_pairs;
             }
             e = (hipError_t)grape_deriv4_launch(h->NP, &d2, sizeof(d2), h->d_H0q3, h->d_Hcq3, h->d_H0p3, h->d_Hcp3, (void *)s, h->deriv4_blocks);
-        } else
-        e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);
+        } else {
+            // (deriv2_kernel: Hermitian operators at 48 and 64 with the verdicts of the four-product kernel; the blocked path's
+            // compiled twin keeps the Taylor sum -- its differential tests compare orders)
+            if (h->deriv_econ && !d2.gpark && !h->large && h->herm) {
+                d2.batch_flag = h->d_batchflag;
+                d2.batch_econ = 1; d2.econ_pairs = h->d_econ_pairs;
+            }
+            e = launch_deriv2(h->NP, d2, h->deriv_blocks, s, h->deriv_stream, h->deriv_stream_never);
+        }
     } else if (h->NP >= 48) {
         DerivMfmaArgs dm{};
         dm.H0p = h->d_H0p; dm.Hcp = h->d_Hcp; dm.eps = h->d_eps; dm.shape = h->d_shape; dm.dts = h->d_dts;

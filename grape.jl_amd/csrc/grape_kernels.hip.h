@@ -3450,7 +3450,10 @@ __global__ void deriv_econ_kernel(DerivEconArgs a) {
         const int cell = kc * a.N_T + n;
         int d;
         if (a.cell_deg) d = a.cell_deg[cell];
-        else d = a.verdict[cell] != 0 ? 0 : a.splan[cell] == 0 ? a.deg0 : a.splan[cell] == 1 ? a.deg1 : 0;
+        else {
+            const int sq = a.splan ? a.splan[cell] : 0;    // (the compiled four-product kernel plans no squarings)
+            d = a.verdict[cell] != 0 ? 0 : sq == 0 ? a.deg0 : sq == 1 ? a.deg1 : 0;
+        }
         ok = d > 0;
         deg = max(deg, d);
     }
@@ -3732,8 +3735,10 @@ struct Deriv2Args {
     // max_order allows more, raises flags[7] instead of the non-convergence error -- deriv_kernel redoes the derivatives
     int deep_redo;
     // round 6: the degrees of the economized series lie behind the batch flags, batch_flag[nbatch_total + batch]
-    // (deriv_econ_kernel; read by the assembly kernels, Hermitian operators only)
+    // (deriv_econ_kernel; Hermitian operators only).  The assembly kernels find the tables behind their 1 / m; the
+    // compiled ones (deriv3_kernel, deriv2_kernel) through econ_pairs: degree M at 64 (M - 16) doubles, (omega_a, sigma_a)
     int batch_econ;
+    const double *econ_pairs;
 #ifdef GRAPE_DIAG
     int ablate;                // diagnostic builds only: bit0 no parking traffic (results wrong)
 #endif
@@ -3873,6 +3878,10 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
             use_g = !__any(valid && (Mc < 2 || Mc > mcap));
         }
         int cur = 0, M = 0, converged = 0;
+        // round 6: degree of the economized polynomial this batch is certified for (asm/gen_d3.py's header), 0: none
+        const int deg = (a.batch_econ && a.batch_flag && a.econ_pairs && !use_g) ? a.batch_flag[a.nbatch_total + batch] : 0;
+        const int capb = (deg && deg - 1 <= mcap) ? deg - 1 : mcap;
+        const double *pairs = nullptr;
         if (use_g) {
             int mm = Mc;
 #pragma unroll
@@ -3895,7 +3904,7 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
                 park[o] = pr_; park[vplane + o] = pi_;
             }
         __syncthreads();
-        for (int m = 1; m <= mcap; ++m) {   // forms u_m
+        for (int m = 1; m <= capb; ++m) {   // forms u_m
             const double *vc = dsm2 + (size_t)cur * 2 * vplane;
             double *vn = dsm2 + (size_t)(ONEBUF ? cur : cur ^ 1) * 2 * vplane;
             const double sfac = dt / (double)m;
@@ -3952,6 +3961,10 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
             // ||u_m|| < tol for every cell of the batch (identical decision in every wave: same LDS values)
             if (m >= 2 && __all(tot < a.tol * a.tol)) { converged = 1; break; }
         }
+        if (!converged && capb != mcap) {   // certified: the deg - 1 orders formed are all the polynomial needs
+            M = deg; converged = 1;
+            pairs = a.econ_pairs + (size_t)(deg - 16) * 64;
+        }
         }   // !use_g
         // orders a = 0..M-1 enter the sum; u_M is below the tolerance (or the cap was hit: flagged below)
 
@@ -3978,7 +3991,7 @@ __global__ void __launch_bounds__((NP / 16 <= 8 ? NP / 16 : 8) * 64) deriv2_kern
         for (int aa = M - 1; aa >= 0; --aa) {
             const double *vc = dsm2 + (size_t)cur * 2 * vplane;
             double *vn = dsm2 + (size_t)(ONEBUF ? cur : cur ^ 1) * 2 * vplane;
-            const double inv = 1.0 / (double)(aa + 1), sfac = dt * inv;
+            const double inv = pairs ? pairs[2 * aa] : 1.0 / (double)(aa + 1), sfac = dt * (pairs ? pairs[2 * aa + 1] : inv);
             double keep_r[ONEBUF ? TPW : 1][4], keep_i[ONEBUF ? TPW : 1][4];
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt) {

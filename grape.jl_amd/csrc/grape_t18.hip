@@ -375,6 +375,18 @@ hipError_t launch_d3_asm(const Deriv3Args &g, hipStream_t s, int blocks, bool ge
 }
 }  // namespace
 
+// the tables of the economized derivative series on the current device, for the compiled kernels: degree M at
+// 64 (M - 16) doubles from the pointer, (omega_a, sigma_a); nullptr when the module cannot be loaded
+extern "C" const double *grape_econ_pairs(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipFunction_t fn;
+    const double *inv = nullptr;
+    if (asm_function(dev, nullptr, &fn, &inv) != hipSuccess || !inv) return nullptr;
+    static_assert(D3_ECON_TAB_B == 64 * 8, "64 doubles per degree");
+    return inv + (D3_PAIRS_OFF + D3_ECON_OFF) / 8;
+}
+
 // derivative overlaps of the blocked path (asm/gen_d4.py): one workgroup per batch, operator fragments with three planes
 namespace {
 struct D4AsmArgs {            // kernel argument block of deriv4_asm_{128,256} (gen_d4.py: KERNARG = 176 bytes)

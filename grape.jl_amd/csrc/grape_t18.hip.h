@@ -932,7 +932,9 @@ __global__ void __launch_bounds__(NT * 64, (T16 && NT == 3) ? 2 : 1) expm_t18_ke
             auto fetch_next = [&](int sk, int r) { if (sk == 1 && r == 0) fa.issue(); };   // (fenced by scheduling barriers on both sides)
             if constexpr (T16) {
                 s = 0; bad = false;
-                if (expm_t16_cell<NT, true>(smem, wave, lane, U, store_prev, fetch_next)) st_t16 += 1;
+                const bool ok16 = expm_t16_cell<NT, true>(smem, wave, lane, U, store_prev, fetch_next);
+                if (tid == 0 && a.cellflag) a.cellflag[cell] = ok16 ? 0 : 1;   // the verdict (round 6: deriv_econ_kernel reads it)
+                if (ok16) st_t16 += 1;
                 else if (tid == 0) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;   // to be redone by the five-product launch
             } else {
                 expm_t18_cell<NT, true, true>(smem, wave, lane, U, s, bad, store_prev, fetch_next);

@@ -282,6 +282,9 @@ def test_series_that_does_not_converge_within_the_parked_terms_is_flagged(progra
     # a batch the sub-step kernel redoes anyway: neither flagged nor booked
     _, flags, stats, _ = run_kernel(prog, d, 1, 1, mcap=6, batch_flag=[1])
     assert flags[0] == 0 and flags[7] == 0 and int(stats[:, 8].sum()) == 0
+    # the degrees of the economized series present (bit 1 of `deep`), this batch not certified: still the error, not the redo counter
+    _, flags, _, _ = run_kernel(prog, d, 1, 1, mcap=6, econ=[[0]])
+    assert flags[0] == 4 and flags[7] == 0
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang"), reason="no assembler")
@@ -348,6 +351,8 @@ def test_streamed_kernel_flags_a_series_that_does_not_converge(program_s):
     _, flags, stats, _ = run_kernel(prog, d, 1, 1, mcap=6, lds_bytes=gen_d3s.LDS_BYTES)
     assert flags[0] == 4 and flags[7] == 0
     assert int(stats[:, 8].sum()) == 6 * 5
+    _, flags, _, _ = run_kernel(prog, d, 1, 1, mcap=6, lds_bytes=gen_d3s.LDS_BYTES, econ=[[0]])
+    assert flags[0] == 4 and flags[7] == 0
 
 
 # ---- general (non-Hermitian) operators: all tiles in a ring of two slots, pass 2 applies the adjoint (GenD3G) ----

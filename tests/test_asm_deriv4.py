@@ -158,3 +158,5 @@ def test_series_that_does_not_converge_is_flagged(program128):
     d = make_inputs(128, 128, 1, 1, 5, seed=3, dt_scale=6.0)
     _, flags, stats = run_kernel(gen, prog, d, 1, mcap=5)
     assert flags[0] == 4 and int(stats[:, 8].sum()) == 5 * 5
+    _, flags, _ = run_kernel(gen, prog, d, 1, mcap=5, econ=[[0]])       # (bit 1 of `deep` is not the redo request)
+    assert flags[0] == 4 and flags[7] == 0

@@ -129,8 +129,12 @@ def run_d3(g, pr, asm, econ=False, **kw):
     (64, 2, 37, 3, {}), (57, 2, 100, 5, {}), (64, 1, 40, 16, {}), (64, 2, 33, 2, {"shape": True}), (60, 2, 18, 3, {"per_traj": True}),
     (64, 6, 70, 3, {}), (64, 3, 40, 2, {"per_traj": True}), (64, 2, 40, 3, {"dt": 0.6}), (64, 2, 40, 3, {"dt": 1.4}),
     (64, 4, 40, 2, {"dt": 1.5}), (64, 2, 40, 2, {"dt": 4.0}),
-    (128, 2, 40, 2, {}), (100, 3, 33, 2, {"shape": True}), (256, 4, 20, 1, {}), (200, 2, 20, 1, {"dt": 1.5}), (128, 2, 20, 2, {"dt": 3.0})])
-def test_economized_derivative_series_against_the_taylor_sum(g, ref, N, L, N_T, K, kw):
+    (128, 2, 40, 2, {}), (100, 3, 33, 2, {"shape": True}), (256, 4, 20, 1, {}), (200, 2, 20, 1, {"dt": 1.5}), (128, 2, 20, 2, {"dt": 3.0}),
+    # the compiled kernels: three tiles per side (deriv3_kernel<3, L> behind the compiled four-product kernel), the shared-batch
+    # kernel (GRAPE_DERIV3=0: deriv2_kernel, what grape_create selects for few batches), the compiled twin at four tiles
+    (48, 2, 70, 3, {}), (40, 4, 33, 2, {"shape": True}), (48, 2, 40, 2, {"env": {"GRAPE_DERIV3": "0"}}),
+    (64, 2, 40, 3, {"env": {"GRAPE_DERIV3": "0"}}), (64, 2, 40, 3, {"asm": False}), (64, 2, 40, 3, {"env": {"GRAPE_EXPM_ASM": "0"}})])
+def test_economized_derivative_series_against_the_taylor_sum(g, ref, N, L, N_T, K, kw, monkeypatch):
     """round 6: batches the exponential kernels certify for a segment of the imaginary axis take the polynomial of that
     segment (tools/econ_coeffs.py) in the derivative kernels (gen_d3.py, gen_d3s.py, gen_d4.py): the four-product kernel's
     verdict (spectral radius <= 1.36: degree 16; a cell exponentiated as A / 2: 2.72, degree 21), the blocked path's bounds
@@ -147,8 +151,10 @@ def test_economized_derivative_series_against_the_taylor_sum(g, ref, N, L, N_T, 
         pr["Hc"] = np.stack([pr["Hc"] * (1.0 + 0.1 * rng.random()) for _ in range(K)])
     if kw.get("dt"):
         pr["tlist"] = pr["tlist"] * kw["dt"]
-    a = run_d3(g, pr, True, econ=True, **args)
-    b = run_d3(g, pr, True, econ=False, **args)
+    for name, val in kw.get("env", {}).items():
+        monkeypatch.setenv(name, val)
+    a = run_d3(g, pr, kw.get("asm", True), econ=True, **args)
+    b = run_d3(g, pr, kw.get("asm", True), econ=False, **args)
     assert a[0] == b[0] and np.array_equal(a[2], b[2])
     gs = max(np.abs(b[1]).max(), 1e-3)
     assert np.abs(a[1] - b[1]).max() <= 1e-13 * gs, np.abs(a[1] - b[1]).max() / gs
