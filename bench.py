@@ -442,7 +442,8 @@ def main():
                                    + (" (general control operators too)" if args.nonhermitian_controls else "")
                                    + (", CONTROL OPERATORS PER TRAJECTORY" if args.per_trajectory_controls else ""),
                        "gradient_method": "gradgen (exact derivative via the series of the gradient-generator "
-                                          "propagator on the extended state)",
+                                          "propagator on the extended state; for Hermitian cells whose spectrum the exponential "
+                                          "kernel has certified, the economized polynomial of that segment: DESIGN.md 4.3)",
                        "one_eval": f"one shard evaluation = functional + full gradient of {K_local} trajectories; "
                                    "value counts shard evaluations completed by all ranks per second",
                        "global_problem_evals_per_s": args.steps / elapsed},
@@ -488,6 +489,7 @@ def main():
             "deriv_kernel": {"flop_per_launch": work["flop_deriv"], "avg_launch_ms": tm["deriv"],
                              "tflops": work["flop_deriv"] / (tm["deriv"] * 1e-3) * 1e-12 if tm["deriv"] > 0 else None,
                              "series_orders_per_cell": work["deriv_orders"] / work["cells"],
+                             "economized_series": os.environ.get("GRAPE_DERIV_ECON", "1") != "0",
                              "kernel": {0: "compiled (deriv3_kernel / deriv2_kernel / deriv_kernel)", 1: "deriv3_asm (csrc/asm/gen_d3.py)",
                                         2: "deriv3s_asm (streamed controls, csrc/asm/gen_d3s.py)",
                                         3: "deriv3g_asm (general operators, csrc/asm/gen_d3s.py)",
