@@ -2148,7 +2148,7 @@ int grape_create(grape_handle **out, const grape_problem *p) try {
         const char *enve = getenv("GRAPE_DERIV_ECON");
         const bool lg_ok = h->large && h->t18 && h->herm && h->lg_spec && !h->series;
         // (the compiled four-product kernel of three and four tiles per side writes the same verdicts: expm_t18_kernel<.., T16>)
-        const bool t16c_ok = h->t16 && h->t18 && h->herm && !h->large && !h->series && h->NT >= 3;
+        const bool t16c_ok = h->t16 && h->t18 && h->herm && !h->large && !h->series && (h->NT >= 3 || (h->NT == 2 && h->t18_small));
         h->deriv_econ = (h->asm16 || lg_ok || t16c_ok) && p->gradient_method == GRAPE_GRAD_GRADGEN && h->taylor_tol >= 1e-16 && h->d_batchflag &&
                         !(enve && atoi(enve) == 0);
         if (h->deriv_econ) h->d_econ_pairs = grape_econ_pairs();   // (the compiled derivative kernels read the tables through a pointer)
@@ -2750,6 +2750,10 @@ int backward_device_impl(grape_handle *h, const double *d_f, double *d_G, hipStr
             d2.nbatch_total = h->K * d2.batches_per_k;
             const bool sub = h->sub_theta > 0.0;
             d2.deep_redo = (!sub && h->taylor_max_order > h->deriv2_maxm) ? 1 : 0;
+            if (h->deriv_econ && h->herm && h->NT == 2) {   // two tiles per side behind the compiled four-product kernel (round 6, 4.3)
+                d2.batch_flag = h->d_batchflag;              // (a flagged batch ends this kernel at once: deriv_kernel does every cell)
+                d2.batch_econ = 1; d2.econ_pairs = h->d_econ_pairs;
+            }
             if (sub) {
                 HIPCHK(h, hipMemsetAsync(h->d_flags + 3, 0, sizeof(int), s));
                 DerivFlagArgs fa{};

@@ -948,7 +948,9 @@ __global__ void __launch_bounds__(NT * 64, (T16 && NT == 3) ? 2 : 1) expm_t18_ke
             // registers there, and this variant runs at the register limit: 84 bytes of scratch per lane with it)
             if constexpr (T16) {
                 s = 0; bad = false;
-                if (expm_t16_cell<NT, false>(smem, wave, lane, U, T18NoHook(), T18NoHook())) st_t16 += 1;
+                const bool ok16 = expm_t16_cell<NT, false>(smem, wave, lane, U, T18NoHook(), T18NoHook());
+                if (tid == 0 && a.cellflag) a.cellflag[cell] = ok16 ? 0 : 1;   // the verdict (deriv_econ_kernel)
+                if (ok16) st_t16 += 1;
                 else if (tid == 0) a.cell_list[atomicAdd(&a.flags[4], 1)] = cell;
             } else {
                 expm_t18_cell<NT, false, CHEB>(smem, wave, lane, U, s, bad, T18NoHook(), T18NoHook());

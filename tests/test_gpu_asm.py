@@ -132,7 +132,7 @@ def run_d3(g, pr, asm, econ=False, **kw):
     (128, 2, 40, 2, {}), (100, 3, 33, 2, {"shape": True}), (256, 4, 20, 1, {}), (200, 2, 20, 1, {"dt": 1.5}), (128, 2, 20, 2, {"dt": 3.0}),
     # the compiled kernels: three tiles per side (deriv3_kernel<3, L> behind the compiled four-product kernel), the shared-batch
     # kernel (GRAPE_DERIV3=0: deriv2_kernel, what grape_create selects for few batches), the compiled twin at four tiles
-    (48, 2, 70, 3, {}), (40, 4, 33, 2, {"shape": True}), (48, 2, 40, 2, {"env": {"GRAPE_DERIV3": "0"}}),
+    (48, 2, 70, 3, {}), (40, 4, 33, 2, {"shape": True}), (48, 2, 40, 2, {"env": {"GRAPE_DERIV3": "0"}}), (32, 2, 70, 3, {}), (20, 5, 33, 2, {}),
     (64, 2, 40, 3, {"env": {"GRAPE_DERIV3": "0"}}), (64, 2, 40, 3, {"asm": False}), (64, 2, 40, 3, {"env": {"GRAPE_EXPM_ASM": "0"}})])
 def test_economized_derivative_series_against_the_taylor_sum(g, ref, N, L, N_T, K, kw, monkeypatch):
     """round 6: batches the exponential kernels certify for a segment of the imaginary axis take the polynomial of that
